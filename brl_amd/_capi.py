@@ -1,0 +1,96 @@
+"""ctypes binding of include/brl_hip.h.  No torch types cross this boundary: raw device
+pointers (tensor.data_ptr()) and the current HIP stream handle only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libbrl_hip.so")
+
+STATE_WORDS = 16
+OBS_SIZE = 480
+NUM_ACTIONS = 38
+
+_vp = C.c_void_p
+
+
+class Fields(C.Structure):
+    _names = ["current_player", "terminated", "rewards", "step_count", "turn", "dealer", "vul_ns", "vul_ew",
+              "shuffled_players", "last_bid", "last_bidder", "call_x", "call_xx", "pass_num",
+              "first_denomination_ns", "first_denomination_ew", "hand", "tricks", "lut_idx", "board_ctr", "illegal"]
+    _fields_ = [(n, _vp) for n in _names]
+
+
+class TransitionPtrs(C.Structure):
+    _names = ["done", "action", "value", "reward", "log_prob", "obs", "legal_action_mask"]
+    _fields_ = [(n, _vp) for n in _names]
+
+
+class TableInfoPtrs(C.Structure):
+    _names = ["terminated", "rewards", "last_bid", "last_bidder", "call_x", "call_xx"]
+    _fields_ = [(n, _vp) for n in _names]
+
+
+class BrlError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads libbrl_hip.so.  Fails loudly — there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BrlError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            "Run `python -m brl_amd.build` (needs hipcc, gfx950). brl_amd has no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    i64, i32, u32, u64, f32 = C.c_int64, C.c_int, C.c_uint32, C.c_uint64, C.c_float
+    L.brl_last_error.restype = C.c_char_p
+    L.brl_version.restype = i32
+    sigs = {
+        "brl_create": [i32, _vp, _vp, i64, C.POINTER(_vp)],
+        "brl_set_lut": [_vp, _vp, _vp, i64],
+        "brl_destroy": [_vp],
+        "brl_set_rng": [_vp, u64, u64],
+        "brl_init_random": [_vp, _vp, i64, u32, _vp],
+        "brl_init_from_deals": [_vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+        "brl_step": [_vp, _vp, _vp, i64, _vp, i32, _vp, _vp, _vp, _vp, _vp, _vp],
+        "brl_observe": [_vp, _vp, i64, _vp, _vp, _vp, _vp],
+        "brl_get_fields": [_vp, _vp, i64, C.POINTER(Fields), _vp],
+        "brl_rollout_random": [_vp, _vp, i64, i32, i32, u32, f32, C.POINTER(TransitionPtrs), _vp, _vp],
+        "brl_policy_step": [_vp, _vp, _vp, i64, _vp, i32, u32, i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+        "brl_gae": [_vp, _vp, _vp, _vp, _vp, f32, f32, i32, i64, _vp, _vp, _vp],
+        "brl_imp_reward": [_vp, _vp, _vp, _vp, i64, _vp],
+        "brl_duplicate_step": [_vp, _vp, _vp, i64, _vp, C.POINTER(TableInfoPtrs), C.POINTER(TableInfoPtrs),
+                               _vp, _vp, _vp, _vp, _vp, _vp],
+    }
+    for name, args in sigs.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = i32
+    _lib = L
+    return L
+
+
+EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_destroy", "brl_set_rng",
+           "brl_init_random", "brl_init_from_deals", "brl_step", "brl_observe", "brl_get_fields",
+           "brl_rollout_random", "brl_policy_step", "brl_gae", "brl_imp_reward", "brl_duplicate_step"]
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise BrlError(f"libbrl_hip error {rc}: {lib().brl_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "brl_amd passes raw pointers: tensors must be contiguous"
+    return t.data_ptr()

@@ -1,0 +1,822 @@
+// brl_kernels.hip — gfx950 kernels + C-ABI (include/brl_hip.h) of libbrl_hip.so.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see brl_amd/build.py)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/brl_hip.h"
+#include "bridge_device.hpp"
+
+using namespace brl;
+
+// =====================================================================================
+// wave-level helpers (K tables per 64-lane wave, 4 waves per 256-thread workgroup)
+// =====================================================================================
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
+
+// Consecutive table groups go to the same XCD (blocks b and b+8 share one): neighbouring
+// rows of the [n,480] / [n,38] outputs share 128-B lines, keep those in ONE L2.  Speed only.
+__device__ __forceinline__ int64_t xcd_block(int64_t b, int64_t nb) {
+  return (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+}
+
+template <int K>
+struct Wave {
+  LaneConst c;
+  uint8_t *wimg;   // this wave's K x 128 B LDS images
+  int tl;          // local table of this lane's logic (lane % K)
+  int64_t table0;  // first table of the wave
+  int64_t table;   // table of this lane's logic
+  bool valid;      // table < n
+};
+
+template <int K>
+__device__ __forceinline__ Wave<K> wave_begin(uint8_t *lds, const uint64_t *state_in, int64_t n, Tbl &t) {
+  Wave<K> w;
+  w.c = make_lane_const();
+  int wave = (int)(threadIdx.x >> 6);
+  int64_t blk = xcd_block((int64_t)blockIdx.x, (int64_t)gridDim.x);
+  w.table0 = (blk * WAVES_PER_BLOCK + wave) * K;
+  w.wimg = lds + wave * K * TABLE_BYTES;
+  uint64_t *wimg64 = reinterpret_cast<uint64_t *>(w.wimg);
+#pragma unroll
+  for (int i = w.c.lane; i < K * 16; i += 64) {
+    int64_t tb = w.table0 + i / 16;
+    wimg64[i] = (state_in != nullptr && tb < n) ? state_in[w.table0 * 16 + i] : 0ull;
+  }
+  wave_lds_fence();
+  w.tl = w.c.lane % K;
+  w.table = w.table0 + w.tl;
+  w.valid = w.table < n;
+  load_scalars(t, w.wimg + w.tl * TABLE_BYTES);
+  return w;
+}
+
+template <int K>
+__device__ __forceinline__ void wave_end(const Wave<K> &w, const Tbl &t, uint64_t *state_out, int64_t n) {
+  if (w.c.lane < K) store_scalars(t, w.wimg + w.tl * TABLE_BYTES);
+  wave_lds_fence();
+  const uint64_t *wimg64 = reinterpret_cast<const uint64_t *>(w.wimg);
+#pragma unroll
+  for (int i = w.c.lane; i < K * 16; i += 64) {
+    int64_t tb = w.table0 + i / 16;
+    if (tb < n) state_out[w.table0 * 16 + i] = wimg64[i];
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void wave_or_hist(const Wave<K> &w, int hist_bit) {
+  if (w.c.lane < K && hist_bit >= 0) {
+    uint32_t *p = reinterpret_cast<uint32_t *>(w.wimg + w.tl * TABLE_BYTES) + (hist_bit >> 5);
+    atomicOr(p, 1u << (hist_bit & 31));  // ds_or_b32
+  }
+}
+
+struct LutRef {
+  const int4 *keys;
+  const int4 *values;
+  uint32_t len;
+};
+
+// A5 post-step half of auto_reset (src/utils.py:45-55) for every table of the wave that
+// just terminated: deal board bctr+1 of that slot, keep (terminated, rewards).
+template <int K>
+__device__ __forceinline__ void wave_reset(const Wave<K> &w, Tbl &t, bool need, const Rng &g, uint64_t env_offset,
+                                           const LutRef &lut, uint32_t next_ctr) {
+  uint64_t needm = __ballot(need) & ((1ull << K) - 1ull);
+  if (needm == 0ull) return;
+  uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+  if (need) {
+    uint32_t keep = t.sc & ((1u << SC_TERM) | (1u << SC_ILLEGAL));
+    fresh_scalars(t, g, env_offset + (uint64_t)w.table, next_ctr, lut.len, keep);
+    int4 kv = lut.keys[t.lut];
+    int4 vv = lut.values[t.lut];
+    q0 = (uint32_t)kv.x; q1 = (uint32_t)kv.y; q2 = (uint32_t)kv.z; q3 = (uint32_t)kv.w;
+    pack_tricks(t, (uint32_t)vv.x, (uint32_t)vv.y, (uint32_t)vv.z, (uint32_t)vv.w);
+  }
+  while (needm) {
+    int j = __ffsll((unsigned long long)needm) - 1;
+    needm &= needm - 1ull;
+    deal_image(w.wimg + j * TABLE_BYTES, __builtin_amdgcn_readlane(q0, j), __builtin_amdgcn_readlane(q1, j),
+               __builtin_amdgcn_readlane(q2, j), __builtin_amdgcn_readlane(q3, j), w.c);
+  }
+  wave_lds_fence();
+}
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int j) {
+  uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, j);
+  uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), j);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// emit obs/mask rows of the wave's K tables; row of table0 is row0 (rows are consecutive)
+template <int K>
+__device__ __forceinline__ void wave_emit(const Wave<K> &w, int64_t n, int oseat, uint32_t vulnib, uint64_t legal,
+                                          uint8_t *obs, uint8_t *mask, int64_t row0) {
+  uint32_t pack = (uint32_t)oseat | (vulnib << 2);
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    if (w.table0 + j < n) {
+      if (obs) {
+        uint32_t p = __builtin_amdgcn_readlane(pack, j);
+        emit_obs_row(w.wimg + j * TABLE_BYTES, (int)(p & 3u), p >> 2, obs + (row0 + j) * BRL_OBS_SIZE, w.c);
+      }
+      if (mask) emit_mask_row(readlane64(legal, j), mask + (row0 + j) * BRL_NUM_ACTIONS, w.c);
+    }
+  }
+}
+
+__device__ __forceinline__ float4 rewards_f32(const Tbl &t) {
+  return make_float4((float)reward_of(t, 0), (float)reward_of(t, 1), (float)reward_of(t, 2), (float)reward_of(t, 3));
+}
+
+__device__ __forceinline__ int sanitize_action(int a, uint32_t &bad) {
+  bad = ((uint32_t)a >= (uint32_t)BRL_NUM_ACTIONS) ? 1u : 0u;
+  return bad ? 0 : a;
+}
+
+// =====================================================================================
+// kernels
+// =====================================================================================
+struct StepOut {
+  uint8_t *obs;
+  uint8_t *mask;
+  float *rewards;
+  uint8_t *terminated;
+  int32_t *current_player;
+};
+
+template <int K>
+__device__ __forceinline__ void wave_step_outputs(const Wave<K> &w, const Tbl &t, int64_t n, const StepOut &o) {
+  int oseat = cur_seat(t);
+  wave_emit<K>(w, n, oseat, vul_nibble(t, oseat), legal_mask(t), o.obs, o.mask, w.table0);
+  if (w.c.lane < K && w.valid) {
+    if (o.rewards) reinterpret_cast<float4 *>(o.rewards)[w.table] = rewards_f32(t);
+    if (o.terminated) o.terminated[w.table] = (uint8_t)bits(t.sc, SC_TERM, 1);
+    if (o.current_player) o.current_player[w.table] = cur_player(t);
+  }
+}
+
+// ---- A1 init(random) ----------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_init_random(uint64_t *state, int64_t n, Rng g, uint64_t env_offset,
+                                                               LutRef lut, uint32_t board_ctr0) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES_PER_BLOCK * K * TABLE_BYTES];
+  Tbl t;
+  Wave<K> w = wave_begin<K>(lds, nullptr, n, t);
+  t.sc = 0;
+  wave_reset<K>(w, t, w.valid, g, env_offset, lut, board_ctr0);
+  wave_end<K>(w, t, state, n);
+}
+
+// ---- A1 init(explicit deals) — one thread per table (not a hot path) ------------------
+__global__ void k_init_explicit(uint64_t *state, int64_t n, const int32_t *hand, const int32_t *dealer,
+                                const uint8_t *vul_ns, const uint8_t *vul_ew, const int32_t *shuffled,
+                                const uint8_t *tricks) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  uint64_t *s = state + e * BRL_STATE_WORDS;
+  for (int i = 0; i < 7; i++) s[i] = 0;
+  for (int seat = 0; seat < 4; seat++) {
+    uint64_t m = 0;
+    for (int i = 0; i < 13; i++) {
+      int card = hand[e * 52 + seat * 13 + i];
+      int suit = card / 13, rank = card % 13;
+      int idx = ((rank + 12) % 13) * 4 + (3 - suit);  // wb5/utils.py:18-19 via pgx card order
+      m |= 1ull << idx;
+    }
+    s[W_HAND + seat] = m << 4;
+  }
+  uint32_t shuf = 0;
+  for (int seat = 0; seat < 4; seat++) shuf |= ((uint32_t)shuffled[e * 4 + seat] & 3u) << (2 * seat);
+  uint32_t sc = ((uint32_t)dealer[e] & 3u) | ((uint32_t)(vul_ns[e] != 0) << SC_VULNS) |
+                ((uint32_t)(vul_ew[e] != 0) << SC_VULEW) | (shuf << SC_SHUF);
+  uint32_t v[4];
+  for (int seat = 0; seat < 4; seat++) {
+    uint32_t x = 0;
+    for (int d = 0; d < 5; d++) x = x * 16u + (tricks[e * 20 + seat * 5 + d] & 15u);
+    v[seat] = x;
+  }
+  Tbl t;
+  pack_tricks(t, v[0], v[1], v[2], v[3]);
+  s[W_SC] = (uint64_t)sc;
+  s[W_FD] = (uint64_t)t.t2 << 32;
+  s[W_TR] = (uint64_t)t.t0 | ((uint64_t)t.t1 << 32);
+  s[W_CTR] = 0xFFFFFFFFull;
+  s[W_REW] = 0;
+}
+
+// ---- A2/A5 step ------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_step(const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                                                        const int32_t *action, int autoreset, Rng g,
+                                                        uint64_t env_offset, LutRef lut, StepOut o) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES_PER_BLOCK * K * TABLE_BYTES];
+  Tbl t;
+  Wave<K> w = wave_begin<K>(lds, state_in, n, t);
+  uint32_t bad;
+  int a = sanitize_action(w.valid ? action[w.table] : 0, bad);
+  if (autoreset) auto_reset_clear(t);
+  bool live = !bits(t.sc, SC_TERM, 1);
+  int hb = table_step(t, a);
+  if (bad && live) t.sc |= (1u << SC_TERM) | (1u << SC_ILLEGAL) | (1u << SC_MASKALL);
+  wave_or_hist<K>(w, hb);
+  wave_lds_fence();
+  if (autoreset) wave_reset<K>(w, t, w.valid && bits(t.sc, SC_TERM, 1), g, env_offset, lut, t.bctr + 1u);
+  wave_step_outputs<K>(w, t, n, o);
+  wave_end<K>(w, t, state_out, n);
+}
+
+// ---- A3 observe --------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_observe(const uint64_t *state, int64_t n, const int32_t *player_id,
+                                                           uint8_t *obs, uint8_t *mask) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES_PER_BLOCK * K * TABLE_BYTES];
+  Tbl t;
+  Wave<K> w = wave_begin<K>(lds, state, n, t);
+  int oseat = cur_seat(t);
+  if (player_id != nullptr && w.valid) oseat = seat_of_player(t, player_id[w.table] & 3);
+  wave_emit<K>(w, n, oseat, vul_nibble(t, oseat), legal_mask(t), obs, mask, w.table0);
+}
+
+// ---- A7 fused random-policy rollout ------------------------------------------------------
+struct RolloutArgs {
+  uint64_t *state;
+  int64_t n;
+  int T;
+  int substeps;
+  uint32_t draw_base;
+  float reward_scale;
+  Rng g;
+  uint64_t env_offset;
+  LutRef lut;
+  const float *neg_log_n;  // [39] -log(n) as float, host-computed
+  brl_transition out;
+  unsigned long long *terminated_count;
+};
+
+template <int K>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_rollout_random(RolloutArgs A) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES_PER_BLOCK * K * TABLE_BYTES];
+  Tbl t;
+  Wave<K> w = wave_begin<K>(lds, A.state, A.n, t);
+  const uint64_t env_id = A.env_offset + (uint64_t)w.table;
+  uint32_t rb[4] = {0, 0, 0, 0};
+  uint32_t rb_idx = 0xFFFFFFFFu;
+  uint32_t tcount = 0;
+  for (int step = 0; step < A.T; step++) {
+    const int64_t row0 = (int64_t)step * A.n + w.table0;
+    // G4: the stored obs / mask are the PRE-step view of the acting player
+    uint64_t legal = legal_mask(t);
+    int oseat = cur_seat(t);
+    wave_emit<K>(w, A.n, oseat, vul_nibble(t, oseat), legal, A.out.obs, A.out.legal_action_mask, row0);
+    const int actor = player_at(t, oseat);  // src/roll_out.py:72
+    int racc0 = 0, racc1 = 0, racc2 = 0, racc3 = 0;
+    uint32_t term_any = 0;
+    int first_action = 0, first_n = 1;
+    for (int k = 0; k < A.substeps; k++) {
+      uint32_t draw = A.draw_base + (uint32_t)(step * A.substeps + k);
+      if ((draw >> 2) != rb_idx) {
+        rb_idx = draw >> 2;
+        philox4x32_10((uint32_t)env_id, rb_idx, STREAM_ACTION, (uint32_t)(env_id >> 32), A.g.k0, A.g.k1, rb);
+      }
+      uint32_t sel = draw & 3u;
+      uint32_t u = (sel == 0) ? rb[0] : ((sel == 1) ? rb[1] : ((sel == 2) ? rb[2] : rb[3]));
+      if (k > 0) legal = legal_mask(t);
+      int nl;
+      int a = random_legal_action(t, legal, u, nl);
+      if (k == 0) {
+        first_action = a;
+        first_n = nl;
+      }
+      auto_reset_clear(t);
+      int hb = table_step(t, a);
+      wave_or_hist<K>(w, hb);
+      wave_lds_fence();
+      uint32_t term = bits(t.sc, SC_TERM, 1);
+      racc0 += reward_of(t, 0); racc1 += reward_of(t, 1); racc2 += reward_of(t, 2); racc3 += reward_of(t, 3);
+      term_any |= term;
+      wave_reset<K>(w, t, w.valid && term, A.g, A.env_offset, A.lut, t.bctr + 1u);
+    }
+    if (A.substeps > 1) {  // src/utils.py:126-128
+      set_rewards(t, racc0, racc1, racc2, racc3);
+      t.sc = (t.sc & ~(1u << SC_TERM)) | (term_any << SC_TERM);
+    }
+    if (w.c.lane < K && w.valid) {
+      const int64_t row = row0 + w.tl;
+      int ra = (actor == 0) ? racc0 : ((actor == 1) ? racc1 : ((actor == 2) ? racc2 : racc3));
+      if (A.out.done) A.out.done[row] = (uint8_t)term_any;
+      if (A.out.action) A.out.action[row] = first_action;
+      if (A.out.value) A.out.value[row] = 0.0f;
+      if (A.out.reward) A.out.reward[row] = (float)ra / A.reward_scale;  // G1, src/roll_out.py:90
+      if (A.out.log_prob) A.out.log_prob[row] = A.neg_log_n[first_n];
+      tcount += term_any;
+    }
+  }
+  if (A.terminated_count != nullptr) {  // G2, src/roll_out.py:85
+    uint32_t v = (w.c.lane < K && w.valid) ? tcount : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (w.c.lane == 0 && v) atomicAdd(A.terminated_count, (unsigned long long)v);
+  }
+  wave_end<K>(w, t, A.state, A.n);
+}
+
+// ---- policy sub-step: masked categorical over logits + auto_reset(step) -------------------
+struct PolicyArgs {
+  const uint64_t *state_in;
+  uint64_t *state_out;
+  int64_t n;
+  const float *logits;
+  int mode;
+  uint32_t draw;
+  int autoreset;
+  Rng g;
+  uint64_t env_offset;
+  LutRef lut;
+  int32_t *action;
+  float *log_prob;
+  StepOut o;  // o.rewards / o.terminated are ACCUMULATED
+};
+
+template <int K>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES_PER_BLOCK * K * TABLE_BYTES];
+  __shared__ float llds[WAVES_PER_BLOCK * K * BRL_NUM_ACTIONS];
+  Tbl t;
+  Wave<K> w = wave_begin<K>(lds, A.state_in, A.n, t);
+  // stage the wave's K x 38 logits (contiguous in [n,38]) through LDS, coalesced
+  float *wl = llds + (threadIdx.x >> 6) * K * BRL_NUM_ACTIONS;
+  for (int i = w.c.lane; i < K * BRL_NUM_ACTIONS; i += 64) {
+    int64_t tb = w.table0 + i / BRL_NUM_ACTIONS;
+    wl[i] = (tb < A.n) ? A.logits[w.table0 * BRL_NUM_ACTIONS + i] : 0.0f;
+  }
+  wave_lds_fence();
+  const float *lg = wl + w.tl * BRL_NUM_ACTIONS;
+  uint64_t legal = legal_mask(t);
+  // masked categorical: illegal actions get probability 0, legal logits unchanged
+  // (src/roll_out.py:27-29).  log-softmax over the legal set, sequential fp32.
+  float mx = -INFINITY;
+  int amax = 0;
+  for (int a = 0; a < BRL_NUM_ACTIONS; a++) {
+    bool ok = (legal >> a) & 1ull;
+    float v = lg[a];
+    if (ok && v > mx) {  // first maximum wins, like argmax
+      mx = v;
+      amax = a;
+    }
+  }
+  float sum = 0.0f;
+  for (int a = 0; a < BRL_NUM_ACTIONS; a++)
+    if ((legal >> a) & 1ull) sum += expf(lg[a] - mx);
+  int act = amax;
+  if (A.mode == 0) {
+    uint32_t r[4];
+    uint64_t env_id = A.env_offset + (uint64_t)w.table;
+    philox4x32_10((uint32_t)env_id, A.draw >> 2, STREAM_ACTION, (uint32_t)(env_id >> 32), A.g.k0, A.g.k1, r);
+    uint32_t sel = A.draw & 3u;
+    uint32_t u32 = (sel == 0) ? r[0] : ((sel == 1) ? r[1] : ((sel == 2) ? r[2] : r[3]));
+    float target = (float)(u32 >> 8) * (1.0f / 16777216.0f) * sum;  // inverse CDF, u in [0,1)
+    float cum = 0.0f;
+    int last = 0;
+    bool found = false;
+    for (int a = 0; a < BRL_NUM_ACTIONS; a++) {
+      if ((legal >> a) & 1ull) {
+        cum += expf(lg[a] - mx);
+        last = a;
+        if (!found && cum > target) {
+          act = a;
+          found = true;
+        }
+      }
+    }
+    if (!found) act = last;
+  }
+  float lp = (lg[act] - mx) - logf(sum);
+  if (A.autoreset) auto_reset_clear(t);
+  int hb = table_step(t, act);
+  wave_or_hist<K>(w, hb);
+  wave_lds_fence();
+  uint32_t term = bits(t.sc, SC_TERM, 1);
+  float4 rw = rewards_f32(t);
+  if (A.autoreset) wave_reset<K>(w, t, w.valid && term, A.g, A.env_offset, A.lut, t.bctr + 1u);
+  int oseat = cur_seat(t);
+  wave_emit<K>(w, A.n, oseat, vul_nibble(t, oseat), legal_mask(t), A.o.obs, A.o.mask, w.table0);
+  if (w.c.lane < K && w.valid) {
+    if (A.action) A.action[w.table] = act;
+    if (A.log_prob) A.log_prob[w.table] = lp;
+    if (A.o.rewards) {
+      float4 *p = reinterpret_cast<float4 *>(A.o.rewards) + w.table;
+      float4 old = *p;
+      *p = make_float4(old.x + rw.x, old.y + rw.y, old.z + rw.z, old.w + rw.w);
+    }
+    if (A.o.terminated) A.o.terminated[w.table] |= (uint8_t)term;
+    if (A.o.current_player) A.o.current_player[w.table] = cur_player(t);
+  }
+  wave_end<K>(w, t, A.state_out, A.n);
+}
+
+// ---- A12 duplicate_step ---------------------------------------------------------------------
+__device__ __forceinline__ float4 imp_vector(float a0, float b0) {
+  const float th[24] = {20, 50, 90, 130, 170, 220, 270, 320, 370, 430, 500, 600,
+                        750, 900, 1100, 1300, 1500, 1750, 2000, 2250, 2500, 3000, 3500, 4000};
+  float d = a0 + b0;
+  float win = (d >= 0.0f) ? 1.0f : -1.0f;  // src/duplicate.py:52-54
+  float ad = fabsf(d);
+  int imp = 0;
+#pragma unroll
+  for (int i = 0; i < 24; i++) imp += (ad >= th[i]) ? 1 : 0;  // src/duplicate.py:46-69
+  float v = (float)imp * win;
+  return make_float4(v, v, -v, -v);
+}
+
+template <int K>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_duplicate_step(const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                                                                  const int32_t *action, brl_table_info TA,
+                                                                  brl_table_info TB, StepOut o) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES_PER_BLOCK * K * TABLE_BYTES];
+  Tbl t;
+  Wave<K> w = wave_begin<K>(lds, state_in, n, t);
+  uint32_t bad;
+  int a = sanitize_action(w.valid ? action[w.table] : 0, bad);
+  bool live = !bits(t.sc, SC_TERM, 1);
+  int hb = table_step(t, a);  // src/duplicate.py:149
+  if (bad && live) t.sc |= (1u << SC_TERM) | (1u << SC_ILLEGAL) | (1u << SC_MASKALL);
+  wave_or_hist<K>(w, hb);
+  wave_lds_fence();
+  bool term = bits(t.sc, SC_TERM, 1);
+  bool a_done = w.valid ? (TA.terminated[w.table] != 0) : true;
+  bool b_done = w.valid ? (TB.terminated[w.table] != 0) : true;
+  bool to_b = w.valid && !a_done && term;          // table A just ended -> replay the board seat-swapped
+  bool emit_imp = w.valid && a_done && term && !b_done;  // table B just ended -> IMP once (G8)
+  float4 rw = rewards_f32(t);
+  // snapshots (src/duplicate.py:165-188) of the state as stepped
+  if (w.c.lane < K && (to_b || emit_imp)) {
+    const brl_table_info &T = to_b ? TA : TB;
+    T.terminated[w.table] = 1;
+    reinterpret_cast<float4 *>(T.rewards)[w.table] = rw;
+    T.last_bid[w.table] = (int)bits(t.sc, SC_LB1, 6) - 1;
+    T.last_bidder[w.table] = bits(t.sc, SC_LB1, 6) ? player_at(t, (int)bits(t.sc, SC_LBSEAT, 2)) : -1;
+    T.call_x[w.table] = (uint8_t)bits(t.sc, SC_X, 1);
+    T.call_xx[w.table] = (uint8_t)bits(t.sc, SC_XX, 1);
+  }
+  if (emit_imp) {
+    float4 ar = reinterpret_cast<const float4 *>(TA.rewards)[w.table];
+    float4 v = imp_vector(ar.x, rw.x);  // src/duplicate.py:157-160
+    set_rewards(t, (int)v.x, (int)v.y, (int)v.z, (int)v.w);
+  } else {
+    t.r01 = 0;  // src/duplicate.py:162
+    t.r23 = 0;
+  }
+  // _duplicate_init (src/duplicate.py:113-128): same hands / dealer / vulnerabilities,
+  // seats [1,0,3,2], everything else back to defaults
+  uint64_t tobm = __ballot(to_b) & ((1ull << K) - 1ull);
+  if (to_b) {
+    uint32_t sh = bits(t.sc, SC_SHUF, 8);
+    uint32_t sw = ((sh >> 2) & 0x03u) | ((sh & 0x03u) << 2) | ((sh >> 2) & 0x30u) | ((sh & 0x30u) << 2);
+    t.sc = (t.sc & 0xFu) | (sw << SC_SHUF);
+    t.sch = 0;
+    t.fd = 0;
+  }
+  if (tobm) {
+    uint64_t *wimg64 = reinterpret_cast<uint64_t *>(w.wimg);
+    for (int j = 0; j < K; j++)
+      if (((tobm >> j) & 1ull) && w.c.lane < 7) wimg64[j * 16 + w.c.lane] = 0ull;
+    wave_lds_fence();
+  }
+  wave_step_outputs<K>(w, t, n, o);
+  wave_end<K>(w, t, state_out, n);
+}
+
+// ---- A9 GAE reverse scan (src/gae.py:20-39): one lane per env, coalesced over envs --------
+__global__ void k_gae(const uint8_t *done, const float *value, const float *reward, const float *last_val, float gamma,
+                      float gamma_lambda, int T, int64_t n, float *adv, float *tgt) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float gae = 0.0f, next_value = last_val[e];
+#pragma unroll 8
+  for (int t = T - 1; t >= 0; t--) {
+    int64_t i = (int64_t)t * n + e;
+    float nd = 1.0f - (float)done[i];
+    float v = value[i];
+    float delta = reward[i] + gamma * next_value * nd - v;  // src/gae.py:28
+    gae = delta + gamma_lambda * nd * gae;                   // src/gae.py:29
+    adv[i] = gae;
+    tgt[i] = gae + v;  // src/gae.py:39
+    next_value = v;
+  }
+}
+
+// ---- A10 _imp_reward -----------------------------------------------------------------------
+__global__ void k_imp_reward(const float *a, const float *b, float *out, int64_t n) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  reinterpret_cast<float4 *>(out)[e] = imp_vector(a[e * 4], b[e * 4]);
+}
+
+// ---- State attribute access (one thread per table; test / host-mirror path) ------------------
+__global__ void k_get_fields(const uint64_t *state, int64_t n, brl_fields F) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const uint64_t *s = state + e * BRL_STATE_WORDS;
+  Tbl t;
+  t.sc = (uint32_t)s[W_SC]; t.sch = (uint32_t)(s[W_SC] >> 32);
+  t.fd = (uint32_t)s[W_FD]; t.t2 = (uint32_t)(s[W_FD] >> 32);
+  t.t0 = (uint32_t)s[W_TR]; t.t1 = (uint32_t)(s[W_TR] >> 32);
+  t.lut = (uint32_t)s[W_CTR]; t.bctr = (uint32_t)(s[W_CTR] >> 32);
+  t.r01 = (uint32_t)s[W_REW]; t.r23 = (uint32_t)(s[W_REW] >> 32);
+  uint32_t lb1 = bits(t.sc, SC_LB1, 6);
+  if (F.current_player) F.current_player[e] = cur_player(t);
+  if (F.terminated) F.terminated[e] = (uint8_t)bits(t.sc, SC_TERM, 1);
+  if (F.rewards) reinterpret_cast<float4 *>(F.rewards)[e] = rewards_f32(t);
+  if (F.step_count) F.step_count[e] = (int)bits(t.sch, SCH_STEP, 10);
+  if (F.turn) F.turn[e] = (int)bits(t.sch, SCH_TURN, 9);
+  if (F.dealer) F.dealer[e] = (int)bits(t.sc, SC_DEALER, 2);
+  if (F.vul_ns) F.vul_ns[e] = (uint8_t)bits(t.sc, SC_VULNS, 1);
+  if (F.vul_ew) F.vul_ew[e] = (uint8_t)bits(t.sc, SC_VULEW, 1);
+  if (F.shuffled_players)
+    for (int k = 0; k < 4; k++) F.shuffled_players[e * 4 + k] = player_at(t, k);
+  if (F.last_bid) F.last_bid[e] = (int)lb1 - 1;
+  if (F.last_bidder) F.last_bidder[e] = lb1 ? player_at(t, (int)bits(t.sc, SC_LBSEAT, 2)) : -1;
+  if (F.call_x) F.call_x[e] = (uint8_t)bits(t.sc, SC_X, 1);
+  if (F.call_xx) F.call_xx[e] = (uint8_t)bits(t.sc, SC_XX, 1);
+  if (F.pass_num) F.pass_num[e] = (int)bits(t.sc, SC_PASS, 3);
+  for (int d = 0; d < 5; d++) {
+    if (F.first_denomination_ns) F.first_denomination_ns[e * 5 + d] = (int)bits(t.fd, 3 * d, 3) - 1;
+    if (F.first_denomination_ew) F.first_denomination_ew[e * 5 + d] = (int)bits(t.fd, 15 + 3 * d, 3) - 1;
+  }
+  if (F.hand) {
+    // invert obs index rank*4+suit back to the pgx card id; ascending ids per seat
+    for (int seat = 0; seat < 4; seat++) {
+      uint64_t m = s[W_HAND + seat] >> 4;
+      int k = 0;
+      for (int card = 0; card < 52; card++) {
+        int suit = card / 13, rank = card % 13;
+        int idx = ((rank + 12) % 13) * 4 + (3 - suit);
+        if ((m >> idx) & 1ull) F.hand[e * 52 + seat * 13 + (k++)] = card;
+      }
+    }
+  }
+  if (F.tricks)
+    for (int seat = 0; seat < 4; seat++)
+      for (int d = 0; d < 5; d++) F.tricks[e * 20 + seat * 5 + d] = (uint8_t)trick_nibble(t, seat, d);
+  if (F.lut_idx) F.lut_idx[e] = (int32_t)t.lut;
+  if (F.board_ctr) F.board_ctr[e] = t.bctr;
+  if (F.illegal) F.illegal[e] = (uint8_t)bits(t.sc, SC_ILLEGAL, 1);
+}
+
+// =====================================================================================
+// C-ABI
+// =====================================================================================
+struct brl_handle {
+  int device;
+  int4 *lut_keys;
+  int4 *lut_values;
+  int64_t lut_len;
+  float *neg_log_n;
+  uint64_t seed;
+  uint64_t env_offset;
+  int tables_per_wave;
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, const char *detail) {
+  snprintf(g_err, sizeof(g_err), fmt, detail ? detail : "");
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) return fail(BRL_E_HIP, #expr ": %s", hipGetErrorString(_e)); \
+  } while (0)
+
+#define NEED(cond, what) \
+  do {                   \
+    if (!(cond)) return fail(BRL_E_ARG, "bad argument: %s", what); \
+  } while (0)
+
+extern "C" const char *brl_last_error(void) { return g_err; }
+extern "C" int brl_version(void) { return 1; }
+
+static int upload_lut(brl_handle *h, const int32_t *keys, const int32_t *values, int64_t len) {
+  if (h->lut_keys) HIP_TRY(hipFree(h->lut_keys));
+  if (h->lut_values) HIP_TRY(hipFree(h->lut_values));
+  h->lut_keys = nullptr;
+  h->lut_values = nullptr;
+  h->lut_len = 0;
+  if (len > 0) {
+    NEED(keys && values, "lut_keys / lut_values are NULL with lut_len > 0");
+    NEED(len < (1ll << 32), "lut_len must be < 2^32");
+    HIP_TRY(hipMalloc(&h->lut_keys, (size_t)len * 16));
+    HIP_TRY(hipMalloc(&h->lut_values, (size_t)len * 16));
+    HIP_TRY(hipMemcpy(h->lut_keys, keys, (size_t)len * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->lut_values, values, (size_t)len * 16, hipMemcpyHostToDevice));
+    h->lut_len = len;
+  }
+  return BRL_OK;
+}
+
+extern "C" int brl_create(int device, const int32_t *lut_keys, const int32_t *lut_values, int64_t lut_len,
+                          brl_handle **out) {
+  NEED(out != nullptr, "out");
+  NEED(lut_len >= 0, "lut_len");
+  HIP_TRY(hipSetDevice(device));
+  brl_handle *h = (brl_handle *)calloc(1, sizeof(brl_handle));
+  NEED(h != nullptr, "out of host memory");
+  h->device = device;
+  h->tables_per_wave = 4;
+  const char *env = getenv("BRL_TABLES_PER_WAVE");
+  if (env) {
+    int k = atoi(env);
+    if (k == 1 || k == 2 || k == 4 || k == 8) h->tables_per_wave = k;
+  }
+  float tab[BRL_NUM_ACTIONS + 1];
+  tab[0] = 0.0f;
+  for (int i = 1; i <= BRL_NUM_ACTIONS; i++) tab[i] = (float)(-log((double)i));
+  hipError_t e = hipMalloc(&h->neg_log_n, sizeof(tab));
+  if (e == hipSuccess) e = hipMemcpy(h->neg_log_n, tab, sizeof(tab), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    free(h);
+    return fail(BRL_E_HIP, "brl_create: %s", hipGetErrorString(e));
+  }
+  int rc = upload_lut(h, lut_keys, lut_values, lut_len);
+  if (rc != BRL_OK) {
+    (void)hipFree(h->neg_log_n);
+    free(h);
+    return rc;
+  }
+  *out = h;
+  return BRL_OK;
+}
+
+extern "C" int brl_set_lut(brl_handle *h, const int32_t *lut_keys, const int32_t *lut_values, int64_t lut_len) {
+  NEED(h != nullptr, "handle");
+  NEED(lut_len >= 0, "lut_len");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());  // in-flight kernels may still read the old table
+  return upload_lut(h, lut_keys, lut_values, lut_len);
+}
+
+extern "C" int brl_destroy(brl_handle *h) {
+  if (!h) return BRL_OK;
+  (void)hipSetDevice(h->device);
+  if (h->lut_keys) (void)hipFree(h->lut_keys);
+  if (h->lut_values) (void)hipFree(h->lut_values);
+  if (h->neg_log_n) (void)hipFree(h->neg_log_n);
+  free(h);
+  return BRL_OK;
+}
+
+extern "C" int brl_set_rng(brl_handle *h, uint64_t seed, uint64_t env_offset) {
+  NEED(h != nullptr, "handle");
+  h->seed = seed;
+  h->env_offset = env_offset;
+  return BRL_OK;
+}
+
+static inline Rng rng_of(const brl_handle *h) { return Rng{(uint32_t)h->seed, (uint32_t)(h->seed >> 32)}; }
+static inline LutRef lut_of(const brl_handle *h) { return LutRef{h->lut_keys, h->lut_values, (uint32_t)h->lut_len}; }
+static inline unsigned wave_grid(int64_t n, int K) {
+  int64_t per_block = (int64_t)WAVES_PER_BLOCK * K;
+  return (unsigned)((n + per_block - 1) / per_block);
+}
+static inline unsigned thread_grid(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+#define LAUNCH_K(h, kernel, n, stream, ...)                                                                  \
+  do {                                                                                                       \
+    hipStream_t _s = (hipStream_t)(stream);                                                                  \
+    switch ((h)->tables_per_wave) {                                                                          \
+      case 1: hipLaunchKernelGGL(kernel<1>, dim3(wave_grid(n, 1)), dim3(BLOCK_THREADS), 0, _s, __VA_ARGS__); break; \
+      case 2: hipLaunchKernelGGL(kernel<2>, dim3(wave_grid(n, 2)), dim3(BLOCK_THREADS), 0, _s, __VA_ARGS__); break; \
+      case 8: hipLaunchKernelGGL(kernel<8>, dim3(wave_grid(n, 8)), dim3(BLOCK_THREADS), 0, _s, __VA_ARGS__); break; \
+      default: hipLaunchKernelGGL(kernel<4>, dim3(wave_grid(n, 4)), dim3(BLOCK_THREADS), 0, _s, __VA_ARGS__); break; \
+    }                                                                                                        \
+    HIP_TRY(hipGetLastError());                                                                              \
+  } while (0)
+
+#define COMMON(h, n)                 \
+  NEED((h) != nullptr, "handle");    \
+  NEED((n) >= 0, "n");               \
+  if ((n) == 0) return BRL_OK;       \
+  HIP_TRY(hipSetDevice((h)->device))
+
+extern "C" int brl_init_random(brl_handle *h, uint64_t *state, int64_t n, uint32_t board_ctr0, void *stream) {
+  COMMON(h, n);
+  NEED(state != nullptr, "state");
+  if (h->lut_len == 0) return fail(BRL_E_NOLUT, "brl_init_random needs a LUT%s", "");
+  LAUNCH_K(h, k_init_random, n, stream, state, n, rng_of(h), h->env_offset, lut_of(h), board_ctr0);
+  return BRL_OK;
+}
+
+extern "C" int brl_init_from_deals(brl_handle *h, uint64_t *state, int64_t n, const int32_t *hand,
+                                   const int32_t *dealer, const uint8_t *vul_ns, const uint8_t *vul_ew,
+                                   const int32_t *shuffled_players, const uint8_t *tricks, void *stream) {
+  COMMON(h, n);
+  NEED(state && hand && dealer && vul_ns && vul_ew && shuffled_players && tricks, "NULL input array");
+  hipLaunchKernelGGL(k_init_explicit, dim3(thread_grid(n, 128)), dim3(128), 0, (hipStream_t)stream, state, n, hand,
+                     dealer, vul_ns, vul_ew, shuffled_players, tricks);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                        const int32_t *action, int autoreset, uint8_t *obs, uint8_t *mask, float *rewards,
+                        uint8_t *terminated, int32_t *current_player, void *stream) {
+  COMMON(h, n);
+  NEED(state_in && state_out && action, "NULL state / action");
+  if (autoreset && h->lut_len == 0) return fail(BRL_E_NOLUT, "auto-reset needs a LUT%s", "");
+  StepOut o{obs, mask, rewards, terminated, current_player};
+  LAUNCH_K(h, k_step, n, stream, state_in, state_out, n, action, autoreset, rng_of(h), h->env_offset, lut_of(h), o);
+  return BRL_OK;
+}
+
+extern "C" int brl_observe(brl_handle *h, const uint64_t *state, int64_t n, const int32_t *player_id, uint8_t *obs,
+                           uint8_t *mask, void *stream) {
+  COMMON(h, n);
+  NEED(state != nullptr, "state");
+  LAUNCH_K(h, k_observe, n, stream, state, n, player_id, obs, mask);
+  return BRL_OK;
+}
+
+extern "C" int brl_get_fields(brl_handle *h, const uint64_t *state, int64_t n, const brl_fields *out, void *stream) {
+  COMMON(h, n);
+  NEED(state && out, "state / out");
+  hipLaunchKernelGGL(k_get_fields, dim3(thread_grid(n, 128)), dim3(128), 0, (hipStream_t)stream, state, n, *out);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int num_steps, int substeps,
+                                  uint32_t draw_base, float reward_scale, const brl_transition *out,
+                                  int64_t *terminated_count, void *stream) {
+  COMMON(h, n);
+  NEED(state && out, "state / out");
+  NEED(num_steps >= 0, "num_steps");
+  NEED(substeps >= 1 && substeps <= 16, "substeps");
+  if (h->lut_len == 0) return fail(BRL_E_NOLUT, "brl_rollout_random auto-resets and needs a LUT%s", "");
+  RolloutArgs A;
+  A.state = state; A.n = n; A.T = num_steps; A.substeps = substeps; A.draw_base = draw_base;
+  A.reward_scale = reward_scale; A.g = rng_of(h); A.env_offset = h->env_offset; A.lut = lut_of(h);
+  A.neg_log_n = h->neg_log_n; A.out = *out; A.terminated_count = (unsigned long long *)terminated_count;
+  LAUNCH_K(h, k_rollout_random, n, stream, A);
+  return BRL_OK;
+}
+
+extern "C" int brl_policy_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                               const float *logits, int mode, uint32_t draw, int autoreset, int32_t *action,
+                               float *log_prob, uint8_t *obs, uint8_t *mask, float *rewards_acc,
+                               uint8_t *terminated_acc, int32_t *current_player, void *stream) {
+  COMMON(h, n);
+  NEED(state_in && state_out && logits, "NULL state / logits");
+  NEED(mode == 0 || mode == 1, "mode");
+  if (autoreset && h->lut_len == 0) return fail(BRL_E_NOLUT, "auto-reset needs a LUT%s", "");
+  PolicyArgs A;
+  A.state_in = state_in; A.state_out = state_out; A.n = n; A.logits = logits; A.mode = mode; A.draw = draw;
+  A.autoreset = autoreset; A.g = rng_of(h); A.env_offset = h->env_offset; A.lut = lut_of(h);
+  A.action = action; A.log_prob = log_prob;
+  A.o = StepOut{obs, mask, rewards_acc, terminated_acc, current_player};
+  LAUNCH_K(h, k_policy_step, n, stream, A);
+  return BRL_OK;
+}
+
+extern "C" int brl_gae(brl_handle *h, const uint8_t *done, const float *value, const float *reward,
+                       const float *last_val, float gamma, float gamma_lambda, int T, int64_t n, float *advantages,
+                       float *targets, void *stream) {
+  COMMON(h, n);
+  NEED(done && value && reward && last_val && advantages && targets, "NULL array");
+  NEED(T >= 0, "T");
+  hipLaunchKernelGGL(k_gae, dim3(thread_grid(n, 64)), dim3(64), 0, (hipStream_t)stream, done, value, reward, last_val,
+                     gamma, gamma_lambda, T, n, advantages, targets);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_imp_reward(brl_handle *h, const float *a, const float *b, float *out, int64_t n, void *stream) {
+  COMMON(h, n);
+  NEED(a && b && out, "NULL array");
+  hipLaunchKernelGGL(k_imp_reward, dim3(thread_grid(n, 128)), dim3(128), 0, (hipStream_t)stream, a, b, out, n);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+static bool table_info_ok(const brl_table_info *t) {
+  return t && t->terminated && t->rewards && t->last_bid && t->last_bidder && t->call_x && t->call_xx;
+}
+
+extern "C" int brl_duplicate_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                                  const int32_t *action, const brl_table_info *table_a,
+                                  const brl_table_info *table_b, uint8_t *obs, uint8_t *mask, float *rewards,
+                                  uint8_t *terminated, int32_t *current_player, void *stream) {
+  COMMON(h, n);
+  NEED(state_in && state_out && action, "NULL state / action");
+  NEED(table_info_ok(table_a) && table_info_ok(table_b), "table_a / table_b has NULL members");
+  StepOut o{obs, mask, rewards, terminated, current_player};
+  LAUNCH_K(h, k_duplicate_step, n, stream, state_in, state_out, n, action, *table_a, *table_b, o);
+  return BRL_OK;
+}

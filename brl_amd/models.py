@@ -1,0 +1,84 @@
+"""The policy/value network of the reference (src/models.py) as a small torch module.
+
+north_star assigns the MLP to PyTorch-ROCm (dense GEMMs -> rocBLAS/hipBLASLt MFMA kernels);
+only the architecture is mirrored here: "DeepMind" = 480 -> 4 x 1024 (ReLU) -> 38 logits + 1
+value (src/models.py:23-33), "FAIR" = the 200-wide residual net (src/models.py:34-69).
+``make_forward_pass`` keeps the Haiku-style ``init / apply(params, x)`` surface
+(src/models.py:73-83); ``params`` is the torch module itself.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+
+def _haiku_linear(fan_in: int, fan_out: int) -> nn.Linear:
+    """hk.Linear default init: truncated normal(stddev = 1/sqrt(fan_in)), zero bias."""
+    lin = nn.Linear(fan_in, fan_out)
+    std = 1.0 / math.sqrt(fan_in)
+    nn.init.trunc_normal_(lin.weight, mean=0.0, std=std, a=-2 * std, b=2 * std)
+    nn.init.zeros_(lin.bias)
+    return lin
+
+
+class ActorCritic(nn.Module):
+    def __init__(self, action_dim: int = 38, activation: str = "relu", model: str = "DeepMind", obs_dim: int = 480):
+        super().__init__()
+        self.model = model
+        self.act = torch.relu if activation == "relu" else torch.tanh
+        if model == "DeepMind":
+            self.body = nn.ModuleList([_haiku_linear(obs_dim, 1024)] + [_haiku_linear(1024, 1024) for _ in range(3)])
+            self.actor = _haiku_linear(1024, action_dim)
+            self.critic = _haiku_linear(1024, 1)
+        elif model == "FAIR":
+            self.l = nn.ModuleList(
+                [_haiku_linear(obs_dim, 200)] + [_haiku_linear(200, 200) for _ in range(5)]
+                + [_haiku_linear(200 + obs_dim, 200)] + [_haiku_linear(200, 200) for _ in range(4)]
+            )
+            self.actor = _haiku_linear(200, action_dim)
+            self.critic = _haiku_linear(200, 1)
+        else:
+            raise ValueError(model)
+
+    def forward(self, x):
+        a = self.act
+        if self.model == "DeepMind":
+            for lin in self.body:
+                x = a(lin(x))
+        else:
+            inp = x
+            L = self.l
+            x = L[0](x); s1 = x
+            x = a(x); x = a(L[1](x)); x = a(L[2](x)); x = x + s1; s2 = x
+            x = a(x); x = a(L[3](x)); x = a(L[4](x)); x = x + s2
+            x = L[5](x)
+            x = torch.cat([x, inp], dim=-1)
+            x = L[6](x); s3 = x
+            x = a(x); x = a(L[7](x)); x = a(L[8](x)); x = x + s3; s4 = x
+            x = a(x); x = a(L[9](x)); x = a(L[10](x)); x = x + s4
+        return self.actor(x), self.critic(x).squeeze(-1)
+
+
+class ForwardPass:
+    """``hk.without_apply_rng(hk.transform(forward_fn))`` look-alike (src/models.py:73-83)."""
+
+    def __init__(self, activation: str, model_type: str):
+        self.activation = activation
+        self.model_type = model_type
+
+    def init(self, rng, x=None, device=None):
+        seed = int(rng) if not torch.is_tensor(rng) else int(rng.reshape(-1)[0].item())
+        devs = [] if device is None or torch.device(device).type == "cpu" else [device]
+        with torch.random.fork_rng(devices=devs):
+            torch.manual_seed(seed)
+            net = ActorCritic(38, self.activation, self.model_type)
+        return net.to(device) if device is not None else net
+
+    def apply(self, params: nn.Module, x):
+        return params(x)
+
+
+def make_forward_pass(activation: str, model_type: str) -> ForwardPass:
+    return ForwardPass(activation, model_type)

@@ -1,0 +1,133 @@
+"""``src/roll_out.py`` on the GPU.
+
+* ``make_random_roll_out`` — BASELINE config 1/2: uniform-random masked policy; the whole
+  T-step scan is ONE kernel launch (``brl_rollout_random``) that streams the time-major
+  Transition buffer to HBM.
+* ``make_roll_out`` — the reference's signature (src/roll_out.py:23,49) with torch MLPs in the
+  loop: per sub-step one GEMM forward (PyTorch-ROCm) + one ``brl_policy_step`` launch, no host
+  synchronisation inside the scan.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+
+from . import _capi
+from ._capi import NUM_ACTIONS, OBS_SIZE, check, ptr
+from .bridge_bidding import BridgeBidding, State, _stream
+from .utils import MODE, SAMPLE, _pass_logits, policy_step
+
+
+class Transition(NamedTuple):  # src/roll_out.py:13-20 ; all time-major [T,N,...]
+    done: torch.Tensor               # bool
+    action: torch.Tensor             # int32
+    value: torch.Tensor              # f32
+    reward: torch.Tensor             # f32  rewards[actor] / reward_scale
+    log_prob: torch.Tensor           # f32
+    obs: torch.Tensor                # bool [T,N,480]
+    legal_action_mask: torch.Tensor  # bool [T,N,38]
+
+
+def alloc_transition(T: int, n: int, device) -> Transition:
+    e = lambda shape, dt: torch.empty(shape, dtype=dt, device=device)  # noqa: E731
+    return Transition(e((T, n), torch.bool), e((T, n), torch.int32), e((T, n), torch.float32),
+                      e((T, n), torch.float32), e((T, n), torch.float32), e((T, n, OBS_SIZE), torch.bool),
+                      e((T, n, NUM_ACTIONS), torch.bool))
+
+
+def _count_tensor(terminated_count, device):
+    if torch.is_tensor(terminated_count):
+        return terminated_count.to(device=device, dtype=torch.int64).reshape(1)
+    return torch.tensor([int(terminated_count)], dtype=torch.int64, device=device)
+
+
+def make_random_roll_out(config, env: BridgeBidding):
+    """roll_out with the uniform-random masked policy (logits = 0 -> masked Categorical, value = 0)
+    and ``normal_step`` (config["game_mode"] == "normal", 1 env.step per scan step — BASELINE
+    config 2) or the 4-sub-step competitive macro-step with every seat random ("competitive").
+    ``runner_state[5]`` (the reference's PRNG key slot) is an int: the index of the next action draw."""
+    T = int(config["num_steps"])
+    substeps = 4 if config.get("game_mode", "normal") == "competitive" else 1
+    reward_scale = float(config.get("reward_scale", 7600))
+
+    def roll_out(runner_state, out: Transition = None):
+        params, opt_state, env_state, last_obs, terminated_count, rng = runner_state
+        n = env_state.num_envs
+        traj = out if out is not None else alloc_transition(T, n, env.device)
+        tc = _count_tensor(terminated_count, env.device)
+        p = _capi.TransitionPtrs()
+        for name in _capi.TransitionPtrs._names:
+            setattr(p, name, ptr(getattr(traj, name)))
+        check(_capi.lib().brl_rollout_random(env._h, ptr(env_state.packed), n, T, substeps, int(rng) & 0xFFFFFFFF,
+                                             reward_scale, C.byref(p), ptr(tc), _stream()))
+        new_state = State(env, env_state.packed)  # updated in place
+        last_obs = new_state.observation if config.get("return_last_obs", True) else None
+        return (params, opt_state, new_state, last_obs, tc, int(rng) + T * substeps), traj
+
+    return roll_out
+
+
+def make_roll_out(config, env: BridgeBidding, actor_forward_pass, opp_forward_pass):
+    """``make_roll_out(config, env, actor_forward_pass, opp_forward_pass)`` (src/roll_out.py:23).
+    Returns ``roll_out(runner_state, opp_params) -> (runner_state, traj_batch)`` (src/roll_out.py:49).
+    Only the masked policy (config["actor_illegal_action_mask"]) is on the hot path."""
+    if not config.get("actor_illegal_action_mask", True):
+        raise NotImplementedError("the unmasked / illegal-action-penalty policy is outside the hot path")
+    T = int(config["num_steps"])
+    reward_scale = float(config["reward_scale"])
+    mode = config.get("game_mode", "competitive")
+    if mode not in ("competitive", "free-run"):
+        raise ValueError(mode)
+
+    def roll_out(runner_state, opp_params):
+        params, opt_state, env_state, last_obs, terminated_count, rng = runner_state
+        n, dev = env_state.num_envs, env.device
+        traj = alloc_transition(T, n, dev)
+        tc = _count_tensor(terminated_count, dev)
+        packed = env_state.packed.clone()  # the caller's env_state stays valid, like a JAX pytree
+        cur = [env_state.current_player.clone(), torch.empty(n, dtype=torch.int32, device=dev)]
+        traj.obs[0].copy_(env_state.observation if last_obs is None else last_obs)
+        traj.legal_action_mask[0].copy_(env_state.legal_action_mask)
+        scratch_obs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=dev)
+        final_obs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=dev)
+        final_mask = torch.empty((n, NUM_ACTIONS), dtype=torch.bool, device=dev)
+        racc = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        tacc = torch.empty(n, dtype=torch.bool, device=dev)
+        draw = int(rng)
+        with torch.no_grad():
+            for t in range(T):
+                actor = cur[t & 1]  # src/roll_out.py:72
+                logits, value = actor_forward_pass.apply(params, traj.obs[t].to(torch.float32))  # :73-76
+                traj.value[t].copy_(value)
+                racc.zero_()
+                tacc.zero_()
+                # sub-step 1: actor samples from the masked Categorical (src/roll_out.py:79-84)
+                policy_step(env, packed, packed, logits, SAMPLE, draw, True, action=traj.action[t],
+                            log_prob=traj.log_prob[t], obs=scratch_obs, rewards_acc=racc, terminated_acc=tacc)
+                last = t + 1 == T
+                obs_out = final_obs if last else traj.obs[t + 1]
+                mask_out = final_mask if last else traj.legal_action_mask[t + 1]
+                for k in (1, 2, 3):  # opp, partner (actor params), opp — src/utils.py:78-120
+                    is_opp = k != 2
+                    if mode == "free-run" and is_opp:
+                        lg, m = _pass_logits(env, n), MODE
+                    else:
+                        fp, pr = (opp_forward_pass, opp_params) if is_opp else (actor_forward_pass, params)
+                        lg, _ = fp.apply(pr, scratch_obs.to(torch.float32))
+                        m = SAMPLE if mode == "competitive" else MODE
+                    fin = k == 3
+                    policy_step(env, packed, packed, lg, m, draw + k, True,
+                                obs=obs_out if fin else scratch_obs, mask=mask_out if fin else None,
+                                rewards_acc=racc, terminated_acc=tacc, current_player=cur[(t + 1) & 1] if fin else None)
+                draw += 4
+                traj.done[t].copy_(tacc)  # G2
+                traj.reward[t].copy_(racc.gather(1, actor.to(torch.int64)[:, None])[:, 0] / reward_scale)  # G1
+                tc += tacc.sum()
+        new_state = State(env, packed, {"observation": final_obs, "legal_action_mask": final_mask,
+                                        "current_player": cur[T & 1]})
+        new_state = new_state.replace(rewards=racc, terminated=tacc)  # src/utils.py:128
+        return (params, opt_state, new_state, new_state.observation, tc, draw), traj
+
+    return roll_out

@@ -1,0 +1,119 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+that include/brl_hip.h declares; the host mirror keeps the reference's names; there is no
+fallback path when the extension or the GPU is missing.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from brl_amd import build
+    return build.build()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "brl_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(brl_[a-z_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    syms = header_symbols()
+    for s in ("brl_create", "brl_destroy", "brl_init_random", "brl_init_from_deals", "brl_step", "brl_observe",
+              "brl_rollout_random", "brl_policy_step", "brl_gae", "brl_imp_reward", "brl_duplicate_step",
+              "brl_get_fields", "brl_set_lut", "brl_set_rng", "brl_last_error"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    lib = ctypes.CDLL(built_lib)
+    for s in header_symbols():
+        assert hasattr(lib, s), f"{s} declared in include/brl_hip.h but not exported"
+
+
+def test_binding_covers_every_declared_symbol(built_lib):
+    from brl_amd import _capi
+    assert sorted(_capi.EXPORTS) == header_symbols()
+    L = _capi.lib()
+    assert L.brl_version() >= 1
+    assert L.brl_last_error() is not None
+
+
+def test_struct_layouts_match_header():
+    from brl_amd import _capi
+    text = open(os.path.join(ROOT, "include", "brl_hip.h")).read()
+    for cls, name in ((_capi.Fields, "brl_fields"), (_capi.TransitionPtrs, "brl_transition"),
+                      (_capi.TableInfoPtrs, "brl_table_info")):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        members = re.findall(r"\*\s*([a-z_]+)\s*;", body)
+        assert members == cls._names, name
+
+
+def test_bad_arguments_are_reported_not_crashed(built_lib):
+    from brl_amd import _capi
+    L = _capi.lib()
+    assert L.brl_set_rng(None, 0, 0) == -1  # BRL_E_ARG
+    assert b"handle" in L.brl_last_error()
+    assert L.brl_destroy(None) == 0
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    import brl_amd
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(brl_amd._capi.BrlError):
+        brl_amd.BridgeBidding(lut=None)
+
+
+def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
+    from brl_amd import _capi
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(_capi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_capi.BrlError, match="no CPU fallback"):
+        _capi.lib()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "brl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "liboracle" not in src and "bridge_oracle" not in src, f
+
+
+def test_host_mirror_keeps_reference_names():
+    import brl_amd
+    from brl_amd import duplicate, gae, models, roll_out, utils
+    assert brl_amd.BridgeBidding.observation_shape == (480,)  # ppo.py:241
+    for mod, names in ((utils, ["auto_reset", "single_play_step_two_policy_commpetitive",
+                                "single_play_step_two_policy_commpetitive_deterministic",
+                                "single_play_step_free_run", "normal_step"]),
+                       (roll_out, ["Transition", "make_roll_out"]), (gae, ["make_calc_gae"]),
+                       (duplicate, ["_imp_reward", "duplicate_init", "duplicate_step", "Table_info"]),
+                       (models, ["ActorCritic", "make_forward_pass"])):
+        for n in names:
+            assert hasattr(mod, n), n
+    assert roll_out.Transition._fields == ("done", "action", "value", "reward", "log_prob", "obs", "legal_action_mask")
+    assert duplicate.Table_info._fields == ("terminated", "rewards", "last_bid", "last_bidder", "call_x", "call_xx")
+
+
+def test_mlp_shapes_match_reference_model():
+    import torch
+    from brl_amd.models import make_forward_pass
+    for model, nparams in (("DeepMind", 480 * 1024 + 1024 + 3 * (1024 * 1024 + 1024) + 1024 * 38 + 38 + 1024 + 1),
+                           ("FAIR", None)):
+        fp = make_forward_pass("relu", model)
+        net = fp.init(0)
+        logits, value = fp.apply(net, torch.zeros(5, 480))
+        assert logits.shape == (5, 38) and value.shape == (5,)
+        if nparams:
+            assert sum(p.numel() for p in net.parameters()) == nparams == 3681319

@@ -1,0 +1,359 @@
+"""-m gpu: the HIP path (through the C-ABI) against the CPU oracle on identical inputs.
+Bit-exact for every integer / byte / index field; float fields are exact too unless a
+tolerance is written in the test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import synthetic_lut
+from tests.gpu_util import assert_state_equal, random_legal_actions, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(dds):
+    import brl_amd
+    return brl_amd.BridgeBidding(lut=(dds["keys"], dds["values"]))
+
+
+def make_env(dds, k):
+    import brl_amd
+    old = os.environ.get("BRL_TABLES_PER_WAVE")
+    os.environ["BRL_TABLES_PER_WAVE"] = str(k)
+    try:
+        return brl_amd.BridgeBidding(lut=(dds["keys"], dds["values"]))
+    finally:
+        if old is None:
+            del os.environ["BRL_TABLES_PER_WAVE"]
+        else:
+            os.environ["BRL_TABLES_PER_WAVE"] = old
+
+
+def test_extension_is_the_in_tree_hip_library():
+    from brl_amd import _capi
+    assert os.path.exists(_capi.LIB_PATH)
+    assert _capi.lib().brl_version() >= 1
+
+
+@pytest.mark.parametrize("n", [1, 3, 17, 1000, 4096])
+def test_init_random_matches_oracle(env, oracle, n):
+    st = env.init(1234, num_envs=n)
+    ref = oracle.init_random(n, seed=1234)
+    assert_state_equal(st, ref, where=f"init n={n}")
+
+
+def test_init_random_env_offset(dds, oracle):
+    import brl_amd
+    e = brl_amd.BridgeBidding(lut=(dds["keys"], dds["values"]), env_offset=5000)
+    st = e.init(77, num_envs=64)
+    ref = oracle.init_random(64, seed=77, env_offset=5000)
+    assert_state_equal(st, ref, where="env_offset")
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 8])
+def test_step_random_auctions_no_reset(dds, oracle, k):
+    env = make_env(dds, k)
+    n = 1531  # ragged on purpose
+    rng = np.random.default_rng(k)
+    st = env.init(9, num_envs=n)
+    ref = oracle.init_random(n, seed=9)
+    for step in range(70):
+        act = random_legal_actions(rng, ref["legal_action_mask"])
+        if step % 3 == 0:  # bias towards passes so that auctions end at all lengths
+            act[rng.random(n) < 0.5] = 0
+        st = env.step(st, torch.from_numpy(act))
+        oracle.step(ref, act)
+        if step % 7 == 0 or step > 60:
+            assert_state_equal(st, ref, where=f"K={k} step {step}")
+    assert ref["terminated"].mean() > 0.9
+
+
+@pytest.mark.parametrize("k", [1, 4, 8])
+def test_step_autoreset(dds, oracle, k):
+    env = make_env(dds, k)
+    n = 777
+    rng = np.random.default_rng(100 + k)
+    st = env.init(31, num_envs=n)
+    ref = oracle.init_random(n, seed=31)
+    for step in range(120):
+        act = random_legal_actions(rng, ref["legal_action_mask"])
+        act[rng.random(n) < 0.35] = 0
+        st = env.step(st, torch.from_numpy(act), autoreset=True, inplace=(step % 2 == 0))
+        oracle.step(ref, act, autoreset=True, seed=31)
+        if step % 10 == 0 or step > 110:
+            assert_state_equal(st, ref, where=f"K={k} autoreset step {step}")
+    assert ref["board_ctr"].min() >= 1
+
+
+def test_explicit_deals_wb5_auction(env, oracle, dds):
+    # wb5/utils.py:61-75
+    auction = [0, 9, 11, 20, 1, 0, 22, 1, 2, 0, 0, 28, 0, 0]
+    n = 40
+    hands = np.stack([oracle.key_to_hand(dds["keys"][i]) for i in range(n)])
+    tricks = dds["tricks"][:n].reshape(n, 20)
+    st = env.init_from_deals(hands, 1, False, False, [0, 3, 1, 2], tricks)
+    ref = oracle.init_explicit(hands, 1, 0, 0, [0, 3, 1, 2], tricks)
+    assert_state_equal(st, ref, where="explicit init")
+    for i, a in enumerate(auction + [0, 0]):
+        st = env.step(st, torch.full((n,), a, dtype=torch.int32))
+        oracle.step(ref, np.full(n, a, np.int32))
+        assert_state_equal(st, ref, where=f"wb5 call {i}")
+    assert ref["terminated"].all()
+
+
+def test_illegal_action_matches_oracle(env, oracle, dds):
+    n = 64
+    st = env.init(3, num_envs=n)
+    ref = oracle.init_random(n, seed=3)
+    for a in ([10] * n, [5] * n):  # second call bids BELOW the first: illegal
+        st = env.step(st, torch.tensor(a, dtype=torch.int32))
+        oracle.step(ref, np.array(a, np.int32))
+    assert ref["illegal"].all()
+    assert_state_equal(st, ref, fields={"terminated", "rewards", "illegal", "legal_action_mask", "current_player", "observation"},
+                       where="illegal")
+
+
+def test_observe_any_player(env, oracle):
+    n = 300
+    rng = np.random.default_rng(5)
+    st = env.init(8, num_envs=n)
+    ref = oracle.init_random(n, seed=8)
+    for _ in range(9):
+        act = random_legal_actions(rng, ref["legal_action_mask"])
+        st = env.step(st, torch.from_numpy(act))
+        oracle.step(ref, act)
+    import brl_amd
+    for p in range(4):
+        got = to_np(brl_amd._observe(st, torch.full((n,), p, dtype=torch.int32)))
+        assert np.array_equal(got, oracle.observe(ref, p))
+    pid = rng.integers(0, 4, n).astype(np.int32)
+    assert np.array_equal(to_np(env.observe(st, torch.from_numpy(pid))), oracle.observe(ref, pid))
+    pos = to_np(brl_amd._player_position(torch.from_numpy(pid), st))
+    assert np.array_equal(pos, np.array([list(ref["shuffled_players"][i]).index(pid[i]) for i in range(n)]))
+
+
+@pytest.mark.parametrize("k,substeps,n,T", [(1, 1, 256, 32), (2, 1, 515, 16), (4, 1, 2048, 32), (8, 1, 1000, 40),
+                                            (4, 4, 1024, 32), (8, 4, 333, 12), (1, 4, 64, 8)])
+def test_fused_random_rollout_matches_oracle(dds, oracle, k, substeps, n, T):
+    import brl_amd
+    env = make_env(dds, k)
+    cfg = {"num_steps": T, "game_mode": "competitive" if substeps == 4 else "normal", "reward_scale": 7600}
+    roll = brl_amd.make_random_roll_out(cfg, env)
+    st = env.init(2024, num_envs=n)
+    ref = oracle.init_random(n, seed=2024)
+    rs = (None, None, st, st.observation, 0, 0)
+    draw = 0
+    for call in range(2):  # two back-to-back rollouts: state and draw counter carry over
+        rs, traj = roll(rs)
+        want = oracle.rollout_random(ref, T, seed=2024, substeps=substeps, draw_base=draw)
+        draw += T * substeps
+        torch.cuda.synchronize()
+        for name in ("obs", "legal_action_mask", "action", "done", "value", "reward", "log_prob"):
+            g, o = to_np(getattr(traj, name)), want[name]
+            assert g.shape == o.shape and np.array_equal(g, o), f"K={k} sub={substeps} call {call}: {name}"
+        assert_state_equal(rs[2], ref, where=f"rollout final state K={k} sub={substeps} call {call}")
+        assert np.array_equal(to_np(rs[3]), ref["observation"])
+        assert rs[5] == draw
+
+
+def test_rollout_terminated_count_accumulates(env, oracle):
+    import brl_amd
+    n, T = 512, 32
+    roll = brl_amd.make_random_roll_out({"num_steps": T}, env)
+    st = env.init(6, num_envs=n)
+    ref = oracle.init_random(n, seed=6)
+    rs = (None, None, st, None, 0, 0)
+    rs, _ = roll(rs)
+    a = oracle.rollout_random(ref, T, seed=6)["terminated_count"]
+    rs, _ = roll(rs)
+    b = oracle.rollout_random(ref, T, seed=6, draw_base=T)["terminated_count"]
+    assert int(rs[4].item()) == a + b and a > 0
+
+
+def test_gae_bit_exact(env, oracle):
+    from brl_amd.gae import gae_scan
+    rng = np.random.default_rng(2)
+    for (T, N, gamma, lam) in ((32, 8192, 1.0, 0.95), (7, 130, 0.99, 0.9), (1, 1, 1.0, 1.0)):
+        done = rng.random((T, N)) < 0.07
+        value = rng.standard_normal((T, N)).astype(np.float32)
+        reward = (rng.standard_normal((T, N)) * 0.2).astype(np.float32)
+        last = rng.standard_normal(N).astype(np.float32)
+        adv, tgt = gae_scan(env, torch.from_numpy(done).cuda(), torch.from_numpy(value).cuda(),
+                            torch.from_numpy(reward).cuda(), torch.from_numpy(last).cuda(), gamma, lam)
+        wa, wt = oracle.gae(done.astype(np.uint8), value, reward, last, gamma, lam)
+        assert np.array_equal(to_np(adv), wa) and np.array_equal(to_np(tgt), wt)
+
+
+def test_imp_reward_kats_and_oracle(env, oracle):
+    import brl_amd
+    from tests.test_oracle_kat import IMP_DOCTESTS
+    for a, b, want in IMP_DOCTESTS:  # src/duplicate.py:20-43
+        got = brl_amd._imp_reward(torch.tensor(a, dtype=torch.float32), torch.tensor(b, dtype=torch.float32), env=env)
+        assert to_np(got).tolist() == [float(x) for x in want]
+    rng = np.random.default_rng(4)
+    a = (rng.integers(-760, 761, (5000, 1)) * 10 * np.array([1, 1, -1, -1])).astype(np.float32)
+    b = (rng.integers(-760, 761, (5000, 1)) * 10 * np.array([1, 1, -1, -1])).astype(np.float32)
+    got = to_np(brl_amd._imp_reward(torch.from_numpy(a), torch.from_numpy(b), env=env))
+    want = np.stack([oracle.imp_reward(a[i], b[i]) for i in range(5000)])
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("k", [1, 4])
+def test_duplicate_step_matches_oracle(dds, oracle, k):
+    import brl_amd
+    from oracle import Oracle
+    env = make_env(dds, k)
+    n = 901
+    rng = np.random.default_rng(21)
+    st = env.init(55, num_envs=n)
+    ref = oracle.init_random(n, seed=55)
+    A, B = brl_amd.Table_info.from_state(st), brl_amd.Table_info.from_state(st)
+    oA, oB = Oracle.table_info_from(ref), Oracle.table_info_from(ref)
+    step_fn = brl_amd.duplicate_step(env.step)
+    cum = np.zeros(n, np.float32)
+    it = 0
+    while not ref["terminated"].all() and it < 700:
+        act = random_legal_actions(rng, ref["legal_action_mask"])
+        act[rng.random(n) < 0.4] = 0
+        st, A, B = step_fn(st, torch.from_numpy(act), A, B)
+        oracle.duplicate_step(ref, act, oA, oB)
+        cum += ref["rewards"][:, 0]
+        if it % 11 == 0:
+            assert_state_equal(st, ref, where=f"duplicate it {it}")
+        it += 1
+    assert ref["terminated"].all()
+    assert_state_equal(st, ref, where="duplicate end")
+    for T, oT in ((A, oA), (B, oB)):  # G12: the snapshot is what "final contract" means
+        for f in ("terminated", "rewards", "last_bid", "last_bidder", "call_x", "call_xx"):
+            assert np.array_equal(to_np(getattr(T, f)).astype(np.float64), oT[f].astype(np.float64)), f
+    assert (oA["terminated"] == 1).all() and (oB["terminated"] == 1).all()
+    # G8: IMP emitted exactly once per board
+    want = np.stack([oracle.imp_reward(oA["rewards"][i], oB["rewards"][i]) for i in range(n)])[:, 0]
+    assert np.array_equal(cum, want)
+    # G11: duplicate_init helper = seat swap on the same deal
+    d = brl_amd.duplicate_init(env.init(55, num_envs=n))
+    f0 = oracle.init_random(n, seed=55)
+    assert np.array_equal(to_np(d._shuffled_players), f0["shuffled_players"][:, [1, 0, 3, 2]])
+    assert np.array_equal(to_np(d._hand), f0["hand"]) and np.array_equal(to_np(d._dealer), f0["dealer"])
+
+
+def _masked_log_softmax(logits, mask):
+    l = np.where(mask.astype(bool), logits.astype(np.float64), -np.inf)
+    m = l.max(1, keepdims=True)
+    return l - m - np.log(np.exp(l - m).sum(1, keepdims=True))
+
+
+def test_policy_step_argmax_and_sample(env, oracle):
+    from brl_amd.utils import policy_step, MODE, SAMPLE
+    n = 4096
+    rng = np.random.default_rng(12)
+    st = env.init(19, num_envs=n)
+    ref = oracle.init_random(n, seed=19)
+    for _ in range(5):
+        act = random_legal_actions(rng, ref["legal_action_mask"])
+        st = env.step(st, torch.from_numpy(act))
+        oracle.step(ref, act)
+    mask = ref["legal_action_mask"].copy()
+    logits = rng.standard_normal((n, 38)).astype(np.float32) * 2
+    lsm = _masked_log_softmax(logits, mask)
+    lg = torch.from_numpy(logits).cuda()
+    action = torch.empty(n, dtype=torch.int32, device="cuda")
+    logp = torch.empty(n, dtype=torch.float32, device="cuda")
+    # arg-max (pi.mode()) — exact
+    out = torch.empty_like(st.packed)
+    policy_step(env, st.packed, out, lg, MODE, 0, False, action=action, log_prob=logp)
+    a = to_np(action)
+    assert np.array_equal(a, np.where(mask.astype(bool), logits, -np.inf).argmax(1))
+    assert np.allclose(to_np(logp), lsm[np.arange(n), a], atol=1e-5)  # fp32 log-softmax tolerance
+    ref2 = ref.copy()
+    oracle.step(ref2, a)
+    from brl_amd.bridge_bidding import State
+    assert_state_equal(State(env, out), ref2, where="policy_step(mode) next state")
+    # sampling: always legal, log-prob of the sampled action, inverse-CDF consistency, frequencies
+    counts = np.zeros((n, 38))
+    for d in range(64):
+        policy_step(env, st.packed, out, lg, SAMPLE, d, False, action=action, log_prob=logp)
+        a = to_np(action)
+        assert mask[np.arange(n), a].all()
+        assert np.allclose(to_np(logp), lsm[np.arange(n), a], atol=1e-5)
+        u = np.array([oracle.action_draw(19, e, d) >> 8 for e in range(0, n, 64)]) / 2.0 ** 24
+        p = np.exp(lsm[::64])
+        cdf = np.cumsum(p, 1)
+        aa = a[::64]
+        hi = cdf[np.arange(len(aa)), aa]
+        lo = hi - p[np.arange(len(aa)), aa]
+        assert ((u >= lo - 1e-5) & (u <= hi + 1e-5)).all()  # the draw falls in the chosen action's CDF cell
+        counts[np.arange(n), a] += 1
+    # pooled chi-square-ish check: empirical frequency of the most likely action tracks its probability
+    top = lsm.argmax(1)
+    emp = counts[np.arange(n), top].sum() / (64 * n)
+    assert abs(emp - np.exp(lsm[np.arange(n), top]).mean()) < 0.01
+
+
+def test_policy_rollout_with_mlp_is_self_consistent(env):
+    import brl_amd
+    from brl_amd.models import make_forward_pass
+    n, T = 512, 8
+    cfg = {"num_steps": T, "reward_scale": 7600, "game_mode": "competitive", "actor_illegal_action_mask": True,
+           "gamma": 1.0, "gae_lambda": 0.95}
+    fp = make_forward_pass("relu", "DeepMind")
+    actor = fp.init(0, device="cuda")
+    opp = fp.init(1, device="cuda")
+    roll = brl_amd.make_roll_out(cfg, env, fp, fp)
+    st = env.init(42, num_envs=n)
+    rs = (actor, None, st, st.observation, 0, 0)
+    rs2, traj = roll(rs, opp)
+    torch.cuda.synchronize()
+    obs, mask, act = to_np(traj.obs), to_np(traj.legal_action_mask), to_np(traj.action)
+    assert obs.shape == (T, n, 480) and mask.shape == (T, n, 38)
+    assert (obs[:, :, 428:].sum(-1) == 13).all()
+    assert np.take_along_axis(mask, act[..., None].astype(np.int64), 2).all()  # sampled action always legal
+    with torch.no_grad():
+        logits, value = actor(traj.obs.reshape(T * n, 480).float())
+    lsm = _masked_log_softmax(to_np(logits), mask.reshape(T * n, 38))
+    assert np.allclose(to_np(traj.log_prob).reshape(-1), lsm[np.arange(T * n), act.reshape(-1)], atol=2e-4)
+    assert np.allclose(to_np(traj.value).reshape(-1), to_np(value), atol=1e-5)
+    r, d = to_np(traj.reward), to_np(traj.done)
+    assert (r[d == 0] == 0).all() and np.abs(r).max() <= 4.0
+    assert int(rs2[4].item()) == int(d.sum())
+    assert np.array_equal(to_np(rs2[3]), to_np(rs2[2].observation))
+    # determinism: same seed, same weights -> same bytes
+    st_b = env.init(42, num_envs=n)
+    _, traj_b = roll((actor, None, st_b, st_b.observation, 0, 0), opp)
+    assert torch.equal(traj.action, traj_b.action) and torch.equal(traj.obs, traj_b.obs)
+    adv, tgt = brl_amd.make_calc_gae(cfg, fp)(rs2, traj)
+    assert adv.shape == (T, n) and torch.isfinite(adv).all() and torch.allclose(tgt, adv + traj.value)
+
+
+def test_full_size_properties(dds):
+    """BASELINE.json size (N=8192, T=32): size-independent properties of the fused rollout."""
+    import brl_amd
+    keys, values = synthetic_lut(5000, seed=1)
+    env = brl_amd.BridgeBidding(lut=(keys, values))
+    n, T = 8192, 32
+    roll = brl_amd.make_random_roll_out({"num_steps": T}, env)
+    st = env.init(0, num_envs=n)
+    rs, traj = roll((None, None, st, None, 0, 0))
+    torch.cuda.synchronize()
+    obs = traj.obs
+    assert bool((obs[:, :, 428:].sum(-1) == 13).all())                      # 13 own cards
+    assert bool((obs[:, :, 0] ^ obs[:, :, 1]).all()) and bool((obs[:, :, 2] ^ obs[:, :, 3]).all())  # vul one-hot
+    hist = obs[:, :, 8:428].reshape(T, n, 35, 3, 4)
+    assert bool((hist.sum(-1) <= 1).all())                                   # one seat per (bid, event)
+    assert bool((hist[:, :, :, 1].sum(-1) <= hist[:, :, :, 0].sum(-1)).all())  # doubled only if bid
+    assert bool((hist[:, :, :, 2].sum(-1) <= hist[:, :, :, 1].sum(-1)).all())  # redoubled only if doubled
+    m = traj.legal_action_mask
+    assert bool(m[:, :, 0].all()) and not bool((m[:, :, 1] & m[:, :, 2]).any())
+    assert bool(torch.gather(m, 2, traj.action.long()[..., None]).all())
+    nl = m.sum(-1).float()
+    assert torch.allclose(traj.log_prob, -torch.log(nl), atol=1e-6)
+    assert bool((traj.reward[~traj.done] == 0).all()) and float(traj.reward.abs().max()) <= 1.0
+    assert int(rs[4].item()) == int(traj.done.sum())
+    # idempotence / determinism: same seed -> identical bytes
+    st2 = env.init(0, num_envs=n)
+    _, traj2 = roll((None, None, st2, None, 0, 0))
+    for a, b in zip(traj, traj2):
+        assert torch.equal(a, b)
