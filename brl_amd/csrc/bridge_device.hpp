@@ -160,61 +160,67 @@ __device__ __forceinline__ void terminal_reward(Tbl &t) {
   set_rewards(t, r[0], r[1], r[2], r[3]);
 }
 
+// A2, the auction itself: one LEGAL-or-not call by `seat` on a live table.  Touches only the
+// scalar words (last bid/bidder, X/XX, pass count, turn, step count, terminated) and returns
+// the history bit to OR into the table's image (-1: none).  Termination: four passes with no
+// bid (pass-out) or three passes after the last bid.
+__device__ __forceinline__ int auction_step(Tbl &t, int action, int seat) {
+  uint32_t sc = t.sc;
+  uint32_t lb1 = bits(sc, SC_LB1, 6);
+  uint32_t pass = bits(sc, SC_PASS, 3);
+  const bool is_pass = action == 0, is_x = action == 1, is_xx = action == 2, is_bid = action >= 3;
+  const int b = action - 3;
+  const int hb_bid = 8 + 12 * b + seat;
+  const int hb_dbl = 8 + 12 * ((int)lb1 - 1) + (is_x ? 4 : 8) + seat;
+  const int hb_pass = 4 + seat;
+  const int hb = is_bid ? hb_bid : (is_pass ? ((lb1 == 0) ? hb_pass : -1) : ((lb1 != 0) ? hb_dbl : -1));
+  pass = is_pass ? pass + 1u : 0u;
+  sc |= (is_x ? (1u << SC_X) : 0u) | (is_xx ? (1u << SC_XX) : 0u);
+  const uint32_t bid_clear = (63u << SC_LB1) | (3u << SC_LBSEAT) | (1u << SC_X) | (1u << SC_XX);
+  const uint32_t bid_set = ((uint32_t)(b + 1) << SC_LB1) | ((uint32_t)seat << SC_LBSEAT);
+  sc = is_bid ? ((sc & ~bid_clear) | bid_set) : sc;
+  lb1 = is_bid ? (uint32_t)(b + 1) : lb1;
+  sc = (sc & ~(7u << SC_PASS)) | (pass << SC_PASS);
+  const bool term = pass == ((lb1 != 0) ? 3u : 4u);
+  sc |= term ? ((1u << SC_TERM) | (1u << SC_MASKALL)) : 0u;  // all-True mask at a terminal (pgx Env.step)
+  t.sc = sc;
+  t.sch += (1u << SCH_STEP) + (term ? 0u : (1u << SCH_TURN));  // _step_count+1 ; next seat unless over
+  return hb;
+}
+
+// first player of each side to name each strain (decides the declarer)
+__device__ __forceinline__ void note_first_denomination(uint32_t &fd, int seat, int action) {
+  int b = action - 3;
+  int level0 = (b * 13) >> 6;
+  int den = b - level0 * 5;
+  int slot = (seat & 1) * 15 + den * 3;
+  bool set = (action >= 3) && (bits(fd, slot & 31, 3) == 0);
+  fd |= set ? ((uint32_t)(seat + 1) << (slot & 31)) : 0u;
+}
+
 // A2: env.step on one table (pgx core.Env.step + bridge _step).
 // Returns the history bit to OR into the LDS image (-1: none).
 __device__ __forceinline__ int table_step(Tbl &t, int action) {
-  int hist_bit = -1;
   if (bits(t.sc, SC_TERM, 1)) {  // finished table stepped again: zero rewards, no-op (G9)
     t.r01 = 0;
     t.r23 = 0;
-    return hist_bit;
+    return -1;
   }
   uint32_t illegal = (uint32_t)((legal_mask(t) >> action) & 1ull) ^ 1u;
   int seat = cur_seat(t);
-  uint32_t lb1 = bits(t.sc, SC_LB1, 6);
-  uint32_t pass = bits(t.sc, SC_PASS, 3);
-  uint32_t sc = t.sc;
-  t.sch += 1u << SCH_STEP;  // _step_count + 1
-  if (action == 0) {
-    pass += 1;
-    hist_bit = (lb1 == 0) ? 4 + seat : -1;
-  } else if (action == 1) {
-    sc |= 1u << SC_X;
-    pass = 0;
-    hist_bit = (lb1 != 0) ? 8 + 12 * ((int)lb1 - 1) + 4 + seat : -1;
-  } else if (action == 2) {
-    sc |= 1u << SC_XX;
-    pass = 0;
-    hist_bit = (lb1 != 0) ? 8 + 12 * ((int)lb1 - 1) + 8 + seat : -1;
-  } else {
-    int b = action - 3;
-    lb1 = (uint32_t)b + 1;
-    int level0 = (b * 13) >> 6;
-    int den = b - level0 * 5;
-    int slot = (seat & 1) * 15 + den * 3;
-    if (bits(t.fd, slot, 3) == 0) t.fd |= (uint32_t)(seat + 1) << slot;
-    sc &= ~((63u << SC_LB1) | (3u << SC_LBSEAT) | (1u << SC_X) | (1u << SC_XX));
-    sc |= (lb1 << SC_LB1) | ((uint32_t)seat << SC_LBSEAT);
-    pass = 0;
-    hist_bit = 8 + 12 * b + seat;
-  }
-  sc = (sc & ~(7u << SC_PASS)) | (pass << SC_PASS);
-  bool term = (lb1 == 0 && pass == 4) || (lb1 != 0 && pass == 3);
-  t.sc = sc;
-  if (term) {
-    t.sc |= 1u << SC_TERM;
+  note_first_denomination(t.fd, seat, action);
+  int hist_bit = auction_step(t, action, seat);
+  if (bits(t.sc, SC_TERM, 1)) {
     terminal_reward(t);
   } else {
-    t.sch += 1u << SCH_TURN;  // next seat to act; bits cannot carry out of 9 (<= 319 calls)
     t.r01 = 0;
     t.r23 = 0;
   }
   if (illegal) {  // [RECALL] pgx: offender -1, every other player +1*(4-1); game over
     int p = player_at(t, seat);
     set_rewards(t, p == 0 ? -1 : 3, p == 1 ? -1 : 3, p == 2 ? -1 : 3, p == 3 ? -1 : 3);
-    t.sc |= (1u << SC_TERM) | (1u << SC_ILLEGAL);
+    t.sc |= (1u << SC_TERM) | (1u << SC_ILLEGAL) | (1u << SC_MASKALL);
   }
-  if (bits(t.sc, SC_TERM, 1)) t.sc |= 1u << SC_MASKALL;
   return hist_bit;
 }
 
@@ -253,21 +259,34 @@ struct Rng {
 // A1: parameters of board number `board_ctr` of env `env_id` (uniform LUT row, dealer,
 // vulnerabilities, one of the 8 team-preserving seatings — SURVEY §8a A1 / App. B), and the
 // fresh scalars.  terminated / illegal / rewards are carried by the caller (src/utils.py:50-54).
-__device__ __forceinline__ void fresh_scalars(Tbl &t, const Rng &g, uint64_t env_id, uint32_t board_ctr,
-                                              uint32_t lut_len, uint32_t keep_bits) {
+// (LUT row, fresh scalar bits) of board number `board_ctr` of env `env_id`
+__device__ __forceinline__ void board_params(const Rng &g, uint64_t env_id, uint32_t board_ctr, uint32_t lut_len,
+                                             uint32_t &idx, uint32_t &sc_bits) {
   uint32_t r[4];
   philox4x32_10((uint32_t)env_id, board_ctr, STREAM_RESET, (uint32_t)(env_id >> 32), g.k0, g.k1, r);
-  uint32_t idx = __umulhi(r[0], lut_len);
+  idx = __umulhi(r[0], lut_len);
   uint32_t dealer = r[1] & 3u, vns = (r[1] >> 2) & 1u, vew = (r[1] >> 3) & 1u, arr = (r[1] >> 4) & 7u;
   uint32_t a0 = arr & 1u, b0 = 2u + ((arr >> 1) & 1u), a1 = 1u - a0, b1 = 5u - b0;
   uint32_t shuf_a = a0 | (b0 << 2) | (a1 << 4) | (b1 << 6);  // NS = team {0,1}
   uint32_t shuf_b = b0 | (a0 << 2) | (b1 << 4) | (a1 << 6);  // NS = team {2,3}
   uint32_t shuf = (arr & 4u) ? shuf_a : shuf_b;
-  t.sc = dealer | (vns << SC_VULNS) | (vew << SC_VULEW) | (shuf << SC_SHUF) | keep_bits;
+  sc_bits = dealer | (vns << SC_VULNS) | (vew << SC_VULEW) | (shuf << SC_SHUF);
+}
+
+__device__ __forceinline__ void apply_fresh(Tbl &t, uint32_t idx, uint32_t sc_bits, uint32_t board_ctr,
+                                            uint32_t keep_bits) {
+  t.sc = sc_bits | keep_bits;
   t.sch = 0;
   t.fd = 0;
   t.lut = idx;
   t.bctr = board_ctr;
+}
+
+__device__ __forceinline__ void fresh_scalars(Tbl &t, const Rng &g, uint64_t env_id, uint32_t board_ctr,
+                                              uint32_t lut_len, uint32_t keep_bits) {
+  uint32_t idx, sc_bits;
+  board_params(g, env_id, board_ctr, lut_len, idx, sc_bits);
+  apply_fresh(t, idx, sc_bits, board_ctr, keep_bits);
 }
 
 __device__ __forceinline__ void pack_tricks(Tbl &t, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
@@ -318,6 +337,98 @@ __device__ __forceinline__ void emit_obs_row(const uint8_t *img, int seat, uint3
   if (c.lane < 60) *reinterpret_cast<uint2 *>(dst_row + c.lane * 8) = make_uint2(lo, hi);
 }
 
+// ---- 4 rows per wave-instruction ------------------------------------------------------------
+// 15 lanes per row, each lane turns ONE dword of the packed image (8 nibbles = 32 observation
+// bits) into 32 output bytes (2 x 16-B stores): a wave writes the 4 x 480-B rows of 4 consecutive
+// tables with two store instructions, and the nibble rotation costs the same for 8 nibbles as for 2.
+struct GroupLane {
+  int r;               // row (table) within the group of 4; 4 = idle lane (lanes 60..63)
+  int ch;              // 32-bit chunk of the packed row, 0..14
+  uint32_t keep_hist;  // chunk 0..12: all history; 13: packed bytes 52, 53(low nibble); 14: none
+  uint32_t keep_hand;
+  uint32_t keep_vul;   // chunk 0 carries the vulnerability nibble
+  int hist_off;        // byte offset of this lane's history dword within the group's 4 images
+  int hand_off;        // byte offset of the row's hand words
+  uint32_t out_off;    // byte offset of this lane's 32 output bytes within the group's 4 rows
+};
+
+__device__ __forceinline__ GroupLane make_group_lane() {
+  GroupLane g;
+  int lane = (int)(threadIdx.x & 63u);
+  g.r = lane / 15;
+  g.ch = lane - g.r * 15;
+  g.keep_hist = (g.ch < 13) ? 0xFFFFFFFFu : ((g.ch == 13) ? 0x00000FFFu : 0u);
+  g.keep_hand = (g.ch < 13) ? 0u : 0xFFFFFFFFu;
+  g.keep_vul = (g.ch == 0) ? 0xFu : 0u;
+  int rr = (g.r < 4) ? g.r : 0;
+  g.hist_off = rr * TABLE_BYTES + 4 * ((g.ch < 13) ? g.ch : 13);
+  g.hand_off = rr * TABLE_BYTES + W_HAND * 8;
+  g.out_off = (uint32_t)(rr * 480 + g.ch * 32);
+  return g;
+}
+
+// The 4 x 38 mask bytes of a group are 152 contiguous bytes = 38 dwords: lane l < 38 writes dword
+// l, whose 4 bytes belong to row qa (the first `split` of them) and row qa+1 (the rest).
+struct MaskLane {
+  int qa, qb;       // rows of the group this lane's bytes come from
+  int sh;           // first action index within row qa
+  int split;        // how many of the 4 bytes belong to row qa (1..4)
+  uint32_t keep_a;  // nibble mask of the row-qa bytes
+  bool active;      // lane < 38
+};
+
+__device__ __forceinline__ MaskLane make_mask_lane() {
+  MaskLane m;
+  int lane = (int)(threadIdx.x & 63u);
+  int b0 = 4 * lane;
+  m.active = lane < 38;
+  m.qa = m.active ? b0 / 38 : 0;
+  m.sh = m.active ? b0 - m.qa * 38 : 0;
+  m.split = (38 - m.sh < 4) ? 38 - m.sh : 4;
+  m.qb = (m.qa + 1 < 4) ? m.qa + 1 : 3;
+  m.keep_a = (1u << m.split) - 1u;
+  return m;
+}
+
+// legal_a / legal_b: the 64-bit legal masks of rows qa / qb (bits above 37 are ignored)
+__device__ __forceinline__ uint32_t mask_dword(uint64_t legal_a, uint64_t legal_b, const MaskLane &m) {
+  uint32_t sa = (uint32_t)(legal_a >> m.sh);
+  uint32_t sb = (uint32_t)legal_b << m.split;
+  uint32_t nib = (sa & m.keep_a) | (sb & (0xFu & ~m.keep_a));
+  return __umul24(nib, 0x204081u) & 0x01010101u;
+}
+
+// this lane's 32 observation bytes of its row (seat / vulnib: the row's observer, per lane).
+// Split into an LDS-load half and a compute+store half so that the loads of several groups can
+// be in flight together (the emit path is LDS-latency bound, not issue bound).
+__device__ __forceinline__ void obs_chunk_load(const uint8_t *img_group, int seat, const GroupLane &g, uint32_t &a,
+                                               uint64_t &H) {
+  a = *reinterpret_cast<const uint32_t *>(img_group + g.hist_off);
+  H = *reinterpret_cast<const uint64_t *>(img_group + g.hand_off + seat * 8);
+}
+
+__device__ __forceinline__ void obs_chunk_store(uint32_t a, uint64_t H, int seat, uint32_t vulnib, uint8_t *dst_group,
+                                                const GroupLane &g) {
+  uint32_t m1 = (0xFu >> seat) * 0x11111111u;
+  uint32_t rot = ((a >> seat) & m1) | ((a << (4 - seat)) & ~m1);
+  uint32_t hv = (g.ch == 13) ? (uint32_t)(H << 8) : (uint32_t)(H >> 24);
+  uint32_t word = (rot & g.keep_hist) | (hv & g.keep_hand) | (vulnib & g.keep_vul);
+  uint32_t d[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) d[i] = __umul24((word >> (4 * i)) & 0xFu, 0x204081u) & 0x01010101u;
+  uint4 *dst = reinterpret_cast<uint4 *>(dst_group + g.out_off);
+  dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
+  dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
+}
+
+__device__ __forceinline__ void emit_obs_chunk(const uint8_t *img_group, int seat, uint32_t vulnib, uint8_t *dst_group,
+                                               const GroupLane &g) {
+  uint32_t a;
+  uint64_t H;
+  obs_chunk_load(img_group, seat, g, a, H);
+  obs_chunk_store(a, H, seat, vulnib, dst_group, g);
+}
+
 __device__ __forceinline__ void emit_mask_row(uint64_t legal, uint8_t *dst_row, const LaneConst &c) {
   if (c.lane < 38) dst_row[c.lane] = (uint8_t)((legal >> c.lane) & 1ull);
 }
@@ -337,6 +448,13 @@ __device__ __forceinline__ void deal_image(uint8_t *img, uint32_t q0, uint32_t q
   uint64_t hv = (c.lane == 7) ? h0 : ((c.lane == 8) ? h1 : ((c.lane == 9) ? h2 : h3));
   if (c.lane < 7) img64[c.lane] = 0ull;
   else if (c.lane < 11) img64[c.lane] = hv << 4;
+}
+
+// LDS operations of ONE wave are performed in issue order, so a lane may read what another lane
+// of the same wave wrote earlier without waiting; only the compiler must keep the order.
+__device__ __forceinline__ void wave_lds_order() {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
 }
 
 __device__ __forceinline__ void wave_lds_fence() {

@@ -1,0 +1,41 @@
+"""Timing build (-DBRL_TIMING): per-wave total vs barrier-wait cycles of k_rollout_ws."""
+import os, sys, subprocess, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+so = "/tmp/libbrl_timing.so"
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+                       "-DBRL_TIMING", "-o", so, os.path.join(ROOT, "brl_amd/csrc/brl_kernels.hip")], stderr=subprocess.DEVNULL)
+from brl_amd import _capi
+_capi.LIB_PATH = so
+import numpy as np, torch, ctypes as C
+import brl_amd
+from brl_amd.roll_out import alloc_transition
+from brl_amd.bridge_bidding import _stream
+from bench import synthetic_lut
+N, T = 8192, 32
+keys, values = synthetic_lut(100000, 0)
+for cfg in os.environ.get("CFGS", "32x16").split(","):
+    tpb, nw = map(int, cfg.split("x"))
+    os.environ["BRL_ROLLOUT_WS"] = cfg
+    os.environ["BRL_DEBUG"] = os.environ.get("DBG", "0")
+    env = brl_amd.BridgeBidding(lut=(keys, values))
+    traj = alloc_transition(T, N, env.device)
+    st = env.init(0, num_envs=N)
+    p = _capi.TransitionPtrs()
+    for f in _capi.TransitionPtrs._names:
+        setattr(p, f, _capi.ptr(getattr(traj, f)))
+    nblk = (N + tpb - 1) // tpb
+    dump = torch.zeros(nblk * nw * 2, dtype=torch.int64, device=env.device)
+    for i in range(5):
+        _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, i * T, 7600.0, C.byref(p), _capi.ptr(dump), _stream()))
+    torch.cuda.synchronize()
+    d = dump.cpu().numpy().reshape(nblk, nw, 2)
+    tot, wait = d[..., 0].mean(0), d[..., 1].mean(0)
+    print(cfg, "cycles(100MHz ticks?) per wave role: total / barrier-wait / work")
+    if int(os.environ.get("DBG", "0")) & 64:
+        seg01 = d[..., 0].mean(0); seg2 = (d[..., 1] & 0xFFFFFFFF).mean(0); seg3 = (d[..., 1] >> 32).mean(0)
+        for w in range(3, nw):
+            print(f"  emit wave {w:2d}: apply+fence {seg01[w]:9.0f}  obs {seg2[w]:9.0f}  mask {seg3[w]:9.0f}")
+        continue
+    for w in range(nw):
+        print(f"  wave {w:2d}: total {tot[w]:9.0f} wait {wait[w]:9.0f} work {tot[w]-wait[w]:9.0f}")

@@ -19,17 +19,25 @@ def env(dds):
     return brl_amd.BridgeBidding(lut=(dds["keys"], dds["values"]))
 
 
-def make_env(dds, k):
+def make_env(dds, k, ws=None):
+    """k: tables per wave of the per-step kernels; ws: "TPBxNW" of the wave-specialised fused
+    rollout, "0" for the K-tables-per-wave fused rollout, None for the library default."""
     import brl_amd
-    old = os.environ.get("BRL_TABLES_PER_WAVE")
-    os.environ["BRL_TABLES_PER_WAVE"] = str(k)
+    new = {"BRL_TABLES_PER_WAVE": str(k), "BRL_ROLLOUT_WS": ws}
+    old = {key: os.environ.get(key) for key in new}
+    for key, v in new.items():
+        if v is None:
+            os.environ.pop(key, None)
+        else:
+            os.environ[key] = v
     try:
         return brl_amd.BridgeBidding(lut=(dds["keys"], dds["values"]))
     finally:
-        if old is None:
-            del os.environ["BRL_TABLES_PER_WAVE"]
-        else:
-            os.environ["BRL_TABLES_PER_WAVE"] = old
+        for key, v in old.items():
+            if v is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = v
 
 
 def test_extension_is_the_in_tree_hip_library():
@@ -135,11 +143,16 @@ def test_observe_any_player(env, oracle):
     assert np.array_equal(pos, np.array([list(ref["shuffled_players"][i]).index(pid[i]) for i in range(n)]))
 
 
-@pytest.mark.parametrize("k,substeps,n,T", [(1, 1, 256, 32), (2, 1, 515, 16), (4, 1, 2048, 32), (8, 1, 1000, 40),
-                                            (4, 4, 1024, 32), (8, 4, 333, 12), (1, 4, 64, 8)])
-def test_fused_random_rollout_matches_oracle(dds, oracle, k, substeps, n, T):
+@pytest.mark.parametrize("k,ws,substeps,n,T", [
+    (1, "0", 1, 256, 32), (2, "0", 1, 515, 16), (4, "0", 1, 2048, 32), (8, "0", 1, 1000, 40),
+    (4, "0", 4, 1024, 32), (8, "0", 4, 333, 12), (1, "0", 4, 64, 8),
+    (4, None, 1, 2048, 32), (4, None, 4, 1000, 16), (4, "32x8", 1, 1, 5), (4, "32x8", 1, 33, 32),
+    (4, "16x5", 1, 1000, 32), (4, "16x7", 4, 515, 12), (4, "32x11", 1, 4099, 32), (4, "64x11", 1, 2048, 32),
+    (4, "64x7", 4, 777, 9), (4, "32x5", 1, 300, 64), (4, "32x7", 1, 129, 7), (4, "32x7", 4, 2048, 40),
+    (4, "32x7", 1, 2, 3), (4, "32x7", 1, 30, 33)])
+def test_fused_random_rollout_matches_oracle(dds, oracle, k, ws, substeps, n, T):
     import brl_amd
-    env = make_env(dds, k)
+    env = make_env(dds, k, ws)
     cfg = {"num_steps": T, "game_mode": "competitive" if substeps == 4 else "normal", "reward_scale": 7600}
     roll = brl_amd.make_random_roll_out(cfg, env)
     st = env.init(2024, num_envs=n)
@@ -153,7 +166,7 @@ def test_fused_random_rollout_matches_oracle(dds, oracle, k, substeps, n, T):
         torch.cuda.synchronize()
         for name in ("obs", "legal_action_mask", "action", "done", "value", "reward", "log_prob"):
             g, o = to_np(getattr(traj, name)), want[name]
-            assert g.shape == o.shape and np.array_equal(g, o), f"K={k} sub={substeps} call {call}: {name}"
+            assert g.shape == o.shape and np.array_equal(g, o), f"K={k} ws={ws} sub={substeps} call {call}: {name}"
         assert_state_equal(rs[2], ref, where=f"rollout final state K={k} sub={substeps} call {call}")
         assert np.array_equal(to_np(rs[3]), ref["observation"])
         assert rs[5] == draw
