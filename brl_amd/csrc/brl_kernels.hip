@@ -351,9 +351,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_rollout_random(RolloutArgs A)
 // passes), which is what makes the 2-deep ring and its 1-sub-step refill latency safe.
 constexpr int CMD_WORDS = 4;
 constexpr int RING_WORDS = 12;  // keys[4] values[4] idx sc_bits pad pad
-// cmd[s] word 0: about sub-step s-1: [8:0] history bit + 1 (0 none) | [9] deal | [18] ring slot dealt
-//                | [19] first sub-step of its macro-step | [20] last | [22:21] acting seat | [28:23] n_legal
-//                about state s: [11:10] observer seat | [15:12] vul nibble | [16] emit row s/substeps
+constexpr int WS_BATCH = 8;     // sub-steps per workgroup barrier
+constexpr int WS_RING = 12;     // boards kept ahead per table (see the loader wave)
+// cmd[s] word 0: about sub-step s-1: [8:0] history bit + 1 (0 none) | [9] deal | [19:16] ring slot dealt
+//                | [22:21] acting seat | [28:23] n_legal
+//                about state s: [11:10] observer seat | [15:12] vul nibble
 // word 1: scalar word `sc` right after sub-step s-1 (before any re-deal)
 // word 2: legal mask of state s, low 32 | word 3: [5:0] legal high ; [13:8] action of sub-step s-1
 
@@ -374,27 +376,44 @@ __device__ __forceinline__ void lds_barrier() {
 #define LDS_BARRIER() lds_barrier()
 #endif
 
+// The T-step scan is latency-bound on ONE dependency chain per table (state(t+1) needs
+// state(t)), so the kernel keeps that chain as short as possible and moves everything that does
+// not feed it onto other waves of the same workgroup.  One workgroup owns TPB consecutive tables:
+//   wave 0        LOGIC  : lane l advances table l in registers — legal mask, action draw,
+//                          auction transition, re-deal bookkeeping.  Nothing else: no reward, no
+//                          first-denomination table, no HBM access in the loop.
+//   wave 1        LOADER : keeps, per table, an LDS ring of the next WS_RING boards of that slot
+//                          (Philox -> LUT row -> 32-B global load).  The only wave that waits on
+//                          loads, so nobody else's vmcnt ever includes them.
+//   wave 2        SCORER : lane l follows table l behind the logic wave: first denominations,
+//                          contract score + DDS tricks -> reward (A4), sums over sub-steps (G1), and
+//                          writes the scalar Transition columns, coalesced over tables.
+//   waves 3..NW-1 EMIT   : each owns a fixed subset of the tables' LDS images, applies the logic
+//                          wave's per-sub-step command (set one history bit, or deal a new board
+//                          from the ring) and streams 4 x 480-B observation rows + 4 x 38-B mask
+//                          rows per store instruction.  Stores only: they never wait on memory.
+// The logic wave posts one 16-byte command per table per sub-step into a double-buffered LDS
+// batch of WS_BATCH sub-steps; ONE s_barrier per batch (preceded by lgkmcnt(0) only — global
+// loads/stores stay in flight across it).  The other waves work one batch behind, each at its own
+// pace, so a slow sub-step on one wave (a deal, a contract to score) is averaged over the batch
+// instead of stalling everybody.
+// Ring safety: a table deals at most once every 4 sub-steps (the shortest auction is four
+// passes), i.e. <= 3 boards per batch.  Boards dealt in batch b are still read by the scorer and
+// emit waves during batch b+1, so the loader refills their slots during batch b+2 (finished before
+// that batch's barrier); the logic wave, then at most in batch b+3, has consumed <= 9 boards since
+// the start of batch b+1 < WS_RING.
 template <int TPB, int NW>
 __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   static_assert(TPB <= 64 && NW >= 4, "logic + loader + scorer + >=1 emit wave");
-#ifdef BRL_TIMING
-  unsigned long long t_wait = 0, t_begin = __builtin_amdgcn_s_memtime();
-  unsigned long long t_seg[4] = {0, 0, 0, 0};
-#define STAMP(i)                                                                     \
-  do {                                                                               \
-    unsigned long long _n;                                                           \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_n)::"memory");       \
-    t_seg[i] += _n - t_last;                                                         \
-    t_last = _n;                                                                     \
-  } while (0)
-#else
-#define STAMP(i)
-#endif
   static_assert(TPB % 4 == 0, "emit waves write 4 consecutive tables per instruction");
   constexpr int NE = NW - 3;
+  constexpr int B = WS_BATCH;
+#ifdef BRL_TIMING
+  unsigned long long t_wait = 0, t_begin = __builtin_amdgcn_s_memtime();
+#endif
   __shared__ __attribute__((aligned(16))) uint8_t img[TPB * TABLE_BYTES];
-  __shared__ __attribute__((aligned(16))) uint32_t cmd[2][TPB][CMD_WORDS];
-  __shared__ __attribute__((aligned(16))) uint32_t ring[TPB][2][RING_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t cmd[2][B][TPB][CMD_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t ring[TPB][WS_RING][RING_WORDS];
   __shared__ float s_neglog[BRL_NUM_ACTIONS + 2];
   const int tid = (int)threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -407,101 +426,110 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   }
   if (tid <= BRL_NUM_ACTIONS) s_neglog[tid] = A.neg_log_n[tid];
   __syncthreads();
-  const int total = A.T * A.substeps;
-  const int tl = c.lane;  // logic / loader / scorer: lane = table
+  const int total = A.T * A.substeps;          // sub-steps; command slots are s = 0..total
+  const int nbatch = (total + 1 + B - 1) / B;  // batches of command slots; slot s is entry s % B of batch s / B
+  const int tl = c.lane;                       // logic / loader / scorer: lane = table
   const int tls = (tl < TPB) ? tl : 0;
   const bool valid = (tl < TPB) && (table0 + tl < A.n);
   const uint64_t env_id = A.env_offset + (uint64_t)(table0 + tl);
 
   if (wave == 1) {
     // ------------------------------------------------------------------ loader wave
-    uint32_t nb = 0;  // next board number of this slot to prefetch
-    if (valid) {
-      uint32_t bctr = (uint32_t)(img64[tl * 16 + W_CTR] >> 32);
+    uint32_t nb = 0;  // next board number of this slot to fetch
+    auto fetch = [&](uint32_t count) {  // fetch boards nb .. nb+count-1 into their ring slots
+      uint32_t idx[3], scb[3];
+      int4 kk[3], vv[3];
 #pragma unroll
-      for (int k = 1; k <= 2; k++) {
-        uint32_t b = bctr + (uint32_t)k, idx, scb;
-        board_params(A.g, env_id, b, A.lut.len, idx, scb);
-        int4 kk = A.lut.keys[idx], vv = A.lut.values[idx];
-        uint4 *dst = reinterpret_cast<uint4 *>(&ring[tl][b & 1u][0]);
-        dst[0] = make_uint4((uint32_t)kk.x, (uint32_t)kk.y, (uint32_t)kk.z, (uint32_t)kk.w);
-        dst[1] = make_uint4((uint32_t)vv.x, (uint32_t)vv.y, (uint32_t)vv.z, (uint32_t)vv.w);
-        dst[2] = make_uint4(idx, scb, 0u, 0u);
+      for (int k = 0; k < 3; k++) {
+        if ((uint32_t)k < count) {
+          board_params(A.g, env_id, nb + (uint32_t)k, A.lut.len, idx[k], scb[k]);
+          kk[k] = A.lut.keys[idx[k]];
+          vv[k] = A.lut.values[idx[k]];
+        }
       }
-      nb = bctr + 3u;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        if ((uint32_t)k < count) {
+          uint4 *dst = reinterpret_cast<uint4 *>(&ring[tls][(nb + (uint32_t)k) % WS_RING][0]);
+          dst[0] = make_uint4((uint32_t)kk[k].x, (uint32_t)kk[k].y, (uint32_t)kk[k].z, (uint32_t)kk[k].w);
+          dst[1] = make_uint4((uint32_t)vv[k].x, (uint32_t)vv[k].y, (uint32_t)vv[k].z, (uint32_t)vv[k].w);
+          dst[2] = make_uint4(idx[k], scb[k], 0u, 0u);
+        }
+      }
+      nb += count;
+    };
+    if (valid) {
+      nb = (uint32_t)(img64[tl * 16 + W_CTR] >> 32) + 1u;
+      fetch(2);  // the first two boards before anybody starts (a third is needed at sub-step 8 at the earliest)
     }
-    __syncthreads();  // ring ready
-    bool pending = false;
-    uint32_t pidx = 0, pscb = 0, pslot = 0;
-    int4 pk = make_int4(0, 0, 0, 0), pv = make_int4(0, 0, 0, 0);
-    for (int s = 0; s <= total; s++) {
+    __syncthreads();  // ring[.. +2] ready
+    if (valid)
+      for (int k = 0; k < (WS_RING - 2 + 2) / 3; k++) fetch(min(3u, (uint32_t)(WS_RING - 2 - 3 * k)));  // rest of the ring, in the background
+    uint32_t dealt_prev = 0;
+    for (int bi = 0; bi < nbatch; bi++) {
       LDS_BARRIER();
-      if (pending) {  // loads issued one sub-step ago have landed by now
-        uint4 *dst = reinterpret_cast<uint4 *>(&ring[tl][pslot][0]);
-        dst[0] = make_uint4((uint32_t)pk.x, (uint32_t)pk.y, (uint32_t)pk.z, (uint32_t)pk.w);
-        dst[1] = make_uint4((uint32_t)pv.x, (uint32_t)pv.y, (uint32_t)pv.z, (uint32_t)pv.w);
-        dst[2] = make_uint4(pidx, pscb, 0u, 0u);
-        pending = false;
+      uint32_t dealt = 0;  // boards this table consumed in batch bi
+      for (int j = 0; j < B; j++) {
+        const int s = bi * B + j;
+        if (s <= total) dealt += (cmd[bi & 1][j][tls][0] >> 9) & 1u;
       }
-      if (valid && s < total && (cmd[s & 1][tl][0] & 0x200u)) {  // board nb-2 was just dealt: refill its slot
-        board_params(A.g, env_id, nb, A.lut.len, pidx, pscb);
-        pk = A.lut.keys[pidx];
-        pv = A.lut.values[pidx];
-        pslot = nb & 1u;
-        pending = true;
-        nb += 1u;
-      }
+      if (valid && dealt_prev) fetch(dealt_prev);  // slots of batch bi-1's boards are free now
+      dealt_prev = dealt;
     }
   } else if (wave == 0) {
     // ------------------------------------------------------------------ logic wave
     Tbl t;
     load_scalars(t, img + tls * TABLE_BYTES);  // only sc / sch / lut / bctr are live here
     __syncthreads();                           // ring ready
-    if (!(A.debug & 8)) __builtin_amdgcn_s_setprio(3);  // the critical chain wins issue arbitration on its SIMD
+    __builtin_amdgcn_s_setprio(3);             // the critical chain wins issue arbitration on its SIMD
     uint32_t rb[4] = {0, 0, 0, 0};
     uint32_t rb_idx = 0xFFFFFFFFu;
     uint32_t pend = 0, pend_act = 0, pend_sc = 0, term_any = 0;
-    for (int s = 0; s <= total; s++) {
-      const bool first = (s % A.substeps) == 0;
-      const bool emit = (s < total) && first;
-      const uint64_t legal = legal_mask(t);
-      const int oseat = cur_seat(t);
-      if (tl < TPB) {
-        uint32_t w0 = pend | ((uint32_t)oseat << 10) | (vul_nibble(t, oseat) << 12) | ((uint32_t)emit << 16);
-        uint32_t w3 = ((uint32_t)(legal >> 32) & 63u) | (pend_act << 8);
-        *reinterpret_cast<uint4 *>(&cmd[s & 1][tl][0]) = make_uint4(w0, pend_sc, (uint32_t)legal, w3);
+    int sub = 0;
+    for (int bi = 0; bi < nbatch; bi++) {
+      for (int j = 0; j < B; j++) {
+        const int s = bi * B + j;
+        if (s > total) break;
+        const uint64_t legal = legal_mask(t);
+        const int oseat = cur_seat(t);
+        if (tl < TPB) {
+          uint32_t w0 = pend | ((uint32_t)oseat << 10) | (vul_nibble(t, oseat) << 12);
+          uint32_t w3 = ((uint32_t)(legal >> 32) & 63u) | (pend_act << 8);
+          *reinterpret_cast<uint4 *>(&cmd[bi & 1][j][tl][0]) = make_uint4(w0, pend_sc, (uint32_t)legal, w3);
+        }
+        if (s == total) continue;
+        const bool first = sub == 0;
+        const bool last = sub + 1 == A.substeps;
+        sub = last ? 0 : sub + 1;
+        if (first) term_any = 0;
+        uint32_t draw = A.draw_base + (uint32_t)s;
+        if ((draw >> 2) != rb_idx) {
+          rb_idx = draw >> 2;
+          philox4x32_10((uint32_t)env_id, rb_idx, STREAM_ACTION, (uint32_t)(env_id >> 32), A.g.k0, A.g.k1, rb);
+        }
+        uint32_t sel = draw & 3u;
+        uint32_t u = (sel == 0) ? rb[0] : ((sel == 1) ? rb[1] : ((sel == 2) ? rb[2] : rb[3]));
+        int nl;
+        int a = random_legal_action(t, legal, u, nl);
+        if (bits(t.sc, SC_TERM, 1)) {  // A5 pre-step half of auto_reset (src/utils.py:34-43)
+          t.sc &= ~(1u << SC_TERM);
+          t.sch &= ~(1023u << SCH_STEP);
+        }
+        int hb = auction_step(t, a, oseat);  // a is legal by construction: no illegal-action path here
+        uint32_t term = bits(t.sc, SC_TERM, 1);
+        term_any |= term;
+        pend_sc = t.sc;
+        pend_act = (uint32_t)a;
+        bool deal = valid && term;
+        uint32_t slot = (t.bctr + 1u) % WS_RING;
+        pend = (uint32_t)(hb + 1) | ((uint32_t)deal << 9) | (slot << 16) | ((uint32_t)oseat << 21) | ((uint32_t)nl << 23);
+        if (deal) {  // A5 post-step half of auto_reset (src/utils.py:45-55): next board from the ring
+          uint2 ib = *reinterpret_cast<const uint2 *>(&ring[tl][slot][8]);
+          apply_fresh(t, ib.x, ib.y, t.bctr + 1u, t.sc & ((1u << SC_TERM) | (1u << SC_ILLEGAL)));
+        }
+        if (last && A.substeps > 1) t.sc = (t.sc & ~(1u << SC_TERM)) | (term_any << SC_TERM);  // src/utils.py:127
       }
       LDS_BARRIER();
-      if (s == total) break;
-      const bool last = ((s + 1) % A.substeps) == 0;
-      if (first) term_any = 0;
-      uint32_t draw = A.draw_base + (uint32_t)s;
-      if ((draw >> 2) != rb_idx) {
-        rb_idx = draw >> 2;
-        philox4x32_10((uint32_t)env_id, rb_idx, STREAM_ACTION, (uint32_t)(env_id >> 32), A.g.k0, A.g.k1, rb);
-      }
-      uint32_t sel = draw & 3u;
-      uint32_t u = (sel == 0) ? rb[0] : ((sel == 1) ? rb[1] : ((sel == 2) ? rb[2] : rb[3]));
-      int nl;
-      int a = random_legal_action(t, legal, u, nl);
-      if (bits(t.sc, SC_TERM, 1)) {  // A5 pre-step half of auto_reset (src/utils.py:34-43)
-        t.sc &= ~(1u << SC_TERM);
-        t.sch &= ~(1023u << SCH_STEP);
-      }
-      int hb = auction_step(t, a, oseat);  // a is legal by construction: no illegal-action path here
-      uint32_t term = bits(t.sc, SC_TERM, 1);
-      term_any |= term;
-      pend_sc = t.sc;
-      pend_act = (uint32_t)a;
-      bool deal = valid && term;
-      uint32_t slot = (t.bctr + 1u) & 1u;
-      pend = (uint32_t)(hb + 1) | ((uint32_t)deal << 9) | (slot << 18) | ((uint32_t)first << 19) |
-             ((uint32_t)last << 20) | ((uint32_t)oseat << 21) | ((uint32_t)nl << 23);
-      if (deal) {  // A5 post-step half of auto_reset (src/utils.py:45-55): next board from the ring
-        uint2 ib = *reinterpret_cast<const uint2 *>(&ring[tl][slot][8]);
-        apply_fresh(t, ib.x, ib.y, t.bctr + 1u, t.sc & ((1u << SC_TERM) | (1u << SC_ILLEGAL)));
-      }
-      if (last && A.substeps > 1) t.sc = (t.sc & ~(1u << SC_TERM)) | (term_any << SC_TERM);  // src/utils.py:127
     }
     if (tl < TPB) {
       uint2 *p = reinterpret_cast<uint2 *>(img + tl * TABLE_BYTES);
@@ -510,59 +538,103 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
     }
   } else if (wave == 2) {
     // ------------------------------------------------------------------ scorer wave
+    // Three passes per batch, so that the expensive contract scoring runs once per finished
+    // board (<= 2 per table and batch) instead of once per sub-step in which ANY table finishes:
+    //   1. per sub-step, cheap: first denominations, new tricks on a re-deal, queue finished boards
+    //   2. per queued board: contract -> DDS tricks -> score -> reward vector (A4), summed per macro-step
+    //   3. per macro-step: the scalar Transition columns, coalesced over tables
+    __shared__ __attribute__((aligned(16))) uint32_t ev[3][64][8];   // finished boards of this batch
+    __shared__ __attribute__((aligned(16))) int acc[WS_BATCH][64][4];  // reward sums by player id per macro-step
+    __shared__ uint32_t minfo[WS_BATCH][64];                          // per macro-step: actor, action, n_legal, done
     Tbl ts;
     load_scalars(ts, img + tls * TABLE_BYTES);  // fd / tricks / rewards are live here
     __syncthreads();                            // ring ready
-    int racc0 = 0, racc1 = 0, racc2 = 0, racc3 = 0, actor = 0;
-    uint32_t first_action = 0, first_n = 1, term_any = 0, tcount = 0;
-    for (int s = 0; s <= total; s++) {
+    int sub = 0;
+    uint32_t cur_info = 0, tcount = 0;
+    int64_t row = table0 + tl;  // this table's Transition row of the next macro-step to be written
+    int4 last_acc = make_int4(reward_of(ts, 0), reward_of(ts, 1), reward_of(ts, 2), reward_of(ts, 3));
+    *reinterpret_cast<int4 *>(&acc[0][tl][0]) = make_int4(0, 0, 0, 0);
+    for (int bi = 0; bi < nbatch; bi++) {
       LDS_BARRIER();
-      if (s == 0) continue;  // cmd[0] describes no sub-step
-      const uint4 w = *reinterpret_cast<const uint4 *>(&cmd[s & 1][tls][0]);
-      const int a = (int)((w.w >> 8) & 63u);
-      const int seat = (int)((w.x >> 21) & 3u);
-      ts.sc = w.y;
-      if (w.x & (1u << 19)) {  // first sub-step of a macro-step: the acting player (src/roll_out.py:72)
-        actor = player_at(ts, seat);
-        racc0 = racc1 = racc2 = racc3 = 0;
-        term_any = 0;
-        first_action = (uint32_t)a;
-        first_n = (w.x >> 23) & 63u;
-      }
-      note_first_denomination(ts.fd, seat, a);
-      const uint32_t term = bits(ts.sc, SC_TERM, 1);
-      if (term) {
-        terminal_reward(ts);  // A4
-      } else {
-        ts.r01 = 0;
-        ts.r23 = 0;
-      }
-      racc0 += reward_of(ts, 0); racc1 += reward_of(ts, 1); racc2 += reward_of(ts, 2); racc3 += reward_of(ts, 3);
-      term_any |= term;
-      if (w.x & 0x200u) {  // the slot was re-dealt: tricks of the new board, no strain named yet
-        const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tls][(w.x >> 18) & 1u][4]);
-        pack_tricks(ts, vv.x, vv.y, vv.z, vv.w);
-        ts.fd = 0;
-      }
-      if (w.x & (1u << 20)) {  // macro-step complete: the scalar Transition columns, coalesced over tables
-        if (A.substeps > 1) set_rewards(ts, racc0, racc1, racc2, racc3);  // src/utils.py:126
-        if (valid) {
-          const int64_t row = (int64_t)((s - 1) / A.substeps) * A.n + table0 + tl;
-          int ra = (actor == 0) ? racc0 : ((actor == 1) ? racc1 : ((actor == 2) ? racc2 : racc3));
-          if (A.out.done) A.out.done[row] = (uint8_t)term_any;  // G2
-          if (A.out.action) A.out.action[row] = (int32_t)first_action;
-          if (A.out.value) A.out.value[row] = 0.0f;
-          if (A.out.reward) A.out.reward[row] = (float)ra / A.reward_scale;  // G1, src/roll_out.py:90
-          if (A.out.log_prob) A.out.log_prob[row] = s_neglog[first_n];
-          tcount += term_any;
+      // ---- pass 1
+      int nev = 0, m = 0;  // m: macro-steps completed so far in this batch
+      // acc[0] carries the partial sums of a macro-step that straddles the batch boundary
+#pragma unroll
+      for (int q = 1; q < B; q++) *reinterpret_cast<int4 *>(&acc[q][tl][0]) = make_int4(0, 0, 0, 0);
+      for (int j = 0; j < B; j++) {
+        const int s = bi * B + j;
+        if (s > total) break;
+        if (s == 0) continue;  // cmd slot 0 describes no sub-step
+        const uint4 w = *reinterpret_cast<const uint4 *>(&cmd[bi & 1][j][tls][0]);
+        const int a = (int)((w.w >> 8) & 63u);
+        const int seat = (int)((w.x >> 21) & 3u);
+        ts.sc = w.y;
+        if (sub == 0)  // first sub-step of a macro-step: the acting player (src/roll_out.py:72), its action
+          cur_info = (uint32_t)player_at(ts, seat) | ((uint32_t)a << 2) | (((w.x >> 23) & 63u) << 8);
+        note_first_denomination(ts.fd, seat, a);
+        if (bits(ts.sc, SC_TERM, 1)) {  // queue the finished board for pass 2
+          uint4 *e = reinterpret_cast<uint4 *>(&ev[nev][tl][0]);
+          e[0] = make_uint4(ts.sc, ts.fd, ts.t0, ts.t1);
+          e[1] = make_uint4(ts.t2, (uint32_t)m, 0u, 0u);
+          nev++;
+          cur_info |= 1u << 14;  // done (G2)
+        }
+        if (w.x & 0x200u) {  // the slot was re-dealt: tricks of the new board, no strain named yet
+          const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tls][(w.x >> 16) & 15u][4]);
+          pack_tricks(ts, vv.x, vv.y, vv.z, vv.w);
+          ts.fd = 0;
+        }
+        if (++sub == A.substeps) {
+          sub = 0;
+          minfo[m][tl] = cur_info;
+          m++;
         }
       }
+      // ---- pass 2
+      for (int e = 0; e < 3; e++) {
+        if (!__any(e < nev)) break;
+        if (e < nev) {
+          const uint4 *p = reinterpret_cast<const uint4 *>(&ev[e][tl][0]);
+          const uint4 e0 = p[0], e1 = p[1];
+          Tbl tb;
+          tb.sc = e0.x; tb.fd = e0.y; tb.t0 = e0.z; tb.t1 = e0.w; tb.t2 = e1.x;
+          terminal_reward(tb);  // A4
+          int *ac = &acc[e1.y & (WS_BATCH - 1)][tl][0];
+          ac[0] += reward_of(tb, 0); ac[1] += reward_of(tb, 1); ac[2] += reward_of(tb, 2); ac[3] += reward_of(tb, 3);
+        }
+      }
+      // ---- pass 3: the m macro-steps completed in this batch
+      for (int q = 0; q < m; q++) {
+        const uint32_t info = minfo[q][tl];
+        const int4 r = *reinterpret_cast<const int4 *>(&acc[q][tl][0]);
+        last_acc = r;
+        if (valid) {
+          const int actor = (int)(info & 3u);
+          const int ra = (actor == 0) ? r.x : ((actor == 1) ? r.y : ((actor == 2) ? r.z : r.w));
+          const uint32_t done = (info >> 14) & 1u;
+          if (A.out.done) A.out.done[row] = (uint8_t)done;  // G2
+          if (A.out.action) A.out.action[row] = (int32_t)((info >> 2) & 63u);
+          if (A.out.value) A.out.value[row] = 0.0f;
+          if (A.out.reward) A.out.reward[row] = (float)ra / A.reward_scale;  // G1, src/roll_out.py:90
+          if (A.out.log_prob) A.out.log_prob[row] = s_neglog[(info >> 8) & 63u];
+          tcount += done;
+        }
+        row += A.n;
+      }
+      {  // a macro-step still in progress (sub != 0) keeps its partial sums in acc[0]; otherwise zero
+        int4 carry = (sub != 0) ? *reinterpret_cast<const int4 *>(&acc[m & (WS_BATCH - 1)][tl][0]) : make_int4(0, 0, 0, 0);
+        if (m >= WS_BATCH) carry = make_int4(0, 0, 0, 0);
+        *reinterpret_cast<int4 *>(&acc[0][tl][0]) = carry;
+      }
     }
+    set_rewards(ts, last_acc.x, last_acc.y, last_acc.z, last_acc.w);  // rewards of the last macro-step (src/utils.py:126)
     if (A.terminated_count != nullptr) {  // src/roll_out.py:85
       uint32_t v = tcount;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+#ifndef BRL_TIMING
       if (c.lane == 0 && v) atomicAdd(A.terminated_count, (unsigned long long)v);
+#endif
     }
     if (tl < TPB) {
       uint2 *p = reinterpret_cast<uint2 *>(img + tl * TABLE_BYTES);
@@ -588,75 +660,79 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
       int64_t rem = (g < NG && !(A.debug & 1)) ? A.n - (table0 + 4 * g) : 0;
       left[k] = (int)max((int64_t)0, min((int64_t)4, rem));
     }
-    for (int s = 0; s <= total; s++) {
+    for (int bi = 0; bi < nbatch; bi++) {
       LDS_BARRIER();
-      const bool emit = (s < total) && (sub == 0) && !(A.debug & 2);  // the same for every table of a sub-step
-      const uint32_t(*cs)[CMD_WORDS] = cmd[s & 1];
-      // ---- round trip 1: each row's command
-      uint32_t w0[GPW];
+      for (int j = 0; j < B; j++) {
+        const int s = bi * B + j;
+        if (s > total) break;
+        const bool emit = (s < total) && (sub == 0) && !(A.debug & 2);  // the same for every table of a sub-step
+        const uint32_t(*cs)[CMD_WORDS] = cmd[bi & 1][j];
+        // ---- round trip 1: each row's command
+        uint32_t w0[GPW];
 #pragma unroll
-      for (int k = 0; k < GPW; k++) {
-        const int g = (wave - 3) + k * NE;
-        w0[k] = (left[k] > 0) ? cs[4 * g + rr][0] : 0u;
-      }
-      // ---- apply sub-step s-1 to the images (one history bit, or a freshly dealt board), then
-      //      round trip 2: image dwords + legal masks.  No wait in between: same-wave LDS order.
-      uint32_t a[GPW];
-      uint64_t H[GPW], la[GPW], lb[GPW];
-#pragma unroll
-      for (int k = 0; k < GPW; k++) {
-        const int g = (wave - 3) + k * NE;
-        if (left[k] <= 0) continue;
-        uint8_t *img_g = img + 4 * g * TABLE_BYTES;
-        const bool is_head = head && (gl.r < left[k]);
-        if (is_head && !(w0[k] & 0x200u) && (w0[k] & 0x1FFu)) {
-          int hb = (int)(w0[k] & 0x1FFu) - 1;
-          atomicOr(reinterpret_cast<uint32_t *>(img_g + gl.r * TABLE_BYTES) + (hb >> 5), 1u << (hb & 31));
+        for (int k = 0; k < GPW; k++) {
+          const int g = (wave - 3) + k * NE;
+          w0[k] = (left[k] > 0) ? cs[4 * g + rr][0] : 0u;
         }
-        uint64_t dealm = __ballot(is_head && (w0[k] & 0x200u));
-        if (dealm) {  // rare: ~1 table in 25 per sub-step
-          do {
-            const int l = __ffsll((unsigned long long)dealm) - 1;  // lane 15*q holds row q's command
-            dealm &= dealm - 1ull;
-            const int q = l / 15;
-            const uint32_t wq = __builtin_amdgcn_readlane(w0[k], l);
-            const uint4 kk = *reinterpret_cast<const uint4 *>(&ring[4 * g + q][(wq >> 18) & 1u][0]);
-            deal_image(img_g + q * TABLE_BYTES, kk.x, kk.y, kk.z, kk.w, c);
-          } while (dealm);
-        }
-        wave_lds_order();
-        if (emit) {
-          obs_chunk_load(img_g, (int)((w0[k] >> 10) & 3u), gl, a[k], H[k]);
-          la[k] = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
-          lb[k] = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
-        }
-      }
-      if (emit) {
+        // ---- apply sub-step s-1 to the images (one history bit, or a freshly dealt board), then
+        //      round trip 2: image dwords + legal masks.  No wait in between: same-wave LDS order.
+        uint32_t a[GPW];
+        uint64_t H[GPW], la[GPW], lb[GPW];
 #pragma unroll
         for (int k = 0; k < GPW; k++) {
           const int g = (wave - 3) + k * NE;
           if (left[k] <= 0) continue;
-          // ---- the 4 observation rows: two 16-B stores per lane
-          if (gl.r < left[k] && A.out.obs)
-            obs_chunk_store(a[k], H[k], (int)((w0[k] >> 10) & 3u), (w0[k] >> 12) & 15u,
-                            A.out.obs + (row0 + 4 * g) * BRL_OBS_SIZE, gl);
-          // ---- the 4 mask rows
-          if (A.out.legal_action_mask) {
-            uint8_t *mdst = A.out.legal_action_mask + (row0 + 4 * g) * BRL_NUM_ACTIONS;
-            if (left[k] >= 4) {  // 152 contiguous bytes, one dword per lane
-              if (ml.active) reinterpret_cast<uint32_t *>(mdst)[c.lane] = mask_dword(la[k], lb[k], ml);
-            } else {  // ragged tail of the batch: row by row
-              for (int q = 0; q < left[k]; q++) {
-                uint64_t lq = *reinterpret_cast<const uint64_t *>(&cs[4 * g + q][2]);
-                emit_mask_row(lq, mdst + q * BRL_NUM_ACTIONS, c);
+          uint8_t *img_g = img + 4 * g * TABLE_BYTES;
+          const bool is_head = head && (gl.r < left[k]);
+          if (is_head && !(w0[k] & 0x200u) && (w0[k] & 0x1FFu)) {
+            int hb = (int)(w0[k] & 0x1FFu) - 1;
+            atomicOr(reinterpret_cast<uint32_t *>(img_g + gl.r * TABLE_BYTES) + (hb >> 5), 1u << (hb & 31));
+          }
+          uint64_t dealm = __ballot(is_head && (w0[k] & 0x200u));
+          if (dealm) {  // rare: ~1 table in 25 per sub-step
+            do {
+              const int l = __ffsll((unsigned long long)dealm) - 1;  // lane 15*q holds row q's command
+              dealm &= dealm - 1ull;
+              const int q = l / 15;
+              const uint32_t wq = __builtin_amdgcn_readlane(w0[k], l);
+              const uint4 kk = *reinterpret_cast<const uint4 *>(&ring[4 * g + q][(wq >> 16) & 15u][0]);
+              deal_image(img_g + q * TABLE_BYTES, kk.x, kk.y, kk.z, kk.w, c);
+            } while (dealm);
+          }
+          wave_lds_order();
+          if (emit) {
+            obs_chunk_load(img_g, (int)((w0[k] >> 10) & 3u), gl, a[k], H[k]);
+            la[k] = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
+            lb[k] = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
+          }
+        }
+        if (emit) {
+#pragma unroll
+          for (int k = 0; k < GPW; k++) {
+            const int g = (wave - 3) + k * NE;
+            if (left[k] <= 0) continue;
+            // ---- the 4 observation rows: two 16-B stores per lane
+            if (gl.r < left[k] && A.out.obs)
+              obs_chunk_store(a[k], H[k], (int)((w0[k] >> 10) & 3u), (w0[k] >> 12) & 15u,
+                              A.out.obs + (row0 + 4 * g) * BRL_OBS_SIZE, gl);
+            // ---- the 4 mask rows
+            if (A.out.legal_action_mask) {
+              uint8_t *mdst = A.out.legal_action_mask + (row0 + 4 * g) * BRL_NUM_ACTIONS;
+              if (left[k] >= 4) {  // 152 contiguous bytes, one dword per lane
+                if (ml.active) reinterpret_cast<uint32_t *>(mdst)[c.lane] = mask_dword(la[k], lb[k], ml);
+              } else {  // ragged tail of the batch: row by row
+                for (int q = 0; q < left[k]; q++) {
+                  uint64_t lq = *reinterpret_cast<const uint64_t *>(&cs[4 * g + q][2]);
+                  emit_mask_row(lq, mdst + q * BRL_NUM_ACTIONS, c);
+                }
               }
             }
           }
         }
-      }
-      if (++sub == A.substeps) {
-        sub = 0;
-        row0 += (A.debug & 32) ? 0 : A.n;
+        if (++sub == A.substeps) {
+          sub = 0;
+          row0 += (A.debug & 32) ? 0 : A.n;
+        }
       }
     }
   }
@@ -665,10 +741,6 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
     unsigned long long *d = A.terminated_count + ((size_t)blockIdx.x * NW + wave) * 2;
     d[0] = __builtin_amdgcn_s_memtime() - t_begin;
     d[1] = t_wait;
-    if (A.debug & 64) {
-      d[0] = t_seg[0] + t_seg[1];
-      d[1] = t_seg[2] + (t_seg[3] << 32);
-    }
   }
 #endif
   __syncthreads();
@@ -1134,7 +1206,7 @@ extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int
 #define LAUNCH_WS(TPB, NW)                                                                             \
   hipLaunchKernelGGL((k_rollout_ws<TPB, NW>), dim3((unsigned)((n + TPB - 1) / TPB)), dim3(NW * 64), 0, \
                      (hipStream_t)stream, A)
-  const int cfg = h->ws_tpb * 100 + h->ws_nw;
+  const int cfg = (substeps <= WS_BATCH) ? h->ws_tpb * 100 + h->ws_nw : 0;  // a macro-step spans <= 2 command batches
   switch (cfg) {
     case 1605: LAUNCH_WS(16, 5); break;
     case 1607: LAUNCH_WS(16, 7); break;
