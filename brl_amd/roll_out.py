@@ -49,7 +49,7 @@ def make_random_roll_out(config, env: BridgeBidding):
     config 2) or the 4-sub-step competitive macro-step with every seat random ("competitive").
     ``runner_state[5]`` (the reference's PRNG key slot) is an int: the index of the next action draw."""
     T = int(config["num_steps"])
-    substeps = 4 if config.get("game_mode", "normal") == "competitive" else 1
+    substeps = int(config.get("substeps", 4 if config.get("game_mode", "normal") == "competitive" else 1))
     reward_scale = float(config.get("reward_scale", 7600))
 
     def roll_out(runner_state, out: Transition = None):

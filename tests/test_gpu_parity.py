@@ -154,7 +154,8 @@ def test_observe_any_player(env, oracle):
 def test_fused_random_rollout_matches_oracle(dds, oracle, k, ws, substeps, n, T):
     import brl_amd
     env = make_env(dds, k, ws)
-    cfg = {"num_steps": T, "game_mode": "competitive" if substeps == 4 else "normal", "reward_scale": 7600}
+    cfg = {"num_steps": T, "game_mode": "competitive" if substeps == 4 else "normal", "substeps": substeps,
+           "reward_scale": 7600}
     roll = brl_amd.make_random_roll_out(cfg, env)
     st = env.init(2024, num_envs=n)
     ref = oracle.init_random(n, seed=2024)
