@@ -1,0 +1,38 @@
+"""Multi-GPU plumbing of the hot path: tables are independent, so the path shards
+with NO data-path collective — rank r owns global tables [r*num_envs, (r+1)*num_envs) and draws
+its boards/actions from the same counter-based streams a single process would use for them.
+The only collectives are bookkeeping: max-over-ranks wall time, summed counters."""
+from __future__ import annotations
+
+import os
+
+
+def rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def shard_offset(rank: int, num_envs_per_rank: int) -> int:
+    """env_offset of rank `rank`: global index of its table 0."""
+    return rank * num_envs_per_rank
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device=None):
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

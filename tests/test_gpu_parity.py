@@ -372,3 +372,48 @@ def test_full_size_properties(dds):
     _, traj2 = roll((None, None, st2, None, 0, 0))
     for a, b in zip(traj, traj2):
         assert torch.equal(a, b)
+
+
+def test_simple_duplicate_evaluate_replays_through_oracle(env, oracle):
+    """Config 3 driver (src/evaluation.py:69-204): record the greedy actions the two MLPs chose on the
+    GPU, replay them through the oracle's duplicate_step, compare IMPs / final contracts (G8, G12)."""
+    import brl_amd
+    from brl_amd.evaluation import make_simple_duplicate_evaluate
+    from brl_amd.models import make_forward_pass
+    from oracle import Oracle
+    n = 640
+    fp = make_forward_pass("relu", "DeepMind")
+    t1, t2 = fp.init(3, device="cuda"), fp.init(4, device="cuda")
+    rec = []
+    ev = make_simple_duplicate_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", n, sync_every=8, record_actions=rec)
+    (mean, se, win), A, B = ev(t1, t2, 99)
+    torch.cuda.synchronize()
+    ref = oracle.init_random(n, seed=99)
+    oA, oB = Oracle.table_info_from(ref), Oracle.table_info_from(ref)
+    cum = np.zeros(n, np.float32)
+    for a in rec:
+        act = to_np(a)
+        live = ref["terminated"] == 0
+        assert (ref["legal_action_mask"][np.arange(n), act][live] == 1).all()  # greedy action is legal
+        oracle.duplicate_step(ref, act, oA, oB)
+        cum += ref["rewards"][:, 0]
+    assert ref["terminated"].all() and oA["terminated"].all() and oB["terminated"].all()
+    for T, oT in ((A, oA), (B, oB)):
+        for f in ("terminated", "rewards", "last_bid", "last_bidder", "call_x", "call_xx"):
+            assert np.array_equal(to_np(getattr(T, f)).astype(np.float64), oT[f].astype(np.float64)), f
+    assert abs(float(mean) - cum.mean()) < 1e-5                                  # fp32 reduction tolerance
+    assert abs(float(se) - cum.std(ddof=1) / np.sqrt(n)) < 1e-5
+    assert abs(float(win) - (cum > 0).mean()) < 1e-6
+    # same network on both sides: every board is bid identically at both tables -> 0 IMP everywhere
+    (mean0, _, win0), _, _ = make_simple_duplicate_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", 256)(t1, t1, 5)
+    assert float(mean0) == 0.0 and float(win0) == 0.0
+
+
+def test_simple_evaluate_runs_and_is_deterministic(env):
+    from brl_amd.evaluation import make_simple_evaluate
+    from brl_amd.models import make_forward_pass
+    fp = make_forward_pass("relu", "DeepMind")
+    a, o = fp.init(1, device="cuda"), fp.init(2, device="cuda")
+    ev = make_simple_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", o, 512)
+    r1, r2 = float(ev(a, 11)), float(ev(a, 11))
+    assert r1 == r2 and abs(r1) <= 7600.0
