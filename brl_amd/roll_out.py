@@ -80,6 +80,17 @@ def make_roll_out(config, env: BridgeBidding, actor_forward_pass, opp_forward_pa
     mode = config.get("game_mode", "competitive")
     if mode not in ("competitive", "free-run"):
         raise ValueError(mode)
+    # Optional reduced-precision INFERENCE for the rollout forwards (MFMA bf16/fp16 GEMMs).  Default
+    # fp32 like the reference; with bf16 the stored log_prob/value differ from the fp32 recomputation
+    # in the PPO ratio by bf16 rounding (SURVEY §7 "Hard parts") — opt-in, never the default.
+    infer_dtype = {None: None, "fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}[config.get("inference_dtype")]
+
+    def forward(fp, pr, obs_bool):
+        if infer_dtype is None:
+            return fp.apply(pr, obs_bool.to(torch.float32))
+        with torch.autocast("cuda", dtype=infer_dtype):
+            lg, v = fp.apply(pr, obs_bool.to(infer_dtype))
+        return lg.float(), v.float()
 
     def roll_out(runner_state, opp_params):
         params, opt_state, env_state, last_obs, terminated_count, rng = runner_state
@@ -99,7 +110,7 @@ def make_roll_out(config, env: BridgeBidding, actor_forward_pass, opp_forward_pa
         with torch.no_grad():
             for t in range(T):
                 actor = cur[t & 1]  # src/roll_out.py:72
-                logits, value = actor_forward_pass.apply(params, traj.obs[t].to(torch.float32))  # :73-76
+                logits, value = forward(actor_forward_pass, params, traj.obs[t])  # :73-76
                 traj.value[t].copy_(value)
                 racc.zero_()
                 tacc.zero_()
@@ -115,7 +126,7 @@ def make_roll_out(config, env: BridgeBidding, actor_forward_pass, opp_forward_pa
                         lg, m = _pass_logits(env, n), MODE
                     else:
                         fp, pr = (opp_forward_pass, opp_params) if is_opp else (actor_forward_pass, params)
-                        lg, _ = fp.apply(pr, scratch_obs.to(torch.float32))
+                        lg, _ = forward(fp, pr, scratch_obs)
                         m = SAMPLE if mode == "competitive" else MODE
                     fin = k == 3
                     policy_step(env, packed, packed, lg, m, draw + k, True,

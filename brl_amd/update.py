@@ -1,0 +1,127 @@
+"""``src/update.py`` — the PPO-clip update, in PyTorch-ROCm.
+
+Dense-GEMM training work: north_star assigns it to PyTorch (rocBLAS/hipBLASLt MFMA GEMMs + autograd),
+not to a custom kernel.  The data it consumes is the time-major ``Transition`` buffer the HIP rollout
+kernels wrote; flattening is ``reshape(T*N, ...)`` -> row ``t*N+n`` (G7, src/update.py:193-206).
+Under ``torch.distributed`` the flat fp32 gradient (3 681 319 elements = 14.7 MB for the DeepMind
+MLP) is all-reduced once per minibatch — RCCL over xGMI on MI355X (backend "nccl"), gloo in the CPU
+tests.  Each rank permutes its own shard (statistically equivalent to the reference's global
+permutation, not bit-equal — SURVEY §8e caveat) and uses ``minibatch_size`` PER RANK.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from .roll_out import Transition
+
+_NEG = torch.finfo(torch.float32).min
+
+
+def make_optimizer(config, params: torch.nn.Module):
+    """ppo.py:186-211: Adam(eps=1e-5), optional linear anneal; global-norm clipping is applied inside
+    ``update_step`` (optax.chain(clip_by_global_norm, adam))."""
+    opt = torch.optim.Adam(params.parameters(), lr=config["lr"], eps=1e-5)
+    sched = None
+    if config.get("anneal_lr", False):
+        per_update = config["num_minibatches"] * config["update_epochs"]
+        sched = torch.optim.lr_scheduler.LambdaLR(
+            opt, lambda count: 1.0 - (count // per_update) / config["num_updates"])  # ppo.py:186-192
+    return {"opt": opt, "sched": sched}
+
+
+def masked_log_softmax(logits, mask):
+    return torch.log_softmax(torch.where(mask, logits, torch.full_like(logits, _NEG)), dim=-1)
+
+
+def ppo_loss(config, logits, value, batch: Transition, gae, targets):
+    """``_loss_fn`` (src/update.py:90-167) on one minibatch; returns (total_loss, aux tuple)."""
+    mask = batch.legal_action_mask
+    if config.get("actor_illegal_action_mask", True):
+        logp_all = masked_log_softmax(logits, mask)          # src/update.py:12-16
+    else:
+        logp_all = torch.log_softmax(logits, dim=-1)
+    log_prob = logp_all.gather(1, batch.action.long()[:, None])[:, 0]
+    if config.get("value_clipping", True):                   # src/update.py:48-60
+        v_clipped = batch.value + (value - batch.value).clamp(-config["clip_eps"], config["clip_eps"])
+        value_loss = 0.5 * torch.maximum((value - targets) ** 2, (v_clipped - targets) ** 2).mean()
+    else:
+        value_loss = 0.5 * ((value - targets) ** 2).mean()
+    logratio = log_prob - batch.log_prob
+    ratio = torch.exp(logratio)
+    if config.get("reward_scaling", False):                  # src/update.py:31-44 (jnp std: ddof=0)
+        gae = (gae - gae.mean()) / (gae.std(unbiased=False) + 1e-8)
+    loss_actor = -torch.minimum(ratio * gae, ratio.clamp(1.0 - config["clip_eps"], 1.0 + config["clip_eps"]) * gae).mean()
+    mlp = masked_log_softmax(logits, mask)
+    p = mlp.exp()
+    entropy = -(torch.where(p > 0, p * mlp, torch.zeros_like(p))).sum(-1).mean()   # distrax: 0 log 0 = 0
+    coef = config.get("illegal_action_l2norm_coef", 0.0)
+    if coef:
+        illegal = torch.softmax(logits, dim=-1) * (~mask)
+        illegal_loss = torch.linalg.matrix_norm(illegal, ord=2) / 2               # jnp.linalg.norm(2-D, ord=2)
+    else:
+        illegal_loss = torch.zeros((), device=logits.device)
+    total = loss_actor + config["vf_coef"] * value_loss - config["ent_coef"] * entropy + coef * illegal_loss
+    with torch.no_grad():
+        approx_kl = ((ratio - 1) - logratio).mean()
+        clipfrac = ((ratio - 1.0).abs() > config["clip_eps"]).float().mean()
+    return total, (value_loss.detach(), loss_actor.detach(), entropy.detach(), approx_kl, clipfrac, illegal_loss.detach())
+
+
+def allreduce_gradients(params: torch.nn.Module):
+    """One flat all-reduce (mean) of every gradient — 14.7 MB for the DeepMind MLP."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    grads = [p.grad for p in params.parameters() if p.grad is not None]
+    flat = torch._utils._flatten_dense_tensors(grads)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(dist.get_world_size())
+    for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+        g.copy_(f)
+
+
+def make_update_step(config, actor_forward_pass, optimizer=None):
+    """``make_update_step(config, actor_forward_pass, optimizer)`` (src/update.py:9); returns
+    ``update_step(runner_state, traj_batch, advantages, targets) -> (runner_state, loss_info)`` (:74,242).
+    ``runner_state[1]`` (opt_state) is the dict from ``make_optimizer``."""
+
+    def update_step(runner_state, traj_batch: Transition, advantages, targets):
+        params, opt_state, env_state, last_obs, terminated_count, rng = runner_state
+        if opt_state is None:
+            opt_state = optimizer if optimizer is not None else make_optimizer(config, params)
+        opt, sched = opt_state["opt"], opt_state["sched"]
+        T, N = traj_batch.action.shape
+        batch_size = T * N
+        mbs = int(config["minibatch_size"])
+        if batch_size % mbs:
+            raise ValueError("batch size must be a multiple of minibatch_size")  # src/update.py:190-192
+        num_mb = batch_size // mbs
+        flat = Transition(*[x.reshape((batch_size,) + x.shape[2:]) for x in traj_batch])  # G7
+        adv_f, tgt_f = advantages.reshape(batch_size), targets.reshape(batch_size)
+        gen = torch.Generator(device=adv_f.device)
+        gen.manual_seed(int(rng) & 0x7FFFFFFF)
+        totals, auxes = [], []
+        for _ in range(int(config["update_epochs"])):
+            perm = torch.randperm(batch_size, device=adv_f.device, generator=gen)   # src/update.py:193
+            row_t, row_a = [], []
+            for m in range(num_mb):
+                idx = perm[m * mbs:(m + 1) * mbs]
+                mb = Transition(*[x.index_select(0, idx) for x in flat])
+                logits, value = actor_forward_pass.apply(params, mb.obs.to(torch.float32))   # G5
+                total, aux = ppo_loss(config, logits, value, mb, adv_f.index_select(0, idx), tgt_f.index_select(0, idx))
+                opt.zero_grad(set_to_none=True)
+                total.backward()
+                allreduce_gradients(params)
+                if config.get("global_gradient_clipping", True):
+                    torch.nn.utils.clip_grad_norm_(params.parameters(), config["max_grad_norm"])
+                opt.step()
+                if sched is not None:
+                    sched.step()
+                row_t.append(total.detach())
+                row_a.append(torch.stack(aux))
+            totals.append(torch.stack(row_t))
+            auxes.append(torch.stack(row_a))
+        loss_info = (torch.stack(totals), tuple(torch.stack(auxes)[..., i] for i in range(6)))
+        return (params, opt_state, env_state, last_obs, terminated_count, int(rng) + 1), loss_info
+
+    return update_step

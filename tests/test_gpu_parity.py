@@ -417,3 +417,15 @@ def test_simple_evaluate_runs_and_is_deterministic(env):
     ev = make_simple_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", o, 512)
     r1, r2 = float(ev(a, 11)), float(ev(a, 11))
     assert r1 == r2 and abs(r1) <= 7600.0
+
+
+def test_ppo_loop_runs_end_to_end(env):
+    """BASELINE config 4 at toy size: roll_out -> calc_gae -> update_step for 2 updates."""
+    from brl_amd.train import DEFAULTS, train
+    cfg = dict(DEFAULTS, num_envs=256, num_steps=8, total_timesteps=256 * 8 * 2, minibatch_size=512, update_epochs=2,
+               lut_len=2000, num_eval_envs=128, eval_interval=2, lr=1e-4)
+    logs = []
+    rs, hist = train(cfg, log=logs.append)
+    assert len(hist) == 2 and all(np.isfinite(h["total_loss"]) for h in hist)
+    assert hist[-1]["steps"] == 256 * 8 * 2 and "imp_vs_initial" in hist[-1]
+    assert abs(hist[-1]["imp_vs_initial"]) <= 24 and 0 <= hist[-1]["win_rate"] <= 1
