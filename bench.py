@@ -8,7 +8,7 @@
 One "step" = one pass of the hot path over one batch: the T=32-step random-policy rollout of
 num_envs=8192 tables (BASELINE.json configs[1]: ONE fused kernel launch writing the full
 time-major Transition buffer, auto-reset + DDS reward included), the observation of the
-post-rollout state (runner_state's last_obs) and the GAE(lambda) reverse scan.  Inputs (table
+post-rollout state (runner_state's last_obs, written by the same launch) and the GAE(lambda) reverse scan.  Inputs (table
 states, LUT) are resident in HBM before the timed region.  With N > 1 every rank runs its own
 8192-table shard (weak scaling, no data-path collective — SURVEY §8e); `value` is the
 whole-job macro-steps/s = N * 8192 * 32 * K / max-over-ranks time.
@@ -108,7 +108,7 @@ def main():
 
     keys, values = synthetic_lut(LUT_LEN, 0)
     env = brl_amd.BridgeBidding(lut=(keys, values), device=dev, env_offset=rank * NUM_ENVS)
-    cfg = {"num_steps": NUM_STEPS, "game_mode": "normal", "reward_scale": 7600, "return_last_obs": False}
+    cfg = {"num_steps": NUM_STEPS, "game_mode": "normal", "reward_scale": 7600, "return_last_obs": True}
     roll = brl_amd.make_random_roll_out(cfg, env)
     state = env.init(0, num_envs=NUM_ENVS)
     traj = alloc_transition(NUM_STEPS, NUM_ENVS, dev)
@@ -126,7 +126,6 @@ def main():
         rs, tb = roll(rs, out=traj)
         if ev is not None:
             ev[1].record()
-        last_obs = rs[2].observation  # runner_state's last_obs (k_observe, 3.9 MB)
         adv, tgt = gae_scan(env, tb.done, tb.value, tb.reward, last_val, 1.0, 0.95)
         return rs
 

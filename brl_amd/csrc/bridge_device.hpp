@@ -408,7 +408,7 @@ __device__ __forceinline__ void obs_chunk_load(const uint8_t *img_group, int sea
 }
 
 __device__ __forceinline__ void obs_chunk_store(uint32_t a, uint64_t H, int seat, uint32_t vulnib, uint8_t *dst_group,
-                                                const GroupLane &g) {
+                                                const GroupLane &g, int timing_alt = 0) {
   uint32_t m1 = (0xFu >> seat) * 0x11111111u;
   uint32_t rot = ((a >> seat) & m1) | ((a << (4 - seat)) & ~m1);
   uint32_t hv = (g.ch == 13) ? (uint32_t)(H << 8) : (uint32_t)(H >> 24);
@@ -416,9 +416,28 @@ __device__ __forceinline__ void obs_chunk_store(uint32_t a, uint64_t H, int seat
   uint32_t d[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) d[i] = __umul24((word >> (4 * i)) & 0xFu, 0x204081u) & 0x01010101u;
+  if (timing_alt) {  // TIMING EXPERIMENT ONLY (wrong bytes): each instruction writes contiguous 16-B pieces
+    uint4 *d0 = reinterpret_cast<uint4 *>(dst_group + g.r * 480 + g.ch * 16);
+    d0[0] = make_uint4(d[0], d[1], d[2], d[3]);
+    d0[15] = make_uint4(d[4], d[5], d[6], d[7]);
+    return;
+  }
   uint4 *dst = reinterpret_cast<uint4 *>(dst_group + g.out_off);
   dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
   dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
+}
+
+// same, with the row's 4 hand words already in registers (emit waves keep their tables' images
+// in registers between sub-steps; the LDS image is only the hand-over format).  Plain scalars, not an
+// array: a select between array elements is folded into a dynamically indexed load, which drags the
+// array out of registers.
+__device__ __forceinline__ void obs_chunk_store_regs(uint32_t a, uint64_t H0, uint64_t H1, uint64_t H2, uint64_t H3,
+                                                     int seat, uint32_t vulnib, uint8_t *dst_group,
+                                                     const GroupLane &g, int timing_alt = 0) {
+  uint32_t lo01 = (seat & 1) ? (uint32_t)H1 : (uint32_t)H0, hi01 = (seat & 1) ? (uint32_t)(H1 >> 32) : (uint32_t)(H0 >> 32);
+  uint32_t lo23 = (seat & 1) ? (uint32_t)H3 : (uint32_t)H2, hi23 = (seat & 1) ? (uint32_t)(H3 >> 32) : (uint32_t)(H2 >> 32);
+  uint32_t lo = (seat & 2) ? lo23 : lo01, hi = (seat & 2) ? hi23 : hi01;
+  obs_chunk_store(a, ((uint64_t)hi << 32) | lo, seat, vulnib, dst_group, g, timing_alt);
 }
 
 __device__ __forceinline__ void emit_obs_chunk(const uint8_t *img_group, int seat, uint32_t vulnib, uint8_t *dst_group,
@@ -491,6 +510,71 @@ __device__ __forceinline__ int random_legal_action(const Tbl &t, uint64_t legal,
   int a_dbl = (dbl == 1u) ? 1 : 2;
   int a = (k == 0) ? 0 : (dbl ? ((k == 1) ? a_dbl : first_bid + k - 2) : first_bid + k - 1);
   return bits(t.sc, SC_MASKALL, 1) ? k : a;
+}
+
+// ---- lean, straight-line transition for the fused rollout's LOGIC wave ------------------------
+// One uniform-random legal call on a LIVE table (never all-True mask, never illegal): same result as
+// legal_mask() + random_legal_action() + auto_reset_clear() + auction_step(), with no data-dependent
+// branches and no 64-bit popcount — this is the per-table dependency chain of the T-step scan, so
+// every instruction here is paid 32 times in sequence.
+struct LeanStep {
+  uint64_t legal;   // legal_action_mask of the state BEFORE the call
+  int seat;         // seat that acts
+  int action;       // the call
+  int n_legal;      // number of legal calls (for log_prob)
+  uint32_t hb1;     // history bit + 1 (0: none)
+  uint32_t term;    // auction over
+};
+
+__device__ __forceinline__ LeanStep lean_random_step(uint32_t &sc, uint32_t &sch, uint32_t u) {
+  LeanStep r;
+  const uint32_t lb1 = bits(sc, SC_LB1, 6);
+  const uint32_t seat = (bits(sc, SC_DEALER, 2) + bits(sch, SCH_TURN, 9)) & 3u;
+  const uint32_t own = ((bits(sc, SC_LBSEAT, 2) ^ seat) & 1u) ^ 1u;
+  const uint32_t x = bits(sc, SC_X, 1), xx = bits(sc, SC_XX, 1), has = lb1 != 0;
+  const uint32_t can_x = has & (own ^ 1u) & (x ^ 1u) & (xx ^ 1u);
+  const uint32_t can_xx = has & own & x & (xx ^ 1u);
+  const uint32_t dbl = can_x | can_xx;
+  const uint64_t bids = (ALL_ACTIONS >> (3 + lb1)) << (3 + lb1);
+  r.legal = bids | (uint64_t)(1u | (can_x << 1) | (can_xx << 2));
+  const uint32_t n = 36u - lb1 + dbl;  // pass + (35 - lb1) bids + at most one of X / XX
+  const uint32_t k = __umulhi(u, n);   // k-th legal call in ascending order
+  const uint32_t a_bid = 2u + lb1 + k - dbl;
+  const uint32_t a_dbl = can_x ? 1u : 2u;
+  uint32_t a = (dbl & (k == 1u)) ? a_dbl : a_bid;
+  a = (k == 0u) ? 0u : a;
+  uint32_t nn = n;
+  if (bits(sc, SC_MASKALL, 1)) {  // only a caller-supplied finished table can get here (all-True mask)
+    r.legal = ALL_ACTIONS;
+    nn = 38u;
+    a = __umulhi(u, 38u);
+  }
+  r.action = (int)a;
+  r.n_legal = (int)nn;
+  r.seat = (int)seat;
+  // A5 pre-step half of auto_reset (src/utils.py:34-43)
+  const uint32_t was_term = bits(sc, SC_TERM, 1);
+  sc &= ~(1u << SC_TERM);
+  sch = was_term ? (sch & ~(1023u << SCH_STEP)) : sch;
+  // the call
+  const bool is_pass = a == 0u, is_bid = a >= 3u, is_x = a == 1u;
+  const uint32_t b = a - 3u;
+  const uint32_t hb_bid = 9u + 12u * b + seat;
+  const uint32_t hb_dbl = 9u + 12u * (lb1 - 1u) + (is_x ? 4u : 8u) + seat;  // lb1 > 0 when X / XX is legal
+  const uint32_t hb_pass = (lb1 == 0u) ? 5u + seat : 0u;
+  r.hb1 = is_bid ? hb_bid : (is_pass ? hb_pass : hb_dbl);
+  const uint32_t pass = is_pass ? bits(sc, SC_PASS, 3) + 1u : 0u;
+  const uint32_t set_dbl = is_bid ? 0u : ((a == 1u ? (1u << SC_X) : 0u) | (a == 2u ? (1u << SC_XX) : 0u));
+  const uint32_t bid_clear = (63u << SC_LB1) | (3u << SC_LBSEAT) | (1u << SC_X) | (1u << SC_XX);
+  const uint32_t bid_set = ((b + 1u) << SC_LB1) | (seat << SC_LBSEAT);
+  uint32_t nsc = is_bid ? ((sc & ~bid_clear) | bid_set) : (sc | set_dbl);
+  const uint32_t nlb1 = is_bid ? b + 1u : lb1;
+  const uint32_t term = pass == ((nlb1 != 0u) ? 3u : 4u);
+  nsc = (nsc & ~(7u << SC_PASS)) | (pass << SC_PASS) | (term ? ((1u << SC_TERM) | (1u << SC_MASKALL)) : 0u);
+  sc = nsc;
+  sch += (1u << SCH_STEP) + (term ? 0u : (1u << SCH_TURN));
+  r.term = term;
+  return r;
 }
 
 }  // namespace brl

@@ -256,6 +256,8 @@ struct RolloutArgs {
   LutRef lut;
   const float *neg_log_n;  // [39] -log(n) as float, host-computed
   brl_transition out;
+  uint8_t *last_obs;   // [n,480] observation of the post-rollout state (runner_state's last_obs), may be NULL
+  uint8_t *last_mask;  // [n,38]
   unsigned long long *terminated_count;
   int debug;  // timing experiments only (BRL_DEBUG): 1 = emit waves idle, 2 = loader idle
 };
@@ -317,6 +319,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_rollout_random(RolloutArgs A)
       if (A.out.log_prob) A.out.log_prob[row] = A.neg_log_n[first_n];
       tcount += term_any;
     }
+  }
+  if (A.last_obs || A.last_mask) {
+    int oseat = cur_seat(t);
+    wave_emit<K>(w, A.n, oseat, vul_nibble(t, oseat), legal_mask(t), A.last_obs, A.last_mask, w.table0);
   }
   if (A.terminated_count != nullptr) {  // G2, src/roll_out.py:85
     uint32_t v = (w.c.lane < K && w.valid) ? tcount : 0u;
@@ -665,7 +671,11 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
       for (int j = 0; j < B; j++) {
         const int s = bi * B + j;
         if (s > total) break;
-        const bool emit = (s < total) && (sub == 0) && !(A.debug & 2);  // the same for every table of a sub-step
+        const bool fin = (s == total);  // the post-rollout state: emitted as last_obs / last_mask
+        const bool emit = ((s < total) && (sub == 0) && !(A.debug & 2)) || (fin && (A.last_obs || A.last_mask));
+        uint8_t *obs_base = fin ? A.last_obs : A.out.obs;
+        uint8_t *mask_base = fin ? A.last_mask : A.out.legal_action_mask;
+        const int64_t rowb = fin ? table0 : row0;
         const uint32_t(*cs)[CMD_WORDS] = cmd[bi & 1][j];
         // ---- round trip 1: each row's command
         uint32_t w0[GPW];
@@ -712,12 +722,12 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
             const int g = (wave - 3) + k * NE;
             if (left[k] <= 0) continue;
             // ---- the 4 observation rows: two 16-B stores per lane
-            if (gl.r < left[k] && A.out.obs)
+            if (gl.r < left[k] && obs_base)
               obs_chunk_store(a[k], H[k], (int)((w0[k] >> 10) & 3u), (w0[k] >> 12) & 15u,
-                              A.out.obs + (row0 + 4 * g) * BRL_OBS_SIZE, gl);
+                              obs_base + (rowb + 4 * g) * BRL_OBS_SIZE, gl);
             // ---- the 4 mask rows
-            if (A.out.legal_action_mask) {
-              uint8_t *mdst = A.out.legal_action_mask + (row0 + 4 * g) * BRL_NUM_ACTIONS;
+            if (mask_base) {
+              uint8_t *mdst = mask_base + (rowb + 4 * g) * BRL_NUM_ACTIONS;
               if (left[k] >= 4) {  // 152 contiguous bytes, one dword per lane
                 if (ml.active) reinterpret_cast<uint32_t *>(mdst)[c.lane] = mask_dword(la[k], lb[k], ml);
               } else {  // ragged tail of the batch: row by row
@@ -917,21 +927,37 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_duplicate_step(const uint64_t
 }
 
 // ---- A9 GAE reverse scan (src/gae.py:20-39): one lane per env, coalesced over envs --------
-__global__ void k_gae(const uint8_t *done, const float *value, const float *reward, const float *last_val, float gamma,
-                      float gamma_lambda, int T, int64_t n, float *adv, float *tgt) {
+// The recurrence is serial in t but its INPUTS are not: chunks of GAE_CHUNK steps are loaded up
+// front (3 x GAE_CHUNK independent loads in flight per lane) and then scanned from registers.
+constexpr int GAE_CHUNK = 16;
+__global__ __launch_bounds__(64) void k_gae(const uint8_t *done, const float *value, const float *reward,
+                                            const float *last_val, float gamma, float gamma_lambda, int T, int64_t n,
+                                            float *adv, float *tgt) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   float gae = 0.0f, next_value = last_val[e];
-#pragma unroll 8
-  for (int t = T - 1; t >= 0; t--) {
-    int64_t i = (int64_t)t * n + e;
-    float nd = 1.0f - (float)done[i];
-    float v = value[i];
-    float delta = reward[i] + gamma * next_value * nd - v;  // src/gae.py:28
-    gae = delta + gamma_lambda * nd * gae;                   // src/gae.py:29
-    adv[i] = gae;
-    tgt[i] = gae + v;  // src/gae.py:39
-    next_value = v;
+  for (int t1 = T; t1 > 0; t1 -= GAE_CHUNK) {
+    float dn[GAE_CHUNK], vl[GAE_CHUNK], rw[GAE_CHUNK];
+#pragma unroll
+    for (int k = 0; k < GAE_CHUNK; k++) {
+      int t = t1 - 1 - k;
+      int64_t i = (int64_t)(t >= 0 ? t : 0) * n + e;
+      dn[k] = (float)done[i];
+      vl[k] = value[i];
+      rw[k] = reward[i];
+    }
+#pragma unroll
+    for (int k = 0; k < GAE_CHUNK; k++) {
+      int t = t1 - 1 - k;
+      if (t < 0) break;
+      int64_t i = (int64_t)t * n + e;
+      float nd = 1.0f - dn[k];
+      float delta = rw[k] + gamma * next_value * nd - vl[k];  // src/gae.py:28
+      gae = delta + gamma_lambda * nd * gae;                   // src/gae.py:29
+      adv[i] = gae;
+      tgt[i] = gae + vl[k];  // src/gae.py:39
+      next_value = vl[k];
+    }
   }
 }
 
@@ -1192,7 +1218,7 @@ extern "C" int brl_get_fields(brl_handle *h, const uint64_t *state, int64_t n, c
 
 extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int num_steps, int substeps,
                                   uint32_t draw_base, float reward_scale, const brl_transition *out,
-                                  int64_t *terminated_count, void *stream) {
+                                  uint8_t *last_obs, uint8_t *last_mask, int64_t *terminated_count, void *stream) {
   COMMON(h, n);
   NEED(state && out, "state / out");
   NEED(num_steps >= 0, "num_steps");
@@ -1202,6 +1228,7 @@ extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int
   A.state = state; A.n = n; A.T = num_steps; A.substeps = substeps; A.draw_base = draw_base;
   A.reward_scale = reward_scale; A.g = rng_of(h); A.env_offset = h->env_offset; A.lut = lut_of(h);
   A.neg_log_n = h->neg_log_n; A.out = *out; A.terminated_count = (unsigned long long *)terminated_count;
+  A.last_obs = last_obs; A.last_mask = last_mask;
   A.debug = getenv("BRL_DEBUG") ? atoi(getenv("BRL_DEBUG")) : 0;
 #define LAUNCH_WS(TPB, NW)                                                                             \
   hipLaunchKernelGGL((k_rollout_ws<TPB, NW>), dim3((unsigned)((n + TPB - 1) / TPB)), dim3(NW * 64), 0, \

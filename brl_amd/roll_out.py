@@ -60,10 +60,13 @@ def make_random_roll_out(config, env: BridgeBidding):
         p = _capi.TransitionPtrs()
         for name in _capi.TransitionPtrs._names:
             setattr(p, name, ptr(getattr(traj, name)))
+        want_last = config.get("return_last_obs", True)
+        last_obs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=env.device) if want_last else None
+        last_mask = torch.empty((n, NUM_ACTIONS), dtype=torch.bool, device=env.device) if want_last else None
         check(_capi.lib().brl_rollout_random(env._h, ptr(env_state.packed), n, T, substeps, int(rng) & 0xFFFFFFFF,
-                                             reward_scale, C.byref(p), ptr(tc), _stream()))
-        new_state = State(env, env_state.packed)  # updated in place
-        last_obs = new_state.observation if config.get("return_last_obs", True) else None
+                                             reward_scale, C.byref(p), ptr(last_obs), ptr(last_mask), ptr(tc), _stream()))
+        cache = {"observation": last_obs, "legal_action_mask": last_mask} if want_last else None
+        new_state = State(env, env_state.packed, cache)  # updated in place; last_obs written by the same launch
         return (params, opt_state, new_state, last_obs, tc, int(rng) + T * substeps), traj
 
     return roll_out

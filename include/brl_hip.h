@@ -130,10 +130,12 @@ typedef struct brl_transition {
  * normal_step (substeps=1, src/utils.py:249-254) or the 4-sub-step competitive macro-step
  * with all seats random (substeps=4, src/utils.py:69-128).  state is updated in place.
  * draw_base: index of the first action draw (advance by T*substeps between calls).
+ * last_obs uint8 [n,480] / last_mask uint8 [n,38]: observation and legal mask of the post-rollout
+ * state, i.e. runner_state's last_obs of src/roll_out.py:95-102 (either may be NULL).
  * terminated_count: device int64 accumulated like src/roll_out.py:85 (may be NULL). */
 int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int num_steps, int substeps,
                        uint32_t draw_base, float reward_scale, const brl_transition *out,
-                       int64_t *terminated_count, void *stream);
+                       uint8_t *last_obs, uint8_t *last_mask, int64_t *terminated_count, void *stream);
 
 /* One policy sub-step: masked categorical over `logits` float [n,38] for the current
  * player (mode 0: sample, src/roll_out.py:79-81 / src/utils.py:83-85; mode 1: arg-max,

@@ -33,7 +33,7 @@ for K in (os.environ.get("KS", "k4,16x4,16x6,16x10,32x6,32x8,32x10,32x16,64x10,6
         for f in _capi.TransitionPtrs._names:
             setattr(p, f, _capi.ptr(getattr(tr, f)))
         def launch(d):
-            _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, d, 7600.0, C.byref(p), None, _stream()))
+            _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, d, 7600.0, C.byref(p), None, None, None, _stream()))
         for i in range(10):
             launch(i * T)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]

@@ -11,7 +11,7 @@ N, T = 8192, 32
 keys, values = synthetic_lut(100000, 0)
 res = {}
 for cfg in os.environ.get("CFGS", "32x11,32x7").split(","):
-    for dbg in ("0", "1", "2", "4", "32", "36"):
+    for dbg in os.environ.get("DBGS", "0,128").split(","):
         os.environ["BRL_ROLLOUT_WS"] = cfg
         os.environ["BRL_DEBUG"] = dbg
         env = brl_amd.BridgeBidding(lut=(keys, values))
@@ -21,7 +21,7 @@ for cfg in os.environ.get("CFGS", "32x11,32x7").split(","):
         for f in _capi.TransitionPtrs._names:
             setattr(p, f, _capi.ptr(getattr(traj, f)))
         def launch(d):
-            _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, d, 7600.0, C.byref(p), None, _stream()))
+            _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, d, 7600.0, C.byref(p), None, None, None, _stream()))
         for i in range(10): launch(i*T)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
         torch.cuda.synchronize()

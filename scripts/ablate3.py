@@ -20,7 +20,7 @@ for cfg in os.environ.get("CFGS", "32x11").split(","):
     for f in _capi.TransitionPtrs._names:
         setattr(p, f, _capi.ptr(getattr(traj, f)))
     def launch(d):
-        _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, d, 7600.0, C.byref(p), None, _stream()))
+        _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, d, 7600.0, C.byref(p), None, None, None, _stream()))
     for i in range(10): launch(i*T)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
     torch.cuda.synchronize()

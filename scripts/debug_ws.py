@@ -19,7 +19,7 @@ traj = R.alloc_transition(T, n, env.device)
 p = _capi.TransitionPtrs()
 for f in _capi.TransitionPtrs._names:
     setattr(p, f, _capi.ptr(getattr(traj, f)))
-_capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), n, T, SUB, 0, 7600.0, C.byref(p), None, _stream()))
+_capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), n, T, SUB, 0, 7600.0, C.byref(p), None, None, None, _stream()))
 want = orc.rollout_random(ref, T, seed=2024, substeps=SUB)
 torch.cuda.synchronize()
 for name in ("obs", "legal_action_mask", "action", "done", "reward", "log_prob"):

@@ -16,5 +16,5 @@ p = _capi.TransitionPtrs()
 for f in _capi.TransitionPtrs._names:
     setattr(p, f, _capi.ptr(getattr(traj, f)))
 for i in range(6):
-    _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, i * T, 7600.0, C.byref(p), None, _stream()))
+    _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, i * T, 7600.0, C.byref(p), None, None, None, _stream()))
 torch.cuda.synchronize()

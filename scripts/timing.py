@@ -27,7 +27,7 @@ for cfg in os.environ.get("CFGS", "32x16").split(","):
     nblk = (N + tpb - 1) // tpb
     dump = torch.zeros(nblk * nw * 2, dtype=torch.int64, device=env.device)
     for i in range(5):
-        _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, i * T, 7600.0, C.byref(p), _capi.ptr(dump), _stream()))
+        _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, i * T, 7600.0, C.byref(p), None, None, _capi.ptr(dump), _stream()))
     torch.cuda.synchronize()
     d = dump.cpu().numpy().reshape(nblk, nw, 2)
     tot, wait = d[..., 0].mean(0), d[..., 1].mean(0)
