@@ -31,6 +31,7 @@ NUM_ENVS = 8192
 NUM_STEPS = 32
 LUT_LEN = 100_000          # ppo.py:128 hash_size
 ROW_BYTES = 535            # obs 480 + mask 38 + action 4 + value 4 + reward 4 + log_prob 4 + done 1
+LAST_ROW_BYTES = 518       # last_obs 480 + its legal mask 38, written once per table by the same launch
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -146,7 +147,7 @@ def main():
     # dominant kernel: k_rollout_random; HIP events on the launch stream, inside the timed region,
     # bracketing exactly that one launch.
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
-    alg_bytes = ROW_BYTES * NUM_ENVS * NUM_STEPS
+    alg_bytes = ROW_BYTES * NUM_ENVS * NUM_STEPS + LAST_ROW_BYTES * NUM_ENVS
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
     macro_steps = world * NUM_ENVS * NUM_STEPS * args.steps

@@ -367,6 +367,89 @@ __device__ __forceinline__ GroupLane make_group_lane() {
   return g;
 }
 
+// ---- register-resident row images (emit waves of the fused rollout) -----------------------------
+// Lane (r, ch) of an emit wave keeps history dword ch of row r and the row's four hand words (as
+// 8 x u32) in registers.  rows_apply / rows_emit are straight-line on purpose: every instruction of
+// this path is executed once per 4 rows per sub-step by a wave that has nothing to overlap it with.
+struct RowRegs {
+  uint32_t a;                                   // history dword `ch` of this lane's row
+  uint32_t h0l, h0h, h1l, h1h, h2l, h2h, h3l, h3h;  // hand words of seats 0..3
+};
+
+__device__ __forceinline__ void rows_load(RowRegs &R, const uint8_t *im, const GroupLane &g) {
+  R.a = *reinterpret_cast<const uint32_t *>(im + 4 * ((g.ch < 13) ? g.ch : 13));
+  const uint2 *h = reinterpret_cast<const uint2 *>(im + W_HAND * 8);
+  uint2 a = h[0], b = h[1], c = h[2], d = h[3];
+  R.h0l = a.x; R.h0h = a.y; R.h1l = b.x; R.h1h = b.y; R.h2l = c.x; R.h2h = c.y; R.h3l = d.x; R.h3h = d.y;
+}
+
+// apply "history bit + 1" of a command to the lane that owns the bit (w0 == 0 for absent rows)
+__device__ __forceinline__ void rows_apply(RowRegs &R, uint32_t w0, const GroupLane &g) {
+  const uint32_t t1 = (w0 & 0x1FFu) - 1u;  // 0xFFFFFFFF when there is no bit
+  const bool hit = ((t1 >> 5) == (uint32_t)g.ch) && !(w0 & 0x200u);
+  R.a |= hit ? (1u << (t1 & 31u)) : 0u;
+}
+
+// this lane's 32 observation bytes (8 dwords) for observer `seat`.
+// RowRegs BY VALUE: a select between two fields loaded through a reference is folded (in this
+// function, before it is inlined) into one dynamically indexed load, which then keeps the caller's
+// struct out of registers.  By value the fields are SSA values before that fold can happen.
+__device__ __forceinline__ void rows_words(RowRegs R, uint32_t seat, uint32_t vulnib, const GroupLane &g,
+                                           uint4 &lo, uint4 &hi) {
+  const bool s1 = (seat & 1u) != 0, s2 = (seat & 2u) != 0;
+  const uint32_t hl = s2 ? (s1 ? R.h3l : R.h2l) : (s1 ? R.h1l : R.h0l);
+  const uint32_t hh = s2 ? (s1 ? R.h3h : R.h2h) : (s1 ? R.h1h : R.h0h);
+  uint32_t x = 0xFu >> seat;  // low (4 - seat) bits of every nibble survive the right shift
+  x |= x << 4;
+  x |= x << 8;
+  const uint32_t m1 = x | (x << 16);
+  const uint32_t rot = ((R.a >> seat) & m1) | ((R.a << (4u - seat)) & ~m1);
+  const uint32_t hv = (g.ch == 13) ? (hl << 8) : __builtin_amdgcn_alignbit(hh, hl, 24);  // (u32)(H<<8) : (u32)(H>>24)
+  const uint32_t word = (rot & g.keep_hist) | (hv & g.keep_hand) | (vulnib & g.keep_vul);
+  lo.x = __umul24(word & 0xFu, 0x204081u) & 0x01010101u;
+  lo.y = __umul24((word >> 4) & 0xFu, 0x204081u) & 0x01010101u;
+  lo.z = __umul24((word >> 8) & 0xFu, 0x204081u) & 0x01010101u;
+  lo.w = __umul24((word >> 12) & 0xFu, 0x204081u) & 0x01010101u;
+  hi.x = __umul24((word >> 16) & 0xFu, 0x204081u) & 0x01010101u;
+  hi.y = __umul24((word >> 20) & 0xFu, 0x204081u) & 0x01010101u;
+  hi.z = __umul24((word >> 24) & 0xFu, 0x204081u) & 0x01010101u;
+  hi.w = __umul24(word >> 28, 0x204081u) & 0x01010101u;
+}
+
+// ---- byte-expanded rows kept in LDS ------------------------------------------------------------
+// The fused rollout keeps, per table, the four 480-byte observation rows (one per observer seat)
+// READY-MADE in LDS: a call changes exactly one byte in each of them, a re-deal rebuilds them, and
+// emitting a row is a plain LDS -> HBM copy (two 16-B loads + two 16-B stores per lane for 4 rows).
+constexpr int EXP_ROW = 512;            // bytes reserved per (table, observer seat); 480 used
+constexpr int EXP_TABLE = 4 * EXP_ROW;  // 2 KB per table
+
+// the eight 0/1-byte dwords of one packed dword of a row (see obs_chunk_store)
+__device__ __forceinline__ void obs_chunk_words(uint32_t a, uint64_t H, int seat, uint32_t vulnib, const GroupLane &g,
+                                                uint32_t d[8]) {
+  uint32_t m1 = (0xFu >> seat) * 0x11111111u;
+  uint32_t rot = ((a >> seat) & m1) | ((a << (4 - seat)) & ~m1);
+  uint32_t hv = (g.ch == 13) ? (uint32_t)(H << 8) : (uint32_t)(H >> 24);
+  uint32_t word = (rot & g.keep_hist) | (hv & g.keep_hand) | (vulnib & g.keep_vul);
+#pragma unroll
+  for (int i = 0; i < 8; i++) d[i] = __umul24((word >> (4 * i)) & 0xFu, 0x204081u) & 0x01010101u;
+}
+
+// (re)build the four expanded rows of ONE table from its packed image; wave-cooperative:
+// lane l -> observer seat l/15, packed dword l%15.  vulbits = vul_NS | vul_EW << 1.
+__device__ __forceinline__ void expand_table(const uint8_t *im, uint32_t vulbits, uint8_t *ex, const GroupLane &g) {
+  if (g.r < 4) {
+    const int v = g.r;
+    uint32_t a = *reinterpret_cast<const uint32_t *>(im + 4 * ((g.ch < 13) ? g.ch : 13));
+    uint64_t H = *reinterpret_cast<const uint64_t *>(im + (W_HAND + v) * 8);
+    uint32_t we = (vulbits >> (v & 1)) & 1u, they = (vulbits >> ((v & 1) ^ 1)) & 1u;
+    uint32_t d[8];
+    obs_chunk_words(a, H, v, (we ? 2u : 1u) | (they ? 8u : 4u), g, d);
+    uint4 *dst = reinterpret_cast<uint4 *>(ex + v * EXP_ROW + g.ch * 32);
+    dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
+    dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
+  }
+}
+
 // The 4 x 38 mask bytes of a group are 152 contiguous bytes = 38 dwords: lane l < 38 writes dword
 // l, whose 4 bytes belong to row qa (the first `split` of them) and row qa+1 (the rest).
 struct MaskLane {

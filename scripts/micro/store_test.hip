@@ -20,9 +20,16 @@ __global__ __launch_bounds__(NW * 64) void k_store(uint8_t *obs, uint8_t *mask, 
         dst[1] = v;
       }
       if (lane < 38) reinterpret_cast<uint32_t *>(mask + row * 38)[lane] = v.w;
-      v.x += mode;  // keep the loop from collapsing
+      v.x += 1;  // keep the loop from collapsing
+      if (mode >= 2) {  // dependent VALU work between the stores (mode = number of 10-op rounds)
+        uint32_t y = v.y;
+        for (int q = 0; q < mode; q++) {
+#pragma unroll
+          for (int z = 0; z < 10; z++) y = y * 0x9E3779B1u + (y >> 7);
+        }
+        v.y = y;
+      }
     }
-    if (mode == 2) __builtin_amdgcn_s_sleep(20);
   }
 }
 int main(int argc, char **argv) {
@@ -30,7 +37,7 @@ int main(int argc, char **argv) {
   uint8_t *obs, *mask;
   hipMalloc(&obs, n * T * 480); hipMalloc(&mask, n * T * 38 + 64);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  for (int cfg = 0; cfg < 4; cfg++) {
+  for (int cfg = 0; cfg < 8; cfg++) {
     float best = 1e9;
     for (int it = 0; it < 20; it++) {
       hipEventRecord(a);
@@ -38,6 +45,10 @@ int main(int argc, char **argv) {
       if (cfg == 1) hipLaunchKernelGGL((k_store<8, 0>), dim3(256), dim3(8 * 64), 0, 0, obs, mask, n, T, 1);
       if (cfg == 2) hipLaunchKernelGGL((k_store<16, 0>), dim3(256), dim3(16 * 64), 0, 0, obs, mask, n, T, 1);
       if (cfg == 3) hipLaunchKernelGGL((k_store<4, 0>), dim3(256), dim3(4 * 64), 0, 0, obs, mask, n, T, 1);
+      if (cfg == 4) hipLaunchKernelGGL((k_store<11, 3>), dim3(256), dim3(11 * 64), 0, 0, obs, mask, n, T, 5);
+      if (cfg == 5) hipLaunchKernelGGL((k_store<11, 3>), dim3(256), dim3(11 * 64), 0, 0, obs, mask, n, T, 10);
+      if (cfg == 6) hipLaunchKernelGGL((k_store<11, 3>), dim3(256), dim3(11 * 64), 0, 0, obs, mask, n, T, 20);
+      if (cfg == 7) hipLaunchKernelGGL((k_store<7, 3>), dim3(256), dim3(7 * 64), 0, 0, obs, mask, n, T, 10);
       hipEventRecord(b); hipEventSynchronize(b);
       float ms; hipEventElapsedTime(&ms, a, b);
       if (ms < best) best = ms;

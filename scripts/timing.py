@@ -35,7 +35,7 @@ for cfg in os.environ.get("CFGS", "32x16").split(","):
     if int(os.environ.get("DBG", "0")) & 64:
         seg01 = d[..., 0].mean(0); seg2 = (d[..., 1] & 0xFFFFFFFF).mean(0); seg3 = (d[..., 1] >> 32).mean(0)
         for w in range(3, nw):
-            print(f"  emit wave {w:2d}: apply+fence {seg01[w]:9.0f}  obs {seg2[w]:9.0f}  mask {seg3[w]:9.0f}")
+            print(f"  emit wave {w:2d}: apply {seg01[w]:9.0f}  obs-copy {seg2[w]:9.0f}  mask {seg3[w]:9.0f}")
         continue
     for w in range(nw):
         print(f"  wave {w:2d}: total {tot[w]:9.0f} wait {wait[w]:9.0f} work {tot[w]-wait[w]:9.0f}")
