@@ -3,7 +3,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
-template <int NW, int NE0>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int NW, int NE0, int NT = 0>
 __global__ __launch_bounds__(NW * 64) void k_store(uint8_t *obs, uint8_t *mask, int64_t n, int T, int mode) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wave < NE0) return;
@@ -15,9 +16,16 @@ __global__ __launch_bounds__(NW * 64) void k_store(uint8_t *obs, uint8_t *mask, 
     for (int g = wave - NE0; g < 8; g += NE) {
       int64_t row = (int64_t)s * n + table0 + 4 * g;
       if (r < 4) {
-        uint4 *dst = reinterpret_cast<uint4 *>(obs + row * 480 + r * 480 + ch * 32);
-        dst[0] = v;
-        dst[1] = v;
+        if (NT) {
+          u32x4 *dst = reinterpret_cast<u32x4 *>(obs + row * 480 + r * 480 + ch * 32);
+          u32x4 vv = {v.x, v.y, v.z, v.w};
+          __builtin_nontemporal_store(vv, dst);
+          __builtin_nontemporal_store(vv, dst + 1);
+        } else {
+          uint4 *dst = reinterpret_cast<uint4 *>(obs + row * 480 + r * 480 + ch * 32);
+          dst[0] = v;
+          dst[1] = v;
+        }
       }
       if (lane < 38) reinterpret_cast<uint32_t *>(mask + row * 38)[lane] = v.w;
       v.x += 1;  // keep the loop from collapsing
@@ -37,7 +45,7 @@ int main(int argc, char **argv) {
   uint8_t *obs, *mask;
   hipMalloc(&obs, n * T * 480); hipMalloc(&mask, n * T * 38 + 64);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  for (int cfg = 0; cfg < 8; cfg++) {
+  for (int cfg = 0; cfg < 10; cfg++) {
     float best = 1e9;
     for (int it = 0; it < 20; it++) {
       hipEventRecord(a);
@@ -49,6 +57,8 @@ int main(int argc, char **argv) {
       if (cfg == 5) hipLaunchKernelGGL((k_store<11, 3>), dim3(256), dim3(11 * 64), 0, 0, obs, mask, n, T, 10);
       if (cfg == 6) hipLaunchKernelGGL((k_store<11, 3>), dim3(256), dim3(11 * 64), 0, 0, obs, mask, n, T, 20);
       if (cfg == 7) hipLaunchKernelGGL((k_store<7, 3>), dim3(256), dim3(7 * 64), 0, 0, obs, mask, n, T, 10);
+      if (cfg == 8) hipLaunchKernelGGL((k_store<11, 3, 1>), dim3(256), dim3(11 * 64), 0, 0, obs, mask, n, T, 1);
+      if (cfg == 9) hipLaunchKernelGGL((k_store<16, 0, 1>), dim3(256), dim3(16 * 64), 0, 0, obs, mask, n, T, 1);
       hipEventRecord(b); hipEventSynchronize(b);
       float ms; hipEventElapsedTime(&ms, a, b);
       if (ms < best) best = ms;
