@@ -21,7 +21,8 @@ _NEG = torch.finfo(torch.float32).min
 def make_optimizer(config, params: torch.nn.Module):
     """ppo.py:186-211: Adam(eps=1e-5), optional linear anneal; global-norm clipping is applied inside
     ``update_step`` (optax.chain(clip_by_global_norm, adam))."""
-    opt = torch.optim.Adam(params.parameters(), lr=config["lr"], eps=1e-5)
+    on_gpu = next(params.parameters()).is_cuda
+    opt = torch.optim.Adam(params.parameters(), lr=config["lr"], eps=1e-5, fused=True if on_gpu else None)  # one kernel per step
     sched = None
     if config.get("anneal_lr", False):
         per_update = config["num_minibatches"] * config["update_epochs"]
@@ -103,12 +104,16 @@ def make_update_step(config, actor_forward_pass, optimizer=None):
         totals, auxes = [], []
         for _ in range(int(config["update_epochs"])):
             perm = torch.randperm(batch_size, device=adv_f.device, generator=gen)   # src/update.py:193
+            # shuffled_batch = take(x, permutation) once per epoch, minibatches are then contiguous views
+            # (src/update.py:198-206) — one gather of the whole buffer instead of 7 per minibatch
+            shuf = Transition(*[x.index_select(0, perm) for x in flat])
+            adv_s, tgt_s = adv_f.index_select(0, perm), tgt_f.index_select(0, perm)
             row_t, row_a = [], []
             for m in range(num_mb):
-                idx = perm[m * mbs:(m + 1) * mbs]
-                mb = Transition(*[x.index_select(0, idx) for x in flat])
+                sl = slice(m * mbs, (m + 1) * mbs)
+                mb = Transition(*[x[sl] for x in shuf])
                 logits, value = actor_forward_pass.apply(params, mb.obs.to(torch.float32))   # G5
-                total, aux = ppo_loss(config, logits, value, mb, adv_f.index_select(0, idx), tgt_f.index_select(0, idx))
+                total, aux = ppo_loss(config, logits, value, mb, adv_s[sl], tgt_s[sl])
                 opt.zero_grad(set_to_none=True)
                 total.backward()
                 allreduce_gradients(params)

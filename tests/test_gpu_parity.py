@@ -429,3 +429,84 @@ def test_ppo_loop_runs_end_to_end(env):
     assert len(hist) == 2 and all(np.isfinite(h["total_loss"]) for h in hist)
     assert hist[-1]["steps"] == 256 * 8 * 2 and "imp_vs_initial" in hist[-1]
     assert abs(hist[-1]["imp_vs_initial"]) <= 24 and 0 <= hist[-1]["win_rate"] <= 1
+
+
+def test_macro_step_matches_manual_composition(env, oracle):
+    """A6 / G3: single_play_step_two_policy_commpetitive_deterministic == step + 3 x (forward, arg-max, step)
+    with auto-reset, rewards summed and terminated OR-ed (src/utils.py:133-202); replayed through the oracle."""
+    from brl_amd.evaluation import masked_mode
+    from brl_amd.models import make_forward_pass
+    from brl_amd.utils import auto_reset, single_play_step_two_policy_commpetitive_deterministic
+    n = 1024
+    fp = make_forward_pass("relu", "FAIR")
+    actor, opp = fp.init(7, device="cuda"), fp.init(8, device="cuda")
+    step_fn = single_play_step_two_policy_commpetitive_deterministic(auto_reset(env.step, env.init), fp, actor, fp, opp)
+    st = env.init(77, num_envs=n)
+    ref = oracle.init_random(n, seed=77)
+    rng = np.random.default_rng(0)
+    for it in range(12):
+        a1 = random_legal_actions(rng, ref["legal_action_mask"])
+        a1[rng.random(n) < 0.5] = 0
+        # manual composition on a copy of the GPU state (env.step is itself checked against the oracle)
+        man = env.step(st, torch.from_numpy(a1), autoreset=True)
+        oracle.step(ref, a1, autoreset=True, seed=77)
+        rsum = ref["rewards"].copy()
+        term = ref["terminated"].copy()
+        for k, net in enumerate((opp, actor, opp)):
+            with torch.no_grad():
+                logits, _ = fp.apply(net, man.observation.float())
+            a = masked_mode(logits, man.legal_action_mask)
+            man = env.step(man, a, autoreset=True)
+            oracle.step(ref, to_np(a), autoreset=True, seed=77)
+            rsum += ref["rewards"]
+            term |= ref["terminated"]
+        ref["rewards"] = rsum          # src/utils.py:126-128
+        ref["terminated"] = term
+        st = step_fn(st, torch.from_numpy(a1), it)
+        assert_state_equal(st, ref, where=f"macro-step {it}")
+
+
+def test_free_run_opponents_always_pass(env, oracle):
+    """G16: single_play_step_free_run — both opponents pass, the partner plays pi.mode() (src/utils.py:205-246)."""
+    from brl_amd.evaluation import masked_mode
+    from brl_amd.models import make_forward_pass
+    from brl_amd.utils import auto_reset, single_play_step_free_run
+    n = 512
+    fp = make_forward_pass("relu", "FAIR")
+    actor = fp.init(3, device="cuda")
+    step_fn = single_play_step_free_run(auto_reset(env.step, env.init), fp, actor)
+    st = env.init(5, num_envs=n)
+    ref = oracle.init_random(n, seed=5)
+    for it in range(6):
+        a1 = np.full(n, 3 + 5 * it, np.int32)  # 1C, 2C, ... always legal here
+        a1[ref["legal_action_mask"][np.arange(n), a1] == 0] = 0
+        oracle.step(ref, a1, autoreset=True, seed=5)
+        rsum, term = ref["rewards"].copy(), ref["terminated"].copy()
+        oracle.step(ref, np.zeros(n, np.int32), autoreset=True, seed=5)           # opponent passes
+        rsum += ref["rewards"]; term |= ref["terminated"]
+        obs = torch.from_numpy(ref["observation"].astype(np.float32)).cuda()
+        with torch.no_grad():
+            logits, _ = fp.apply(actor, obs)
+        a3 = to_np(masked_mode(logits, torch.from_numpy(ref["legal_action_mask"].astype(bool)).cuda()))
+        oracle.step(ref, a3, autoreset=True, seed=5)                               # partner, greedy
+        rsum += ref["rewards"]; term |= ref["terminated"]
+        oracle.step(ref, np.zeros(n, np.int32), autoreset=True, seed=5)           # opponent passes
+        rsum += ref["rewards"]; term |= ref["terminated"]
+        ref["rewards"], ref["terminated"] = rsum, term
+        st = step_fn(st, torch.from_numpy(a1), it)
+        assert_state_equal(st, ref, where=f"free-run macro-step {it}")
+
+
+def test_lut_rotation_reinitialises_envs(dds, oracle):
+    """G14 (ppo.py:525-549): swap the hash table, re-init every env; later boards come from the new table."""
+    import brl_amd
+    from oracle import Oracle
+    k2, v2 = synthetic_lut(777, seed=9)
+    env = brl_amd.BridgeBidding(lut=(dds["keys"], dds["values"]))
+    st = env.init(1, num_envs=300)
+    assert int(st._lut_idx.max()) < 1000
+    env.set_lut((k2, v2))
+    st = env.init(2, num_envs=300)
+    ref = Oracle(k2, v2).init_random(300, seed=2)
+    assert_state_equal(st, ref, where="after LUT rotation")
+    assert int(st._lut_idx.max()) < 777
