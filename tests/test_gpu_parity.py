@@ -510,3 +510,23 @@ def test_lut_rotation_reinitialises_envs(dds, oracle):
     ref = Oracle(k2, v2).init_random(300, seed=2)
     assert_state_equal(st, ref, where="after LUT rotation")
     assert int(st._lut_idx.max()) < 777
+
+
+def test_graphed_update_matches_eager_update():
+    """The hipGraph-captured minibatch step must produce the same parameters as the eager one."""
+    from brl_amd.models import make_forward_pass
+    from brl_amd.update import make_update_step
+    from tests.test_update_cpu import CFG, fake_batch
+    tb, adv, tgt = fake_batch(4, 256, seed=3)
+    tb = type(tb)(*[x.cuda() for x in tb]); adv, tgt = adv.cuda(), tgt.cuda()
+    fp = make_forward_pass("relu", "DeepMind")
+    outs = []
+    for graph in (False, True):
+        net = fp.init(11, device="cuda")
+        cfg = dict(CFG, minibatch_size=256, update_epochs=2, graph_update=graph)
+        rs, (total, aux) = make_update_step(cfg, fp)((net, None, None, None, 0, 5), tb, adv, tgt)
+        if graph:
+            assert rs[1].get("graphed"), rs[1].get("graph_error")
+        outs.append((torch.cat([p.detach().reshape(-1) for p in net.parameters()]), total))
+    assert torch.allclose(outs[0][1], outs[1][1], atol=1e-5)            # same losses (fp32 reduction order may differ)
+    assert torch.allclose(outs[0][0], outs[1][0], atol=1e-5, rtol=1e-4)  # same updated parameters
