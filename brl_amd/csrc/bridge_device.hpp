@@ -367,89 +367,6 @@ __device__ __forceinline__ GroupLane make_group_lane() {
   return g;
 }
 
-// ---- register-resident row images (emit waves of the fused rollout) -----------------------------
-// Lane (r, ch) of an emit wave keeps history dword ch of row r and the row's four hand words (as
-// 8 x u32) in registers.  rows_apply / rows_emit are straight-line on purpose: every instruction of
-// this path is executed once per 4 rows per sub-step by a wave that has nothing to overlap it with.
-struct RowRegs {
-  uint32_t a;                                   // history dword `ch` of this lane's row
-  uint32_t h0l, h0h, h1l, h1h, h2l, h2h, h3l, h3h;  // hand words of seats 0..3
-};
-
-__device__ __forceinline__ void rows_load(RowRegs &R, const uint8_t *im, const GroupLane &g) {
-  R.a = *reinterpret_cast<const uint32_t *>(im + 4 * ((g.ch < 13) ? g.ch : 13));
-  const uint2 *h = reinterpret_cast<const uint2 *>(im + W_HAND * 8);
-  uint2 a = h[0], b = h[1], c = h[2], d = h[3];
-  R.h0l = a.x; R.h0h = a.y; R.h1l = b.x; R.h1h = b.y; R.h2l = c.x; R.h2h = c.y; R.h3l = d.x; R.h3h = d.y;
-}
-
-// apply "history bit + 1" of a command to the lane that owns the bit (w0 == 0 for absent rows)
-__device__ __forceinline__ void rows_apply(RowRegs &R, uint32_t w0, const GroupLane &g) {
-  const uint32_t t1 = (w0 & 0x1FFu) - 1u;  // 0xFFFFFFFF when there is no bit
-  const bool hit = ((t1 >> 5) == (uint32_t)g.ch) && !(w0 & 0x200u);
-  R.a |= hit ? (1u << (t1 & 31u)) : 0u;
-}
-
-// this lane's 32 observation bytes (8 dwords) for observer `seat`.
-// RowRegs BY VALUE: a select between two fields loaded through a reference is folded (in this
-// function, before it is inlined) into one dynamically indexed load, which then keeps the caller's
-// struct out of registers.  By value the fields are SSA values before that fold can happen.
-__device__ __forceinline__ void rows_words(RowRegs R, uint32_t seat, uint32_t vulnib, const GroupLane &g,
-                                           uint4 &lo, uint4 &hi) {
-  const bool s1 = (seat & 1u) != 0, s2 = (seat & 2u) != 0;
-  const uint32_t hl = s2 ? (s1 ? R.h3l : R.h2l) : (s1 ? R.h1l : R.h0l);
-  const uint32_t hh = s2 ? (s1 ? R.h3h : R.h2h) : (s1 ? R.h1h : R.h0h);
-  uint32_t x = 0xFu >> seat;  // low (4 - seat) bits of every nibble survive the right shift
-  x |= x << 4;
-  x |= x << 8;
-  const uint32_t m1 = x | (x << 16);
-  const uint32_t rot = ((R.a >> seat) & m1) | ((R.a << (4u - seat)) & ~m1);
-  const uint32_t hv = (g.ch == 13) ? (hl << 8) : __builtin_amdgcn_alignbit(hh, hl, 24);  // (u32)(H<<8) : (u32)(H>>24)
-  const uint32_t word = (rot & g.keep_hist) | (hv & g.keep_hand) | (vulnib & g.keep_vul);
-  lo.x = __umul24(word & 0xFu, 0x204081u) & 0x01010101u;
-  lo.y = __umul24((word >> 4) & 0xFu, 0x204081u) & 0x01010101u;
-  lo.z = __umul24((word >> 8) & 0xFu, 0x204081u) & 0x01010101u;
-  lo.w = __umul24((word >> 12) & 0xFu, 0x204081u) & 0x01010101u;
-  hi.x = __umul24((word >> 16) & 0xFu, 0x204081u) & 0x01010101u;
-  hi.y = __umul24((word >> 20) & 0xFu, 0x204081u) & 0x01010101u;
-  hi.z = __umul24((word >> 24) & 0xFu, 0x204081u) & 0x01010101u;
-  hi.w = __umul24(word >> 28, 0x204081u) & 0x01010101u;
-}
-
-// ---- byte-expanded rows kept in LDS ------------------------------------------------------------
-// The fused rollout keeps, per table, the four 480-byte observation rows (one per observer seat)
-// READY-MADE in LDS: a call changes exactly one byte in each of them, a re-deal rebuilds them, and
-// emitting a row is a plain LDS -> HBM copy (two 16-B loads + two 16-B stores per lane for 4 rows).
-constexpr int EXP_ROW = 512;            // bytes reserved per (table, observer seat); 480 used
-constexpr int EXP_TABLE = 4 * EXP_ROW;  // 2 KB per table
-
-// the eight 0/1-byte dwords of one packed dword of a row (see obs_chunk_store)
-__device__ __forceinline__ void obs_chunk_words(uint32_t a, uint64_t H, int seat, uint32_t vulnib, const GroupLane &g,
-                                                uint32_t d[8]) {
-  uint32_t m1 = (0xFu >> seat) * 0x11111111u;
-  uint32_t rot = ((a >> seat) & m1) | ((a << (4 - seat)) & ~m1);
-  uint32_t hv = (g.ch == 13) ? (uint32_t)(H << 8) : (uint32_t)(H >> 24);
-  uint32_t word = (rot & g.keep_hist) | (hv & g.keep_hand) | (vulnib & g.keep_vul);
-#pragma unroll
-  for (int i = 0; i < 8; i++) d[i] = __umul24((word >> (4 * i)) & 0xFu, 0x204081u) & 0x01010101u;
-}
-
-// (re)build the four expanded rows of ONE table from its packed image; wave-cooperative:
-// lane l -> observer seat l/15, packed dword l%15.  vulbits = vul_NS | vul_EW << 1.
-__device__ __forceinline__ void expand_table(const uint8_t *im, uint32_t vulbits, uint8_t *ex, const GroupLane &g) {
-  if (g.r < 4) {
-    const int v = g.r;
-    uint32_t a = *reinterpret_cast<const uint32_t *>(im + 4 * ((g.ch < 13) ? g.ch : 13));
-    uint64_t H = *reinterpret_cast<const uint64_t *>(im + (W_HAND + v) * 8);
-    uint32_t we = (vulbits >> (v & 1)) & 1u, they = (vulbits >> ((v & 1) ^ 1)) & 1u;
-    uint32_t d[8];
-    obs_chunk_words(a, H, v, (we ? 2u : 1u) | (they ? 8u : 4u), g, d);
-    uint4 *dst = reinterpret_cast<uint4 *>(ex + v * EXP_ROW + g.ch * 32);
-    dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
-    dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
-  }
-}
-
 // The 4 x 38 mask bytes of a group are 152 contiguous bytes = 38 dwords: lane l < 38 writes dword
 // l, whose 4 bytes belong to row qa (the first `split` of them) and row qa+1 (the rest).
 struct MaskLane {
@@ -491,7 +408,7 @@ __device__ __forceinline__ void obs_chunk_load(const uint8_t *img_group, int sea
 }
 
 __device__ __forceinline__ void obs_chunk_store(uint32_t a, uint64_t H, int seat, uint32_t vulnib, uint8_t *dst_group,
-                                                const GroupLane &g, int timing_alt = 0) {
+                                                const GroupLane &g) {
   uint32_t m1 = (0xFu >> seat) * 0x11111111u;
   uint32_t rot = ((a >> seat) & m1) | ((a << (4 - seat)) & ~m1);
   uint32_t hv = (g.ch == 13) ? (uint32_t)(H << 8) : (uint32_t)(H >> 24);
@@ -499,28 +416,9 @@ __device__ __forceinline__ void obs_chunk_store(uint32_t a, uint64_t H, int seat
   uint32_t d[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) d[i] = __umul24((word >> (4 * i)) & 0xFu, 0x204081u) & 0x01010101u;
-  if (timing_alt) {  // TIMING EXPERIMENT ONLY (wrong bytes): each instruction writes contiguous 16-B pieces
-    uint4 *d0 = reinterpret_cast<uint4 *>(dst_group + g.r * 480 + g.ch * 16);
-    d0[0] = make_uint4(d[0], d[1], d[2], d[3]);
-    d0[15] = make_uint4(d[4], d[5], d[6], d[7]);
-    return;
-  }
   uint4 *dst = reinterpret_cast<uint4 *>(dst_group + g.out_off);
   dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
   dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
-}
-
-// same, with the row's 4 hand words already in registers (emit waves keep their tables' images
-// in registers between sub-steps; the LDS image is only the hand-over format).  Plain scalars, not an
-// array: a select between array elements is folded into a dynamically indexed load, which drags the
-// array out of registers.
-__device__ __forceinline__ void obs_chunk_store_regs(uint32_t a, uint64_t H0, uint64_t H1, uint64_t H2, uint64_t H3,
-                                                     int seat, uint32_t vulnib, uint8_t *dst_group,
-                                                     const GroupLane &g, int timing_alt = 0) {
-  uint32_t lo01 = (seat & 1) ? (uint32_t)H1 : (uint32_t)H0, hi01 = (seat & 1) ? (uint32_t)(H1 >> 32) : (uint32_t)(H0 >> 32);
-  uint32_t lo23 = (seat & 1) ? (uint32_t)H3 : (uint32_t)H2, hi23 = (seat & 1) ? (uint32_t)(H3 >> 32) : (uint32_t)(H2 >> 32);
-  uint32_t lo = (seat & 2) ? lo23 : lo01, hi = (seat & 2) ? hi23 : hi01;
-  obs_chunk_store(a, ((uint64_t)hi << 32) | lo, seat, vulnib, dst_group, g, timing_alt);
 }
 
 __device__ __forceinline__ void emit_obs_chunk(const uint8_t *img_group, int seat, uint32_t vulnib, uint8_t *dst_group,
@@ -593,71 +491,6 @@ __device__ __forceinline__ int random_legal_action(const Tbl &t, uint64_t legal,
   int a_dbl = (dbl == 1u) ? 1 : 2;
   int a = (k == 0) ? 0 : (dbl ? ((k == 1) ? a_dbl : first_bid + k - 2) : first_bid + k - 1);
   return bits(t.sc, SC_MASKALL, 1) ? k : a;
-}
-
-// ---- lean, straight-line transition for the fused rollout's LOGIC wave ------------------------
-// One uniform-random legal call on a LIVE table (never all-True mask, never illegal): same result as
-// legal_mask() + random_legal_action() + auto_reset_clear() + auction_step(), with no data-dependent
-// branches and no 64-bit popcount — this is the per-table dependency chain of the T-step scan, so
-// every instruction here is paid 32 times in sequence.
-struct LeanStep {
-  uint64_t legal;   // legal_action_mask of the state BEFORE the call
-  int seat;         // seat that acts
-  int action;       // the call
-  int n_legal;      // number of legal calls (for log_prob)
-  uint32_t hb1;     // history bit + 1 (0: none)
-  uint32_t term;    // auction over
-};
-
-__device__ __forceinline__ LeanStep lean_random_step(uint32_t &sc, uint32_t &sch, uint32_t u) {
-  LeanStep r;
-  const uint32_t lb1 = bits(sc, SC_LB1, 6);
-  const uint32_t seat = (bits(sc, SC_DEALER, 2) + bits(sch, SCH_TURN, 9)) & 3u;
-  const uint32_t own = ((bits(sc, SC_LBSEAT, 2) ^ seat) & 1u) ^ 1u;
-  const uint32_t x = bits(sc, SC_X, 1), xx = bits(sc, SC_XX, 1), has = lb1 != 0;
-  const uint32_t can_x = has & (own ^ 1u) & (x ^ 1u) & (xx ^ 1u);
-  const uint32_t can_xx = has & own & x & (xx ^ 1u);
-  const uint32_t dbl = can_x | can_xx;
-  const uint64_t bids = (ALL_ACTIONS >> (3 + lb1)) << (3 + lb1);
-  r.legal = bids | (uint64_t)(1u | (can_x << 1) | (can_xx << 2));
-  const uint32_t n = 36u - lb1 + dbl;  // pass + (35 - lb1) bids + at most one of X / XX
-  const uint32_t k = __umulhi(u, n);   // k-th legal call in ascending order
-  const uint32_t a_bid = 2u + lb1 + k - dbl;
-  const uint32_t a_dbl = can_x ? 1u : 2u;
-  uint32_t a = (dbl & (k == 1u)) ? a_dbl : a_bid;
-  a = (k == 0u) ? 0u : a;
-  uint32_t nn = n;
-  if (bits(sc, SC_MASKALL, 1)) {  // only a caller-supplied finished table can get here (all-True mask)
-    r.legal = ALL_ACTIONS;
-    nn = 38u;
-    a = __umulhi(u, 38u);
-  }
-  r.action = (int)a;
-  r.n_legal = (int)nn;
-  r.seat = (int)seat;
-  // A5 pre-step half of auto_reset (src/utils.py:34-43)
-  const uint32_t was_term = bits(sc, SC_TERM, 1);
-  sc &= ~(1u << SC_TERM);
-  sch = was_term ? (sch & ~(1023u << SCH_STEP)) : sch;
-  // the call
-  const bool is_pass = a == 0u, is_bid = a >= 3u, is_x = a == 1u;
-  const uint32_t b = a - 3u;
-  const uint32_t hb_bid = 9u + 12u * b + seat;
-  const uint32_t hb_dbl = 9u + 12u * (lb1 - 1u) + (is_x ? 4u : 8u) + seat;  // lb1 > 0 when X / XX is legal
-  const uint32_t hb_pass = (lb1 == 0u) ? 5u + seat : 0u;
-  r.hb1 = is_bid ? hb_bid : (is_pass ? hb_pass : hb_dbl);
-  const uint32_t pass = is_pass ? bits(sc, SC_PASS, 3) + 1u : 0u;
-  const uint32_t set_dbl = is_bid ? 0u : ((a == 1u ? (1u << SC_X) : 0u) | (a == 2u ? (1u << SC_XX) : 0u));
-  const uint32_t bid_clear = (63u << SC_LB1) | (3u << SC_LBSEAT) | (1u << SC_X) | (1u << SC_XX);
-  const uint32_t bid_set = ((b + 1u) << SC_LB1) | (seat << SC_LBSEAT);
-  uint32_t nsc = is_bid ? ((sc & ~bid_clear) | bid_set) : (sc | set_dbl);
-  const uint32_t nlb1 = is_bid ? b + 1u : lb1;
-  const uint32_t term = pass == ((nlb1 != 0u) ? 3u : 4u);
-  nsc = (nsc & ~(7u << SC_PASS)) | (pass << SC_PASS) | (term ? ((1u << SC_TERM) | (1u << SC_MASKALL)) : 0u);
-  sc = nsc;
-  sch += (1u << SCH_STEP) + (term ? 0u : (1u << SCH_TURN));
-  r.term = term;
-  return r;
 }
 
 }  // namespace brl
