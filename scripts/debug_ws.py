@@ -1,6 +1,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from brl_amd import _capi as _c0
+if os.environ.get('LIB'):
+    _c0.LIB_PATH = os.environ['LIB']
 import brl_amd
 from oracle import Oracle
 d = np.load("tests/golden/wb5_dds_1000.npz")

@@ -7,7 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "../../include/brl_hip.h"
+#include "../include/brl_hip.h"
 #include "bridge_device.hpp"
 
 using namespace brl;
@@ -365,15 +365,8 @@ constexpr int WS_RING = 12;     // boards kept ahead per table (see the loader w
 // word 1: scalar word `sc` right after sub-step s-1 (before any re-deal)
 // word 2: legal mask of state s, low 32 | word 3: [5:0] legal high ; [13:8] action of sub-step s-1
 
-// Command batches: short at the start so that the follower waves — and with them the HBM stores, which
-// the kernel is bound by — start after ONE sub-step instead of eight; slot s is entry s - ws_bstart(b)
-// of batch b.
-__device__ __forceinline__ int ws_bstart(int b) { return (b < 4) ? ((1 << b) >> 1) : 8 * (b - 3); }  // 0,1,2,4,8,16,24,..
-__device__ __forceinline__ int ws_blen(int b) { return (b < 4) ? ((b == 0) ? 1 : (1 << (b - 1))) : WS_BATCH; }  // 1,1,2,4,8,8,..
-__device__ __forceinline__ int ws_nbatch(int total) {  // batches needed for slots 0..total
-  if (total < 8) return (total < 1) ? 1 : ((total < 2) ? 2 : ((total < 4) ? 3 : 4));
-  return 4 + (total - 8) / WS_BATCH + 1;
-}
+__device__ __forceinline__ int ws_bstart(int b) { return b * WS_BATCH; }
+__device__ __forceinline__ int ws_blen(int b) { return WS_BATCH; }
 
 __device__ __forceinline__ void lds_barrier() {
   // LDS-visible workgroup barrier that leaves global loads/stores in flight (no vmcnt wait)
@@ -444,90 +437,70 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
     img64[i] = (tb < A.n) ? A.state[table0 * 16 + i] : 0ull;
   }
   if (tid <= BRL_NUM_ACTIONS) s_neglog[tid] = A.neg_log_n[tid];
-  const int total = A.T * A.substeps;   // sub-steps; command slots are s = 0..total
-  const int nbatch = ws_nbatch(total);  // batches of command slots (ws_bstart / ws_blen)
-  const int tl = c.lane;                // logic / loader / scorer: lane = table
+  __syncthreads();
+  const int total = A.T * A.substeps;          // sub-steps; command slots are s = 0..total
+  const int nbatch = (total + 1 + B - 1) / B;  // batches of command slots; slot s is entry s % B of batch s / B
+  const int tl = c.lane;                       // logic / loader / scorer: lane = table
   const int tls = (tl < TPB) ? tl : 0;
   const bool valid = (tl < TPB) && (table0 + tl < A.n);
   const uint64_t env_id = A.env_offset + (uint64_t)(table0 + tl);
-  // loader state (wave 1): next board to fetch, boards in flight
-  uint32_t nb = 0, nb0 = 0, pbase = 0, pidx[3] = {0, 0, 0}, pscb[3] = {0, 0, 0};
-  int4 pk[3], pv[3];
-  if (wave == 1 && valid) {  // the first two boards of every table, in parallel with the image load above
-    nb0 = (uint32_t)(A.state[(table0 + tl) * 16 + W_CTR] >> 32) + 1u;
-    nb = nb0;
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-      board_params(A.g, env_id, nb + (uint32_t)k, A.lut.len, pidx[k], pscb[k]);
-      pk[k] = A.lut.keys[pidx[k]];
-      pv[k] = A.lut.values[pidx[k]];
-    }
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-      uint4 *dst = reinterpret_cast<uint4 *>(&ring[tl][(nb + (uint32_t)k) % WS_RING][0]);
-      dst[0] = make_uint4((uint32_t)pk[k].x, (uint32_t)pk[k].y, (uint32_t)pk[k].z, (uint32_t)pk[k].w);
-      dst[1] = make_uint4((uint32_t)pv[k].x, (uint32_t)pv[k].y, (uint32_t)pv[k].z, (uint32_t)pv[k].w);
-      dst[2] = make_uint4(pidx[k], pscb[k], 0u, 0u);
-    }
-    nb += 2u;
-  }
-  __syncthreads();  // images + the first two boards of the ring are in LDS
 
   if (wave == 1) {
     // ------------------------------------------------------------------ loader wave
-    // (its first two boards were fetched in the prologue, before the workgroup's first barrier)
-    uint32_t pcount = 0;  // boards whose loads were issued in the previous iteration
-    uint32_t dealt_total = 0, dealt_prev_total = 0;
-    for (int bi = 0; bi < nbatch; bi++) {
-      LDS_BARRIER();
-      // commit what was issued one batch ago (its loads landed long before)
+    uint32_t nb = 0;  // next board number of this slot to fetch
+    auto fetch = [&](uint32_t count) {  // fetch boards nb .. nb+count-1 into their ring slots
+      uint32_t idx[3], scb[3];
+      int4 kk[3], vv[3];
 #pragma unroll
       for (int k = 0; k < 3; k++) {
-        if ((uint32_t)k < pcount) {
-          uint4 *dst = reinterpret_cast<uint4 *>(&ring[tls][(pbase + (uint32_t)k) % WS_RING][0]);
-          dst[0] = make_uint4((uint32_t)pk[k].x, (uint32_t)pk[k].y, (uint32_t)pk[k].z, (uint32_t)pk[k].w);
-          dst[1] = make_uint4((uint32_t)pv[k].x, (uint32_t)pv[k].y, (uint32_t)pv[k].z, (uint32_t)pv[k].w);
-          dst[2] = make_uint4(pidx[k], pscb[k], 0u, 0u);
+        if ((uint32_t)k < count) {
+          board_params(A.g, env_id, nb + (uint32_t)k, A.lut.len, idx[k], scb[k]);
+          kk[k] = A.lut.keys[idx[k]];
+          vv[k] = A.lut.values[idx[k]];
         }
       }
-      pcount = 0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        if ((uint32_t)k < count) {
+          uint4 *dst = reinterpret_cast<uint4 *>(&ring[tls][(nb + (uint32_t)k) % WS_RING][0]);
+          dst[0] = make_uint4((uint32_t)kk[k].x, (uint32_t)kk[k].y, (uint32_t)kk[k].z, (uint32_t)kk[k].w);
+          dst[1] = make_uint4((uint32_t)vv[k].x, (uint32_t)vv[k].y, (uint32_t)vv[k].z, (uint32_t)vv[k].w);
+          dst[2] = make_uint4(idx[k], scb[k], 0u, 0u);
+        }
+      }
+      nb += count;
+    };
+    if (valid) {
+      nb = (uint32_t)(img64[tl * 16 + W_CTR] >> 32) + 1u;
+      fetch(2);  // the first two boards before anybody starts (a third is needed at sub-step 8 at the earliest)
+    }
+    __syncthreads();  // ring[.. +2] ready
+    if (valid)
+      for (int k = 0; k < (WS_RING - 2 + 2) / 3; k++) fetch(min(3u, (uint32_t)(WS_RING - 2 - 3 * k)));  // rest of the ring, in the background
+    uint32_t dealt_prev = 0;
+    for (int bi = 0; bi < nbatch; bi++) {
+      LDS_BARRIER();
       uint32_t dealt = 0;  // boards this table consumed in batch bi
-      for (int j = 0; j < ws_blen(bi); j++) {
-        const int s = ws_bstart(bi) + j;
+      for (int j = 0; j < B; j++) {
+        const int s = bi * B + j;
         if (s <= total) dealt += (cmd[bi & 1][j][tls][0] >> 9) & 1u;
       }
-      // keep WS_RING boards ahead of what had been consumed by the end of batch bi-1 (slots of boards
-      // dealt in batch bi are still being read by the scorer / emit waves): at most 3 fetches per batch,
-      // issued now, committed after the next barrier — the loader never holds a barrier up.
-      const uint32_t want = nb0 + (uint32_t)WS_RING + dealt_prev_total;
-      if (valid && nb < want) {
-        pbase = nb;
-        pcount = min(3u, want - nb);
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          if ((uint32_t)k < pcount) {
-            board_params(A.g, env_id, nb + (uint32_t)k, A.lut.len, pidx[k], pscb[k]);
-            pk[k] = A.lut.keys[pidx[k]];
-            pv[k] = A.lut.values[pidx[k]];
-          }
-        }
-        nb += pcount;
-      }
-      dealt_prev_total = dealt_total;
-      dealt_total += dealt;
+      if (valid && dealt_prev) fetch(dealt_prev);  // slots of batch bi-1's boards are free now
+      dealt_prev = dealt;
     }
   } else if (wave == 0) {
     // ------------------------------------------------------------------ logic wave
     Tbl t;
     load_scalars(t, img + tls * TABLE_BYTES);  // only sc / sch / lut / bctr are live here
+    __syncthreads();                           // ring ready
     __builtin_amdgcn_s_setprio(3);             // the critical chain wins issue arbitration on its SIMD
     uint32_t rb[4] = {0, 0, 0, 0};
     uint32_t rb_idx = 0xFFFFFFFFu;
     uint32_t pend = 0, pend_act = 0, pend_sc = 0, term_any = 0;
     int sub = 0;
     for (int bi = 0; bi < nbatch; bi++) {
-      for (int j = 0; j < ws_blen(bi); j++) {
-        const int s = ws_bstart(bi) + j;
+      for (int j = 0; j < B; j++) {
+        const int s = bi * B + j;
         if (s > total) break;
         const uint64_t legal = legal_mask(t);
         const int oseat = cur_seat(t);
@@ -587,6 +560,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
     __shared__ uint32_t minfo[WS_BATCH][64];                          // per macro-step: actor, action, n_legal, done
     Tbl ts;
     load_scalars(ts, img + tls * TABLE_BYTES);  // fd / tricks / rewards are live here
+    __syncthreads();                            // ring ready
     int sub = 0;
     uint32_t cur_info = 0, tcount = 0;
     int64_t row = table0 + tl;  // this table's Transition row of the next macro-step to be written
@@ -599,8 +573,8 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
       // acc[0] carries the partial sums of a macro-step that straddles the batch boundary
 #pragma unroll
       for (int q = 1; q < B; q++) *reinterpret_cast<int4 *>(&acc[q][tl][0]) = make_int4(0, 0, 0, 0);
-      for (int j = 0; j < ws_blen(bi); j++) {
-        const int s = ws_bstart(bi) + j;
+      for (int j = 0; j < B; j++) {
+        const int s = bi * B + j;
         if (s > total) break;
         if (s == 0) continue;  // cmd slot 0 describes no sub-step
         const uint4 w = *reinterpret_cast<const uint4 *>(&cmd[bi & 1][j][tls][0]);
@@ -682,99 +656,114 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
     }
   } else {
     // ------------------------------------------------------------------ emit waves
+    // The emit waves execute their instruction stream serially (one wave, no ILP), so the cost of a
+    // sub-step is simply (instructions x ~4 cycles): the hot path below is straight-line and small.
+    //   * each wave keeps the images of its tables IN REGISTERS (RowRegs: lane (r, ch) = history dword ch
+    //     of row r + the row's hand words); a call is applied with a few VALU ops on the owning lane;
+    //   * all commands of a batch are loaded up front (ONE LDS round trip per batch) and the sub-steps
+    //     are processed from registers in an unrolled loop;
+    //   * a re-deal (about one table in 25 per sub-step) and ragged groups take the slow path.
+    __syncthreads();  // ring ready
     const GroupLane gl = make_group_lane();
     const MaskLane ml = make_mask_lane();
     constexpr int NG = TPB / 4;              // groups of 4 consecutive tables
-    constexpr int GPW = (NG + NE - 1) / NE;  // groups per emit wave, interleaved to overlap LDS latency
+    constexpr int GPW = (NG + NE - 1) / NE;  // groups per emit wave
     const bool head = (gl.r < 4) && (gl.ch == 0);  // one lane per row does the row's bookkeeping
     const int rr = (gl.r < 4) ? gl.r : 3;
     int sub = 0;            // s % substeps
     int64_t row0 = table0;  // first Transition row of this workgroup at macro-step s / substeps
-    int left[GPW];          // rows of each group that exist (0..4)
+    int left[GPW];
+    RowRegs R[GPW];
 #pragma unroll
     for (int k = 0; k < GPW; k++) {
       const int g = (wave - 3) + k * NE;
       int64_t rem = (g < NG && !(A.debug & 1)) ? A.n - (table0 + 4 * g) : 0;
       left[k] = (int)max((int64_t)0, min((int64_t)4, rem));
+      rows_load(R[k], img + (4 * ((left[k] > 0) ? g : 0) + rr) * TABLE_BYTES, gl);
     }
     for (int bi = 0; bi < nbatch; bi++) {
       LDS_BARRIER();
-      for (int j = 0; j < ws_blen(bi); j++) {
-        const int s = ws_bstart(bi) + j;
-        if (s > total) break;
-        const bool fin = (s == total);  // the post-rollout state: emitted as last_obs / last_mask
-        const bool emit = ((s < total) && (sub == 0) && !(A.debug & 2)) || (fin && (A.last_obs || A.last_mask));
-        uint8_t *obs_base = fin ? A.last_obs : A.out.obs;
-        uint8_t *mask_base = fin ? A.last_mask : A.out.legal_action_mask;
-        const int64_t rowb = fin ? table0 : row0;
-        const uint32_t(*cs)[CMD_WORDS] = cmd[bi & 1][j];
-        // ---- round trip 1: each row's command
-        uint32_t w0[GPW];
+      const int blen = ws_blen(bi), bstart = ws_bstart(bi);
 #pragma unroll
-        for (int k = 0; k < GPW; k++) {
-          const int g = (wave - 3) + k * NE;
-          w0[k] = (left[k] > 0) ? cs[4 * g + rr][0] : 0u;
-        }
-        // ---- apply sub-step s-1 to the images (one history bit, or a freshly dealt board), then
-        //      round trip 2: image dwords + legal masks.  No wait in between: same-wave LDS order.
-        uint32_t a[GPW];
-        uint64_t H[GPW], la[GPW], lb[GPW];
-#pragma unroll
-        for (int k = 0; k < GPW; k++) {
-          const int g = (wave - 3) + k * NE;
-          if (left[k] <= 0) continue;
-          uint8_t *img_g = img + 4 * g * TABLE_BYTES;
-          const bool is_head = head && (gl.r < left[k]);
-          if (is_head && !(w0[k] & 0x200u) && (w0[k] & 0x1FFu)) {
-            int hb = (int)(w0[k] & 0x1FFu) - 1;
-            atomicOr(reinterpret_cast<uint32_t *>(img_g + gl.r * TABLE_BYTES) + (hb >> 5), 1u << (hb & 31));
-          }
-          uint64_t dealm = __ballot(is_head && (w0[k] & 0x200u));
-          if (dealm) {  // rare: ~1 table in 25 per sub-step
-            do {
-              const int l = __ffsll((unsigned long long)dealm) - 1;  // lane 15*q holds row q's command
-              dealm &= dealm - 1ull;
+      for (int k = 0; k < GPW; k++) {
+        const int g = (wave - 3) + k * NE;
+        if (left[k] <= 0) continue;
+        const bool rowok = gl.r < left[k];
+        const bool full = left[k] == 4;
+        int sub_k = sub;
+        uint8_t *obs_p = A.out.obs ? A.out.obs + (row0 + 4 * g) * BRL_OBS_SIZE : nullptr;  // rows of this group, this macro-step
+        uint8_t *mask_p = A.out.legal_action_mask ? A.out.legal_action_mask + (row0 + 4 * g) * BRL_NUM_ACTIONS : nullptr;
+#pragma nounroll
+        for (int j = 0; j < blen; j++) {
+          const int s = bstart + j;
+          if (s > total) break;
+          const uint32_t w0 = rowok ? cmd[bi & 1][j][4 * g + rr][0] : 0u;
+          const uint64_t la_j = *reinterpret_cast<const uint64_t *>(&cmd[bi & 1][j][4 * g + ml.qa][2]);
+          const uint64_t lb_j = *reinterpret_cast<const uint64_t *>(&cmd[bi & 1][j][4 * g + ml.qb][2]);
+          // ---- apply sub-step s-1: one history bit (in registers), or a freshly dealt board (slow path)
+          rows_apply(R[k], w0, gl);
+          if (__builtin_expect(__ballot((w0 & 0x200u) != 0) != 0ull, 0)) {
+            uint64_t dm = __ballot(head && (w0 & 0x200u));
+            uint8_t *img_g = img + 4 * g * TABLE_BYTES;
+            while (dm) {
+              const int l = __ffsll((unsigned long long)dm) - 1;  // lane 15*q holds row q's command
+              dm &= dm - 1ull;
               const int q = l / 15;
-              const uint32_t wq = __builtin_amdgcn_readlane(w0[k], l);
+              const uint32_t wq = __builtin_amdgcn_readlane(w0, l);
               const uint4 kk = *reinterpret_cast<const uint4 *>(&ring[4 * g + q][(wq >> 16) & 15u][0]);
               deal_image(img_g + q * TABLE_BYTES, kk.x, kk.y, kk.z, kk.w, c);
-            } while (dealm);
+            }
+            wave_lds_order();
+            if (w0 & 0x200u) rows_load(R[k], img + (4 * g + rr) * TABLE_BYTES, gl);  // lanes of a dealt row (history is 0 there)
           }
-          wave_lds_order();
+          // ---- emit: slots < total write Transition row s / substeps (first sub-step only); slot `total`
+          //      is the post-rollout state -> last_obs / last_mask
+          const bool fin = (s == total);
+          const bool emit = fin ? true : ((sub_k == 0) && !(A.debug & 2));
+          uint8_t *od = fin ? (A.last_obs ? A.last_obs + (table0 + 4 * g) * BRL_OBS_SIZE : nullptr) : obs_p;
+          uint8_t *md = fin ? (A.last_mask ? A.last_mask + (table0 + 4 * g) * BRL_NUM_ACTIONS : nullptr) : mask_p;
           if (emit) {
-            obs_chunk_load(img_g, (int)((w0[k] >> 10) & 3u), gl, a[k], H[k]);
-            la[k] = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
-            lb[k] = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
-          }
-        }
-        if (emit) {
-#pragma unroll
-          for (int k = 0; k < GPW; k++) {
-            const int g = (wave - 3) + k * NE;
-            if (left[k] <= 0) continue;
-            // ---- the 4 observation rows: two 16-B stores per lane
-            if (gl.r < left[k] && obs_base)
-              obs_chunk_store(a[k], H[k], (int)((w0[k] >> 10) & 3u), (w0[k] >> 12) & 15u,
-                              obs_base + (rowb + 4 * g) * BRL_OBS_SIZE, gl);
-            // ---- the 4 mask rows
-            if (mask_base) {
-              uint8_t *mdst = mask_base + (rowb + 4 * g) * BRL_NUM_ACTIONS;
-              if (left[k] >= 4) {  // 152 contiguous bytes, one dword per lane
-                if (ml.active) reinterpret_cast<uint32_t *>(mdst)[c.lane] = mask_dword(la[k], lb[k], ml);
+            if (od) {
+              uint4 lo, hi;
+              rows_words(R[k], (w0 >> 10) & 3u, (w0 >> 12) & 15u, gl, lo, hi);
+              if (rowok) {
+                uint4 *dst = reinterpret_cast<uint4 *>(od + gl.out_off);
+                dst[0] = lo;
+                dst[1] = hi;
+              }
+            }
+            if (md) {
+              if (full) {  // 152 contiguous bytes, one dword per lane
+                if (ml.active) reinterpret_cast<uint32_t *>(md)[c.lane] = mask_dword(la_j, lb_j, ml);
               } else {  // ragged tail of the batch: row by row
                 for (int q = 0; q < left[k]; q++) {
-                  uint64_t lq = *reinterpret_cast<const uint64_t *>(&cs[4 * g + q][2]);
-                  emit_mask_row(lq, mdst + q * BRL_NUM_ACTIONS, c);
+                  uint64_t lq = *reinterpret_cast<const uint64_t *>(&cmd[bi & 1][j][4 * g + q][2]);
+                  emit_mask_row(lq, md + q * BRL_NUM_ACTIONS, c);
                 }
               }
             }
           }
+          if (!fin && ++sub_k == A.substeps) {
+            sub_k = 0;
+            if (obs_p) obs_p += (A.debug & 32) ? 0 : A.n * BRL_OBS_SIZE;
+            if (mask_p) mask_p += (A.debug & 32) ? 0 : A.n * BRL_NUM_ACTIONS;
+          }
         }
+      }
+      for (int j = 0; j < blen; j++) {  // advance the macro-step cursor past this batch
+        if (bstart + j >= total) break;
         if (++sub == A.substeps) {
           sub = 0;
           row0 += (A.debug & 32) ? 0 : A.n;
         }
       }
+    }
+    // hand the history back to the LDS images (the hand words there are already current)
+#pragma unroll
+    for (int k = 0; k < GPW; k++) {
+      const int g = (wave - 3) + k * NE;
+      if (left[k] > 0 && gl.r < left[k] && gl.ch <= 13)
+        *reinterpret_cast<uint32_t *>(img + (4 * g + gl.r) * TABLE_BYTES + 4 * gl.ch) = R[k].a;
     }
   }
 #ifdef BRL_TIMING

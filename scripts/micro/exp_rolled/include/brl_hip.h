@@ -1,0 +1,181 @@
+/*
+ * brl_hip.h — C-ABI of libbrl_hip.so: the MI355X-native (gfx950) bridge-bidding
+ * environment + PPO-rollout hot path of harukaki/brl.
+ *
+ * The reference has no FFI layer: its boundary for this path is the Python API of
+ * pgx.bridge_bidding plus src/{utils,roll_out,duplicate,gae}.py.  Each entry point below
+ * names the reference interface it replaces (file:line under /root/reference).  The
+ * Python host mirror in brl_amd/ binds these with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (BRL_E_*); the message is in the
+ *     thread-local brl_last_error().
+ *   - unless a parameter says "host", every pointer is a DEVICE pointer on the handle's
+ *     GPU, owned by the caller (e.g. torch tensors: tensor.data_ptr()).  The library owns
+ *     only the handle, its device copy of the double-dummy LUT and a small constant table.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and nothing
+ *     synchronises the device (pass torch.cuda.current_stream().cuda_stream).
+ *   - a handle is not thread-safe; use one per (device, stream).
+ *   - per-table state is caller-owned and opaque: BRL_STATE_WORDS x uint64 per table
+ *     (128 B, bit-packed: DESIGN.md "Data layout").  state_in == state_out is allowed.
+ *   - batch arrays are batch-major [n, ...]; rollout outputs are time-major [T, n, ...]
+ *     exactly like the reference's traj_batch (src/roll_out.py:105-107).
+ *   - bool arrays are 1 byte per element (0/1), like the reference's jnp.bool_ arrays.
+ */
+#ifndef BRL_HIP_H
+#define BRL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BRL_STATE_WORDS 16  /* uint64 words per table */
+#define BRL_OBS_SIZE 480    /* env.observation_shape == (480,)  ppo.py:241 */
+#define BRL_NUM_ACTIONS 38  /* 0 Pass, 1 X, 2 XX, 3.. bids      src/duplicate.py:9-12 */
+
+#define BRL_OK 0
+#define BRL_E_ARG (-1)     /* bad argument */
+#define BRL_E_HIP (-2)     /* a HIP runtime call failed */
+#define BRL_E_NOLUT (-3)   /* a reset was requested but the handle has no LUT */
+
+typedef struct brl_handle brl_handle;
+
+const char *brl_last_error(void);
+int brl_version(void);
+
+/* BridgeBidding(dds_results_table_path)  — ppo.py:303, pgx.bridge_bidding.BridgeBidding.
+ * lut_keys/lut_values: HOST pointers, int32 [lut_len,4] each, pgx packing (key: one word
+ * per suit S,H,D,C, 13 base-4 digits = owner seat; value: one word per declarer seat, 5
+ * hex digits = tricks in C,D,H,S,NT).  lut_len may be 0 (explicit deals only). */
+int brl_create(int device, const int32_t *lut_keys, const int32_t *lut_values, int64_t lut_len,
+               brl_handle **out);
+/* LUT rotation — ppo.py:525-549 swaps the hash table; same arguments as brl_create. */
+int brl_set_lut(brl_handle *h, const int32_t *lut_keys, const int32_t *lut_values, int64_t lut_len);
+int brl_destroy(brl_handle *h);
+
+/* Seed of the counter-based RNG (Philox4x32-10) and the global index of this handle's
+ * table 0 (rank * num_envs when env shards are spread over GPUs).  Replaces the PRNGKey
+ * plumbing of ppo.py:314-333 / src/utils.py:49. */
+int brl_set_rng(brl_handle *h, uint64_t seed, uint64_t env_offset);
+
+/* jax.vmap(env.init)(keys)  — ppo.py:305,318.  Deals board number `board_ctr0` of every
+ * table's stream: uniform LUT row, dealer, vulnerabilities, one of the 8 team-preserving
+ * seatings. */
+int brl_init_random(brl_handle *h, uint64_t *state, int64_t n, uint32_t board_ctr0, void *stream);
+
+/* Explicit deals — the fields _duplicate_init copies (src/duplicate.py:120-128).
+ * hand int32 [n,52] (13 pgx card ids per seat N,E,S,W), dealer int32 [n], vul_ns/vul_ew
+ * uint8 [n], shuffled_players int32 [n,4] (seat -> player id), tricks uint8 [n,20]
+ * ([declarer seat][C,D,H,S,NT]). */
+int brl_init_from_deals(brl_handle *h, uint64_t *state, int64_t n, const int32_t *hand,
+                        const int32_t *dealer, const uint8_t *vul_ns, const uint8_t *vul_ew,
+                        const int32_t *shuffled_players, const uint8_t *tricks, void *stream);
+
+/* env.step(state, action) — src/utils.py:44 (pgx core.Env.step); with autoreset != 0 it is
+ * auto_reset(env.step, env.init) — src/utils.py:9-58.  action int32 [n].
+ * Optional outputs for the NEW state (any may be NULL): obs uint8 [n,480] and
+ * mask uint8 [n,38] of the new current player, rewards float [n,4] by player id,
+ * terminated uint8 [n], current_player int32 [n]. */
+int brl_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+             const int32_t *action, int autoreset, uint8_t *obs, uint8_t *mask, float *rewards,
+             uint8_t *terminated, int32_t *current_player, void *stream);
+
+/* _observe(state, player_id) — src/duplicate.py:6,134; player_id int32 [n] or NULL for
+ * state.current_player.  obs uint8 [n,480]; mask uint8 [n,38] = state.legal_action_mask
+ * (either may be NULL). */
+int brl_observe(brl_handle *h, const uint64_t *state, int64_t n, const int32_t *player_id,
+                uint8_t *obs, uint8_t *mask, void *stream);
+
+/* State attribute access (pgx State fields).  Every pointer may be NULL. */
+typedef struct brl_fields {
+  int32_t *current_player;        /* [n]    */
+  uint8_t *terminated;            /* [n]    */
+  float *rewards;                 /* [n,4]  */
+  int32_t *step_count;            /* [n]    */
+  int32_t *turn;                  /* [n]    */
+  int32_t *dealer;                /* [n]    */
+  uint8_t *vul_ns;                /* [n]    */
+  uint8_t *vul_ew;                /* [n]    */
+  int32_t *shuffled_players;      /* [n,4]  */
+  int32_t *last_bid;              /* [n]    */
+  int32_t *last_bidder;           /* [n] player id, -1 none */
+  uint8_t *call_x;                /* [n]    */
+  uint8_t *call_xx;               /* [n]    */
+  int32_t *pass_num;              /* [n]    */
+  int32_t *first_denomination_ns; /* [n,5] seat, -1 none */
+  int32_t *first_denomination_ew; /* [n,5]  */
+  int32_t *hand;                  /* [n,52] ascending card ids per seat */
+  uint8_t *tricks;                /* [n,20] */
+  int32_t *lut_idx;               /* [n] -1 for explicit deals */
+  uint32_t *board_ctr;            /* [n]    */
+  uint8_t *illegal;               /* [n] an illegal action was taken on this table */
+} brl_fields;
+int brl_get_fields(brl_handle *h, const uint64_t *state, int64_t n, const brl_fields *out, void *stream);
+
+/* Transition — src/roll_out.py:13-20; time-major [T,n,...].  Any pointer may be NULL. */
+typedef struct brl_transition {
+  uint8_t *done;               /* [T,n]      */
+  int32_t *action;             /* [T,n]      */
+  float *value;                /* [T,n]      */
+  float *reward;               /* [T,n]  rewards[actor] / reward_scale */
+  float *log_prob;             /* [T,n]      */
+  uint8_t *obs;                /* [T,n,480]  */
+  uint8_t *legal_action_mask;  /* [T,n,38]   */
+} brl_transition;
+
+/* roll_out with the uniform-random masked policy, T-loop fused into one launch —
+ * src/roll_out.py:49-108 with auto_reset(env.step, env.init) (src/utils.py:9-58) and
+ * normal_step (substeps=1, src/utils.py:249-254) or the 4-sub-step competitive macro-step
+ * with all seats random (substeps=4, src/utils.py:69-128).  state is updated in place.
+ * draw_base: index of the first action draw (advance by T*substeps between calls).
+ * last_obs uint8 [n,480] / last_mask uint8 [n,38]: observation and legal mask of the post-rollout
+ * state, i.e. runner_state's last_obs of src/roll_out.py:95-102 (either may be NULL).
+ * terminated_count: device int64 accumulated like src/roll_out.py:85 (may be NULL). */
+int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int num_steps, int substeps,
+                       uint32_t draw_base, float reward_scale, const brl_transition *out,
+                       uint8_t *last_obs, uint8_t *last_mask, int64_t *terminated_count, void *stream);
+
+/* One policy sub-step: masked categorical over `logits` float [n,38] for the current
+ * player (mode 0: sample, src/roll_out.py:79-81 / src/utils.py:83-85; mode 1: arg-max,
+ * src/utils.py:157,174 / src/evaluation.py:135), then auto_reset(env.step) when
+ * autoreset != 0.  Uses draw index `draw` of each table's action stream.
+ * Outputs (any may be NULL): action int32 [n], log_prob float [n] (log-softmax over legal
+ * actions at the chosen action), then as brl_step.  rewards_acc float [n,4] and
+ * terminated_acc uint8 [n], when given, are ACCUMULATED (+=, |=) — src/utils.py:126-127. */
+int brl_policy_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                    const float *logits, int mode, uint32_t draw, int autoreset, int32_t *action,
+                    float *log_prob, uint8_t *obs, uint8_t *mask, float *rewards_acc,
+                    uint8_t *terminated_acc, int32_t *current_player, void *stream);
+
+/* calc_gae's reverse scan — src/gae.py:20-39.  done uint8 [T,n], value/reward float
+ * [T,n], last_val float [n]; gamma_lambda = float32(gamma * gae_lambda). */
+int brl_gae(brl_handle *h, const uint8_t *done, const float *value, const float *reward,
+            const float *last_val, float gamma, float gamma_lambda, int T, int64_t n,
+            float *advantages, float *targets, void *stream);
+
+/* _imp_reward — src/duplicate.py:15-70.  a, b, out float [n,4]. */
+int brl_imp_reward(brl_handle *h, const float *a, const float *b, float *out, int64_t n, void *stream);
+
+/* Table_info — src/duplicate.py:138-144 (struct of arrays). */
+typedef struct brl_table_info {
+  uint8_t *terminated;  /* [n]   */
+  float *rewards;       /* [n,4] */
+  int32_t *last_bid;    /* [n]   */
+  int32_t *last_bidder; /* [n]   */
+  uint8_t *call_x;      /* [n]   */
+  uint8_t *call_xx;     /* [n]   */
+} brl_table_info;
+
+/* duplicate_step(env.step) — src/duplicate.py:147-192; table_a/table_b updated in place.
+ * Optional outputs as brl_step (rewards = the IMP vector on the step table B ends, else 0). */
+int brl_duplicate_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                       const int32_t *action, const brl_table_info *table_a,
+                       const brl_table_info *table_b, uint8_t *obs, uint8_t *mask, float *rewards,
+                       uint8_t *terminated, int32_t *current_player, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRL_HIP_H */

@@ -7,8 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "../../include/brl_hip.h"
-#include "bridge_device.hpp"
+#include "/root/repo/include/brl_hip.h"
+#include "/root/repo/brl_amd/csrc/bridge_device.hpp"
 
 using namespace brl;
 
@@ -365,12 +365,9 @@ constexpr int WS_RING = 12;     // boards kept ahead per table (see the loader w
 // word 1: scalar word `sc` right after sub-step s-1 (before any re-deal)
 // word 2: legal mask of state s, low 32 | word 3: [5:0] legal high ; [13:8] action of sub-step s-1
 
-// Command batches: short at the start so that the follower waves — and with them the HBM stores, which
-// the kernel is bound by — start after ONE sub-step instead of eight; slot s is entry s - ws_bstart(b)
-// of batch b.
 __device__ __forceinline__ int ws_bstart(int b) { return (b < 4) ? ((1 << b) >> 1) : 8 * (b - 3); }  // 0,1,2,4,8,16,24,..
 __device__ __forceinline__ int ws_blen(int b) { return (b < 4) ? ((b == 0) ? 1 : (1 << (b - 1))) : WS_BATCH; }  // 1,1,2,4,8,8,..
-__device__ __forceinline__ int ws_nbatch(int total) {  // batches needed for slots 0..total
+__device__ __forceinline__ int ws_nbatch(int total) {
   if (total < 8) return (total < 1) ? 1 : ((total < 2) ? 2 : ((total < 4) ? 3 : 4));
   return 4 + (total - 8) / WS_BATCH + 1;
 }
@@ -444,82 +441,62 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
     img64[i] = (tb < A.n) ? A.state[table0 * 16 + i] : 0ull;
   }
   if (tid <= BRL_NUM_ACTIONS) s_neglog[tid] = A.neg_log_n[tid];
-  const int total = A.T * A.substeps;   // sub-steps; command slots are s = 0..total
-  const int nbatch = ws_nbatch(total);  // batches of command slots (ws_bstart / ws_blen)
-  const int tl = c.lane;                // logic / loader / scorer: lane = table
+  __syncthreads();
+  const int total = A.T * A.substeps;          // sub-steps; command slots are s = 0..total
+  const int nbatch = ws_nbatch(total);
+  const int tl = c.lane;                       // logic / loader / scorer: lane = table
   const int tls = (tl < TPB) ? tl : 0;
   const bool valid = (tl < TPB) && (table0 + tl < A.n);
   const uint64_t env_id = A.env_offset + (uint64_t)(table0 + tl);
-  // loader state (wave 1): next board to fetch, boards in flight
-  uint32_t nb = 0, nb0 = 0, pbase = 0, pidx[3] = {0, 0, 0}, pscb[3] = {0, 0, 0};
-  int4 pk[3], pv[3];
-  if (wave == 1 && valid) {  // the first two boards of every table, in parallel with the image load above
-    nb0 = (uint32_t)(A.state[(table0 + tl) * 16 + W_CTR] >> 32) + 1u;
-    nb = nb0;
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-      board_params(A.g, env_id, nb + (uint32_t)k, A.lut.len, pidx[k], pscb[k]);
-      pk[k] = A.lut.keys[pidx[k]];
-      pv[k] = A.lut.values[pidx[k]];
-    }
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-      uint4 *dst = reinterpret_cast<uint4 *>(&ring[tl][(nb + (uint32_t)k) % WS_RING][0]);
-      dst[0] = make_uint4((uint32_t)pk[k].x, (uint32_t)pk[k].y, (uint32_t)pk[k].z, (uint32_t)pk[k].w);
-      dst[1] = make_uint4((uint32_t)pv[k].x, (uint32_t)pv[k].y, (uint32_t)pv[k].z, (uint32_t)pv[k].w);
-      dst[2] = make_uint4(pidx[k], pscb[k], 0u, 0u);
-    }
-    nb += 2u;
-  }
-  __syncthreads();  // images + the first two boards of the ring are in LDS
 
   if (wave == 1) {
     // ------------------------------------------------------------------ loader wave
-    // (its first two boards were fetched in the prologue, before the workgroup's first barrier)
-    uint32_t pcount = 0;  // boards whose loads were issued in the previous iteration
-    uint32_t dealt_total = 0, dealt_prev_total = 0;
-    for (int bi = 0; bi < nbatch; bi++) {
-      LDS_BARRIER();
-      // commit what was issued one batch ago (its loads landed long before)
+    uint32_t nb = 0;  // next board number of this slot to fetch
+    auto fetch = [&](uint32_t count) {  // fetch boards nb .. nb+count-1 into their ring slots
+      uint32_t idx[3], scb[3];
+      int4 kk[3], vv[3];
 #pragma unroll
       for (int k = 0; k < 3; k++) {
-        if ((uint32_t)k < pcount) {
-          uint4 *dst = reinterpret_cast<uint4 *>(&ring[tls][(pbase + (uint32_t)k) % WS_RING][0]);
-          dst[0] = make_uint4((uint32_t)pk[k].x, (uint32_t)pk[k].y, (uint32_t)pk[k].z, (uint32_t)pk[k].w);
-          dst[1] = make_uint4((uint32_t)pv[k].x, (uint32_t)pv[k].y, (uint32_t)pv[k].z, (uint32_t)pv[k].w);
-          dst[2] = make_uint4(pidx[k], pscb[k], 0u, 0u);
+        if ((uint32_t)k < count) {
+          board_params(A.g, env_id, nb + (uint32_t)k, A.lut.len, idx[k], scb[k]);
+          kk[k] = A.lut.keys[idx[k]];
+          vv[k] = A.lut.values[idx[k]];
         }
       }
-      pcount = 0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        if ((uint32_t)k < count) {
+          uint4 *dst = reinterpret_cast<uint4 *>(&ring[tls][(nb + (uint32_t)k) % WS_RING][0]);
+          dst[0] = make_uint4((uint32_t)kk[k].x, (uint32_t)kk[k].y, (uint32_t)kk[k].z, (uint32_t)kk[k].w);
+          dst[1] = make_uint4((uint32_t)vv[k].x, (uint32_t)vv[k].y, (uint32_t)vv[k].z, (uint32_t)vv[k].w);
+          dst[2] = make_uint4(idx[k], scb[k], 0u, 0u);
+        }
+      }
+      nb += count;
+    };
+    if (valid) {
+      nb = (uint32_t)(img64[tl * 16 + W_CTR] >> 32) + 1u;
+      fetch(2);  // the first two boards before anybody starts (a third is needed at sub-step 8 at the earliest)
+    }
+    __syncthreads();  // ring[.. +2] ready
+    if (valid)
+      for (int k = 0; k < (WS_RING - 2 + 2) / 3; k++) fetch(min(3u, (uint32_t)(WS_RING - 2 - 3 * k)));  // rest of the ring, in the background
+    uint32_t dealt_prev = 0;
+    for (int bi = 0; bi < nbatch; bi++) {
+      LDS_BARRIER();
       uint32_t dealt = 0;  // boards this table consumed in batch bi
       for (int j = 0; j < ws_blen(bi); j++) {
         const int s = ws_bstart(bi) + j;
         if (s <= total) dealt += (cmd[bi & 1][j][tls][0] >> 9) & 1u;
       }
-      // keep WS_RING boards ahead of what had been consumed by the end of batch bi-1 (slots of boards
-      // dealt in batch bi are still being read by the scorer / emit waves): at most 3 fetches per batch,
-      // issued now, committed after the next barrier — the loader never holds a barrier up.
-      const uint32_t want = nb0 + (uint32_t)WS_RING + dealt_prev_total;
-      if (valid && nb < want) {
-        pbase = nb;
-        pcount = min(3u, want - nb);
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          if ((uint32_t)k < pcount) {
-            board_params(A.g, env_id, nb + (uint32_t)k, A.lut.len, pidx[k], pscb[k]);
-            pk[k] = A.lut.keys[pidx[k]];
-            pv[k] = A.lut.values[pidx[k]];
-          }
-        }
-        nb += pcount;
-      }
-      dealt_prev_total = dealt_total;
-      dealt_total += dealt;
+      if (valid && dealt_prev) fetch(dealt_prev);  // slots of batch bi-1's boards are free now
+      dealt_prev = dealt;
     }
   } else if (wave == 0) {
     // ------------------------------------------------------------------ logic wave
     Tbl t;
     load_scalars(t, img + tls * TABLE_BYTES);  // only sc / sch / lut / bctr are live here
+    __syncthreads();                           // ring ready
     __builtin_amdgcn_s_setprio(3);             // the critical chain wins issue arbitration on its SIMD
     uint32_t rb[4] = {0, 0, 0, 0};
     uint32_t rb_idx = 0xFFFFFFFFu;
@@ -587,6 +564,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
     __shared__ uint32_t minfo[WS_BATCH][64];                          // per macro-step: actor, action, n_legal, done
     Tbl ts;
     load_scalars(ts, img + tls * TABLE_BYTES);  // fd / tricks / rewards are live here
+    __syncthreads();                            // ring ready
     int sub = 0;
     uint32_t cur_info = 0, tcount = 0;
     int64_t row = table0 + tl;  // this table's Transition row of the next macro-step to be written
@@ -682,6 +660,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
     }
   } else {
     // ------------------------------------------------------------------ emit waves
+    __syncthreads();  // ring ready
     const GroupLane gl = make_group_lane();
     const MaskLane ml = make_mask_lane();
     constexpr int NG = TPB / 4;              // groups of 4 consecutive tables

@@ -3,8 +3,9 @@ import os, sys, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = "/tmp/libbrl_timing.so"
+SRC = os.environ.get("SRC", os.path.join(ROOT, "brl_amd/csrc/brl_kernels.hip"))
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-                       "-DBRL_TIMING", "-o", so, os.path.join(ROOT, "brl_amd/csrc/brl_kernels.hip")], stderr=subprocess.DEVNULL)
+                       "-DBRL_TIMING", "-o", so, SRC], stderr=subprocess.DEVNULL)
 from brl_amd import _capi
 _capi.LIB_PATH = so
 import numpy as np, torch, ctypes as C
@@ -25,11 +26,20 @@ for cfg in os.environ.get("CFGS", "32x16").split(","):
     for f in _capi.TransitionPtrs._names:
         setattr(p, f, _capi.ptr(getattr(traj, f)))
     nblk = (N + tpb - 1) // tpb
-    dump = torch.zeros(nblk * nw * 2, dtype=torch.int64, device=env.device)
+    dump = torch.zeros(nblk * nw * 2 + nblk * nw * 32, dtype=torch.int64, device=env.device)
     for i in range(5):
         _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, i * T, 7600.0, C.byref(p), None, None, _capi.ptr(dump), _stream()))
     torch.cuda.synchronize()
-    d = dump.cpu().numpy().reshape(nblk, nw, 2)
+    full = dump.cpu().numpy()
+    d = full[:nblk * nw * 2].reshape(nblk, nw, 2)
+    if int(os.environ.get('DBG', '0')) & 256:
+        tl = full[nblk * nw * 2:].reshape(nblk, nw, 16, 2)
+        wg = 5
+        print('timeline of workgroup', wg, '(cycles since wave start): arrive->release per barrier')
+        for w in range(nw):
+            print(f'  wave {w:2d}: ' + ' '.join(f'{int(a)//100:4d}>{int(r)//100:4d}' for a, r in tl[wg, w] if r))
+        print('  total', d[wg, :, 0] // 100)
+        continue
     tot, wait = d[..., 0].mean(0), d[..., 1].mean(0)
     print(cfg, "cycles(100MHz ticks?) per wave role: total / barrier-wait / work")
     if int(os.environ.get("DBG", "0")) & 64:
