@@ -530,3 +530,36 @@ def test_graphed_update_matches_eager_update():
         outs.append((torch.cat([p.detach().reshape(-1) for p in net.parameters()]), total))
     assert torch.allclose(outs[0][1], outs[1][1], atol=1e-5)            # same losses (fp32 reduction order may differ)
     assert torch.allclose(outs[0][0], outs[1][0], atol=1e-5, rtol=1e-4)  # same updated parameters
+
+
+def test_longest_auction_319_calls(env, oracle, dds):
+    """Maximum size of the domain: the 319-call auction fills every history nibble and the 9-bit turn counter."""
+    from tests.test_oracle_kat import longest_auction
+    calls = longest_auction()
+    n = 8
+    hands = np.stack([oracle.key_to_hand(dds["keys"][i]) for i in range(n)])
+    tricks = dds["tricks"][:n].reshape(n, 20)
+    st = env.init_from_deals(hands, 3, True, True, [1, 3, 0, 2], tricks)
+    ref = oracle.init_explicit(hands, 3, 1, 1, [1, 3, 0, 2], tricks)
+    for i, a in enumerate(calls):
+        st = env.step(st, torch.full((n,), a, dtype=torch.int32), inplace=True)
+        oracle.step(ref, np.full(n, a, np.int32))
+        if i % 40 == 0 or i > 312:
+            assert_state_equal(st, ref, where=f"longest auction call {i}")
+    assert ref["terminated"].all() and int(ref["turn"][0]) == 318
+
+
+def test_rollout_regression_vectors_gpu(env):
+    """The HIP rollout reproduces the committed SHA-256 regression vectors without the oracle in the loop."""
+    import hashlib, json
+    import brl_amd
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rollout_regression.json")
+    for rec in json.load(open(here)):
+        c = rec["case"]
+        roll = brl_amd.make_random_roll_out({"num_steps": c["T"], "substeps": c["substeps"]}, env)
+        st = env.init(c["seed"], num_envs=c["n"])
+        rs, traj = roll((None, None, st, None, 0, 0))
+        torch.cuda.synchronize()
+        assert int(rs[4].item()) == rec["terminated_count"]
+        for k, want in rec["sha256"].items():
+            assert hashlib.sha256(np.ascontiguousarray(to_np(getattr(traj, k))).tobytes()).hexdigest() == want, k

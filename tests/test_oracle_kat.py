@@ -360,3 +360,45 @@ def test_gae_matches_numpy_f32(oracle):
             nv = value[t]
             assert (adv[t] == gae).all()
             assert (tgt[t] == gae + value[t]).all()
+
+
+def longest_auction():
+    """The 319-call auction (pgx's _bidding_history length): P P P, then every bid doubled and redoubled
+    with two passes in between, closed by three passes."""
+    calls = [0, 0, 0]
+    for b in range(35):
+        calls += [3 + b, 0, 0, 1, 0, 0, 2]
+        calls += [0, 0] if b < 34 else [0, 0, 0]
+    return calls
+
+
+def test_longest_auction_oracle_and_pyref(oracle, dds):
+    calls = longest_auction()
+    assert len(calls) == 319
+    hand = oracle.key_to_hand(dds["keys"][11])
+    st = oracle.init_explicit(hand, 3, 1, 1, [1, 3, 0, 2], dds["tricks"][11].reshape(20))
+    ref = pyref.PyTable(hand, 3, 1, 1, [1, 3, 0, 2], dds["tricks"][11])
+    for i, a in enumerate(calls):
+        assert st["terminated"][0] == 0 and st["legal_action_mask"][0][a] == 1, i
+        oracle.step(st, [a])
+        ref.step(a)
+    assert st["terminated"][0] == 1 and ref.terminated and st["turn"][0] == 318
+    assert st["last_bid"][0] == 34 and st["call_x"][0] == 1 and st["call_xx"][0] == 1
+    assert st["rewards"][0].tolist() == ref.rewards
+    obs = st["observation"][0]
+    assert (obs == ref.observe()).all()
+    assert obs[4:8].sum() == 3 and obs[8:428].reshape(35, 3, 4).sum(-1).min() == 1  # every (bid, event) nibble used once
+
+
+def test_rollout_regression_vectors(oracle):
+    """tests/golden/rollout_regression.json: the oracle still produces the bytes it produced when the
+    vectors were committed (self-generated regression vectors, see make_regression_vectors.py)."""
+    import json, os
+    from tests.golden.make_regression_vectors import digest
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rollout_regression.json")
+    for rec in json.load(open(here)):
+        c = rec["case"]
+        st = oracle.init_random(c["n"], seed=c["seed"])
+        out = oracle.rollout_random(st, c["T"], seed=c["seed"], substeps=c["substeps"])
+        assert out["terminated_count"] == rec["terminated_count"]
+        assert digest(out) == rec["sha256"]
