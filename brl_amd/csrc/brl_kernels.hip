@@ -697,7 +697,72 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
       int64_t rem = (g < NG && !(A.debug & 1)) ? A.n - (table0 + 4 * g) : 0;
       left[k] = (int)max((int64_t)0, min((int64_t)4, rem));
     }
-    for (int bi = 0; bi < nbatch; bi++) {
+    // FAST PATH (substeps == 1, every group of this wave complete, obs + mask requested — the BASELINE
+    // configuration): the same work as the general loop below with everything loop-invariant hoisted: per-lane
+    // output pointers advanced by a constant, no per-step emit / tail / pointer selection.  The slot of the
+    // post-rollout state (s == total) is left to the general code.
+    bool fast = (A.substeps == 1) && A.out.obs && A.out.legal_action_mask && !A.debug;
+#pragma unroll
+    for (int k = 0; k < GPW; k++) fast = fast && (left[k] == 4 || left[k] == 0);
+    int bi0 = 0;  // first batch the general loop still has to process
+    if (fast) {
+      uint8_t *optr[GPW];
+      uint32_t *mptr[GPW];
+#pragma unroll
+      for (int k = 0; k < GPW; k++) {
+        const int g = (wave - 3) + k * NE;
+        optr[k] = A.out.obs + (table0 + 4 * g) * BRL_OBS_SIZE + gl.out_off;
+        mptr[k] = reinterpret_cast<uint32_t *>(A.out.legal_action_mask + (table0 + 4 * g) * BRL_NUM_ACTIONS) + c.lane;
+      }
+      const int64_t ostep = A.n * BRL_OBS_SIZE, mstep = A.n * BRL_NUM_ACTIONS;
+      const bool olane = gl.r < 4;
+      for (; bi0 < nbatch; bi0++) {
+        const int bstart = ws_bstart(bi0), blen = ws_blen(bi0);
+        if (bstart + blen > total) break;  // the batch holding slot `total` goes through the general loop
+        LDS_BARRIER();
+        for (int j = 0; j < blen; j++) {
+          const uint32_t(*cs)[CMD_WORDS] = cmd[bi0 & 1][j];
+#pragma unroll
+          for (int k = 0; k < GPW; k++) {
+            if (left[k] == 0) continue;
+            const int g = (wave - 3) + k * NE;
+            uint8_t *img_g = img + 4 * g * TABLE_BYTES;
+            const uint32_t w0 = cs[4 * g + rr][0];
+            if (head && !(w0 & 0x200u) && (w0 & 0x1FFu)) {
+              int hb = (int)(w0 & 0x1FFu) - 1;
+              atomicOr(reinterpret_cast<uint32_t *>(img_g + gl.r * TABLE_BYTES) + (hb >> 5), 1u << (hb & 31));
+            }
+            uint64_t dealm = __ballot(head && (w0 & 0x200u));
+            while (dealm) {  // rare: ~1 table in 25 per sub-step
+              const int l = __ffsll((unsigned long long)dealm) - 1;  // lane 15*q holds row q's command
+              dealm &= dealm - 1ull;
+              const int q = l / 15;
+              const uint32_t wq = __builtin_amdgcn_readlane(w0, l);
+              const uint4 kk = *reinterpret_cast<const uint4 *>(&ring[4 * g + q][(wq >> 16) & 15u][0]);
+              deal_image(img_g + q * TABLE_BYTES, kk.x, kk.y, kk.z, kk.w, c);
+            }
+            wave_lds_order();
+            uint32_t a;
+            uint64_t H;
+            obs_chunk_load(img_g, (int)((w0 >> 10) & 3u), gl, a, H);
+            const uint64_t la = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
+            const uint64_t lb = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
+            uint32_t d[8];
+            {
+              GroupLane gz = gl;
+              gz.out_off = 0;
+              if (olane) obs_chunk_store(a, H, (int)((w0 >> 10) & 3u), (w0 >> 12) & 15u, optr[k], gz);
+            }
+            if (ml.active) *mptr[k] = mask_dword(la, lb, ml);
+            optr[k] += ostep;
+            mptr[k] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(mptr[k]) + mstep);
+            (void)d;
+          }
+        }
+      }
+      row0 = table0 + (int64_t)ws_bstart(bi0) * A.n;  // substeps == 1: macro-step index == slot index
+    }
+    for (int bi = bi0; bi < nbatch; bi++) {
       LDS_BARRIER();
       for (int j = 0; j < ws_blen(bi); j++) {
         const int s = ws_bstart(bi) + j;

@@ -2,6 +2,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, ctypes as C
+from brl_amd import _capi as _c0
+if os.environ.get('LIB'):
+    _c0.LIB_PATH = os.environ['LIB']
 import brl_amd
 from brl_amd import _capi
 from brl_amd.roll_out import alloc_transition
