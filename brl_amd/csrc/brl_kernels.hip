@@ -599,11 +599,14 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
       // acc[0] carries the partial sums of a macro-step that straddles the batch boundary
 #pragma unroll
       for (int q = 1; q < B; q++) *reinterpret_cast<int4 *>(&acc[q][tl][0]) = make_int4(0, 0, 0, 0);
-      for (int j = 0; j < ws_blen(bi); j++) {
+      const int blen = ws_blen(bi);
+      uint4 wn = *reinterpret_cast<const uint4 *>(&cmd[bi & 1][0][tls][0]);
+      for (int j = 0; j < blen; j++) {
         const int s = ws_bstart(bi) + j;
         if (s > total) break;
+        const uint4 w = wn;  // the next command is fetched while this one is processed
+        wn = *reinterpret_cast<const uint4 *>(&cmd[bi & 1][(j + 1 < blen) ? j + 1 : j][tls][0]);
         if (s == 0) continue;  // cmd slot 0 describes no sub-step
-        const uint4 w = *reinterpret_cast<const uint4 *>(&cmd[bi & 1][j][tls][0]);
         const int a = (int)((w.w >> 8) & 63u);
         const int seat = (int)((w.x >> 21) & 3u);
         ts.sc = w.y;
@@ -641,23 +644,33 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
           ac[0] += reward_of(tb, 0); ac[1] += reward_of(tb, 1); ac[2] += reward_of(tb, 2); ac[3] += reward_of(tb, 3);
         }
       }
-      // ---- pass 3: the m macro-steps completed in this batch
-      for (int q = 0; q < m; q++) {
-        const uint32_t info = minfo[q][tl];
-        const int4 r = *reinterpret_cast<const int4 *>(&acc[q][tl][0]);
-        last_acc = r;
-        if (valid) {
-          const int actor = (int)(info & 3u);
-          const int ra = (actor == 0) ? r.x : ((actor == 1) ? r.y : ((actor == 2) ? r.z : r.w));
-          const uint32_t done = (info >> 14) & 1u;
-          if (A.out.done) A.out.done[row] = (uint8_t)done;  // G2
-          if (A.out.action) A.out.action[row] = (int32_t)((info >> 2) & 63u);
-          if (A.out.value) A.out.value[row] = 0.0f;
-          if (A.out.reward) A.out.reward[row] = (float)ra / A.reward_scale;  // G1, src/roll_out.py:90
-          if (A.out.log_prob) A.out.log_prob[row] = s_neglog[(info >> 8) & 63u];
-          tcount += done;
+      // ---- pass 3: the m macro-steps completed in this batch; with TPB <= 32 the upper half of the wave
+      //      writes the odd ones, so one store instruction covers two rows of a column
+      wave_lds_order();
+      if (m > 0) last_acc = *reinterpret_cast<const int4 *>(&acc[m - 1][tl][0]);
+      {
+        constexpr bool TWO = (TPB <= 32);
+        const int half = TWO ? (c.lane >> 5) : 0;
+        const int tq = TWO ? (c.lane & 31) : c.lane;  // table handled by this lane in pass 3
+        const bool vq = (tq < TPB) && (table0 + tq < A.n);
+        for (int q0 = 0; q0 < m; q0 += (TWO ? 2 : 1)) {
+          const int q = q0 + half;
+          if (q < m && vq) {
+            const uint32_t info = minfo[q][tq];
+            const int4 r = *reinterpret_cast<const int4 *>(&acc[q][tq][0]);
+            const int actor = (int)(info & 3u);
+            const int ra = (actor == 0) ? r.x : ((actor == 1) ? r.y : ((actor == 2) ? r.z : r.w));
+            const uint32_t done = (info >> 14) & 1u;
+            const int64_t rw = row + (int64_t)q * A.n + (tq - tl);
+            if (A.out.done) A.out.done[rw] = (uint8_t)done;  // G2
+            if (A.out.action) A.out.action[rw] = (int32_t)((info >> 2) & 63u);
+            if (A.out.value) A.out.value[rw] = 0.0f;
+            if (A.out.reward) A.out.reward[rw] = (float)ra / A.reward_scale;  // G1, src/roll_out.py:90
+            if (A.out.log_prob) A.out.log_prob[rw] = s_neglog[(info >> 8) & 63u];
+            tcount += done;
+          }
         }
-        row += A.n;
+        row += (int64_t)m * A.n;
       }
       {  // a macro-step still in progress (sub != 0) keeps its partial sums in acc[0]; otherwise zero
         int4 carry = (sub != 0) ? *reinterpret_cast<const int4 *>(&acc[m & (WS_BATCH - 1)][tl][0]) : make_int4(0, 0, 0, 0);
