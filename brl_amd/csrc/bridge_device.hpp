@@ -88,6 +88,12 @@ __device__ __forceinline__ uint32_t vul_nibble(const Tbl &t, int seat) {
   return (we ? 2u : 1u) | (they ? 8u : 4u);
 }
 
+__device__ __forceinline__ uint32_t vul_nibble_sc(uint32_t sc, int seat) {
+  uint32_t ns = bits(sc, SC_VULNS, 1), ew = bits(sc, SC_VULEW, 1);
+  uint32_t we = (seat & 1) ? ew : ns, they = (seat & 1) ? ns : ew;
+  return (we ? 2u : 1u) | (they ? 8u : 4u);
+}
+
 // A2: legal_action_mask of the player to act, derived from the scalars:
 // Pass always; bids strictly above the last bid; X iff the last bid is the opponents' and
 // undoubled; XX iff own side's bid is doubled and not redoubled; all-True at a terminal.
@@ -491,6 +497,71 @@ __device__ __forceinline__ int random_legal_action(const Tbl &t, uint64_t legal,
   int a_dbl = (dbl == 1u) ? 1 : 2;
   int a = (k == 0) ? 0 : (dbl ? ((k == 1) ? a_dbl : first_bid + k - 2) : first_bid + k - 1);
   return bits(t.sc, SC_MASKALL, 1) ? k : a;
+}
+
+// ---- lean, straight-line transition for the fused rollout's LOGIC wave ------------------------
+// One uniform-random legal call on a LIVE table (never all-True mask, never illegal): same result as
+// legal_mask() + random_legal_action() + auto_reset_clear() + auction_step(), with no data-dependent
+// branches and no 64-bit popcount — this is the per-table dependency chain of the T-step scan, so
+// every instruction here is paid 32 times in sequence.
+struct LeanStep {
+  uint64_t legal;   // legal_action_mask of the state BEFORE the call
+  int seat;         // seat that acts
+  int action;       // the call
+  int n_legal;      // number of legal calls (for log_prob)
+  uint32_t hb1;     // history bit + 1 (0: none)
+  uint32_t term;    // auction over
+};
+
+__device__ __forceinline__ LeanStep lean_random_step(uint32_t &sc, uint32_t &sch, uint32_t u) {
+  LeanStep r;
+  const uint32_t lb1 = bits(sc, SC_LB1, 6);
+  const uint32_t seat = (bits(sc, SC_DEALER, 2) + bits(sch, SCH_TURN, 9)) & 3u;
+  const uint32_t own = ((bits(sc, SC_LBSEAT, 2) ^ seat) & 1u) ^ 1u;
+  const uint32_t x = bits(sc, SC_X, 1), xx = bits(sc, SC_XX, 1), has = lb1 != 0;
+  const uint32_t can_x = has & (own ^ 1u) & (x ^ 1u) & (xx ^ 1u);
+  const uint32_t can_xx = has & own & x & (xx ^ 1u);
+  const uint32_t dbl = can_x | can_xx;
+  const uint64_t bids = (ALL_ACTIONS >> (3 + lb1)) << (3 + lb1);
+  r.legal = bids | (uint64_t)(1u | (can_x << 1) | (can_xx << 2));
+  const uint32_t n = 36u - lb1 + dbl;  // pass + (35 - lb1) bids + at most one of X / XX
+  const uint32_t k = __umulhi(u, n);   // k-th legal call in ascending order
+  const uint32_t a_bid = 2u + lb1 + k - dbl;
+  const uint32_t a_dbl = can_x ? 1u : 2u;
+  uint32_t a = (dbl & (k == 1u)) ? a_dbl : a_bid;
+  a = (k == 0u) ? 0u : a;
+  uint32_t nn = n;
+  if (bits(sc, SC_MASKALL, 1)) {  // only a caller-supplied finished table can get here (all-True mask)
+    r.legal = ALL_ACTIONS;
+    nn = 38u;
+    a = __umulhi(u, 38u);
+  }
+  r.action = (int)a;
+  r.n_legal = (int)nn;
+  r.seat = (int)seat;
+  // A5 pre-step half of auto_reset (src/utils.py:34-43)
+  const uint32_t was_term = bits(sc, SC_TERM, 1);
+  sc &= ~(1u << SC_TERM);
+  sch = was_term ? (sch & ~(1023u << SCH_STEP)) : sch;
+  // the call
+  const bool is_pass = a == 0u, is_bid = a >= 3u, is_x = a == 1u;
+  const uint32_t b = a - 3u;
+  const uint32_t hb_bid = 9u + 12u * b + seat;
+  const uint32_t hb_dbl = 9u + 12u * (lb1 - 1u) + (is_x ? 4u : 8u) + seat;  // lb1 > 0 when X / XX is legal
+  const uint32_t hb_pass = (lb1 == 0u) ? 5u + seat : 0u;
+  r.hb1 = is_bid ? hb_bid : (is_pass ? hb_pass : hb_dbl);
+  const uint32_t pass = is_pass ? bits(sc, SC_PASS, 3) + 1u : 0u;
+  const uint32_t set_dbl = is_bid ? 0u : ((a == 1u ? (1u << SC_X) : 0u) | (a == 2u ? (1u << SC_XX) : 0u));
+  const uint32_t bid_clear = (63u << SC_LB1) | (3u << SC_LBSEAT) | (1u << SC_X) | (1u << SC_XX);
+  const uint32_t bid_set = ((b + 1u) << SC_LB1) | (seat << SC_LBSEAT);
+  uint32_t nsc = is_bid ? ((sc & ~bid_clear) | bid_set) : (sc | set_dbl);
+  const uint32_t nlb1 = is_bid ? b + 1u : lb1;
+  const uint32_t term = pass == ((nlb1 != 0u) ? 3u : 4u);
+  nsc = (nsc & ~(7u << SC_PASS)) | (pass << SC_PASS) | (term ? ((1u << SC_TERM) | (1u << SC_MASKALL)) : 0u);
+  sc = nsc;
+  sch += (1u << SCH_STEP) + (term ? 0u : (1u << SCH_TURN));
+  r.term = term;
+  return r;
 }
 
 }  // namespace brl

@@ -433,6 +433,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   __shared__ __attribute__((aligned(16))) uint8_t img[TPB * TABLE_BYTES];
   __shared__ __attribute__((aligned(16))) uint32_t cmd[2][B][TPB][CMD_WORDS];
   __shared__ __attribute__((aligned(16))) uint32_t ring[TPB][WS_RING][RING_WORDS];
+  __shared__ uint32_t udraw[2][WS_BATCH][TPB];  // action draws of a batch, precomputed by the loader wave
   __shared__ float s_neglog[BRL_NUM_ACTIONS + 2];
   const int tid = (int)threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -471,7 +472,23 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
     }
     nb += 2u;
   }
-  __syncthreads();  // images + the first two boards of the ring are in LDS
+  // action draws (Philox is state-independent, so it does not belong on the logic wave's dependency
+  // chain): the loader computes udraw[b & 1][j][table] for command batch b one batch ahead of the logic wave
+  uint32_t rbk[4] = {0, 0, 0, 0};
+  uint32_t rbk_idx = 0xFFFFFFFFu;
+  auto draws = [&](int b) {
+    for (int j = 0; j < ws_blen(b); j++) {
+      const uint32_t draw = A.draw_base + (uint32_t)(ws_bstart(b) + j);
+      if ((draw >> 2) != rbk_idx) {
+        rbk_idx = draw >> 2;
+        philox4x32_10((uint32_t)env_id, rbk_idx, STREAM_ACTION, (uint32_t)(env_id >> 32), A.g.k0, A.g.k1, rbk);
+      }
+      const uint32_t sel = draw & 3u;
+      if (tl < TPB) udraw[b & 1][j][tl] = (sel == 0) ? rbk[0] : ((sel == 1) ? rbk[1] : ((sel == 2) ? rbk[2] : rbk[3]));
+    }
+  };
+  if (wave == 1) draws(0);
+  __syncthreads();  // images, the first two boards of the ring and the draws of batch 0 are in LDS
 
   if (wave == 1) {
     // ------------------------------------------------------------------ loader wave
@@ -479,6 +496,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
     uint32_t pcount = 0;  // boards whose loads were issued in the previous iteration
     uint32_t dealt_total = 0, dealt_prev_total = 0;
     for (int bi = 0; bi < nbatch; bi++) {
+      if (bi + 1 < nbatch) draws(bi + 1);  // the logic wave starts batch bi+1 right after this barrier
       LDS_BARRIER();
       // commit what was issued one batch ago (its loads landed long before)
 #pragma unroll
@@ -518,62 +536,59 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
     }
   } else if (wave == 0) {
     // ------------------------------------------------------------------ logic wave
-    Tbl t;
-    load_scalars(t, img + tls * TABLE_BYTES);  // only sc / sch / lut / bctr are live here
-    __builtin_amdgcn_s_setprio(3);             // the critical chain wins issue arbitration on its SIMD
-    uint32_t rb[4] = {0, 0, 0, 0};
-    uint32_t rb_idx = 0xFFFFFFFFu;
+    uint32_t sc, sch, lut, bctr;
+    {
+      const uint2 *p = reinterpret_cast<const uint2 *>(img + tls * TABLE_BYTES);
+      uint2 a = p[W_SC], d = p[W_CTR];
+      sc = a.x; sch = a.y; lut = d.x; bctr = d.y;
+    }
+    __builtin_amdgcn_s_setprio(3);  // the critical chain wins issue arbitration on its SIMD
+    // (LUT row, fresh scalars) of the NEXT board of this slot, read ahead of the deal that uses them
+    uint2 nxt = *reinterpret_cast<const uint2 *>(&ring[tls][(bctr + 1u) % WS_RING][8]);
     uint32_t pend = 0, pend_act = 0, pend_sc = 0, term_any = 0;
     int sub = 0;
     for (int bi = 0; bi < nbatch; bi++) {
-      for (int j = 0; j < ws_blen(bi); j++) {
+      const int blen = ws_blen(bi);
+      uint32_t un = udraw[bi & 1][0][tls];
+      for (int j = 0; j < blen; j++) {
         const int s = ws_bstart(bi) + j;
         if (s > total) break;
-        const uint64_t legal = legal_mask(t);
-        const int oseat = cur_seat(t);
-        if (tl < TPB) {
-          uint32_t w0 = pend | ((uint32_t)oseat << 10) | (vul_nibble(t, oseat) << 12);
-          uint32_t w3 = ((uint32_t)(legal >> 32) & 63u) | (pend_act << 8);
-          *reinterpret_cast<uint4 *>(&cmd[bi & 1][j][tl][0]) = make_uint4(w0, pend_sc, (uint32_t)legal, w3);
+        const uint32_t u = un;
+        un = udraw[bi & 1][(j + 1 < blen) ? j + 1 : j][tls];  // next sub-step's draw, off the chain
+        uint32_t nsc = sc, nsch = sch;
+        const LeanStep st = lean_random_step(nsc, nsch, u);
+        if (tl < TPB) {  // command slot s: what sub-step s-1 did + how state s looks
+          uint32_t w0 = pend | ((uint32_t)st.seat << 10) | (vul_nibble_sc(sc, st.seat) << 12);
+          uint32_t w3 = ((uint32_t)(st.legal >> 32) & 63u) | (pend_act << 8);
+          *reinterpret_cast<uint4 *>(&cmd[bi & 1][j][tl][0]) = make_uint4(w0, pend_sc, (uint32_t)st.legal, w3);
         }
         if (s == total) continue;
         const bool first = sub == 0;
         const bool last = sub + 1 == A.substeps;
         sub = last ? 0 : sub + 1;
-        if (first) term_any = 0;
-        uint32_t draw = A.draw_base + (uint32_t)s;
-        if ((draw >> 2) != rb_idx) {
-          rb_idx = draw >> 2;
-          philox4x32_10((uint32_t)env_id, rb_idx, STREAM_ACTION, (uint32_t)(env_id >> 32), A.g.k0, A.g.k1, rb);
-        }
-        uint32_t sel = draw & 3u;
-        uint32_t u = (sel == 0) ? rb[0] : ((sel == 1) ? rb[1] : ((sel == 2) ? rb[2] : rb[3]));
-        int nl;
-        int a = random_legal_action(t, legal, u, nl);
-        if (bits(t.sc, SC_TERM, 1)) {  // A5 pre-step half of auto_reset (src/utils.py:34-43)
-          t.sc &= ~(1u << SC_TERM);
-          t.sch &= ~(1023u << SCH_STEP);
-        }
-        int hb = auction_step(t, a, oseat);  // a is legal by construction: no illegal-action path here
-        uint32_t term = bits(t.sc, SC_TERM, 1);
-        term_any |= term;
-        pend_sc = t.sc;
-        pend_act = (uint32_t)a;
-        bool deal = valid && term;
-        uint32_t slot = (t.bctr + 1u) % WS_RING;
-        pend = (uint32_t)(hb + 1) | ((uint32_t)deal << 9) | (slot << 16) | ((uint32_t)oseat << 21) | ((uint32_t)nl << 23);
+        term_any = first ? st.term : (term_any | st.term);
+        sc = nsc;
+        sch = nsch;
+        pend_sc = sc;
+        pend_act = (uint32_t)st.action;
+        const bool deal = valid && st.term;
+        const uint32_t slot = (bctr + 1u) % WS_RING;
+        pend = st.hb1 | ((uint32_t)deal << 9) | (slot << 16) | ((uint32_t)st.seat << 21) | ((uint32_t)st.n_legal << 23);
         if (deal) {  // A5 post-step half of auto_reset (src/utils.py:45-55): next board from the ring
-          uint2 ib = *reinterpret_cast<const uint2 *>(&ring[tl][slot][8]);
-          apply_fresh(t, ib.x, ib.y, t.bctr + 1u, t.sc & ((1u << SC_TERM) | (1u << SC_ILLEGAL)));
+          sc = nxt.y | (sc & ((1u << SC_TERM) | (1u << SC_ILLEGAL)));
+          sch = 0;
+          lut = nxt.x;
+          bctr += 1u;
+          nxt = *reinterpret_cast<const uint2 *>(&ring[tl][(bctr + 1u) % WS_RING][8]);
         }
-        if (last && A.substeps > 1) t.sc = (t.sc & ~(1u << SC_TERM)) | (term_any << SC_TERM);  // src/utils.py:127
+        if (last && A.substeps > 1) sc = (sc & ~(1u << SC_TERM)) | (term_any << SC_TERM);  // src/utils.py:127
       }
       LDS_BARRIER();
     }
     if (tl < TPB) {
       uint2 *p = reinterpret_cast<uint2 *>(img + tl * TABLE_BYTES);
-      p[W_SC] = make_uint2(t.sc, t.sch);
-      p[W_CTR] = make_uint2(t.lut, t.bctr);
+      p[W_SC] = make_uint2(sc, sch);
+      p[W_CTR] = make_uint2(lut, bctr);
     }
   } else if (wave == 2) {
     // ------------------------------------------------------------------ scorer wave
