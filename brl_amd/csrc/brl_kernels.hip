@@ -433,6 +433,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   __shared__ __attribute__((aligned(16))) uint8_t img[TPB * TABLE_BYTES];
   __shared__ __attribute__((aligned(16))) uint32_t cmd[2][B][TPB][CMD_WORDS];
   __shared__ __attribute__((aligned(16))) uint32_t ring[TPB][WS_RING][RING_WORDS];
+  __shared__ int ring_ready;  // set by the loader wave once the first two boards of every table are in the ring
   __shared__ uint32_t udraw[2][WS_BATCH][TPB];  // action draws of a batch, precomputed by the loader wave
   __shared__ float s_neglog[BRL_NUM_ACTIONS + 2];
   const int tid = (int)threadIdx.x;
@@ -454,24 +455,8 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   // loader state (wave 1): next board to fetch, boards in flight
   uint32_t nb = 0, nb0 = 0, pbase = 0, pidx[3] = {0, 0, 0}, pscb[3] = {0, 0, 0};
   int4 pk[3], pv[3];
-  if (wave == 1 && valid) {  // the first two boards of every table, in parallel with the image load above
-    nb0 = (uint32_t)(A.state[(table0 + tl) * 16 + W_CTR] >> 32) + 1u;
-    nb = nb0;
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-      board_params(A.g, env_id, nb + (uint32_t)k, A.lut.len, pidx[k], pscb[k]);
-      pk[k] = A.lut.keys[pidx[k]];
-      pv[k] = A.lut.values[pidx[k]];
-    }
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-      uint4 *dst = reinterpret_cast<uint4 *>(&ring[tl][(nb + (uint32_t)k) % WS_RING][0]);
-      dst[0] = make_uint4((uint32_t)pk[k].x, (uint32_t)pk[k].y, (uint32_t)pk[k].z, (uint32_t)pk[k].w);
-      dst[1] = make_uint4((uint32_t)pv[k].x, (uint32_t)pv[k].y, (uint32_t)pv[k].z, (uint32_t)pv[k].w);
-      dst[2] = make_uint4(pidx[k], pscb[k], 0u, 0u);
-    }
-    nb += 2u;
-  }
+  uint64_t ctr_word = 0;
+  if (wave == 1 && valid) ctr_word = A.state[(table0 + tl) * 16 + W_CTR];  // issued now, needed after the barrier
   // action draws (Philox is state-independent, so it does not belong on the logic wave's dependency
   // chain): the loader computes udraw[b & 1][j][table] for command batch b one batch ahead of the logic wave
   uint32_t rbk[4] = {0, 0, 0, 0};
@@ -488,12 +473,29 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
     }
   };
   if (wave == 1) draws(0);
-  __syncthreads();  // images, the first two boards of the ring and the draws of batch 0 are in LDS
+  if (tid == 0) ring_ready = 0;
+  __syncthreads();  // images and the draws of batch 0 are in LDS; the ring follows (ring_ready)
+  uint32_t pcount = 0;  // (loader) boards whose loads are in flight
+  if (wave == 1 && valid) {
+    // the first two boards of every table: loads ISSUED here, committed to the ring after the first batch
+    // barrier (loader loop) — everybody else has already started; only a DEAL needs the ring, and the logic
+    // wave checks ring_ready before its first one
+    nb0 = (uint32_t)(ctr_word >> 32) + 1u;
+    nb = nb0;
+    pbase = nb;
+    pcount = 2;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      board_params(A.g, env_id, nb + (uint32_t)k, A.lut.len, pidx[k], pscb[k]);
+      pk[k] = A.lut.keys[pidx[k]];
+      pv[k] = A.lut.values[pidx[k]];
+    }
+    nb += 2u;
+  }
 
   if (wave == 1) {
     // ------------------------------------------------------------------ loader wave
     // (its first two boards were fetched in the prologue, before the workgroup's first barrier)
-    uint32_t pcount = 0;  // boards whose loads were issued in the previous iteration
     uint32_t dealt_total = 0, dealt_prev_total = 0;
     for (int bi = 0; bi < nbatch; bi++) {
       if (bi + 1 < nbatch) draws(bi + 1);  // the logic wave starts batch bi+1 right after this barrier
@@ -509,6 +511,10 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
         }
       }
       pcount = 0;
+      if (bi == 0) {  // the first two boards are in the ring now
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (c.lane == 0) __hip_atomic_store(&ring_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
       uint32_t dealt = 0;  // boards this table consumed in batch bi
       for (int j = 0; j < ws_blen(bi); j++) {
         const int s = ws_bstart(bi) + j;
@@ -543,8 +549,10 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
       sc = a.x; sch = a.y; lut = d.x; bctr = d.y;
     }
     __builtin_amdgcn_s_setprio(3);  // the critical chain wins issue arbitration on its SIMD
-    // (LUT row, fresh scalars) of the NEXT board of this slot, read ahead of the deal that uses them
-    uint2 nxt = *reinterpret_cast<const uint2 *>(&ring[tls][(bctr + 1u) % WS_RING][8]);
+    // (LUT row, fresh scalars) of the NEXT board of this slot, read ahead of the deal that uses them; the very
+    // first read waits for the loader's ring_ready (the ring is filled while the first sub-steps run)
+    uint2 nxt = make_uint2(0u, 0u);
+    bool have_nxt = false;
     uint32_t pend = 0, pend_act = 0, pend_sc = 0, term_any = 0;
     int sub = 0;
     for (int bi = 0; bi < nbatch; bi++) {
@@ -562,7 +570,11 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
           uint32_t w3 = ((uint32_t)(st.legal >> 32) & 63u) | (pend_act << 8);
           *reinterpret_cast<uint4 *>(&cmd[bi & 1][j][tl][0]) = make_uint4(w0, pend_sc, (uint32_t)st.legal, w3);
         }
-        if (s == total) continue;
+        // the barrier that publishes a batch sits right after its LAST post — before that sub-step is
+        // committed — so followers start one sub-step earlier and a deal at sub-step 0 can wait for ring_ready
+        // (the loader raises it after the first barrier)
+        if (j == blen - 1 || s == total) LDS_BARRIER();
+        if (s == total) break;
         const bool first = sub == 0;
         const bool last = sub + 1 == A.substeps;
         sub = last ? 0 : sub + 1;
@@ -574,6 +586,11 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
         const bool deal = valid && st.term;
         const uint32_t slot = (bctr + 1u) % WS_RING;
         pend = st.hb1 | ((uint32_t)deal << 9) | (slot << 16) | ((uint32_t)st.seat << 21) | ((uint32_t)st.n_legal << 23);
+        if (!have_nxt && __any(deal)) {  // uniform: first deal of the wave
+          while (__hip_atomic_load(&ring_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+          nxt = *reinterpret_cast<const uint2 *>(&ring[tls][(bctr + 1u) % WS_RING][8]);
+          have_nxt = true;
+        }
         if (deal) {  // A5 post-step half of auto_reset (src/utils.py:45-55): next board from the ring
           sc = nxt.y | (sc & ((1u << SC_TERM) | (1u << SC_ILLEGAL)));
           sch = 0;
@@ -583,7 +600,6 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
         }
         if (last && A.substeps > 1) sc = (sc & ~(1u << SC_TERM)) | (term_any << SC_TERM);  // src/utils.py:127
       }
-      LDS_BARRIER();
     }
     if (tl < TPB) {
       uint2 *p = reinterpret_cast<uint2 *>(img + tl * TABLE_BYTES);
@@ -729,7 +745,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
     // configuration): the same work as the general loop below with everything loop-invariant hoisted: per-lane
     // output pointers advanced by a constant, no per-step emit / tail / pointer selection.  The slot of the
     // post-rollout state (s == total) is left to the general code.
-    bool fast = (A.substeps == 1) && A.out.obs && A.out.legal_action_mask && !A.debug;
+    bool fast = (A.substeps == 1) && A.out.obs && A.out.legal_action_mask && !(A.debug & ~256);
 #pragma unroll
     for (int k = 0; k < GPW; k++) fast = fast && (left[k] == 4 || left[k] == 0);
     int bi0 = 0;  // first batch the general loop still has to process
