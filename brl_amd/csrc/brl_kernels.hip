@@ -904,6 +904,8 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   }
 }
 
+#include "rollout_flow.hpp"
+
 // ---- policy sub-step: masked categorical over logits + auto_reset(step) -------------------
 struct PolicyArgs {
   const uint64_t *state_in;
@@ -1177,6 +1179,7 @@ struct brl_handle {
   int tables_per_wave;
   int ws_tpb;  // tables per workgroup of the wave-specialised rollout, 0 = use the K-tables-per-wave kernel
   int ws_nw;   // waves per workgroup (1 logic + ws_nw-1 emit)
+  int flow;    // 1: flag-synchronised k_rollout_flow instead of the batch-barrier k_rollout_ws
 };
 
 static thread_local char g_err[512] = "";
@@ -1234,6 +1237,7 @@ extern "C" int brl_create(int device, const int32_t *lut_keys, const int32_t *lu
   }
   h->ws_tpb = 32;
   h->ws_nw = 11;
+  h->flow = getenv("BRL_ROLLOUT_FLOW") ? atoi(getenv("BRL_ROLLOUT_FLOW")) : 0;
   const char *ws = getenv("BRL_ROLLOUT_WS");  // "TPBxNW" (16x5 16x7 32x5 32x7 32x8 32x11 64x7 64x11) or "0"
   if (ws) {
     int a = 0, b = 0;
@@ -1378,6 +1382,19 @@ extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int
   hipLaunchKernelGGL((k_rollout_ws<TPB, NW>), dim3((unsigned)((n + TPB - 1) / TPB)), dim3(NW * 64), 0, \
                      (hipStream_t)stream, A)
   const int cfg = (substeps <= WS_BATCH) ? h->ws_tpb * 100 + h->ws_nw : 0;  // a macro-step spans <= 2 command batches
+#define LAUNCH_FLOW(TPB, NW)                                                                             \
+  hipLaunchKernelGGL((k_rollout_flow<TPB, NW>), dim3((unsigned)((n + TPB - 1) / TPB)), dim3(NW * 64), 0, \
+                     (hipStream_t)stream, A)
+  if (h->flow && (cfg == 1607 || cfg == 3207 || cfg == 3211)) {
+    switch (cfg) {  // the flow kernel has one more wave (prep) for the same number of emit waves
+      case 1607: LAUNCH_FLOW(16, 8); break;
+      case 3207: LAUNCH_FLOW(32, 8); break;
+      default: LAUNCH_FLOW(32, 12); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return BRL_OK;
+  }
+#undef LAUNCH_FLOW
   switch (cfg) {
     case 1605: LAUNCH_WS(16, 5); break;
     case 1607: LAUNCH_WS(16, 7); break;
