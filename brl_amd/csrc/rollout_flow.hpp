@@ -66,6 +66,102 @@ __device__ __forceinline__ uint32_t fast_step(uint32_t d, uint32_t u) {
   return dn;
 }
 
+// ---- byte images of the emit waves ----------------------------------------------------------------
+// Per table BROW bytes: [0, 416) = observation bytes 0..415 with the seats of every 4-byte group in ABSOLUTE
+// order (bytes 0..3, the vulnerability, are unused: they come with the command); then for each observer seat
+// a 64-byte tail = observation bytes 416..479 as that seat sees them: the last bid's 12 history bytes
+// (absolute order, replicated) followed by the seat's own 52 hand bytes.
+constexpr int BTAIL = 416, BROW = BTAIL + 4 * 64;
+
+struct ByteLane {
+  uint32_t src_off;   // this lane's 32 source bytes within the group's 4 byte images (observer seat 0)
+  uint32_t tail_sel;  // all-ones for chunks 13 / 14 (observer-specific tail)
+  uint32_t rot_a;     // 24 where dwords 0..2 hold history (rotate by the observer's seat), else 0
+  uint32_t rot_b;     // same for dwords 3..7
+  bool vul;           // chunk 0: dword 0 is the vulnerability nibble of the command
+  uint32_t out_off;   // this lane's 32 output bytes within the group's 4 rows
+};
+
+__device__ __forceinline__ ByteLane make_byte_lane() {
+  ByteLane b;
+  const int lane = (int)(threadIdx.x & 63u);
+  const int r = lane / 15, ch = lane - r * 15, rr = (r < 4) ? r : 0;
+  b.src_off = (uint32_t)(rr * BROW + ((ch <= 12) ? 32 * ch : BTAIL + 32 * (ch - 13)));
+  b.tail_sel = (ch >= 13) ? 0xFFFFFFFFu : 0u;
+  b.rot_a = (ch <= 13) ? 24u : 0u;
+  b.rot_b = (ch <= 12) ? 24u : 0u;
+  b.vul = (ch == 0);
+  b.out_off = (uint32_t)(rr * 480 + ch * 32);
+  return b;
+}
+
+__device__ __forceinline__ void expand32(uint32_t word, uint4 &lo, uint4 &hi) {  // 32 bits -> 32 bytes of 0/1
+  uint32_t d[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) d[i] = __umul24((word >> (4 * i)) & 0xFu, 0x204081u) & 0x01010101u;
+  lo = make_uint4(d[0], d[1], d[2], d[3]);
+  hi = make_uint4(d[4], d[5], d[6], d[7]);
+}
+
+// byte images of a group of 4 tables from their packed images (once per launch)
+__device__ __forceinline__ void bimg_build(const uint8_t *img_group, uint8_t *bimg_group, const GroupLane &g,
+                                           const ByteLane &b) {
+  if (g.r >= 4) return;
+  const uint32_t a = *reinterpret_cast<const uint32_t *>(img_group + g.hist_off);
+  uint4 lo, hi;
+  if (g.ch <= 12) {
+    expand32(a, lo, hi);
+    uint4 *dst = reinterpret_cast<uint4 *>(bimg_group + b.src_off);
+    dst[0] = lo;
+    dst[1] = hi;
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const uint64_t H = *reinterpret_cast<const uint64_t *>(img_group + g.hand_off + s * 8);
+      const uint32_t hv = (g.ch == 13) ? (uint32_t)(H << 8) : (uint32_t)(H >> 24);
+      expand32((a & g.keep_hist) | (hv & g.keep_hand), lo, hi);
+      uint4 *dst = reinterpret_cast<uint4 *>(bimg_group + b.src_off + 64 * s);
+      dst[0] = lo;
+      dst[1] = hi;
+    }
+  }
+}
+
+// a freshly dealt board in one table's byte image: no history, the four hands from the LUT key
+__device__ __forceinline__ void deal_bytes(uint8_t *brow, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3,
+                                           const LaneConst &c) {
+  if (c.lane < BTAIL / 16) *reinterpret_cast<uint4 *>(brow + 16 * c.lane) = make_uint4(0u, 0u, 0u, 0u);
+  else if (c.lane < BTAIL / 16 + 4) *reinterpret_cast<uint4 *>(brow + BTAIL + 64 * (c.lane - BTAIL / 16)) = make_uint4(0u, 0u, 0u, 0u);
+  wave_lds_order();
+  const uint32_t ksel = (c.dsuit == 0) ? q0 : ((c.dsuit == 1) ? q1 : ((c.dsuit == 2) ? q2 : q3));
+  const uint32_t owner = (ksel >> c.dshift) & 3u;
+  if (c.lane < 52) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) brow[BTAIL + 64 * s + 12 + c.lane] = (uint8_t)(owner == (uint32_t)s);
+  }
+}
+
+__device__ __forceinline__ void byte_chunk_load(const uint8_t *bimg_group, uint32_t seat, const ByteLane &b, uint4 &q0,
+                                                uint4 &q1) {
+  const uint4 *src = reinterpret_cast<const uint4 *>(bimg_group + b.src_off + ((seat << 6) & b.tail_sel));
+  q0 = src[0];
+  q1 = src[1];
+}
+
+__device__ __forceinline__ void byte_chunk_store(uint4 q0, uint4 q1, uint32_t seat, uint32_t vulnib, uint8_t *dst,
+                                                 const ByteLane &b) {
+  const uint32_t ra = (seat << 3) & b.rot_a, rb = (seat << 3) & b.rot_b;
+  // relative seat j = absolute seat (observer + j) & 3: rotate every 4-byte group right by `seat` bytes
+  uint32_t d0 = __builtin_amdgcn_alignbit(q0.x, q0.x, ra);
+  const uint32_t vd = __umul24(vulnib, 0x204081u) & 0x01010101u;
+  d0 = b.vul ? vd : d0;
+  uint4 *o = reinterpret_cast<uint4 *>(dst);
+  o[0] = make_uint4(d0, __builtin_amdgcn_alignbit(q0.y, q0.y, ra), __builtin_amdgcn_alignbit(q0.z, q0.z, ra),
+                    __builtin_amdgcn_alignbit(q0.w, q0.w, rb));
+  o[1] = make_uint4(__builtin_amdgcn_alignbit(q1.x, q1.x, rb), __builtin_amdgcn_alignbit(q1.y, q1.y, rb),
+                    __builtin_amdgcn_alignbit(q1.z, q1.z, rb), __builtin_amdgcn_alignbit(q1.w, q1.w, rb));
+}
+
 // min over f_done[first .. first+count-1] (count <= 16), uniform over the wave
 __device__ __forceinline__ int fl_min_done(const int *f_done, int first, int count, int lane) {
   int v = fl_ld(&f_done[first + (lane & 15) % count]);
@@ -96,6 +192,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
   constexpr int NE = NW - FW_EMIT0;
   constexpr int B = WS_BATCH;
   __shared__ __attribute__((aligned(16))) uint8_t img[TPB * TABLE_BYTES];
+  __shared__ __attribute__((aligned(16))) uint8_t bimg[TPB * BROW];  // byte images (emit waves)
   __shared__ __attribute__((aligned(16))) uint32_t cmd[FL_CR][TPB][CMD_WORDS];
   __shared__ __attribute__((aligned(16))) uint32_t ring[TPB][WS_RING][RING_WORDS];
   __shared__ __attribute__((aligned(8))) uint2 spost[FL_CR][TPB];  // fast mode: (d, static word) of state s
@@ -609,8 +706,13 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
     }
   } else {
     // ------------------------------------------------------------------ emit waves
+    // Observation rows are copied from BYTE images (bimg): one byte per observation bit, seats in absolute
+    // order, so a lane's 32 output bytes are two 16-byte LDS reads plus one rotate per dword (the observer's
+    // seat) instead of 8 nibble extractions + 8 multiplies + 8 masks.  The packed images (img) are kept up to
+    // date too (one ds_or per call): they are what goes back to HBM as the table state.
     const GroupLane gl = make_group_lane();
     const MaskLane ml = make_mask_lane();
+    const ByteLane bl = make_byte_lane();
     constexpr int NG = TPB / 4;
     constexpr int GPW = (NG + NE - 1) / NE;
     const bool head = (gl.r < 4) && (gl.ch == 0);
@@ -623,7 +725,9 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
       const int g = (wave - FW_EMIT0) + k * NE;
       int64_t rem = (g < NG && !(A.debug & 1)) ? A.n - (table0 + 4 * g) : 0;
       left[k] = (int)max((int64_t)0, min((int64_t)4, rem));
+      if (g < NG) bimg_build(img + 4 * g * TABLE_BYTES, bimg + 4 * g * BROW, gl, bl);
     }
+    wave_lds_order();
     int avail = 0;  // command slots known to be posted
     bool dead = false;
     auto wait_slot = [&](int s) {
@@ -636,6 +740,34 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
       if (aborted()) dead = true;
       fl_order();
     };
+    // sub-step s-1 applied to group g's images: one call (history bit) or a freshly dealt board per row
+    auto apply = [&](int g, uint32_t w0, int rows) {
+      uint8_t *img_g = img + 4 * g * TABLE_BYTES;
+      uint8_t *bimg_g = bimg + 4 * g * BROW;
+      const bool is_head = head && (gl.r < rows);
+      if (is_head && !(w0 & 0x200u) && (w0 & 0x1FFu)) {
+        const int hb = (int)(w0 & 0x1FFu) - 1;
+        atomicOr(reinterpret_cast<uint32_t *>(img_g + gl.r * TABLE_BYTES) + (hb >> 5), 1u << (hb & 31));
+        uint8_t *brow = bimg_g + gl.r * BROW;
+        if (hb < BTAIL) {
+          brow[hb] = 1;
+        } else {  // the last bid's 12 bytes live in the four observer tails
+#pragma unroll
+          for (int q = 0; q < 4; q++) brow[hb + 64 * q] = 1;
+        }
+      }
+      uint64_t dealm = __ballot(is_head && (w0 & 0x200u));
+      while (dealm) {  // rare: ~1 table in 25 per sub-step
+        const int l = __ffsll((unsigned long long)dealm) - 1;  // lane 15*q holds row q's command
+        dealm &= dealm - 1ull;
+        const int q = l / 15;
+        const uint32_t wq = __builtin_amdgcn_readlane(w0, l);
+        const uint4 kk = *reinterpret_cast<const uint4 *>(&ring[4 * g + q][(wq >> 16) & 15u][0]);
+        deal_image(img_g + q * TABLE_BYTES, kk.x, kk.y, kk.z, kk.w, c);
+        deal_bytes(bimg_g + q * BROW, kk.x, kk.y, kk.z, kk.w, c);
+      }
+      wave_lds_order();
+    };
     bool fast = (A.substeps == 1) && A.out.obs && A.out.legal_action_mask;
 #pragma unroll
     for (int k = 0; k < GPW; k++) fast = fast && (left[k] == 4 || left[k] == 0);
@@ -646,44 +778,56 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
 #pragma unroll
       for (int k = 0; k < GPW; k++) {
         const int g = (wave - FW_EMIT0) + k * NE;
-        optr[k] = A.out.obs + (table0 + 4 * g) * BRL_OBS_SIZE + gl.out_off;
+        optr[k] = A.out.obs + (table0 + 4 * g) * BRL_OBS_SIZE + bl.out_off;
         mptr[k] = reinterpret_cast<uint32_t *>(A.out.legal_action_mask + (table0 + 4 * g) * BRL_NUM_ACTIONS) + c.lane;
       }
       const int64_t ostep = A.n * BRL_OBS_SIZE, mstep = A.n * BRL_NUM_ACTIONS;
       const bool olane = gl.r < 4;
-      GroupLane gz = gl;
-      gz.out_off = 0;
+      // software-pipelined: the command words of slot s+1 (when already posted) are read while slot s is
+      // processed, so a slot costs ONE LDS round trip (the image chunks) instead of two
+      uint32_t pw0[GPW];
+      uint64_t pla[GPW], plb[GPW];
+      bool have = false;
       for (; s_next < total; s_next++) {
         wait_slot(s_next);
         if (dead) break;
         const uint32_t(*cs)[CMD_WORDS] = cmd[s_next & (FL_CR - 1)];
+        if (!have) {
+#pragma unroll
+          for (int k = 0; k < GPW; k++) {
+            const int g = (wave - FW_EMIT0) + k * NE;
+            if (left[k] == 0) continue;
+            pw0[k] = cs[4 * g + rr][0];
+            pla[k] = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
+            plb[k] = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
+          }
+        }
+        uint32_t w0c[GPW];
+        uint64_t lac[GPW], lbc[GPW];
+#pragma unroll
+        for (int k = 0; k < GPW; k++) { w0c[k] = pw0[k]; lac[k] = pla[k]; lbc[k] = plb[k]; }
+        have = (s_next + 1 < avail) && (s_next + 1 < total);
+        if (have) {
+          const uint32_t(*cn)[CMD_WORDS] = cmd[(s_next + 1) & (FL_CR - 1)];
+#pragma unroll
+          for (int k = 0; k < GPW; k++) {
+            const int g = (wave - FW_EMIT0) + k * NE;
+            if (left[k] == 0) continue;
+            pw0[k] = cn[4 * g + rr][0];
+            pla[k] = *reinterpret_cast<const uint64_t *>(&cn[4 * g + ml.qa][2]);
+            plb[k] = *reinterpret_cast<const uint64_t *>(&cn[4 * g + ml.qb][2]);
+          }
+        }
 #pragma unroll
         for (int k = 0; k < GPW; k++) {
           if (left[k] == 0) continue;
           const int g = (wave - FW_EMIT0) + k * NE;
-          uint8_t *img_g = img + 4 * g * TABLE_BYTES;
-          const uint32_t w0 = cs[4 * g + rr][0];
-          if (head && !(w0 & 0x200u) && (w0 & 0x1FFu)) {
-            int hb = (int)(w0 & 0x1FFu) - 1;
-            atomicOr(reinterpret_cast<uint32_t *>(img_g + gl.r * TABLE_BYTES) + (hb >> 5), 1u << (hb & 31));
-          }
-          uint64_t dealm = __ballot(head && (w0 & 0x200u));
-          while (dealm) {  // rare: ~1 table in 25 per sub-step
-            const int l = __ffsll((unsigned long long)dealm) - 1;  // lane 15*q holds row q's command
-            dealm &= dealm - 1ull;
-            const int q = l / 15;
-            const uint32_t wq = __builtin_amdgcn_readlane(w0, l);
-            const uint4 kk = *reinterpret_cast<const uint4 *>(&ring[4 * g + q][(wq >> 16) & 15u][0]);
-            deal_image(img_g + q * TABLE_BYTES, kk.x, kk.y, kk.z, kk.w, c);
-          }
-          wave_lds_order();
-          uint32_t a;
-          uint64_t H;
-          obs_chunk_load(img_g, (int)((w0 >> 10) & 3u), gl, a, H);
-          const uint64_t la = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
-          const uint64_t lb = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
-          if (olane) obs_chunk_store(a, H, (int)((w0 >> 10) & 3u), (w0 >> 12) & 15u, optr[k], gz);
-          if (ml.active) *mptr[k] = mask_dword(la, lb, ml);
+          const uint32_t w0 = w0c[k];
+          apply(g, w0, 4);
+          uint4 q0, q1;
+          byte_chunk_load(bimg + 4 * g * BROW, (w0 >> 10) & 3u, bl, q0, q1);
+          if (olane && !(A.debug & 8)) byte_chunk_store(q0, q1, (w0 >> 10) & 3u, (w0 >> 12) & 15u, optr[k], bl);
+          if (ml.active && !(A.debug & 16)) *mptr[k] = mask_dword(lac[k], lbc[k], ml);
           optr[k] += ostep;
           mptr[k] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(mptr[k]) + mstep);
         }
@@ -702,59 +846,28 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
       uint8_t *mask_base = fin ? A.last_mask : A.out.legal_action_mask;
       const int64_t rowb = fin ? table0 : row0;
       const uint32_t(*cs)[CMD_WORDS] = cmd[s & (FL_CR - 1)];
-      uint32_t w0[GPW];
-#pragma unroll
-      for (int k = 0; k < GPW; k++) {
-        const int g = (wave - FW_EMIT0) + k * NE;
-        w0[k] = (left[k] > 0) ? cs[4 * g + rr][0] : 0u;
-      }
-      uint32_t a[GPW];
-      uint64_t H[GPW], la[GPW], lb[GPW];
 #pragma unroll
       for (int k = 0; k < GPW; k++) {
         const int g = (wave - FW_EMIT0) + k * NE;
         if (left[k] <= 0) continue;
-        uint8_t *img_g = img + 4 * g * TABLE_BYTES;
-        const bool is_head = head && (gl.r < left[k]);
-        if (is_head && !(w0[k] & 0x200u) && (w0[k] & 0x1FFu)) {
-          int hb = (int)(w0[k] & 0x1FFu) - 1;
-          atomicOr(reinterpret_cast<uint32_t *>(img_g + gl.r * TABLE_BYTES) + (hb >> 5), 1u << (hb & 31));
-        }
-        uint64_t dealm = __ballot(is_head && (w0[k] & 0x200u));
-        if (dealm) {
-          do {
-            const int l = __ffsll((unsigned long long)dealm) - 1;
-            dealm &= dealm - 1ull;
-            const int q = l / 15;
-            const uint32_t wq = __builtin_amdgcn_readlane(w0[k], l);
-            const uint4 kk = *reinterpret_cast<const uint4 *>(&ring[4 * g + q][(wq >> 16) & 15u][0]);
-            deal_image(img_g + q * TABLE_BYTES, kk.x, kk.y, kk.z, kk.w, c);
-          } while (dealm);
-        }
-        wave_lds_order();
-        if (emit) {
-          obs_chunk_load(img_g, (int)((w0[k] >> 10) & 3u), gl, a[k], H[k]);
-          la[k] = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
-          lb[k] = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
-        }
-      }
-      if (emit) {
-#pragma unroll
-        for (int k = 0; k < GPW; k++) {
-          const int g = (wave - FW_EMIT0) + k * NE;
-          if (left[k] <= 0) continue;
-          if (gl.r < left[k] && obs_base)
-            obs_chunk_store(a[k], H[k], (int)((w0[k] >> 10) & 3u), (w0[k] >> 12) & 15u,
-                            obs_base + (rowb + 4 * g) * BRL_OBS_SIZE, gl);
-          if (mask_base) {
-            uint8_t *mdst = mask_base + (rowb + 4 * g) * BRL_NUM_ACTIONS;
-            if (left[k] >= 4) {
-              if (ml.active) reinterpret_cast<uint32_t *>(mdst)[c.lane] = mask_dword(la[k], lb[k], ml);
-            } else {
-              for (int q = 0; q < left[k]; q++) {
-                uint64_t lq = *reinterpret_cast<const uint64_t *>(&cs[4 * g + q][2]);
-                emit_mask_row(lq, mdst + q * BRL_NUM_ACTIONS, c);
-              }
+        const uint32_t w0 = cs[4 * g + rr][0];
+        apply(g, w0, left[k]);
+        if (!emit) continue;
+        uint4 q0, q1;
+        byte_chunk_load(bimg + 4 * g * BROW, (w0 >> 10) & 3u, bl, q0, q1);
+        const uint64_t la = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
+        const uint64_t lb = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
+        if (gl.r < left[k] && obs_base)
+          byte_chunk_store(q0, q1, (w0 >> 10) & 3u, (w0 >> 12) & 15u,
+                           obs_base + (rowb + 4 * g) * BRL_OBS_SIZE + bl.out_off, bl);
+        if (mask_base) {
+          uint8_t *mdst = mask_base + (rowb + 4 * g) * BRL_NUM_ACTIONS;
+          if (left[k] >= 4) {
+            if (ml.active) reinterpret_cast<uint32_t *>(mdst)[c.lane] = mask_dword(la, lb, ml);
+          } else {
+            for (int q = 0; q < left[k]; q++) {
+              uint64_t lq = *reinterpret_cast<const uint64_t *>(&cs[4 * g + q][2]);
+              emit_mask_row(lq, mdst + q * BRL_NUM_ACTIONS, c);
             }
           }
         }
