@@ -80,7 +80,26 @@ struct LutRef {
   const int4 *keys;
   const int4 *values;
   uint32_t len;
+  const uint4 *hands;  // per row: the four packed hand words (hand_obs[seat] << 4, image words 7..10), derived from keys
 };
+
+// the packed hand words of every LUT row, once per upload: what a re-deal copies into a table image
+// (same card -> observation-bit mapping as deal_image: obs bit i = rank * 4 + suit, wb5/vis_pgx.py:13-24)
+__global__ void k_lut_hands(const int4 *keys, uint4 *hands, int64_t len) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= len) return;
+  const int4 k = keys[r];
+  uint64_t h[4] = {0ull, 0ull, 0ull, 0ull};
+  for (int i = 0; i < 52; i++) {
+    const int os_rank = i >> 2, os_suit = i & 3, dsuit = 3 - os_suit, rank = (os_rank + 1) % 13;
+    const uint32_t w = (uint32_t)((dsuit == 0) ? k.x : ((dsuit == 1) ? k.y : ((dsuit == 2) ? k.z : k.w)));
+    const uint32_t owner = (w >> (2 * (12 - rank))) & 3u;
+#pragma unroll
+    for (int s = 0; s < 4; s++) h[s] |= (owner == (uint32_t)s) ? (1ull << (4 + i)) : 0ull;
+  }
+  hands[2 * r] = make_uint4((uint32_t)h[0], (uint32_t)(h[0] >> 32), (uint32_t)h[1], (uint32_t)(h[1] >> 32));
+  hands[2 * r + 1] = make_uint4((uint32_t)h[2], (uint32_t)(h[2] >> 32), (uint32_t)h[3], (uint32_t)(h[3] >> 32));
+}
 
 // A5 post-step half of auto_reset (src/utils.py:45-55) for every table of the wave that
 // just terminated: deal board bctr+1 of that slot, keep (terminated, rewards).
@@ -1172,6 +1191,7 @@ struct brl_handle {
   int device;
   int4 *lut_keys;
   int4 *lut_values;
+  uint4 *lut_hands;
   int64_t lut_len;
   float *neg_log_n;
   uint64_t seed;
@@ -1206,8 +1226,10 @@ extern "C" int brl_version(void) { return 1; }
 static int upload_lut(brl_handle *h, const int32_t *keys, const int32_t *values, int64_t len) {
   if (h->lut_keys) HIP_TRY(hipFree(h->lut_keys));
   if (h->lut_values) HIP_TRY(hipFree(h->lut_values));
+  if (h->lut_hands) HIP_TRY(hipFree(h->lut_hands));
   h->lut_keys = nullptr;
   h->lut_values = nullptr;
+  h->lut_hands = nullptr;
   h->lut_len = 0;
   if (len > 0) {
     NEED(keys && values, "lut_keys / lut_values are NULL with lut_len > 0");
@@ -1216,6 +1238,10 @@ static int upload_lut(brl_handle *h, const int32_t *keys, const int32_t *values,
     HIP_TRY(hipMalloc(&h->lut_values, (size_t)len * 16));
     HIP_TRY(hipMemcpy(h->lut_keys, keys, (size_t)len * 16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->lut_values, values, (size_t)len * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&h->lut_hands, (size_t)len * 32));
+    hipLaunchKernelGGL(k_lut_hands, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, 0, h->lut_keys, h->lut_hands, len);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
     h->lut_len = len;
   }
   return BRL_OK;
@@ -1280,6 +1306,7 @@ extern "C" int brl_destroy(brl_handle *h) {
   (void)hipSetDevice(h->device);
   if (h->lut_keys) (void)hipFree(h->lut_keys);
   if (h->lut_values) (void)hipFree(h->lut_values);
+  if (h->lut_hands) (void)hipFree(h->lut_hands);
   if (h->neg_log_n) (void)hipFree(h->neg_log_n);
   free(h);
   return BRL_OK;
@@ -1293,7 +1320,7 @@ extern "C" int brl_set_rng(brl_handle *h, uint64_t seed, uint64_t env_offset) {
 }
 
 static inline Rng rng_of(const brl_handle *h) { return Rng{(uint32_t)h->seed, (uint32_t)(h->seed >> 32)}; }
-static inline LutRef lut_of(const brl_handle *h) { return LutRef{h->lut_keys, h->lut_values, (uint32_t)h->lut_len}; }
+static inline LutRef lut_of(const brl_handle *h) { return LutRef{h->lut_keys, h->lut_values, (uint32_t)h->lut_len, h->lut_hands}; }
 static inline unsigned wave_grid(int64_t n, int K) {
   int64_t per_block = (int64_t)WAVES_PER_BLOCK * K;
   return (unsigned)((n + per_block - 1) / per_block);
@@ -1386,10 +1413,10 @@ extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int
   hipLaunchKernelGGL((k_rollout_flow<TPB, NW>), dim3((unsigned)((n + TPB - 1) / TPB)), dim3(NW * 64), 0, \
                      (hipStream_t)stream, A)
   if (h->flow && (cfg == 1607 || cfg == 3207 || cfg == 3211)) {
-    switch (cfg) {  // the flow kernel has one more wave (prep) for the same number of emit waves
-      case 1607: LAUNCH_FLOW(16, 8); break;
-      case 3207: LAUNCH_FLOW(32, 8); break;
-      default: LAUNCH_FLOW(32, 12); break;
+    switch (cfg) {  // the flow kernel has two more waves (apply, prep) for the same number of emit waves
+      case 1607: LAUNCH_FLOW(16, 9); break;
+      case 3207: LAUNCH_FLOW(32, 9); break;
+      default: LAUNCH_FLOW(32, 13); break;
     }
     HIP_TRY(hipGetLastError());
     return BRL_OK;

@@ -31,6 +31,12 @@ __device__ __forceinline__ void fl_st(int *p, int v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void fl_order() { asm volatile("" ::: "memory"); }
+// Waiting waves sleep (s_sleep FL_NAP = 64 * FL_NAP clocks per poll) so that their polling does not eat the
+// CU's instruction issue slots — the waves on the critical chain need them; the two producers the followers
+// actually wait for (prep: commands, apply: byte images) ping them awake right after publishing (s_wakeup ends
+// every s_sleep of the workgroup; the flag must be visible first, hence the lgkmcnt wait).
+#define FL_NAP 8
+__device__ __forceinline__ void fl_wake() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory"); }
 
 // ---- chain-friendly auction state of the logic wave (fast mode) -----------------------------------
 // d: [8:0] dealer + turn (seat = low 2 bits) | [14:9] rem = 35 - lb1 | [16:15] last bidder seat |
@@ -38,7 +44,10 @@ __device__ __forceinline__ void fl_order() { asm volatile("" ::: "memory"); }
 //    player to act is on the last bidder's side); X / XX is legal iff e is 0 or 5 |
 //    [22:20] pass count, +1 once a bid exists  => the auction is over iff bit 22 is set.
 constexpr uint32_t FD_REM = 9, FD_LBSEAT = 15, FD_E = 17, FD_PASS = 20, FD_TERM = 22;
-constexpr uint32_t FL_TAG_VALID = 0x80000u;  // ring entry word 9 = sc_bits | (valid | board & 0x7FFFF) << 12
+constexpr uint32_t FL_TAG_VALID = 0x80000u;  // ring entry word FR_TAG = sc_bits | (valid | board & 0x7FFFF) << 12
+// ring entry (64 B): the board's four packed hand words (precomputed per LUT row, k_lut_hands), its DDS values,
+// its LUT row and fresh scalars | tag
+constexpr int FR_WORDS = 16, FR_HANDS = 0, FR_VALUES = 8, FR_IDX = 12, FR_TAG = 13;
 
 __device__ __forceinline__ uint32_t fast_from_legacy(uint32_t sc, uint32_t sch) {
   const uint32_t lb1 = bits(sc, SC_LB1, 6), st = bits(sc, SC_DEALER, 2) + bits(sch, SCH_TURN, 9);
@@ -141,6 +150,45 @@ __device__ __forceinline__ void deal_bytes(uint8_t *brow, uint32_t q0, uint32_t 
   }
 }
 
+// the same for BOTH images of a table with one set of ballots: packed image (history zero, the four hand
+// words) and byte image (history zero; lane L < 52 writes the 4 hand bytes [4j, 4j+4) of seat L / 13's tail,
+// j = L % 13; lanes 52..63 clear the 4 x 3 history dwords of the tails)
+struct DealLane {
+  uint32_t seat;  // whose hand word this lane expands (lanes < 52)
+  uint32_t sh;    // bit offset of its 4 cards in that word
+  uint32_t off;   // byte offset of the dword it writes within the table's byte image
+};
+__device__ __forceinline__ DealLane make_deal_lane() {
+  DealLane d;
+  const uint32_t lane = threadIdx.x & 63u;
+  if (lane < 52u) {
+    d.seat = lane / 13u;
+    d.sh = 4u * (lane - 13u * d.seat);
+    d.off = (uint32_t)BTAIL + 64u * d.seat + 12u + d.sh;
+  } else {
+    const uint32_t q = lane - 52u;
+    d.seat = 4u;
+    d.sh = 0u;
+    d.off = (uint32_t)BTAIL + 64u * (q / 3u) + 4u * (q % 3u);
+  }
+  return d;
+}
+__device__ __forceinline__ void deal_both(uint8_t *img, uint8_t *brow, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3,
+                                          const LaneConst &c, const DealLane &dl) {
+  const uint32_t ksel = (c.dsuit == 0) ? q0 : ((c.dsuit == 1) ? q1 : ((c.dsuit == 2) ? q2 : q3));
+  const uint32_t owner = (ksel >> c.dshift) & 3u;
+  const bool card = c.lane < 52;
+  const uint64_t h0 = __ballot(card && owner == 0u), h1 = __ballot(card && owner == 1u);
+  const uint64_t h2 = __ballot(card && owner == 2u), h3 = __ballot(card && owner == 3u);
+  uint64_t *img64 = reinterpret_cast<uint64_t *>(img);
+  const uint64_t hv = (c.lane == 7) ? h0 : ((c.lane == 8) ? h1 : ((c.lane == 9) ? h2 : h3));
+  if (c.lane < 11) img64[c.lane] = (c.lane < 7) ? 0ull : (hv << 4);
+  if (c.lane < BTAIL / 16) *reinterpret_cast<uint4 *>(brow + 16 * c.lane) = make_uint4(0u, 0u, 0u, 0u);
+  const uint64_t hs = (dl.seat == 0u) ? h0 : ((dl.seat == 1u) ? h1 : ((dl.seat == 2u) ? h2 : h3));
+  const uint32_t nib = (dl.seat < 4u) ? ((uint32_t)(hs >> dl.sh) & 0xFu) : 0u;
+  *reinterpret_cast<uint32_t *>(brow + dl.off) = __umul24(nib, 0x204081u) & 0x01010101u;
+}
+
 __device__ __forceinline__ void byte_chunk_load(const uint8_t *bimg_group, uint32_t seat, const ByteLane &b, uint4 &q0,
                                                 uint4 &q1) {
   const uint4 *src = reinterpret_cast<const uint4 *>(bimg_group + b.src_off + ((seat << 6) & b.tail_sel));
@@ -183,22 +231,26 @@ __device__ __forceinline__ int fl_min_done(const int *f_done, int first, int cou
 #endif
 
 // wave roles
-constexpr int FW_LOGIC = 0, FW_LOADER = 1, FW_SCORER = 2, FW_PREP = 3, FW_EMIT0 = 4;
+// (hardware wave w runs on SIMD w % 4: the four sequential chains — logic, prep, apply, scorer — get one SIMD
+// each, ahead of the emit waves they share it with: s_setprio below)
+constexpr int FW_LOGIC = 0, FW_PREP = 1, FW_APPLY = 2, FW_SCORER = 3, FW_LOADER = 4, FW_EMIT0 = 5;
 
 template <int TPB, int NW>
 __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
-  static_assert(TPB <= 32 && NW >= 5 && NW <= 16, "logic + loader + scorer + prep + >=1 emit wave");
+  static_assert(TPB <= 32 && NW >= 6 && NW <= 16, "logic + loader + scorer + apply + prep + >=1 emit wave");
   static_assert(TPB % 4 == 0, "emit waves write 4 consecutive tables per instruction");
   constexpr int NE = NW - FW_EMIT0;
   constexpr int B = WS_BATCH;
   __shared__ __attribute__((aligned(16))) uint8_t img[TPB * TABLE_BYTES];
-  __shared__ __attribute__((aligned(16))) uint8_t bimg[TPB * BROW];  // byte images (emit waves)
+  __shared__ __attribute__((aligned(16))) uint8_t bimg[2 * TPB * BROW];  // byte images: bimg[s & 1] holds state s
   __shared__ __attribute__((aligned(16))) uint32_t cmd[FL_CR][TPB][CMD_WORDS];
-  __shared__ __attribute__((aligned(16))) uint32_t ring[TPB][WS_RING][RING_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t ring[TPB][WS_RING][FR_WORDS];
   __shared__ __attribute__((aligned(8))) uint2 spost[FL_CR][TPB];  // fast mode: (d, static word) of state s
   __shared__ uint32_t udraw[FL_DR][TPB];
   __shared__ int f_state;    // states posted by the logic wave (fast mode)
   __shared__ int f_posted;   // command slots posted (prep wave; the logic wave in legacy mode)
+  __shared__ int f_applied;  // states the apply wave has put into the byte images
+  __shared__ int f_built[16]; // per emit wave: its groups' byte images are built
   __shared__ int f_draws;    // action draws produced by the loader wave
   __shared__ int f_mode;     // 0 undecided, 1 fast (logic -> prep -> followers), 2 legacy (logic -> followers)
   __shared__ int f_abort;
@@ -240,17 +292,18 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
     for (; ndraw < first; ndraw++) draw_slot(ndraw);
     if (tl < TPB) {  // no board in the ring yet: clear the valid bit of every entry's tag
 #pragma unroll
-      for (int k = 0; k < WS_RING; k++) ring[tl][k][9] = 0u;
+      for (int k = 0; k < WS_RING; k++) ring[tl][k][FR_TAG] = 0u;
     }
   }
   if (tid == 0) {
     f_state = 0;
     f_posted = 0;
+    f_applied = 0;
     f_mode = 0;
     f_abort = 0;
     f_draws = min(total + 1, 4 - (int)(A.draw_base & 3u));
   }
-  if (tid < 16) f_done[tid] = 0;
+  if (tid < 16) { f_done[tid] = 0; f_built[tid] = 0; }
   __syncthreads();  // images and the first draws are in LDS; the ring follows (entry tags)
   FL_STAMP(1);
 
@@ -259,7 +312,8 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
   if (wave == FW_LOADER) {
     // ------------------------------------------------------------------ loader wave
     uint32_t nb = 0, nb0 = 0, pbase = 0, pcount = 0, pidx[3] = {0, 0, 0}, pscb[3] = {0, 0, 0};
-    int4 pk[3], pv[3];
+    uint4 pha[3], phb[3];
+    int4 pv[3];
     if (valid) {
       nb0 = (uint32_t)(ctr_word >> 32) + 1u;
       nb = nb0;
@@ -268,7 +322,8 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         board_params(A.g, env_id, nb + (uint32_t)k, A.lut.len, pidx[k], pscb[k]);
-        pk[k] = A.lut.keys[pidx[k]];
+        pha[k] = A.lut.hands[2 * (size_t)pidx[k]];
+        phb[k] = A.lut.hands[2 * (size_t)pidx[k] + 1];
         pv[k] = A.lut.values[pidx[k]];
       }
       nb += 2u;
@@ -301,20 +356,21 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
             const uint32_t b = pbase + (uint32_t)k;
             uint32_t *e = &ring[tls][b % WS_RING][0];
             uint4 *dst = reinterpret_cast<uint4 *>(e);
-            dst[0] = make_uint4((uint32_t)pk[k].x, (uint32_t)pk[k].y, (uint32_t)pk[k].z, (uint32_t)pk[k].w);
-            dst[1] = make_uint4((uint32_t)pv[k].x, (uint32_t)pv[k].y, (uint32_t)pv[k].z, (uint32_t)pv[k].w);
-            e[8] = pidx[k];
+            dst[0] = pha[k];
+            dst[1] = phb[k];
+            dst[2] = make_uint4((uint32_t)pv[k].x, (uint32_t)pv[k].y, (uint32_t)pv[k].z, (uint32_t)pv[k].w);
+            e[FR_IDX] = pidx[k];
             fl_order();
-            __hip_atomic_store(&e[9], pscb[k] | ((FL_TAG_VALID | (b & 0x7FFFFu)) << 12), __ATOMIC_RELAXED,
+            __hip_atomic_store(&e[FR_TAG], pscb[k] | ((FL_TAG_VALID | (b & 0x7FFFFu)) << 12), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
           }
         }
         pcount = 0;
         progress = true;
       }
-      // 3. boards whose slots every reader (scorer + emit waves) is done with
+      // 3. boards whose slots every reader (scorer + apply waves) is done with
       {
-        const int R = fl_min_done(f_done, FW_SCORER, NW - FW_SCORER, c.lane);
+        const int R = fl_min_done(f_done, FW_APPLY, 2, c.lane);
         if (R > lo) {
           uint32_t dealt = 0;
           for (int s = lo; s < R; s++) dealt += (cmd[s & (FL_CR - 1)][tls][0] >> 9) & 1u;
@@ -337,7 +393,8 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
             for (int k = 0; k < 3; k++) {
               if ((uint32_t)k < pcount) {
                 board_params(A.g, env_id, nb + (uint32_t)k, A.lut.len, pidx[k], pscb[k]);
-                pk[k] = A.lut.keys[pidx[k]];
+                pha[k] = A.lut.hands[2 * (size_t)pidx[k]];
+                phb[k] = A.lut.hands[2 * (size_t)pidx[k] + 1];
                 pv[k] = A.lut.values[pidx[k]];
               }
             }
@@ -350,7 +407,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
       if (progress) {
         idle = 0;
       } else {
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(FL_NAP);
         if (++idle > FL_SPIN_MAX) { if (c.lane == 0) fl_st(&f_abort, 1); break; }
         if (aborted()) break;
       }
@@ -371,7 +428,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
     // against the board's tag when it is used (the loader may not have filled the entry yet)
     uint32_t rslot = (bctr + 1u) % WS_RING;
     auto ring_peek = [&]() {
-      const uint64_t v = __hip_atomic_load(reinterpret_cast<const uint64_t *>(&ring[tls][rslot][8]), __ATOMIC_RELAXED,
+      const uint64_t v = __hip_atomic_load(reinterpret_cast<const uint64_t *>(&ring[tls][rslot][FR_IDX]), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
       return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
     };
@@ -379,7 +436,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
     auto ring_take = [&](bool deal) {  // make sure `nxt` is board bctr + 1 for every dealing lane
       int spins = 0;
       while (__any(deal && (nxt.y >> 12) != (FL_TAG_VALID | ((bctr + 1u) & 0x7FFFFu)))) {
-        if (spins) __builtin_amdgcn_s_sleep(1);
+        if (spins) __builtin_amdgcn_s_sleep(FL_NAP);
         nxt = ring_peek();
         if (++spins > FL_SPIN_MAX || aborted()) { dead = true; break; }
       }
@@ -391,7 +448,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
       if (s + 1 >= draws_seen) {
         int spins = 0;
         while ((draws_seen = fl_ld(&f_draws)) <= s + 1) {
-          __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_s_sleep(FL_NAP);
           if (++spins > FL_SPIN_MAX || aborted()) { dead = true; break; }
         }
       }
@@ -407,7 +464,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
         if (s >= space_upto) {  // the state ring is full: wait for the prep wave
           int spins = 0;
           while ((space_upto = fl_ld(&f_done[FW_PREP]) + FL_CR) <= s) {
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(FL_NAP);
             if (++spins > FL_SPIN_MAX || aborted()) { dead = true; break; }
           }
         }
@@ -444,9 +501,9 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
         if (s >= space_upto) {  // the command ring is full: wait for the slowest follower
           int spins = 0;
           for (;;) {
-            space_upto = fl_min_done(f_done, 1, NW - 1, c.lane) + FL_CR;
+            space_upto = fl_min_done(f_done, FW_APPLY, NW - FW_APPLY, c.lane) + FL_CR;
             if (s < space_upto) break;
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(FL_NAP);
             if (++spins > FL_SPIN_MAX || aborted()) { dead = true; break; }
           }
         }
@@ -495,12 +552,13 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
     // Shadows the logic wave with the full legacy step: same draws, and on a re-deal the fresh scalars come
     // with the posted state, so it never touches the board ring.  Command slot s = what sub-step s-1 did +
     // how state s looks (legal mask, observer seat, vulnerability nibble).
+    __builtin_amdgcn_s_setprio(2);
     bool dead = false;
     int mode = 0;
     {
       int spins = 0;
       while ((mode = fl_ld(&f_mode)) == 0) {
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(FL_NAP);
         if (++spins > FL_SPIN_MAX || aborted()) { dead = true; break; }
       }
     }
@@ -517,7 +575,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
         if (s >= seen) {
           int spins = 0;
           while ((seen = fl_ld(&f_state)) <= s) {
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(FL_NAP);
             if (++spins > FL_SPIN_MAX || aborted()) { dead = true; break; }
           }
           if (aborted()) dead = true;
@@ -554,9 +612,9 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
         if (s >= space_upto) {  // the command ring is full: wait for the slowest follower
           int spins = 0;
           for (;;) {
-            space_upto = fl_min_done(f_done, 1, NW - 1, c.lane) + FL_CR;
+            space_upto = fl_min_done(f_done, FW_APPLY, NW - FW_APPLY, c.lane) + FL_CR;
             if (s < space_upto) break;
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(FL_NAP);
             if (++spins > FL_SPIN_MAX || aborted()) { dead = true; break; }
           }
         }
@@ -567,6 +625,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
         }
         fl_order();
         if (c.lane == 0) fl_st(&f_posted, s + 1);
+        fl_wake();
         FL_STAMP(2 + s);
       }
       if (tl < TPB) reinterpret_cast<uint2 *>(img + tl * TABLE_BYTES)[W_SC] = make_uint2(sc, sch);
@@ -581,6 +640,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
   } else if (wave == FW_SCORER) {
     // ------------------------------------------------------------------ scorer wave
     // Works in batches of WS_BATCH command slots (three passes, see k_rollout_ws).
+    __builtin_amdgcn_s_setprio(1);
     __shared__ __attribute__((aligned(16))) uint32_t ev[3][64][8];     // finished boards of this batch
     __shared__ __attribute__((aligned(16))) int acc[WS_BATCH][64][4];  // reward sums by player id per macro-step
     __shared__ uint32_t minfo[WS_BATCH][64];                           // per macro-step: actor, action, n_legal, done
@@ -598,7 +658,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
       {
         int spins = 0;
         while (fl_ld(&f_posted) < s1) {
-          __builtin_amdgcn_s_sleep(4);
+          __builtin_amdgcn_s_sleep(FL_NAP);
           if (++spins > FL_SPIN_MAX || aborted()) { dead = true; break; }
         }
         if (aborted()) dead = true;
@@ -628,7 +688,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
           cur_info |= 1u << 14;  // done (G2)
         }
         if (w.x & 0x200u) {
-          const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tls][(w.x >> 16) & 15u][4]);
+          const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tls][(w.x >> 16) & 15u][FR_VALUES]);
           pack_tricks(ts, vv.x, vv.y, vv.z, vv.w);
           ts.fd = 0;
         }
@@ -704,18 +764,192 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
       p[W_TR] = make_uint2(ts.t0, ts.t1);
       p[W_REW] = make_uint2(ts.r01, ts.r23);
     }
+  } else if (wave == FW_APPLY) {
+    // ------------------------------------------------------------------ apply wave
+    __builtin_amdgcn_s_setprio(2);
+    // Keeps the images up to date for everybody: the packed images (img: what goes back to HBM) and TWO byte
+    // images per table (bimg[s & 1] holds state s), so that the emit waves only copy.  Lane = table for the
+    // calls (one byte per call and copy); a re-deal is wave-cooperative.  bimg[s & 1] was last written for
+    // state s-2, so it needs the calls of sub-steps s-2 (carried over from the previous command) and s-1.
+    bool dead = false;
+    uint32_t w0p = 0;  // command word 0 of slot s-1
+    const int dg = c.lane >> 4, dj = c.lane & 15;  // deal pass: 16 lanes per table, lane dj <-> rank dj (4 cards)
+#ifdef BRL_TIMING
+    unsigned long long dp_t[4] = {0, 0, 0, 0};
+    int dp_n = 0;
+#endif
+    auto deal_pass = [&](uint64_t mask, uint32_t wsrc, uint8_t *bdst, bool packed) {
+      while (mask) {
+#ifdef BRL_TIMING
+        const unsigned long long ta = __builtin_amdgcn_s_memtime();
+        dp_n++;
+#endif
+        int q[4];
+        uint32_t wq[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          q[k] = mask ? (int)__ffsll((unsigned long long)mask) - 1 : -1;
+          mask &= mask - (mask ? 1ull : 0ull);
+          wq[k] = __builtin_amdgcn_readlane(wsrc, q[k] < 0 ? 0 : q[k]);
+        }
+        const int tq = (dg == 0) ? q[0] : ((dg == 1) ? q[1] : ((dg == 2) ? q[2] : q[3]));
+        const uint32_t wt = (dg == 0) ? wq[0] : ((dg == 1) ? wq[1] : ((dg == 2) ? wq[2] : wq[3]));
+#ifdef BRL_TIMING
+        const unsigned long long tb = __builtin_amdgcn_s_memtime();
+        unsigned long long tc = tb;
+#endif
+        if (tq >= 0) {
+          const uint32_t *e = &ring[tq][(wt >> 16) & 15u][FR_HANDS];
+          const uint4 ha = *reinterpret_cast<const uint4 *>(e), hb = *reinterpret_cast<const uint4 *>(e + 4);
+#ifdef BRL_TIMING
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          tc = __builtin_amdgcn_s_memtime();
+#endif
+          const uint64_t h0 = (uint64_t)ha.x | ((uint64_t)ha.y << 32), h1 = (uint64_t)ha.z | ((uint64_t)ha.w << 32);
+          const uint64_t h2 = (uint64_t)hb.x | ((uint64_t)hb.y << 32), h3 = (uint64_t)hb.z | ((uint64_t)hb.w << 32);
+          uint8_t *brow = bdst + tq * BROW;
+          // no history: 26 x 16 B by 16 lanes in two writes (the second one clamped)
+          *reinterpret_cast<uint4 *>(brow + 16 * dj) = make_uint4(0u, 0u, 0u, 0u);
+          *reinterpret_cast<uint4 *>(brow + 16 * min(16 + dj, BTAIL / 16 - 1)) = make_uint4(0u, 0u, 0u, 0u);
+          // the four observer tails: lane dj < 13 expands rank dj's 4 cards of every hand, lanes 13..15 clear
+          // the 3 history dwords
+          const uint32_t sh = 4u * (uint32_t)dj + 4u;
+          const uint32_t off = (dj < 13) ? 12u + 4u * (uint32_t)dj : 4u * (uint32_t)(dj - 13);
+          const uint32_t keep = (dj < 13) ? 0x01010101u : 0u;
+          uint32_t *t0 = reinterpret_cast<uint32_t *>(brow + BTAIL + off);
+          t0[0] = __umul24((uint32_t)(h0 >> sh) & 0xFu, 0x204081u) & keep;
+          t0[16] = __umul24((uint32_t)(h1 >> sh) & 0xFu, 0x204081u) & keep;
+          t0[32] = __umul24((uint32_t)(h2 >> sh) & 0xFu, 0x204081u) & keep;
+          t0[48] = __umul24((uint32_t)(h3 >> sh) & 0xFu, 0x204081u) & keep;
+          if (packed && dj < 11) {
+            const uint64_t hv = (dj == 7) ? h0 : ((dj == 8) ? h1 : ((dj == 9) ? h2 : h3));
+            reinterpret_cast<uint64_t *>(img + tq * TABLE_BYTES)[dj] = (dj < 7) ? 0ull : hv;
+          }
+        }
+#ifdef BRL_TIMING
+        {
+          const unsigned long long td = __builtin_amdgcn_s_memtime();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const unsigned long long te = __builtin_amdgcn_s_memtime();
+          dp_t[0] += tb - ta; dp_t[1] += tc - tb; dp_t[2] += td - tc; dp_t[3] += te - td;
+        }
+#endif
+      }
+    };
+    int posted = 0, emit_read = 0;
+    {  // the emit waves build both byte images from the packed ones first
+      int spins = 0;
+      while (fl_min_done(f_built, FW_EMIT0, NE, c.lane) < 1) {
+        __builtin_amdgcn_s_sleep(FL_NAP);
+        if (++spins > FL_SPIN_MAX || aborted()) { dead = true; break; }
+      }
+    }
+#ifdef BRL_TIMING
+    unsigned long long ap_t[4] = {0, 0, 0, 0};
+    int ap_ndeal = 0;
+#endif
+    for (int s = 0; s <= total && !dead; s++) {
+#ifdef BRL_TIMING
+      const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+#endif
+      if (s >= posted) {
+        int spins = 0;
+        while ((posted = fl_ld(&f_posted)) <= s) {
+          __builtin_amdgcn_s_sleep(FL_NAP);
+          if (++spins > FL_SPIN_MAX || aborted()) { dead = true; break; }
+        }
+        if (aborted()) dead = true;
+        if (dead) break;
+        fl_order();
+      }
+      if (s - 1 > emit_read) {  // every emit wave must have read state s-2 out of bimg[s & 1]
+        int spins = 0;
+        while ((emit_read = fl_min_done(f_done, FW_EMIT0, NE, c.lane)) < s - 1) {
+          __builtin_amdgcn_s_sleep(FL_NAP);
+          if (++spins > FL_SPIN_MAX || aborted()) { dead = true; break; }
+        }
+        if (dead) break;
+      }
+#ifdef BRL_TIMING
+      const unsigned long long tp1 = __builtin_amdgcn_s_memtime();
+#endif
+      const uint32_t w0 = cmd[s & (FL_CR - 1)][tls][0];
+      uint8_t *bcur = bimg + (s & 1) * (TPB * BROW);
+      const uint8_t *bold = bimg + ((s & 1) ^ 1) * (TPB * BROW);
+      const bool deal_now = valid && (w0 & 0x200u), deal_prev = valid && (w0p & 0x200u);
+      // re-deals, up to 4 tables per pass (16 lanes each): boards dealt at this slot (packed + byte image) and,
+      // carried over, those dealt one slot ago (this copy of the byte image still holds the old board)
+      deal_pass((A.debug & 32) ? 0ull : __ballot(deal_now), w0, bcur, true);
+#ifdef BRL_TIMING
+      const unsigned long long tp2 = __builtin_amdgcn_s_memtime();
+      ap_ndeal += __popcll(__ballot(deal_now));
+#endif
+      deal_pass((A.debug & 64) ? 0ull : __ballot(deal_prev), w0p, bcur, false);
+#ifdef BRL_TIMING
+      const unsigned long long tp3 = __builtin_amdgcn_s_memtime();
+#endif
+      wave_lds_order();
+      if (tl < TPB) {
+        uint8_t *brow = bcur + tl * BROW;
+        const uint32_t hp = (deal_prev || deal_now) ? 0u : (w0p & 0x1FFu);  // call of sub-step s-2
+        const uint32_t hn = deal_now ? 0u : (w0 & 0x1FFu);                 // call of sub-step s-1
+        if (hn) {
+          const int hb = (int)hn - 1;
+          atomicOr(reinterpret_cast<uint32_t *>(img + tl * TABLE_BYTES) + (hb >> 5), 1u << (hb & 31));
+        }
+#pragma unroll
+        for (int which = 0; which < 2; which++) {
+          const uint32_t h = which ? hn : hp;
+          if (h) {
+            const int hb = (int)h - 1;
+            if (hb < BTAIL) {
+              brow[hb] = 1;
+            } else {  // the last bid's 12 bytes live in the four observer tails
+#pragma unroll
+              for (int q = 0; q < 4; q++) brow[hb + 64 * q] = 1;
+            }
+          }
+        }
+      }
+#ifdef BRL_TIMING
+      {
+        const unsigned long long tp4 = __builtin_amdgcn_s_memtime();
+        ap_t[0] += tp1 - tp0; ap_t[1] += tp2 - tp1; ap_t[2] += tp3 - tp2; ap_t[3] += tp4 - tp3;
+      }
+#endif
+      w0p = w0;
+      fl_order();
+      if (c.lane == 0) {
+        fl_st(&f_applied, s + 1);
+        fl_st(&f_done[FW_APPLY], s);  // the ring entry of a board dealt at slot s is read once more, at slot s+1
+      }
+      fl_wake();
+      FL_STAMP(2 + s);
+    }
+#ifdef BRL_TIMING
+    if (c.lane == 0 && A.terminated_count) {
+      unsigned long long *d = A.terminated_count + ((size_t)blockIdx.x * NW + wave) * 48;
+      d[38] = ap_t[0]; d[39] = ap_t[1]; d[40] = ap_t[2]; d[41] = ap_t[3]; d[42] = (unsigned long long)ap_ndeal;
+      d[43] = dp_t[0]; d[44] = dp_t[1]; d[45] = dp_t[2]; d[37] = dp_t[3]; d[36] = (unsigned long long)dp_n;
+    }
+#endif
+    if (c.lane == 0) {
+      fl_st(&f_done[FW_APPLY], total + 1);
+      if (dead) {
+        fl_st(&f_abort, 1);
+        fl_st(&f_applied, total + 1);
+      }
+    }
   } else {
     // ------------------------------------------------------------------ emit waves
-    // Observation rows are copied from BYTE images (bimg): one byte per observation bit, seats in absolute
-    // order, so a lane's 32 output bytes are two 16-byte LDS reads plus one rotate per dword (the observer's
-    // seat) instead of 8 nibble extractions + 8 multiplies + 8 masks.  The packed images (img) are kept up to
-    // date too (one ds_or per call): they are what goes back to HBM as the table state.
+    // Copy-only: bimg[s & 1] (kept by the apply wave) -> 4 observation rows per store instruction, plus the 4
+    // legal-mask rows from the command.  One byte per observation bit with the seats in absolute order, so a
+    // lane's 32 output bytes are two 16-byte LDS reads and one rotate per dword (the observer's seat).
     const GroupLane gl = make_group_lane();
     const MaskLane ml = make_mask_lane();
     const ByteLane bl = make_byte_lane();
     constexpr int NG = TPB / 4;
     constexpr int GPW = (NG + NE - 1) / NE;
-    const bool head = (gl.r < 4) && (gl.ch == 0);
     const int rr = (gl.r < 4) ? gl.r : 3;
     int sub = 0;
     int64_t row0 = table0;
@@ -725,48 +959,28 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
       const int g = (wave - FW_EMIT0) + k * NE;
       int64_t rem = (g < NG && !(A.debug & 1)) ? A.n - (table0 + 4 * g) : 0;
       left[k] = (int)max((int64_t)0, min((int64_t)4, rem));
-      if (g < NG) bimg_build(img + 4 * g * TABLE_BYTES, bimg + 4 * g * BROW, gl, bl);
+      if (g < NG) {
+        bimg_build(img + 4 * g * TABLE_BYTES, bimg + 4 * g * BROW, gl, bl);
+        bimg_build(img + 4 * g * TABLE_BYTES, bimg + TPB * BROW + 4 * g * BROW, gl, bl);
+      }
     }
-    wave_lds_order();
-    int avail = 0;  // command slots known to be posted
+    fl_order();  // the apply wave waits for every emit wave's f_built before it touches the byte images
+    if (c.lane == 0) fl_st(&f_built[wave], 1);
+    if (A.debug & 128) {  // experiment: no emit waves at all
+      if (c.lane == 0) fl_st(&f_done[wave], total + 1);
+      goto flow_done;
+    }
+    int avail = 0;  // states known to be in the byte images
     bool dead = false;
     auto wait_slot = [&](int s) {
       if (s < avail) return;
       int spins = 0;
-      while ((avail = fl_ld(&f_posted)) <= s) {
-        __builtin_amdgcn_s_sleep(1);
+      while ((avail = fl_ld(&f_applied)) <= s) {
+        __builtin_amdgcn_s_sleep(FL_NAP);
         if (++spins > FL_SPIN_MAX || aborted()) { dead = true; break; }
       }
       if (aborted()) dead = true;
       fl_order();
-    };
-    // sub-step s-1 applied to group g's images: one call (history bit) or a freshly dealt board per row
-    auto apply = [&](int g, uint32_t w0, int rows) {
-      uint8_t *img_g = img + 4 * g * TABLE_BYTES;
-      uint8_t *bimg_g = bimg + 4 * g * BROW;
-      const bool is_head = head && (gl.r < rows);
-      if (is_head && !(w0 & 0x200u) && (w0 & 0x1FFu)) {
-        const int hb = (int)(w0 & 0x1FFu) - 1;
-        atomicOr(reinterpret_cast<uint32_t *>(img_g + gl.r * TABLE_BYTES) + (hb >> 5), 1u << (hb & 31));
-        uint8_t *brow = bimg_g + gl.r * BROW;
-        if (hb < BTAIL) {
-          brow[hb] = 1;
-        } else {  // the last bid's 12 bytes live in the four observer tails
-#pragma unroll
-          for (int q = 0; q < 4; q++) brow[hb + 64 * q] = 1;
-        }
-      }
-      uint64_t dealm = __ballot(is_head && (w0 & 0x200u));
-      while (dealm) {  // rare: ~1 table in 25 per sub-step
-        const int l = __ffsll((unsigned long long)dealm) - 1;  // lane 15*q holds row q's command
-        dealm &= dealm - 1ull;
-        const int q = l / 15;
-        const uint32_t wq = __builtin_amdgcn_readlane(w0, l);
-        const uint4 kk = *reinterpret_cast<const uint4 *>(&ring[4 * g + q][(wq >> 16) & 15u][0]);
-        deal_image(img_g + q * TABLE_BYTES, kk.x, kk.y, kk.z, kk.w, c);
-        deal_bytes(bimg_g + q * BROW, kk.x, kk.y, kk.z, kk.w, c);
-      }
-      wave_lds_order();
     };
     bool fast = (A.substeps == 1) && A.out.obs && A.out.legal_action_mask;
 #pragma unroll
@@ -783,56 +997,33 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
       }
       const int64_t ostep = A.n * BRL_OBS_SIZE, mstep = A.n * BRL_NUM_ACTIONS;
       const bool olane = gl.r < 4;
-      // software-pipelined: the command words of slot s+1 (when already posted) are read while slot s is
-      // processed, so a slot costs ONE LDS round trip (the image chunks) instead of two
-      uint32_t pw0[GPW];
-      uint64_t pla[GPW], plb[GPW];
-      bool have = false;
       for (; s_next < total; s_next++) {
         wait_slot(s_next);
         if (dead) break;
         const uint32_t(*cs)[CMD_WORDS] = cmd[s_next & (FL_CR - 1)];
-        if (!have) {
-#pragma unroll
-          for (int k = 0; k < GPW; k++) {
-            const int g = (wave - FW_EMIT0) + k * NE;
-            if (left[k] == 0) continue;
-            pw0[k] = cs[4 * g + rr][0];
-            pla[k] = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
-            plb[k] = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
-          }
-        }
-        uint32_t w0c[GPW];
-        uint64_t lac[GPW], lbc[GPW];
-#pragma unroll
-        for (int k = 0; k < GPW; k++) { w0c[k] = pw0[k]; lac[k] = pla[k]; lbc[k] = plb[k]; }
-        have = (s_next + 1 < avail) && (s_next + 1 < total);
-        if (have) {
-          const uint32_t(*cn)[CMD_WORDS] = cmd[(s_next + 1) & (FL_CR - 1)];
-#pragma unroll
-          for (int k = 0; k < GPW; k++) {
-            const int g = (wave - FW_EMIT0) + k * NE;
-            if (left[k] == 0) continue;
-            pw0[k] = cn[4 * g + rr][0];
-            pla[k] = *reinterpret_cast<const uint64_t *>(&cn[4 * g + ml.qa][2]);
-            plb[k] = *reinterpret_cast<const uint64_t *>(&cn[4 * g + ml.qb][2]);
-          }
-        }
+        const uint8_t *bsrc = bimg + (s_next & 1) * (TPB * BROW);
+        uint32_t w0[GPW];
+        uint4 q0[GPW], q1[GPW];
+        uint64_t la[GPW], lb[GPW];
 #pragma unroll
         for (int k = 0; k < GPW; k++) {
           if (left[k] == 0) continue;
           const int g = (wave - FW_EMIT0) + k * NE;
-          const uint32_t w0 = w0c[k];
-          apply(g, w0, 4);
-          uint4 q0, q1;
-          byte_chunk_load(bimg + 4 * g * BROW, (w0 >> 10) & 3u, bl, q0, q1);
-          if (olane && !(A.debug & 8)) byte_chunk_store(q0, q1, (w0 >> 10) & 3u, (w0 >> 12) & 15u, optr[k], bl);
-          if (ml.active && !(A.debug & 16)) *mptr[k] = mask_dword(lac[k], lbc[k], ml);
+          w0[k] = cs[4 * g + rr][0];
+          la[k] = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
+          lb[k] = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
+          byte_chunk_load(bsrc + 4 * g * BROW, (w0[k] >> 10) & 3u, bl, q0[k], q1[k]);
+        }
+        fl_order();
+        if (c.lane == 0) fl_st(&f_done[wave], s_next + 1);  // behind this wave's LDS reads of the slot
+#pragma unroll
+        for (int k = 0; k < GPW; k++) {
+          if (left[k] == 0) continue;
+          if (olane) byte_chunk_store(q0[k], q1[k], (w0[k] >> 10) & 3u, (w0[k] >> 12) & 15u, optr[k], bl);
+          if (ml.active) *mptr[k] = mask_dword(la[k], lb[k], ml);
           optr[k] += ostep;
           mptr[k] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(mptr[k]) + mstep);
         }
-        fl_order();
-        if (c.lane == 0) fl_st(&f_done[wave], s_next + 1);  // behind this wave's cmd / ring reads of the slot
         FL_STAMP(2 + s_next);
       }
       row0 = table0 + (int64_t)s_next * A.n;  // substeps == 1: macro-step index == slot index
@@ -846,33 +1037,35 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
       uint8_t *mask_base = fin ? A.last_mask : A.out.legal_action_mask;
       const int64_t rowb = fin ? table0 : row0;
       const uint32_t(*cs)[CMD_WORDS] = cmd[s & (FL_CR - 1)];
+      const uint8_t *bsrc = bimg + (s & 1) * (TPB * BROW);
+      if (emit) {
 #pragma unroll
-      for (int k = 0; k < GPW; k++) {
-        const int g = (wave - FW_EMIT0) + k * NE;
-        if (left[k] <= 0) continue;
-        const uint32_t w0 = cs[4 * g + rr][0];
-        apply(g, w0, left[k]);
-        if (!emit) continue;
-        uint4 q0, q1;
-        byte_chunk_load(bimg + 4 * g * BROW, (w0 >> 10) & 3u, bl, q0, q1);
-        const uint64_t la = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
-        const uint64_t lb = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
-        if (gl.r < left[k] && obs_base)
-          byte_chunk_store(q0, q1, (w0 >> 10) & 3u, (w0 >> 12) & 15u,
-                           obs_base + (rowb + 4 * g) * BRL_OBS_SIZE + bl.out_off, bl);
-        if (mask_base) {
-          uint8_t *mdst = mask_base + (rowb + 4 * g) * BRL_NUM_ACTIONS;
-          if (left[k] >= 4) {
-            if (ml.active) reinterpret_cast<uint32_t *>(mdst)[c.lane] = mask_dword(la, lb, ml);
-          } else {
-            for (int q = 0; q < left[k]; q++) {
-              uint64_t lq = *reinterpret_cast<const uint64_t *>(&cs[4 * g + q][2]);
-              emit_mask_row(lq, mdst + q * BRL_NUM_ACTIONS, c);
+        for (int k = 0; k < GPW; k++) {
+          const int g = (wave - FW_EMIT0) + k * NE;
+          if (left[k] <= 0) continue;
+          const uint32_t w0 = cs[4 * g + rr][0];
+          uint4 q0, q1;
+          byte_chunk_load(bsrc + 4 * g * BROW, (w0 >> 10) & 3u, bl, q0, q1);
+          const uint64_t la = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
+          const uint64_t lb = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
+          if (gl.r < left[k] && obs_base)
+            byte_chunk_store(q0, q1, (w0 >> 10) & 3u, (w0 >> 12) & 15u,
+                             obs_base + (rowb + 4 * g) * BRL_OBS_SIZE + bl.out_off, bl);
+          if (mask_base) {
+            uint8_t *mdst = mask_base + (rowb + 4 * g) * BRL_NUM_ACTIONS;
+            if (left[k] >= 4) {
+              if (ml.active) reinterpret_cast<uint32_t *>(mdst)[c.lane] = mask_dword(la, lb, ml);
+            } else {
+              for (int q = 0; q < left[k]; q++) {
+                uint64_t lq = *reinterpret_cast<const uint64_t *>(&cs[4 * g + q][2]);
+                emit_mask_row(lq, mdst + q * BRL_NUM_ACTIONS, c);
+              }
             }
           }
         }
       }
       fl_order();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (general path) the LDS reads above have returned
       if (c.lane == 0) fl_st(&f_done[wave], s + 1);
       FL_STAMP(2 + s);
       if (++sub == A.substeps) {
@@ -882,6 +1075,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
     }
     if (dead && c.lane == 0) fl_st(&f_done[wave], total + 1);
   }
+flow_done:
   FL_STAMP(46);
   __syncthreads();
   for (int i = tid; i < TPB * 16; i += NW * 64) {

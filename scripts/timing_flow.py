@@ -17,7 +17,7 @@ from brl_amd.bridge_bidding import _stream
 from bench import synthetic_lut
 N, T = 8192, 32
 keys, values = synthetic_lut(100000, 0)
-tpb, nw = 32, 12
+tpb, nw = 32, 13
 BRIEF = os.environ.get("BRIEF")
 env = brl_amd.BridgeBidding(lut=(keys, values))
 traj = alloc_transition(T, N, env.device)
@@ -38,7 +38,7 @@ starts = d[:, :, 0].min(1) - t0
 ends = d[:, :, 47].max(1) - t0
 print("workgroup start spread: min %d max %d ; end: min %d max %d ; per-workgroup duration mean %d" % (
     starts.min(), starts.max(), ends.min(), ends.max(), (ends - starts).mean()))
-names = ["logic", "loader", "scorer", "prep"] + ["emit%d" % i for i in range(nw - 4)]
+names = ["logic", "prep", "apply", "scorer", "loader"] + ["emit%d" % i for i in range(nw - 5)]
 for wg in ([] if BRIEF else [int(x) for x in os.environ.get("WGS", "5,130").split(",")]):
     b0 = d[wg, :, 0].min()
     print("workgroup", wg, "(start +%d)" % (b0 - t0))
@@ -49,9 +49,15 @@ for wg in ([] if BRIEF else [int(x) for x in os.environ.get("WGS", "5,130").spli
 # averages over all workgroups: per-slot completion time of the logic wave and the slowest emit wave
 rel = d - d[:, :, 0].min(1)[:, None, None]
 lg = rel[:, 0, 2:36].mean(0)
-em = rel[:, 4:, 2:36].max(1).mean(0)
-pr = rel[:, 3, 2:36].mean(0)
+em = rel[:, 5:, 2:36].max(1).mean(0)
+pr = rel[:, 1, 2:36].mean(0)
+ap = rel[:, 2, 2:36].mean(0)
+print('mean over workgroups: apply done time per slot :', ' '.join('%5d' % v for v in ap))
 print('mean over workgroups: prep post time per slot  :', ' '.join('%5d' % v for v in pr))
 print("mean over workgroups: logic post time per slot :", " ".join("%5d" % v for v in lg))
 print("mean over workgroups: slowest emit done / slot :", " ".join("%5d" % v for v in em))
+ph = d[:, 2, 38:43].mean(0)
+print("apply wave phases (mean cycles per launch): wait %d  deal-loop %d  copy-loop %d  calls %d ; deals %.1f" % tuple(ph))
+dp = d[:, 2, [36, 43, 44, 45, 37]].mean(0)
+print("deal passes %.1f per launch; cycles: select %d  ring-read %d  compute+issue-writes %d  drain-writes %d" % tuple(dp))
 print("mean sync stamp", rel[:, :, 1].mean(), "mean end", rel[:, :, 46].max(1).mean(), rel[:, :, 47].max(1).mean())
