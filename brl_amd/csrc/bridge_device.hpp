@@ -456,6 +456,15 @@ __device__ __forceinline__ void deal_image(uint8_t *img, uint32_t q0, uint32_t q
   else if (c.lane < 11) img64[c.lane] = hv << 4;
 }
 
+// The same from the four packed hand words of the board's LUT row (precomputed once per LUT upload,
+// k_lut_hands): no ballots, a re-deal is one 8-byte copy per lane.  `hands` points at 4 x uint64 in LDS.
+__device__ __forceinline__ void deal_hands(uint8_t *img, const uint32_t *hands, const LaneConst &c) {
+  if (c.lane < 11) {
+    const uint64_t hv = *reinterpret_cast<const uint64_t *>(hands + 2 * ((c.lane > 7) ? c.lane - 7 : 0));
+    reinterpret_cast<uint64_t *>(img)[c.lane] = (c.lane < 7) ? 0ull : hv;
+  }
+}
+
 // LDS operations of ONE wave are performed in issue order, so a lane may read what another lane
 // of the same wave wrote earlier without waiting; only the compiler must keep the order.
 __device__ __forceinline__ void wave_lds_order() {

@@ -76,6 +76,8 @@ __device__ __forceinline__ void wave_or_hist(const Wave<K> &w, int hist_bit) {
   }
 }
 
+typedef uint32_t brl_u32x4 __attribute__((ext_vector_type(4)));
+
 struct LutRef {
   const int4 *keys;
   const int4 *values;
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_rollout_random(RolloutArgs A)
 // everybody else.  A table deals at most once every 4 sub-steps (the shortest auction is four
 // passes), which is what makes the 2-deep ring and its 1-sub-step refill latency safe.
 constexpr int CMD_WORDS = 4;
-constexpr int RING_WORDS = 12;  // keys[4] values[4] idx sc_bits pad pad
+constexpr int RING_WORDS = 16;  // hands[8] (the four packed hand words, k_lut_hands) values[4] idx sc_bits pad pad
 constexpr int WS_BATCH = 8;     // sub-steps per workgroup barrier
 constexpr int WS_RING = 12;     // boards kept ahead per table (see the loader wave)
 // cmd[s] word 0: about sub-step s-1: [8:0] history bit + 1 (0 none) | [9] deal | [19:16] ring slot dealt
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   const uint64_t env_id = A.env_offset + (uint64_t)(table0 + tl);
   // loader state (wave 1): next board to fetch, boards in flight
   uint32_t nb = 0, nb0 = 0, pbase = 0, pidx[3] = {0, 0, 0}, pscb[3] = {0, 0, 0};
-  int4 pk[3], pv[3];
+  brl_u32x4 pha[3], phb[3], pv[3];  // (native vectors: HIP's uint4 struct arrays are not promoted to registers here)
   uint64_t ctr_word = 0;
   if (wave == 1 && valid) ctr_word = A.state[(table0 + tl) * 16 + W_CTR];  // issued now, needed after the barrier
   // action draws (Philox is state-independent, so it does not belong on the logic wave's dependency
@@ -506,8 +508,9 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       board_params(A.g, env_id, nb + (uint32_t)k, A.lut.len, pidx[k], pscb[k]);
-      pk[k] = A.lut.keys[pidx[k]];
-      pv[k] = A.lut.values[pidx[k]];
+      pha[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)pidx[k]];
+      phb[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)pidx[k] + 1];
+      pv[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.values)[pidx[k]];
     }
     nb += 2u;
   }
@@ -524,9 +527,11 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
       for (int k = 0; k < 3; k++) {
         if ((uint32_t)k < pcount) {
           uint4 *dst = reinterpret_cast<uint4 *>(&ring[tls][(pbase + (uint32_t)k) % WS_RING][0]);
-          dst[0] = make_uint4((uint32_t)pk[k].x, (uint32_t)pk[k].y, (uint32_t)pk[k].z, (uint32_t)pk[k].w);
-          dst[1] = make_uint4((uint32_t)pv[k].x, (uint32_t)pv[k].y, (uint32_t)pv[k].z, (uint32_t)pv[k].w);
-          dst[2] = make_uint4(pidx[k], pscb[k], 0u, 0u);
+          brl_u32x4 *dv = reinterpret_cast<brl_u32x4 *>(dst);
+          dv[0] = pha[k];
+          dv[1] = phb[k];
+          dv[2] = pv[k];
+          dst[3] = make_uint4(pidx[k], pscb[k], 0u, 0u);
         }
       }
       pcount = 0;
@@ -550,8 +555,9 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
         for (int k = 0; k < 3; k++) {
           if ((uint32_t)k < pcount) {
             board_params(A.g, env_id, nb + (uint32_t)k, A.lut.len, pidx[k], pscb[k]);
-            pk[k] = A.lut.keys[pidx[k]];
-            pv[k] = A.lut.values[pidx[k]];
+            pha[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)pidx[k]];
+            phb[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)pidx[k] + 1];
+            pv[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.values)[pidx[k]];
           }
         }
         nb += pcount;
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
         pend = st.hb1 | ((uint32_t)deal << 9) | (slot << 16) | ((uint32_t)st.seat << 21) | ((uint32_t)st.n_legal << 23);
         if (!have_nxt && __any(deal)) {  // uniform: first deal of the wave
           while (__hip_atomic_load(&ring_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
-          nxt = *reinterpret_cast<const uint2 *>(&ring[tls][(bctr + 1u) % WS_RING][8]);
+          nxt = *reinterpret_cast<const uint2 *>(&ring[tls][(bctr + 1u) % WS_RING][12]);
           have_nxt = true;
         }
         if (deal) {  // A5 post-step half of auto_reset (src/utils.py:45-55): next board from the ring
@@ -615,7 +621,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
           sch = 0;
           lut = nxt.x;
           bctr += 1u;
-          nxt = *reinterpret_cast<const uint2 *>(&ring[tl][(bctr + 1u) % WS_RING][8]);
+          nxt = *reinterpret_cast<const uint2 *>(&ring[tl][(bctr + 1u) % WS_RING][12]);
         }
         if (last && A.substeps > 1) sc = (sc & ~(1u << SC_TERM)) | (term_any << SC_TERM);  // src/utils.py:127
       }
@@ -671,7 +677,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
           cur_info |= 1u << 14;  // done (G2)
         }
         if (w.x & 0x200u) {  // the slot was re-dealt: tricks of the new board, no strain named yet
-          const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tls][(w.x >> 16) & 15u][4]);
+          const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tls][(w.x >> 16) & 15u][8]);
           pack_tricks(ts, vv.x, vv.y, vv.z, vv.w);
           ts.fd = 0;
         }
@@ -801,8 +807,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
               dealm &= dealm - 1ull;
               const int q = l / 15;
               const uint32_t wq = __builtin_amdgcn_readlane(w0, l);
-              const uint4 kk = *reinterpret_cast<const uint4 *>(&ring[4 * g + q][(wq >> 16) & 15u][0]);
-              deal_image(img_g + q * TABLE_BYTES, kk.x, kk.y, kk.z, kk.w, c);
+              deal_hands(img_g + q * TABLE_BYTES, &ring[4 * g + q][(wq >> 16) & 15u][0], c);
             }
             wave_lds_order();
             uint32_t a;
@@ -864,8 +869,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
               dealm &= dealm - 1ull;
               const int q = l / 15;
               const uint32_t wq = __builtin_amdgcn_readlane(w0[k], l);
-              const uint4 kk = *reinterpret_cast<const uint4 *>(&ring[4 * g + q][(wq >> 16) & 15u][0]);
-              deal_image(img_g + q * TABLE_BYTES, kk.x, kk.y, kk.z, kk.w, c);
+              deal_hands(img_g + q * TABLE_BYTES, &ring[4 * g + q][(wq >> 16) & 15u][0], c);
             } while (dealm);
           }
           wave_lds_order();
@@ -924,6 +928,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
 }
 
 #include "rollout_flow.hpp"
+#include "rollout_pipe.hpp"
 
 // ---- policy sub-step: masked categorical over logits + auto_reset(step) -------------------
 struct PolicyArgs {
@@ -1200,6 +1205,7 @@ struct brl_handle {
   int ws_tpb;  // tables per workgroup of the wave-specialised rollout, 0 = use the K-tables-per-wave kernel
   int ws_nw;   // waves per workgroup (1 logic + ws_nw-1 emit)
   int flow;    // 1: flag-synchronised k_rollout_flow instead of the batch-barrier k_rollout_ws
+  int pipe;    // NP > 0: k_rollout_pipe with NP prep waves (BRL_ROLLOUT_PIPE)
 };
 
 static thread_local char g_err[512] = "";
@@ -1264,6 +1270,7 @@ extern "C" int brl_create(int device, const int32_t *lut_keys, const int32_t *lu
   h->ws_tpb = 32;
   h->ws_nw = 11;
   h->flow = getenv("BRL_ROLLOUT_FLOW") ? atoi(getenv("BRL_ROLLOUT_FLOW")) : 0;
+  h->pipe = getenv("BRL_ROLLOUT_PIPE") ? atoi(getenv("BRL_ROLLOUT_PIPE")) : 0;
   const char *ws = getenv("BRL_ROLLOUT_WS");  // "TPBxNW" (16x5 16x7 32x5 32x7 32x8 32x11 64x7 64x11) or "0"
   if (ws) {
     int a = 0, b = 0;
@@ -1422,6 +1429,19 @@ extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int
     return BRL_OK;
   }
 #undef LAUNCH_FLOW
+#define LAUNCH_PIPE(TPB, NW, NP)                                                                             \
+  hipLaunchKernelGGL((k_rollout_pipe<TPB, NW, NP>), dim3((unsigned)((n + TPB - 1) / TPB)), dim3(NW * 64), 0, \
+                     (hipStream_t)stream, A)
+  if (h->pipe && cfg == 3211) {
+    switch (h->pipe) {
+      case 1: LAUNCH_PIPE(32, 12, 1); break;
+      case 3: LAUNCH_PIPE(32, 14, 3); break;
+      default: LAUNCH_PIPE(32, 13, 2); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return BRL_OK;
+  }
+#undef LAUNCH_PIPE
   switch (cfg) {
     case 1605: LAUNCH_WS(16, 5); break;
     case 1607: LAUNCH_WS(16, 7); break;

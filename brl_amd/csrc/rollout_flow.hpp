@@ -58,6 +58,19 @@ __device__ __forceinline__ uint32_t fast_from_legacy(uint32_t sc, uint32_t sch) 
          ((bits(sc, SC_PASS, 3) + has) << FD_PASS);
 }
 
+// back to the packed scalars (sc, sch) of the table state — valid for a live auction with substeps == 1, where
+// _step_count == _turn; TERM / ILLEGAL and the board constants ride in the static word
+__device__ __forceinline__ void fast_to_legacy(uint32_t d, uint32_t stw, uint32_t &sc, uint32_t &sch) {
+  const uint32_t lb1 = 35u - __builtin_amdgcn_ubfe(d, FD_REM, 6), has = lb1 != 0u;
+  const uint32_t dbl = __builtin_amdgcn_ubfe(d, FD_E, 2);
+  const uint32_t x = has & (uint32_t)(dbl >= 1u), xx = has & (uint32_t)(dbl == 2u);
+  const uint32_t pass = __builtin_amdgcn_ubfe(d, FD_PASS, 3) - has;
+  const uint32_t turn = ((d & 0x1FFu) - (stw & 3u)) & 0x1FFu;
+  sc = (stw & 0x0A000FFFu) | (lb1 << SC_LB1) | (__builtin_amdgcn_ubfe(d, FD_LBSEAT, 2) << SC_LBSEAT) | (x << SC_X) |
+       (xx << SC_XX) | (pass << SC_PASS);
+  sch = turn | (turn << SCH_STEP);
+}
+
 // one call by the player to act, drawn uniformly from the legal ones with the 32-bit draw u (same choice as
 // lean_random_step: the k-th legal call in ascending order, k = mulhi(u, n_legal))
 __device__ __forceinline__ uint32_t fast_step(uint32_t d, uint32_t u) {
@@ -312,8 +325,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
   if (wave == FW_LOADER) {
     // ------------------------------------------------------------------ loader wave
     uint32_t nb = 0, nb0 = 0, pbase = 0, pcount = 0, pidx[3] = {0, 0, 0}, pscb[3] = {0, 0, 0};
-    uint4 pha[3], phb[3];
-    int4 pv[3];
+    brl_u32x4 pha[3], phb[3], pv[3];  // (native vectors: HIP's uint4 struct arrays are not promoted to registers here)
     if (valid) {
       nb0 = (uint32_t)(ctr_word >> 32) + 1u;
       nb = nb0;
@@ -322,9 +334,9 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         board_params(A.g, env_id, nb + (uint32_t)k, A.lut.len, pidx[k], pscb[k]);
-        pha[k] = A.lut.hands[2 * (size_t)pidx[k]];
-        phb[k] = A.lut.hands[2 * (size_t)pidx[k] + 1];
-        pv[k] = A.lut.values[pidx[k]];
+        pha[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)pidx[k]];
+        phb[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)pidx[k] + 1];
+        pv[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.values)[pidx[k]];
       }
       nb += 2u;
     }
@@ -356,9 +368,10 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
             const uint32_t b = pbase + (uint32_t)k;
             uint32_t *e = &ring[tls][b % WS_RING][0];
             uint4 *dst = reinterpret_cast<uint4 *>(e);
-            dst[0] = pha[k];
-            dst[1] = phb[k];
-            dst[2] = make_uint4((uint32_t)pv[k].x, (uint32_t)pv[k].y, (uint32_t)pv[k].z, (uint32_t)pv[k].w);
+            brl_u32x4 *dv = reinterpret_cast<brl_u32x4 *>(dst);
+            dv[0] = pha[k];
+            dv[1] = phb[k];
+            dv[2] = pv[k];
             e[FR_IDX] = pidx[k];
             fl_order();
             __hip_atomic_store(&e[FR_TAG], pscb[k] | ((FL_TAG_VALID | (b & 0x7FFFFu)) << 12), __ATOMIC_RELAXED,
@@ -393,9 +406,9 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_flow(RolloutArgs A) {
             for (int k = 0; k < 3; k++) {
               if ((uint32_t)k < pcount) {
                 board_params(A.g, env_id, nb + (uint32_t)k, A.lut.len, pidx[k], pscb[k]);
-                pha[k] = A.lut.hands[2 * (size_t)pidx[k]];
-                phb[k] = A.lut.hands[2 * (size_t)pidx[k] + 1];
-                pv[k] = A.lut.values[pidx[k]];
+                pha[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)pidx[k]];
+                phb[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)pidx[k] + 1];
+                pv[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.values)[pidx[k]];
               }
             }
             nb += pcount;

@@ -17,6 +17,7 @@ N, T = 8192, 32
 keys, values = synthetic_lut(100000, 0)
 for cfg in os.environ.get("CFGS", "32x16").split(","):
     tpb, nw = map(int, cfg.split("x"))
+    nw_dump = int(os.environ.get("NW_DUMP", nw))  # waves per workgroup of the kernel actually launched (pipe: +NP)
     os.environ["BRL_ROLLOUT_WS"] = cfg
     os.environ["BRL_DEBUG"] = os.environ.get("DBG", "0")
     env = brl_amd.BridgeBidding(lut=(keys, values))
@@ -26,11 +27,12 @@ for cfg in os.environ.get("CFGS", "32x16").split(","):
     for f in _capi.TransitionPtrs._names:
         setattr(p, f, _capi.ptr(getattr(traj, f)))
     nblk = (N + tpb - 1) // tpb
-    dump = torch.zeros(nblk * nw * 2 + nblk * nw * 32, dtype=torch.int64, device=env.device)
+    dump = torch.zeros(nblk * nw_dump * 2 + nblk * nw_dump * 32, dtype=torch.int64, device=env.device)
     for i in range(5):
         _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, i * T, 7600.0, C.byref(p), None, None, _capi.ptr(dump), _stream()))
     torch.cuda.synchronize()
     full = dump.cpu().numpy()
+    nw = nw_dump
     d = full[:nblk * nw * 2].reshape(nblk, nw, 2)
     if int(os.environ.get('DBG', '0')) & 256:
         tl = full[nblk * nw * 2:].reshape(nblk, nw, 16, 2)
