@@ -447,6 +447,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   constexpr int NE = NW - 3;
   constexpr int B = WS_BATCH;
 #ifdef BRL_TIMING
+  unsigned long long t_probe0 = 0, t_probe1 = 0, t_probe_n = 0;
   unsigned long long t_wait = 0, t_begin = __builtin_amdgcn_s_memtime();
   unsigned long long t_arr[16], t_rel[16];
   int t_nb = 0;
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
     // configuration): the same work as the general loop below with everything loop-invariant hoisted: per-lane
     // output pointers advanced by a constant, no per-step emit / tail / pointer selection.  The slot of the
     // post-rollout state (s == total) is left to the general code.
-    bool fast = (A.substeps == 1) && A.out.obs && A.out.legal_action_mask && !(A.debug & ~256);
+    bool fast = (A.substeps == 1) && A.out.obs && A.out.legal_action_mask && !(A.debug & ~(256 | 1024));
 #pragma unroll
     for (int k = 0; k < GPW; k++) fast = fast && (left[k] == 4 || left[k] == 0);
     int bi0 = 0;  // first batch the general loop still has to process
@@ -796,7 +797,27 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
             if (left[k] == 0) continue;
             const int g = (wave - 3) + k * NE;
             uint8_t *img_g = img + 4 * g * TABLE_BYTES;
+#ifdef BRL_TIMING
+            unsigned long long tq0 = 0, tq1 = 0, tq2 = 0;
+            if (A.debug & 1024) {  // latency probe: an empty s_memtime pair vs one around the command read
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              tq0 = __builtin_amdgcn_s_memtime();
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              tq1 = __builtin_amdgcn_s_memtime();
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+#endif
             const uint32_t w0 = cs[4 * g + rr][0];
+#ifdef BRL_TIMING
+            if (A.debug & 1024) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              tq2 = __builtin_amdgcn_s_memtime();
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              t_probe0 += tq1 - tq0;
+              t_probe1 += tq2 - tq1;
+              t_probe_n++;
+            }
+#endif
             if (head && !(w0 & 0x200u) && (w0 & 0x1FFu)) {
               int hb = (int)(w0 & 0x1FFu) - 1;
               atomicOr(reinterpret_cast<uint32_t *>(img_g + gl.r * TABLE_BYTES) + (hb >> 5), 1u << (hb & 31));
@@ -917,6 +938,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
     if (A.debug & 256) {  // timeline: per-barrier arrival / release stamps after the per-wave summary area
       unsigned long long *tl = A.terminated_count + (size_t)gridDim.x * NW * 2 + ((size_t)blockIdx.x * NW + wave) * 32;
       for (int q = 0; q < 16; q++) { tl[2 * q] = (q < t_nb) ? t_arr[q] : 0; tl[2 * q + 1] = (q < t_nb) ? t_rel[q] : 0; }
+      if (A.debug & 1024) { tl[29] = t_probe0; tl[30] = t_probe1; tl[31] = t_probe_n; }
     }
   }
 #endif
@@ -927,7 +949,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   }
 }
 
-#include "rollout_flow.hpp"
+#include "rollout_common.hpp"
 #include "rollout_pipe.hpp"
 
 // ---- policy sub-step: masked categorical over logits + auto_reset(step) -------------------
@@ -1099,7 +1121,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_duplicate_step(const uint64_t
 // ---- A9 GAE reverse scan (src/gae.py:20-39): one lane per env, coalesced over envs --------
 // The recurrence is serial in t but its INPUTS are not: chunks of GAE_CHUNK steps are loaded up
 // front (3 x GAE_CHUNK independent loads in flight per lane) and then scanned from registers.
-constexpr int GAE_CHUNK = 16;
+constexpr int GAE_CHUNK = 32;  // all of a typical rollout's steps (ppo.py:36 num_steps=32) in flight at once
 __global__ __launch_bounds__(64) void k_gae(const uint8_t *done, const float *value, const float *reward,
                                             const float *last_val, float gamma, float gamma_lambda, int T, int64_t n,
                                             float *adv, float *tgt) {
@@ -1204,7 +1226,6 @@ struct brl_handle {
   int tables_per_wave;
   int ws_tpb;  // tables per workgroup of the wave-specialised rollout, 0 = use the K-tables-per-wave kernel
   int ws_nw;   // waves per workgroup (1 logic + ws_nw-1 emit)
-  int flow;    // 1: flag-synchronised k_rollout_flow instead of the batch-barrier k_rollout_ws
   int pipe;    // NP > 0: k_rollout_pipe with NP prep waves (BRL_ROLLOUT_PIPE)
 };
 
@@ -1269,7 +1290,6 @@ extern "C" int brl_create(int device, const int32_t *lut_keys, const int32_t *lu
   }
   h->ws_tpb = 32;
   h->ws_nw = 11;
-  h->flow = getenv("BRL_ROLLOUT_FLOW") ? atoi(getenv("BRL_ROLLOUT_FLOW")) : 0;
   h->pipe = getenv("BRL_ROLLOUT_PIPE") ? atoi(getenv("BRL_ROLLOUT_PIPE")) : 0;
   const char *ws = getenv("BRL_ROLLOUT_WS");  // "TPBxNW" (16x5 16x7 32x5 32x7 32x8 32x11 64x7 64x11) or "0"
   if (ws) {
@@ -1416,19 +1436,6 @@ extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int
   hipLaunchKernelGGL((k_rollout_ws<TPB, NW>), dim3((unsigned)((n + TPB - 1) / TPB)), dim3(NW * 64), 0, \
                      (hipStream_t)stream, A)
   const int cfg = (substeps <= WS_BATCH) ? h->ws_tpb * 100 + h->ws_nw : 0;  // a macro-step spans <= 2 command batches
-#define LAUNCH_FLOW(TPB, NW)                                                                             \
-  hipLaunchKernelGGL((k_rollout_flow<TPB, NW>), dim3((unsigned)((n + TPB - 1) / TPB)), dim3(NW * 64), 0, \
-                     (hipStream_t)stream, A)
-  if (h->flow && (cfg == 1607 || cfg == 3207 || cfg == 3211)) {
-    switch (cfg) {  // the flow kernel has two more waves (apply, prep) for the same number of emit waves
-      case 1607: LAUNCH_FLOW(16, 9); break;
-      case 3207: LAUNCH_FLOW(32, 9); break;
-      default: LAUNCH_FLOW(32, 13); break;
-    }
-    HIP_TRY(hipGetLastError());
-    return BRL_OK;
-  }
-#undef LAUNCH_FLOW
 #define LAUNCH_PIPE(TPB, NW, NP)                                                                             \
   hipLaunchKernelGGL((k_rollout_pipe<TPB, NW, NP>), dim3((unsigned)((n + TPB - 1) / TPB)), dim3(NW * 64), 0, \
                      (hipStream_t)stream, A)

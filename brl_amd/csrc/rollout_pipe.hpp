@@ -1,6 +1,6 @@
 // rollout_pipe.hpp — the fused random-policy rollout as a three-stage batch pipeline.
 // Same roles, LDS images, commands and emit path as k_rollout_ws (brl_kernels.hip), with the per-table
-// dependency chain cut down to its minimum: the logic wave runs fast_step (rollout_flow.hpp) on a packed
+// dependency chain cut down to its minimum: the logic wave runs fast_step (rollout_common.hpp) on a packed
 // word and posts only that state; NP prep waves, one batch behind, re-run the full step slot-parallel and
 // build the 16-byte commands; the loader / scorer / emit waves work two batches behind the logic wave.
 // One s_barrier per batch as in k_rollout_ws — waiting waves cost no issue slots.
@@ -24,6 +24,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_pipe(RolloutArgs A) {
   int t_nb = 0;
 #endif
   __shared__ __attribute__((aligned(16))) uint8_t img[TPB * TABLE_BYTES];
+  __shared__ __attribute__((aligned(16))) uint8_t bimg[TPB * BROW];  // byte images (emit waves)
   __shared__ __attribute__((aligned(16))) uint32_t cmd[4][B][TPB][CMD_WORDS];  // batch b -> cmd[b & 3]
   __shared__ __attribute__((aligned(8))) uint2 spost[2][B + 1][TPB];  // fast mode: (d, static word) of the states of batch b; entry 0 = the state before the batch
   __shared__ __attribute__((aligned(16))) uint32_t ring[TPB][PR_RING][RING_WORDS];
@@ -419,10 +420,16 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_pipe(RolloutArgs A) {
     }
   } else {
     // ------------------------------------------------------------------ emit waves
+    // Each wave owns the images of its groups of 4 tables: the packed ones (img, what goes back to HBM) and BYTE
+    // images (bimg: one byte per observation bit, seats in absolute order — rollout_common.hpp), so that a lane's 32
+    // output bytes are two 16-byte LDS reads and one rotate per dword instead of 8 nibble extractions, 8 multiplies
+    // and 8 masks.  Per sub-step: apply the command (one call = one bit + one byte, or a re-deal), then copy.
     const GroupLane gl = make_group_lane();
     const MaskLane ml = make_mask_lane();
+    const ByteLane bl = make_byte_lane();
+    const DealLane dl = make_deal_lane();
     constexpr int NG = TPB / 4;              // groups of 4 consecutive tables
-    constexpr int GPW = (NG + NE - 1) / NE;  // groups per emit wave, interleaved to overlap LDS latency
+    constexpr int GPW = (NG + NE - 1) / NE;  // groups per emit wave
     const bool head = (gl.r < 4) && (gl.ch == 0);  // one lane per row does the row's bookkeeping
     const int rr = (gl.r < 4) ? gl.r : 3;
     int sub = 0;            // s % substeps
@@ -433,11 +440,40 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_pipe(RolloutArgs A) {
       const int g = (wave - E0) + k * NE;
       int64_t rem = (g < NG && !(A.debug & 1)) ? A.n - (table0 + 4 * g) : 0;
       left[k] = (int)max((int64_t)0, min((int64_t)4, rem));
+      if (g < NG) bimg_build(img + 4 * g * TABLE_BYTES, bimg + 4 * g * BROW, gl, bl);
     }
+    wave_lds_order();
+    // sub-step s-1 applied to group g's images: one call per row, or a freshly dealt board
+    auto apply = [&](int g, uint32_t w0, int rows) {
+      uint8_t *img_g = img + 4 * g * TABLE_BYTES;
+      uint8_t *bimg_g = bimg + 4 * g * BROW;
+      const bool is_head = head && (gl.r < rows);
+      if (is_head && !(w0 & 0x200u) && (w0 & 0x1FFu)) {
+        const int hb = (int)(w0 & 0x1FFu) - 1;
+        atomicOr(reinterpret_cast<uint32_t *>(img_g + gl.r * TABLE_BYTES) + (hb >> 5), 1u << (hb & 31));
+        uint8_t *brow = bimg_g + gl.r * BROW;
+        if (hb < BTAIL) {
+          brow[hb] = 1;
+        } else {  // the last bid's 12 bytes live in the four observer tails
+#pragma unroll
+          for (int q = 0; q < 4; q++) brow[hb + 64 * q] = 1;
+        }
+      }
+      uint64_t dealm = __ballot(is_head && (w0 & 0x200u));
+      while (dealm) {  // ~1 table in 11 per sub-step
+        const int l = __ffsll((unsigned long long)dealm) - 1;  // lane 15*q holds row q's command
+        dealm &= dealm - 1ull;
+        const int q = l / 15;
+        const uint32_t wq = __builtin_amdgcn_readlane(w0, l);
+        const uint32_t *e = &ring[4 * g + q][(wq >> 16) & 15u][0];
+        deal_hands(img_g + q * TABLE_BYTES, e, c);
+        deal_bytes_hands(bimg_g + q * BROW, e, c, dl);
+      }
+      wave_lds_order();
+    };
     // FAST PATH (substeps == 1, every group of this wave complete, obs + mask requested — the BASELINE
-    // configuration): the same work as the general loop below with everything loop-invariant hoisted: per-lane
-    // output pointers advanced by a constant, no per-step emit / tail / pointer selection.  The slot of the
-    // post-rollout state (s == total) is left to the general code.
+    // configuration): per-lane output pointers advanced by a constant, no per-step emit / tail / pointer
+    // selection.  The slot of the post-rollout state (s == total) is left to the general code.
     LDS_BARRIER();  // stage 0
     bool fast = (A.substeps == 1) && A.out.obs && A.out.legal_action_mask && !(A.debug & ~256);
 #pragma unroll
@@ -449,7 +485,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_pipe(RolloutArgs A) {
 #pragma unroll
       for (int k = 0; k < GPW; k++) {
         const int g = (wave - E0) + k * NE;
-        optr[k] = A.out.obs + (table0 + 4 * g) * BRL_OBS_SIZE + gl.out_off;
+        optr[k] = A.out.obs + (table0 + 4 * g) * BRL_OBS_SIZE + bl.out_off;
         mptr[k] = reinterpret_cast<uint32_t *>(A.out.legal_action_mask + (table0 + 4 * g) * BRL_NUM_ACTIONS) + c.lane;
       }
       const int64_t ostep = A.n * BRL_OBS_SIZE, mstep = A.n * BRL_NUM_ACTIONS;
@@ -464,36 +500,16 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_pipe(RolloutArgs A) {
           for (int k = 0; k < GPW; k++) {
             if (left[k] == 0) continue;
             const int g = (wave - E0) + k * NE;
-            uint8_t *img_g = img + 4 * g * TABLE_BYTES;
             const uint32_t w0 = cs[4 * g + rr][0];
-            if (head && !(w0 & 0x200u) && (w0 & 0x1FFu)) {
-              int hb = (int)(w0 & 0x1FFu) - 1;
-              atomicOr(reinterpret_cast<uint32_t *>(img_g + gl.r * TABLE_BYTES) + (hb >> 5), 1u << (hb & 31));
-            }
-            uint64_t dealm = __ballot(head && (w0 & 0x200u));
-            while (dealm) {  // rare: ~1 table in 25 per sub-step
-              const int l = __ffsll((unsigned long long)dealm) - 1;  // lane 15*q holds row q's command
-              dealm &= dealm - 1ull;
-              const int q = l / 15;
-              const uint32_t wq = __builtin_amdgcn_readlane(w0, l);
-              deal_hands(img_g + q * TABLE_BYTES, &ring[4 * g + q][(wq >> 16) & 15u][0], c);
-            }
-            wave_lds_order();
-            uint32_t a;
-            uint64_t H;
-            obs_chunk_load(img_g, (int)((w0 >> 10) & 3u), gl, a, H);
+            apply(g, w0, 4);
+            uint4 q0, q1;
+            byte_chunk_load(bimg + 4 * g * BROW, (w0 >> 10) & 3u, bl, q0, q1);
             const uint64_t la = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
             const uint64_t lb = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
-            uint32_t d[8];
-            {
-              GroupLane gz = gl;
-              gz.out_off = 0;
-              if (olane) obs_chunk_store(a, H, (int)((w0 >> 10) & 3u), (w0 >> 12) & 15u, optr[k], gz);
-            }
+            if (olane) byte_chunk_store(q0, q1, (w0 >> 10) & 3u, (w0 >> 12) & 15u, optr[k], bl);
             if (ml.active) *mptr[k] = mask_dword(la, lb, ml);
             optr[k] += ostep;
             mptr[k] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(mptr[k]) + mstep);
-            (void)d;
           }
         }
       }
@@ -510,63 +526,30 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_pipe(RolloutArgs A) {
         uint8_t *mask_base = fin ? A.last_mask : A.out.legal_action_mask;
         const int64_t rowb = fin ? table0 : row0;
         const uint32_t(*cs)[CMD_WORDS] = cmd[bi & 3][j];
-        // ---- round trip 1: each row's command
-        uint32_t w0[GPW];
-#pragma unroll
-        for (int k = 0; k < GPW; k++) {
-          const int g = (wave - E0) + k * NE;
-          w0[k] = (left[k] > 0) ? cs[4 * g + rr][0] : 0u;
-        }
-        // ---- apply sub-step s-1 to the images (one history bit, or a freshly dealt board), then
-        //      round trip 2: image dwords + legal masks.  No wait in between: same-wave LDS order.
-        uint32_t a[GPW];
-        uint64_t H[GPW], la[GPW], lb[GPW];
 #pragma unroll
         for (int k = 0; k < GPW; k++) {
           const int g = (wave - E0) + k * NE;
           if (left[k] <= 0) continue;
-          uint8_t *img_g = img + 4 * g * TABLE_BYTES;
-          const bool is_head = head && (gl.r < left[k]);
-          if (is_head && !(w0[k] & 0x200u) && (w0[k] & 0x1FFu)) {
-            int hb = (int)(w0[k] & 0x1FFu) - 1;
-            atomicOr(reinterpret_cast<uint32_t *>(img_g + gl.r * TABLE_BYTES) + (hb >> 5), 1u << (hb & 31));
-          }
-          uint64_t dealm = __ballot(is_head && (w0[k] & 0x200u));
-          if (dealm) {  // rare: ~1 table in 25 per sub-step
-            do {
-              const int l = __ffsll((unsigned long long)dealm) - 1;  // lane 15*q holds row q's command
-              dealm &= dealm - 1ull;
-              const int q = l / 15;
-              const uint32_t wq = __builtin_amdgcn_readlane(w0[k], l);
-              deal_hands(img_g + q * TABLE_BYTES, &ring[4 * g + q][(wq >> 16) & 15u][0], c);
-            } while (dealm);
-          }
-          wave_lds_order();
-          if (emit) {
-            obs_chunk_load(img_g, (int)((w0[k] >> 10) & 3u), gl, a[k], H[k]);
-            la[k] = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
-            lb[k] = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
-          }
-        }
-        if (emit) {
-#pragma unroll
-          for (int k = 0; k < GPW; k++) {
-            const int g = (wave - E0) + k * NE;
-            if (left[k] <= 0) continue;
-            // ---- the 4 observation rows: two 16-B stores per lane
-            if (gl.r < left[k] && obs_base)
-              obs_chunk_store(a[k], H[k], (int)((w0[k] >> 10) & 3u), (w0[k] >> 12) & 15u,
-                              obs_base + (rowb + 4 * g) * BRL_OBS_SIZE, gl);
-            // ---- the 4 mask rows
-            if (mask_base) {
-              uint8_t *mdst = mask_base + (rowb + 4 * g) * BRL_NUM_ACTIONS;
-              if (left[k] >= 4) {  // 152 contiguous bytes, one dword per lane
-                if (ml.active) reinterpret_cast<uint32_t *>(mdst)[c.lane] = mask_dword(la[k], lb[k], ml);
-              } else {  // ragged tail of the batch: row by row
-                for (int q = 0; q < left[k]; q++) {
-                  uint64_t lq = *reinterpret_cast<const uint64_t *>(&cs[4 * g + q][2]);
-                  emit_mask_row(lq, mdst + q * BRL_NUM_ACTIONS, c);
-                }
+          const uint32_t w0 = cs[4 * g + rr][0];
+          apply(g, w0, left[k]);
+          if (!emit) continue;
+          uint4 q0, q1;
+          byte_chunk_load(bimg + 4 * g * BROW, (w0 >> 10) & 3u, bl, q0, q1);
+          const uint64_t la = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
+          const uint64_t lb = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
+          // ---- the 4 observation rows: two 16-B stores per lane
+          if (gl.r < left[k] && obs_base)
+            byte_chunk_store(q0, q1, (w0 >> 10) & 3u, (w0 >> 12) & 15u,
+                             obs_base + (rowb + 4 * g) * BRL_OBS_SIZE + bl.out_off, bl);
+          // ---- the 4 mask rows
+          if (mask_base) {
+            uint8_t *mdst = mask_base + (rowb + 4 * g) * BRL_NUM_ACTIONS;
+            if (left[k] >= 4) {  // 152 contiguous bytes, one dword per lane
+              if (ml.active) reinterpret_cast<uint32_t *>(mdst)[c.lane] = mask_dword(la, lb, ml);
+            } else {  // ragged tail of the batch: row by row
+              for (int q = 0; q < left[k]; q++) {
+                uint64_t lq = *reinterpret_cast<const uint64_t *>(&cs[4 * g + q][2]);
+                emit_mask_row(lq, mdst + q * BRL_NUM_ACTIONS, c);
               }
             }
           }
@@ -576,7 +559,8 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_pipe(RolloutArgs A) {
           row0 += (A.debug & 32) ? 0 : A.n;
         }
       }
-    }    LDS_BARRIER();
+    }
+    LDS_BARRIER();
   }
 #ifdef BRL_TIMING
   if (c.lane == 0 && A.terminated_count) {  // timing build only: terminated_count doubles as a dump buffer

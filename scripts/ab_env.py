@@ -1,4 +1,4 @@
-"""Same-box A/B of rollout-kernel settings given as env specs ("BRL_ROLLOUT_FLOW=1,BRL_DEBUG=0" ...):
+"""Same-box A/B of rollout-kernel settings given as env specs ("BRL_ROLLOUT_PIPE=2,BRL_DEBUG=0" ...):
 alternates them in subprocesses (scripts/ablate3.py), reports the sorted medians."""
 import json, os, subprocess, sys
 specs = sys.argv[1:]

@@ -19,11 +19,12 @@ def env(dds):
     return brl_amd.BridgeBidding(lut=(dds["keys"], dds["values"]))
 
 
-def make_env(dds, k, ws=None):
+def make_env(dds, k, ws=None, pipe=None):
     """k: tables per wave of the per-step kernels; ws: "TPBxNW" of the wave-specialised fused
-    rollout, "0" for the K-tables-per-wave fused rollout, None for the library default."""
+    rollout, "0" for the K-tables-per-wave fused rollout, None for the library default; pipe: number of
+    prep waves of the pipelined variant k_rollout_pipe (BRL_ROLLOUT_PIPE), None for off."""
     import brl_amd
-    new = {"BRL_TABLES_PER_WAVE": str(k), "BRL_ROLLOUT_WS": ws}
+    new = {"BRL_TABLES_PER_WAVE": str(k), "BRL_ROLLOUT_WS": ws, "BRL_ROLLOUT_PIPE": pipe}
     old = {key: os.environ.get(key) for key in new}
     for key, v in new.items():
         if v is None:
@@ -172,6 +173,31 @@ def test_fused_random_rollout_matches_oracle(dds, oracle, k, ws, substeps, n, T)
         assert_state_equal(rs[2], ref, where=f"rollout final state K={k} sub={substeps} call {call}")
         assert np.array_equal(to_np(rs[3]), ref["observation"])
         assert rs[5] == draw
+
+
+@pytest.mark.parametrize("pipe,substeps,n,T", [("2", 1, 2048, 32), ("1", 1, 515, 40), ("3", 1, 33, 7), ("2", 4, 300, 8),
+                                                ("2", 1, 1, 3), ("2", 1, 4099, 33)])
+def test_pipelined_rollout_matches_oracle(dds, oracle, pipe, substeps, n, T):
+    """k_rollout_pipe (opt-in, BRL_ROLLOUT_PIPE = prep waves): minimal logic chain + slot-parallel prep waves +
+    byte-image emit; substeps > 1 takes its legacy mode.  Same contract as the default kernel."""
+    import brl_amd
+    env = make_env(dds, 4, None, pipe)
+    cfg = {"num_steps": T, "game_mode": "competitive" if substeps == 4 else "normal", "substeps": substeps,
+           "reward_scale": 7600, "return_last_obs": True}
+    roll = brl_amd.make_random_roll_out(cfg, env)
+    st = env.init(77, num_envs=n)
+    ref = oracle.init_random(n, seed=77)
+    rs = (None, None, st, st.observation, 0, 0)
+    draw = 0
+    for call in range(3):
+        rs, traj = roll(rs)
+        want = oracle.rollout_random(ref, T, seed=77, substeps=substeps, draw_base=draw)
+        draw += T * substeps
+        torch.cuda.synchronize()
+        for name in ("obs", "legal_action_mask", "action", "done", "value", "reward", "log_prob"):
+            assert np.array_equal(to_np(getattr(traj, name)), want[name]), f"pipe={pipe} sub={substeps} call {call}: {name}"
+        assert_state_equal(rs[2], ref, where=f"pipelined rollout final state pipe={pipe} call {call}")
+        assert np.array_equal(to_np(rs[3]), ref["observation"])
 
 
 def test_rollout_terminated_count_accumulates(env, oracle):
