@@ -12,7 +12,8 @@
  *     thread-local brl_last_error().
  *   - unless a parameter says "host", every pointer is a DEVICE pointer on the handle's
  *     GPU, owned by the caller (e.g. torch tensors: tensor.data_ptr()).  The library owns
- *     only the handle, its device copy of the double-dummy LUT and a small constant table.
+ *     only the handle, its device copy of the double-dummy LUT (plus the packed hand words it
+ *     derives from the keys at upload, 32 B per row) and a small constant table.
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and nothing
  *     synchronises the device (pass torch.cuda.current_stream().cuda_stream).
  *   - a handle is not thread-safe; use one per (device, stream).
