@@ -132,7 +132,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_pipe(RolloutArgs A) {
         }
         dealt_total += dealt;
       }
-      const uint32_t want = nb0 + (uint32_t)PR_RING + dealt_total;
+      const uint32_t want = nb0 + (uint32_t)PR_RING - 1u + dealt_total;  // (-1: a board's entry lives until the NEXT deal: the scorer reads its DDS values when it ends)
       if (valid && nb < want && t + 1 < nbatch + 2) {
         pbase = nb;
         pcount = min(3u, want - nb);
@@ -305,13 +305,14 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_pipe(RolloutArgs A) {
     //   1. per sub-step, cheap: first denominations, new tricks on a re-deal, queue finished boards
     //   2. per queued board: contract -> DDS tricks -> score -> reward vector (A4), summed per macro-step
     //   3. per macro-step: the scalar Transition columns, coalesced over tables
-    __shared__ __attribute__((aligned(16))) uint32_t ev[3][64][8];   // finished boards of this batch
+    __shared__ __attribute__((aligned(16))) uint32_t ev[3 * 64][8];  // finished boards of this batch, compacted (<= 3 per table)
     __shared__ __attribute__((aligned(16))) int acc[WS_BATCH][64][4];  // reward sums by player id per macro-step
     __shared__ uint32_t minfo[WS_BATCH][64];                          // per macro-step: actor, action, n_legal, done
     Tbl ts;
     load_scalars(ts, img + tls * TABLE_BYTES);  // fd / tricks / rewards are live here
     int sub = 0;
     uint32_t cur_info = 0, tcount = 0;
+    uint32_t vslot = 15u;  // ring slot of the table's current board; 15: the board it came in with
     int64_t row = table0 + tl;  // this table's Transition row of the next macro-step to be written
     int4 last_acc = make_int4(reward_of(ts, 0), reward_of(ts, 1), reward_of(ts, 2), reward_of(ts, 3));
     *reinterpret_cast<int4 *>(&acc[0][tl][0]) = make_int4(0, 0, 0, 0);
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_pipe(RolloutArgs A) {
     for (int bi = 0; bi < nbatch; bi++) {
       LDS_BARRIER();
       // ---- pass 1
-      int nev = 0, m = 0;  // m: macro-steps completed so far in this batch
+      int nev = 0, m = 0;  // nev: boards queued (uniform); m: macro-steps completed so far in this batch
       // acc[0] carries the partial sums of a macro-step that straddles the batch boundary
 #pragma unroll
       for (int q = 1; q < B; q++) *reinterpret_cast<int4 *>(&acc[q][tl][0]) = make_int4(0, 0, 0, 0);
@@ -337,17 +338,21 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_pipe(RolloutArgs A) {
         if (sub == 0)  // first sub-step of a macro-step: the acting player (src/roll_out.py:72), its action
           cur_info = (uint32_t)player_at(ts, seat) | ((uint32_t)a << 2) | (((w.x >> 23) & 63u) << 8);
         note_first_denomination(ts.fd, seat, a);
-        if (bits(ts.sc, SC_TERM, 1)) {  // queue the finished board for pass 2
-          uint4 *e = reinterpret_cast<uint4 *>(&ev[nev][tl][0]);
-          e[0] = make_uint4(ts.sc, ts.fd, ts.t0, ts.t1);
-          e[1] = make_uint4(ts.t2, (uint32_t)m, 0u, 0u);
-          nev++;
-          cur_info |= 1u << 14;  // done (G2)
+        const bool fin = (tl < TPB) && bits(ts.sc, SC_TERM, 1);
+        const uint64_t fm = __ballot(fin);
+        if (fm) {  // queue the finished boards for pass 2, compacted over the tables: one lane per board there
+          if (fin) {
+            const int pos = nev + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+            *reinterpret_cast<uint4 *>(&ev[pos][0]) = make_uint4(ts.sc, ts.fd, (uint32_t)m | ((uint32_t)tl << 8), vslot);
+            cur_info |= 1u << 14;  // done (G2)
+          }
+          nev += __popcll(fm);
         }
-        if (w.x & 0x200u) {  // the slot was re-dealt: tricks of the new board, no strain named yet
-          const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tls][(w.x >> 16) & 15u][8]);
-          pack_tricks(ts, vv.x, vv.y, vv.z, vv.w);
-          ts.fd = 0;
+        {  // the slot was re-dealt: no strain named yet; the new board's DDS values stay in its ring entry until
+           // the board is scored (the loader frees an entry one board late for that)
+          const bool dealt = (w.x & 0x200u) != 0u;
+          vslot = dealt ? ((w.x >> 16) & 15u) : vslot;
+          ts.fd = dealt ? 0u : ts.fd;
         }
         if (++sub == A.substeps) {
           sub = 0;
@@ -356,16 +361,26 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_pipe(RolloutArgs A) {
         }
       }
       // ---- pass 2
-      for (int e = 0; e < 3; e++) {
-        if (!__any(e < nev)) break;
+      wave_lds_order();
+      for (int e0 = 0; e0 < nev; e0 += 64) {  // (a table finishes at most one board per macro-step: no two lanes share a cell)
+        const int e = e0 + c.lane;
         if (e < nev) {
-          const uint4 *p = reinterpret_cast<const uint4 *>(&ev[e][tl][0]);
-          const uint4 e0 = p[0], e1 = p[1];
+          const uint4 q = *reinterpret_cast<const uint4 *>(&ev[e][0]);
+          const uint32_t tt = (q.z >> 8) & 63u;
           Tbl tb;
-          tb.sc = e0.x; tb.fd = e0.y; tb.t0 = e0.z; tb.t1 = e0.w; tb.t2 = e1.x;
+          tb.sc = q.x; tb.fd = q.y;
+          if (q.w < 15u) {  // a board dealt in this launch: DDS values from its ring entry
+            const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tt][q.w][8]);
+            pack_tricks(tb, vv.x, vv.y, vv.z, vv.w);
+          } else {          // the board the table came in with: its tricks are in the packed image
+            const uint2 *ip = reinterpret_cast<const uint2 *>(img + tt * TABLE_BYTES);
+            const uint2 tr = ip[W_TR], fdw = ip[W_FD];
+            tb.t0 = tr.x; tb.t1 = tr.y; tb.t2 = fdw.y;
+          }
           terminal_reward(tb);  // A4
-          int *ac = &acc[e1.y & (WS_BATCH - 1)][tl][0];
-          ac[0] += reward_of(tb, 0); ac[1] += reward_of(tb, 1); ac[2] += reward_of(tb, 2); ac[3] += reward_of(tb, 3);
+          int *ac = &acc[q.z & (WS_BATCH - 1)][tt][0];
+          atomicAdd(&ac[0], reward_of(tb, 0)); atomicAdd(&ac[1], reward_of(tb, 1));  // (substeps >= 8: two boards of a
+          atomicAdd(&ac[2], reward_of(tb, 2)); atomicAdd(&ac[3], reward_of(tb, 3));  //  table can end in one macro-step)
         }
       }
       // ---- pass 3: the m macro-steps completed in this batch; with TPB <= 32 the upper half of the wave
@@ -413,6 +428,10 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_pipe(RolloutArgs A) {
 #endif
     }
     if (tl < TPB) {
+      if (vslot < 15u) {
+        const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tl][vslot][8]);
+        pack_tricks(ts, vv.x, vv.y, vv.z, vv.w);
+      }
       uint2 *p = reinterpret_cast<uint2 *>(img + tl * TABLE_BYTES);
       p[W_FD] = make_uint2(ts.fd, ts.t2);
       p[W_TR] = make_uint2(ts.t0, ts.t1);

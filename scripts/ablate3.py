@@ -8,7 +8,7 @@ import brl_amd
 from brl_amd.roll_out import alloc_transition
 from brl_amd.bridge_bidding import _stream
 from bench import synthetic_lut
-N, T = 8192, 32
+N, T = int(os.environ.get('N', 8192)), 32
 keys, values = synthetic_lut(100000, 0)
 res = {}
 for cfg in os.environ.get("CFGS", "32x11").split(","):

@@ -41,6 +41,8 @@ for cfg in os.environ.get("CFGS", "32x16").split(","):
         for w in range(nw):
             print(f'  wave {w:2d}: ' + ' '.join(f'{int(a)//100:4d}>{int(r)//100:4d}' for a, r in tl[wg, w] if r))
         print('  total', d[wg, :, 0] // 100)
+        sc = full[nblk * nw * 2:].reshape(nblk, nw, 32)[:, 2, 29:31].mean(0)
+        print('scorer wave: pass 1 %.0f cycles, pass 2 %.0f cycles per launch (rest of its work: pass 3 + bookkeeping)' % (sc[0], sc[1]))
         if int(os.environ.get('DBG', '0')) & 1024:
             pr = full[nblk * nw * 2:].reshape(nblk, nw, 32)[:, 3:, 29:32].sum((0, 1))
             print('latency probe (emit waves): empty s_memtime pair %.0f cycles, pair around one ds_read_b32 %.0f cycles, n=%d' % (pr[0] / pr[2], pr[1] / pr[2], pr[2]))
