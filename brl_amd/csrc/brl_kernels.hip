@@ -830,27 +830,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
             if (left[k] == 0) continue;
             const int g = (wave - 3) + k * NE;
             uint8_t *img_g = img + 4 * g * TABLE_BYTES;
-#ifdef BRL_TIMING
-            unsigned long long tq0 = 0, tq1 = 0, tq2 = 0;
-            if (A.debug & 1024) {  // latency probe: an empty s_memtime pair vs one around the command read
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-              tq0 = __builtin_amdgcn_s_memtime();
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-              tq1 = __builtin_amdgcn_s_memtime();
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-#endif
             const uint32_t w0 = cs[4 * g + rr][0];
-#ifdef BRL_TIMING
-            if (A.debug & 1024) {
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-              tq2 = __builtin_amdgcn_s_memtime();
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-              t_probe0 += tq1 - tq0;
-              t_probe1 += tq2 - tq1;
-              t_probe_n++;
-            }
-#endif
             if (head && !(w0 & 0x200u) && (w0 & 0x1FFu)) {
               int hb = (int)(w0 & 0x1FFu) - 1;
               atomicOr(reinterpret_cast<uint32_t *>(img_g + gl.r * TABLE_BYTES) + (hb >> 5), 1u << (hb & 31));
