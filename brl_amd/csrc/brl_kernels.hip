@@ -1444,7 +1444,11 @@ extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int
   A.reward_scale = reward_scale; A.g = rng_of(h); A.env_offset = h->env_offset; A.lut = lut_of(h);
   A.neg_log_n = h->neg_log_n; A.out = *out; A.terminated_count = (unsigned long long *)terminated_count;
   A.last_obs = last_obs; A.last_mask = last_mask;
+#ifdef BRL_TIMING  // experiment switches (some of them change the outputs): timing builds only (scripts/timing.py)
   A.debug = getenv("BRL_DEBUG") ? atoi(getenv("BRL_DEBUG")) : 0;
+#else
+  A.debug = 0;
+#endif
 #define LAUNCH_WS(TPB, NW)                                                                             \
   hipLaunchKernelGGL((k_rollout_ws<TPB, NW>), dim3((unsigned)((n + TPB - 1) / TPB)), dim3(NW * 64), 0, \
                      (hipStream_t)stream, A)
