@@ -88,9 +88,38 @@ def make_roll_out(config, env: BridgeBidding, actor_forward_pass, opp_forward_pa
     # in the PPO ratio by bf16 rounding (SURVEY §7 "Hard parts") — opt-in, never the default.
     infer_dtype = {None: None, "fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}[config.get("inference_dtype")]
 
+    snapshots = {}  # id(params) -> low-precision copy of the weights, rebuilt on every roll_out call
+
+    def _snapshot(pr):
+        """bf16/fp16 copy of a "DeepMind" ReLU MLP for inference: weights cast ONCE per rollout (autocast re-casts
+        every fp32 weight on every forward: 12 extra kernels x 128 forwards), the two heads as one 39-row GEMM, and
+        bias + ReLU in the GEMM epilogue (torch._addmm_activation -> hipBLASLt) when available."""
+        if getattr(pr, "model", None) != "DeepMind" or pr.act is not torch.relu:
+            return None
+        body = [(lin.weight.detach().to(infer_dtype).t().contiguous(), lin.bias.detach().to(infer_dtype)) for lin in pr.body]
+        head_w = torch.cat([pr.actor.weight, pr.critic.weight], 0).detach().to(infer_dtype).t().contiguous()
+        head_b = torch.cat([pr.actor.bias, pr.critic.bias], 0).detach().to(infer_dtype)
+        return body, head_w, head_b
+
+    def _fused_forward(snap, obs_bool):
+        body, head_w, head_b = snap
+        x = obs_bool.to(infer_dtype)
+        for w, b in body:
+            if hasattr(torch, "_addmm_activation"):
+                x = torch._addmm_activation(b, x, w, use_gelu=False)  # relu(x @ w + b) in one kernel
+            else:
+                x = torch.addmm(b, x, w).relu_()
+        out = torch.addmm(head_b, x, head_w).float()
+        return out[:, :NUM_ACTIONS], out[:, NUM_ACTIONS]
+
     def forward(fp, pr, obs_bool):
         if infer_dtype is None:
             return fp.apply(pr, obs_bool.to(torch.float32))
+        snap = snapshots.get(id(pr), False)
+        if snap is False:
+            snap = snapshots[id(pr)] = _snapshot(pr)
+        if snap is not None:
+            return _fused_forward(snap, obs_bool)
         with torch.autocast("cuda", dtype=infer_dtype):
             lg, v = fp.apply(pr, obs_bool.to(infer_dtype))
         return lg.float(), v.float()
@@ -98,6 +127,7 @@ def make_roll_out(config, env: BridgeBidding, actor_forward_pass, opp_forward_pa
     def roll_out(runner_state, opp_params):
         params, opt_state, env_state, last_obs, terminated_count, rng = runner_state
         n, dev = env_state.num_envs, env.device
+        snapshots.clear()  # the weights may have been updated since the last rollout
         traj = alloc_transition(T, n, dev)
         tc = _count_tensor(terminated_count, dev)
         packed = env_state.packed.clone()  # the caller's env_state stays valid, like a JAX pytree

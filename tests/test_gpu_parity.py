@@ -369,6 +369,40 @@ def test_policy_rollout_with_mlp_is_self_consistent(env):
     assert adv.shape == (T, n) and torch.isfinite(adv).all() and torch.allclose(tgt, adv + traj.value)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_policy_rollout_low_precision_inference(env, dt):
+    """Opt-in bf16 / fp16 inference (weights cast once per rollout, bias + ReLU in the GEMM epilogue, both heads in
+    one GEMM): sampled actions legal, stored log_prob / value equal to the fp32 recomputation within the rounding
+    of the inference dtype (tolerances below), update-to-update weight changes picked up."""
+    import brl_amd
+    from brl_amd.models import make_forward_pass
+    n, T = 1024, 6
+    cfg = {"num_steps": T, "reward_scale": 7600, "game_mode": "competitive", "actor_illegal_action_mask": True,
+           "inference_dtype": dt}
+    fp = make_forward_pass("relu", "DeepMind")
+    actor, opp = fp.init(0, device="cuda"), fp.init(1, device="cuda")
+    roll = brl_amd.make_roll_out(cfg, env, fp, fp)
+    st = env.init(7, num_envs=n)
+    rs2, traj = roll((actor, None, st, st.observation, 0, 0), opp)
+    torch.cuda.synchronize()
+    mask, act = to_np(traj.legal_action_mask), to_np(traj.action)
+    assert np.take_along_axis(mask, act[..., None].astype(np.int64), 2).all()
+    with torch.no_grad():
+        logits, value = actor(traj.obs.reshape(T * n, 480).float())
+    lsm = _masked_log_softmax(to_np(logits), mask.reshape(T * n, 38))
+    tol = 0.08 if dt == "bf16" else 0.02  # 8 / 11 mantissa bits through 5 layers of 1024-wide dot products
+    assert np.abs(to_np(traj.log_prob).reshape(-1) - lsm[np.arange(T * n), act.reshape(-1)]).max() < tol
+    assert np.abs(to_np(traj.value).reshape(-1) - to_np(value)).max() < tol
+    # new weights -> new snapshot on the next call
+    with torch.no_grad():
+        for p in actor.parameters():
+            p.mul_(0.5)
+    _, traj2 = roll((actor, None, st, st.observation, 0, 0), opp)
+    with torch.no_grad():
+        _, value2 = actor(traj2.obs.reshape(T * n, 480).float())
+    assert np.abs(to_np(traj2.value).reshape(-1) - to_np(value2)).max() < tol
+
+
 def test_full_size_properties(dds):
     """BASELINE.json size (N=8192, T=32): size-independent properties of the fused rollout."""
     import brl_amd
