@@ -12,7 +12,7 @@ import torch
 
 from .bridge_bidding import BridgeBidding
 from .duplicate import Table_info, duplicate_step
-from .models import make_forward_pass
+from .models import InferenceSnapshot, make_forward_pass
 from .utils import single_play_step_two_policy_commpetitive_deterministic
 
 _NEG = torch.finfo(torch.float32).min
@@ -40,11 +40,12 @@ def make_simple_duplicate_evaluate(eval_env: BridgeBidding, team1_activation, te
             table_b_info = Table_info.from_state(state)              # :104-111
             cum_return = torch.zeros(num_eval_envs, dtype=torch.float32, device=eval_env.device)
             count = 0
+            snap1, snap2 = InferenceSnapshot.make(team1_params), InferenceSnapshot.make(team2_params)
             while True:
                 obs = state.observation.to(torch.float32)
                 # G10: the reference evaluates both networks for every env and selects; so do we
-                l1, _ = team1_forward_pass.apply(team1_params, obs)
-                l2, _ = team2_forward_pass.apply(team2_params, obs)
+                l1, _ = snap1(obs) if snap1 is not None else team1_forward_pass.apply(team1_params, obs)
+                l2, _ = snap2(obs) if snap2 is not None else team2_forward_pass.apply(team2_params, obs)
                 team1 = (state.current_player < 2)[:, None]          # players {0,1} are team 1 (:148)
                 action = masked_mode(torch.where(team1, l1, l2), state.legal_action_mask)
                 if record_actions is not None:

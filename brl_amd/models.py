@@ -61,6 +61,36 @@ class ActorCritic(nn.Module):
         return self.actor(x), self.critic(x).squeeze(-1)
 
 
+class InferenceSnapshot:
+    """Inference-only copy of a "DeepMind" ReLU ActorCritic (no autograd): weights transposed (and cast to `dtype`
+    when given) ONCE, bias + ReLU in the GEMM epilogue (``torch._addmm_activation`` -> hipBLASLt), the actor and
+    critic heads as one 39-row GEMM.  Build one per rollout / evaluation call — it does not follow later weight
+    updates.  ``make`` returns None for architectures it does not cover (callers fall back to ``module(x)``)."""
+
+    def __init__(self, module: "ActorCritic", dtype=None):
+        self.dtype = dtype or torch.float32
+        dt = self.dtype
+        self.body = [(lin.weight.detach().to(dt).t().contiguous(), lin.bias.detach().to(dt)) for lin in module.body]
+        self.head_w = torch.cat([module.actor.weight, module.critic.weight], 0).detach().to(dt).t().contiguous()
+        self.head_b = torch.cat([module.actor.bias, module.critic.bias], 0).detach().to(dt)
+        self.n_actions = module.actor.weight.shape[0]
+
+    @staticmethod
+    def make(module, dtype=None):
+        if getattr(module, "model", None) != "DeepMind" or module.act is not torch.relu:
+            return None
+        return InferenceSnapshot(module, dtype)
+
+    def __call__(self, obs):
+        """obs: [n, 480] bool / float -> (logits f32 [n, 38], value f32 [n])"""
+        x = obs.to(self.dtype)
+        fused = hasattr(torch, "_addmm_activation")
+        for w, b in self.body:
+            x = torch._addmm_activation(b, x, w, use_gelu=False) if fused else torch.addmm(b, x, w).relu_()
+        out = torch.addmm(self.head_b, x, self.head_w).float()
+        return out[:, :self.n_actions], out[:, self.n_actions]
+
+
 class ForwardPass:
     """``hk.without_apply_rng(hk.transform(forward_fn))`` look-alike (src/models.py:73-83)."""
 

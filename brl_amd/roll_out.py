@@ -17,6 +17,7 @@ import torch
 from . import _capi
 from ._capi import NUM_ACTIONS, OBS_SIZE, check, ptr
 from .bridge_bidding import BridgeBidding, State, _stream
+from .models import InferenceSnapshot
 from .utils import MODE, SAMPLE, _pass_logits, policy_step
 
 
@@ -88,38 +89,16 @@ def make_roll_out(config, env: BridgeBidding, actor_forward_pass, opp_forward_pa
     # in the PPO ratio by bf16 rounding (SURVEY §7 "Hard parts") — opt-in, never the default.
     infer_dtype = {None: None, "fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}[config.get("inference_dtype")]
 
-    snapshots = {}  # id(params) -> low-precision copy of the weights, rebuilt on every roll_out call
-
-    def _snapshot(pr):
-        """bf16/fp16 copy of a "DeepMind" ReLU MLP for inference: weights cast ONCE per rollout (autocast re-casts
-        every fp32 weight on every forward: 12 extra kernels x 128 forwards), the two heads as one 39-row GEMM, and
-        bias + ReLU in the GEMM epilogue (torch._addmm_activation -> hipBLASLt) when available."""
-        if getattr(pr, "model", None) != "DeepMind" or pr.act is not torch.relu:
-            return None
-        body = [(lin.weight.detach().to(infer_dtype).t().contiguous(), lin.bias.detach().to(infer_dtype)) for lin in pr.body]
-        head_w = torch.cat([pr.actor.weight, pr.critic.weight], 0).detach().to(infer_dtype).t().contiguous()
-        head_b = torch.cat([pr.actor.bias, pr.critic.bias], 0).detach().to(infer_dtype)
-        return body, head_w, head_b
-
-    def _fused_forward(snap, obs_bool):
-        body, head_w, head_b = snap
-        x = obs_bool.to(infer_dtype)
-        for w, b in body:
-            if hasattr(torch, "_addmm_activation"):
-                x = torch._addmm_activation(b, x, w, use_gelu=False)  # relu(x @ w + b) in one kernel
-            else:
-                x = torch.addmm(b, x, w).relu_()
-        out = torch.addmm(head_b, x, head_w).float()
-        return out[:, :NUM_ACTIONS], out[:, NUM_ACTIONS]
+    snapshots = {}  # id(params) -> InferenceSnapshot (or None), rebuilt on every roll_out call
 
     def forward(fp, pr, obs_bool):
-        if infer_dtype is None:
-            return fp.apply(pr, obs_bool.to(torch.float32))
         snap = snapshots.get(id(pr), False)
         if snap is False:
-            snap = snapshots[id(pr)] = _snapshot(pr)
-        if snap is not None:
-            return _fused_forward(snap, obs_bool)
+            snap = snapshots[id(pr)] = InferenceSnapshot.make(pr, infer_dtype)
+        if snap is not None:  # "DeepMind" ReLU MLP: fused epilogues, merged heads (fp32 by default)
+            return snap(obs_bool)
+        if infer_dtype is None:
+            return fp.apply(pr, obs_bool.to(torch.float32))
         with torch.autocast("cuda", dtype=infer_dtype):
             lg, v = fp.apply(pr, obs_bool.to(infer_dtype))
         return lg.float(), v.float()
