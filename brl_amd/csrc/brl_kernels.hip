@@ -380,6 +380,7 @@ constexpr int CMD_WORDS = 4;
 constexpr int RING_WORDS = 16;  // hands[8] (the four packed hand words, k_lut_hands) values[4] idx sc_bits pad pad
 constexpr int WS_BATCH = 8;     // sub-steps per workgroup barrier
 constexpr int WS_RING = 12;     // boards kept ahead per table (see the loader wave)
+constexpr uint32_t NO_SLOT = 0xFFu;  // scorer: the table still plays the board it came in with (ring slots are 0..15)
 // cmd[s] word 0: about sub-step s-1: [8:0] history bit + 1 (0 none) | [9] deal | [19:16] ring slot dealt
 //                | [22:21] acting seat | [28:23] n_legal
 //                about state s: [11:10] observer seat | [15:12] vul nibble
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
     load_scalars(ts, img + tls * TABLE_BYTES);  // fd / tricks / rewards are live here
     int sub = 0;
     uint32_t cur_info = 0, tcount = 0;
-    uint32_t vslot = 15u;  // ring slot of the table's current board; 15: the board it came in with
+    uint32_t vslot = NO_SLOT;  // ring slot of the table's current board; NO_SLOT: the board it came in with
     int64_t row = table0 + tl;  // this table's Transition row of the next macro-step to be written
     int4 last_acc = make_int4(reward_of(ts, 0), reward_of(ts, 1), reward_of(ts, 2), reward_of(ts, 3));
     *reinterpret_cast<int4 *>(&acc[0][tl][0]) = make_int4(0, 0, 0, 0);
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
           const uint32_t tt = (q.z >> 8) & 63u;
           Tbl tb;
           tb.sc = q.x; tb.fd = q.y;
-          if (q.w < 15u) {  // a board dealt in this launch: DDS values from its ring entry
+          if (q.w != NO_SLOT) {  // a board dealt in this launch: DDS values from its ring entry
             const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tt][q.w][8]);
             pack_tricks(tb, vv.x, vv.y, vv.z, vv.w);
           } else {          // the board the table came in with: its tricks are in the packed image
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
 #endif
     }
     if (tl < TPB) {
-      if (vslot < 15u) {
+      if (vslot != NO_SLOT) {
         const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tl][vslot][8]);
         pack_tricks(ts, vv.x, vv.y, vv.z, vv.w);
       }

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_pipe(RolloutArgs A) {
     load_scalars(ts, img + tls * TABLE_BYTES);  // fd / tricks / rewards are live here
     int sub = 0;
     uint32_t cur_info = 0, tcount = 0;
-    uint32_t vslot = 15u;  // ring slot of the table's current board; 15: the board it came in with
+    uint32_t vslot = NO_SLOT;  // ring slot of the table's current board; NO_SLOT: the board it came in with
     int64_t row = table0 + tl;  // this table's Transition row of the next macro-step to be written
     int4 last_acc = make_int4(reward_of(ts, 0), reward_of(ts, 1), reward_of(ts, 2), reward_of(ts, 3));
     *reinterpret_cast<int4 *>(&acc[0][tl][0]) = make_int4(0, 0, 0, 0);
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_pipe(RolloutArgs A) {
           const uint32_t tt = (q.z >> 8) & 63u;
           Tbl tb;
           tb.sc = q.x; tb.fd = q.y;
-          if (q.w < 15u) {  // a board dealt in this launch: DDS values from its ring entry
+          if (q.w != NO_SLOT) {  // a board dealt in this launch: DDS values from its ring entry
             const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tt][q.w][8]);
             pack_tricks(tb, vv.x, vv.y, vv.z, vv.w);
           } else {          // the board the table came in with: its tricks are in the packed image
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_pipe(RolloutArgs A) {
 #endif
     }
     if (tl < TPB) {
-      if (vslot < 15u) {
+      if (vslot != NO_SLOT) {
         const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tl][vslot][8]);
         pack_tricks(ts, vv.x, vv.y, vv.z, vv.w);
       }

@@ -1,0 +1,40 @@
+"""Soak test of the fused rollout kernels: many back-to-back launches over changing seeds / sizes / step counts,
+with periodic bit-exact checks against the CPU oracle.  Run under `timeout` (a hang is the failure mode looked for)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import brl_amd
+from oracle import Oracle
+from bench import synthetic_lut
+budget = float(os.environ.get("SOAK_SECONDS", "60"))
+keys, values = synthetic_lut(20000, 3)
+orc = Oracle(keys, values)
+env = brl_amd.BridgeBidding(lut=(keys, values))
+rng = np.random.default_rng(0)
+t_end = time.time() + budget
+launches = checks = 0
+while time.time() < t_end:
+    n = int(rng.choice([1, 31, 32, 33, 500, 2048, 8192]))
+    T = int(rng.choice([1, 7, 32, 33, 64]))
+    sub = int(rng.choice([1, 1, 1, 4]))
+    seed = int(rng.integers(1 << 30))
+    env.set_rng(seed) if hasattr(env, "set_rng") else None
+    roll = brl_amd.make_random_roll_out({"num_steps": T, "substeps": sub, "game_mode": "competitive" if sub == 4 else "normal"}, env)
+    st = env.init(seed, num_envs=n)
+    rs = (None, None, st, None, 0, 0)
+    check = n <= 2048 and checks < 400
+    ref = orc.init_random(n, seed=seed) if check else None
+    draw = 0
+    for rep in range(int(rng.integers(1, 40))):
+        rs, traj = roll(rs)
+        launches += 1
+        if check and rep < 3:
+            want = orc.rollout_random(ref, T, seed=seed, substeps=sub, draw_base=draw)
+            torch.cuda.synchronize()
+            for name in ("obs", "legal_action_mask", "action", "done", "reward"):
+                g = getattr(traj, name).cpu().numpy()
+                assert np.array_equal(g.astype(want[name].dtype), want[name]), (name, n, T, sub, seed, rep)
+            checks += 1
+        draw += T * sub
+    torch.cuda.synchronize()
+print(f"soak ok: {launches} launches, {checks} oracle checks, pipe={os.environ.get('BRL_ROLLOUT_PIPE', 'off')}")

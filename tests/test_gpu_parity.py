@@ -176,7 +176,7 @@ def test_fused_random_rollout_matches_oracle(dds, oracle, k, ws, substeps, n, T)
 
 
 @pytest.mark.parametrize("pipe,substeps,n,T", [("2", 1, 2048, 32), ("1", 1, 515, 40), ("3", 1, 33, 7), ("2", 4, 300, 8),
-                                                ("2", 1, 1, 3), ("2", 1, 4099, 33)])
+                                                ("2", 1, 1, 3), ("2", 1, 4099, 33), ("2", 1, 500, 64)])
 def test_pipelined_rollout_matches_oracle(dds, oracle, pipe, substeps, n, T):
     """k_rollout_pipe (opt-in, BRL_ROLLOUT_PIPE = prep waves): minimal logic chain + slot-parallel prep waves +
     byte-image emit; substeps > 1 takes its legacy mode.  Same contract as the default kernel."""
