@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
         "brl_get_fields": [_vp, _vp, i64, C.POINTER(Fields), _vp],
         "brl_rollout_random": [_vp, _vp, i64, i32, i32, u32, f32, C.POINTER(TransitionPtrs), _vp, _vp, _vp, _vp],
         "brl_policy_step": [_vp, _vp, _vp, i64, _vp, i32, u32, i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+        "brl_policy_step_at": [_vp, _vp, _vp, i64, _vp, i32, _vp, u32, i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+        "brl_obs_cast": [_vp, _vp, i64, _vp, i32, _vp],
         "brl_gae": [_vp, _vp, _vp, _vp, _vp, f32, f32, i32, i64, _vp, _vp, _vp],
         "brl_imp_reward": [_vp, _vp, _vp, _vp, i64, _vp],
         "brl_duplicate_step": [_vp, _vp, _vp, i64, _vp, C.POINTER(TableInfoPtrs), C.POINTER(TableInfoPtrs),
@@ -80,7 +82,7 @@ def lib() -> C.CDLL:
 
 EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_destroy", "brl_set_rng",
            "brl_init_random", "brl_init_from_deals", "brl_step", "brl_observe", "brl_get_fields",
-           "brl_rollout_random", "brl_policy_step", "brl_gae", "brl_imp_reward", "brl_duplicate_step"]
+           "brl_rollout_random", "brl_policy_step", "brl_policy_step_at", "brl_obs_cast", "brl_gae", "brl_imp_reward", "brl_duplicate_step"]
 
 
 def check(rc: int) -> None:

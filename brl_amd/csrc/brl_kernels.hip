@@ -974,6 +974,7 @@ struct PolicyArgs {
   const float *logits;
   int mode;
   uint32_t draw;
+  const uint32_t *draw_dev;  // optional: the draw index is draw + *draw_dev (hipGraph-captured loops)
   int autoreset;
   Rng g;
   uint64_t env_offset;
@@ -1017,8 +1018,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
   if (A.mode == 0) {
     uint32_t r[4];
     uint64_t env_id = A.env_offset + (uint64_t)w.table;
-    philox4x32_10((uint32_t)env_id, A.draw >> 2, STREAM_ACTION, (uint32_t)(env_id >> 32), A.g.k0, A.g.k1, r);
-    uint32_t sel = A.draw & 3u;
+    const uint32_t draw = A.draw + (A.draw_dev ? *A.draw_dev : 0u);
+    philox4x32_10((uint32_t)env_id, draw >> 2, STREAM_ACTION, (uint32_t)(env_id >> 32), A.g.k0, A.g.k1, r);
+    uint32_t sel = draw & 3u;
     uint32_t u32 = (sel == 0) ? r[0] : ((sel == 1) ? r[1] : ((sel == 2) ? r[2] : r[3]));
     float target = (float)(u32 >> 8) * (1.0f / 16777216.0f) * sum;  // inverse CDF, u in [0,1)
     float cum = 0.0f;
@@ -1483,20 +1485,79 @@ extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int
   return BRL_OK;
 }
 
-extern "C" int brl_policy_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
-                               const float *logits, int mode, uint32_t draw, int autoreset, int32_t *action,
-                               float *log_prob, uint8_t *obs, uint8_t *mask, float *rewards_acc,
-                               uint8_t *terminated_acc, int32_t *current_player, void *stream) {
+static int policy_step_impl(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                            const float *logits, int mode, const uint32_t *draw_dev, uint32_t draw, int autoreset,
+                            int32_t *action, float *log_prob, uint8_t *obs, uint8_t *mask, float *rewards_acc,
+                            uint8_t *terminated_acc, int32_t *current_player, void *stream) {
   COMMON(h, n);
   NEED(state_in && state_out && logits, "NULL state / logits");
   NEED(mode == 0 || mode == 1, "mode");
   if (autoreset && h->lut_len == 0) return fail(BRL_E_NOLUT, "auto-reset needs a LUT%s", "");
   PolicyArgs A;
   A.state_in = state_in; A.state_out = state_out; A.n = n; A.logits = logits; A.mode = mode; A.draw = draw;
+  A.draw_dev = draw_dev;
   A.autoreset = autoreset; A.g = rng_of(h); A.env_offset = h->env_offset; A.lut = lut_of(h);
   A.action = action; A.log_prob = log_prob;
   A.o = StepOut{obs, mask, rewards_acc, terminated_acc, current_player};
   LAUNCH_K(h, k_policy_step, n, stream, A);
+  return BRL_OK;
+}
+
+extern "C" int brl_policy_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                               const float *logits, int mode, uint32_t draw, int autoreset, int32_t *action,
+                               float *log_prob, uint8_t *obs, uint8_t *mask, float *rewards_acc,
+                               uint8_t *terminated_acc, int32_t *current_player, void *stream) {
+  return policy_step_impl(h, state_in, state_out, n, logits, mode, nullptr, draw, autoreset, action, log_prob, obs, mask,
+                          rewards_acc, terminated_acc, current_player, stream);
+}
+
+extern "C" int brl_policy_step_at(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                                  const float *logits, int mode, const uint32_t *draw_base, uint32_t draw_offset,
+                                  int autoreset, int32_t *action, float *log_prob, uint8_t *obs, uint8_t *mask,
+                                  float *rewards_acc, uint8_t *terminated_acc, int32_t *current_player, void *stream) {
+  if (!draw_base) return fail(BRL_E_ARG, "brl_policy_step_at: draw_base is NULL%s", "");
+  return policy_step_impl(h, state_in, state_out, n, logits, mode, draw_base, draw_offset, autoreset, action, log_prob, obs,
+                          mask, rewards_acc, terminated_acc, current_player, stream);
+}
+
+// observation bytes (0/1) -> the network's input dtype: 16 bytes in, 16 elements out per thread
+// (src/roll_out.py:75 `last_obs.astype(jnp.float32)`; torch's generic bool->bf16 copy takes 15 us for 3.9 MB)
+template <int FMT>  // 0: f32, 1: bf16 (0x3F80), 2: f16 (0x3C00)
+__global__ __launch_bounds__(256) void k_obs_cast(const uint4 *in, void *out, int64_t n16) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n16) return;
+  const uint4 v = in[i];
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  if (FMT == 0) {
+    float4 *o = reinterpret_cast<float4 *>(out) + 4 * i;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      o[k] = make_float4((w[k] & 1u) ? 1.0f : 0.0f, (w[k] & 0x100u) ? 1.0f : 0.0f, (w[k] & 0x10000u) ? 1.0f : 0.0f,
+                         (w[k] & 0x1000000u) ? 1.0f : 0.0f);
+  } else {
+    const uint32_t one = (FMT == 1) ? 0x3F80u : 0x3C00u;
+    uint4 *o = reinterpret_cast<uint4 *>(out) + 2 * i;
+    uint32_t h[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {  // bytes (b0,b1,b2,b3) of a dword -> halves (b0,b1) and (b2,b3)
+      h[2 * k] = ((w[k] & 1u) ? one : 0u) | ((w[k] & 0x100u) ? (one << 16) : 0u);
+      h[2 * k + 1] = ((w[k] & 0x10000u) ? one : 0u) | ((w[k] & 0x1000000u) ? (one << 16) : 0u);
+    }
+    o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+  }
+}
+
+extern "C" int brl_obs_cast(brl_handle *h, const uint8_t *obs, int64_t n, void *out, int fmt, void *stream) {
+  COMMON(h, n);
+  NEED(obs && out, "NULL obs / out");
+  NEED(fmt >= 0 && fmt <= 2, "fmt");
+  const int64_t n16 = n * (BRL_OBS_SIZE / 16);
+  const dim3 grid((unsigned)((n16 + 255) / 256)), block(256);
+  if (fmt == 0) hipLaunchKernelGGL(k_obs_cast<0>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, out, n16);
+  else if (fmt == 1) hipLaunchKernelGGL(k_obs_cast<1>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, out, n16);
+  else hipLaunchKernelGGL(k_obs_cast<2>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, out, n16);
+  HIP_TRY(hipGetLastError());
   return BRL_OK;
 }
 

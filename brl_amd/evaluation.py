@@ -42,7 +42,11 @@ def make_simple_duplicate_evaluate(eval_env: BridgeBidding, team1_activation, te
             count = 0
             snap1, snap2 = InferenceSnapshot.make(team1_params), InferenceSnapshot.make(team2_params)
             while True:
-                obs = state.observation.to(torch.float32)
+                obs = state.observation
+                if snap1 is None or snap2 is None:
+                    obs = obs.to(torch.float32)
+                elif snap1.dtype == snap2.dtype:
+                    obs = snap1._input(obs)  # one conversion for both networks
                 # G10: the reference evaluates both networks for every env and selects; so do we
                 l1, _ = snap1(obs) if snap1 is not None else team1_forward_pass.apply(team1_params, obs)
                 l2, _ = snap2(obs) if snap2 is not None else team2_forward_pass.apply(team2_params, obs)

@@ -21,15 +21,17 @@ def sync_time(fn, reps=3):
     for _ in range(reps): out = fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps, out
-for dt in (None, "bf16"):
-    cfg = dict(DEFAULTS, num_envs=N, num_steps=T, inference_dtype=dt)
+for dt, graph in ((None, False), ("bf16", False), ("bf16", True)):
+    cfg = dict(DEFAULTS, num_envs=N, num_steps=T, inference_dtype=dt, graph_rollout=graph)
     roll = brl_amd.make_roll_out(cfg, env, fp, fp)
     st = env.init(0, num_envs=N)
     rs = (params, None, st, st.observation, 0, 0)
-    t, (rs2, traj) = sync_time(lambda: roll(rs, opp))
-    res[f"rollout_{dt or 'fp32'}_ms"] = round(t * 1e3, 2)
-    res[f"rollout_{dt or 'fp32'}_macro_steps_per_s"] = round(N * T / t)
-    res[f"rollout_{dt or 'fp32'}_raw_env_steps_per_s"] = round(4 * N * T / t)
+    roll(rs, opp)  # (graph capture on the first call)
+    t, (rs2, traj) = sync_time(lambda: roll(rs, opp), 5)
+    tag = (dt or "fp32") + ("_graph" if graph else "")
+    res[f"rollout_{tag}_ms"] = round(t * 1e3, 2)
+    res[f"rollout_{tag}_macro_steps_per_s"] = round(N * T / t)
+    res[f"rollout_{tag}_raw_env_steps_per_s"] = round(4 * N * T / t)
 cfg = dict(DEFAULTS, num_envs=N, num_steps=T)
 cfg["num_minibatches"] = N * T // cfg["minibatch_size"]; cfg["num_updates"] = 1
 calc_gae = brl_amd.make_calc_gae(cfg, fp)

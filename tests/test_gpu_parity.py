@@ -403,6 +403,46 @@ def test_policy_rollout_low_precision_inference(env, dt):
     assert np.abs(to_np(traj2.value).reshape(-1) - to_np(value2)).max() < tol
 
 
+def test_obs_cast_matches_torch(env):
+    from brl_amd import _capi
+    from brl_amd.bridge_bidding import _stream
+    st = env.init(1, num_envs=777)
+    obs = st.observation
+    for fmt, dt in ((0, torch.float32), (1, torch.bfloat16), (2, torch.float16)):
+        out = torch.empty(obs.shape, dtype=dt, device=obs.device)
+        _capi.check(_capi.lib().brl_obs_cast(env._h, obs.data_ptr(), obs.shape[0], out.data_ptr(), fmt, _stream()))
+        assert torch.equal(out, obs.to(dt))
+
+
+@pytest.mark.parametrize("dt", [None, "bf16"])
+def test_graphed_policy_rollout_matches_eager(env, dt):
+    """config["graph_rollout"]: every macro-step replayed from a hipGraph (device-side draw index,
+    brl_policy_step_at) — same bytes as the eager loop, call after call, also after a weight update."""
+    import brl_amd
+    from brl_amd.models import make_forward_pass
+    n, T = 640, 5
+    base = {"num_steps": T, "reward_scale": 7600, "game_mode": "competitive", "actor_illegal_action_mask": True,
+            "inference_dtype": dt}
+    fp = make_forward_pass("relu", "DeepMind")
+    actor, opp = fp.init(3, device="cuda"), fp.init(4, device="cuda")
+    eager = brl_amd.make_roll_out(base, env, fp, fp)
+    graphed = brl_amd.make_roll_out(dict(base, graph_rollout=True), env, fp, fp)
+    st = env.init(11, num_envs=n)
+    rs_e = rs_g = (actor, None, st, st.observation, 0, 0)
+    for call in range(3):
+        rs_e, tr_e = eager(rs_e, opp)
+        rs_g, tr_g = graphed(rs_g, opp)
+        torch.cuda.synchronize()
+        for name in tr_e._fields:
+            assert torch.equal(getattr(tr_e, name), getattr(tr_g, name)), f"{dt} call {call}: {name}"
+        assert torch.equal(rs_e[2].packed, rs_g[2].packed) and torch.equal(rs_e[3], rs_g[3])
+        assert int(rs_e[4].item()) == int(rs_g[4].item()) and rs_e[5] == rs_g[5]
+        assert torch.equal(rs_e[2].rewards, rs_g[2].rewards) and torch.equal(rs_e[2].terminated, rs_g[2].terminated)
+        with torch.no_grad():  # "update": the next call must see the new weights
+            for p in actor.parameters():
+                p.add_(0.01 * torch.randn_like(p))
+
+
 def test_full_size_properties(dds):
     """BASELINE.json size (N=8192, T=32): size-independent properties of the fused rollout."""
     import brl_amd
