@@ -354,28 +354,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_rollout_random(RolloutArgs A)
   wave_end<K>(w, t, A.state, A.n);
 }
 
-// ---- A7 fused random-policy rollout, wave-specialised ("ws") -------------------------------
-// The T-step scan is latency-bound on ONE dependency chain per table (state(t+1) needs
-// state(t)), so the kernel keeps that chain as short as possible and moves everything that does
-// not feed it onto other waves of the same workgroup.  One workgroup owns TPB consecutive tables:
-//   wave 0        LOGIC  : lane l advances table l in registers — legal mask, action draw,
-//                          auction transition, re-deal bookkeeping.  Nothing else: no reward, no
-//                          first-denomination table, no HBM access in the loop.
-//   wave 1        LOADER : keeps, per table, a 2-deep LDS ring of the NEXT boards of that slot
-//                          (Philox -> LUT row -> 32-B global load).  The only wave that waits on
-//                          loads, so nobody else's vmcnt ever includes them.
-//   wave 2        SCORER : lane l follows table l one sub-step behind the logic wave: first
-//                          denominations, contract score + DDS tricks -> reward (A4), sums over
-//                          sub-steps (G1), and writes the scalar Transition columns, coalesced
-//                          over tables.
-//   waves 3..NW-1 EMIT   : each owns a fixed subset of the tables' LDS images, applies the logic
-//                          wave's per-sub-step command (set one history bit, or deal a new board
-//                          from the ring) and streams the 480-B observation row + 38-B mask row.
-//                          Stores only: they never wait on memory.
-// One s_barrier per sub-step (preceded by lgkmcnt(0) only — global loads/stores stay in flight
-// across it); commands are double-buffered in LDS, so the logic wave runs one sub-step ahead of
-// everybody else.  A table deals at most once every 4 sub-steps (the shortest auction is four
-// passes), which is what makes the 2-deep ring and its 1-sub-step refill latency safe.
+// ---- A7 fused random-policy rollout, wave-specialised ("ws"): constants and command format; the kernel and
+// the description of its roles follow below ---------------------------------------------------------------
 constexpr int CMD_WORDS = 4;
 constexpr int RING_WORDS = 16;  // hands[8] (the four packed hand words, k_lut_hands) values[4] idx sc_bits pad pad
 constexpr int WS_BATCH = 8;     // sub-steps per workgroup barrier
@@ -422,11 +402,13 @@ __device__ __forceinline__ void lds_barrier() {
 //                          auction transition, re-deal bookkeeping.  Nothing else: no reward, no
 //                          first-denomination table, no HBM access in the loop.
 //   wave 1        LOADER : keeps, per table, an LDS ring of the next WS_RING boards of that slot
-//                          (Philox -> LUT row -> 32-B global load).  The only wave that waits on
+//                          (Philox -> LUT row -> its packed hand words + DDS values, 48 B) and computes
+//                          the Philox action draws one batch ahead.  The only wave that waits on
 //                          loads, so nobody else's vmcnt ever includes them.
-//   wave 2        SCORER : lane l follows table l behind the logic wave: first denominations,
-//                          contract score + DDS tricks -> reward (A4), sums over sub-steps (G1), and
-//                          writes the scalar Transition columns, coalesced over tables.
+//   wave 2        SCORER : lane l follows table l behind the logic wave: first denominations; finished
+//                          boards are queued, compacted over the tables, and scored one lane per board
+//                          (contract + DDS tricks -> reward, A4); sums over sub-steps (G1); writes the
+//                          scalar Transition columns, coalesced over tables.  (Runs on hardware wave 3.)
 //   waves 3..NW-1 EMIT   : each owns a fixed subset of the tables' LDS images, applies the logic
 //                          wave's per-sub-step command (set one history bit, or deal a new board
 //                          from the ring) and streams 4 x 480-B observation rows + 4 x 38-B mask
@@ -440,7 +422,8 @@ __device__ __forceinline__ void lds_barrier() {
 // passes), i.e. <= 3 boards per batch.  Boards dealt in batch b are still read by the scorer and
 // emit waves during batch b+1, so the loader refills their slots during batch b+2 (finished before
 // that batch's barrier); the logic wave, then at most in batch b+3, has consumed <= 9 boards since
-// the start of batch b+1 < WS_RING.
+// the start of batch b+1 < WS_RING - 1.  (- 1: a board's ring entry is kept one deal longer than that, because
+// the scorer reads its DDS values when the board ENDS, i.e. in the batch of the next deal.)
 template <int TPB, int NW>
 __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   static_assert(TPB <= 64 && NW >= 4, "logic + loader + scorer + >=1 emit wave");
