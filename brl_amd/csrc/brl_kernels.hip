@@ -971,6 +971,7 @@ template <int K>
 __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES_PER_BLOCK * K * TABLE_BYTES];
   __shared__ float llds[WAVES_PER_BLOCK * K * BRL_NUM_ACTIONS];
+  __shared__ float elds[WAVES_PER_BLOCK * K * BRL_NUM_ACTIONS];
   Tbl t;
   Wave<K> w = wave_begin<K>(lds, A.state_in, A.n, t);
   // stage the wave's K x 38 logits (contiguous in [n,38]) through LDS, coalesced
@@ -994,9 +995,14 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
       amax = a;
     }
   }
+  // exp(logit - max) of every action ONCE, spread over the 64 / K lanes that share the table; the sums below
+  // then run sequentially in action order on every lane (same fp32 rounding as the scalar oracle)
+  float *ew = elds + ((threadIdx.x >> 6) * K + w.tl) * BRL_NUM_ACTIONS;
+  for (int a = w.c.lane / K; a < BRL_NUM_ACTIONS; a += 64 / K) ew[a] = expf(lg[a] - mx);
+  wave_lds_fence();
   float sum = 0.0f;
   for (int a = 0; a < BRL_NUM_ACTIONS; a++)
-    if ((legal >> a) & 1ull) sum += expf(lg[a] - mx);
+    if ((legal >> a) & 1ull) sum += ew[a];
   int act = amax;
   if (A.mode == 0) {
     uint32_t r[4];
@@ -1011,7 +1017,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
     bool found = false;
     for (int a = 0; a < BRL_NUM_ACTIONS; a++) {
       if ((legal >> a) & 1ull) {
-        cum += expf(lg[a] - mx);
+        cum += ew[a];
         last = a;
         if (!found && cum > target) {
           act = a;
