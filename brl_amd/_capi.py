@@ -65,7 +65,7 @@ def lib() -> C.CDLL:
         "brl_get_fields": [_vp, _vp, i64, C.POINTER(Fields), _vp],
         "brl_rollout_random": [_vp, _vp, i64, i32, i32, u32, f32, C.POINTER(TransitionPtrs), _vp, _vp, _vp, _vp],
         "brl_policy_step": [_vp, _vp, _vp, i64, _vp, i32, u32, i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-        "brl_policy_step_at": [_vp, _vp, _vp, i64, _vp, i32, _vp, u32, i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+        "brl_policy_step_at": [_vp, _vp, _vp, i64, _vp, i64, i32, _vp, u32, i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
         "brl_obs_cast": [_vp, _vp, i64, _vp, i32, _vp],
         "brl_gae": [_vp, _vp, _vp, _vp, _vp, f32, f32, i32, i64, _vp, _vp, _vp],
         "brl_imp_reward": [_vp, _vp, _vp, _vp, i64, _vp],

@@ -955,6 +955,7 @@ struct PolicyArgs {
   uint64_t *state_out;
   int64_t n;
   const float *logits;
+  int64_t logits_stride;  // elements between the rows of two consecutive tables (>= 38)
   int mode;
   uint32_t draw;
   const uint32_t *draw_dev;  // optional: the draw index is draw + *draw_dev (hipGraph-captured loops)
@@ -978,7 +979,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
   float *wl = llds + (threadIdx.x >> 6) * K * BRL_NUM_ACTIONS;
   for (int i = w.c.lane; i < K * BRL_NUM_ACTIONS; i += 64) {
     int64_t tb = w.table0 + i / BRL_NUM_ACTIONS;
-    wl[i] = (tb < A.n) ? A.logits[w.table0 * BRL_NUM_ACTIONS + i] : 0.0f;
+    wl[i] = (tb < A.n) ? A.logits[tb * A.logits_stride + (i - (i / BRL_NUM_ACTIONS) * BRL_NUM_ACTIONS)] : 0.0f;
   }
   wave_lds_fence();
   const float *lg = wl + w.tl * BRL_NUM_ACTIONS;
@@ -1475,15 +1476,18 @@ extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int
 }
 
 static int policy_step_impl(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
-                            const float *logits, int mode, const uint32_t *draw_dev, uint32_t draw, int autoreset,
+                            const float *logits, int64_t logits_stride, int mode, const uint32_t *draw_dev, uint32_t draw,
+                            int autoreset,
                             int32_t *action, float *log_prob, uint8_t *obs, uint8_t *mask, float *rewards_acc,
                             uint8_t *terminated_acc, int32_t *current_player, void *stream) {
   COMMON(h, n);
   NEED(state_in && state_out && logits, "NULL state / logits");
   NEED(mode == 0 || mode == 1, "mode");
+  NEED(logits_stride >= BRL_NUM_ACTIONS, "logits_stride");
   if (autoreset && h->lut_len == 0) return fail(BRL_E_NOLUT, "auto-reset needs a LUT%s", "");
   PolicyArgs A;
   A.state_in = state_in; A.state_out = state_out; A.n = n; A.logits = logits; A.mode = mode; A.draw = draw;
+  A.logits_stride = logits_stride;
   A.draw_dev = draw_dev;
   A.autoreset = autoreset; A.g = rng_of(h); A.env_offset = h->env_offset; A.lut = lut_of(h);
   A.action = action; A.log_prob = log_prob;
@@ -1496,17 +1500,17 @@ extern "C" int brl_policy_step(brl_handle *h, const uint64_t *state_in, uint64_t
                                const float *logits, int mode, uint32_t draw, int autoreset, int32_t *action,
                                float *log_prob, uint8_t *obs, uint8_t *mask, float *rewards_acc,
                                uint8_t *terminated_acc, int32_t *current_player, void *stream) {
-  return policy_step_impl(h, state_in, state_out, n, logits, mode, nullptr, draw, autoreset, action, log_prob, obs, mask,
-                          rewards_acc, terminated_acc, current_player, stream);
+  return policy_step_impl(h, state_in, state_out, n, logits, BRL_NUM_ACTIONS, mode, nullptr, draw, autoreset, action,
+                          log_prob, obs, mask, rewards_acc, terminated_acc, current_player, stream);
 }
 
 extern "C" int brl_policy_step_at(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
-                                  const float *logits, int mode, const uint32_t *draw_base, uint32_t draw_offset,
-                                  int autoreset, int32_t *action, float *log_prob, uint8_t *obs, uint8_t *mask,
-                                  float *rewards_acc, uint8_t *terminated_acc, int32_t *current_player, void *stream) {
-  if (!draw_base) return fail(BRL_E_ARG, "brl_policy_step_at: draw_base is NULL%s", "");
-  return policy_step_impl(h, state_in, state_out, n, logits, mode, draw_base, draw_offset, autoreset, action, log_prob, obs,
-                          mask, rewards_acc, terminated_acc, current_player, stream);
+                                  const float *logits, int64_t logits_stride, int mode, const uint32_t *draw_base,
+                                  uint32_t draw_offset, int autoreset, int32_t *action, float *log_prob, uint8_t *obs,
+                                  uint8_t *mask, float *rewards_acc, uint8_t *terminated_acc, int32_t *current_player,
+                                  void *stream) {
+  return policy_step_impl(h, state_in, state_out, n, logits, logits_stride, mode, draw_base, draw_offset, autoreset,
+                          action, log_prob, obs, mask, rewards_acc, terminated_acc, current_player, stream);
 }
 
 // observation bytes (0/1) -> the network's input dtype: 16 bytes in, 16 elements out per thread

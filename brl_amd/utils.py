@@ -55,13 +55,16 @@ def policy_step(env: BridgeBidding, packed_in, packed_out, logits, mode: int, dr
     """One launch of ``brl_policy_step`` (include/brl_hip.h).  With ``draw_base`` (a 1-element int32/uint32 device
     tensor) the draw index is ``draw_base[0] + draw``, read on the device (``brl_policy_step_at``: hipGraph replays)."""
     n = packed_in.shape[0]
-    logits = logits.to(torch.float32).contiguous()
+    logits = logits.to(torch.float32)
     assert logits.shape == (n, NUM_ACTIONS)
-    if draw_base is not None:
-        check(_capi.lib().brl_policy_step_at(env._h, ptr(packed_in), ptr(packed_out), n, ptr(logits), int(mode),
-                                             ptr(draw_base), int(draw) & 0xFFFFFFFF, int(bool(autoreset)), ptr(action),
-                                             ptr(log_prob), ptr(obs), ptr(mask), ptr(rewards_acc), ptr(terminated_acc),
-                                             ptr(current_player), _stream()))
+    strided = logits.stride(1) == 1 and logits.stride(0) >= NUM_ACTIONS  # e.g. the first 38 columns of a [n,39] matrix
+    if not strided:
+        logits = logits.contiguous()
+    if draw_base is not None or logits.stride(0) != NUM_ACTIONS:
+        check(_capi.lib().brl_policy_step_at(env._h, ptr(packed_in), ptr(packed_out), n, logits.data_ptr(),
+                                             logits.stride(0), int(mode), ptr(draw_base), int(draw) & 0xFFFFFFFF,
+                                             int(bool(autoreset)), ptr(action), ptr(log_prob), ptr(obs), ptr(mask),
+                                             ptr(rewards_acc), ptr(terminated_acc), ptr(current_player), _stream()))
         return
     check(_capi.lib().brl_policy_step(env._h, ptr(packed_in), ptr(packed_out), n, ptr(logits), int(mode),
                                       int(draw) & 0xFFFFFFFF, int(bool(autoreset)), ptr(action), ptr(log_prob),

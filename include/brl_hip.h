@@ -150,14 +150,18 @@ int brl_policy_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out
                     float *log_prob, uint8_t *obs, uint8_t *mask, float *rewards_acc,
                     uint8_t *terminated_acc, int32_t *current_player, void *stream);
 
-/* The same with the draw index taken from DEVICE memory: draw = *draw_base + draw_offset, read by the kernel when it
- * runs.  For loops captured once in a hipGraph and replayed (the arguments of a captured launch are frozen; the
- * counter is advanced by another node of the graph) — the reference's jitted scan has no host in its loop either
- * (src/roll_out.py:63-108). */
+/* The same, generalised for loops that run without the host and for logits that are a slice of a wider matrix:
+ *  - logits_stride: elements between the rows of consecutive tables (38 = dense; 39 when the actor and critic heads
+ *    are one GEMM and the logits are its first 38 columns);
+ *  - draw_base (device pointer, may be NULL): the draw index is *draw_base + draw_offset, read by the kernel when it
+ *    runs — for scans captured once in a hipGraph and replayed (the arguments of a captured launch are frozen, the
+ *    counter is advanced by another node of the graph); the reference's jitted scan has no host in its loop either
+ *    (src/roll_out.py:63-108). */
 int brl_policy_step_at(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
-                       const float *logits, int mode, const uint32_t *draw_base, uint32_t draw_offset,
-                       int autoreset, int32_t *action, float *log_prob, uint8_t *obs, uint8_t *mask,
-                       float *rewards_acc, uint8_t *terminated_acc, int32_t *current_player, void *stream);
+                       const float *logits, int64_t logits_stride, int mode, const uint32_t *draw_base,
+                       uint32_t draw_offset, int autoreset, int32_t *action, float *log_prob, uint8_t *obs,
+                       uint8_t *mask, float *rewards_acc, uint8_t *terminated_acc, int32_t *current_player,
+                       void *stream);
 
 /* Observation bytes -> network input: `last_obs.astype(jnp.float32)` (src/roll_out.py:75) and its low-precision
  * variants.  obs uint8 [n,480] (0/1); out [n,480] of float (fmt 0), bf16 (fmt 1) or fp16 (fmt 2). */
