@@ -116,3 +116,30 @@ def test_allreduce_is_noop_without_process_group():
         p.grad = torch.ones_like(p)
     allreduce_gradients(net)
     assert all(bool((p.grad == 1).all()) for p in net.parameters())
+
+
+def test_inference_snapshot_matches_module_cpu():
+    """models.InferenceSnapshot (fused bias+ReLU epilogue, merged heads) == the module's own forward; refresh()
+    re-reads updated weights into the same tensors (their addresses are baked into captured graphs)."""
+    import torch
+    from brl_amd.models import InferenceSnapshot, make_forward_pass
+    fp = make_forward_pass("relu", "DeepMind")
+    net = fp.init(5)
+    x = (torch.rand(64, 480) < 0.1)
+    snap = InferenceSnapshot.make(net)
+    assert snap is not None
+    with torch.no_grad():
+        lg, v = net(x.float())
+        lg2, v2 = snap(x)
+    assert lg2.shape == (64, 38) and v2.shape == (64,)
+    assert torch.allclose(lg, lg2, atol=1e-5) and torch.allclose(v, v2, atol=1e-5)
+    ptrs = [w.data_ptr() for w, _ in snap.body] + [snap.head_w.data_ptr()]
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(0.5)
+        snap.refresh(net)
+        lg3, v3 = net(x.float())
+        lg4, v4 = snap(x)
+    assert torch.allclose(lg3, lg4, atol=1e-5) and torch.allclose(v3, v4, atol=1e-5)
+    assert ptrs == [w.data_ptr() for w, _ in snap.body] + [snap.head_w.data_ptr()]
+    assert InferenceSnapshot.make(make_forward_pass("relu", "FAIR").init(0)) is None  # not covered: callers fall back
