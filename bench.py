@@ -175,7 +175,7 @@ def main():
                    "parallelism": f"env-shard x{world}, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
-                     "kernel": "k_rollout_ws<%s>" % os.environ.get("BRL_ROLLOUT_WS", "32x11").replace("x", ","), "kernel_ms": kern_ms, "kernel_ms_samples": len(events), "algorithmic_bytes_per_launch": alg_bytes},
+                     "kernel": "k_rollout_ws<%s>" % os.environ.get("BRL_ROLLOUT_WS", "32x12").replace("x", ","), "kernel_ms": kern_ms, "kernel_ms_samples": len(events), "algorithmic_bytes_per_launch": alg_bytes},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -424,11 +424,12 @@ __device__ __forceinline__ void lds_barrier() {
 // that batch's barrier); the logic wave, then at most in batch b+3, has consumed <= 9 boards since
 // the start of batch b+1 < WS_RING - 1.  (- 1: a board's ring entry is kept one deal longer than that, because
 // the scorer reads its DDS values when the board ENDS, i.e. in the batch of the next deal.)
-template <int TPB, int NW>
+template <int TPB, int NW, int MW = 0>
 __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
-  static_assert(TPB <= 64 && NW >= 4, "logic + loader + scorer + >=1 emit wave");
+  static_assert(TPB <= 64 && NW >= 4 + MW, "logic + loader + scorer + >=1 emit wave (+ mask wave)");
   static_assert(TPB % 4 == 0, "emit waves write 4 consecutive tables per instruction");
-  constexpr int NE = NW - 3;
+  static_assert(MW == 0 || TPB == 32, "the mask wave writes the 32 x 38 mask bytes of a sub-step as 76 16-byte chunks");
+  constexpr int NE = NW - 3 - MW;  // MW = 1: the last wave writes every table's legal-mask row instead of the emit waves
   constexpr int B = WS_BATCH;
 #ifdef BRL_TIMING
   unsigned long long t_probe0 = 0, t_probe1 = 0, t_probe_n = 0;
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   // role index; hardware wave w runs on SIMD w % 4, and with NW = 11 SIMD 3 hosts only two waves: the scorer (the
   // longest chain after the logic wave) takes hardware wave 3 there, the first emit role hardware wave 2
   const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave = (NW == 11 && !(A.debug & 2048)) ? ((hw_wave == 2) ? 3 : ((hw_wave == 3) ? 2 : hw_wave)) : hw_wave;
+  const int wave = (NW >= 11 && !(A.debug & 2048)) ? ((hw_wave == 2) ? 3 : ((hw_wave == 3) ? 2 : hw_wave)) : hw_wave;
   const LaneConst c = make_lane_const();
   const int64_t table0 = xcd_block((int64_t)blockIdx.x, (int64_t)gridDim.x) * TPB;
   uint64_t *img64 = reinterpret_cast<uint64_t *>(img);
@@ -456,6 +457,9 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   }
   if (tid <= BRL_NUM_ACTIONS) s_neglog[tid] = A.neg_log_n[tid];
   const int total = A.T * A.substeps;   // sub-steps; command slots are s = 0..total
+  // (MW) the mask wave takes over the legal-mask rows of a workgroup whose 32 tables all exist, in the fast-path batches
+  const bool mask_by_wave = (MW != 0) && (A.substeps == 1) && A.out.obs && A.out.legal_action_mask &&
+                            !(A.debug & ~(256 | 1024 | 2048)) && (table0 + TPB <= A.n);
   const int nbatch = ws_nbatch(total);  // batches of command slots (ws_bstart / ws_blen)
   const int tl = c.lane;                // logic / loader / scorer: lane = table
   const int tls = (tl < TPB) ? tl : 0;
@@ -718,6 +722,39 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
 #endif
       wave_lds_order();
       if (m > 0) last_acc = *reinterpret_cast<const int4 *>(&acc[m - 1][tl][0]);
+      const bool wide = (TPB == 32) && (table0 + TPB <= A.n) && A.out.done && A.out.action && A.out.value &&
+                        A.out.reward && A.out.log_prob;
+      if (wide) {
+        // every table of the workgroup exists and every column is requested: lane l writes 4 consecutive tables of
+        // macro-step l / 8 — ONE 16-byte store per lane and float column covers all 8 macro-steps of a batch
+        // (5 store instructions per batch instead of 20)
+        const int q = c.lane >> 3, t4 = 4 * (c.lane & 7);
+        if (q < m) {
+          const uint4 info4 = *reinterpret_cast<const uint4 *>(&minfo[q][t4]);
+          const uint32_t inf[4] = {info4.x, info4.y, info4.z, info4.w};
+          float rew[4], lgp[4];
+          uint32_t act[4], dn = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int4 r = *reinterpret_cast<const int4 *>(&acc[q][t4 + k][0]);
+            const int actor = (int)(inf[k] & 3u);
+            const int ra = (actor == 0) ? r.x : ((actor == 1) ? r.y : ((actor == 2) ? r.z : r.w));
+            rew[k] = (float)ra / A.reward_scale;  // G1, src/roll_out.py:90
+            lgp[k] = s_neglog[(inf[k] >> 8) & 63u];
+            act[k] = (inf[k] >> 2) & 63u;
+            const uint32_t done = (inf[k] >> 14) & 1u;
+            dn |= done << (8 * k);
+            tcount += done;
+          }
+          const int64_t rw = (row - tl) + (int64_t)q * A.n + t4;  // row - tl: the workgroup's first table at this macro-step
+          *reinterpret_cast<brl_u32x4 *>(A.out.action + rw) = brl_u32x4{act[0], act[1], act[2], act[3]};
+          *reinterpret_cast<float4 *>(A.out.value + rw) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          *reinterpret_cast<float4 *>(A.out.reward + rw) = make_float4(rew[0], rew[1], rew[2], rew[3]);
+          *reinterpret_cast<float4 *>(A.out.log_prob + rw) = make_float4(lgp[0], lgp[1], lgp[2], lgp[3]);
+          *reinterpret_cast<uint32_t *>(A.out.done + rw) = dn;  // G2
+        }
+        row += (int64_t)m * A.n;
+      } else
       {
         constexpr bool TWO = (TPB <= 32);
         const int half = TWO ? (c.lane >> 5) : 0;
@@ -766,6 +803,41 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
       p[W_FD] = make_uint2(ts.fd, ts.t2);
       p[W_TR] = make_uint2(ts.t0, ts.t1);
       p[W_REW] = make_uint2(ts.r01, ts.r23);
+    }
+  } else if (MW != 0 && wave == NW - 1) {
+    // ------------------------------------------------------------------ mask wave
+    // The 32 legal-mask rows of a sub-step are 1216 contiguous bytes = 76 chunks of 16 B: lane l writes chunk l, lanes
+    // < 12 also chunk 64 + l.  A chunk holds the bytes of table ta (from action `off` on) and possibly of ta + 1.
+    uint32_t ta[2], tb[2], off[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const uint32_t cidx = (uint32_t)c.lane + 64u * (uint32_t)q;
+      const uint32_t byte0 = 16u * ((cidx < 76u) ? cidx : 75u);
+      ta[q] = byte0 / BRL_NUM_ACTIONS;
+      off[q] = byte0 - ta[q] * BRL_NUM_ACTIONS;
+      tb[q] = (ta[q] + 1u < (uint32_t)TPB) ? ta[q] + 1u : ta[q];
+    }
+    uint8_t *mrow = A.out.legal_action_mask + table0 * BRL_NUM_ACTIONS;
+    const int64_t mstep = A.n * BRL_NUM_ACTIONS;
+    for (int bi = 0; bi < nbatch; bi++) {
+      LDS_BARRIER();
+      const int bstart = ws_bstart(bi), blen = ws_blen(bi);
+      if (!mask_by_wave || bstart + blen > total) continue;  // that batch (and every ragged block) is the emit waves'
+      for (int j = 0; j < blen; j++) {
+        const uint32_t(*cs)[CMD_WORDS] = cmd[bi & 1][j];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          if (q == 1 && c.lane >= 12) break;
+          const uint64_t la = *reinterpret_cast<const uint64_t *>(&cs[ta[q]][2]) & ALL_ACTIONS;
+          const uint64_t lb = *reinterpret_cast<const uint64_t *>(&cs[tb[q]][2]) & ALL_ACTIONS;
+          const uint32_t bits16 = (uint32_t)((la >> off[q]) | (lb << (BRL_NUM_ACTIONS - off[q])));
+          uint32_t d[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) d[i] = __umul24((bits16 >> (4 * i)) & 0xFu, 0x204081u) & 0x01010101u;
+          *reinterpret_cast<uint4 *>(mrow + 16 * (c.lane + 64 * q)) = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+        mrow += mstep;
+      }
     }
   } else {
     // ------------------------------------------------------------------ emit waves
@@ -831,18 +903,18 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
             uint32_t a;
             uint64_t H;
             obs_chunk_load(img_g, (int)((w0 >> 10) & 3u), gl, a, H);
-            const uint64_t la = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
-            const uint64_t lb = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
-            uint32_t d[8];
             {
               GroupLane gz = gl;
               gz.out_off = 0;
               if (olane) obs_chunk_store(a, H, (int)((w0 >> 10) & 3u), (w0 >> 12) & 15u, optr[k], gz);
             }
-            if (ml.active) *mptr[k] = mask_dword(la, lb, ml);
             optr[k] += ostep;
-            mptr[k] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(mptr[k]) + mstep);
-            (void)d;
+            if (!mask_by_wave) {  // (uniform)
+              const uint64_t la = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qa][2]);
+              const uint64_t lb = *reinterpret_cast<const uint64_t *>(&cs[4 * g + ml.qb][2]);
+              if (ml.active) *mptr[k] = mask_dword(la, lb, ml);
+              mptr[k] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(mptr[k]) + mstep);
+            }
           }
         }
       }
@@ -1295,9 +1367,9 @@ extern "C" int brl_create(int device, const int32_t *lut_keys, const int32_t *lu
     if (k == 1 || k == 2 || k == 4 || k == 8) h->tables_per_wave = k;
   }
   h->ws_tpb = 32;
-  h->ws_nw = 11;
+  h->ws_nw = 12;  // 32x12 = logic, loader, scorer, 8 emit waves, mask wave
   h->pipe = getenv("BRL_ROLLOUT_PIPE") ? atoi(getenv("BRL_ROLLOUT_PIPE")) : 0;
-  const char *ws = getenv("BRL_ROLLOUT_WS");  // "TPBxNW" (16x5 16x7 32x5 32x7 32x8 32x11 64x7 64x11) or "0"
+  const char *ws = getenv("BRL_ROLLOUT_WS");  // "TPBxNW" (16x5 16x7 32x5 32x7 32x8 32x11 32x12) or "0"
   if (ws) {
     int a = 0, b = 0;
     if (sscanf(ws, "%dx%d", &a, &b) == 2) {
@@ -1466,6 +1538,7 @@ extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int
     case 3207: LAUNCH_WS(32, 7); break;
     case 3208: LAUNCH_WS(32, 8); break;
     case 3211: LAUNCH_WS(32, 11); break;
+    case 3212: hipLaunchKernelGGL((k_rollout_ws<32, 12, 1>), dim3((unsigned)((n + 31) / 32)), dim3(12 * 64), 0, (hipStream_t)stream, A); break;
     case 6407: LAUNCH_WS(64, 7); break;
     case 6411: LAUNCH_WS(64, 11); break;
     default: LAUNCH_K(h, k_rollout_random, n, stream, A); return BRL_OK;

@@ -151,7 +151,8 @@ def test_observe_any_player(env, oracle):
     (4, "16x5", 1, 1000, 32), (4, "16x7", 4, 515, 12), (4, "32x11", 1, 4099, 32), (4, "16x7", 1, 2048, 32),
     (4, "16x5", 4, 777, 9), (4, "32x5", 1, 300, 64), (4, "32x7", 1, 129, 7), (4, "32x4", 4, 2048, 40),
     (4, "32x7", 1, 2, 3), (4, "32x7", 1, 30, 33), (4, "32x11", 3, 700, 21), (4, "32x4", 2, 450, 19),
-    (4, "32x11", 8, 130, 5), (4, "32x11", 9, 130, 3)])
+    (4, "32x11", 8, 130, 5), (4, "32x11", 9, 130, 3),
+    (4, "32x12", 1, 2048, 32), (4, "32x12", 1, 4099, 33), (4, "32x12", 4, 515, 12), (4, "32x12", 1, 33, 7)])
 def test_fused_random_rollout_matches_oracle(dds, oracle, k, ws, substeps, n, T):
     import brl_amd
     env = make_env(dds, k, ws)
