@@ -1,24 +1,30 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/s of the fused bridge-bidding rollout on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]           # N > 1: starts N ranks itself (one per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # or under torchrun (WORLD_SIZE must equal N)
+    python bench.py --config ppo [--steps K]                        # secondary: configs[3] phase timing (not the metric)
 
 One "step" = one pass of the hot path over one batch: the T=32-step random-policy rollout of
 num_envs=8192 tables (BASELINE.json configs[1]: ONE fused kernel launch writing the full
 time-major Transition buffer, auto-reset + DDS reward included), the observation of the
-post-rollout state (runner_state's last_obs, written by the same launch) and the GAE(lambda) reverse scan.  Inputs (table
-states, LUT) are resident in HBM before the timed region.  With N > 1 every rank runs its own
-8192-table shard (weak scaling, no data-path collective — SURVEY §8e); `value` is the
-whole-job macro-steps/s = N * 8192 * 32 * K / max-over-ranks time.
-Prints ONE JSON line on rank 0.
+post-rollout state (runner_state's last_obs, written by the same launch) and the GAE(lambda) reverse scan.
+Inputs (table states, LUT) are resident in HBM before the timed region; the Transition buffer rotates over
+NBUF = 3 allocations (433 MB > the 256 MB Infinity Cache), so the stores have to reach HBM.  With N > 1 every rank
+runs its own 8192-table shard (weak scaling, no data-path collective — SURVEY §8e); `value` is the whole-job
+macro-steps/s = N * 8192 * 32 * K / max-over-ranks time.  Prints ONE JSON line on rank 0.
+
+`roofline` is measured in THIS run: after the timed region, KERNEL_LAUNCHES back-to-back launches of the rollout kernel
+alone (same rotating buffers, the C-ABI called directly) between ONE pair of HIP events on the launch stream.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,8 +37,13 @@ NUM_ENVS = 8192
 NUM_STEPS = 32
 LUT_LEN = 100_000          # ppo.py:128 hash_size
 ROW_BYTES = 535            # obs 480 + mask 38 + action 4 + value 4 + reward 4 + log_prob 4 + done 1
-LAST_ROW_BYTES = 518       # last_obs 480 + its legal mask 38, written once per table by the same launch
+OBS_BYTES = 480            # the observation path alone
+LAST_ROW_BYTES = 518       # last_obs 480 + its legal mask 38, written once per table by the same launch (not counted)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+NBUF = 3                   # Transition buffers in rotation: 3 x 144 MB > 256 MB Infinity Cache
+KERNEL_LAUNCHES = 128      # launches between the one event pair of the kernel-only loop
+METRIC = "env-steps/sec at num_envs=8192, 32-step rollout, 1/2/4/8 MI355X"
+FAKE = os.environ.get("BRL_BENCH_FAKE") == "1"  # launcher self-test (tests/test_bench_launcher.py): gloo, no GPU, no compute
 
 
 def synthetic_lut(n: int, seed: int = 0):
@@ -73,12 +84,43 @@ def cpu_baseline(keys, values, budget_s: float = 12.0):
 
 
 def pmc_traffic():
-    """HBM bytes per rollout launch from the committed rocprofv3 --pmc summary, if any."""
+    """HBM bytes per rollout launch from the committed rocprofv3 --pmc summary (a SEPARATE run of this command:
+    counters cannot be collected inside the timed run), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        return json.load(open(path)).get("rollout_hbm_bytes_per_launch")
+        d = json.load(open(path))
+        return d.get("rollout_hbm_bytes_per_launch"), d.get("source", "profiles/pmc_traffic.json")
     except Exception:
-        return None
+        return None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torchrun starts the N ranks itself
+# ---------------------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n: int, argv) -> int:
+    """One child process per GPU (rank r -> cuda:r), rendezvous on 127.0.0.1; the parent never touches the GPU.
+    Rank 0's stdout (the ONE JSON line) is passed through; the exit code is the worst child's."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
 
 
 def main():
@@ -86,78 +128,133 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="rollout", choices=["rollout", "ppo"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    import torch
-
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))  # before anything initialises a GPU in this process
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
+        if FAKE:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif not FAKE:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", torch.cuda.current_device())
-
-    import brl_amd
-    from brl_amd.gae import gae_scan
-    from brl_amd.roll_out import alloc_transition
-
-    keys, values = synthetic_lut(LUT_LEN, 0)
-    env = brl_amd.BridgeBidding(lut=(keys, values), device=dev, env_offset=rank * NUM_ENVS)
-    cfg = {"num_steps": NUM_STEPS, "game_mode": "normal", "reward_scale": 7600, "return_last_obs": True}
-    roll = brl_amd.make_random_roll_out(cfg, env)
-    state = env.init(0, num_envs=NUM_ENVS)
-    traj = alloc_transition(NUM_STEPS, NUM_ENVS, dev)
-    last_val = torch.zeros(NUM_ENVS, dtype=torch.float32, device=dev)  # the random policy has no critic
-    rs = (None, None, state, None, 0, 0)
+    dev = torch.device("cpu") if FAKE else torch.device("cuda", torch.cuda.current_device())
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not FAKE:
+            torch.cuda.synchronize()
 
-    def one_step(rs, ev=None):
-        if ev is not None:
-            ev[0].record()
-        rs, tb = roll(rs, out=traj)
-        if ev is not None:
-            ev[1].record()
-        adv, tgt = gae_scan(env, tb.done, tb.value, tb.reward, last_val, 1.0, 0.95)
-        return rs
+    def max_over_ranks(x: float) -> float:
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    for _ in range(args.warmup):
-        rs = one_step(rs)
-    # HIP events around the rollout launch of every EV_EVERY-th timed step: an event pair costs ~6 us of stream
-    # time on this stack (scripts/graph_probe.py: 39.1 us per step without, 45.3 with a pair on every step), so
-    # bracketing every launch would measure the instrumentation.  The sampled launches are inside the timed region.
-    EV_EVERY = 8
-    events = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for i in range(0, args.steps, EV_EVERY)}
+    if args.config == "ppo":
+        out = bench_ppo(args, torch, dev, rank, world, barrier, max_over_ranks)
+    else:
+        out = bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks):
+    env_offset = rank * NUM_ENVS
+    keys, values = synthetic_lut(LUT_LEN, 0)
+    kern_ms = float("nan")
+    if FAKE:
+        def one_step(i):
+            time.sleep(0.002)
+    else:
+        import ctypes as C
+
+        import brl_amd
+        from brl_amd import _capi
+        from brl_amd.gae import gae_scan
+        from brl_amd.roll_out import alloc_transition
+
+        env = brl_amd.BridgeBidding(lut=(keys, values), device=dev, env_offset=env_offset)
+        cfg = {"num_steps": NUM_STEPS, "game_mode": "normal", "reward_scale": 7600, "return_last_obs": True}
+        roll = brl_amd.make_random_roll_out(cfg, env)
+        state = env.init(0, num_envs=NUM_ENVS)
+        trajs = [alloc_transition(NUM_STEPS, NUM_ENVS, dev) for _ in range(NBUF)]
+        last_val = torch.zeros(NUM_ENVS, dtype=torch.float32, device=dev)  # the random policy has no critic
+        box = {"rs": (None, None, state, None, 0, 0)}
+
+        def one_step(i):
+            box["rs"], tb = roll(box["rs"], out=trajs[i % NBUF])
+            gae_scan(env, tb.done, tb.value, tb.reward, last_val, 1.0, 0.95)
+
+    for i in range(args.warmup):
+        one_step(i)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        rs = one_step(rs, events.get(i))
+        one_step(i)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
-    # dominant kernel: k_rollout_random; HIP events on the launch stream, inside the timed region,
-    # bracketing exactly that one launch.
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()])) if events else float("nan")
-    alg_bytes = ROW_BYTES * NUM_ENVS * NUM_STEPS + LAST_ROW_BYTES * NUM_ENVS
+    if not FAKE:
+        # the dominant kernel alone: KERNEL_LAUNCHES launches of k_rollout_ws between ONE HIP-event pair on the
+        # launch stream (no per-launch events: a pair costs ~6 us of stream time), through the C-ABI directly
+        rs = box["rs"]
+        packed, draw = rs[2].packed, int(rs[5])
+        tc = torch.zeros(1, dtype=torch.int64, device=dev)
+        last_obs = torch.empty((NUM_ENVS, 480), dtype=torch.bool, device=dev)
+        last_mask = torch.empty((NUM_ENVS, 38), dtype=torch.bool, device=dev)
+        ptrs = []
+        for tr in trajs:
+            p = _capi.TransitionPtrs()
+            for name in _capi.TransitionPtrs._names:
+                setattr(p, name, getattr(tr, name).data_ptr())
+            ptrs.append(p)
+        stream = torch.cuda.current_stream()
+        lib, h = _capi.lib(), env._h
+
+        def launch(i):
+            _capi.check(lib.brl_rollout_random(h, packed.data_ptr(), NUM_ENVS, NUM_STEPS, 1, (draw + i * NUM_STEPS) & 0xFFFFFFFF,
+                                               7600.0, C.byref(ptrs[i % NBUF]), last_obs.data_ptr(), last_mask.data_ptr(),
+                                               tc.data_ptr(), stream.cuda_stream))
+        for i in range(8):
+            launch(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for i in range(KERNEL_LAUNCHES):
+            launch(8 + i)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        kern_ms = e0.elapsed_time(e1) / KERNEL_LAUNCHES
+
+    rows = NUM_ENVS * NUM_STEPS
+    alg_bytes = ROW_BYTES * rows                      # 535 B per macro-step row x rows per launch
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-
-    macro_steps = world * NUM_ENVS * NUM_STEPS * args.steps
+    achieved_obs = OBS_BYTES * rows / (kern_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic()
+    macro_steps = world * rows * args.steps
     out = {
-        "metric": "env-steps/sec at num_envs=8192, 32-step rollout, 1/2/4/8 MI355X",
+        "metric": METRIC,
         "value": macro_steps / elapsed,
         "unit": "env-steps/s",
         "n_gpus": world,
@@ -168,24 +265,92 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u8",
-        "data": "synthetic",
+        "data": "FAKE (launcher self-test, no compute)" if FAKE else "synthetic",
         "config": {"workload": "configs[1]: num_envs=8192 num_steps=32 random-policy rollout + DDS reward (fused "
                                "kernel) + last_obs + GAE scan", "num_envs_per_gpu": NUM_ENVS, "num_steps": NUM_STEPS,
-                   "lut_len": LUT_LEN, "env_steps_per_macro_step": 1, "tables_per_wave": os.environ.get("BRL_TABLES_PER_WAVE", "4"),
+                   "lut_len": LUT_LEN, "env_steps_per_macro_step": 1, "transition_buffers_in_rotation": NBUF,
+                   "env_offsets": [r * NUM_ENVS for r in range(world)],
                    "parallelism": f"env-shard x{world}, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
-                     "kernel": "k_rollout_ws<%s>" % os.environ.get("BRL_ROLLOUT_WS", "32x12").replace("x", ","), "kernel_ms": kern_ms, "kernel_ms_samples": len(events), "algorithmic_bytes_per_launch": alg_bytes},
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "k_rollout_ws<32,12,1>", "kernel_ms": kern_ms,
+                     "kernel_ms_method": f"{KERNEL_LAUNCHES} back-to-back launches between one HIP-event pair, "
+                                         f"{NBUF} rotating 144 MB output buffers (rank 0)",
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "obs_path": {"bytes_per_launch": OBS_BYTES * rows, "achieved": achieved_obs,
+                                  "frac": achieved_obs / HBM_PEAK_GBS},
+                     "not_counted_bytes_per_launch": LAST_ROW_BYTES * NUM_ENVS + 2 * 128 * NUM_ENVS},
     }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(keys, values)
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        out["cpu_baseline"] = cpu_baseline(keys, values) if (world == 1 and not args.no_cpu_baseline and not FAKE) else None
+    return out
+
+
+def bench_ppo(args, torch, dev, rank, world, barrier, max_over_ranks):
+    """Secondary mode (NOT the BASELINE metric): BASELINE.json configs[3] — the ppo.py iteration at num_envs=8192,
+    num_steps=32, minibatch 1024, 10 epochs with the DeepMind MLP: roll_out (4 forwards + 4 env sub-steps per macro-
+    step), calc_gae, update_step, timed per phase; GEMM throughput against the dense MFMA peaks."""
+    import brl_amd
+    from brl_amd.models import make_forward_pass
+    from brl_amd.train import DEFAULTS
+    from brl_amd.update import make_optimizer, make_update_step
+
+    cfg = dict(DEFAULTS, num_envs=NUM_ENVS, num_steps=NUM_STEPS, minibatch_size=1024, update_epochs=10,
+               inference_dtype=os.environ.get("BRL_INFER_DTYPE", "bf16"), graph_rollout=True)
+    cfg["num_minibatches"] = cfg["num_envs"] * cfg["num_steps"] // cfg["minibatch_size"]
+    keys, values = synthetic_lut(LUT_LEN, 0)
+    env = brl_amd.BridgeBidding(lut=(keys, values), device=dev, env_offset=rank * NUM_ENVS)
+    fp = make_forward_pass("relu", "DeepMind")
+    params = fp.init(0, device=dev)
+    opt_state = make_optimizer(cfg, params)
+    roll_out = brl_amd.make_roll_out(cfg, env, fp, fp)
+    calc_gae = brl_amd.make_calc_gae(cfg, fp)
+    update_step = make_update_step(cfg, fp)
+    st = env.init(0, num_envs=NUM_ENVS)
+    rs = (params, opt_state, st, st.observation, 0, 0)
+    iters = max(1, min(args.steps, 5))
+    phases = {"rollout": [], "gae": [], "update": []}
+
+    def one_iter(rs, record):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        rs, traj = roll_out(rs, rs[0])
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        adv, tgt = calc_gae(rs, traj)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        rs, _ = update_step(rs, traj, adv, tgt)
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        if record:
+            phases["rollout"].append(t1 - t0); phases["gae"].append(t2 - t1); phases["update"].append(t3 - t2)
+        return rs
+
+    rs = one_iter(rs, False)  # graph capture, hipBLASLt heuristics
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        rs = one_iter(rs, True)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    med = {k: float(np.median(v)) for k, v in phases.items()}
+    rows = NUM_ENVS * NUM_STEPS
+    fwd_flop = 2 * 3_677_184                      # SURVEY §8d: 7.354 MFLOP per forward per sample
+    roll_flop = 4 * rows * fwd_flop + NUM_ENVS * fwd_flop
+    upd_flop = 3 * rows * fwd_flop * cfg["update_epochs"]
+    return {
+        "metric": "ppo.py iteration macro-steps/sec at num_envs=8192, num_steps=32, minibatch 1024, 10 epochs (secondary, configs[3])",
+        "value": world * rows * iters / elapsed, "unit": "macro-steps/s", "n_gpus": world, "steps": iters, "warmup": 1,
+        "ms_per_step": elapsed / iters * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": f"rollout inference {cfg['inference_dtype']}, update fp32", "data": "synthetic",
+        "config": {"workload": "configs[3]: roll_out (policy in the loop, competitive) + calc_gae + update_step",
+                   "num_envs_per_gpu": NUM_ENVS, "num_steps": NUM_STEPS, "minibatch_size": 1024, "update_epochs": 10,
+                   "graph_rollout": True},
+        "phases_ms": {k: v * 1e3 for k, v in med.items()},
+        "rollout": {"macro_steps_per_s": rows / med["rollout"], "raw_env_steps_per_s": 4 * rows / med["rollout"],
+                    "gemm_tflops": roll_flop / med["rollout"] / 1e12,
+                    "mfma_peak_tflops": 2500.0 if cfg["inference_dtype"] in ("bf16", "fp16") else 157.3},
+        "update": {"gemm_tflops": upd_flop / med["update"] / 1e12, "mfma_peak_tflops": 157.3,
+                   "note": "fp32 GEMMs (fwd + 2x bwd), 2560 minibatch steps of 1024 samples, hipGraph-replayed"},
+    }
 
 
 if __name__ == "__main__":

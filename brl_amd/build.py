@@ -8,7 +8,16 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG, "csrc", "brl_kernels.hip")
-DEPS = [SRC, os.path.join(PKG, "csrc", "bridge_device.hpp"), os.path.join(os.path.dirname(PKG), "include", "brl_hip.h")]
+INCLUDE = os.path.join(os.path.dirname(PKG), "include")
+
+
+def deps():
+    """every source the library is built from: csrc/*.hip, csrc/*.hpp, include/*.h"""
+    import glob
+    return sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.hpp"))
+                  + glob.glob(os.path.join(INCLUDE, "*.h")))
+
+
 OUT = os.path.join(PKG, "lib", "libbrl_hip.so")
 
 # -ffp-contract=off: GAE / reward arithmetic must round like the scalar oracle (no FMA fusion)
@@ -26,7 +35,7 @@ def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in deps())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

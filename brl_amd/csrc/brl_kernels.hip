@@ -1018,10 +1018,16 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   }
 }
 
-#include "rollout_common.hpp"
-#include "rollout_pipe.hpp"
-
 // ---- policy sub-step: masked categorical over logits + auto_reset(step) -------------------
+// What brl_set_rng / brl_set_lut change, mirrored in device memory: the policy sub-step reads it from there instead
+// of taking it by value, so that a hipGraph replay of a captured launch follows a later re-seed or LUT rotation
+// (ppo.py:525-549) instead of reading freed tables / a stale key.
+struct DevCtx {
+  LutRef lut;
+  Rng g;
+  uint64_t env_offset;
+};
+
 struct PolicyArgs {
   const uint64_t *state_in;
   uint64_t *state_out;
@@ -1032,82 +1038,120 @@ struct PolicyArgs {
   uint32_t draw;
   const uint32_t *draw_dev;  // optional: the draw index is draw + *draw_dev (hipGraph-captured loops)
   int autoreset;
-  Rng g;
-  uint64_t env_offset;
-  LutRef lut;
+  const DevCtx *ctx;  // device-resident (see DevCtx)
   int32_t *action;
   float *log_prob;
   StepOut o;  // o.rewards / o.terminated are ACCUMULATED
 };
 
+// Masked categorical of one table on the 64 / K lanes that share it (lane l: table l % K, slot l / K): slot s holds the
+// NI consecutive actions [s * NI, s * NI + NI).  Returns the chosen action and its log-probability on every lane of the
+// table.  `cand`: the actions the distribution ranges over — the legal ones (masked policy, src/roll_out.py:27-29) or
+// all 38 (unmasked / illegal-action-penalty policy, src/roll_out.py:33-39).
+//   mode bit 0: 0 = pi.sample (inverse CDF in action order with the 24-bit uniform of `u32`), 1 = pi.mode (first max)
 template <int K>
-__global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES_PER_BLOCK * K * TABLE_BYTES];
-  __shared__ float llds[WAVES_PER_BLOCK * K * BRL_NUM_ACTIONS];
-  __shared__ float elds[WAVES_PER_BLOCK * K * BRL_NUM_ACTIONS];
-  Tbl t;
-  Wave<K> w = wave_begin<K>(lds, A.state_in, A.n, t);
-  // stage the wave's K x 38 logits (contiguous in [n,38]) through LDS, coalesced
-  float *wl = llds + (threadIdx.x >> 6) * K * BRL_NUM_ACTIONS;
-  for (int i = w.c.lane; i < K * BRL_NUM_ACTIONS; i += 64) {
-    int64_t tb = w.table0 + i / BRL_NUM_ACTIONS;
-    wl[i] = (tb < A.n) ? A.logits[tb * A.logits_stride + (i - (i / BRL_NUM_ACTIONS) * BRL_NUM_ACTIONS)] : 0.0f;
-  }
-  wave_lds_fence();
-  const float *lg = wl + w.tl * BRL_NUM_ACTIONS;
-  uint64_t legal = legal_mask(t);
-  // masked categorical: illegal actions get probability 0, legal logits unchanged
-  // (src/roll_out.py:27-29).  log-softmax over the legal set, sequential fp32.
+__device__ __forceinline__ int categorical(const float *logits_row, bool valid, uint64_t cand, int mode, uint32_t u32,
+                                           int lane, float &log_prob) {
+  constexpr int LPT = 64 / K;
+  constexpr int NI = (BRL_NUM_ACTIONS + LPT - 1) / LPT;
+  const int tl = lane % K, slot = lane / K;
+  float lg[NI], e[NI];
+  bool ok[NI];
   float mx = -INFINITY;
-  int amax = 0;
-  for (int a = 0; a < BRL_NUM_ACTIONS; a++) {
-    bool ok = (legal >> a) & 1ull;
-    float v = lg[a];
-    if (ok && v > mx) {  // first maximum wins, like argmax
-      mx = v;
+  int amax = 64;
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+    const int a = slot * NI + i;
+    const bool in = a < BRL_NUM_ACTIONS;
+    lg[i] = (in && valid) ? logits_row[a] : 0.0f;
+    ok[i] = in && ((cand >> (a & 63)) & 1ull);
+    if (ok[i] && lg[i] > mx) {  // first maximum wins, like argmax
+      mx = lg[i];
       amax = a;
     }
   }
-  // exp(logit - max) of every action ONCE, spread over the 64 / K lanes that share the table; the sums below
-  // then run sequentially in action order on every lane (same fp32 rounding as the scalar oracle)
-  float *ew = elds + ((threadIdx.x >> 6) * K + w.tl) * BRL_NUM_ACTIONS;
-  for (int a = w.c.lane / K; a < BRL_NUM_ACTIONS; a += 64 / K) ew[a] = expf(lg[a] - mx);
-  wave_lds_fence();
-  float sum = 0.0f;
-  for (int a = 0; a < BRL_NUM_ACTIONS; a++)
-    if ((legal >> a) & 1ull) sum += ew[a];
+#pragma unroll
+  for (int off = K; off < 64; off <<= 1) {
+    const float omx = __shfl_xor(mx, off, 64);
+    const int oam = __shfl_xor(amax, off, 64);
+    const bool take = (omx > mx) || (omx == mx && oam < amax);
+    mx = take ? omx : mx;
+    amax = take ? oam : amax;
+  }
+  amax = (amax >= BRL_NUM_ACTIONS) ? 0 : amax;  // (no finite candidate logit: NaN / -inf everywhere)
+  float own = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+    e[i] = ok[i] ? expf(lg[i] - mx) : 0.0f;
+    own += e[i];
+  }
+  // inclusive scan of the slots' sums in action order
+  float incl = own;
+#pragma unroll
+  for (int off = 1; off < LPT; off <<= 1) {
+    const float v = __shfl_up(incl, off * K, 64);
+    incl += (slot >= off) ? v : 0.0f;
+  }
+  const float total = __shfl(incl, (LPT - 1) * K + tl, 64);
+  float excl = __shfl_up(incl, K, 64);
+  excl = (slot == 0) ? 0.0f : excl;
   int act = amax;
-  if (A.mode == 0) {
-    uint32_t r[4];
-    uint64_t env_id = A.env_offset + (uint64_t)w.table;
-    const uint32_t draw = A.draw + (A.draw_dev ? *A.draw_dev : 0u);
-    philox4x32_10((uint32_t)env_id, draw >> 2, STREAM_ACTION, (uint32_t)(env_id >> 32), A.g.k0, A.g.k1, r);
-    uint32_t sel = draw & 3u;
-    uint32_t u32 = (sel == 0) ? r[0] : ((sel == 1) ? r[1] : ((sel == 2) ? r[2] : r[3]));
-    float target = (float)(u32 >> 8) * (1.0f / 16777216.0f) * sum;  // inverse CDF, u in [0,1)
-    float cum = 0.0f;
-    int last = 0;
-    bool found = false;
-    for (int a = 0; a < BRL_NUM_ACTIONS; a++) {
-      if ((legal >> a) & 1ull) {
-        cum += ew[a];
-        last = a;
-        if (!found && cum > target) {
-          act = a;
-          found = true;
-        }
+  if (!(mode & 1)) {
+    const float target = (float)(u32 >> 8) * (1.0f / 16777216.0f) * total;  // inverse CDF, u in [0,1)
+    float cum = excl;
+    int first = 64, last = -1;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      cum += e[i];
+      if (ok[i]) {
+        last = slot * NI + i;
+        first = (first == 64 && cum > target) ? slot * NI + i : first;
       }
     }
-    if (!found) act = last;
+#pragma unroll
+    for (int off = K; off < 64; off <<= 1) {
+      first = min(first, __shfl_xor(first, off, 64));
+      last = max(last, __shfl_xor(last, off, 64));
+    }
+    act = (first < 64) ? first : max(last, 0);
   }
-  float lp = (lg[act] - mx) - logf(sum);
+  // the chosen action's logit lives on slot act / NI
+  const int ai = act % NI;
+  float sel = lg[0];
+#pragma unroll
+  for (int i = 1; i < NI; i++) sel = (ai == i) ? lg[i] : sel;
+  const float la = __shfl(sel, (act / NI) * K + tl, 64);
+  log_prob = (la - mx) - logf(total);
+  return act;
+}
+
+template <int K>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES_PER_BLOCK * K * TABLE_BYTES];
+  Tbl t;
+  Wave<K> w = wave_begin<K>(lds, A.state_in, A.n, t);
+  const DevCtx cx = *A.ctx;
+  const uint64_t legal = legal_mask(t);
+  const uint64_t cand = (A.mode & 2) ? ALL_ACTIONS : legal;  // bit 1: the unmasked policy
+  uint32_t u32 = 0;
+  if (!(A.mode & 1)) {
+    uint32_t r[4];
+    const uint64_t env_id = cx.env_offset + (uint64_t)w.table;
+    const uint32_t draw = A.draw + (A.draw_dev ? *A.draw_dev : 0u);
+    philox4x32_10((uint32_t)env_id, draw >> 2, STREAM_ACTION, (uint32_t)(env_id >> 32), cx.g.k0, cx.g.k1, r);
+    const uint32_t sel = draw & 3u;
+    u32 = (sel == 0) ? r[0] : ((sel == 1) ? r[1] : ((sel == 2) ? r[2] : r[3]));
+  }
+  float lp;
+  const int act = categorical<K>(A.logits + (w.valid ? w.table : 0) * A.logits_stride, w.valid, cand, A.mode, u32,
+                                 w.c.lane, lp);
   if (A.autoreset) auto_reset_clear(t);
   int hb = table_step(t, act);
   wave_or_hist<K>(w, hb);
   wave_lds_fence();
   uint32_t term = bits(t.sc, SC_TERM, 1);
   float4 rw = rewards_f32(t);
-  if (A.autoreset) wave_reset<K>(w, t, w.valid && term, A.g, A.env_offset, A.lut, t.bctr + 1u);
+  if (A.autoreset) wave_reset<K>(w, t, w.valid && term, cx.g, cx.env_offset, cx.lut, t.bctr + 1u);
   int oseat = cur_seat(t);
   wave_emit<K>(w, A.n, oseat, vul_nibble(t, oseat), legal_mask(t), A.o.obs, A.o.mask, w.table0);
   if (w.c.lane < K && w.valid) {
@@ -1301,10 +1345,9 @@ struct brl_handle {
   float *neg_log_n;
   uint64_t seed;
   uint64_t env_offset;
+  DevCtx *ctx_dev;  // device mirror of (LUT, seed, env_offset), read by the policy sub-step
   int tables_per_wave;
-  int ws_tpb;  // tables per workgroup of the wave-specialised rollout, 0 = use the K-tables-per-wave kernel
-  int ws_nw;   // waves per workgroup (1 logic + ws_nw-1 emit)
-  int pipe;    // NP > 0: k_rollout_pipe with NP prep waves (BRL_ROLLOUT_PIPE)
+  int ws;  // 1: wave-specialised fused rollout k_rollout_ws<32,12,1> (default); 0: k_rollout_random<K> (BRL_ROLLOUT_WS=0)
 };
 
 static thread_local char g_err[512] = "";
@@ -1328,28 +1371,42 @@ static int fail(int code, const char *fmt, const char *detail) {
 extern "C" const char *brl_last_error(void) { return g_err; }
 extern "C" int brl_version(void) { return 1; }
 
+static inline Rng rng_of(const brl_handle *h) { return Rng{(uint32_t)h->seed, (uint32_t)(h->seed >> 32)}; }
+static inline LutRef lut_of(const brl_handle *h) { return LutRef{h->lut_keys, h->lut_values, (uint32_t)h->lut_len, h->lut_hands}; }
+
+// Refresh the device mirror.  Callers have synchronised the device: nothing in flight reads the old contents.
+static int sync_ctx(brl_handle *h) {
+  DevCtx c{lut_of(h), rng_of(h), h->env_offset};
+  HIP_TRY(hipMemcpy(h->ctx_dev, &c, sizeof(c), hipMemcpyHostToDevice));
+  return BRL_OK;
+}
+
 static int upload_lut(brl_handle *h, const int32_t *keys, const int32_t *values, int64_t len) {
-  if (h->lut_keys) HIP_TRY(hipFree(h->lut_keys));
-  if (h->lut_values) HIP_TRY(hipFree(h->lut_values));
-  if (h->lut_hands) HIP_TRY(hipFree(h->lut_hands));
-  h->lut_keys = nullptr;
-  h->lut_values = nullptr;
-  h->lut_hands = nullptr;
-  h->lut_len = 0;
+  if (len != h->lut_len) {  // same-size rotation (ppo.py:128: every file holds hash_size rows) reuses the allocations
+    if (h->lut_keys) HIP_TRY(hipFree(h->lut_keys));
+    if (h->lut_values) HIP_TRY(hipFree(h->lut_values));
+    if (h->lut_hands) HIP_TRY(hipFree(h->lut_hands));
+    h->lut_keys = nullptr;
+    h->lut_values = nullptr;
+    h->lut_hands = nullptr;
+    h->lut_len = 0;
+  }
   if (len > 0) {
     NEED(keys && values, "lut_keys / lut_values are NULL with lut_len > 0");
     NEED(len < (1ll << 32), "lut_len must be < 2^32");
-    HIP_TRY(hipMalloc(&h->lut_keys, (size_t)len * 16));
-    HIP_TRY(hipMalloc(&h->lut_values, (size_t)len * 16));
+    if (!h->lut_keys) {
+      HIP_TRY(hipMalloc(&h->lut_keys, (size_t)len * 16));
+      HIP_TRY(hipMalloc(&h->lut_values, (size_t)len * 16));
+      HIP_TRY(hipMalloc(&h->lut_hands, (size_t)len * 32));
+    }
     HIP_TRY(hipMemcpy(h->lut_keys, keys, (size_t)len * 16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->lut_values, values, (size_t)len * 16, hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&h->lut_hands, (size_t)len * 32));
     hipLaunchKernelGGL(k_lut_hands, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, 0, h->lut_keys, h->lut_hands, len);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     h->lut_len = len;
   }
-  return BRL_OK;
+  return sync_ctx(h);
 }
 
 extern "C" int brl_create(int device, const int32_t *lut_keys, const int32_t *lut_values, int64_t lut_len,
@@ -1366,24 +1423,15 @@ extern "C" int brl_create(int device, const int32_t *lut_keys, const int32_t *lu
     int k = atoi(env);
     if (k == 1 || k == 2 || k == 4 || k == 8) h->tables_per_wave = k;
   }
-  h->ws_tpb = 32;
-  h->ws_nw = 12;  // 32x12 = logic, loader, scorer, 8 emit waves, mask wave
-  h->pipe = getenv("BRL_ROLLOUT_PIPE") ? atoi(getenv("BRL_ROLLOUT_PIPE")) : 0;
-  const char *ws = getenv("BRL_ROLLOUT_WS");  // "TPBxNW" (16x5 16x7 32x5 32x7 32x8 32x11 32x12) or "0"
-  if (ws) {
-    int a = 0, b = 0;
-    if (sscanf(ws, "%dx%d", &a, &b) == 2) {
-      h->ws_tpb = a;
-      h->ws_nw = b;
-    } else if (atoi(ws) == 0) {
-      h->ws_tpb = 0;
-    }
-  }
+  h->ws = 1;
+  const char *ws = getenv("BRL_ROLLOUT_WS");  // "0": the K-tables-per-wave fused rollout (A/B baseline)
+  if (ws && ws[0] == '0' && ws[1] == 0) h->ws = 0;
   float tab[BRL_NUM_ACTIONS + 1];
   tab[0] = 0.0f;
   for (int i = 1; i <= BRL_NUM_ACTIONS; i++) tab[i] = (float)(-log((double)i));
   hipError_t e = hipMalloc(&h->neg_log_n, sizeof(tab));
   if (e == hipSuccess) e = hipMemcpy(h->neg_log_n, tab, sizeof(tab), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&h->ctx_dev, sizeof(DevCtx));
   if (e != hipSuccess) {
     free(h);
     return fail(BRL_E_HIP, "brl_create: %s", hipGetErrorString(e));
@@ -1391,6 +1439,7 @@ extern "C" int brl_create(int device, const int32_t *lut_keys, const int32_t *lu
   int rc = upload_lut(h, lut_keys, lut_values, lut_len);
   if (rc != BRL_OK) {
     (void)hipFree(h->neg_log_n);
+    (void)hipFree(h->ctx_dev);
     free(h);
     return rc;
   }
@@ -1413,19 +1462,21 @@ extern "C" int brl_destroy(brl_handle *h) {
   if (h->lut_values) (void)hipFree(h->lut_values);
   if (h->lut_hands) (void)hipFree(h->lut_hands);
   if (h->neg_log_n) (void)hipFree(h->neg_log_n);
+  if (h->ctx_dev) (void)hipFree(h->ctx_dev);
   free(h);
   return BRL_OK;
 }
 
 extern "C" int brl_set_rng(brl_handle *h, uint64_t seed, uint64_t env_offset) {
   NEED(h != nullptr, "handle");
+  if (seed == h->seed && env_offset == h->env_offset) return BRL_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());  // launches in flight (and captured graphs being replayed) may still read the old key
   h->seed = seed;
   h->env_offset = env_offset;
-  return BRL_OK;
+  return sync_ctx(h);
 }
 
-static inline Rng rng_of(const brl_handle *h) { return Rng{(uint32_t)h->seed, (uint32_t)(h->seed >> 32)}; }
-static inline LutRef lut_of(const brl_handle *h) { return LutRef{h->lut_keys, h->lut_values, (uint32_t)h->lut_len, h->lut_hands}; }
 static inline unsigned wave_grid(int64_t n, int K) {
   int64_t per_block = (int64_t)WAVES_PER_BLOCK * K;
   return (unsigned)((n + per_block - 1) / per_block);
@@ -1514,36 +1565,14 @@ extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int
 #else
   A.debug = 0;
 #endif
-#define LAUNCH_WS(TPB, NW)                                                                             \
-  hipLaunchKernelGGL((k_rollout_ws<TPB, NW>), dim3((unsigned)((n + TPB - 1) / TPB)), dim3(NW * 64), 0, \
-                     (hipStream_t)stream, A)
-  const int cfg = (substeps <= WS_BATCH) ? h->ws_tpb * 100 + h->ws_nw : 0;  // a macro-step spans <= 2 command batches
-#define LAUNCH_PIPE(TPB, NW, NP)                                                                             \
-  hipLaunchKernelGGL((k_rollout_pipe<TPB, NW, NP>), dim3((unsigned)((n + TPB - 1) / TPB)), dim3(NW * 64), 0, \
-                     (hipStream_t)stream, A)
-  if (h->pipe && cfg == 3211) {
-    switch (h->pipe) {
-      case 1: LAUNCH_PIPE(32, 12, 1); break;
-      case 3: LAUNCH_PIPE(32, 14, 3); break;
-      default: LAUNCH_PIPE(32, 13, 2); break;
-    }
-    HIP_TRY(hipGetLastError());
+  // the wave-specialised kernel serves a macro-step that spans <= 2 command batches; longer ones (and BRL_ROLLOUT_WS=0)
+  // take the K-tables-per-wave kernel
+  if (h->ws && substeps <= WS_BATCH) {
+    hipLaunchKernelGGL((k_rollout_ws<32, 12, 1>), dim3((unsigned)((n + 31) / 32)), dim3(12 * 64), 0, (hipStream_t)stream, A);
+  } else {
+    LAUNCH_K(h, k_rollout_random, n, stream, A);
     return BRL_OK;
   }
-#undef LAUNCH_PIPE
-  switch (cfg) {
-    case 1605: LAUNCH_WS(16, 5); break;
-    case 1607: LAUNCH_WS(16, 7); break;
-    case 3205: LAUNCH_WS(32, 5); break;
-    case 3207: LAUNCH_WS(32, 7); break;
-    case 3208: LAUNCH_WS(32, 8); break;
-    case 3211: LAUNCH_WS(32, 11); break;
-    case 3212: hipLaunchKernelGGL((k_rollout_ws<32, 12, 1>), dim3((unsigned)((n + 31) / 32)), dim3(12 * 64), 0, (hipStream_t)stream, A); break;
-    case 6407: LAUNCH_WS(64, 7); break;
-    case 6411: LAUNCH_WS(64, 11); break;
-    default: LAUNCH_K(h, k_rollout_random, n, stream, A); return BRL_OK;
-  }
-#undef LAUNCH_WS
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }
@@ -1555,14 +1584,14 @@ static int policy_step_impl(brl_handle *h, const uint64_t *state_in, uint64_t *s
                             uint8_t *terminated_acc, int32_t *current_player, void *stream) {
   COMMON(h, n);
   NEED(state_in && state_out && logits, "NULL state / logits");
-  NEED(mode == 0 || mode == 1, "mode");
+  NEED(mode >= 0 && mode <= 3, "mode");
   NEED(logits_stride >= BRL_NUM_ACTIONS, "logits_stride");
   if (autoreset && h->lut_len == 0) return fail(BRL_E_NOLUT, "auto-reset needs a LUT%s", "");
   PolicyArgs A;
   A.state_in = state_in; A.state_out = state_out; A.n = n; A.logits = logits; A.mode = mode; A.draw = draw;
   A.logits_stride = logits_stride;
   A.draw_dev = draw_dev;
-  A.autoreset = autoreset; A.g = rng_of(h); A.env_offset = h->env_offset; A.lut = lut_of(h);
+  A.autoreset = autoreset; A.ctx = h->ctx_dev;
   A.action = action; A.log_prob = log_prob;
   A.o = StepOut{obs, mask, rewards_acc, terminated_acc, current_player};
   LAUNCH_K(h, k_policy_step, n, stream, A);

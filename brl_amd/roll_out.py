@@ -18,7 +18,7 @@ from . import _capi
 from ._capi import NUM_ACTIONS, OBS_SIZE, check, ptr
 from .bridge_bidding import BridgeBidding, State, _stream
 from .models import InferenceSnapshot
-from .utils import MODE, SAMPLE, _pass_logits, policy_step
+from .utils import MODE, SAMPLE, UNMASKED, _pass_logits, policy_step
 
 
 class Transition(NamedTuple):  # src/roll_out.py:13-20 ; all time-major [T,N,...]
@@ -73,55 +73,102 @@ def make_random_roll_out(config, env: BridgeBidding):
     return roll_out
 
 
-class _GraphedRollout:
-    """The competitive policy-in-the-loop rollout with every macro-step captured ONCE in a hipGraph and replayed
-    (opt-in, config["graph_rollout"]): the eager loop issues ~50 launches per macro-step and, with low-precision
-    inference, is bound by the host's launch rate, not by the GPU.  One graph per scan step t (they differ only in the
-    Transition rows they read and write), all sharing one memory pool.  Differences from the eager path that a caller
-    can see: the returned Transition buffers are REUSED by the next call (consume them first — the PPO loop does),
-    and the action-draw index lives in device memory (``brl_policy_step_at``).  Same outputs, bit for bit, as the
-    eager path with the same inference dtype."""
+class _PolicyRollout:
+    """``_env_step`` (src/roll_out.py:63-103) with torch MLPs in the loop — ONE implementation for the eager scan and
+    for the hipGraph scan (config["graph_rollout"]: every macro-step captured once and replayed; the eager loop issues
+    ~50 launches per macro-step and, with low-precision inference, is bound by the host's launch rate).
 
-    def __init__(self, env, n, T, reward_scale, infer_dtype, actor, opp):
+    Per macro-step: actor forward -> ``brl_policy_step_at`` (sample, log_prob, auto_reset(step)) -> 3 x (forward of the
+    network whose turn it is -> ``brl_policy_step_at``) with rewards summed and ``terminated`` OR-ed on the device
+    (src/utils.py:69-128).  The action-draw index lives in device memory in both modes.  In graph mode the Transition
+    buffers are static and REUSED by the next call (consume them first — the PPO loop does); the captured launches read
+    the handle's RNG key / LUT through the library's device-resident context, so ``env.seed`` / ``env.set_lut`` between
+    calls are followed by the replays.  ``sub_actions`` [T,3,n] keeps the actions of sub-steps 2-4 (tests replay the
+    whole rollout through the oracle)."""
+
+    def __init__(self, env, n, T, reward_scale, game_mode, masked, infer_dtype, actor_fp, opp_fp, static):
         self.env, self.n, self.T, self.reward_scale = env, n, T, reward_scale
+        self.game_mode, self.masked, self.infer_dtype, self.static = game_mode, masked, infer_dtype, static
+        self.actor_fp, self.opp_fp = actor_fp, opp_fp
+        self.graphs = None
+        self.snap_actor = self.snap_opp = None
+        if static:
+            self._alloc()
+
+    def _alloc(self):
+        env, n, T = self.env, self.n, self.T
         dev = env.device
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)  # noqa: E731
         self.traj = alloc_transition(T, n, dev)
-        self.packed = torch.empty((n, 16), dtype=torch.int64, device=dev)
-        self.cur = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(2)]
-        self.scratch_obs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=dev)
-        self.final_obs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=dev)
-        self.final_mask = torch.empty((n, NUM_ACTIONS), dtype=torch.bool, device=dev)
-        self.racc = torch.empty((n, 4), dtype=torch.float32, device=dev)
-        self.tacc = torch.empty(n, dtype=torch.bool, device=dev)
+        self.packed = e((n, 16), torch.int64)
+        self.cur = [e(n, torch.int32) for _ in range(2)]
+        self.scratch_obs = e((n, OBS_SIZE), torch.bool)
+        self.final_obs = e((n, OBS_SIZE), torch.bool)
+        self.final_mask = e((n, NUM_ACTIONS), torch.bool)
+        self.racc = e((n, 4), torch.float32)
+        self.tacc = e(n, torch.bool)
+        self.sub_actions = e((T, 3, n), torch.int32)
         self.draw = torch.zeros(1, dtype=torch.int32, device=dev)
         self.tc = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.snap_actor = InferenceSnapshot.make(actor, infer_dtype, env)
-        self.snap_opp = InferenceSnapshot.make(opp, infer_dtype, env)
-        self.graphs = None
 
+    # ---- the networks -------------------------------------------------------------------------------------------
+    def _bind(self, params, opp_params):
+        """(Re)build the inference views of the two networks for this call."""
+        if self.static:
+            if self.snap_actor is None:
+                self.snap_actor = InferenceSnapshot.make(params, self.infer_dtype, self.env)
+                self.snap_opp = InferenceSnapshot.make(opp_params, self.infer_dtype, self.env)
+            else:  # weights are re-read INTO the tensors whose addresses the graphs hold
+                self.snap_actor.refresh(params)
+                self.snap_opp.refresh(opp_params)
+        else:  # eager: host-bound, torch's own cast launches faster than brl_obs_cast
+            self.snap_actor = InferenceSnapshot.make(params, self.infer_dtype)
+            self.snap_opp = self.snap_actor if opp_params is params else InferenceSnapshot.make(opp_params, self.infer_dtype)
+        self.params, self.opp_params = params, opp_params
+
+    def _forward(self, is_opp, obs_bool):
+        snap = self.snap_opp if is_opp else self.snap_actor
+        if snap is not None:  # "DeepMind" ReLU MLP: fused epilogues, merged heads (fp32 by default)
+            return snap(obs_bool)
+        fp, pr = (self.opp_fp, self.opp_params) if is_opp else (self.actor_fp, self.params)
+        if self.infer_dtype is None:
+            return fp.apply(pr, obs_bool.to(torch.float32))
+        with torch.autocast("cuda", dtype=self.infer_dtype):
+            lg, v = fp.apply(pr, obs_bool.to(self.infer_dtype))
+        return lg.float(), v.float()
+
+    # ---- one scan step ------------------------------------------------------------------------------------------
     def _macro_step(self, t):
         env, traj, packed, cur = self.env, self.traj, self.packed, self.cur
         racc, tacc, T = self.racc, self.tacc, self.T
-        actor = cur[t & 1]  # src/roll_out.py:72
-        logits, value = self.snap_actor(traj.obs[t])  # :73-76
+        competitive = self.game_mode == "competitive"
+        actor = cur[t & 1]                                              # src/roll_out.py:72
+        logits, value = self._forward(False, traj.obs[t])               # :73-76
         traj.value[t].copy_(value)
         racc.zero_()
         tacc.zero_()
-        policy_step(env, packed, packed, logits, SAMPLE, 0, True, action=traj.action[t], log_prob=traj.log_prob[t],
-                    obs=self.scratch_obs, rewards_acc=racc, terminated_acc=tacc, draw_base=self.draw)
+        # sub-step 1: the actor samples from the (un)masked Categorical (src/roll_out.py:27-39,79-84)
+        policy_step(env, packed, packed, logits, SAMPLE if self.masked else SAMPLE | UNMASKED, 0, True,
+                    action=traj.action[t], log_prob=traj.log_prob[t], obs=self.scratch_obs, rewards_acc=racc,
+                    terminated_acc=tacc, draw_base=self.draw)
         last = t + 1 == T
         obs_out = self.final_obs if last else traj.obs[t + 1]
         mask_out = self.final_mask if last else traj.legal_action_mask[t + 1]
-        for k in (1, 2, 3):  # opp, partner (actor params), opp — src/utils.py:78-120
-            lg, _ = (self.snap_opp if k != 2 else self.snap_actor)(self.scratch_obs)
+        for k in (1, 2, 3):  # opp, partner (actor params), opp — src/utils.py:78-120; always masked
+            is_opp = k != 2
+            if not competitive and is_opp:                              # free-run: opponents pass (src/utils.py:205-246)
+                lg, m = _pass_logits(env, self.n), MODE
+            else:
+                lg, _ = self._forward(is_opp, self.scratch_obs)
+                m = SAMPLE if competitive else MODE
             fin = k == 3
-            policy_step(env, packed, packed, lg, SAMPLE, k, True, obs=obs_out if fin else self.scratch_obs,
-                        mask=mask_out if fin else None, rewards_acc=racc, terminated_acc=tacc,
-                        current_player=cur[(t + 1) & 1] if fin else None, draw_base=self.draw)
+            policy_step(env, packed, packed, lg, m, k, True, action=self.sub_actions[t, k - 1],
+                        obs=obs_out if fin else self.scratch_obs, mask=mask_out if fin else None, rewards_acc=racc,
+                        terminated_acc=tacc, current_player=cur[(t + 1) & 1] if fin else None, draw_base=self.draw)
         self.draw.add_(4)
-        traj.done[t].copy_(tacc)  # G2
-        traj.reward[t].copy_(racc.gather(1, actor.to(torch.int64)[:, None])[:, 0] / self.reward_scale)  # G1
-        self.tc.add_(tacc.sum())
+        traj.done[t].copy_(tacc)                                                                          # G2
+        traj.reward[t].copy_(racc.gather(1, actor.to(torch.int64)[:, None])[:, 0] / self.reward_scale)    # G1, :90
+        self.tc.add_(tacc.sum())                                                                          # :85
 
     def _capture(self):
         # warm-up on a side stream (allocator, hipBLASLt heuristics), then one capture per scan step
@@ -140,39 +187,50 @@ class _GraphedRollout:
                     self._macro_step(t)
                 self.graphs.append(g)
 
+    def _load(self, env_state, last_obs, terminated_count, rng):
+        traj = self.traj
+        self.packed.copy_(env_state.packed)  # the caller's env_state stays valid, like a JAX pytree
+        self.cur[0].copy_(env_state.current_player)
+        traj.obs[0].copy_(env_state.observation if last_obs is None else last_obs)
+        traj.legal_action_mask[0].copy_(env_state.legal_action_mask)
+        self.tc.copy_(_count_tensor(terminated_count, self.env.device))
+        self.draw.fill_(int(rng) & 0x7FFFFFFF)
+
     def run(self, runner_state, opp_params):
         params, opt_state, env_state, last_obs, terminated_count, rng = runner_state
-        env, n, T, traj = self.env, self.n, self.T, self.traj
+        T = self.T
         with torch.no_grad():
-            if self.graphs is None:
-                self.packed.copy_(env_state.packed)
-                self.cur[0].copy_(env_state.current_player)
-                traj.obs[0].copy_(env_state.observation if last_obs is None else last_obs)
+            if not self.static:
+                self._alloc()  # the returned Transition belongs to the caller
+            self._bind(params, opp_params)
+            if self.static and self.graphs is None:
+                self._load(env_state, last_obs, terminated_count, rng)
                 self._capture()
-            self.snap_actor.refresh(params)
-            self.snap_opp.refresh(opp_params)
-            self.packed.copy_(env_state.packed)
-            self.cur[0].copy_(env_state.current_player)
-            traj.obs[0].copy_(env_state.observation if last_obs is None else last_obs)
-            traj.legal_action_mask[0].copy_(env_state.legal_action_mask)
-            self.tc.copy_(_count_tensor(terminated_count, env.device))
-            self.draw.fill_(int(rng) & 0x7FFFFFFF)
-            for g in self.graphs:
-                g.replay()
-            packed = self.packed.clone()  # the returned state owns its tables; the static buffers are reused
-            final_obs, final_mask = self.final_obs.clone(), self.final_mask.clone()
-            new_state = State(env, packed, {"observation": final_obs, "legal_action_mask": final_mask,
-                                            "current_player": self.cur[T & 1].clone()})
-            new_state = new_state.replace(rewards=self.racc.clone(), terminated=self.tacc.clone())  # src/utils.py:128
-        return (params, opt_state, new_state, new_state.observation, self.tc.clone(), int(rng) + 4 * T), traj
+            self._load(env_state, last_obs, terminated_count, rng)
+            if self.static:
+                for g in self.graphs:
+                    g.replay()
+            else:
+                for t in range(T):
+                    self._macro_step(t)
+            own = (lambda x: x.clone()) if self.static else (lambda x: x)  # static buffers are reused by the next call
+            new_state = State(self.env, own(self.packed), {"observation": own(self.final_obs),
+                                                           "legal_action_mask": own(self.final_mask),
+                                                           "current_player": own(self.cur[T & 1])})
+            new_state = new_state.replace(rewards=own(self.racc), terminated=own(self.tacc))  # src/utils.py:128
+        return (params, opt_state, new_state, new_state.observation, own(self.tc), int(rng) + 4 * T), self.traj
 
 
 def make_roll_out(config, env: BridgeBidding, actor_forward_pass, opp_forward_pass):
     """``make_roll_out(config, env, actor_forward_pass, opp_forward_pass)`` (src/roll_out.py:23).
     Returns ``roll_out(runner_state, opp_params) -> (runner_state, traj_batch)`` (src/roll_out.py:49).
-    Only the masked policy (config["actor_illegal_action_mask"]) is on the hot path."""
-    if not config.get("actor_illegal_action_mask", True):
-        raise NotImplementedError("the unmasked / illegal-action-penalty policy is outside the hot path")
+    ``config["actor_illegal_action_mask"]`` selects the masked policy, otherwise
+    ``config["actor_illegal_action_penalty"]`` the unmasked one (src/roll_out.py:24-39: the actor may then draw an
+    illegal call, which ends the board with pgx's penalty rewards).  After a call, ``roll_out.sub_actions`` holds the
+    [T,3,n] actions of sub-steps 2-4."""
+    masked = bool(config.get("actor_illegal_action_mask", True))
+    if not masked and not config.get("actor_illegal_action_penalty", False):
+        raise ValueError("set actor_illegal_action_mask or actor_illegal_action_penalty (src/roll_out.py:24-39)")
     T = int(config["num_steps"])
     reward_scale = float(config["reward_scale"])
     mode = config.get("game_mode", "competitive")
@@ -182,78 +240,21 @@ def make_roll_out(config, env: BridgeBidding, actor_forward_pass, opp_forward_pa
     # fp32 like the reference; with bf16 the stored log_prob/value differ from the fp32 recomputation
     # in the PPO ratio by bf16 rounding (SURVEY §7 "Hard parts") — opt-in, never the default.
     infer_dtype = {None: None, "fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}[config.get("inference_dtype")]
-
-    snapshots = {}  # id(params) -> InferenceSnapshot (or None), rebuilt on every roll_out call
-
-    def forward(fp, pr, obs_bool):
-        snap = snapshots.get(id(pr), False)
-        if snap is False:
-            snap = snapshots[id(pr)] = InferenceSnapshot.make(pr, infer_dtype)  # (eager: host-bound, torch's cast launches faster)
-        if snap is not None:  # "DeepMind" ReLU MLP: fused epilogues, merged heads (fp32 by default)
-            return snap(obs_bool)
-        if infer_dtype is None:
-            return fp.apply(pr, obs_bool.to(torch.float32))
-        with torch.autocast("cuda", dtype=infer_dtype):
-            lg, v = fp.apply(pr, obs_bool.to(infer_dtype))
-        return lg.float(), v.float()
-
-    graphed = {}  # (n,) -> _GraphedRollout, built on first use when config["graph_rollout"] is set
+    engines = {}  # (n, static) -> _PolicyRollout
 
     def roll_out(runner_state, opp_params):
-        params, opt_state, env_state, last_obs, terminated_count, rng = runner_state
-        n, dev = env_state.num_envs, env.device
-        if config.get("graph_rollout") and mode == "competitive":
-            gr = graphed.get(n)
-            if gr is None and InferenceSnapshot.make(params, infer_dtype) is not None \
-                    and InferenceSnapshot.make(opp_params, infer_dtype) is not None:
-                gr = graphed[n] = _GraphedRollout(env, n, T, reward_scale, infer_dtype, params, opp_params)
-            if gr is not None:
-                return gr.run(runner_state, opp_params)
-        snapshots.clear()  # the weights may have been updated since the last rollout
-        traj = alloc_transition(T, n, dev)
-        tc = _count_tensor(terminated_count, dev)
-        packed = env_state.packed.clone()  # the caller's env_state stays valid, like a JAX pytree
-        cur = [env_state.current_player.clone(), torch.empty(n, dtype=torch.int32, device=dev)]
-        traj.obs[0].copy_(env_state.observation if last_obs is None else last_obs)
-        traj.legal_action_mask[0].copy_(env_state.legal_action_mask)
-        scratch_obs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=dev)
-        final_obs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=dev)
-        final_mask = torch.empty((n, NUM_ACTIONS), dtype=torch.bool, device=dev)
-        racc = torch.empty((n, 4), dtype=torch.float32, device=dev)
-        tacc = torch.empty(n, dtype=torch.bool, device=dev)
-        draw = int(rng)
-        with torch.no_grad():
-            for t in range(T):
-                actor = cur[t & 1]  # src/roll_out.py:72
-                logits, value = forward(actor_forward_pass, params, traj.obs[t])  # :73-76
-                traj.value[t].copy_(value)
-                racc.zero_()
-                tacc.zero_()
-                # sub-step 1: actor samples from the masked Categorical (src/roll_out.py:79-84)
-                policy_step(env, packed, packed, logits, SAMPLE, draw, True, action=traj.action[t],
-                            log_prob=traj.log_prob[t], obs=scratch_obs, rewards_acc=racc, terminated_acc=tacc)
-                last = t + 1 == T
-                obs_out = final_obs if last else traj.obs[t + 1]
-                mask_out = final_mask if last else traj.legal_action_mask[t + 1]
-                for k in (1, 2, 3):  # opp, partner (actor params), opp — src/utils.py:78-120
-                    is_opp = k != 2
-                    if mode == "free-run" and is_opp:
-                        lg, m = _pass_logits(env, n), MODE
-                    else:
-                        fp, pr = (opp_forward_pass, opp_params) if is_opp else (actor_forward_pass, params)
-                        lg, _ = forward(fp, pr, scratch_obs)
-                        m = SAMPLE if mode == "competitive" else MODE
-                    fin = k == 3
-                    policy_step(env, packed, packed, lg, m, draw + k, True,
-                                obs=obs_out if fin else scratch_obs, mask=mask_out if fin else None,
-                                rewards_acc=racc, terminated_acc=tacc, current_player=cur[(t + 1) & 1] if fin else None)
-                draw += 4
-                traj.done[t].copy_(tacc)  # G2
-                traj.reward[t].copy_(racc.gather(1, actor.to(torch.int64)[:, None])[:, 0] / reward_scale)  # G1
-                tc += tacc.sum()
-        new_state = State(env, packed, {"observation": final_obs, "legal_action_mask": final_mask,
-                                        "current_player": cur[T & 1]})
-        new_state = new_state.replace(rewards=racc, terminated=tacc)  # src/utils.py:128
-        return (params, opt_state, new_state, new_state.observation, tc, draw), traj
+        params, env_state = runner_state[0], runner_state[2]
+        n = env_state.num_envs
+        static = bool(config.get("graph_rollout")) and mode == "competitive" \
+            and InferenceSnapshot.make(params, infer_dtype) is not None \
+            and InferenceSnapshot.make(opp_params, infer_dtype) is not None
+        eng = engines.get((n, static))
+        if eng is None:
+            eng = engines[(n, static)] = _PolicyRollout(env, n, T, reward_scale, mode, masked, infer_dtype,
+                                                        actor_forward_pass, opp_forward_pass, static)
+        out = eng.run(runner_state, opp_params)
+        roll_out.sub_actions = eng.sub_actions
+        return out
 
+    roll_out.sub_actions = None
     return roll_out

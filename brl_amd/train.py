@@ -73,7 +73,9 @@ def train(config, log=print):
     roll_out = brl_amd.make_roll_out(config, env, fp, fp)
     calc_gae = brl_amd.make_calc_gae(config, fp)
     update_step = make_update_step(config, fp)
-    evaluate = make_simple_duplicate_evaluate(env, config["actor_activation"], config["actor_model_type"],
+    # evaluation has its OWN handle: env.init(seed) re-keys a handle's RNG, which must not leak into the training tables
+    eval_env = brl_amd.BridgeBidding(lut=lut, device=dev, env_offset=shard_offset(rank, config["num_eval_envs"]))
+    evaluate = make_simple_duplicate_evaluate(eval_env, config["actor_activation"], config["actor_model_type"],
                                               config["opp_activation"], config["opp_model_type"], config["num_eval_envs"])
     env_state = env.init(config["seed"], num_envs=config["num_envs"])
     runner_state = (params, opt_state, env_state, env_state.observation, 0, 0)

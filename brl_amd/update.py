@@ -37,6 +37,23 @@ def masked_log_softmax(logits, mask):
     return torch.log_softmax(torch.where(mask, logits, torch.full_like(logits, _NEG)), dim=-1)
 
 
+def spectral_norm_nonneg(a: torch.Tensor, squarings: int = 8) -> torch.Tensor:
+    """Largest singular value of a non-negative [B, A] matrix without an SVD (which costs more than the whole
+    minibatch step and does not capture into a hipGraph): sqrt of the top eigenvalue of the A x A Gram matrix, found
+    by repeated squaring (G^(2^k) collapses onto the Perron eigenvector; relative error ~ (l2/l1)^(2^(k+1))).
+    Used for the LOGGED illegal-action norm when its coefficient is 0 (src/update.py:136-141); with a non-zero
+    coefficient the differentiable ``torch.linalg.matrix_norm(ord=2)`` is used."""
+    g = a.t() @ a
+    tiny = torch.finfo(g.dtype).tiny
+    m = g / g.diagonal().sum().clamp_min(tiny)
+    for _ in range(squarings):
+        m = m @ m
+        m = m / m.diagonal().sum().clamp_min(tiny)
+    v = m.sum(dim=1)
+    lam = (v @ (g @ v)) / (v @ v).clamp_min(tiny)
+    return lam.clamp_min(0).sqrt()
+
+
 def ppo_loss(config, logits, value, batch: Transition, gae, targets):
     """``_loss_fn`` (src/update.py:90-167) on one minibatch; returns (total_loss, aux tuple)."""
     mask = batch.legal_action_mask
@@ -58,13 +75,18 @@ def ppo_loss(config, logits, value, batch: Transition, gae, targets):
     mlp = masked_log_softmax(logits, mask)
     p = mlp.exp()
     entropy = -(torch.where(p > 0, p * mlp, torch.zeros_like(p))).sum(-1).mean()   # distrax: 0 log 0 = 0
+    # src/update.py:136-141: the L2 (spectral) norm of the illegal-action probabilities is always computed and
+    # logged, whatever its coefficient; it joins the gradient only when the coefficient is non-zero
     coef = config.get("illegal_action_l2norm_coef", 0.0)
     if coef:
         illegal = torch.softmax(logits, dim=-1) * (~mask)
         illegal_loss = torch.linalg.matrix_norm(illegal, ord=2) / 2               # jnp.linalg.norm(2-D, ord=2)
     else:
-        illegal_loss = torch.zeros((), device=logits.device)
-    total = loss_actor + config["vf_coef"] * value_loss - config["ent_coef"] * entropy + coef * illegal_loss
+        with torch.no_grad():
+            illegal_loss = spectral_norm_nonneg(torch.softmax(logits, dim=-1) * (~mask)) / 2
+    total = loss_actor + config["vf_coef"] * value_loss - config["ent_coef"] * entropy
+    if coef:
+        total = total + coef * illegal_loss
     with torch.no_grad():
         approx_kl = ((ratio - 1) - logratio).mean()
         clipfrac = ((ratio - 1.0).abs() > config["clip_eps"]).float().mean()
@@ -98,27 +120,38 @@ class GraphedMinibatch:
                              z((mbs, 38), torch.bool))
         self.mb.legal_action_mask[:, 0] = True  # a valid dummy batch for the warm-up iterations
         self.gae, self.tgt = z((mbs,), torch.float32), z((mbs,), torch.float32)
-        # warm-up on a side stream with the REAL optimizer would move the weights: save / restore them
-        saved = [p.detach().clone() for p in params.parameters()]
-        saved_opt = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict().items() if k != "state"}
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                self._step()
-        torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = self._step()
-        # undo what warm-up + capture did to the parameters and the optimizer moments
-        with torch.no_grad():
-            for p, q in zip(params.parameters(), saved):
-                p.copy_(q)
-            for st in opt.state.values():
-                for k, v in st.items():
-                    if torch.is_tensor(v):
-                        v.zero_()
-        del saved_opt
+        # Warm-up and capture run the REAL optimizer on a dummy batch: snapshot the parameters and the optimizer state
+        # (moments, step counts — the graph may be built after eager steps or from a loaded optimizer) and put them
+        # back IN PLACE afterwards, also when capture fails (the captured graph holds these tensors' addresses).
+        saved_p = [p.detach().clone() for p in params.parameters()]
+        saved_s = {p: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                   for p, st in opt.state.items()}
+        self.graph = None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self._step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self.out = self._step()
+            self.graph = graph
+        finally:
+            with torch.no_grad():
+                for p, q in zip(params.parameters(), saved_p):
+                    p.copy_(q)
+                for p, st in opt.state.items():
+                    old = saved_s.get(p)
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            if old is not None and k in old:
+                                v.copy_(old[k])
+                            else:
+                                v.zero_()  # state created by the warm-up: zero moments / step 0 == a fresh Adam state
+                        elif old is not None and k in old:
+                            st[k] = old[k]
 
     def _step(self):
         logits, value = self.fp.apply(self.params, self.mb.obs.to(torch.float32))

@@ -13,6 +13,7 @@ from ._capi import NUM_ACTIONS, OBS_SIZE, check, ptr
 from .bridge_bidding import BridgeBidding, State, _stream
 
 SAMPLE, MODE = 0, 1  # pi.sample(seed) / pi.mode()
+UNMASKED = 2         # OR-ed in: the categorical ranges over all 38 actions (src/roll_out.py:33-39)
 
 
 def _env_of(step_fn) -> BridgeBidding:

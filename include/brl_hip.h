@@ -14,8 +14,11 @@
  *     GPU, owned by the caller (e.g. torch tensors: tensor.data_ptr()).  The library owns
  *     only the handle, its device copy of the double-dummy LUT (plus the packed hand words it
  *     derives from the keys at upload, 32 B per row) and a small constant table.
- *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and nothing
- *     synchronises the device (pass torch.cuda.current_stream().cuda_stream).
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and the compute entry points never
+ *     synchronise (pass torch.cuda.current_stream().cuda_stream).  The three functions WITHOUT a stream
+ *     argument that change what launches read — brl_create, brl_set_lut, brl_set_rng (when the values change) —
+ *     call hipDeviceSynchronize first: kernels in flight may still read the old table / key.  Every entry point
+ *     makes the handle's device current (hipSetDevice).
  *   - a handle is not thread-safe; use one per (device, stream).
  *   - per-table state is caller-owned and opaque: BRL_STATE_WORDS x uint64 per table
  *     (128 B, bit-packed: DESIGN.md "Data layout").  state_in == state_out is allowed.
@@ -52,13 +55,16 @@ int brl_version(void);
  * hex digits = tricks in C,D,H,S,NT).  lut_len may be 0 (explicit deals only). */
 int brl_create(int device, const int32_t *lut_keys, const int32_t *lut_values, int64_t lut_len,
                brl_handle **out);
-/* LUT rotation — ppo.py:525-549 swaps the hash table; same arguments as brl_create. */
+/* LUT rotation — ppo.py:525-549 swaps the hash table; same arguments as brl_create.  Synchronises the device; a
+ * table of the same length is copied over the old one (device addresses unchanged). */
 int brl_set_lut(brl_handle *h, const int32_t *lut_keys, const int32_t *lut_values, int64_t lut_len);
 int brl_destroy(brl_handle *h);
 
 /* Seed of the counter-based RNG (Philox4x32-10) and the global index of this handle's
  * table 0 (rank * num_envs when env shards are spread over GPUs).  Replaces the PRNGKey
- * plumbing of ppo.py:314-333 / src/utils.py:49. */
+ * plumbing of ppo.py:314-333 / src/utils.py:49.  brl_init_random / brl_step / brl_rollout_random take the key by
+ * value at launch; brl_policy_step[_at] read it (and the LUT) from a device-resident mirror, so a hipGraph replay of
+ * a captured policy sub-step follows later brl_set_rng / brl_set_lut calls. */
 int brl_set_rng(brl_handle *h, uint64_t seed, uint64_t env_offset);
 
 /* jax.vmap(env.init)(keys)  — ppo.py:305,318.  Deals board number `board_ctr0` of every
@@ -139,11 +145,12 @@ int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int num_steps,
                        uint8_t *last_obs, uint8_t *last_mask, int64_t *terminated_count, void *stream);
 
 /* One policy sub-step: masked categorical over `logits` float [n,38] for the current
- * player (mode 0: sample, src/roll_out.py:79-81 / src/utils.py:83-85; mode 1: arg-max,
- * src/utils.py:157,174 / src/evaluation.py:135), then auto_reset(env.step) when
- * autoreset != 0.  Uses draw index `draw` of each table's action stream.
- * Outputs (any may be NULL): action int32 [n], log_prob float [n] (log-softmax over legal
- * actions at the chosen action), then as brl_step.  rewards_acc float [n,4] and
+ * player (mode bit 0 clear: sample, src/roll_out.py:79-81 / src/utils.py:83-85; set: arg-max,
+ * src/utils.py:157,174 / src/evaluation.py:135; mode bit 1 set: the UNMASKED categorical of the
+ * illegal-action-penalty policy, src/roll_out.py:33-39 — an illegal draw ends the board with the pgx
+ * penalty), then auto_reset(env.step) when autoreset != 0.  Uses draw index `draw` of each table's action stream.
+ * Outputs (any may be NULL): action int32 [n], log_prob float [n] (log-softmax over the legal —
+ * or, unmasked, all — actions at the chosen action), then as brl_step.  rewards_acc float [n,4] and
  * terminated_acc uint8 [n], when given, are ACCUMULATED (+=, |=) — src/utils.py:126-127. */
 int brl_policy_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
                     const float *logits, int mode, uint32_t draw, int autoreset, int32_t *action,

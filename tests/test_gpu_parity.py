@@ -19,12 +19,11 @@ def env(dds):
     return brl_amd.BridgeBidding(lut=(dds["keys"], dds["values"]))
 
 
-def make_env(dds, k, ws=None, pipe=None):
-    """k: tables per wave of the per-step kernels; ws: "TPBxNW" of the wave-specialised fused
-    rollout, "0" for the K-tables-per-wave fused rollout, None for the library default; pipe: number of
-    prep waves of the pipelined variant k_rollout_pipe (BRL_ROLLOUT_PIPE), None for off."""
+def make_env(dds, k, ws=None):
+    """k: tables per wave of the per-step kernels; ws: "0" for the K-tables-per-wave fused rollout
+    (k_rollout_random<K>), None for the library default (the wave-specialised k_rollout_ws)."""
     import brl_amd
-    new = {"BRL_TABLES_PER_WAVE": str(k), "BRL_ROLLOUT_WS": ws, "BRL_ROLLOUT_PIPE": pipe}
+    new = {"BRL_TABLES_PER_WAVE": str(k), "BRL_ROLLOUT_WS": ws}
     old = {key: os.environ.get(key) for key in new}
     for key, v in new.items():
         if v is None:
@@ -147,12 +146,11 @@ def test_observe_any_player(env, oracle):
 @pytest.mark.parametrize("k,ws,substeps,n,T", [
     (1, "0", 1, 256, 32), (2, "0", 1, 515, 16), (4, "0", 1, 2048, 32), (8, "0", 1, 1000, 40),
     (4, "0", 4, 1024, 32), (8, "0", 4, 333, 12), (1, "0", 4, 64, 8),
-    (4, None, 1, 2048, 32), (4, None, 4, 1000, 16), (4, "32x8", 1, 1, 5), (4, "32x8", 1, 33, 32),
-    (4, "16x5", 1, 1000, 32), (4, "16x7", 4, 515, 12), (4, "32x11", 1, 4099, 32), (4, "16x7", 1, 2048, 32),
-    (4, "16x5", 4, 777, 9), (4, "32x5", 1, 300, 64), (4, "32x7", 1, 129, 7), (4, "32x4", 4, 2048, 40),
-    (4, "32x7", 1, 2, 3), (4, "32x7", 1, 30, 33), (4, "32x11", 3, 700, 21), (4, "32x4", 2, 450, 19),
-    (4, "32x11", 8, 130, 5), (4, "32x11", 9, 130, 3),
-    (4, "32x12", 1, 2048, 32), (4, "32x12", 1, 4099, 33), (4, "32x12", 4, 515, 12), (4, "32x12", 1, 33, 7)])
+    (4, None, 1, 128, 32),   # BASELINE.json configs[0]: num_envs=128, num_steps=32, random policy
+    (4, None, 1, 2048, 32), (4, None, 4, 1000, 16), (4, None, 1, 1, 5), (4, None, 1, 33, 32),
+    (4, None, 1, 4099, 33), (4, None, 4, 515, 12), (4, None, 1, 33, 7), (4, None, 1, 300, 64), (4, None, 1, 129, 7),
+    (4, None, 4, 2048, 40), (4, None, 1, 2, 3), (4, None, 1, 30, 33), (4, None, 3, 700, 21), (4, None, 2, 450, 19),
+    (4, None, 8, 130, 5), (4, None, 9, 130, 3)])
 def test_fused_random_rollout_matches_oracle(dds, oracle, k, ws, substeps, n, T):
     import brl_amd
     env = make_env(dds, k, ws)
@@ -174,31 +172,6 @@ def test_fused_random_rollout_matches_oracle(dds, oracle, k, ws, substeps, n, T)
         assert_state_equal(rs[2], ref, where=f"rollout final state K={k} sub={substeps} call {call}")
         assert np.array_equal(to_np(rs[3]), ref["observation"])
         assert rs[5] == draw
-
-
-@pytest.mark.parametrize("pipe,substeps,n,T", [("2", 1, 2048, 32), ("1", 1, 515, 40), ("3", 1, 33, 7), ("2", 4, 300, 8),
-                                                ("2", 1, 1, 3), ("2", 1, 4099, 33), ("2", 1, 500, 64)])
-def test_pipelined_rollout_matches_oracle(dds, oracle, pipe, substeps, n, T):
-    """k_rollout_pipe (opt-in, BRL_ROLLOUT_PIPE = prep waves): minimal logic chain + slot-parallel prep waves +
-    byte-image emit; substeps > 1 takes its legacy mode.  Same contract as the default kernel."""
-    import brl_amd
-    env = make_env(dds, 4, None, pipe)
-    cfg = {"num_steps": T, "game_mode": "competitive" if substeps == 4 else "normal", "substeps": substeps,
-           "reward_scale": 7600, "return_last_obs": True}
-    roll = brl_amd.make_random_roll_out(cfg, env)
-    st = env.init(77, num_envs=n)
-    ref = oracle.init_random(n, seed=77)
-    rs = (None, None, st, st.observation, 0, 0)
-    draw = 0
-    for call in range(3):
-        rs, traj = roll(rs)
-        want = oracle.rollout_random(ref, T, seed=77, substeps=substeps, draw_base=draw)
-        draw += T * substeps
-        torch.cuda.synchronize()
-        for name in ("obs", "legal_action_mask", "action", "done", "value", "reward", "log_prob"):
-            assert np.array_equal(to_np(getattr(traj, name)), want[name]), f"pipe={pipe} sub={substeps} call {call}: {name}"
-        assert_state_equal(rs[2], ref, where=f"pipelined rollout final state pipe={pipe} call {call}")
-        assert np.array_equal(to_np(rs[3]), ref["observation"])
 
 
 def test_rollout_terminated_count_accumulates(env, oracle):
@@ -335,6 +308,154 @@ def test_policy_step_argmax_and_sample(env, oracle):
     assert abs(emp - np.exp(lsm[np.arange(n), top]).mean()) < 0.01
 
 
+def replay_policy_rollout(oracle, ref, traj, sub_actions, seed, reward_scale=7600.0, env_offset=0):
+    """Replays the recorded actions of a policy-in-the-loop rollout (sub-step 1: traj.action, sub-steps 2-4:
+    sub_actions) through the oracle's auto_reset(step) and returns the Transition columns the reference's _env_step
+    would have stored (src/roll_out.py:63-103, src/utils.py:69-128): pre-step obs / mask of the acting player (G4),
+    done = OR of the four terminated flags (G2), reward = (r1+r2+r3+r4)[actor] / reward_scale (G1), boards replaced
+    mid-macro-step (G3).  `ref` ends as the post-rollout state (rewards / terminated of the last macro-step)."""
+    act0, sub = to_np(traj.action), to_np(sub_actions)
+    T, n = act0.shape
+    want = {"obs": np.zeros((T, n, 480), np.uint8), "legal_action_mask": np.zeros((T, n, 38), np.uint8),
+            "done": np.zeros((T, n), np.uint8), "reward": np.zeros((T, n), np.float32)}
+    count = 0
+    for t in range(T):
+        want["obs"][t] = ref["observation"]
+        want["legal_action_mask"][t] = ref["legal_action_mask"]
+        actor = ref["current_player"].copy()
+        racc = np.zeros((n, 4), np.float32)
+        term = np.zeros(n, np.int32)
+        for k in range(4):
+            oracle.step(ref, act0[t] if k == 0 else sub[t, k - 1], autoreset=True, seed=seed, env_offset=env_offset)
+            racc += ref["rewards"]
+            term |= ref["terminated"]
+        want["done"][t] = term
+        want["reward"][t] = racc[np.arange(n), actor] / np.float32(reward_scale)
+        count += int(term.sum())
+    ref["rewards"] = racc          # src/utils.py:126-128
+    ref["terminated"] = term
+    want["terminated_count"] = count
+    return want
+
+
+POLICY_CFG = {"reward_scale": 7600, "game_mode": "competitive", "actor_illegal_action_mask": True,
+              "gamma": 1.0, "gae_lambda": 0.95}
+
+
+@pytest.mark.parametrize("n,T,graph,dt,calls", [(2048, 32, False, None, 2), (2048, 32, True, None, 2),
+                                                (8192, 32, True, "bf16", 1), (1000, 9, False, "bf16", 2)])
+def test_policy_rollout_replays_through_oracle(env, oracle, n, T, graph, dt, calls):
+    """A7 with MLPs in the loop (BASELINE configs[2]/[3] rollout): every integer / byte column of the Transition and the
+    final packed state bit-exact vs the oracle replay of the recorded actions; reward exact (integer scores / 7600 in
+    fp32); value / log_prob vs an fp32 torch recomputation on the stored obs (tolerances stated below)."""
+    import brl_amd
+    from brl_amd.models import make_forward_pass
+    cfg = dict(POLICY_CFG, num_steps=T, graph_rollout=graph, inference_dtype=dt)
+    fp = make_forward_pass("relu", "DeepMind")
+    actor, opp = fp.init(0, device="cuda"), fp.init(1, device="cuda")
+    roll = brl_amd.make_roll_out(cfg, env, fp, fp)
+    seed = 4242
+    st = env.init(seed, num_envs=n)
+    ref = oracle.init_random(n, seed=seed)
+    rs = (actor, None, st, st.observation, 0, 0)
+    total = 0
+    for call in range(calls):
+        rs, traj = roll(rs, opp)
+        torch.cuda.synchronize()
+        want = replay_policy_rollout(oracle, ref, traj, roll.sub_actions, seed)
+        where = f"n={n} T={T} graph={graph} dt={dt} call {call}"
+        for name in ("obs", "legal_action_mask", "done", "reward"):
+            assert np.array_equal(to_np(getattr(traj, name)), want[name]), f"{where}: {name}"
+        mask, act = want["legal_action_mask"], to_np(traj.action)
+        assert np.take_along_axis(mask, act[..., None].astype(np.int64), 2).all(), f"{where}: sampled action illegal"
+        assert_state_equal(rs[2], ref, where=f"{where}: final state")
+        assert np.array_equal(to_np(rs[3]), ref["observation"])
+        total += want["terminated_count"]
+        assert int(rs[4].item()) == total and rs[5] == 4 * T * (call + 1)
+        with torch.no_grad():
+            logits, value = actor(traj.obs.reshape(T * n, 480).float())
+        lsm = _masked_log_softmax(to_np(logits), mask.reshape(T * n, 38))
+        # fp32 inference: accumulation order of the GEMMs differs (fused epilogue / merged heads): 2e-4; bf16: 8 mantissa bits
+        tol = 2e-4 if dt is None else 0.08
+        assert np.abs(to_np(traj.log_prob).reshape(-1) - lsm[np.arange(T * n), act.reshape(-1)]).max() < tol
+        assert np.abs(to_np(traj.value).reshape(-1) - to_np(value)).max() < tol
+    assert total > 0
+
+
+@pytest.mark.parametrize("variant", ["free-run", "unmasked", "fair-tanh"])
+def test_policy_rollout_variants_replay_through_oracle(env, oracle, variant):
+    """free-run (G16: opponents pass, partner greedy), the unmasked / illegal-action-penalty policy
+    (src/roll_out.py:33-39: the actor may draw an illegal call -> pgx penalty, board over) and a network outside
+    InferenceSnapshot's coverage (FAIR, tanh) — all replayed through the oracle like the competitive rollout."""
+    import brl_amd
+    from brl_amd.models import make_forward_pass
+    n, T, seed = 700, 12, 99
+    cfg = dict(POLICY_CFG, num_steps=T)
+    fp = make_forward_pass("relu", "DeepMind")
+    if variant == "free-run":
+        cfg["game_mode"] = "free-run"
+    elif variant == "unmasked":
+        cfg.update(actor_illegal_action_mask=False, actor_illegal_action_penalty=True)
+    else:
+        fp = make_forward_pass("tanh", "FAIR")
+    actor, opp = fp.init(5, device="cuda"), fp.init(6, device="cuda")
+    roll = brl_amd.make_roll_out(cfg, env, fp, fp)
+    st = env.init(seed, num_envs=n)
+    ref = oracle.init_random(n, seed=seed)
+    rs, traj = roll((actor, None, st, st.observation, 0, 0), opp)
+    torch.cuda.synchronize()
+    want = replay_policy_rollout(oracle, ref, traj, roll.sub_actions, seed)
+    for name in ("obs", "legal_action_mask", "done", "reward"):
+        assert np.array_equal(to_np(getattr(traj, name)), want[name]), f"{variant}: {name}"
+    assert_state_equal(rs[2], ref, where=f"{variant}: final state")
+    act, sub, mask = to_np(traj.action), to_np(roll.sub_actions), want["legal_action_mask"]
+    legal = np.take_along_axis(mask, act[..., None].astype(np.int64), 2)[..., 0]
+    with torch.no_grad():
+        logits, _ = actor(traj.obs.reshape(T * n, 480).float())
+    if variant == "unmasked":
+        assert (legal == 0).any()           # random weights: illegal calls do get drawn ...
+        bad = legal == 0                    # ... and end the board at once with the offender's -1 (scaled)
+        assert (to_np(traj.done)[bad] == 1).all()
+        lsm = _masked_log_softmax(to_np(logits), np.ones((T * n, 38), np.uint8))   # log-prob under the UNMASKED softmax
+    else:
+        assert legal.all()
+        lsm = _masked_log_softmax(to_np(logits), mask.reshape(T * n, 38))
+    assert np.abs(to_np(traj.log_prob).reshape(-1) - lsm[np.arange(T * n), act.reshape(-1)]).max() < 2e-4
+    if variant == "free-run":
+        assert (sub[:, 0] == 0).all() and (sub[:, 2] == 0).all()   # both opponents always pass
+
+
+def test_graphed_rollout_follows_reseed_and_lut_rotation(dds, oracle):
+    """The captured launches read the RNG key / LUT through the library's device-resident context: after env.seed /
+    env.set_lut (ppo.py:525-549) graph replays deal from the NEW table with the NEW key — checked against the oracle."""
+    import brl_amd
+    from brl_amd.models import make_forward_pass
+    from oracle import Oracle
+    n, T = 600, 6
+    env = brl_amd.BridgeBidding(lut=(dds["keys"], dds["values"]))
+    fp = make_forward_pass("relu", "DeepMind")
+    actor, opp = fp.init(0, device="cuda"), fp.init(1, device="cuda")
+    roll = brl_amd.make_roll_out(dict(POLICY_CFG, num_steps=T, graph_rollout=True), env, fp, fp)
+    st = env.init(5, num_envs=n)
+    ref = oracle.init_random(n, seed=5)
+    rs, traj = roll((actor, None, st, st.observation, 0, 0), opp)
+    torch.cuda.synchronize()
+    want = replay_policy_rollout(oracle, ref, traj, roll.sub_actions, 5)
+    assert np.array_equal(to_np(traj.obs), want["obs"])
+    k2, v2 = synthetic_lut(777, seed=9)
+    env.set_lut((k2, v2))               # LUT rotation: new table, every env re-initialised (G14) with a new key
+    orc2 = Oracle(k2, v2)
+    st = env.init(6, num_envs=n)
+    ref = orc2.init_random(n, seed=6)
+    rs, traj = roll((actor, None, st, st.observation, rs[4], rs[5]), opp)
+    torch.cuda.synchronize()
+    want = replay_policy_rollout(orc2, ref, traj, roll.sub_actions, 6)
+    for name in ("obs", "legal_action_mask", "done", "reward"):
+        assert np.array_equal(to_np(getattr(traj, name)), want[name]), name
+    assert_state_equal(rs[2], ref, where="graphed rollout after LUT rotation")
+    assert int(rs[2]._lut_idx.max()) < 777 and int(rs[2]._board_count.max()) >= 1
+
+
 def test_policy_rollout_with_mlp_is_self_consistent(env):
     import brl_amd
     from brl_amd.models import make_forward_pass
@@ -447,7 +568,8 @@ def test_graphed_policy_rollout_matches_eager(env, dt):
 def test_full_size_properties(dds):
     """BASELINE.json size (N=8192, T=32): size-independent properties of the fused rollout."""
     import brl_amd
-    keys, values = synthetic_lut(5000, seed=1)
+    from bench import synthetic_lut as bench_lut
+    keys, values = bench_lut(100_000, 0)   # the bench's own table: 100 000 rows (ppo.py:128 hash_size)
     env = brl_amd.BridgeBidding(lut=(keys, values))
     n, T = 8192, 32
     roll = brl_amd.make_random_roll_out({"num_steps": T}, env)
@@ -475,14 +597,14 @@ def test_full_size_properties(dds):
         assert torch.equal(a, b)
 
 
-def test_simple_duplicate_evaluate_replays_through_oracle(env, oracle):
+@pytest.mark.parametrize("n", [640, 8192])   # 8192 = BASELINE.json configs[2] (num_envs=8192 duplicate self-play)
+def test_simple_duplicate_evaluate_replays_through_oracle(env, oracle, n):
     """Config 3 driver (src/evaluation.py:69-204): record the greedy actions the two MLPs chose on the
     GPU, replay them through the oracle's duplicate_step, compare IMPs / final contracts (G8, G12)."""
     import brl_amd
     from brl_amd.evaluation import make_simple_duplicate_evaluate
     from brl_amd.models import make_forward_pass
     from oracle import Oracle
-    n = 640
     fp = make_forward_pass("relu", "DeepMind")
     t1, t2 = fp.init(3, device="cuda"), fp.init(4, device="cuda")
     rec = []

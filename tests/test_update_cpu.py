@@ -47,7 +47,11 @@ def numpy_loss(cfg, logits, value, b, gae, tgt):
     la = -np.minimum(ratio * gae, np.clip(ratio, 1 - cfg["clip_eps"], 1 + cfg["clip_eps"]) * gae).mean()
     p = np.exp(lsm)
     ent = -(np.where(mask, p * lsm, 0.0)).sum(1).mean()
-    return la + cfg["vf_coef"] * vl - cfg["ent_coef"] * ent, vl, la, ent
+    ul = logits - logits.max(1, keepdims=True)
+    probs = np.exp(ul) / np.exp(ul).sum(1, keepdims=True)
+    ill = np.linalg.norm(probs * ~mask, ord=2) / 2          # src/update.py:136-141 (2-D ord=2: largest singular value)
+    total = la + cfg["vf_coef"] * vl - cfg["ent_coef"] * ent + cfg.get("illegal_action_l2norm_coef", 0.0) * ill
+    return total, vl, la, ent, ill
 
 
 def test_loss_matches_numpy_restatement():
@@ -61,6 +65,22 @@ def test_loss_matches_numpy_restatement():
     want = numpy_loss(CFG, logits, value, flat, adv.reshape(-1), tgt.reshape(-1))
     assert abs(float(total) - want[0]) < 1e-5   # fp32 vs fp64
     assert abs(float(aux[0]) - want[1]) < 1e-5 and abs(float(aux[1]) - want[2]) < 1e-5 and abs(float(aux[2]) - want[3]) < 1e-5
+    # the illegal-action norm is logged whatever its coefficient (src/update.py:136-141): SVD-free estimate, 1e-4 relative
+    assert abs(float(aux[5]) - want[4]) < 1e-4 * want[4] and want[4] > 0
+    cfg = dict(CFG, illegal_action_l2norm_coef=0.3)  # with a coefficient: the exact, differentiable norm joins the loss
+    total2, aux2 = ppo_loss(cfg, logits, value, flat, adv.reshape(-1), tgt.reshape(-1))
+    want2 = numpy_loss(cfg, logits, value, flat, adv.reshape(-1), tgt.reshape(-1))
+    assert abs(float(total2) - want2[0]) < 1e-5 and abs(float(aux2[5]) - want2[4]) < 1e-5
+
+
+def test_spectral_norm_without_svd():
+    from brl_amd.update import spectral_norm_nonneg
+    g = torch.Generator().manual_seed(1)
+    for shape in ((1024, 38), (64, 38), (5, 38)):
+        a = torch.rand(shape, generator=g) * (torch.rand(shape, generator=g) < 0.6)
+        want = float(torch.linalg.matrix_norm(a.double(), ord=2))
+        assert abs(float(spectral_norm_nonneg(a)) - want) < 1e-4 * want
+    assert float(spectral_norm_nonneg(torch.zeros(8, 38))) == 0.0
 
 
 def test_update_step_shapes_and_progress():
