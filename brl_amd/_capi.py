@@ -32,6 +32,14 @@ class TableInfoPtrs(C.Structure):
     _fields_ = [(n, _vp) for n in _names]
 
 
+class EvalStatsPtrs(C.Structure):
+    _names = ["illegal_prob_sum", "step_count", "pass_count", "bid_count"]
+    _fields_ = [(n, _vp) for n in _names]
+
+
+EVAL_COUNTS = 231  # BRL_EVAL_COUNTS
+
+
 class BrlError(RuntimeError):
     pass
 
@@ -71,6 +79,9 @@ def lib() -> C.CDLL:
         "brl_imp_reward": [_vp, _vp, _vp, _vp, i64, _vp],
         "brl_duplicate_step": [_vp, _vp, _vp, i64, _vp, C.POINTER(TableInfoPtrs), C.POINTER(TableInfoPtrs),
                                _vp, _vp, _vp, _vp, _vp, _vp],
+        "brl_eval_step": [_vp, _vp, _vp, i64, _vp, i64, _vp, i64, C.POINTER(TableInfoPtrs), C.POINTER(TableInfoPtrs),
+                          C.POINTER(EvalStatsPtrs), i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+        "brl_eval_reduce": [_vp, i64, C.POINTER(TableInfoPtrs), C.POINTER(TableInfoPtrs), _vp, _vp, _vp, _vp],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)
@@ -82,7 +93,8 @@ def lib() -> C.CDLL:
 
 EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_destroy", "brl_set_rng",
            "brl_init_random", "brl_init_from_deals", "brl_step", "brl_observe", "brl_get_fields",
-           "brl_rollout_random", "brl_policy_step", "brl_policy_step_at", "brl_obs_cast", "brl_gae", "brl_imp_reward", "brl_duplicate_step"]
+           "brl_rollout_random", "brl_policy_step", "brl_policy_step_at", "brl_obs_cast", "brl_gae", "brl_imp_reward", "brl_duplicate_step",
+           "brl_eval_step", "brl_eval_reduce"]
 
 
 def check(rc: int) -> None:

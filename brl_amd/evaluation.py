@@ -1,17 +1,27 @@
-"""``src/evaluation.py`` hot-path evaluators on the GPU.
+"""``src/evaluation.py`` on the GPU.
 
-``make_simple_duplicate_evaluate`` — BASELINE config 3: N boards, each played at table A and then,
-seat-swapped, at table B (``duplicate_step``); greedy (``pi.mode()``) actions from two MLPs chosen
-by ``current_player in {0,1}`` (src/evaluation.py:146-151); returns (mean IMP, standard error,
-win rate) like src/evaluation.py:199-202.  ``make_simple_evaluate`` — the single-table
-deterministic evaluator of src/evaluation.py:11-66.
-"""
+* ``make_simple_duplicate_evaluate`` — BASELINE config 3 (src/evaluation.py:69-204): N boards, each played at table A
+  and then, seat-swapped, at table B (``duplicate_step``); greedy (``pi.mode()``) actions from two MLPs chosen by
+  ``current_player in {0,1}`` (:146-151); returns (mean IMP, standard error, win rate) like :199-202.
+* ``make_evaluate`` — the evaluator with bidding statistics (src/evaluation.py:207-1032), duplicate or single table,
+  and ``make_evaluate_log`` (:1035-1115), the flat ``eval/...`` dict ppo.py logs every ``num_eval_step`` iterations.
+* ``make_simple_evaluate`` — the single-table deterministic evaluator of src/evaluation.py:11-66.
+
+Every loop iteration is two (merged) GEMM forwards in PyTorch-ROCm plus ONE ``brl_eval_step`` launch: team selection,
+masked arg-max, the step log (illegal-action probability mass, step / pass / bid counters), ``duplicate_step`` and the
+return accumulators all happen in that kernel; the end-of-run histograms come from ``brl_eval_reduce`` as exact integer
+counts.  The loop condition ``~state.terminated.all()`` is read back every ``sync_every`` iterations (finished boards
+keep receiving no-op steps, G9, so overshooting changes nothing)."""
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 
-from .bridge_bidding import BridgeBidding
-from .duplicate import Table_info, duplicate_step
+from . import _capi
+from ._capi import NUM_ACTIONS, OBS_SIZE, check, ptr
+from .bridge_bidding import BridgeBidding, State, _stream
+from .duplicate import Table_info
 from .models import InferenceSnapshot, make_forward_pass
 from .utils import single_play_step_two_policy_commpetitive_deterministic
 
@@ -23,15 +33,78 @@ def masked_mode(logits: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     return torch.where(mask, logits, torch.full_like(logits, _NEG)).argmax(dim=-1).to(torch.int32)
 
 
+class _Forward:
+    """logits of one team's network for a batch of observations: the fused inference snapshot when the architecture is
+    covered (DeepMind / ReLU), else the module itself.  Returns a float32 [n, >=38] matrix whose first 38 columns are
+    the logits (row stride may be 39: merged actor + critic heads)."""
+
+    def __init__(self, forward_pass, params):
+        self.fp, self.params = forward_pass, params
+        self.snap = InferenceSnapshot.make(params)
+
+    def __call__(self, obs_bool, obs_f32):
+        if self.snap is not None:
+            return self.snap.heads(obs_f32)
+        logits, _ = self.fp.apply(self.params, obs_f32)
+        return logits.contiguous()
+
+
+class EvalStats:
+    """Device buffers behind ``brl_eval_stats`` (include/brl_hip.h)."""
+
+    def __init__(self, n, device):
+        self.illegal_prob_sum = torch.zeros((n, 2), dtype=torch.float32, device=device)
+        self.step_count = torch.zeros((n, 2), dtype=torch.int32, device=device)
+        self.pass_count = torch.zeros((n, 2), dtype=torch.int32, device=device)
+        self.bid_count = torch.zeros((n, 2, 35), dtype=torch.int32, device=device)
+
+    def ptrs(self):
+        p = _capi.EvalStatsPtrs()
+        for name in _capi.EvalStatsPtrs._names:
+            setattr(p, name, ptr(getattr(self, name)))
+        return p
+
+
+def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward, tables, stats, bid_set, cum_return,
+               rewards_sum, sync_every, record_actions=None, record_logits=None):
+    """Runs ``brl_eval_step`` until every board is finished; ``state.packed`` is advanced in place."""
+    n, dev = state.num_envs, env.device
+    obs = state.observation
+    term = torch.empty(n, dtype=torch.bool, device=dev)
+    action = torch.empty(n, dtype=torch.int32, device=dev)
+    pa = tables[0]._ptrs() if tables else None
+    pb = tables[1]._ptrs() if tables else None
+    ps = stats.ptrs() if stats is not None else None
+    packed = state.packed
+    count = 0
+    while True:
+        x = obs.to(torch.float32)
+        l1 = fwd1(obs, x)
+        l2 = fwd2(obs, x) if fwd2 is not fwd1 else l1   # G10: the reference evaluates both networks and selects
+        if record_logits is not None:
+            team1 = (State(env, packed).current_player < 2)[:, None]
+            record_logits.append(torch.where(team1, l1[:, :NUM_ACTIONS], l2[:, :NUM_ACTIONS]).clone())
+        nobs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=dev)
+        check(_capi.lib().brl_eval_step(
+            env._h, ptr(packed), ptr(packed), n, l1.data_ptr(), l1.stride(0), l2.data_ptr(), l2.stride(0),
+            C.byref(pa) if pa is not None else None, C.byref(pb) if pb is not None else None,
+            C.byref(ps) if ps is not None else None, int(bid_set),
+            ptr(cum_return), ptr(rewards_sum), ptr(action), ptr(nobs), None, None, ptr(term), None, _stream()))
+        obs = nobs
+        if record_actions is not None:
+            record_actions.append(action.clone())
+        count += 1
+        if count % sync_every == 0 and bool(term.all()):
+            break
+    return State(env, packed, {"observation": obs, "terminated": term}), count
+
+
 def make_simple_duplicate_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_type, team2_activation,
                                    team2_model_type, num_eval_envs, sync_every: int = 16, record_actions=None):
-    """src/evaluation.py:69-204.  ``sync_every``: the ``~state.terminated.all()`` loop condition is
-    read back every that many iterations (finished boards keep receiving no-op steps, G9, so
-    overshooting changes nothing).  ``record_actions``: optional list that receives each iteration's
-    action tensor (tests replay them through the oracle)."""
+    """src/evaluation.py:69-204.  ``record_actions``: optional list that receives each iteration's action tensor
+    (tests replay them through the oracle)."""
     team1_forward_pass = make_forward_pass(team1_activation, team1_model_type)
     team2_forward_pass = make_forward_pass(team2_activation, team2_model_type)
-    step_fn = duplicate_step(eval_env.step)
 
     def duplicate_evaluate(team1_params, team2_params, rng_key):
         with torch.no_grad():
@@ -39,26 +112,10 @@ def make_simple_duplicate_evaluate(eval_env: BridgeBidding, team1_activation, te
             table_a_info = Table_info.from_state(state)              # :96-103
             table_b_info = Table_info.from_state(state)              # :104-111
             cum_return = torch.zeros(num_eval_envs, dtype=torch.float32, device=eval_env.device)
-            count = 0
-            snap1, snap2 = InferenceSnapshot.make(team1_params), InferenceSnapshot.make(team2_params)
-            while True:
-                obs = state.observation
-                if snap1 is None or snap2 is None:
-                    obs = obs.to(torch.float32)
-                elif snap1.dtype == snap2.dtype:
-                    obs = snap1._input(obs)  # one conversion for both networks
-                # G10: the reference evaluates both networks for every env and selects; so do we
-                l1, _ = snap1(obs) if snap1 is not None else team1_forward_pass.apply(team1_params, obs)
-                l2, _ = snap2(obs) if snap2 is not None else team2_forward_pass.apply(team2_params, obs)
-                team1 = (state.current_player < 2)[:, None]          # players {0,1} are team 1 (:148)
-                action = masked_mode(torch.where(team1, l1, l2), state.legal_action_mask)
-                if record_actions is not None:
-                    record_actions.append(action.clone())
-                state, table_a_info, table_b_info = step_fn(state, action, table_a_info, table_b_info, inplace=True)
-                cum_return += state.rewards[:, 0]                    # G8, :167-169
-                count += 1
-                if count % sync_every == 0 and bool(state.terminated.all()):
-                    break
+            fwd1 = _Forward(team1_forward_pass, team1_params)
+            fwd2 = fwd1 if team2_params is team1_params else _Forward(team2_forward_pass, team2_params)
+            _eval_loop(eval_env, state, fwd1, fwd2, (table_a_info, table_b_info), None, 0, cum_return, None,
+                       sync_every, record_actions)                   # :120-197; cum_return += rewards[:, 0] (G8)
             n = float(num_eval_envs)
             std_error = cum_return.std(unbiased=True) / (n ** 0.5)   # :199
             win_rate = (cum_return > 0).sum() / n                    # :200
@@ -66,6 +123,123 @@ def make_simple_duplicate_evaluate(eval_env: BridgeBidding, team1_activation, te
         return log_info, table_a_info, table_b_info
 
     return duplicate_evaluate
+
+
+def make_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_type, team2_activation, team2_model_type,
+                  team2_params, num_eval_envs, game_mode="competitive", duplicate=False, sync_every: int = 16,
+                  record_actions=None, record_logits=None):
+    """``make_evaluate`` (src/evaluation.py:207-1032).  ``team2_params`` replaces the reference's pickle path.
+    Returns ``duplicate_evaluate(actor_params, rng_key) -> (log_info, table_a_info, table_b_info)`` (23-entry
+    log_info, :985-1031) or, with ``duplicate=False``, ``evaluate(actor_params, rng_key) -> (state, log_info)``
+    (19 entries, :583-605).  Feed ``log_info`` of the duplicate variant to ``make_evaluate_log``.
+
+    game_mode "free-run": the opponents (players {2,3}) always pass (:243-247) — their "logits" are a constant row
+    whose arg-max is Pass and whose softmax mass on illegal actions is what the reference's one-hot probs give."""
+    actor_forward_pass = make_forward_pass(team1_activation, team1_model_type)
+    opp_forward_pass = make_forward_pass(team2_activation, team2_model_type)
+    if game_mode not in ("competitive", "free-run"):
+        raise ValueError(game_mode)
+
+    class _PassOnly:
+        """free-run opponent: probs = one-hot(Pass) (src/evaluation.py:243-247); logits with softmax == that one-hot."""
+
+        def __init__(self, n, device):
+            self.lg = torch.full((n, NUM_ACTIONS), -1e30, dtype=torch.float32, device=device)
+            self.lg[:, 0] = 0.0
+
+        def __call__(self, obs_bool, obs_f32):
+            return self.lg
+
+    def run(actor_params, rng_key, dup):
+        n, dev = num_eval_envs, eval_env.device
+        with torch.no_grad():
+            state = eval_env.init(rng_key, num_envs=n)
+            tables = (Table_info.from_state(state), Table_info.from_state(state)) if dup else None
+            cum_return = torch.zeros(n, dtype=torch.float32, device=dev)
+            rewards_sum = None if dup else torch.zeros((n, 4), dtype=torch.float32, device=dev)
+            stats = EvalStats(n, dev)
+            fwd1 = _Forward(actor_forward_pass, actor_params)
+            fwd2 = _PassOnly(n, dev) if game_mode == "free-run" else _Forward(opp_forward_pass, team2_params)
+            # the single-table evaluator marks a bid as made (.set(1), :349-358), the duplicate one counts it (:704-713)
+            state, _ = _eval_loop(eval_env, state, fwd1, fwd2, tables, stats, 0 if dup else 1, cum_return, rewards_sum,
+                                  sync_every, record_actions, record_logits)
+            if not dup:  # make_terminated_log on the final state (:463-487): one "table" built from it
+                f = State(eval_env, state.packed)
+                tables = (Table_info(f.terminated, rewards_sum, f._last_bid, f._last_bidder, f._call_x, f._call_xx),)
+            counts = torch.empty(_capi.EVAL_COUNTS, dtype=torch.int64, device=dev)
+            pa = tables[0]._ptrs()
+            pb = tables[1]._ptrs() if dup else None
+            check(_capi.lib().brl_eval_reduce(eval_env._h, n, C.byref(pa), C.byref(pb) if pb is not None else None,
+                                              ptr(stats.bid_count), ptr(state.packed), ptr(counts), _stream()))
+            c = counts.to(torch.float64)
+            fn = float(n)
+            steps = stats.step_count.to(torch.float32)
+            illegal = (stats.illegal_prob_sum / steps).mean(dim=0)          # :857-862 (x / y per board, then mean)
+            passes = (stats.pass_count.to(torch.float32) / steps).mean(dim=0)  # :1029-1030
+            ntab = 2.0 if dup else 1.0
+
+            def both(i):  # (table A + table B) / 2 of a per-table ratio count / n  (:985-1028)
+                return ((c[i] + (c[80 + i] if dup else 0.0)) / fn / ntab).to(torch.float32)
+
+            def both_vec(i):
+                return ((c[i:i + 35] + (c[80 + i:80 + i + 35] if dup else 0.0)) / fn / ntab).to(torch.float32)
+
+            bid_div = 2.0 if dup else 1.0                                    # :992-993 actor_bid.mean(axis=0) / 2
+            actor_bid = (c[160:195] / fn / bid_div).to(torch.float32)
+            opp_bid = (c[195:230] / fn / bid_div).to(torch.float32)
+            step_count_mean = (c[230] / fn).to(torch.float32)                # state._step_count.mean()
+            common = (illegal[0], illegal[1], step_count_mean, actor_bid, opp_bid, both_vec(10), both_vec(45),
+                      (c[10:45].sum() + (c[90:125].sum() if dup else 0.0)).div(fn * ntab).to(torch.float32),  # declarer ratios
+                      (c[45:80].sum() + (c[125:160].sum() if dup else 0.0)).div(fn * ntab).to(torch.float32),
+                      both(1), both(2), both(3), both(4), both(5), both(6), both(7), both(8), both(0))
+            if dup:
+                std_error = cum_return.std(unbiased=True) / (fn ** 0.5)      # :984
+                score = ((c[9] / fn + c[89] / fn) / 2).to(torch.float32)      # :988
+                log_info = (cum_return.mean(), std_error, score) + common + (passes[0], passes[1])
+                return log_info, tables[0], tables[1]
+            final = State(eval_env, state.packed).replace(rewards=rewards_sum)  # :582
+            return final, (cum_return.mean(),) + common
+
+    def duplicate_evaluate(actor_params, rng_key):
+        return run(actor_params, rng_key, True)
+
+    def evaluate(actor_params, rng_key):
+        return run(actor_params, rng_key, False)
+
+    return duplicate_evaluate if duplicate else evaluate
+
+
+def make_evaluate_log(log_info):
+    """``make_evaluate_log`` (src/evaluation.py:1035-1115): the 23-entry ``log_info`` of the duplicate evaluator as
+    the flat dict ppo.py merges into its wandb log (python floats; the reference keeps jnp scalars)."""
+    (imp_mean, std_error, score_mean, actor_illegal, opp_illegal, step_count_mean, actor_bid, opp_bid, actor_contract,
+     opp_contract, actor_declarer, opp_declarer, actor_x, actor_xx, opp_x, opp_xx, actor_make, opp_make, actor_down,
+     opp_down, pass_out, actor_pass, opp_pass) = log_info
+    f = float
+    log = {
+        "eval/IMP_reward": f(imp_mean), "eval/IMP_SE": f(std_error), "eval/score_reward": f(score_mean),
+        "eval/actor_illegal_action_probs": f(actor_illegal), "eval/opp_illegal_action_probs": f(opp_illegal),
+        "eval/step count": f(step_count_mean), "eval/actor_declarer_ratio": f(actor_declarer),
+        "eval/opp_declarer_ratio": f(opp_declarer), "eval/actor_doubled_ratio": f(actor_x),
+        "eval/actor_redoubled_ratio": f(actor_xx), "eval/opp_doubled_ratio": f(opp_x),
+        "eval/opp_redoubled_ratio": f(opp_xx), "eval/actor_make_contract_ratio": f(actor_make),
+        "eval/opp_make_contract_ratio": f(opp_make), "eval/actor_down_contract_ratio": f(actor_down),
+        "eval/opp_down_contract_ratio": f(opp_down), "eval/pass_out_ratio": f(pass_out),
+        "eval/actor_pass_ratio": f(actor_pass), "eval/opp_pass_ratio": f(opp_pass),
+    }
+    ab, ob, ac, oc = (x.detach().cpu().tolist() for x in (actor_bid, opp_bid, actor_contract, opp_contract))
+    groups = ({}, {}, {}, {})
+    index = 0
+    for number in range(1, 8):                 # :1092-1107: bid index = (level - 1) * 5 + strain, strains C D H S NT
+        for suit in ("C", "D", "H", "S", "NT"):
+            groups[0][f"eval/actor_bid_probs/{number}{suit}"] = ab[index]
+            groups[1][f"eval/actor_contract_probs/{number}{suit}"] = ac[index]
+            groups[2][f"eval/opp_bid_probs/{number}{suit}"] = ob[index]
+            groups[3][f"eval/opp_contract_probs/{number}{suit}"] = oc[index]
+            index += 1
+    for g in groups:
+        log.update(g)
+    return log
 
 
 def make_simple_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_type, team2_activation,

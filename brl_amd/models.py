@@ -108,13 +108,18 @@ class InferenceSnapshot:
             return x
         return obs.to(self.dtype)
 
-    def __call__(self, obs):
-        """obs: [n, 480] bool / float -> (logits f32 [n, 38], value f32 [n])"""
+    def heads(self, obs):
+        """obs: [n, 480] bool / float -> f32 [n, 39]: the 38 logits and the value as ONE matrix (row stride 39; the
+        kernels take the logits as a strided slice of it)"""
         x = self._input(obs)
         fused = hasattr(torch, "_addmm_activation")
         for w, b in self.body:
             x = torch._addmm_activation(b, x, w, use_gelu=False) if fused else torch.addmm(b, x, w).relu_()
-        out = torch.addmm(self.head_b, x, self.head_w).float()
+        return torch.addmm(self.head_b, x, self.head_w).float()
+
+    def __call__(self, obs):
+        """obs: [n, 480] bool / float -> (logits f32 [n, 38], value f32 [n])"""
+        out = self.heads(obs)
         return out[:, :self.n_actions], out[:, self.n_actions]
 
 

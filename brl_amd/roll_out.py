@@ -110,6 +110,9 @@ class _PolicyRollout:
         self.sub_actions = e((T, 3, n), torch.int32)
         self.draw = torch.zeros(1, dtype=torch.int32, device=dev)
         self.tc = torch.zeros(1, dtype=torch.int64, device=dev)
+        # a TENSOR divisor: torch turns `x / python_float` into x * (1 / float) on the GPU, which is not the correctly
+        # rounded quotient `rewards / config["reward_scale"]` (src/roll_out.py:90) that the fused kernel and the oracle compute
+        self.scale = torch.tensor(self.reward_scale, dtype=torch.float32, device=dev)
 
     # ---- the networks -------------------------------------------------------------------------------------------
     def _bind(self, params, opp_params):
@@ -167,7 +170,7 @@ class _PolicyRollout:
                         terminated_acc=tacc, current_player=cur[(t + 1) & 1] if fin else None, draw_base=self.draw)
         self.draw.add_(4)
         traj.done[t].copy_(tacc)                                                                          # G2
-        traj.reward[t].copy_(racc.gather(1, actor.to(torch.int64)[:, None])[:, 0] / self.reward_scale)    # G1, :90
+        torch.div(racc.gather(1, actor.to(torch.int64)[:, None])[:, 0], self.scale, out=traj.reward[t])      # G1, :90
         self.tc.add_(tacc.sum())                                                                          # :85
 
     def _capture(self):

@@ -200,6 +200,41 @@ int brl_duplicate_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_
                        const brl_table_info *table_b, uint8_t *obs, uint8_t *mask, float *rewards,
                        uint8_t *terminated, int32_t *current_player, void *stream);
 
+/* Per-board counters of the evaluators' step log — src/evaluation.py:649-735 (duplicate) / :299-378 (single table);
+ * index [board, team] with team 0 = players {0,1} (the "actor" side), team 1 = players {2,3}.  Any pointer may be NULL. */
+typedef struct brl_eval_stats {
+  float *illegal_prob_sum;  /* [n,2]    sum over the team's calls of the UNMASKED softmax mass on illegal actions */
+  int32_t *step_count;      /* [n,2]    calls made by the team */
+  int32_t *pass_count;      /* [n,2]    of which passes */
+  int32_t *bid_count;       /* [n,2,35] how often the team made each bid (or 0/1 "made it at all": bid_set) */
+} brl_eval_stats;
+
+/* One iteration of an evaluator's loop with the networks' logits as input — src/evaluation.py:146-169 (simple
+ * duplicate), :749-790 (duplicate with statistics), :380-403 (single table): per board the network of the team to act
+ * (players {0,1}: logits_team1, else logits_team2; float [n,38] with row strides) plays masked_pi.mode(); boards that
+ * are not finished update `stats`; then duplicate_step (table_a/table_b given, src/duplicate.py:147-192) or env.step
+ * (both NULL); cum_return float [n] += rewards[0], rewards_sum float [n,4] += rewards (either may be NULL);
+ * action_out int32 [n] (may be NULL).  Remaining outputs as brl_step. */
+int brl_eval_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                  const float *logits_team1, int64_t stride1, const float *logits_team2, int64_t stride2,
+                  const brl_table_info *table_a, const brl_table_info *table_b, const brl_eval_stats *stats,
+                  int bid_set, float *cum_return, float *rewards_sum, int32_t *action_out, uint8_t *obs,
+                  uint8_t *mask, float *rewards, uint8_t *terminated, int32_t *current_player, void *stream);
+
+/* End-of-run histograms behind make_evaluate's log_info — src/evaluation.py:841-1031 (make_terminated_log,
+ * make_contract_log) — as exact integer counts.  out: device int64 [BRL_EVAL_COUNTS], zeroed by the call:
+ *   out[t*80 + 0] pass-outs at table t (0 = A, 1 = B; table_b may be NULL)
+ *   out[t*80 + 1 + 2*team], out[t*80 + 2 + 2*team]  doubled / redoubled contracts declared by the team
+ *   out[t*80 + 5 + team] / out[t*80 + 7 + team]      boards with rewards[0] >= 0 / < 0 by declaring team (the
+ *                                                    reference's make_contract / down_contract, :951-984)
+ *   out[t*80 + 9]                                    sum of rewards[0] (table scores are integers)
+ *   out[t*80 + 10 + 35*team + bid]                   final contracts by declaring team and bid
+ *   out[160 + 35*team + bid]                         sum over boards of stats.bid_count (bid_count may be NULL)
+ *   out[230]                                         sum of _step_count of `state` (may be NULL) */
+#define BRL_EVAL_COUNTS 231
+int brl_eval_reduce(brl_handle *h, int64_t n, const brl_table_info *table_a, const brl_table_info *table_b,
+                    const int32_t *bid_count, const uint64_t *state, int64_t *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -632,6 +632,85 @@ def test_simple_duplicate_evaluate_replays_through_oracle(env, oracle, n):
     assert float(mean0) == 0.0 and float(win0) == 0.0
 
 
+def _replay_evaluate(oracle, rec_actions, rec_logits, seed, n, duplicate):
+    """Replays make_evaluate's loop through the oracle with the recorded greedy actions / logits and restates its
+    statistics with oracle/eval_stats.py (numpy, after src/evaluation.py:583-1031)."""
+    from oracle import Oracle
+    from oracle.eval_stats import StepLog
+    ref = oracle.init_random(n, seed=seed)
+    oA, oB = Oracle.table_info_from(ref), Oracle.table_info_from(ref)
+    cum = np.zeros(n, np.float32)
+    rsum = np.zeros((n, 4), np.float32)
+    log = StepLog(n)
+    for a_t, l_t in zip(rec_actions, rec_logits):
+        act, lg = to_np(a_t), to_np(l_t)
+        live = ref["terminated"] == 0
+        masked = np.where(ref["legal_action_mask"].astype(bool), lg, -np.inf)
+        assert np.array_equal(act[live], masked.argmax(1)[live])   # masked_pi.mode() of the acting team's network
+        log.update(ref["terminated"], ref["current_player"], ref["legal_action_mask"], lg, act, bid_set=not duplicate)
+        if duplicate:
+            oracle.duplicate_step(ref, act, oA, oB)
+        else:
+            oracle.step(ref, act)
+            rsum += ref["rewards"]
+        cum += ref["rewards"][:, 0]
+    assert ref["terminated"].all()
+    return ref, oA, oB, cum, rsum, log
+
+
+def _assert_log_info(got, want, names=None):
+    assert len(got) == len(want)
+    for i, (g, w) in enumerate(zip(got, want)):
+        g, w = to_np(g).astype(np.float64), np.asarray(w, np.float64)
+        # counts / n in fp32 on both sides, sums of <= 8192 terms: 1e-6 absolute + 1e-5 relative
+        assert g.shape == w.shape and np.allclose(g, w, rtol=1e-5, atol=1e-6), f"log_info[{i}]: {g} != {w}"
+
+
+@pytest.mark.parametrize("n,game_mode", [(640, "competitive"), (2048, "competitive"), (300, "free-run")])
+def test_duplicate_evaluate_with_statistics_matches_oracle(env, oracle, n, game_mode):
+    """§8f-2 make_evaluate(duplicate=True) (src/evaluation.py:607-1032) + make_evaluate_log (:1035-1115): every one of
+    the 23 log_info entries vs the numpy restatement fed by the oracle replay; Table_info snapshots bit-exact."""
+    from brl_amd.evaluation import make_evaluate, make_evaluate_log
+    from brl_amd.models import make_forward_pass
+    from oracle.eval_stats import EVAL_LOG_KEYS, duplicate_log_info
+    fp = make_forward_pass("relu", "DeepMind")
+    actor, opp = fp.init(3, device="cuda"), fp.init(4, device="cuda")
+    ra, rl = [], []
+    ev = make_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", opp, n, game_mode=game_mode, duplicate=True,
+                       sync_every=8, record_actions=ra, record_logits=rl)
+    log_info, A, B = ev(actor, 321)
+    torch.cuda.synchronize()
+    ref, oA, oB, cum, _, log = _replay_evaluate(oracle, ra, rl, 321, n, True)
+    for T, oT in ((A, oA), (B, oB)):
+        for f in ("terminated", "rewards", "last_bid", "last_bidder", "call_x", "call_xx"):
+            assert np.array_equal(to_np(getattr(T, f)).astype(np.float64), oT[f].astype(np.float64)), f
+    _assert_log_info(log_info, duplicate_log_info(cum, log, ref["step_count"], oA, oB))
+    d = make_evaluate_log(log_info)
+    assert list(d)[:19] == EVAL_LOG_KEYS and len(d) == 19 + 4 * 35
+    assert d["eval/actor_bid_probs/1C"] == float(log_info[6][0]) and d["eval/opp_contract_probs/7NT"] == float(log_info[9][34])
+    if game_mode == "free-run":
+        assert d["eval/opp_pass_ratio"] == 1.0 and d["eval/opp_illegal_action_probs"] == 0.0
+
+
+def test_single_table_evaluate_with_statistics_matches_oracle(env, oracle):
+    """make_evaluate(duplicate=False) (src/evaluation.py:229-605): 19-entry log_info, rewards accumulated on the state."""
+    from brl_amd.evaluation import make_evaluate
+    from brl_amd.models import make_forward_pass
+    from oracle.eval_stats import single_log_info
+    n = 900
+    fp = make_forward_pass("relu", "DeepMind")
+    actor, opp = fp.init(8, device="cuda"), fp.init(9, device="cuda")
+    ra, rl = [], []
+    ev = make_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", opp, n, duplicate=False, sync_every=4,
+                       record_actions=ra, record_logits=rl)
+    state, log_info = ev(actor, 55)
+    torch.cuda.synchronize()
+    ref, _, _, cum, rsum, log = _replay_evaluate(oracle, ra, rl, 55, n, False)
+    _assert_log_info(log_info, single_log_info(cum, log, ref))
+    ref["rewards"] = rsum   # state.replace(rewards=rewards) (:582)
+    assert_state_equal(state, ref, where="single-table evaluate final state")
+
+
 def test_simple_evaluate_runs_and_is_deterministic(env):
     from brl_amd.evaluation import make_simple_evaluate
     from brl_amd.models import make_forward_pass
