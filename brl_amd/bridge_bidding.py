@@ -122,23 +122,77 @@ class State:
         out["legal_action_mask"] = self.legal_action_mask
         return out
 
+    _BOARD_KEYS = ("_hand", "_dealer", "_vul_NS", "_vul_EW", "_shuffled_players")
+
     def replace(self, **kw):
-        """Only what the hot path uses: ``state.replace(rewards=, terminated=)`` of the macro-step
-        (src/utils.py:128).  Returns a new State sharing nothing with the old one."""
-        unknown = set(kw) - {"rewards", "terminated"}
+        """``state.replace(**fields)`` — the call sites of the reference: ``rewards=, terminated=`` of the macro-step
+        (src/utils.py:128) and of the evaluators (src/evaluation.py:591); the board fields ``_hand, _dealer, _vul_NS,
+        _vul_EW, _shuffled_players`` that ``_duplicate_init`` / ``wb5`` set on a freshly initialised state
+        (src/duplicate.py:120-128, wb5/utils.py:69-75, wb5/vis_pgx.py:51-56).  ``current_player`` and
+        ``legal_action_mask`` are DERIVED here (``_shuffled_players[(dealer + turn) % 4]``; the rule mask), so a value
+        passed for them must agree with the other fields (checked for ``current_player``); ``observation`` is recomputed.
+        Replacing ``_hand`` looks the new deal up in the handle's double-dummy table (pgx does that at the end of the
+        auction); a deal that is not in the table gets zero tricks.  Returns a new State sharing nothing with the old."""
+        known = set(self._BOARD_KEYS) | {"rewards", "terminated", "current_player", "legal_action_mask", "observation"}
+        unknown = set(kw) - known
         if unknown:
-            raise NotImplementedError(f"State.replace({sorted(unknown)}) is outside the hot path")
+            raise NotImplementedError(f"State.replace({sorted(unknown)}): not a field the reference ever replaces")
+        dev = self.packed.device
         packed = self.packed.clone()
-        cache = {k: v for k, v in self._cache.items() if k in ("observation", "legal_action_mask", "current_player")}
+        board = any(k in kw for k in self._BOARD_KEYS)
+        keep = ("current_player",) if not board else ()
+        if not board:
+            keep += ("observation", "legal_action_mask")
+        cache = {k: v for k, v in self._cache.items() if k in keep}
+        n = self.num_envs
+        sc = packed[:, 11]
+        if "_dealer" in kw:
+            d = torch.as_tensor(kw["_dealer"], device=dev).to(torch.int64).expand(n) & 3
+            sc = (sc & ~3) | d
+        if "_vul_NS" in kw:
+            sc = (sc & ~(1 << 2)) | (torch.as_tensor(kw["_vul_NS"], device=dev).to(torch.int64).expand(n) & 1) << 2
+        if "_vul_EW" in kw:
+            sc = (sc & ~(1 << 3)) | (torch.as_tensor(kw["_vul_EW"], device=dev).to(torch.int64).expand(n) & 1) << 3
+        if "_shuffled_players" in kw:
+            sp = torch.as_tensor(kw["_shuffled_players"], device=dev).to(torch.int64).expand(n, 4)
+            if not bool((sp.sort(dim=1).values == torch.arange(4, device=dev)).all()):
+                raise ValueError("_shuffled_players rows must be permutations of 0..3")
+            code = sp[:, 0] | (sp[:, 1] << 2) | (sp[:, 2] << 4) | (sp[:, 3] << 6)
+            sc = (sc & ~(0xFF << 4)) | (code << 4)
+        packed[:, 11] = sc
+        if "_hand" in kw:
+            hand = torch.as_tensor(kw["_hand"], device=dev).to(torch.int64).expand(n, 52)
+            if not bool((hand.sort(dim=1).values == torch.arange(52, device=dev)).all()):
+                raise ValueError("every _hand row must be a permutation of 0..51")
+            # observation bit of a pgx card id: rank * 4 + suit with ranks 2..A and suits C,D,H,S (wb5/utils.py:18-19)
+            idx = ((hand % 13 + 12) % 13) * 4 + (3 - hand // 13)
+            words = (torch.ones_like(idx) << (idx + 4)).reshape(n, 4, 13).sum(dim=2)
+            packed[:, 7:11] = words
+            tricks, rows = self.env.lookup_deal(hand.cpu().numpy())
+            t = torch.as_tensor(tricks, dtype=torch.int64, device=dev)           # [n,20] = [seat][C,D,H,S,NT]
+            nib = torch.zeros((n, 20), dtype=torch.int64, device=dev)
+            for seat in range(4):
+                for den in range(5):
+                    nib[:, seat * 5 + (4 - den)] = t[:, seat * 5 + den]         # nibble index of bridge_device.hpp
+            lo = sum(nib[:, i] << (4 * i) for i in range(16))
+            hi = sum(nib[:, 16 + i] << (4 * i) for i in range(4))
+            packed[:, 13] = lo
+            packed[:, 12] = (packed[:, 12] & 0xFFFFFFFF) | (hi << 32)
+            packed[:, 14] = (packed[:, 14] & ~0xFFFFFFFF) | torch.as_tensor(rows, dtype=torch.int64, device=dev) & 0xFFFFFFFF
         if "rewards" in kw:
-            r = kw["rewards"].to(torch.float32).round().to(torch.int64) & 0xFFFF
+            r = torch.as_tensor(kw["rewards"], device=dev).to(torch.float32).round().to(torch.int64) & 0xFFFF
             packed[:, 15] = r[:, 0] | (r[:, 1] << 16) | (r[:, 2] << 32) | (r[:, 3] << 48)
-            cache["rewards"] = kw["rewards"].to(torch.float32)
+            cache["rewards"] = torch.as_tensor(kw["rewards"], device=dev).to(torch.float32)
         if "terminated" in kw:
-            bit = kw["terminated"].to(torch.int64) << 25
-            packed[:, 11] = (packed[:, 11] & ~(1 << 25)) | bit
-            cache["terminated"] = kw["terminated"].to(torch.bool)
-        return State(self.env, packed, cache)
+            term = torch.as_tensor(kw["terminated"], device=dev)
+            packed[:, 11] = (packed[:, 11] & ~(1 << 25)) | (term.to(torch.int64) << 25)
+            cache["terminated"] = term.to(torch.bool)
+        out = State(self.env, packed, cache)
+        if "current_player" in kw:
+            want = torch.as_tensor(kw["current_player"], device=dev).to(torch.int32).expand(n)
+            if not bool((out.current_player == want).all()):
+                raise ValueError("current_player is derived: it must equal _shuffled_players[(_dealer + _turn) % 4]")
+        return out
 
 
 class BridgeBidding:
@@ -170,6 +224,7 @@ class BridgeBidding:
         check(L.brl_create(self.device.index, keys.ctypes.data if len(keys) else None,
                            values.ctypes.data if len(values) else None, len(keys), C.byref(self._h)))
         self._lut_len = len(keys)
+        self._lut_keys, self._lut_values, self._key_index = keys, values, None
         check(L.brl_set_rng(self._h, 0, self.env_offset))
 
     @staticmethod
@@ -196,6 +251,25 @@ class BridgeBidding:
         check(_capi.lib().brl_set_lut(self._h, keys.ctypes.data if len(keys) else None,
                                       values.ctypes.data if len(values) else None, len(keys)))
         self._lut_len = len(keys)
+        self._lut_keys, self._lut_values, self._key_index = keys, values, None
+
+    def lookup_deal(self, hand):
+        """hand int [n,52] (13 pgx card ids per seat) -> (tricks uint8 [n,20], LUT row int64 [n], -1 if absent): the
+        deal's entry in this handle's double-dummy table, found by its pgx key (host-side dictionary; not a hot path)."""
+        hand = np.asarray(hand, dtype=np.int64).reshape(-1, 52)
+        n = hand.shape[0]
+        if self._key_index is None:
+            self._key_index = {tuple(int(x) for x in k): i for i, k in enumerate(self._lut_keys)} if self._lut_len else {}
+        owner = np.zeros((n, 52), np.int64)
+        owner[np.arange(n)[:, None], hand] = np.repeat(np.arange(4), 13)[None, :]
+        keys = (owner.reshape(n, 4, 13) * (4 ** np.arange(12, -1, -1, dtype=np.int64))).sum(-1).astype(np.int32)
+        rows = np.array([self._key_index.get(tuple(int(x) for x in k), -1) for k in keys], np.int64)
+        tricks = np.zeros((n, 20), np.uint8)
+        found = rows >= 0
+        if found.any():
+            v = self._lut_values[rows[found]].astype(np.int64)                    # one word per declarer seat
+            tricks[found] = ((v[:, :, None] >> (4 * np.arange(4, -1, -1))) & 15).reshape(-1, 20)
+        return tricks, rows
 
     def seed(self, seed: int, env_offset: Optional[int] = None):
         self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF

@@ -36,3 +36,15 @@ def sum_over_ranks(value, device=None):
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def broadcast_int(value: int, device=None, src: int = 0) -> int:
+    """rank `src`'s integer on every rank (e.g. the index of the FSP / PFSP opponent rank 0 drew, ppo.py:376-460)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.broadcast(t, src=src)
+    return int(t.item())

@@ -2,7 +2,8 @@
 
 north_star assigns the MLP to PyTorch-ROCm (dense GEMMs -> rocBLAS/hipBLASLt MFMA kernels);
 only the architecture is mirrored here: "DeepMind" = 480 -> 4 x 1024 (ReLU) -> 38 logits + 1
-value (src/models.py:23-33), "FAIR" = the 200-wide residual net (src/models.py:34-69).
+value (src/models.py:23-33; "DeepMind_6" / "DeepMind_8" = the deeper variants of wb5/models.py:34-88),
+"FAIR" = the 200-wide residual net (src/models.py:34-69).
 ``make_forward_pass`` keeps the Haiku-style ``init / apply(params, x)`` surface
 (src/models.py:73-83); ``params`` is the torch module itself.
 """
@@ -28,8 +29,9 @@ class ActorCritic(nn.Module):
         super().__init__()
         self.model = model
         self.act = torch.relu if activation == "relu" else torch.tanh
-        if model == "DeepMind":
-            self.body = nn.ModuleList([_haiku_linear(obs_dim, 1024)] + [_haiku_linear(1024, 1024) for _ in range(3)])
+        if model.startswith("DeepMind"):  # "DeepMind" = 4 hidden layers; "DeepMind_6" / "DeepMind_8": wb5/models.py:34-88
+            depth = int(model.split("_")[1]) if "_" in model else 4
+            self.body = nn.ModuleList([_haiku_linear(obs_dim, 1024)] + [_haiku_linear(1024, 1024) for _ in range(depth - 1)])
             self.actor = _haiku_linear(1024, action_dim)
             self.critic = _haiku_linear(1024, 1)
         elif model == "FAIR":
@@ -44,7 +46,7 @@ class ActorCritic(nn.Module):
 
     def forward(self, x):
         a = self.act
-        if self.model == "DeepMind":
+        if self.model.startswith("DeepMind"):
             for lin in self.body:
                 x = a(lin(x))
         else:
@@ -91,7 +93,7 @@ class InferenceSnapshot:
 
     @staticmethod
     def make(module, dtype=None, env=None):
-        if getattr(module, "model", None) != "DeepMind" or module.act is not torch.relu:
+        if not str(getattr(module, "model", "")).startswith("DeepMind") or module.act is not torch.relu:
             return None
         return InferenceSnapshot(module, dtype, env)
 

@@ -834,6 +834,99 @@ def test_graphed_update_matches_eager_update():
     assert torch.allclose(outs[0][0], outs[1][0], atol=1e-5, rtol=1e-4)  # same updated parameters
 
 
+def test_state_replace_board_fields(env, oracle, dds):
+    """``state.replace(_hand=, _dealer=, _vul_NS=, _vul_EW=, _shuffled_players=, current_player=)`` on a fresh state
+    (src/duplicate.py:120-128, wb5/utils.py:69-75, wb5/vis_pgx.py:51-56) == the oracle's explicit deal; the replaced
+    hand's double-dummy tricks come from the handle's table; then the wb5 auction is played on it."""
+    n = 64
+    rng = np.random.default_rng(3)
+    rows = rng.integers(0, 1000, n)
+    hands = np.stack([oracle.key_to_hand(dds["keys"][r]) for r in rows])
+    tricks = dds["tricks"][rows].reshape(n, 20)
+    dealer = rng.integers(0, 4, n).astype(np.int32)
+    vns, vew = rng.integers(0, 2, n).astype(np.int32), rng.integers(0, 2, n).astype(np.int32)
+    perms = np.array([[0, 3, 1, 2], [2, 0, 3, 1], [1, 2, 0, 3], [3, 1, 2, 0]], np.int32)
+    shuf = perms[rng.integers(0, 4, n)]
+    st = env.init(99, num_envs=n)
+    cur = shuf[np.arange(n), dealer]
+    st = st.replace(_hand=torch.from_numpy(hands), _dealer=torch.from_numpy(dealer), _vul_NS=torch.from_numpy(vns).bool(),
+                    _vul_EW=torch.from_numpy(vew).bool(), _shuffled_players=torch.from_numpy(shuf),
+                    current_player=torch.from_numpy(cur))
+    ref = oracle.init_explicit(hands, dealer, vns, vew, shuf, tricks)
+    skip = {"lut_idx", "board_ctr"}
+    fields = set(__import__("tests.gpu_util", fromlist=["FIELD_MAP"]).FIELD_MAP) - skip
+    assert_state_equal(st, ref, fields=fields, where="replace(board fields)")
+    assert np.array_equal(to_np(st._lut_idx), rows)
+    for i, a in enumerate([0, 9, 11, 20, 1, 0, 22, 1, 2, 0, 0, 28, 0, 0, 0]):   # wb5/utils.py:61-64 (+ the closing pass)
+        st = env.step(st, torch.full((n,), a, dtype=torch.int32))
+        oracle.step(ref, np.full(n, a, np.int32))
+        assert_state_equal(st, ref, fields=fields, where=f"replace + call {i}")
+    assert ref["terminated"].all() and np.abs(ref["rewards"]).max() > 0
+    with pytest.raises(ValueError):
+        env.init(1, num_envs=4).replace(_dealer=2, current_player=torch.tensor([9, 9, 9, 9]))
+    with pytest.raises(NotImplementedError):
+        env.init(1, num_envs=4).replace(_turn=3)
+    # a deal that is not in the table: zero tricks, row -1
+    other = np.stack([np.random.default_rng(i).permutation(52) for i in range(4)])
+    s2 = env.init(1, num_envs=4).replace(_hand=torch.from_numpy(other))
+    assert (to_np(s2._dds_tricks) == 0).all() and (to_np(s2._lut_idx) == -1).all()
+    assert np.array_equal(np.sort(to_np(s2._hand).reshape(4, 4, 13), 2), np.sort(other.reshape(4, 4, 13), 2))
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_update_step_matches_numpy_restatement_gpu(graph):
+    """§8f-1 on the device: one full PPO minibatch step at minibatch 1024 (forward, _loss_fn, backward, global-norm
+    clip, Adam) vs the float64 numpy restatement, eager and hipGraph-replayed (tolerances in tests/test_update_cpu.py)."""
+    from tests.test_update_cpu import check_update_against_numpy
+    check_update_against_numpy("cuda", graph=graph, T=4, N=256)
+
+
+def test_ppo_loss_on_device_matches_numpy_at_minibatch_1024():
+    from brl_amd.models import make_forward_pass
+    from brl_amd.roll_out import Transition
+    from brl_amd.update import ppo_loss
+    from tests.test_update_cpu import CFG, fake_batch, numpy_loss
+    tb, adv, tgt = fake_batch(8, 128, seed=5)
+    flat = Transition(*[x.reshape((1024,) + x.shape[2:]).cuda() for x in tb])
+    fp = make_forward_pass("relu", "DeepMind")
+    net = fp.init(2, device="cuda")
+    for coef in (0.0, 0.25):
+        cfg = dict(CFG, illegal_action_l2norm_coef=coef)
+        with torch.no_grad():
+            logits, value = fp.apply(net, flat.obs.float())
+            total, aux = ppo_loss(cfg, logits, value, flat, adv.reshape(-1).cuda(), tgt.reshape(-1).cuda())
+        cpu = Transition(*[x.cpu() for x in flat])
+        want = numpy_loss(cfg, logits.cpu(), value.cpu(), cpu, adv.reshape(-1), tgt.reshape(-1))
+        assert abs(float(total) - want[0]) < 1e-5                              # fp32 reductions vs fp64
+        for k in range(3):
+            assert abs(float(aux[k]) - want[k + 1]) < 1e-5
+        assert abs(float(aux[5]) - want[4]) < 1e-4 * want[4]                   # illegal-action norm (SVD-free when coef == 0)
+
+
+def test_graphed_update_built_after_eager_steps_keeps_adam_state():
+    """A hipGraph minibatch step captured AFTER eager steps (optimizer moments / step counts already live) must continue
+    from that state: same parameters as staying eager."""
+    from brl_amd.models import make_forward_pass
+    from brl_amd.update import make_update_step
+    from tests.test_update_cpu import CFG, fake_batch
+    fp = make_forward_pass("relu", "DeepMind")
+    outs = []
+    for late_graph in (False, True):
+        net = fp.init(11, device="cuda")
+        rs = (net, None, None, None, 0, 5)
+        for it in range(3):
+            tb, adv, tgt = fake_batch(4, 256, seed=20 + it)
+            tb = type(tb)(*[x.cuda() for x in tb])
+            cfg = dict(CFG, minibatch_size=256, update_epochs=1, graph_update=(late_graph and it >= 1))
+            rs, _ = make_update_step(cfg, fp)(rs, tb, adv.cuda(), tgt.cuda())
+        if late_graph:
+            assert rs[1].get("graphed"), rs[1].get("graph_error")
+        outs.append(torch.cat([p.detach().reshape(-1) for p in net.parameters()]))
+        steps = {int(st["step"]) for st in rs[1]["opt"].state.values()}
+        assert steps == {12}   # 3 updates x 4 minibatches, none lost to the capture's warm-up
+    assert torch.allclose(outs[0], outs[1], atol=1e-5, rtol=1e-4)
+
+
 def test_longest_auction_319_calls(env, oracle, dds):
     """Maximum size of the domain: the 319-call auction fills every history nibble and the 9-bit turn counter."""
     from tests.test_oracle_kat import longest_auction

@@ -101,6 +101,44 @@ def test_update_step_shapes_and_progress():
     assert float(aux2[0][-1].mean()) < float(aux2[0][0].mean())
 
 
+def check_update_against_numpy(device, graph, T=4, N=256, seed=0):
+    """One PPO minibatch step (minibatch = the whole batch, one epoch, fresh Adam) of brl_amd.update on `device` vs
+    the float64 numpy restatement tests/ppo_numpy.py: losses, pre-clip gradient norm through the clipped update, and
+    every parameter after the step.  Tolerances: fp32 GEMMs vs fp64 — loss terms 2e-5 absolute; a parameter moves by
+    lr * g / (|g| + 1e-5) on its first Adam step, so 2 % of lr bounds the effect of a 1e-3 relative gradient error."""
+    from tests.ppo_numpy import adam_first_step, loss_and_grads, params_of
+    tb, adv, tgt = fake_batch(T, N, seed=seed)
+    B = T * N
+    cfg = dict(CFG, minibatch_size=B, update_epochs=1, lr=1e-3, graph_update=graph)
+    fp = make_forward_pass("relu", "DeepMind")
+    net = fp.init(4, device=device)
+    P0 = params_of(net)
+    flat = Transition(*[x.reshape((B,) + x.shape[2:]) for x in tb])
+    perm = torch.randperm(B, generator=torch.Generator(device=device).manual_seed(9 & 0x7FFFFFFF), device=device).cpu()
+    # (the loss is a mean over the minibatch: the permutation only changes the summation order)
+    want_total, want_aux, G = loss_and_grads(cfg, P0, flat.obs.numpy(), flat.legal_action_mask.numpy(),
+                                             flat.action.numpy().astype(np.int64), flat.value.double().numpy(),
+                                             flat.log_prob.double().numpy(), adv.reshape(-1).double().numpy(),
+                                             tgt.reshape(-1).double().numpy())
+    P1, gn = adam_first_step(cfg, P0, G)
+    tbd = Transition(*[x.to(device) for x in tb])
+    rs, (total, aux) = make_update_step(cfg, fp)((net, None, None, None, 0, 9), tbd, adv.to(device), tgt.to(device))
+    if graph:
+        assert rs[1].get("graphed"), rs[1].get("graph_error")
+    assert abs(float(total[0, 0]) - want_total) < 2e-5
+    for k in range(5):
+        assert abs(float(aux[k][0, 0]) - want_aux[k]) < 2e-5, k
+    got = params_of(net)
+    worst = max(max(np.abs(a - c).max(), np.abs(b - d).max()) for (a, b), (c, d) in zip(got, P1))
+    moved = max(np.abs(a - c).max() for (a, _), (c, _) in zip(P0, P1))
+    assert worst < 0.02 * cfg["lr"] and moved > 0.5 * cfg["lr"], (worst, moved, gn)
+    return perm
+
+
+def test_update_step_matches_numpy_restatement_cpu():
+    check_update_against_numpy("cpu", graph=False, T=2, N=128)
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
