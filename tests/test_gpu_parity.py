@@ -721,16 +721,34 @@ def test_simple_evaluate_runs_and_is_deterministic(env):
     assert r1 == r2 and abs(r1) <= 7600.0
 
 
-def test_ppo_loop_runs_end_to_end(env):
-    """BASELINE config 4 at toy size: roll_out -> calc_gae -> update_step for 2 updates."""
+def test_ppo_loop_runs_end_to_end(env, tmp_path):
+    """BASELINE config 4 at toy size — the ppo.py:348-570 loop: evaluations, FSP pool behind the threshold gate,
+    roll_out -> calc_gae -> update_step, the reference's log keys, LUT rotation after hash_size boards (G14),
+    checkpoints + final params / opt_state."""
+    from brl_amd import checkpoint as ckpt
     from brl_amd.train import DEFAULTS, train
-    cfg = dict(DEFAULTS, num_envs=256, num_steps=8, total_timesteps=256 * 8 * 2, minibatch_size=512, update_epochs=2,
-               lut_len=2000, num_eval_envs=128, eval_interval=2, lr=1e-4)
+    cfg = dict(DEFAULTS, num_envs=256, num_steps=8, total_timesteps=256 * 8 * 4, minibatch_size=512, update_epochs=2,
+               lut_len=2000, synthetic_lut_files=2, hash_size=300, num_eval_envs=128, num_prioritized_envs=64,
+               num_eval_step=2, lr=1e-4, ratio_model_zoo=1.0, prioritized_fictitious=True, log_path=str(tmp_path),
+               exp_name="t", graph_rollout=True)
     logs = []
     rs, hist = train(cfg, log=logs.append)
-    assert len(hist) == 2 and all(np.isfinite(h["total_loss"]) for h in hist)
-    assert hist[-1]["steps"] == 256 * 8 * 2 and "imp_vs_initial" in hist[-1]
-    assert abs(hist[-1]["imp_vs_initial"]) <= 24 and 0 <= hist[-1]["win_rate"] <= 1
+    assert len(hist) == 4 and all(np.isfinite(h["train/total_loss"]) for h in hist)
+    for key in ("train/score", "train/value_loss", "train/loss_actor", "train/illegal_action_loss", "train/policy_entropy",
+                "train/clipflacs", "train/approx_kl", "train/lr", "train/imp_opp_before", "train/imp_opp_after",
+                "board_num", "steps"):                                   # ppo.py:501-519
+        assert key in hist[-1], key
+    assert hist[-1]["steps"] == 256 * 8 * 4 and hist[0]["train/illegal_action_loss"] > 0
+    assert "eval/IMP_reward" in hist[0] and "eval/IMP_reward" in hist[2] and "eval/IMP_reward" not in hist[1]
+    assert abs(hist[-1]["train/imp_opp_after"]) <= 24
+    assert any("hash_table_next" in h for h in hist)                    # >= 300 boards finish per update: the table rotates
+    assert hist[0]["opponent"] == "latest" and any(h["opponent"].startswith("params-") for h in hist[1:])   # FSP pool in use
+    pool = os.path.join(str(tmp_path), "t", "rl_params")
+    assert ckpt.list_checkpoints(pool) == [f"params-{i:08}.pt" for i in (1, 2, 3, 4)]
+    assert os.path.exists(os.path.join(pool, "opt_state-00000004.pt"))
+    back = ckpt.load_params(os.path.join(pool, "params-00000004.pt"), "relu", "DeepMind", "cuda")
+    for a, b in zip(back.parameters(), rs[0].parameters()):
+        assert torch.equal(a, b)
 
 
 def test_macro_step_matches_manual_composition(env, oracle):
