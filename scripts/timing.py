@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 so = "/tmp/libbrl_timing.so"
 SRC = os.environ.get("SRC", os.path.join(ROOT, "brl_amd/csrc/brl_kernels.hip"))
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-                       "-DBRL_TIMING", "-o", so, SRC], stderr=subprocess.DEVNULL)
+                       "-DBRL_TIMING"] + os.environ.get("FLAGS", "").split() + ["-o", so, SRC], stderr=subprocess.DEVNULL)
 from brl_amd import _capi
 _capi.LIB_PATH = so
 import numpy as np, torch, ctypes as C
@@ -45,7 +45,7 @@ for cfg in os.environ.get("CFGS", "32x16").split(","):
         print('scorer wave: pass 1 %.0f cycles, pass 2 %.0f cycles per launch (rest of its work: pass 3 + bookkeeping)' % (sc[0], sc[1]))
         if int(os.environ.get('DBG', '0')) & 1024:
             pr = full[nblk * nw * 2:].reshape(nblk, nw, 32)[:, 3:, 29:32].sum((0, 1))
-            print('latency probe (emit waves): empty s_memtime pair %.0f cycles, pair around one ds_read_b32 %.0f cycles, n=%d' % (pr[0] / pr[2], pr[1] / pr[2], pr[2]))
+            print('emit waves, per sub-step: command read + image update + deals %.0f cycles, copy + bookkeeping %.0f cycles, n=%d' % (pr[0] / pr[2], pr[1] / pr[2], pr[2]))
         continue
     tot, wait = d[..., 0].mean(0), d[..., 1].mean(0)
     print(cfg, "cycles(100MHz ticks?) per wave role: total / barrier-wait / work")
