@@ -82,6 +82,8 @@ def lib() -> C.CDLL:
         "brl_eval_step": [_vp, _vp, _vp, i64, _vp, i64, _vp, i64, C.POINTER(TableInfoPtrs), C.POINTER(TableInfoPtrs),
                           C.POINTER(EvalStatsPtrs), i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
         "brl_eval_reduce": [_vp, i64, C.POINTER(TableInfoPtrs), C.POINTER(TableInfoPtrs), _vp, _vp, _vp, _vp],
+        "brl_ppo_loss": [i32, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, i64, f32, f32, f32, i32, i32, _vp, _vp, _vp, _vp, _vp],
+        "brl_ppo_stats": [i32, _vp, i64, _vp, f32, f32, _vp, _vp],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)
@@ -94,7 +96,7 @@ def lib() -> C.CDLL:
 EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_destroy", "brl_set_rng",
            "brl_init_random", "brl_init_from_deals", "brl_step", "brl_observe", "brl_get_fields",
            "brl_rollout_random", "brl_policy_step", "brl_policy_step_at", "brl_obs_cast", "brl_gae", "brl_imp_reward", "brl_duplicate_step",
-           "brl_eval_step", "brl_eval_reduce"]
+           "brl_eval_step", "brl_eval_reduce", "brl_ppo_loss", "brl_ppo_stats"]
 
 
 def check(rc: int) -> None:

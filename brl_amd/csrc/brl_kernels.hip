@@ -1394,14 +1394,15 @@ __global__ __launch_bounds__(64) void k_gae(const uint8_t *done, const float *va
 #pragma unroll
     for (int k = 0; k < GAE_CHUNK; k++) {
       int t = t1 - 1 - k;
-      if (t < 0) break;
-      int64_t i = (int64_t)t * n + e;
-      float nd = 1.0f - dn[k];
-      float delta = rw[k] + gamma * next_value * nd - vl[k];  // src/gae.py:28
-      gae = delta + gamma_lambda * nd * gae;                   // src/gae.py:29
-      adv[i] = gae;
-      tgt[i] = gae + vl[k];  // src/gae.py:39
-      next_value = vl[k];
+      if (t >= 0) {
+        int64_t i = (int64_t)t * n + e;
+        float nd = 1.0f - dn[k];
+        float delta = rw[k] + gamma * next_value * nd - vl[k];  // src/gae.py:28
+        gae = delta + gamma_lambda * nd * gae;                   // src/gae.py:29
+        adv[i] = gae;
+        tgt[i] = gae + vl[k];  // src/gae.py:39
+        next_value = vl[k];
+      }
     }
   }
 }
@@ -1462,6 +1463,172 @@ __global__ void k_get_fields(const uint64_t *state, int64_t n, brl_fields F) {
   if (F.lut_idx) F.lut_idx[e] = (int32_t)t.lut;
   if (F.board_ctr) F.board_ctr[e] = t.bctr;
   if (F.illegal) F.illegal[e] = (uint8_t)bits(t.sc, SC_ILLEGAL, 1);
+}
+
+// ---- PPO-clip loss and its gradient w.r.t. the network outputs, one launch (src/update.py:90-167) ------------
+// One wave per sample, lane a = action a.  Forward: masked log-softmax -> log-prob of the taken action, ratio,
+// clipped surrogate; clipped value loss; entropy of the masked policy; approx-KL / clip-fraction.  Backward: the
+// derivative of  loss_actor + vf_coef * value_loss - ent_coef * entropy  (means over the minibatch) w.r.t. logits
+// and value — what autograd would hand to the last Linear layers, so torch only runs the GEMMs.
+struct PpoArgs {
+  const float *logits;
+  int64_t ls;
+  const float *value;
+  const uint8_t *mask;
+  const int32_t *action;
+  const float *old_value, *old_logp, *gae, *tgt;
+  int64_t B;
+  float clip_eps, vf_coef, ent_coef;
+  int masked, value_clipping;
+  float *dlogits, *dvalue, *partials, *illp;
+};
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_ppo_loss(PpoArgs A) {
+  __shared__ float part[4][8];
+  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  const bool valid = b < A.B;
+  const bool in = lane < BRL_NUM_ACTIONS;
+  const int64_t bb = valid ? b : 0;
+  const float lg = in ? A.logits[bb * A.ls + lane] : 0.0f;
+  const bool legal = in && A.mask[bb * BRL_NUM_ACTIONS + lane] != 0;
+  const float invB = 1.0f / (float)A.B;
+  // masked policy (src/update.py:12-16, 132-135): log-softmax over the legal actions
+  const float mx = wave_max_f(legal ? lg : -INFINITY);
+  const float lse = logf(wave_sum_f(legal ? expf(lg - mx) : 0.0f));
+  const float lsm = legal ? (lg - mx) - lse : 0.0f;
+  const float p = legal ? expf(lsm) : 0.0f;
+  // the unmasked softmax: illegal-action probabilities (src/update.py:136-141) and, for the unmasked policy, log-prob
+  const float mx2 = wave_max_f(in ? lg : -INFINITY);
+  const float lse2 = logf(wave_sum_f(in ? expf(lg - mx2) : 0.0f));
+  const float lsm2 = in ? (lg - mx2) - lse2 : 0.0f;
+  const float p2 = in ? expf(lsm2) : 0.0f;
+  const int act = A.action[bb];
+  const float lsel = A.masked ? lsm : lsm2, psel = A.masked ? p : p2;
+  const float lp = __shfl(lsel, act & 63, 64);
+  const float logratio = lp - A.old_logp[bb];
+  const float ratio = expf(logratio);
+  const float g = A.gae[bb];
+  const float eps = A.clip_eps;
+  const float a1 = ratio * g, a2 = fminf(fmaxf(ratio, 1.0f - eps), 1.0f + eps) * g;
+  const float la = -fminf(a1, a2);
+  const bool inside = (ratio >= 1.0f - eps) && (ratio <= 1.0f + eps);
+  const float dratio = ((a1 < a2) || inside) ? -g : 0.0f;  // d(-min(a1, a2)) / d ratio (ties: both branches agree)
+  const float dlp = dratio * ratio * invB;
+  // value loss (src/update.py:48-60)
+  const float v = A.value[bb], ov = A.old_value[bb], t = A.tgt[bb];
+  float vl, dv;
+  if (A.value_clipping) {
+    const float dcl = fminf(fmaxf(v - ov, -eps), eps);
+    const float vc = ov + dcl;
+    const float l1 = (v - t) * (v - t), l2 = (vc - t) * (vc - t);
+    vl = 0.5f * fmaxf(l1, l2);
+    const bool unclipped = (v - ov >= -eps) && (v - ov <= eps);
+    dv = (l1 >= l2) ? (v - t) : (unclipped ? (vc - t) : 0.0f);
+  } else {
+    vl = 0.5f * (v - t) * (v - t);
+    dv = v - t;
+  }
+  // entropy of the masked policy, 0 log 0 = 0 (distrax)
+  const float H = -wave_sum_f((legal && p > 0.0f) ? p * lsm : 0.0f);
+  const float dH = legal ? -p * (lsm + H) : 0.0f;
+  const float onehot = (lane == act) ? 1.0f : 0.0f;
+  const bool live = A.masked ? legal : in;
+  const float dz = (live ? dlp * (onehot - psel) : 0.0f) - A.ent_coef * invB * dH;
+  if (valid && in) {
+    A.dlogits[b * BRL_NUM_ACTIONS + lane] = dz;
+    if (A.illp) A.illp[b * BRL_NUM_ACTIONS + lane] = legal ? 0.0f : p2;
+  }
+  if (lane == 0) {
+    if (valid) A.dvalue[b] = A.vf_coef * dv * invB;
+    part[wave][0] = valid ? vl : 0.0f;
+    part[wave][1] = valid ? la : 0.0f;
+    part[wave][2] = valid ? H : 0.0f;
+    part[wave][3] = valid ? (ratio - 1.0f) - logratio : 0.0f;
+    part[wave][4] = (valid && fabsf(ratio - 1.0f) > eps) ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {  // per-block partial sums in a fixed order (deterministic statistics)
+    const int k = (int)threadIdx.x;
+    A.partials[(int64_t)blockIdx.x * 8 + k] = (k < 5) ? ((part[0][k] + part[1][k]) + (part[2][k] + part[3][k])) : 0.0f;
+  }
+}
+
+// The logged statistics of one minibatch step, one block: column sums of brl_ppo_loss's per-block partials / batch
+// (fixed order: deterministic), total = loss_actor + vf_coef * value_loss - ent_coef * entropy, and the illegal-action
+// norm: largest singular value / 2 of the non-negative [B, 38] matrix P = softmax(logits) * ~mask from its 38 x 38 Gram
+// matrix G = P^T P (one small GEMM in torch): sqrt of G's top eigenvalue by 8 squarings (G^256 collapses onto the
+// Perron vector) + a Rayleigh quotient — `jnp.linalg.norm(illegal_action_probabilities, ord=2) / 2`
+// (src/update.py:138-141) without an SVD.
+//   out[0] total  [1] value_loss  [2] loss_actor  [3] entropy  [4] approx_kl  [5] clipfrac  [6] illegal-action norm / 2
+__global__ __launch_bounds__(512) void k_ppo_stats(const float *partials, int64_t nblk, int64_t batch, const float *G,
+                                                   float vf_coef, float ent_coef, float *out) {
+  constexpr int D = BRL_NUM_ACTIONS, DD = D * D;
+  __shared__ float g[DD], m[DD], t[DD], vec[D], red[2], st[8];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (wv >= 3) {  // waves 3..7: one statistic each — lane l adds rows l, l + 64, ... in order, then a fixed butterfly
+    const int k = wv - 3;
+    float s = 0.0f;
+    for (int64_t i = lane; i < nblk; i += 64) s += partials[i * 8 + k];
+    s = wave_sum_f(s);
+    if (lane == 0) st[k] = s / (float)batch;
+  }
+  for (int e = tid; e < DD; e += 512) g[e] = G ? G[e] : 0.0f;
+  __syncthreads();
+  auto trace_of = [&](const float *x) {  // wave 0, fixed butterfly
+    if (wv == 0) {
+      const float s = wave_sum_f((lane < D) ? x[lane * D + lane] : 0.0f);
+      if (lane == 0) red[0] = fmaxf(s, 1.17549435e-38f);
+    }
+    __syncthreads();
+    return red[0];
+  };
+  float tr = trace_of(g);
+  for (int e = tid; e < DD; e += 512) m[e] = g[e] / tr;
+  __syncthreads();
+  for (int it = 0; it < 8; it++) {
+    for (int e = tid; e < DD; e += 512) {
+      const int i = e / D, j = e - i * D;
+      float s = 0.0f;
+#pragma unroll 2
+      for (int k = 0; k < D; k++) s += m[i * D + k] * m[k * D + j];
+      t[e] = s;
+    }
+    __syncthreads();
+    tr = trace_of(t);
+    for (int e = tid; e < DD; e += 512) m[e] = t[e] / tr;
+    __syncthreads();
+  }
+  if (tid < D) {
+    float s = 0.0f;
+    for (int k = 0; k < D; k++) s += m[tid * D + k];
+    vec[tid] = s;
+  }
+  __syncthreads();
+  if (wv == 0) {  // Rayleigh quotient v^T G v / v^T v
+    float gv = 0.0f;
+    if (lane < D)
+      for (int k = 0; k < D; k++) gv += g[lane * D + k] * vec[k];
+    const float vi = (lane < D) ? vec[lane] : 0.0f;
+    const float num = wave_sum_f(vi * gv), den = wave_sum_f(vi * vi);
+    if (lane == 0) {
+      out[6] = 0.5f * sqrtf(fmaxf(num / fmaxf(den, 1.17549435e-38f), 0.0f));
+      out[0] = st[1] + vf_coef * st[0] - ent_coef * st[2];
+      out[1] = st[0]; out[2] = st[1]; out[3] = st[2]; out[4] = st[3]; out[5] = st[4];
+      out[7] = 0.0f;
+    }
+  }
 }
 
 // =====================================================================================
@@ -1859,6 +2026,33 @@ extern "C" int brl_eval_reduce(brl_handle *h, int64_t n, const brl_table_info *t
   HIP_TRY(hipMemsetAsync(out, 0, sizeof(int64_t) * EV_TOTAL, (hipStream_t)stream));
   hipLaunchKernelGGL(k_eval_reduce, dim3(thread_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, *table_a,
                      table_b ? *table_b : *table_a, table_b ? 1 : 0, bid_count, state, (long long *)out);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_ppo_loss(int device, const float *logits, int64_t logits_stride, const float *value, const uint8_t *mask,
+                            const int32_t *action, const float *old_value, const float *old_log_prob, const float *gae,
+                            const float *targets, int64_t batch, float clip_eps, float vf_coef, float ent_coef, int masked,
+                            int value_clipping, float *dlogits, float *dvalue, float *partials, float *illegal_probs,
+                            void *stream) {
+  NEED(batch > 0, "batch");
+  NEED(logits && value && mask && action && old_value && old_log_prob && gae && targets, "NULL input array");
+  NEED(dlogits && dvalue && partials, "NULL output array");
+  NEED(logits_stride >= BRL_NUM_ACTIONS, "logits_stride");
+  HIP_TRY(hipSetDevice(device));
+  PpoArgs A{logits, logits_stride, value, mask, action, old_value, old_log_prob, gae, targets, batch, clip_eps, vf_coef,
+            ent_coef, masked, value_clipping, dlogits, dvalue, partials, illegal_probs};
+  hipLaunchKernelGGL(k_ppo_loss, dim3(thread_grid(batch, 4)), dim3(256), 0, (hipStream_t)stream, A);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_ppo_stats(int device, const float *partials, int64_t batch, const float *gram, float vf_coef,
+                             float ent_coef, float *out, void *stream) {
+  NEED(partials && out && batch > 0, "partials / out / batch");
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(k_ppo_stats, dim3(1), dim3(512), 0, (hipStream_t)stream, partials, (int64_t)thread_grid(batch, 4), batch,
+                     gram, vf_coef, ent_coef, out);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

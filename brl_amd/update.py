@@ -93,6 +93,60 @@ def ppo_loss(config, logits, value, batch: Transition, gae, targets):
     return total, (value_loss.detach(), loss_actor.detach(), entropy.detach(), approx_kl, clipfrac, illegal_loss.detach())
 
 
+def fused_loss_ok(config, logits) -> bool:
+    """The one-launch HIP loss (``brl_ppo_loss``) covers everything except a non-zero illegal-action coefficient (its
+    spectral norm then needs a gradient); CPU tensors take the torch path."""
+    return bool(config.get("fused_loss", True)) and logits.is_cuda and not config.get("illegal_action_l2norm_coef", 0.0)
+
+
+def ppo_loss_fused(config, logits, value, batch: Transition, gae, targets):
+    """``_loss_fn`` (src/update.py:90-167) as ONE HIP launch that also returns d(total)/d(logits, value): torch then
+    differentiates only the GEMMs (``torch.autograd.backward([logits, value], grads)``) instead of ~120 elementwise
+    forward + backward launches per minibatch.  Returns (total, aux, (dlogits, dvalue)); total / aux are detached."""
+    from . import _capi
+    B = logits.shape[0]
+    dev = logits.device
+    logits_c = logits.detach()
+    if logits_c.stride(1) != 1:
+        logits_c = logits_c.contiguous()
+    value_c = value.detach().contiguous()
+    if config.get("reward_scaling", False):                  # src/update.py:31-44 (jnp std: ddof=0)
+        gae = (gae - gae.mean()) / (gae.std(unbiased=False) + 1e-8)
+    f32 = lambda x: x.to(torch.float32).contiguous()  # noqa: E731
+    mask = batch.legal_action_mask.contiguous()
+    action = batch.action.to(torch.int32).contiguous()
+    dlogits = torch.empty((B, 38), dtype=torch.float32, device=dev)
+    dvalue = torch.empty(B, dtype=torch.float32, device=dev)
+    partials = torch.empty(((B + 3) // 4, 8), dtype=torch.float32, device=dev)
+    illp = torch.empty((B, 38), dtype=torch.float32, device=dev)
+    out = torch.empty(8, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    L = _capi.lib()
+    old_v, old_lp, gae_c, tgt_c = f32(batch.value), f32(batch.log_prob), f32(gae), f32(targets)
+    _capi.check(L.brl_ppo_loss(dev.index, logits_c.data_ptr(), logits_c.stride(0), value_c.data_ptr(), mask.data_ptr(),
+                               action.data_ptr(), old_v.data_ptr(), old_lp.data_ptr(), gae_c.data_ptr(), tgt_c.data_ptr(), B,
+                               float(config["clip_eps"]), float(config["vf_coef"]), float(config["ent_coef"]),
+                               int(bool(config.get("actor_illegal_action_mask", True))),
+                               int(bool(config.get("value_clipping", True))), dlogits.data_ptr(), dvalue.data_ptr(),
+                               partials.data_ptr(), illp.data_ptr(), stream))
+    gram = illp.t() @ illp                                   # 38 x 38; its top eigenvalue = (largest singular value)^2
+    _capi.check(L.brl_ppo_stats(dev.index, partials.data_ptr(), B, gram.data_ptr(), float(config["vf_coef"]),
+                                float(config["ent_coef"]), out.data_ptr(), stream))
+    # out: total, value_loss, loss_actor, entropy, approx_kl, clipfrac, illegal-action norm / 2
+    return out[0], tuple(out[1 + k] for k in range(6)), (dlogits, dvalue)
+
+
+def loss_and_backward(config, logits, value, batch, gae, targets):
+    """forward loss + gradients into ``.grad`` of whatever produced (logits, value); returns (total, aux) detached."""
+    if fused_loss_ok(config, logits):
+        total, aux, grads = ppo_loss_fused(config, logits, value, batch, gae, targets)
+        torch.autograd.backward([logits, value], list(grads))
+        return total, aux
+    total, aux = ppo_loss(config, logits, value, batch, gae, targets)
+    total.backward()
+    return total.detach(), aux
+
+
 def allreduce_gradients(params: torch.nn.Module):
     """One flat all-reduce (mean) of every gradient — 14.7 MB for the DeepMind MLP."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -155,17 +209,16 @@ class GraphedMinibatch:
 
     def _step(self):
         logits, value = self.fp.apply(self.params, self.mb.obs.to(torch.float32))
-        total, aux = ppo_loss(self.cfg, logits, value, self.mb, self.gae, self.tgt)
         self.opt.zero_grad(set_to_none=False)
-        total.backward()
+        total, aux = loss_and_backward(self.cfg, logits, value, self.mb, self.gae, self.tgt)
         if self.cfg.get("global_gradient_clipping", True):
             torch.nn.utils.clip_grad_norm_(self.params.parameters(), self.cfg["max_grad_norm"])
         self.opt.step()
-        return total.detach(), torch.stack(aux)
+        return total, torch.stack(aux)
 
     def run(self, mb: Transition, gae, tgt):
-        for dst, src in zip(self.mb, mb):
-            dst.copy_(src)
+        for name in ("action", "value", "log_prob", "obs", "legal_action_mask"):  # what _loss_fn reads (not done / reward)
+            getattr(self.mb, name).copy_(getattr(mb, name))
         self.gae.copy_(gae)
         self.tgt.copy_(tgt)
         self.graph.replay()
@@ -220,16 +273,15 @@ def make_update_step(config, actor_forward_pass, optimizer=None):
                     row_a.append(aux_d)
                     continue
                 logits, value = actor_forward_pass.apply(params, mb.obs.to(torch.float32))   # G5
-                total, aux = ppo_loss(config, logits, value, mb, adv_s[sl], tgt_s[sl])
                 opt.zero_grad(set_to_none=True)
-                total.backward()
+                total, aux = loss_and_backward(config, logits, value, mb, adv_s[sl], tgt_s[sl])
                 allreduce_gradients(params)
                 if config.get("global_gradient_clipping", True):
                     torch.nn.utils.clip_grad_norm_(params.parameters(), config["max_grad_norm"])
                 opt.step()
                 if sched is not None:
                     sched.step()
-                row_t.append(total.detach())
+                row_t.append(total)
                 row_a.append(torch.stack(aux))
             totals.append(torch.stack(row_t))
             auxes.append(torch.stack(row_a))

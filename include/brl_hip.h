@@ -235,6 +235,28 @@ int brl_eval_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, 
 int brl_eval_reduce(brl_handle *h, int64_t n, const brl_table_info *table_a, const brl_table_info *table_b,
                     const int32_t *bid_count, const uint64_t *state, int64_t *out, void *stream);
 
+/* `_loss_fn` of the PPO update — src/update.py:90-167 — and its gradient w.r.t. the network's outputs in ONE launch
+ * (the reference lets jax.value_and_grad differentiate ~60 elementwise ops; here torch differentiates only the GEMMs).
+ * Inputs, one row per minibatch sample: logits float [batch,38] (row stride given), value float [batch], mask uint8
+ * [batch,38] (traj_batch.legal_action_mask), action int32, old_value / old_log_prob / gae / targets float [batch].
+ * masked != 0: the masked policy (src/update.py:12-16), else the unmasked one (:18-21); value_clipping: :48-60.
+ * Outputs: dlogits float [batch,38] and dvalue float [batch] = d(loss_actor + vf_coef * value_loss - ent_coef * entropy)
+ * / d(logits, value) with the 1/batch of the means folded in; partials float [ceil(batch/4), 8]: per-block sums of
+ * (value-loss term, actor-loss term, entropy, approx-KL term, clipped?) — column sums / batch are the logged
+ * statistics; illegal_probs float [batch,38] (may be NULL): softmax(logits) * ~mask (:136-137).
+ * No handle: `device` is the HIP device the arrays live on. */
+int brl_ppo_loss(int device, const float *logits, int64_t logits_stride, const float *value, const uint8_t *mask,
+                 const int32_t *action, const float *old_value, const float *old_log_prob, const float *gae,
+                 const float *targets, int64_t batch, float clip_eps, float vf_coef, float ent_coef, int masked,
+                 int value_clipping, float *dlogits, float *dvalue, float *partials, float *illegal_probs, void *stream);
+
+/* The logged statistics of that minibatch step (src/update.py:142-167), one launch: partials as written by brl_ppo_loss
+ * for `batch` samples; gram = P^T P (row-major float [38,38], may be NULL) of P = illegal_probs, from which
+ * `jnp.linalg.norm(P, ord=2) / 2` (:138-141) is obtained without an SVD (8 squarings + Rayleigh quotient).
+ * out: float [8] = total_loss, value_loss, loss_actor, entropy, approx_kl, clipfrac, illegal-action norm / 2, 0. */
+int brl_ppo_stats(int device, const float *partials, int64_t batch, const float *gram, float vf_coef, float ent_coef,
+                  float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

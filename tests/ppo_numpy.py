@@ -21,6 +21,54 @@ def forward(params, x):
     return logits, value, hs, zs
 
 
+def head_loss(cfg, logits, value, mask, action, old_value, old_log_prob, gae, tgt):
+    """`_loss_fn` on given network outputs (float64) -> (total, (value_loss, loss_actor, entropy, approx_kl, clipfrac),
+    dlogits, dvalue): the derivative w.r.t. the outputs, hand-derived.  cfg["actor_illegal_action_mask"] False = the
+    unmasked policy for the log-prob (src/update.py:18-21); the entropy is always the masked policy's (:132-135)."""
+    B = logits.shape[0]
+    eps = cfg["clip_eps"]
+    mask = mask.astype(bool)
+    masked = cfg.get("actor_illegal_action_mask", True)
+    ml = np.where(mask, logits, -np.inf)
+    ml = ml - ml.max(1, keepdims=True)
+    lsm = ml - np.log(np.exp(ml).sum(1, keepdims=True))
+    p = np.exp(lsm)
+    ul = logits - logits.max(1, keepdims=True)
+    lsm_u = ul - np.log(np.exp(ul).sum(1, keepdims=True))
+    idx = np.arange(B)
+    lsel, psel = (lsm, p) if masked else (lsm_u, np.exp(lsm_u))
+    lp = lsel[idx, action]
+    logratio = lp - old_log_prob
+    ratio = np.exp(logratio)
+    if cfg.get("value_clipping", True):
+        vc = old_value + np.clip(value - old_value, -eps, eps)
+        l1, l2 = (value - tgt) ** 2, (vc - tgt) ** 2
+        value_loss = 0.5 * np.maximum(l1, l2).mean()
+        dv = np.where(l1 >= l2, value - tgt, (vc - tgt) * (np.abs(value - old_value) < eps))
+    else:
+        value_loss = 0.5 * ((value - tgt) ** 2).mean()
+        dv = value - tgt
+    dv = dv / B * cfg["vf_coef"]
+    a1, a2 = ratio * gae, np.clip(ratio, 1 - eps, 1 + eps) * gae
+    loss_actor = -np.minimum(a1, a2).mean()
+    inside_r = (ratio > 1 - eps) & (ratio < 1 + eps)
+    dlp = -np.where((a1 < a2) | inside_r, gae, 0.0) / B * ratio
+    plogp = np.where(mask, p * np.where(mask, lsm, 0.0), 0.0)
+    ent_i = -plogp.sum(1)
+    entropy = ent_i.mean()
+    total = loss_actor + cfg["vf_coef"] * value_loss - cfg["ent_coef"] * entropy
+    onehot = np.zeros_like(p)
+    onehot[idx, action] = 1.0
+    dlogits = dlp[:, None] * (onehot - psel)
+    if masked:
+        dlogits = np.where(mask, dlogits, 0.0)
+    dH = -np.where(mask, p * (np.where(mask, lsm, 0.0) + ent_i[:, None]), 0.0)
+    dlogits = dlogits - cfg["ent_coef"] * dH / B
+    approx_kl = ((ratio - 1) - logratio).mean()
+    clipfrac = (np.abs(ratio - 1.0) > eps).mean()
+    return total, (value_loss, loss_actor, entropy, approx_kl, clipfrac), dlogits, dv
+
+
 def loss_and_grads(cfg, params, obs, mask, action, old_value, old_log_prob, gae, tgt):
     """-> (total, (value_loss, loss_actor, entropy, approx_kl, clipfrac), grads like params)"""
     B = obs.shape[0]

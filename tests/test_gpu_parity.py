@@ -921,6 +921,47 @@ def test_ppo_loss_on_device_matches_numpy_at_minibatch_1024():
         assert abs(float(aux[5]) - want[4]) < 1e-4 * want[4]                   # illegal-action norm (SVD-free when coef == 0)
 
 
+@pytest.mark.parametrize("masked,vclip,B", [(True, True, 1024), (False, True, 1024), (True, False, 333)])
+def test_fused_ppo_loss_kernel_matches_numpy(masked, vclip, B):
+    """brl_ppo_loss / brl_spectral_half_norm (one launch each) vs the float64 restatement tests/ppo_numpy.head_loss:
+    the five statistics, the illegal-action norm and the gradient w.r.t. logits / value that autograd would produce.
+    Tolerances: fp32 exp / log and 1024-term sums vs fp64 — 2e-6 absolute on per-sample gradients of size <= 1e-3."""
+    from brl_amd.roll_out import Transition
+    from brl_amd.update import ppo_loss, ppo_loss_fused
+    from tests.ppo_numpy import head_loss
+    from tests.test_update_cpu import CFG, fake_batch
+    T = 1
+    tb, adv, tgt = fake_batch(T, B, seed=17)
+    flat = Transition(*[x.reshape((B,) + x.shape[2:]).cuda() for x in tb])
+    g = torch.Generator().manual_seed(3)
+    logits = (torch.randn(B, 38, generator=g) * 1.5).cuda().requires_grad_(True)
+    value = (torch.randn(B, generator=g) * 0.2).cuda().requires_grad_(True)
+    # a stored log_prob near the current one, so that ratios straddle the clip range
+    with torch.no_grad():
+        lsm = torch.log_softmax(torch.where(flat.legal_action_mask, logits, torch.full_like(logits, -1e30)) if masked else logits, -1)
+        old_lp = lsm.gather(1, flat.action.long()[:, None])[:, 0] + 0.3 * torch.randn(B, generator=g).cuda()
+    flat = flat._replace(log_prob=old_lp)
+    cfg = dict(CFG, actor_illegal_action_mask=masked, value_clipping=vclip)
+    total, aux, (dl, dv) = ppo_loss_fused(cfg, logits, value, flat, adv.reshape(-1).cuda(), tgt.reshape(-1).cuda())
+    want = head_loss(cfg, logits.detach().double().cpu().numpy(), value.detach().double().cpu().numpy(),
+                     to_np(flat.legal_action_mask), to_np(flat.action).astype(np.int64), flat.value.double().cpu().numpy(),
+                     old_lp.double().cpu().numpy(), adv.reshape(-1).double().numpy(), tgt.reshape(-1).double().numpy())
+    assert abs(float(total) - want[0]) < 2e-5
+    for k in range(5):
+        assert abs(float(aux[k]) - want[1][k]) < 2e-5, k
+    assert 0.05 < float(aux[4]) < 0.95                                       # both clip branches exercised
+    assert np.abs(to_np(dl).astype(np.float64) - want[2]).max() < 2e-6 and np.abs(want[2]).max() > 1e-5
+    assert np.abs(to_np(dv).astype(np.float64) - want[3]).max() < 2e-6
+    p = torch.softmax(logits.detach().double(), -1) * (~flat.legal_action_mask)
+    sv = float(torch.linalg.matrix_norm(p, ord=2)) / 2
+    assert abs(float(aux[5]) - sv) < 1e-4 * sv                               # SVD-free norm: 1e-4 relative
+    # and against torch autograd on the unfused loss (same device, fp32)
+    t2, aux2 = ppo_loss(cfg, logits, value, flat, adv.reshape(-1).cuda(), tgt.reshape(-1).cuda())
+    t2.backward()
+    assert torch.allclose(logits.grad, dl, atol=2e-6) and torch.allclose(value.grad, dv, atol=2e-6)
+    assert abs(float(t2) - float(total)) < 2e-5
+
+
 def test_graphed_update_built_after_eager_steps_keeps_adam_state():
     """A hipGraph minibatch step captured AFTER eager steps (optimizer moments / step counts already live) must continue
     from that state: same parameters as staying eager."""
