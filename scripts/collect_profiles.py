@@ -6,7 +6,7 @@ tag, rnd = sys.argv[1], sys.argv[2]
 src = os.path.join("gpurun_out", tag)
 dst = os.path.join("profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-for f in ("kernel_stats.csv", "pmc_raw.json", "bench.json", "pytest_gpu.txt", "smoke.txt", "bench_K1.json", "bench_K2.json", "bench_K8.json"):
+for f in ("kernel_stats.csv", "pmc_raw.json", "pmc_mix.txt", "bench.json", "pytest_gpu.txt", "smoke.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
 pmc = json.load(open(os.path.join(src, "pmc_raw.json")))
