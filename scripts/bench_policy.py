@@ -42,8 +42,13 @@ opt_state = make_optimizer(cfg, params)
 t, _ = sync_time(lambda: upd((params, opt_state, rs2[2], rs2[3], rs2[4], 0), traj, adv, tgt), 2)
 res["update_one_epoch_ms"] = round(t * 1e3, 1)
 res["update_per_minibatch_ms"] = round(t * 1e3 / cfg["num_minibatches"], 3)
-ev = make_simple_duplicate_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", N)
+eval_env = brl_amd.BridgeBidding(lut=synthetic_lut(100000, 1))
+ev = make_simple_duplicate_evaluate(eval_env, "relu", "DeepMind", "relu", "DeepMind", N)
 t, (info, _, _) = sync_time(lambda: ev(params, opp, 3), 2)
 res["duplicate_eval_8192_boards_ms"] = round(t * 1e3, 1)
 res["duplicate_eval_boards_per_s"] = round(N / t)
+from brl_amd.evaluation import make_evaluate
+ev2 = make_evaluate(eval_env, "relu", "DeepMind", "relu", "DeepMind", opp, N, duplicate=True)
+t, _ = sync_time(lambda: ev2(params, 3), 2)
+res["duplicate_eval_with_statistics_8192_boards_ms"] = round(t * 1e3, 1)
 print(json.dumps(res))
