@@ -20,7 +20,8 @@ from bench import synthetic_lut
 N, T = 8192, 32
 keys, values = synthetic_lut(100000, 0)
 env = brl_amd.BridgeBidding(lut=(keys, values))
-trajs = [alloc_transition(T, N, env.device) for _ in range(3)]
+NB = int(os.environ.get('NBUF', '3'))
+trajs = [alloc_transition(T, N, env.device) for _ in range(NB)]
 st = env.init(0, num_envs=N)
 ptrs = []
 for tr in trajs:
@@ -32,7 +33,7 @@ lo = torch.empty((N, 480), dtype=torch.bool, device=env.device); lm = torch.empt
 tc = torch.zeros(1, dtype=torch.int64, device=env.device)
 s = torch.cuda.current_stream()
 def launch(i):
-    _capi.check(_capi.lib().brl_rollout_random(env._h, st.packed.data_ptr(), N, T, 1, (i * T) & 0xFFFFFFFF, 7600.0, C.byref(ptrs[i % 3]),
+    _capi.check(_capi.lib().brl_rollout_random(env._h, st.packed.data_ptr(), N, T, 1, (i * T) & 0xFFFFFFFF, 7600.0, C.byref(ptrs[i % NB]),
                                                lo.data_ptr(), lm.data_ptr(), tc.data_ptr(), s.cuda_stream))
 launch(0); torch.cuda.synchronize()
 h = hashlib.sha256()
@@ -47,7 +48,23 @@ for rep in range(5):
     for i in range(128): launch(10 + rep * 128 + i)
     e1.record(s); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1) / 128 * 1e3)
-print(json.dumps({"us": round(float(np.median(ts)), 2), "min": round(min(ts), 2), "sha": h.hexdigest()[:12]}))
+iso = []
+for i in range(40):   # isolated launches: one event pair each, host sync in between
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record(s); launch(1000 + i); e1.record(s); torch.cuda.synchronize()
+    iso.append(e0.elapsed_time(e1) * 1e3)
+from brl_amd.gae import gae_scan
+lv = torch.zeros(N, dtype=torch.float32, device=env.device)
+mix = []
+for rep in range(3):  # the bench's step: rollout + GAE alternating, 128 steps per event pair
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record(s)
+    for i in range(128):
+        launch(2000 + rep * 128 + i); tb = trajs[i % NB]; gae_scan(env, tb.done, tb.value, tb.reward, lv, 1.0, 0.95)
+    e1.record(s); torch.cuda.synchronize()
+    mix.append(e0.elapsed_time(e1) / 128 * 1e3)
+print(json.dumps({"us": round(float(np.median(ts)), 2), "min": round(min(ts), 2), "iso": round(float(np.median(iso)), 2),
+                  "step": round(float(np.median(mix)), 2), "sha": h.hexdigest()[:12]}))
 '''
 
 def main():
@@ -63,18 +80,19 @@ def main():
     if "--run" in sys.argv:
         res = {n: [] for n, _ in variants}
         sha = {}
+        extra = {}
         for rep in range(int(os.environ.get("REPS", "3"))):
             for name, _ in variants:
                 code = f"ROOT={ROOT!r}\nLIB={os.path.join(VDIR, name + '.so')!r}\n" + BODY
-                r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+                r = subprocess.run(["timeout", "-k", "5", "90", sys.executable, "-c", code], capture_output=True, text=True)
                 try:
                     d = json.loads(r.stdout.strip().splitlines()[-1])
-                    res[name].append(d["us"]); sha[name] = d["sha"]
+                    res[name].append(d["us"]); sha[name] = d["sha"]; extra.setdefault(name, []).append((d["iso"], d["step"]))
                 except Exception:
                     print(name, "FAILED", r.stderr[-800:])
         base = sha.get(variants[0][0])
         for name, _ in variants:
             v = sorted(res[name])
-            print(f"{name:14s} median {v[len(v)//2] if v else None}  all {v}  {'same-bytes' if sha.get(name) == base else 'DIFFERENT OUTPUT'}")
+            print(f"{name:14s} median {v[len(v)//2] if v else None}  all {v}  isolated/step(rollout+gae) {extra.get(name)}  {'same-bytes' if sha.get(name) == base else 'DIFFERENT OUTPUT'}")
 
 main()

@@ -367,16 +367,14 @@ constexpr uint32_t NO_SLOT = 0xFFu;  // scorer: the table still plays the board 
 // word 1: scalar word `sc` right after sub-step s-1 (before any re-deal)
 // word 2: legal mask of state s, low 32 | word 3: [5:0] legal high ; [13:8] action of sub-step s-1
 
-// Command batches: ONE slot first, so that the follower waves — and with them the HBM stores, which the launch is
-// bound by once its output is larger than the Infinity Cache — start after one sub-step instead of eight; then 3, 4 and
-// 8s: every batch costs the loader (Philox calls of a refill) and the scorer (passes 2 / 3) a fixed ~3 k cycles, more
-// than the logic wave needs for one or two sub-steps, so 1- and 2-slot batches after the first are paced by them
-// (1,1,2,4,8,.. -> 1,3,4,8,..: 34.0 -> 32.9 us, profiles/r02).  Slot s is entry s - ws_bstart(b) of batch b.
-__device__ __forceinline__ int ws_bstart(int b) { return (b < 3) ? ((b == 0) ? 0 : ((b == 1) ? 1 : 4)) : 8 * (b - 2); }  // 0,1,4,8,16,24,..
-__device__ __forceinline__ int ws_blen(int b) { return (b < 3) ? ((b == 0) ? 1 : ((b == 1) ? 3 : 4)) : WS_BATCH; }           // 1,3,4,8,8,..
+// Command batches: short at the start so that the follower waves — and with them the HBM stores, which
+// the kernel is bound by — start after ONE sub-step instead of eight; slot s is entry s - ws_bstart(b)
+// of batch b.
+__device__ __forceinline__ int ws_bstart(int b) { return (b < 4) ? ((1 << b) >> 1) : 8 * (b - 3); }  // 0,1,2,4,8,16,24,..
+__device__ __forceinline__ int ws_blen(int b) { return (b < 4) ? ((b == 0) ? 1 : (1 << (b - 1))) : WS_BATCH; }  // 1,1,2,4,8,8,..
 __device__ __forceinline__ int ws_nbatch(int total) {  // batches needed for slots 0..total
-  if (total < 8) return (total < 1) ? 1 : ((total < 4) ? 2 : 3);
-  return 3 + (total - 8) / WS_BATCH + 1;
+  if (total < 8) return (total < 1) ? 1 : ((total < 2) ? 2 : ((total < 4) ? 3 : 4));
+  return 4 + (total - 8) / WS_BATCH + 1;
 }
 
 __device__ __forceinline__ void lds_barrier() {
@@ -442,9 +440,13 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   __shared__ __attribute__((aligned(16))) uint8_t img[TPB * TABLE_BYTES];
   __shared__ __attribute__((aligned(16))) uint32_t cmd[2][B][TPB][CMD_WORDS];
   __shared__ __attribute__((aligned(16))) uint32_t ring[TPB][WS_RING][RING_WORDS];
-  __shared__ int ring_ready;  // set by the loader wave once the first three boards of every table are in the ring
+  __shared__ int ring_ready;  // set by the loader wave once the first two boards of every table are in the ring
   __shared__ uint32_t udraw[2][WS_BATCH][TPB];  // action draws of a batch, precomputed by the loader wave
   __shared__ float s_neglog[BRL_NUM_ACTIONS + 2];
+#ifdef BRL_PADLDS
+  __shared__ uint8_t padlds[BRL_PADLDS];
+  if (A.debug == 12345) padlds[threadIdx.x] = 1;  // (keeps the allocation alive)
+#endif
   const int tid = (int)threadIdx.x;
   // role index; hardware wave w runs on SIMD w % 4, and with NW = 11 SIMD 3 hosts only two waves: the scorer (the
   // longest chain after the logic wave) takes hardware wave 3 there, the first emit role hardware wave 2
@@ -471,12 +473,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   uint32_t nb = 0, nb0 = 0, pbase = 0, pidx[3] = {0, 0, 0}, pscb[3] = {0, 0, 0};
   brl_u32x4 pha[3], phb[3], pv[3];  // (native vectors: HIP's uint4 struct arrays are not promoted to registers here)
   uint64_t ctr_word = 0;
-  // (loader) lanes 32..63 shadow tables 0..31 in the prologue: they fetch each table's THIRD board in the same Philox
-  // pass in which lanes 0..31 fetch the first — the wave is half empty otherwise (TPB = 32 tables)
-  const int lt = c.lane & (TPB - 1);
-  const bool lup = (TPB == 32) && (c.lane >= TPB);
-  const bool lvalid = (table0 + lt < A.n);
-  if (wave == 1 && lvalid) ctr_word = A.state[(table0 + lt) * 16 + W_CTR];  // issued now, needed after the barrier
+  if (wave == 1 && valid) ctr_word = A.state[(table0 + tl) * 16 + W_CTR];  // issued now, needed after the barrier
   // action draws (Philox is state-independent, so it does not belong on the logic wave's dependency
   // chain): the loader computes udraw[b & 1][j][table] for command batch b one batch ahead of the logic wave
   uint32_t rbk[4] = {0, 0, 0, 0};
@@ -496,31 +493,27 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   if (tid == 0) ring_ready = 0;
   __syncthreads();  // images and the draws of batch 0 are in LDS; the ring follows (ring_ready)
   uint32_t pcount = 0;  // (loader) boards whose loads are in flight
-  if (wave == 1 && lvalid) {
-    // the first three boards of every table: loads ISSUED here, committed to the ring after the first batch
+  if (wave == 1 && valid) {
+    // the first two boards of every table: loads ISSUED here, committed to the ring after the first batch
     // barrier (loader loop) — everybody else has already started; only a DEAL needs the ring, and the logic
-    // wave checks ring_ready before its first one.  (Three: a table that deals at sub-steps 0 and 4 reads the third
-    // entry during the third batch, just after the refill issued behind the first barrier is committed.)
-    // Lanes 0..31: boards nb0, nb0 + 1; lanes 32..63: board nb0 + 2 of table lane - 32.
-    const uint64_t eid = A.env_offset + (uint64_t)(table0 + lt);
+    // wave checks ring_ready before its first one
     nb0 = (uint32_t)(ctr_word >> 32) + 1u;
-    pbase = nb0 + (lup ? 2u : 0u);
-    pcount = lup ? 1u : 2u;
+    nb = nb0;
+    pbase = nb;
+    pcount = 2;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-      if ((uint32_t)k < pcount) {
-        board_params(A.g, eid, pbase + (uint32_t)k, A.lut.len, pidx[k], pscb[k]);
-        pha[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)pidx[k]];
-        phb[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)pidx[k] + 1];
-        pv[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.values)[pidx[k]];
-      }
+      board_params(A.g, env_id, nb + (uint32_t)k, A.lut.len, pidx[k], pscb[k]);
+      pha[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)pidx[k]];
+      phb[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)pidx[k] + 1];
+      pv[k] = reinterpret_cast<const brl_u32x4 *>(A.lut.values)[pidx[k]];
     }
-    nb = nb0 + ((TPB == 32) ? 3u : 2u);
+    nb += 2u;
   }
 
   if (wave == 1) {
     // ------------------------------------------------------------------ loader wave
-    // (its first three boards were fetched in the prologue, before the workgroup's first barrier)
+    // (its first two boards were fetched in the prologue, before the workgroup's first barrier)
     uint32_t dealt_total = 0, dealt_prev_total = 0;
     for (int bi = 0; bi < nbatch; bi++) {
       if (bi + 1 < nbatch) draws(bi + 1);  // the logic wave starts batch bi+1 right after this barrier
@@ -529,7 +522,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         if ((uint32_t)k < pcount) {
-          uint4 *dst = reinterpret_cast<uint4 *>(&ring[lt][(pbase + (uint32_t)k) % WS_RING][0]);
+          uint4 *dst = reinterpret_cast<uint4 *>(&ring[tls][(pbase + (uint32_t)k) % WS_RING][0]);
           brl_u32x4 *dv = reinterpret_cast<brl_u32x4 *>(dst);
           dv[0] = pha[k];
           dv[1] = phb[k];
@@ -538,7 +531,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
         }
       }
       pcount = 0;
-      if (bi == 0) {  // the first three boards are in the ring now
+      if (bi == 0) {  // the first two boards are in the ring now
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (c.lane == 0) __hip_atomic_store(&ring_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }

@@ -1,0 +1,263 @@
+/*
+ * brl_hip.h — C-ABI of libbrl_hip.so: the MI355X-native (gfx950) bridge-bidding
+ * environment + PPO-rollout hot path of harukaki/brl.
+ *
+ * The reference has no FFI layer: its boundary for this path is the Python API of
+ * pgx.bridge_bidding plus src/{utils,roll_out,duplicate,gae}.py.  Each entry point below
+ * names the reference interface it replaces (file:line under /root/reference).  The
+ * Python host mirror in brl_amd/ binds these with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (BRL_E_*); the message is in the
+ *     thread-local brl_last_error().
+ *   - unless a parameter says "host", every pointer is a DEVICE pointer on the handle's
+ *     GPU, owned by the caller (e.g. torch tensors: tensor.data_ptr()).  The library owns
+ *     only the handle, its device copy of the double-dummy LUT (plus the packed hand words it
+ *     derives from the keys at upload, 32 B per row) and a small constant table.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and the compute entry points never
+ *     synchronise (pass torch.cuda.current_stream().cuda_stream).  The three functions WITHOUT a stream
+ *     argument that change what launches read — brl_create, brl_set_lut, brl_set_rng (when the values change) —
+ *     call hipDeviceSynchronize first: kernels in flight may still read the old table / key.  Every entry point
+ *     makes the handle's device current (hipSetDevice).
+ *   - a handle is not thread-safe; use one per (device, stream).
+ *   - per-table state is caller-owned and opaque: BRL_STATE_WORDS x uint64 per table
+ *     (128 B, bit-packed: DESIGN.md "Data layout").  state_in == state_out is allowed.
+ *   - batch arrays are batch-major [n, ...]; rollout outputs are time-major [T, n, ...]
+ *     exactly like the reference's traj_batch (src/roll_out.py:105-107).
+ *   - bool arrays are 1 byte per element (0/1), like the reference's jnp.bool_ arrays.
+ */
+#ifndef BRL_HIP_H
+#define BRL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BRL_STATE_WORDS 16  /* uint64 words per table */
+#define BRL_OBS_SIZE 480    /* env.observation_shape == (480,)  ppo.py:241 */
+#define BRL_NUM_ACTIONS 38  /* 0 Pass, 1 X, 2 XX, 3.. bids      src/duplicate.py:9-12 */
+
+#define BRL_OK 0
+#define BRL_E_ARG (-1)     /* bad argument */
+#define BRL_E_HIP (-2)     /* a HIP runtime call failed */
+#define BRL_E_NOLUT (-3)   /* a reset was requested but the handle has no LUT */
+
+typedef struct brl_handle brl_handle;
+
+const char *brl_last_error(void);
+int brl_version(void);
+
+/* BridgeBidding(dds_results_table_path)  — ppo.py:303, pgx.bridge_bidding.BridgeBidding.
+ * lut_keys/lut_values: HOST pointers, int32 [lut_len,4] each, pgx packing (key: one word
+ * per suit S,H,D,C, 13 base-4 digits = owner seat; value: one word per declarer seat, 5
+ * hex digits = tricks in C,D,H,S,NT).  lut_len may be 0 (explicit deals only). */
+int brl_create(int device, const int32_t *lut_keys, const int32_t *lut_values, int64_t lut_len,
+               brl_handle **out);
+/* LUT rotation — ppo.py:525-549 swaps the hash table; same arguments as brl_create.  Synchronises the device; a
+ * table of the same length is copied over the old one (device addresses unchanged). */
+int brl_set_lut(brl_handle *h, const int32_t *lut_keys, const int32_t *lut_values, int64_t lut_len);
+int brl_destroy(brl_handle *h);
+
+/* Seed of the counter-based RNG (Philox4x32-10) and the global index of this handle's
+ * table 0 (rank * num_envs when env shards are spread over GPUs).  Replaces the PRNGKey
+ * plumbing of ppo.py:314-333 / src/utils.py:49.  brl_init_random / brl_step / brl_rollout_random take the key by
+ * value at launch; brl_policy_step[_at] read it (and the LUT) from a device-resident mirror, so a hipGraph replay of
+ * a captured policy sub-step follows later brl_set_rng / brl_set_lut calls. */
+int brl_set_rng(brl_handle *h, uint64_t seed, uint64_t env_offset);
+
+/* jax.vmap(env.init)(keys)  — ppo.py:305,318.  Deals board number `board_ctr0` of every
+ * table's stream: uniform LUT row, dealer, vulnerabilities, one of the 8 team-preserving
+ * seatings. */
+int brl_init_random(brl_handle *h, uint64_t *state, int64_t n, uint32_t board_ctr0, void *stream);
+
+/* Explicit deals — the fields _duplicate_init copies (src/duplicate.py:120-128).
+ * hand int32 [n,52] (13 pgx card ids per seat N,E,S,W), dealer int32 [n], vul_ns/vul_ew
+ * uint8 [n], shuffled_players int32 [n,4] (seat -> player id), tricks uint8 [n,20]
+ * ([declarer seat][C,D,H,S,NT]). */
+int brl_init_from_deals(brl_handle *h, uint64_t *state, int64_t n, const int32_t *hand,
+                        const int32_t *dealer, const uint8_t *vul_ns, const uint8_t *vul_ew,
+                        const int32_t *shuffled_players, const uint8_t *tricks, void *stream);
+
+/* env.step(state, action) — src/utils.py:44 (pgx core.Env.step); with autoreset != 0 it is
+ * auto_reset(env.step, env.init) — src/utils.py:9-58.  action int32 [n].
+ * Optional outputs for the NEW state (any may be NULL): obs uint8 [n,480] and
+ * mask uint8 [n,38] of the new current player, rewards float [n,4] by player id,
+ * terminated uint8 [n], current_player int32 [n]. */
+int brl_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+             const int32_t *action, int autoreset, uint8_t *obs, uint8_t *mask, float *rewards,
+             uint8_t *terminated, int32_t *current_player, void *stream);
+
+/* _observe(state, player_id) — src/duplicate.py:6,134; player_id int32 [n] or NULL for
+ * state.current_player.  obs uint8 [n,480]; mask uint8 [n,38] = state.legal_action_mask
+ * (either may be NULL). */
+int brl_observe(brl_handle *h, const uint64_t *state, int64_t n, const int32_t *player_id,
+                uint8_t *obs, uint8_t *mask, void *stream);
+
+/* State attribute access (pgx State fields).  Every pointer may be NULL. */
+typedef struct brl_fields {
+  int32_t *current_player;        /* [n]    */
+  uint8_t *terminated;            /* [n]    */
+  float *rewards;                 /* [n,4]  */
+  int32_t *step_count;            /* [n]    */
+  int32_t *turn;                  /* [n]    */
+  int32_t *dealer;                /* [n]    */
+  uint8_t *vul_ns;                /* [n]    */
+  uint8_t *vul_ew;                /* [n]    */
+  int32_t *shuffled_players;      /* [n,4]  */
+  int32_t *last_bid;              /* [n]    */
+  int32_t *last_bidder;           /* [n] player id, -1 none */
+  uint8_t *call_x;                /* [n]    */
+  uint8_t *call_xx;               /* [n]    */
+  int32_t *pass_num;              /* [n]    */
+  int32_t *first_denomination_ns; /* [n,5] seat, -1 none */
+  int32_t *first_denomination_ew; /* [n,5]  */
+  int32_t *hand;                  /* [n,52] ascending card ids per seat */
+  uint8_t *tricks;                /* [n,20] */
+  int32_t *lut_idx;               /* [n] -1 for explicit deals */
+  uint32_t *board_ctr;            /* [n]    */
+  uint8_t *illegal;               /* [n] an illegal action was taken on this table */
+} brl_fields;
+int brl_get_fields(brl_handle *h, const uint64_t *state, int64_t n, const brl_fields *out, void *stream);
+
+/* Transition — src/roll_out.py:13-20; time-major [T,n,...].  Any pointer may be NULL. */
+typedef struct brl_transition {
+  uint8_t *done;               /* [T,n]      */
+  int32_t *action;             /* [T,n]      */
+  float *value;                /* [T,n]      */
+  float *reward;               /* [T,n]  rewards[actor] / reward_scale */
+  float *log_prob;             /* [T,n]      */
+  uint8_t *obs;                /* [T,n,480]  */
+  uint8_t *legal_action_mask;  /* [T,n,38]   */
+} brl_transition;
+
+/* roll_out with the uniform-random masked policy, T-loop fused into one launch —
+ * src/roll_out.py:49-108 with auto_reset(env.step, env.init) (src/utils.py:9-58) and
+ * normal_step (substeps=1, src/utils.py:249-254) or the 4-sub-step competitive macro-step
+ * with all seats random (substeps=4, src/utils.py:69-128).  state is updated in place.
+ * draw_base: index of the first action draw (advance by T*substeps between calls).
+ * last_obs uint8 [n,480] / last_mask uint8 [n,38]: observation and legal mask of the post-rollout
+ * state, i.e. runner_state's last_obs of src/roll_out.py:95-102 (either may be NULL).
+ * terminated_count: device int64 accumulated like src/roll_out.py:85 (may be NULL). */
+int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int num_steps, int substeps,
+                       uint32_t draw_base, float reward_scale, const brl_transition *out,
+                       uint8_t *last_obs, uint8_t *last_mask, int64_t *terminated_count, void *stream);
+
+/* One policy sub-step: masked categorical over `logits` float [n,38] for the current
+ * player (mode bit 0 clear: sample, src/roll_out.py:79-81 / src/utils.py:83-85; set: arg-max,
+ * src/utils.py:157,174 / src/evaluation.py:135; mode bit 1 set: the UNMASKED categorical of the
+ * illegal-action-penalty policy, src/roll_out.py:33-39 — an illegal draw ends the board with the pgx
+ * penalty), then auto_reset(env.step) when autoreset != 0.  Uses draw index `draw` of each table's action stream.
+ * Outputs (any may be NULL): action int32 [n], log_prob float [n] (log-softmax over the legal —
+ * or, unmasked, all — actions at the chosen action), then as brl_step.  rewards_acc float [n,4] and
+ * terminated_acc uint8 [n], when given, are ACCUMULATED (+=, |=) — src/utils.py:126-127. */
+int brl_policy_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                    const float *logits, int mode, uint32_t draw, int autoreset, int32_t *action,
+                    float *log_prob, uint8_t *obs, uint8_t *mask, float *rewards_acc,
+                    uint8_t *terminated_acc, int32_t *current_player, void *stream);
+
+/* The same, generalised for loops that run without the host and for logits that are a slice of a wider matrix:
+ *  - logits_stride: elements between the rows of consecutive tables (38 = dense; 39 when the actor and critic heads
+ *    are one GEMM and the logits are its first 38 columns);
+ *  - draw_base (device pointer, may be NULL): the draw index is *draw_base + draw_offset, read by the kernel when it
+ *    runs — for scans captured once in a hipGraph and replayed (the arguments of a captured launch are frozen, the
+ *    counter is advanced by another node of the graph); the reference's jitted scan has no host in its loop either
+ *    (src/roll_out.py:63-108). */
+int brl_policy_step_at(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                       const float *logits, int64_t logits_stride, int mode, const uint32_t *draw_base,
+                       uint32_t draw_offset, int autoreset, int32_t *action, float *log_prob, uint8_t *obs,
+                       uint8_t *mask, float *rewards_acc, uint8_t *terminated_acc, int32_t *current_player,
+                       void *stream);
+
+/* Observation bytes -> network input: `last_obs.astype(jnp.float32)` (src/roll_out.py:75) and its low-precision
+ * variants.  obs uint8 [n,480] (0/1); out [n,480] of float (fmt 0), bf16 (fmt 1) or fp16 (fmt 2). */
+int brl_obs_cast(brl_handle *h, const uint8_t *obs, int64_t n, void *out, int fmt, void *stream);
+
+/* calc_gae's reverse scan — src/gae.py:20-39.  done uint8 [T,n], value/reward float
+ * [T,n], last_val float [n]; gamma_lambda = float32(gamma * gae_lambda). */
+int brl_gae(brl_handle *h, const uint8_t *done, const float *value, const float *reward,
+            const float *last_val, float gamma, float gamma_lambda, int T, int64_t n,
+            float *advantages, float *targets, void *stream);
+
+/* _imp_reward — src/duplicate.py:15-70.  a, b, out float [n,4]. */
+int brl_imp_reward(brl_handle *h, const float *a, const float *b, float *out, int64_t n, void *stream);
+
+/* Table_info — src/duplicate.py:138-144 (struct of arrays). */
+typedef struct brl_table_info {
+  uint8_t *terminated;  /* [n]   */
+  float *rewards;       /* [n,4] */
+  int32_t *last_bid;    /* [n]   */
+  int32_t *last_bidder; /* [n]   */
+  uint8_t *call_x;      /* [n]   */
+  uint8_t *call_xx;     /* [n]   */
+} brl_table_info;
+
+/* duplicate_step(env.step) — src/duplicate.py:147-192; table_a/table_b updated in place.
+ * Optional outputs as brl_step (rewards = the IMP vector on the step table B ends, else 0). */
+int brl_duplicate_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                       const int32_t *action, const brl_table_info *table_a,
+                       const brl_table_info *table_b, uint8_t *obs, uint8_t *mask, float *rewards,
+                       uint8_t *terminated, int32_t *current_player, void *stream);
+
+/* Per-board counters of the evaluators' step log — src/evaluation.py:649-735 (duplicate) / :299-378 (single table);
+ * index [board, team] with team 0 = players {0,1} (the "actor" side), team 1 = players {2,3}.  Any pointer may be NULL. */
+typedef struct brl_eval_stats {
+  float *illegal_prob_sum;  /* [n,2]    sum over the team's calls of the UNMASKED softmax mass on illegal actions */
+  int32_t *step_count;      /* [n,2]    calls made by the team */
+  int32_t *pass_count;      /* [n,2]    of which passes */
+  int32_t *bid_count;       /* [n,2,35] how often the team made each bid (or 0/1 "made it at all": bid_set) */
+} brl_eval_stats;
+
+/* One iteration of an evaluator's loop with the networks' logits as input — src/evaluation.py:146-169 (simple
+ * duplicate), :749-790 (duplicate with statistics), :380-403 (single table): per board the network of the team to act
+ * (players {0,1}: logits_team1, else logits_team2; float [n,38] with row strides) plays masked_pi.mode(); boards that
+ * are not finished update `stats`; then duplicate_step (table_a/table_b given, src/duplicate.py:147-192) or env.step
+ * (both NULL); cum_return float [n] += rewards[0], rewards_sum float [n,4] += rewards (either may be NULL);
+ * action_out int32 [n] (may be NULL).  Remaining outputs as brl_step. */
+int brl_eval_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                  const float *logits_team1, int64_t stride1, const float *logits_team2, int64_t stride2,
+                  const brl_table_info *table_a, const brl_table_info *table_b, const brl_eval_stats *stats,
+                  int bid_set, float *cum_return, float *rewards_sum, int32_t *action_out, uint8_t *obs,
+                  uint8_t *mask, float *rewards, uint8_t *terminated, int32_t *current_player, void *stream);
+
+/* End-of-run histograms behind make_evaluate's log_info — src/evaluation.py:841-1031 (make_terminated_log,
+ * make_contract_log) — as exact integer counts.  out: device int64 [BRL_EVAL_COUNTS], zeroed by the call:
+ *   out[t*80 + 0] pass-outs at table t (0 = A, 1 = B; table_b may be NULL)
+ *   out[t*80 + 1 + 2*team], out[t*80 + 2 + 2*team]  doubled / redoubled contracts declared by the team
+ *   out[t*80 + 5 + team] / out[t*80 + 7 + team]      boards with rewards[0] >= 0 / < 0 by declaring team (the
+ *                                                    reference's make_contract / down_contract, :951-984)
+ *   out[t*80 + 9]                                    sum of rewards[0] (table scores are integers)
+ *   out[t*80 + 10 + 35*team + bid]                   final contracts by declaring team and bid
+ *   out[160 + 35*team + bid]                         sum over boards of stats.bid_count (bid_count may be NULL)
+ *   out[230]                                         sum of _step_count of `state` (may be NULL) */
+#define BRL_EVAL_COUNTS 231
+int brl_eval_reduce(brl_handle *h, int64_t n, const brl_table_info *table_a, const brl_table_info *table_b,
+                    const int32_t *bid_count, const uint64_t *state, int64_t *out, void *stream);
+
+/* `_loss_fn` of the PPO update — src/update.py:90-167 — and its gradient w.r.t. the network's outputs in ONE launch
+ * (the reference lets jax.value_and_grad differentiate ~60 elementwise ops; here torch differentiates only the GEMMs).
+ * Inputs, one row per minibatch sample: logits float [batch,38] (row stride given), value float [batch], mask uint8
+ * [batch,38] (traj_batch.legal_action_mask), action int32, old_value / old_log_prob / gae / targets float [batch].
+ * masked != 0: the masked policy (src/update.py:12-16), else the unmasked one (:18-21); value_clipping: :48-60.
+ * Outputs: dlogits float [batch,38] and dvalue float [batch] = d(loss_actor + vf_coef * value_loss - ent_coef * entropy)
+ * / d(logits, value) with the 1/batch of the means folded in; partials float [ceil(batch/4), 8]: per-block sums of
+ * (value-loss term, actor-loss term, entropy, approx-KL term, clipped?) — column sums / batch are the logged
+ * statistics; illegal_probs float [batch,38] (may be NULL): softmax(logits) * ~mask (:136-137).
+ * No handle: `device` is the HIP device the arrays live on. */
+int brl_ppo_loss(int device, const float *logits, int64_t logits_stride, const float *value, const uint8_t *mask,
+                 const int32_t *action, const float *old_value, const float *old_log_prob, const float *gae,
+                 const float *targets, int64_t batch, float clip_eps, float vf_coef, float ent_coef, int masked,
+                 int value_clipping, float *dlogits, float *dvalue, float *partials, float *illegal_probs, void *stream);
+
+/* The logged statistics of that minibatch step (src/update.py:142-167), one launch: partials as written by brl_ppo_loss
+ * for `batch` samples; gram = P^T P (row-major float [38,38], may be NULL) of P = illegal_probs, from which
+ * `jnp.linalg.norm(P, ord=2) / 2` (:138-141) is obtained without an SVD (8 squarings + Rayleigh quotient).
+ * out: float [8] = total_loss, value_loss, loss_actor, entropy, approx_kl, clipfrac, illegal-action norm / 2, 0. */
+int brl_ppo_stats(int device, const float *partials, int64_t batch, const float *gram, float vf_coef, float ent_coef,
+                  float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRL_HIP_H */

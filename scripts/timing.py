@@ -48,6 +48,9 @@ for cfg in os.environ.get("CFGS", "32x16").split(","):
             print('emit waves, per sub-step: command read + image update + deals %.0f cycles, copy + bookkeeping %.0f cycles, n=%d' % (pr[0] / pr[2], pr[1] / pr[2], pr[2]))
         continue
     tot, wait = d[..., 0].mean(0), d[..., 1].mean(0)
+    per_block = d[..., 0].max(1)
+    print("per-workgroup launch length (slowest wave): mean %.0f  p50 %.0f  p95 %.0f  max %.0f" % (
+        per_block.mean(), np.percentile(per_block, 50), np.percentile(per_block, 95), per_block.max()))
     print(cfg, "cycles(100MHz ticks?) per wave role: total / barrier-wait / work")
     if int(os.environ.get("DBG", "0")) & 64:
         seg01 = d[..., 0].mean(0); seg2 = (d[..., 1] & 0xFFFFFFFF).mean(0); seg3 = (d[..., 1] >> 32).mean(0)
