@@ -1,0 +1,308 @@
+/*
+ * brl_shim.c — the CPU oracle behind the SAME C symbols as libbrl_hip.so (include/brl_hip.h), so that a
+ * parity scenario written against the C-ABI can be pointed at either library.  TEST INFRASTRUCTURE ONLY, like the rest
+ * of oracle/: nothing under brl_amd/ may load it (tests/test_capi_cpu.py checks), and it takes HOST pointers.
+ *
+ * The ABI's per-table state is opaque to callers ("BRL_STATE_WORDS x uint64, caller-owned"): here word 0 of a table's 16
+ * words holds 1 + the index of an `orc_state` in the handle's arena, the other words are unused.  A call with
+ * state_out != state_in allocates fresh arena entries (the arena only grows; brl_destroy frees it).
+ * Entry points the oracle has no counterpart for (policy sub-step over logits, dtype casts, evaluator / PPO kernels)
+ * are exported and return BRL_E_ARG with a message.
+ */
+#include "bridge_oracle.c"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../include/brl_hip.h"
+
+struct brl_handle {
+  int32_t *keys, *values;
+  int64_t lut_len;
+  uint64_t seed, env_offset;
+  orc_state *arena;
+  int64_t used, cap;
+};
+
+static _Thread_local char g_err[256] = "";
+static int fail(const char *msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return BRL_E_ARG;
+}
+const char *brl_last_error(void) { return g_err; }
+int brl_version(void) { return 1; }
+
+static int set_lut(brl_handle *h, const int32_t *keys, const int32_t *values, int64_t len) {
+  free(h->keys);
+  free(h->values);
+  h->keys = h->values = NULL;
+  h->lut_len = 0;
+  if (len > 0) {
+    if (!keys || !values) return fail("lut_keys / lut_values are NULL with lut_len > 0");
+    h->keys = (int32_t *)malloc((size_t)len * 16);
+    h->values = (int32_t *)malloc((size_t)len * 16);
+    memcpy(h->keys, keys, (size_t)len * 16);
+    memcpy(h->values, values, (size_t)len * 16);
+    h->lut_len = len;
+  }
+  return BRL_OK;
+}
+
+int brl_create(int device, const int32_t *lut_keys, const int32_t *lut_values, int64_t lut_len, brl_handle **out) {
+  (void)device;
+  if (!out || lut_len < 0) return fail("bad argument");
+  brl_handle *h = (brl_handle *)calloc(1, sizeof(brl_handle));
+  int rc = set_lut(h, lut_keys, lut_values, lut_len);
+  if (rc) {
+    free(h);
+    return rc;
+  }
+  *out = h;
+  return BRL_OK;
+}
+int brl_set_lut(brl_handle *h, const int32_t *k, const int32_t *v, int64_t len) { return h ? set_lut(h, k, v, len) : fail("handle"); }
+int brl_destroy(brl_handle *h) {
+  if (h) {
+    free(h->keys);
+    free(h->values);
+    free(h->arena);
+    free(h);
+  }
+  return BRL_OK;
+}
+int brl_set_rng(brl_handle *h, uint64_t seed, uint64_t env_offset) {
+  if (!h) return fail("bad argument: handle");
+  h->seed = seed;
+  h->env_offset = env_offset;
+  return BRL_OK;
+}
+
+static orc_state *fresh(brl_handle *h, uint64_t *slot_word) {
+  if (h->used == h->cap) {
+    h->cap = h->cap ? 2 * h->cap : 1024;
+    h->arena = (orc_state *)realloc(h->arena, (size_t)h->cap * sizeof(orc_state));
+  }
+  *slot_word = (uint64_t)(++h->used);
+  return &h->arena[h->used - 1];
+}
+static orc_state *at(brl_handle *h, const uint64_t *state, int64_t e) { return &h->arena[state[e * BRL_STATE_WORDS] - 1]; }
+
+/* state_out entry for table e: the input entry when in place, else a fresh copy of it */
+static orc_state *out_entry(brl_handle *h, const uint64_t *in, uint64_t *out, int64_t e) {
+  if (in == out) return at(h, in, e);
+  uint64_t w;
+  int64_t src = (int64_t)in[e * BRL_STATE_WORDS] - 1;
+  orc_state *d = fresh(h, &w); /* may move the arena: index the source afterwards */
+  *d = h->arena[src];
+  memset(out + e * BRL_STATE_WORDS, 0, BRL_STATE_WORDS * 8);
+  out[e * BRL_STATE_WORDS] = w;
+  return d;
+}
+
+static void outputs(const orc_state *s, int64_t e, uint8_t *obs, uint8_t *mask, float *rewards, uint8_t *terminated,
+                    int32_t *current_player) {
+  if (obs) memcpy(obs + e * BRL_OBS_SIZE, s->observation, BRL_OBS_SIZE);
+  if (mask) memcpy(mask + e * BRL_NUM_ACTIONS, s->legal_action_mask, BRL_NUM_ACTIONS);
+  if (rewards) memcpy(rewards + e * 4, s->rewards, 16);
+  if (terminated) terminated[e] = (uint8_t)s->terminated;
+  if (current_player) current_player[e] = s->current_player;
+}
+
+int brl_init_random(brl_handle *h, uint64_t *state, int64_t n, uint32_t board_ctr0, void *stream) {
+  (void)stream;
+  if (!h || !state || n < 0) return fail("bad argument");
+  if (h->lut_len == 0) return BRL_E_NOLUT;
+  for (int64_t e = 0; e < n; e++) {
+    uint64_t w;
+    orc_state *s = fresh(h, &w);
+    orc_init_random(s, h->seed, h->env_offset + (uint64_t)e, board_ctr0, h->keys, h->values, h->lut_len);
+    memset(state + e * BRL_STATE_WORDS, 0, BRL_STATE_WORDS * 8);
+    state[e * BRL_STATE_WORDS] = w;
+  }
+  return BRL_OK;
+}
+
+int brl_init_from_deals(brl_handle *h, uint64_t *state, int64_t n, const int32_t *hand, const int32_t *dealer,
+                        const uint8_t *vul_ns, const uint8_t *vul_ew, const int32_t *shuffled_players,
+                        const uint8_t *tricks, void *stream) {
+  (void)stream;
+  if (!h || !state || !hand || !dealer || !vul_ns || !vul_ew || !shuffled_players || !tricks) return fail("NULL input array");
+  for (int64_t e = 0; e < n; e++) {
+    uint64_t w;
+    orc_state *s = fresh(h, &w);
+    orc_init_explicit(s, hand + e * 52, dealer[e], vul_ns[e] != 0, vul_ew[e] != 0, shuffled_players + e * 4, tricks + e * 20);
+    memset(state + e * BRL_STATE_WORDS, 0, BRL_STATE_WORDS * 8);
+    state[e * BRL_STATE_WORDS] = w;
+  }
+  return BRL_OK;
+}
+
+int brl_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n, const int32_t *action,
+             int autoreset, uint8_t *obs, uint8_t *mask, float *rewards, uint8_t *terminated, int32_t *current_player,
+             void *stream) {
+  (void)stream;
+  if (!h || !state_in || !state_out || !action) return fail("NULL state / action");
+  if (autoreset && h->lut_len == 0) return BRL_E_NOLUT;
+  for (int64_t e = 0; e < n; e++) {
+    orc_state *s = out_entry(h, state_in, state_out, e);
+    if (autoreset)
+      orc_auto_reset_step(s, action[e], h->seed, h->env_offset + (uint64_t)e, h->keys, h->values, h->lut_len);
+    else
+      orc_step(s, action[e]);
+    outputs(s, e, obs, mask, rewards, terminated, current_player);
+  }
+  return BRL_OK;
+}
+
+int brl_observe(brl_handle *h, const uint64_t *state, int64_t n, const int32_t *player_id, uint8_t *obs, uint8_t *mask,
+                void *stream) {
+  (void)stream;
+  if (!h || !state) return fail("state");
+  for (int64_t e = 0; e < n; e++) {
+    const orc_state *s = at(h, state, e);
+    if (obs) orc_observe(s, player_id ? player_id[e] : s->current_player, obs + e * BRL_OBS_SIZE);
+    if (mask) memcpy(mask + e * BRL_NUM_ACTIONS, s->legal_action_mask, BRL_NUM_ACTIONS);
+  }
+  return BRL_OK;
+}
+
+int brl_get_fields(brl_handle *h, const uint64_t *state, int64_t n, const brl_fields *F, void *stream) {
+  (void)stream;
+  if (!h || !state || !F) return fail("state / out");
+  for (int64_t e = 0; e < n; e++) {
+    const orc_state *s = at(h, state, e);
+    if (F->current_player) F->current_player[e] = s->current_player;
+    if (F->terminated) F->terminated[e] = (uint8_t)s->terminated;
+    if (F->rewards) memcpy(F->rewards + e * 4, s->rewards, 16);
+    if (F->step_count) F->step_count[e] = s->step_count;
+    if (F->turn) F->turn[e] = s->turn;
+    if (F->dealer) F->dealer[e] = s->dealer;
+    if (F->vul_ns) F->vul_ns[e] = (uint8_t)s->vul_ns;
+    if (F->vul_ew) F->vul_ew[e] = (uint8_t)s->vul_ew;
+    if (F->shuffled_players) memcpy(F->shuffled_players + e * 4, s->shuffled_players, 16);
+    if (F->last_bid) F->last_bid[e] = s->last_bid;
+    if (F->last_bidder) F->last_bidder[e] = s->last_bidder;
+    if (F->call_x) F->call_x[e] = (uint8_t)s->call_x;
+    if (F->call_xx) F->call_xx[e] = (uint8_t)s->call_xx;
+    if (F->pass_num) F->pass_num[e] = s->pass_num;
+    if (F->first_denomination_ns) memcpy(F->first_denomination_ns + e * 5, s->first_denomination_ns, 20);
+    if (F->first_denomination_ew) memcpy(F->first_denomination_ew + e * 5, s->first_denomination_ew, 20);
+    if (F->hand) memcpy(F->hand + e * 52, s->hand, 208);
+    if (F->tricks) memcpy(F->tricks + e * 20, s->tricks, 20);
+    if (F->lut_idx) F->lut_idx[e] = s->lut_idx;
+    if (F->board_ctr) F->board_ctr[e] = s->board_ctr;
+    if (F->illegal) F->illegal[e] = (uint8_t)s->illegal;
+  }
+  return BRL_OK;
+}
+
+int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int num_steps, int substeps, uint32_t draw_base,
+                       float reward_scale, const brl_transition *out, uint8_t *last_obs, uint8_t *last_mask,
+                       int64_t *terminated_count, void *stream) {
+  (void)stream;
+  if (!h || !state || !out) return fail("state / out");
+  if (h->lut_len == 0) return BRL_E_NOLUT;
+  orc_state *tmp = (orc_state *)malloc((size_t)n * sizeof(orc_state));
+  for (int64_t e = 0; e < n; e++) tmp[e] = *at(h, state, e);
+  int64_t tc = 0;
+  orc_rollout_random(tmp, n, num_steps, substeps, h->seed, h->env_offset, draw_base, h->keys, h->values, h->lut_len,
+                     reward_scale, out->obs, out->legal_action_mask, out->action, out->log_prob, out->value, out->reward,
+                     out->done, &tc);
+  for (int64_t e = 0; e < n; e++) {
+    *at(h, state, e) = tmp[e];
+    outputs(&tmp[e], e, last_obs, last_mask, NULL, NULL, NULL);
+  }
+  free(tmp);
+  if (terminated_count) *terminated_count += tc;
+  return BRL_OK;
+}
+
+int brl_gae(brl_handle *h, const uint8_t *done, const float *value, const float *reward, const float *last_val,
+            float gamma, float gamma_lambda, int T, int64_t n, float *advantages, float *targets, void *stream) {
+  (void)h;
+  (void)stream;
+  orc_gae(done, value, reward, last_val, gamma, gamma_lambda, T, n, advantages, targets);
+  return BRL_OK;
+}
+
+int brl_imp_reward(brl_handle *h, const float *a, const float *b, float *out, int64_t n, void *stream) {
+  (void)h;
+  (void)stream;
+  for (int64_t e = 0; e < n; e++) orc_imp_reward(a + 4 * e, b + 4 * e, out + 4 * e);
+  return BRL_OK;
+}
+
+static void load_info(const brl_table_info *T, int64_t e, orc_table_info *t) {
+  t->terminated = T->terminated[e];
+  memcpy(t->rewards, T->rewards + 4 * e, 16);
+  t->last_bid = T->last_bid[e];
+  t->last_bidder = T->last_bidder[e];
+  t->call_x = T->call_x[e];
+  t->call_xx = T->call_xx[e];
+}
+static void store_info(const orc_table_info *t, int64_t e, const brl_table_info *T) {
+  T->terminated[e] = (uint8_t)t->terminated;
+  memcpy(T->rewards + 4 * e, t->rewards, 16);
+  T->last_bid[e] = t->last_bid;
+  T->last_bidder[e] = t->last_bidder;
+  T->call_x[e] = (uint8_t)t->call_x;
+  T->call_xx[e] = (uint8_t)t->call_xx;
+}
+
+int brl_duplicate_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n, const int32_t *action,
+                       const brl_table_info *table_a, const brl_table_info *table_b, uint8_t *obs, uint8_t *mask,
+                       float *rewards, uint8_t *terminated, int32_t *current_player, void *stream) {
+  (void)stream;
+  if (!h || !state_in || !state_out || !action || !table_a || !table_b) return fail("NULL argument");
+  for (int64_t e = 0; e < n; e++) {
+    orc_state *s = out_entry(h, state_in, state_out, e);
+    orc_table_info A, B;
+    load_info(table_a, e, &A);
+    load_info(table_b, e, &B);
+    orc_duplicate_step(s, action[e], &A, &B);
+    store_info(&A, e, table_a);
+    store_info(&B, e, table_b);
+    outputs(s, e, obs, mask, rewards, terminated, current_player);
+  }
+  return BRL_OK;
+}
+
+/* ---- no oracle counterpart: exported (with the header's signatures) so that one binding loads either library */
+#define NOT_HERE(name) return fail(name ": not implemented by the oracle shim (no CPU counterpart)")
+int brl_policy_step(brl_handle *h, const uint64_t *si, uint64_t *so, int64_t n, const float *lg, int mode, uint32_t draw,
+                    int ar, int32_t *a, float *lp, uint8_t *o, uint8_t *m, float *r, uint8_t *t, int32_t *c, void *s) {
+  (void)h; (void)si; (void)so; (void)n; (void)lg; (void)mode; (void)draw; (void)ar; (void)a; (void)lp; (void)o; (void)m; (void)r; (void)t; (void)c; (void)s;
+  NOT_HERE("brl_policy_step");
+}
+int brl_policy_step_at(brl_handle *h, const uint64_t *si, uint64_t *so, int64_t n, const float *lg, int64_t ls, int mode,
+                       const uint32_t *db, uint32_t d, int ar, int32_t *a, float *lp, uint8_t *o, uint8_t *m, float *r,
+                       uint8_t *t, int32_t *c, void *s) {
+  (void)h; (void)si; (void)so; (void)n; (void)lg; (void)ls; (void)mode; (void)db; (void)d; (void)ar; (void)a; (void)lp; (void)o; (void)m; (void)r; (void)t; (void)c; (void)s;
+  NOT_HERE("brl_policy_step_at");
+}
+int brl_obs_cast(brl_handle *h, const uint8_t *obs, int64_t n, void *out, int fmt, void *s) {
+  (void)h; (void)obs; (void)n; (void)out; (void)fmt; (void)s;
+  NOT_HERE("brl_obs_cast");
+}
+int brl_eval_step(brl_handle *h, const uint64_t *si, uint64_t *so, int64_t n, const float *l1, int64_t s1, const float *l2,
+                  int64_t s2, const brl_table_info *ta, const brl_table_info *tb, const brl_eval_stats *st, int bs,
+                  float *cr, float *rs, int32_t *ao, uint8_t *o, uint8_t *m, float *r, uint8_t *t, int32_t *c, void *s) {
+  (void)h; (void)si; (void)so; (void)n; (void)l1; (void)s1; (void)l2; (void)s2; (void)ta; (void)tb; (void)st; (void)bs; (void)cr; (void)rs; (void)ao; (void)o; (void)m; (void)r; (void)t; (void)c; (void)s;
+  NOT_HERE("brl_eval_step");
+}
+int brl_eval_reduce(brl_handle *h, int64_t n, const brl_table_info *ta, const brl_table_info *tb, const int32_t *bc,
+                    const uint64_t *st, int64_t *out, void *s) {
+  (void)h; (void)n; (void)ta; (void)tb; (void)bc; (void)st; (void)out; (void)s;
+  NOT_HERE("brl_eval_reduce");
+}
+int brl_ppo_loss(int device, const float *lg, int64_t ls, const float *v, const uint8_t *m, const int32_t *a, const float *ov,
+                 const float *olp, const float *g, const float *t, int64_t b, float ce, float vc, float ec, int mk, int vcl,
+                 float *dl, float *dv, float *pt, float *ip, void *s) {
+  (void)device; (void)lg; (void)ls; (void)v; (void)m; (void)a; (void)ov; (void)olp; (void)g; (void)t; (void)b; (void)ce; (void)vc; (void)ec; (void)mk; (void)vcl; (void)dl; (void)dv; (void)pt; (void)ip; (void)s;
+  NOT_HERE("brl_ppo_loss");
+}
+int brl_ppo_stats(int device, const float *pt, int64_t b, const float *gram, float vc, float ec, float *out, void *s) {
+  (void)device; (void)pt; (void)b; (void)gram; (void)vc; (void)ec; (void)out; (void)s;
+  NOT_HERE("brl_ppo_stats");
+}

@@ -21,15 +21,19 @@ for cfg in os.environ.get("CFGS", "32x16").split(","):
     os.environ["BRL_ROLLOUT_WS"] = cfg
     os.environ["BRL_DEBUG"] = os.environ.get("DBG", "0")
     env = brl_amd.BridgeBidding(lut=(keys, values))
-    traj = alloc_transition(T, N, env.device)
+    NB = int(os.environ.get("NBUF", "1"))
+    trajs = [alloc_transition(T, N, env.device) for _ in range(NB)]
     st = env.init(0, num_envs=N)
-    p = _capi.TransitionPtrs()
-    for f in _capi.TransitionPtrs._names:
-        setattr(p, f, _capi.ptr(getattr(traj, f)))
+    ps = []
+    for traj in trajs:
+        p = _capi.TransitionPtrs()
+        for f in _capi.TransitionPtrs._names:
+            setattr(p, f, _capi.ptr(getattr(traj, f)))
+        ps.append(p)
     nblk = (N + tpb - 1) // tpb
     dump = torch.zeros(nblk * nw_dump * 2 + nblk * nw_dump * 32, dtype=torch.int64, device=env.device)
-    for i in range(5):
-        _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, i * T, 7600.0, C.byref(p), None, None, _capi.ptr(dump), _stream()))
+    for i in range(5 if NB == 1 else 4 * NB + 1):
+        _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, i * T, 7600.0, C.byref(ps[i % NB]), None, None, _capi.ptr(dump), _stream()))
     torch.cuda.synchronize()
     full = dump.cpu().numpy()
     nw = nw_dump

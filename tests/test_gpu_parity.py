@@ -751,6 +751,29 @@ def test_ppo_loop_runs_end_to_end(env, tmp_path):
         assert torch.equal(a, b)
 
 
+def test_ppo_iteration_at_config3_size(tmp_path):
+    """BASELINE.json configs[3] at ITS size: one ppo.py iteration with num_envs=8192, num_steps=32, minibatch 1024,
+    10 epochs (2560 minibatch steps), DeepMind MLP, hipGraph rollout + update — finite statistics, every env-step
+    counted, the weights moved, the pool file written."""
+    from brl_amd import checkpoint as ckpt
+    from brl_amd.train import DEFAULTS, train
+    cfg = dict(DEFAULTS, num_envs=8192, num_steps=32, total_timesteps=8192 * 32, minibatch_size=1024, update_epochs=10,
+               lr=1e-5, evaluate=False, log_path=str(tmp_path), exp_name="c3", graph_rollout=True, inference_dtype="bf16",
+               hash_size=50_000)
+    rs, hist = train(cfg, log=lambda s: None)
+    h = hist[0]
+    assert len(hist) == 1 and h["steps"] == 8192 * 32 and h["board_num"] > 8192       # ~100 k boards per rollout
+    for key in ("train/total_loss", "train/value_loss", "train/loss_actor", "train/policy_entropy", "train/approx_kl",
+                "train/clipflacs", "train/illegal_action_loss"):
+        assert np.isfinite(h[key]), key
+    assert 0.0 < h["train/policy_entropy"] < np.log(38) and 0.0 <= h["train/clipflacs"] <= 1.0
+    assert "hash_table_next" in h                                                      # ~96 k boards > hash_size: table rotated (G14)
+    fresh = __import__("brl_amd.models", fromlist=["make_forward_pass"]).make_forward_pass("relu", "DeepMind").init(0, device="cuda")
+    moved = max(float((a - b).abs().max()) for a, b in zip(rs[0].parameters(), fresh.parameters()))
+    assert 0.0 < moved <= 2560 * 1e-5 * 1.01                                            # 2560 Adam steps of at most lr = 1e-5 each
+    assert ckpt.list_checkpoints(os.path.join(str(tmp_path), "c3", "rl_params")) == ["params-00000001.pt"]
+
+
 def test_macro_step_matches_manual_composition(env, oracle):
     """A6 / G3: single_play_step_two_policy_commpetitive_deterministic == step + 3 x (forward, arg-max, step)
     with auto-reset, rewards summed and terminated OR-ed (src/utils.py:133-202); replayed through the oracle."""
