@@ -1029,6 +1029,8 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
   }
 }
 
+#include "rollout_fs.hpp"  // k_rollout_fs: the flag-synchronised form of the same launch (default for the BASELINE shape)
+
 // ---- policy sub-step: masked categorical over logits + auto_reset(step) -------------------
 // What brl_set_rng / brl_set_lut change, mirrored in device memory: the policy sub-step reads it from there instead
 // of taking it by value, so that a hipGraph replay of a captured launch follows a later re-seed or LUT rotation
@@ -1657,6 +1659,7 @@ struct brl_handle {
   DevCtx *ctx_dev;  // device mirror of (LUT, seed, env_offset), read by the policy sub-step
   int tables_per_wave;
   int ws;  // 1: wave-specialised fused rollout k_rollout_ws<32,12,1> (default); 0: k_rollout_random<K> (BRL_ROLLOUT_WS=0)
+  int fs;  // 1: flag-synchronised k_rollout_fs where it applies (default); 0: always k_rollout_ws (BRL_ROLLOUT_FS=0)
 };
 
 static thread_local char g_err[512] = "";
@@ -1735,6 +1738,9 @@ extern "C" int brl_create(int device, const int32_t *lut_keys, const int32_t *lu
   h->ws = 1;
   const char *ws = getenv("BRL_ROLLOUT_WS");  // "0": the K-tables-per-wave fused rollout (A/B baseline)
   if (ws && ws[0] == '0' && ws[1] == 0) h->ws = 0;
+  h->fs = 1;
+  const char *fs = getenv("BRL_ROLLOUT_FS");  // "0": the barrier-synchronised k_rollout_ws for every shape (A/B, tests)
+  if (fs && fs[0] == '0' && fs[1] == 0) h->fs = 0;
   float tab[BRL_NUM_ACTIONS + 1];
   tab[0] = 0.0f;
   for (int i = 1; i <= BRL_NUM_ACTIONS; i++) tab[i] = (float)(-log((double)i));
@@ -1876,7 +1882,11 @@ extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int
 #endif
   // the wave-specialised kernel serves a macro-step that spans <= 2 command batches; longer ones (and BRL_ROLLOUT_WS=0)
   // take the K-tables-per-wave kernel
-  if (h->ws && substeps <= WS_BATCH) {
+  const bool all_cols = out->obs && out->legal_action_mask && out->done && out->action && out->value && out->reward && out->log_prob;
+  if (h->ws && h->fs && substeps == 1 && num_steps <= FS_MAX_TOTAL && n % FS_TPB == 0 && all_cols) {
+    // the BASELINE shape: flag-synchronised kernel (rollout_fs.hpp)
+    hipLaunchKernelGGL(k_rollout_fs, dim3((unsigned)(n / FS_TPB)), dim3(FS_NW * 64), 0, (hipStream_t)stream, A);
+  } else if (h->ws && substeps <= WS_BATCH) {
     hipLaunchKernelGGL((k_rollout_ws<32, 12, 1>), dim3((unsigned)((n + 31) / 32)), dim3(12 * 64), 0, (hipStream_t)stream, A);
   } else {
     LAUNCH_K(h, k_rollout_random, n, stream, A);

@@ -1,0 +1,445 @@
+// rollout_fs.hpp — k_rollout_fs: the fused random-policy rollout (A7, src/roll_out.py:63-107 with a uniform random legal policy),
+// flag-synchronised.  Included by brl_kernels.hip after k_rollout_ws (shares RolloutArgs, the command format and LutRef).
+//
+// Same roles as k_rollout_ws — one workgroup owns 32 consecutive tables; a LOGIC wave runs the per-table dependency chain,
+// a LOADER fetches boards, a SCORER writes the scalar Transition columns, EMIT waves write observations — but NO workgroup
+// barrier inside the launch:
+//   * the whole launch's commands fit in LDS (one 16-byte command per table and slot, <= 41 slots = 21 KB), so the logic
+//     wave never waits for a follower: it posts slot s and publishes `posted = s + 1` with a plain LDS store (LDS
+//     operations of one wave are performed in order, so a reader that sees the counter sees the commands);
+//   * every follower consumes slot s as soon as it is posted, at its own pace (it polls `posted` only when it has caught up);
+//   * <= 11 boards per table can be dealt in <= 40 sub-steps, so the 12-entry board ring never wraps: the loader fetches
+//     all 12 boards of every table up front (two per pass, one in each half of the wave), publishes `ring_count`, and
+//     then turns into the wave that writes the legal-mask rows.
+// Why (profiles/r02/r02_rollout_experiments.txt §5): with the output going to HBM the launch is  T = (time until the
+// stores start and are never starved) + (store time of 140 MB).  A store-only probe paced like this hand-off
+// (scripts/micro/store_test4.hip) needs 24-25 us; paced like k_rollout_ws's batches (1,3,4,8,8,..) 29-31 us.
+// The probe also says HOW to store: fully contiguous 960-byte wave instructions, non-temporal (each instruction writes
+// whole 64-byte pieces, nothing to merge in L2): 25.7 us for the launch's bytes against 30.7 us for 2 x 16 B per lane at a
+// 32-byte stride through L2.  So an emit lane here expands 16 observation bits into ONE 16-byte piece of two rows
+// (rows r and r + 2 of its group: the two instructions cover rows 0-1 and rows 2-3).
+//
+// Serves substeps == 1, T <= 40, n % 32 == 0 with every Transition column requested (the BASELINE configuration);
+// everything else takes k_rollout_ws / k_rollout_random.  Bit-identical outputs (tests/test_gpu_parity.py).
+#pragma once
+
+constexpr int FS_TPB = 32;
+constexpr int FS_NW = 11;          // logic, loader/mask, scorer, 8 emit
+constexpr int FS_MAX_TOTAL = 40;   // sub-steps per launch
+constexpr int FS_RING = 12;
+constexpr int FS_CHUNK = 8;        // scorer: slots per pass
+
+__device__ __forceinline__ int fs_flag_read(const int *p) {
+  int v = *reinterpret_cast<const volatile int *>(p);
+  asm volatile("" ::: "memory");
+  return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ void fs_flag_write(int *p, int v) {
+  asm volatile("" ::: "memory");  // everything written before stays before (same-wave LDS order does the rest)
+  *reinterpret_cast<volatile int *>(p) = v;
+}
+// wait until slot s is posted; `avail` caches the last value seen
+__device__ __forceinline__ void fs_wait(const int *flag, int s, int &avail) {
+  if (s < avail) return;
+  for (;;) {
+    avail = fs_flag_read(flag);
+    if (s < avail) return;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+#ifdef BRL_TIMING
+#define FS_STAMP(k) do { if (fs_nst < 16) { fs_t[fs_nst++] = __builtin_amdgcn_s_memtime() - t_begin; } } while (0)
+#else
+#define FS_STAMP(k) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
+  constexpr int TPB = FS_TPB, NW = FS_NW;
+#ifdef BRL_TIMING
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+  unsigned long long fs_t[16];
+  int fs_nst = 0;
+  unsigned long long t_wait = 0;
+#endif
+  __shared__ __attribute__((aligned(16))) uint8_t img[TPB * TABLE_BYTES];
+  __shared__ __attribute__((aligned(16))) uint32_t cmd[FS_MAX_TOTAL + 1][TPB][CMD_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t ring[TPB][FS_RING][RING_WORDS];
+  __shared__ uint32_t udraw[FS_MAX_TOTAL + 4][TPB];
+  __shared__ float s_neglog[BRL_NUM_ACTIONS + 2];
+  __shared__ int posted, ring_count;
+  __shared__ __attribute__((aligned(16))) uint32_t ev[3 * TPB][4];       // scorer: finished boards of a chunk (<= 3 per table)
+  __shared__ __attribute__((aligned(16))) int acc[FS_CHUNK][TPB][4];      // scorer: reward by player id per slot of a chunk
+  __shared__ __attribute__((aligned(16))) uint32_t minfo[FS_CHUNK][TPB];  // scorer: actor, action, n_legal, done
+
+  const int tid = (int)threadIdx.x;
+  const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // hardware wave w runs on SIMD w % 4: SIMD 3 hosts only two waves, the scorer takes hardware wave 3 there
+  const int wave = (hw_wave == 2) ? 3 : ((hw_wave == 3) ? 2 : hw_wave);
+  const LaneConst c = make_lane_const();
+  const int64_t table0 = xcd_block((int64_t)blockIdx.x, (int64_t)gridDim.x) * TPB;
+  const int total = A.T;  // substeps == 1: sub-step s == macro-step s; command slots 0..total
+  uint64_t *img64 = reinterpret_cast<uint64_t *>(img);
+  for (int i = tid; i < TPB * 16; i += NW * 64) img64[i] = A.state[table0 * 16 + i];
+  if (tid <= BRL_NUM_ACTIONS) s_neglog[tid] = A.neg_log_n[tid];
+  const int lt = c.lane & (TPB - 1);
+  uint64_t ctr_word = 0;
+  if (wave == 1) ctr_word = A.state[(table0 + lt) * 16 + W_CTR];  // issued now, needed after the barrier
+  {
+    // every action draw of the launch (Philox is state-independent): draw d = draw_base + s lives in word d & 3 of block
+    // d >> 2 (counter arithmetic mod 2^32, like k_rollout_random); one (table, block) per thread
+    const uint32_t fb = A.draw_base >> 2;
+    const int nblk = (total > 0) ? (int)(((A.draw_base & 3u) + (uint32_t)total + 3u) >> 2) : 0;
+    for (int task = tid; task < TPB * nblk; task += NW * 64) {
+      const int tb = task & (TPB - 1);
+      const uint32_t blk = (fb + (uint32_t)(task >> 5)) & 0x3FFFFFFFu;
+      const uint64_t eid = A.env_offset + (uint64_t)(table0 + tb);
+      uint32_t rb[4];
+      philox4x32_10((uint32_t)eid, blk, STREAM_ACTION, (uint32_t)(eid >> 32), A.g.k0, A.g.k1, rb);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t s = ((blk << 2) | (uint32_t)k) - A.draw_base;
+        if (s < (uint32_t)total) udraw[s][tb] = rb[k];
+      }
+    }
+  }
+  if (tid == 0) {
+    posted = 0;
+    ring_count = 0;
+  }
+  __syncthreads();  // images, draws and the two counters are in LDS
+
+  if (wave == 0) {
+    // ------------------------------------------------------------------ logic wave: lane = table, lanes 32..63 mirror 0..31
+    const int tl = lt;
+    uint32_t sc, sch, lut, bctr;
+    {
+      const uint2 *p = reinterpret_cast<const uint2 *>(img + tl * TABLE_BYTES);
+      uint2 a = p[W_SC], d = p[W_CTR];
+      sc = a.x; sch = a.y; lut = d.x; bctr = d.y;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    uint2 nxt = make_uint2(0u, 0u);  // (LUT row, fresh scalars) of this table's next board, read one deal ahead
+    bool have_nxt = false;
+    int ring_seen = 0, kub = 0;      // ring passes known complete; deals of any one table so far (upper bound)
+    uint32_t pend = 0, pend_act = 0, pend_sc = 0;
+    uint32_t un = udraw[0][tl];
+    for (int s = 0;; s++) {
+      const uint32_t u = un;
+      un = udraw[(s + 1 < total) ? s + 1 : s][tl];  // next sub-step's draw, off the chain
+      uint32_t nsc = sc, nsch = sch;
+      const LeanStep st = lean_random_step(nsc, nsch, u);
+      if (c.lane < TPB) {  // command slot s: what sub-step s-1 did + how state s looks
+        uint32_t w0 = pend | ((uint32_t)st.seat << 10) | (vul_nibble_sc(sc, st.seat) << 12);
+        uint32_t w3 = ((uint32_t)(st.legal >> 32) & 63u) | (pend_act << 8);
+        *reinterpret_cast<uint4 *>(&cmd[s][tl][0]) = make_uint4(w0, pend_sc, (uint32_t)st.legal, w3);
+      }
+      if (c.lane == 0) fs_flag_write(&posted, s + 1);
+      if ((s & 7) == 0) FS_STAMP(s);
+      if (s == total) break;
+      sc = nsc;
+      sch = nsch;
+      pend_sc = sc;
+      pend_act = (uint32_t)st.action;
+      const bool deal = st.term != 0u;
+      const uint32_t slot = (bctr + 1u) % FS_RING;
+      pend = st.hb1 | ((uint32_t)deal << 9) | (slot << 16) | ((uint32_t)st.seat << 21) | ((uint32_t)st.n_legal << 23);
+      if (__any(deal)) {
+        // the j-th sub-step with a deal reads ring entries of passes <= j (entry of the deal + the one read ahead)
+        kub++;
+        const int need = (kub + 1 < FS_RING) ? kub + 1 : FS_RING;
+        while (ring_seen < need) {
+          ring_seen = fs_flag_read(&ring_count);
+          if (ring_seen < need) __builtin_amdgcn_s_sleep(1);
+        }
+        if (!have_nxt) {
+          nxt = *reinterpret_cast<const uint2 *>(&ring[tl][(bctr + 1u) % FS_RING][12]);
+          have_nxt = true;
+        }
+        if (deal) {  // A5 post-step half of auto_reset (src/utils.py:45-55): next board from the ring
+          sc = nxt.y | (sc & ((1u << SC_TERM) | (1u << SC_ILLEGAL)));
+          sch = 0;
+          lut = nxt.x;
+          bctr += 1u;
+          nxt = *reinterpret_cast<const uint2 *>(&ring[tl][(bctr + 1u) % FS_RING][12]);
+        }
+      }
+    }
+    if (c.lane < TPB) {
+      uint2 *p = reinterpret_cast<uint2 *>(img + tl * TABLE_BYTES);
+      p[W_SC] = make_uint2(sc, sch);
+      p[W_CTR] = make_uint2(lut, bctr);
+    }
+  } else if (wave == 1) {
+    // ------------------------------------------------------------------ loader, then mask wave
+    {
+      const int half = c.lane >> 5;
+      const uint64_t eid = A.env_offset + (uint64_t)(table0 + lt);
+      const uint32_t nb0 = (uint32_t)(ctr_word >> 32) + 1u;
+      constexpr int NP = FS_RING / 2;  // passes: lanes 0..31 fetch board nb0 + 2 i, lanes 32..63 board nb0 + 2 i + 1
+      brl_u32x4 pha[NP], phb[NP], pv[NP];
+      uint32_t pidx[NP], pscb[NP];
+      auto issue = [&](int i) {
+        board_params(A.g, eid, nb0 + (uint32_t)(2 * i + half), A.lut.len, pidx[i], pscb[i]);
+        pha[i] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)pidx[i]];
+        phb[i] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)pidx[i] + 1];
+        pv[i] = reinterpret_cast<const brl_u32x4 *>(A.lut.values)[pidx[i]];
+      };
+      auto commit = [&](int i) {
+        uint4 *dst = reinterpret_cast<uint4 *>(&ring[lt][(nb0 + (uint32_t)(2 * i + half)) % FS_RING][0]);
+        brl_u32x4 *dv = reinterpret_cast<brl_u32x4 *>(dst);
+        dv[0] = pha[i];
+        dv[1] = phb[i];
+        dv[2] = pv[i];
+        dst[3] = make_uint4(pidx[i], pscb[i], 0u, 0u);
+        if (c.lane == 0) fs_flag_write(&ring_count, 2 * i + 2);
+      };
+      issue(0);
+      issue(1);
+#pragma unroll
+      for (int i = 0; i < NP; i++) {
+        commit(i);
+        if (i + 2 < NP) issue(i + 2);
+      }
+      FS_STAMP(0);
+    }
+    // The 32 legal-mask rows of a slot are 1216 contiguous bytes = 76 chunks of 16 B: lane l writes chunk l, lanes < 12
+    // also chunk 64 + l.  A chunk holds the bytes of table ta (from action `off` on) and possibly of ta + 1.
+    uint32_t ta[2], tb[2], off[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const uint32_t cidx = (uint32_t)c.lane + 64u * (uint32_t)q;
+      const uint32_t byte0 = 16u * ((cidx < 76u) ? cidx : 75u);
+      ta[q] = byte0 / BRL_NUM_ACTIONS;
+      off[q] = byte0 - ta[q] * BRL_NUM_ACTIONS;
+      tb[q] = (ta[q] + 1u < (uint32_t)TPB) ? ta[q] + 1u : ta[q];
+    }
+    uint8_t *mrow = A.out.legal_action_mask + table0 * BRL_NUM_ACTIONS;
+    const int64_t mstep = A.n * BRL_NUM_ACTIONS;
+    int avail = 0;
+    for (int s = 0; s <= total; s++) {
+      fs_wait(&posted, s, avail);
+      uint8_t *dstrow = (s < total) ? mrow : ((A.last_mask != nullptr) ? A.last_mask + table0 * BRL_NUM_ACTIONS : nullptr);
+      mrow += mstep;
+      if (dstrow == nullptr) continue;
+      const uint32_t(*cs)[CMD_WORDS] = cmd[s];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        if (q == 1 && c.lane >= 12) break;
+        const uint64_t la = *reinterpret_cast<const uint64_t *>(&cs[ta[q]][2]) & ALL_ACTIONS;
+        const uint64_t lb = *reinterpret_cast<const uint64_t *>(&cs[tb[q]][2]) & ALL_ACTIONS;
+        const uint32_t bits16 = (uint32_t)((la >> off[q]) | (lb << (BRL_NUM_ACTIONS - off[q])));
+        uint32_t d[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) d[i] = __umul24((bits16 >> (4 * i)) & 0xFu, 0x204081u) & 0x01010101u;
+        *reinterpret_cast<uint4 *>(dstrow + 16 * (c.lane + 64 * q)) = make_uint4(d[0], d[1], d[2], d[3]);
+      }
+    }
+  } else if (wave == 2) {
+    // ------------------------------------------------------------------ scorer wave: lane = table (lanes 32..63 idle in
+    // pass 1); chunks of <= 8 posted slots: 1. first denominations, queue finished boards; 2. one lane per finished
+    // board: contract -> DDS tricks -> score -> reward vector (A4); 3. the scalar Transition columns, 16-byte stores
+    const int tl = lt;
+    const bool mine = c.lane < TPB;
+    Tbl ts;
+    load_scalars(ts, img + tl * TABLE_BYTES);
+    uint32_t tcount = 0;
+    uint32_t vslot = NO_SLOT;  // ring slot of the table's current board; NO_SLOT: the board it came in with
+    int4 last_acc = make_int4(reward_of(ts, 0), reward_of(ts, 1), reward_of(ts, 2), reward_of(ts, 3));
+    int avail = 0;
+    int s = 1;  // slot s describes sub-step s - 1 = macro-step s - 1
+    while (s <= total) {
+      fs_wait(&posted, s, avail);
+      const int c1 = (avail < s + FS_CHUNK) ? avail : s + FS_CHUNK;  // slots [s, c1)
+      const int m = c1 - s;
+      // ---- pass 1
+      int nev = 0;
+      uint4 wn = *reinterpret_cast<const uint4 *>(&cmd[s][tl][0]);
+      for (int j = 0; j < m; j++) {
+        const uint4 w = wn;
+        wn = *reinterpret_cast<const uint4 *>(&cmd[(j + 1 < m) ? s + j + 1 : s + j][tl][0]);
+        const int a = (int)((w.w >> 8) & 63u);
+        const int seat = (int)((w.x >> 21) & 3u);
+        ts.sc = w.y;
+        // the acting player (src/roll_out.py:72), its action, n_legal
+        uint32_t info = (uint32_t)player_at(ts, seat) | ((uint32_t)a << 2) | (((w.x >> 23) & 63u) << 8);
+        note_first_denomination(ts.fd, seat, a);
+        const bool fin = mine && bits(ts.sc, SC_TERM, 1);
+        const uint64_t fm = __ballot(fin);
+        if (fm) {  // queue the finished boards, compacted over the tables: one lane per board in pass 2
+          if (fin) {
+            const int pos = nev + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+            *reinterpret_cast<uint4 *>(&ev[pos][0]) = make_uint4(ts.sc, ts.fd, (uint32_t)j | ((uint32_t)tl << 8), vslot);
+            info |= 1u << 14;  // done (G2)
+          }
+          nev += __popcll(fm);
+        }
+        const bool dealt = (w.x & 0x200u) != 0u;  // re-dealt: no strain named yet; DDS values stay in the ring entry
+        vslot = dealt ? ((w.x >> 16) & 15u) : vslot;
+        ts.fd = dealt ? 0u : ts.fd;
+        if (mine) {
+          minfo[j][tl] = info;
+          *reinterpret_cast<int4 *>(&acc[j][tl][0]) = make_int4(0, 0, 0, 0);
+        }
+      }
+      // ---- pass 2
+      wave_lds_order();
+      for (int e0 = 0; e0 < nev; e0 += 64) {
+        const int e = e0 + c.lane;
+        if (e < nev) {
+          const uint4 q = *reinterpret_cast<const uint4 *>(&ev[e][0]);
+          const uint32_t tt = (q.z >> 8) & 63u;
+          Tbl tb;
+          tb.sc = q.x; tb.fd = q.y;
+          if (q.w != NO_SLOT) {  // a board dealt in this launch: DDS values from its ring entry
+            const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tt][q.w][8]);
+            pack_tricks(tb, vv.x, vv.y, vv.z, vv.w);
+          } else {  // the board the table came in with: its tricks are in the packed image
+            const uint2 *ip = reinterpret_cast<const uint2 *>(img + tt * TABLE_BYTES);
+            const uint2 tr = ip[W_TR], fdw = ip[W_FD];
+            tb.t0 = tr.x; tb.t1 = tr.y; tb.t2 = fdw.y;
+          }
+          terminal_reward(tb);  // A4
+          *reinterpret_cast<int4 *>(&acc[q.z & 7u][tt][0]) = make_int4(reward_of(tb, 0), reward_of(tb, 1), reward_of(tb, 2), reward_of(tb, 3));
+        }
+      }
+      // ---- pass 3: lane l writes 4 consecutive tables of slot s + l / 8: one 16-byte store per lane and float column
+      wave_lds_order();
+      if (mine) last_acc = *reinterpret_cast<const int4 *>(&acc[m - 1][tl][0]);
+      {
+        const int q = c.lane >> 3, t4 = 4 * (c.lane & 7);
+        if (q < m) {
+          const uint4 info4 = *reinterpret_cast<const uint4 *>(&minfo[q][t4]);
+          const uint32_t inf[4] = {info4.x, info4.y, info4.z, info4.w};
+          float rew[4], lgp[4];
+          uint32_t act[4], dn = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int4 r = *reinterpret_cast<const int4 *>(&acc[q][t4 + k][0]);
+            const int actor = (int)(inf[k] & 3u);
+            const int ra = (actor == 0) ? r.x : ((actor == 1) ? r.y : ((actor == 2) ? r.z : r.w));
+            rew[k] = (float)ra / A.reward_scale;  // G1, src/roll_out.py:90
+            lgp[k] = s_neglog[(inf[k] >> 8) & 63u];
+            act[k] = (inf[k] >> 2) & 63u;
+            const uint32_t done = (inf[k] >> 14) & 1u;
+            dn |= done << (8 * k);
+            tcount += done;
+          }
+          const int64_t rw = (int64_t)(s - 1 + q) * A.n + table0 + t4;
+          *reinterpret_cast<brl_u32x4 *>(A.out.action + rw) = brl_u32x4{act[0], act[1], act[2], act[3]};
+          *reinterpret_cast<float4 *>(A.out.value + rw) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          *reinterpret_cast<float4 *>(A.out.reward + rw) = make_float4(rew[0], rew[1], rew[2], rew[3]);
+          *reinterpret_cast<float4 *>(A.out.log_prob + rw) = make_float4(lgp[0], lgp[1], lgp[2], lgp[3]);
+          *reinterpret_cast<uint32_t *>(A.out.done + rw) = dn;  // G2
+        }
+      }
+      wave_lds_order();  // pass 3's reads of acc / minfo precede the next chunk's writes (same-wave LDS order)
+      s = c1;
+    }
+    set_rewards(ts, last_acc.x, last_acc.y, last_acc.z, last_acc.w);  // rewards of the last macro-step (src/utils.py:126)
+    if (A.terminated_count != nullptr) {  // src/roll_out.py:85
+      uint32_t v = tcount;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+#ifndef BRL_TIMING
+      if (c.lane == 0 && v) atomicAdd(A.terminated_count, (unsigned long long)v);
+#endif
+    }
+    if (mine) {
+      if (vslot != NO_SLOT) {
+        const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tl][vslot][8]);
+        pack_tricks(ts, vv.x, vv.y, vv.z, vv.w);
+      }
+      uint2 *p = reinterpret_cast<uint2 *>(img + tl * TABLE_BYTES);
+      p[W_FD] = make_uint2(ts.fd, ts.t2);
+      p[W_TR] = make_uint2(ts.t0, ts.t1);
+      p[W_REW] = make_uint2(ts.r01, ts.r23);
+    }
+  } else {
+    // ------------------------------------------------------------------ emit waves: wave 3 + g owns tables 4 g .. 4 g + 3
+    // lane L < 60 holds 16-byte piece L of rows 0-1 (960 contiguous bytes) and piece L of rows 2-3: piece L is half
+    // L & 1 of packed dword q = (L >> 1) % 15 of row r = (L >> 1) / 15 (and of row r + 2)
+    const int g = wave - 3;
+    uint8_t *img_g = img + 4 * g * TABLE_BYTES;
+    const int L = c.lane;
+    const bool active = L < 60;
+    const int pq = active ? (L >> 1) : 29;
+    const int r = pq / 15, q = pq - 15 * r;
+    const int half = L & 1;
+    const uint32_t keep_hist = (q < 13) ? 0xFFFFFFFFu : ((q == 13) ? 0x00000FFFu : 0u);
+    const uint32_t keep_hand = (q < 13) ? 0u : 0xFFFFFFFFu;
+    const uint32_t keep_vul = (q == 0) ? 0xFu : 0u;
+    const int hist_off = r * TABLE_BYTES + 4 * ((q < 13) ? q : 13);
+    const int hand_off = r * TABLE_BYTES + W_HAND * 8;
+    const bool head = active && (q == 0);  // lanes 0, 1, 30, 31: bookkeeping of rows 0, 2, 1, 3
+    const int hrow = r + 2 * half;
+    const int sh16 = 16 * half;
+    uint8_t *optr = A.out.obs + (table0 + 4 * g) * BRL_OBS_SIZE + 16 * L;
+    const int64_t ostep = A.n * BRL_OBS_SIZE;
+    int avail = 0;
+    for (int s = 0; s <= total; s++) {
+#ifdef BRL_TIMING
+      const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
+      fs_wait(&posted, s, avail);
+#ifdef BRL_TIMING
+      t_wait += __builtin_amdgcn_s_memtime() - tw0;
+      if ((s & 7) == 0) FS_STAMP(s);
+#endif
+      const uint32_t(*cs)[CMD_WORDS] = cmd[s];
+      const uint32_t w0a = cs[4 * g + r][0], w0b = cs[4 * g + r + 2][0];
+      const uint32_t wh = half ? w0b : w0a;
+      // apply sub-step s-1 to the images: one history bit, or a freshly dealt board
+      if (head && !(wh & 0x200u) && (wh & 0x1FFu)) {
+        const int hb = (int)(wh & 0x1FFu) - 1;
+        atomicOr(reinterpret_cast<uint32_t *>(img_g + hrow * TABLE_BYTES) + (hb >> 5), 1u << (hb & 31));
+      }
+      uint64_t dealm = __ballot(head && (wh & 0x200u));
+      while (dealm) {  // rare: ~1 table in 25 per sub-step
+        const int l = __ffsll((unsigned long long)dealm) - 1;
+        dealm &= dealm - 1ull;
+        const int row = ((l >= 30) ? 1 : 0) + 2 * (l & 1);
+        const uint32_t wq = __builtin_amdgcn_readlane(wh, l);
+        deal_hands(img_g + row * TABLE_BYTES, &ring[4 * g + row][(wq >> 16) & 15u][0], c);
+      }
+      wave_lds_order();
+      const int seat0 = (int)((w0a >> 10) & 3u), seat1 = (int)((w0b >> 10) & 3u);
+      const uint32_t a0 = *reinterpret_cast<const uint32_t *>(img_g + hist_off);
+      const uint32_t a1 = *reinterpret_cast<const uint32_t *>(img_g + hist_off + 2 * TABLE_BYTES);
+      const uint64_t H0 = *reinterpret_cast<const uint64_t *>(img_g + hand_off + seat0 * 8);
+      const uint64_t H1 = *reinterpret_cast<const uint64_t *>(img_g + hand_off + 2 * TABLE_BYTES + seat1 * 8);
+      uint8_t *dst = (s < total) ? optr : ((A.last_obs != nullptr) ? A.last_obs + (table0 + 4 * g) * BRL_OBS_SIZE + 16 * L : nullptr);
+      optr += ostep;
+      if (active && dst != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const uint32_t a = k ? a1 : a0;
+          const uint64_t H = k ? H1 : H0;
+          const int seat = k ? seat1 : seat0;
+          const uint32_t vul = ((k ? w0b : w0a) >> 12) & 15u;
+          const uint32_t m1 = (0xFu >> seat) * 0x11111111u;
+          const uint32_t rot = ((a >> seat) & m1) | ((a << (4 - seat)) & ~m1);
+          const uint32_t hv = (q == 13) ? (uint32_t)(H << 8) : (uint32_t)(H >> 24);
+          const uint32_t word = ((rot & keep_hist) | (hv & keep_hand) | (vul & keep_vul)) >> sh16;
+          brl_u32x4 d;
+          d.x = __umul24(word & 0xFu, 0x204081u) & 0x01010101u;
+          d.y = __umul24((word >> 4) & 0xFu, 0x204081u) & 0x01010101u;
+          d.z = __umul24((word >> 8) & 0xFu, 0x204081u) & 0x01010101u;
+          d.w = __umul24((word >> 12) & 0xFu, 0x204081u) & 0x01010101u;
+          __builtin_nontemporal_store(d, reinterpret_cast<brl_u32x4 *>(dst + 960 * k));
+        }
+      }
+    }
+  }
+#ifdef BRL_TIMING
+  if (c.lane == 0 && A.terminated_count) {  // timing build only: terminated_count doubles as a dump buffer
+    unsigned long long *d = A.terminated_count + ((size_t)blockIdx.x * NW + wave) * 2;
+    d[0] = __builtin_amdgcn_s_memtime() - t_begin;
+    d[1] = t_wait;
+    unsigned long long *tl = A.terminated_count + (size_t)gridDim.x * NW * 2 + ((size_t)blockIdx.x * NW + wave) * 32;
+    for (int k = 0; k < 16; k++) { tl[2 * k] = (k < fs_nst) ? fs_t[k] : 0; tl[2 * k + 1] = (k < fs_nst) ? fs_t[k] : 0; }
+  }
+#endif
+  __syncthreads();
+  for (int i = tid; i < TPB * 16; i += NW * 64) A.state[table0 * 16 + i] = img64[i];
+}

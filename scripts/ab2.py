@@ -75,16 +75,18 @@ def main():
         for name, flags in variants:
             out = os.path.join(VDIR, name + ".so")
             subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
-                                  + flags + ["-o", out, SRC], stderr=subprocess.DEVNULL)
+                                  + [f for f in flags if not f.startswith("env:")] + ["-o", out, SRC], stderr=subprocess.DEVNULL)
             print("built", out)
     if "--run" in sys.argv:
         res = {n: [] for n, _ in variants}
         sha = {}
         extra = {}
         for rep in range(int(os.environ.get("REPS", "3"))):
-            for name, _ in variants:
+            for name, flags in variants:
                 code = f"ROOT={ROOT!r}\nLIB={os.path.join(VDIR, name + '.so')!r}\n" + BODY
-                r = subprocess.run(["timeout", "-k", "5", "90", sys.executable, "-c", code], capture_output=True, text=True)
+                envv = dict(os.environ)
+                envv.update(dict(f[4:].split("=", 1) for f in flags if f.startswith("env:")))  # e.g. env:BRL_ROLLOUT_FS=0
+                r = subprocess.run(["timeout", "-k", "5", "90", sys.executable, "-c", code], capture_output=True, text=True, env=envv)
                 try:
                     d = json.loads(r.stdout.strip().splitlines()[-1])
                     res[name].append(d["us"]); sha[name] = d["sha"]; extra.setdefault(name, []).append((d["iso"], d["step"]))

@@ -19,11 +19,14 @@ def env(dds):
     return brl_amd.BridgeBidding(lut=(dds["keys"], dds["values"]))
 
 
-def make_env(dds, k, ws=None):
+def make_env(dds, k, ws=None, lut=None):
     """k: tables per wave of the per-step kernels; ws: "0" for the K-tables-per-wave fused rollout
-    (k_rollout_random<K>), None for the library default (the wave-specialised k_rollout_ws)."""
+    (k_rollout_random<K>), "ws" for the barrier-synchronised wave-specialised kernel (k_rollout_ws) on every shape,
+    None for the library default (the flag-synchronised k_rollout_fs where it applies: substeps 1, T <= 40, n % 32 == 0;
+    k_rollout_ws otherwise)."""
     import brl_amd
-    new = {"BRL_TABLES_PER_WAVE": str(k), "BRL_ROLLOUT_WS": ws}
+    new = {"BRL_TABLES_PER_WAVE": str(k), "BRL_ROLLOUT_WS": "0" if ws == "0" else None,
+           "BRL_ROLLOUT_FS": "0" if ws == "ws" else None}
     old = {key: os.environ.get(key) for key in new}
     for key, v in new.items():
         if v is None:
@@ -31,7 +34,7 @@ def make_env(dds, k, ws=None):
         else:
             os.environ[key] = v
     try:
-        return brl_amd.BridgeBidding(lut=(dds["keys"], dds["values"]))
+        return brl_amd.BridgeBidding(lut=lut if lut is not None else (dds["keys"], dds["values"]))
     finally:
         for key, v in old.items():
             if v is None:
@@ -150,7 +153,10 @@ def test_observe_any_player(env, oracle):
     (4, None, 1, 2048, 32), (4, None, 4, 1000, 16), (4, None, 1, 1, 5), (4, None, 1, 33, 32),
     (4, None, 1, 4099, 33), (4, None, 4, 515, 12), (4, None, 1, 33, 7), (4, None, 1, 300, 64), (4, None, 1, 129, 7),
     (4, None, 4, 2048, 40), (4, None, 1, 2, 3), (4, None, 1, 30, 33), (4, None, 3, 700, 21), (4, None, 2, 450, 19),
-    (4, None, 8, 130, 5), (4, None, 9, 130, 3)])
+    (4, None, 8, 130, 5), (4, None, 9, 130, 3),
+    # the same shapes as the k_rollout_fs cases above (128x32, 2048x32), forced onto k_rollout_ws; more k_rollout_fs shapes
+    (4, "ws", 1, 128, 32), (4, "ws", 1, 2048, 32), (4, None, 1, 32, 1), (4, None, 1, 64, 40), (4, None, 1, 96, 3),
+    (4, None, 1, 4096, 33), (4, None, 1, 160, 9), (4, None, 1, 8192, 32)])
 def test_fused_random_rollout_matches_oracle(dds, oracle, k, ws, substeps, n, T):
     import brl_amd
     env = make_env(dds, k, ws)
@@ -595,6 +601,28 @@ def test_full_size_properties(dds):
     _, traj2 = roll((None, None, st2, None, 0, 0))
     for a, b in zip(traj, traj2):
         assert torch.equal(a, b)
+
+
+def test_flag_synchronised_rollout_equals_barrier_kernel_at_full_size():
+    """k_rollout_fs (default at the BASELINE shape) and k_rollout_ws write the same bytes: 8192 x 32, 100 000-row LUT,
+    three back-to-back rollouts (state, draw counter and terminated_count carry over)."""
+    import brl_amd
+    from bench import synthetic_lut as bench_lut
+    lut = bench_lut(100_000, 0)
+    outs = []
+    for ws in (None, "ws"):
+        env = make_env(None, 4, ws, lut=lut)
+        roll = brl_amd.make_random_roll_out({"num_steps": 32}, env)
+        rs = (None, None, env.init(5, num_envs=8192), None, 0, 0)
+        got = []
+        for _ in range(3):
+            rs, traj = roll(rs)
+            got.append([t.clone() for t in traj] + [rs[2].packed.clone(), rs[3].clone(), rs[4].clone()])
+        outs.append(got)
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert int(outs[0][-1][-1].item()) > 0
 
 
 @pytest.mark.parametrize("n", [640, 8192])   # 8192 = BASELINE.json configs[2] (num_envs=8192 duplicate self-play)
