@@ -191,20 +191,55 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks):
 
         import brl_amd
         from brl_amd import _capi
-        from brl_amd.gae import gae_scan
         from brl_amd.roll_out import alloc_transition
 
         env = brl_amd.BridgeBidding(lut=(keys, values), device=dev, env_offset=env_offset)
-        cfg = {"num_steps": NUM_STEPS, "game_mode": "normal", "reward_scale": 7600, "return_last_obs": True}
-        roll = brl_amd.make_random_roll_out(cfg, env)
         state = env.init(0, num_envs=NUM_ENVS)
+        packed = state.packed
         trajs = [alloc_transition(NUM_STEPS, NUM_ENVS, dev) for _ in range(NBUF)]
+        # everything a step touches is allocated once: the production loop (brl_amd/train.py) does the same, and at
+        # ~30 us of GPU time per step the host must not spend its time in the allocator
+        advs = [torch.empty((NUM_STEPS, NUM_ENVS), dtype=torch.float32, device=dev) for _ in range(NBUF)]
+        tgts = [torch.empty((NUM_STEPS, NUM_ENVS), dtype=torch.float32, device=dev) for _ in range(NBUF)]
         last_val = torch.zeros(NUM_ENVS, dtype=torch.float32, device=dev)  # the random policy has no critic
-        box = {"rs": (None, None, state, None, 0, 0)}
+        last_obs = torch.empty((NUM_ENVS, 480), dtype=torch.bool, device=dev)
+        last_mask = torch.empty((NUM_ENVS, 38), dtype=torch.bool, device=dev)
+        tc = torch.zeros(1, dtype=torch.int64, device=dev)
+        ptrs = []
+        for tr in trajs:
+            p = _capi.TransitionPtrs()
+            for name in _capi.TransitionPtrs._names:
+                setattr(p, name, getattr(tr, name).data_ptr())
+            ptrs.append(p)
+        lib, h = _capi.lib(), env._h
+        main = torch.cuda.current_stream()
+        # BRL_BENCH_OVERLAP=1 (experiment, off by default): GAE of step i on a second stream beside the rollout of step
+        # i+1 (it only reads step i's buffer); rollout_done[k] orders GAE after its rollout, gae_done[k] orders the NEXT
+        # writer of buffer k after that GAE.  Measured: 38.4 us per step against 31.6 us in one stream — the two
+        # cross-stream event edges per step cost more than the 5-us GAE launch they hide.
+        overlap = os.environ.get("BRL_BENCH_OVERLAP", "0") == "1"
+        side = torch.cuda.Stream(device=dev) if overlap else main
+        rollout_done = [torch.cuda.Event() for _ in range(NBUF)]
+        gae_done = [torch.cuda.Event() for _ in range(NBUF)]
+        gl = float(torch.tensor(1.0 * 0.95, dtype=torch.float32))  # gamma * gae_lambda as ppo.py forms it
+        box = {"draw": 0}
 
         def one_step(i):
-            box["rs"], tb = roll(box["rs"], out=trajs[i % NBUF])
-            gae_scan(env, tb.done, tb.value, tb.reward, last_val, 1.0, 0.95)
+            k = i % NBUF
+            if overlap:
+                main.wait_event(gae_done[k])          # buffer k's previous GAE has read it
+            _capi.check(lib.brl_rollout_random(h, packed.data_ptr(), NUM_ENVS, NUM_STEPS, 1, box["draw"] & 0xFFFFFFFF, 7600.0,
+                                               C.byref(ptrs[k]), last_obs.data_ptr(), last_mask.data_ptr(), tc.data_ptr(),
+                                               main.cuda_stream))
+            box["draw"] += NUM_STEPS
+            if overlap:
+                rollout_done[k].record(main)
+                side.wait_event(rollout_done[k])
+            tr = trajs[k]
+            _capi.check(lib.brl_gae(h, tr.done.data_ptr(), tr.value.data_ptr(), tr.reward.data_ptr(), last_val.data_ptr(),
+                                    1.0, gl, NUM_STEPS, NUM_ENVS, advs[k].data_ptr(), tgts[k].data_ptr(), side.cuda_stream))
+            if overlap:
+                gae_done[k].record(side)
 
     for i in range(args.warmup):
         one_step(i)
@@ -216,21 +251,10 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks):
     elapsed = max_over_ranks(time.perf_counter() - t0)
 
     if not FAKE:
-        # the dominant kernel alone: KERNEL_LAUNCHES launches of k_rollout_ws between ONE HIP-event pair on the
+        # the dominant kernel alone: KERNEL_LAUNCHES launches of k_rollout_fs between ONE HIP-event pair on the
         # launch stream (no per-launch events: a pair costs ~6 us of stream time), through the C-ABI directly
-        rs = box["rs"]
-        packed, draw = rs[2].packed, int(rs[5])
-        tc = torch.zeros(1, dtype=torch.int64, device=dev)
-        last_obs = torch.empty((NUM_ENVS, 480), dtype=torch.bool, device=dev)
-        last_mask = torch.empty((NUM_ENVS, 38), dtype=torch.bool, device=dev)
-        ptrs = []
-        for tr in trajs:
-            p = _capi.TransitionPtrs()
-            for name in _capi.TransitionPtrs._names:
-                setattr(p, name, getattr(tr, name).data_ptr())
-            ptrs.append(p)
-        stream = torch.cuda.current_stream()
-        lib, h = _capi.lib(), env._h
+        draw = box["draw"]
+        stream = main
 
         def launch(i):
             _capi.check(lib.brl_rollout_random(h, packed.data_ptr(), NUM_ENVS, NUM_STEPS, 1, (draw + i * NUM_STEPS) & 0xFFFFFFFF,
@@ -269,12 +293,13 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks):
         "config": {"workload": "configs[1]: num_envs=8192 num_steps=32 random-policy rollout + DDS reward (fused "
                                "kernel) + last_obs + GAE scan", "num_envs_per_gpu": NUM_ENVS, "num_steps": NUM_STEPS,
                    "lut_len": LUT_LEN, "env_steps_per_macro_step": 1, "transition_buffers_in_rotation": NBUF,
+                   "gae": "second stream, beside the next step's rollout" if os.environ.get("BRL_BENCH_OVERLAP", "0") == "1" else "same stream",
                    "env_offsets": [r * NUM_ENVS for r in range(world)],
                    "parallelism": f"env-shard x{world}, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "k_rollout_ws<32,12,1>", "kernel_ms": kern_ms,
+                     "kernel": "k_rollout_fs", "kernel_ms": kern_ms,
                      "kernel_ms_method": f"{KERNEL_LAUNCHES} back-to-back launches between one HIP-event pair, "
                                          f"{NBUF} rotating 144 MB output buffers (rank 0)",
                      "algorithmic_bytes_per_launch": alg_bytes,

@@ -573,4 +573,75 @@ __device__ __forceinline__ LeanStep lean_random_step(uint32_t &sc, uint32_t &sch
   return r;
 }
 
+// ---- the same transition, split for k_rollout_fs -----------------------------------------------------------
+// Its logic wave keeps only what feeds the per-table dependency chain (lean_pick + lean_apply: the call of a uniform draw
+// and the scalars after it); what the follower waves need besides — legal mask, n_legal, history bit — is recomputed
+// off the chain, slot-parallel, by a helper wave (lean_legal, lean_hb1).  Together they equal lean_random_step.
+__device__ __forceinline__ uint32_t lean_seat(uint32_t sc, uint32_t sch) {
+  return (bits(sc, SC_DEALER, 2) + bits(sch, SCH_TURN, 9)) & 3u;
+}
+
+__device__ __forceinline__ void lean_doubles(uint32_t sc, uint32_t seat, uint32_t lb1, uint32_t &can_x, uint32_t &can_xx) {
+  const uint32_t own = ((bits(sc, SC_LBSEAT, 2) ^ seat) & 1u) ^ 1u;
+  const uint32_t x = bits(sc, SC_X, 1), xx = bits(sc, SC_XX, 1), has = lb1 != 0;
+  can_x = has & (own ^ 1u) & (x ^ 1u) & (xx ^ 1u);
+  can_xx = has & own & x & (xx ^ 1u);
+}
+
+// the uniform-random legal call of the player to act: k-th legal action in ascending order, k = mulhi(draw, n_legal)
+__device__ __forceinline__ uint32_t lean_pick(uint32_t sc, uint32_t seat, uint32_t lb1, uint32_t u) {
+  uint32_t can_x, can_xx;
+  lean_doubles(sc, seat, lb1, can_x, can_xx);
+  const uint32_t dbl = can_x | can_xx;
+  const uint32_t n = 36u - lb1 + dbl;  // pass + (35 - lb1) bids + at most one of X / XX
+  const uint32_t k = __umulhi(u, n);
+  const uint32_t a_bid = 2u + lb1 + k - dbl;
+  const uint32_t a_dbl = can_x ? 1u : 2u;
+  uint32_t a = (dbl & (k == 1u)) ? a_dbl : a_bid;
+  a = (k == 0u) ? 0u : a;
+  if (bits(sc, SC_MASKALL, 1)) a = __umulhi(u, 38u);  // a caller-supplied finished table: all-True mask
+  return a;
+}
+
+// A5 pre-step half of auto_reset (src/utils.py:34-43) + the call `a` by `seat`; returns "auction over"
+__device__ __forceinline__ uint32_t lean_apply(uint32_t &sc, uint32_t &sch, uint32_t a, uint32_t seat, uint32_t lb1) {
+  const uint32_t was_term = bits(sc, SC_TERM, 1);
+  sc &= ~(1u << SC_TERM);
+  sch = was_term ? (sch & ~(1023u << SCH_STEP)) : sch;
+  const bool is_pass = a == 0u, is_bid = a >= 3u;
+  const uint32_t b = a - 3u;
+  const uint32_t pass = is_pass ? bits(sc, SC_PASS, 3) + 1u : 0u;
+  const uint32_t set_dbl = is_bid ? 0u : ((a == 1u ? (1u << SC_X) : 0u) | (a == 2u ? (1u << SC_XX) : 0u));
+  const uint32_t bid_clear = (63u << SC_LB1) | (3u << SC_LBSEAT) | (1u << SC_X) | (1u << SC_XX);
+  const uint32_t bid_set = ((b + 1u) << SC_LB1) | (seat << SC_LBSEAT);
+  uint32_t nsc = is_bid ? ((sc & ~bid_clear) | bid_set) : (sc | set_dbl);
+  const uint32_t nlb1 = is_bid ? b + 1u : lb1;
+  const uint32_t term = pass == ((nlb1 != 0u) ? 3u : 4u);
+  nsc = (nsc & ~(7u << SC_PASS)) | (pass << SC_PASS) | (term ? ((1u << SC_TERM) | (1u << SC_MASKALL)) : 0u);
+  sc = nsc;
+  sch += (1u << SCH_STEP) + (term ? 0u : (1u << SCH_TURN));
+  return term;
+}
+
+// legal_action_mask and its population count for the player to act at `seat`
+__device__ __forceinline__ uint64_t lean_legal(uint32_t sc, uint32_t seat, uint32_t &n_legal) {
+  const uint32_t lb1 = bits(sc, SC_LB1, 6);
+  uint32_t can_x, can_xx;
+  lean_doubles(sc, seat, lb1, can_x, can_xx);
+  const uint64_t bids = (ALL_ACTIONS >> (3 + lb1)) << (3 + lb1);
+  const bool all = bits(sc, SC_MASKALL, 1) != 0u;
+  n_legal = all ? 38u : 36u - lb1 + (can_x | can_xx);
+  return all ? ALL_ACTIONS : (bids | (uint64_t)(1u | (can_x << 1) | (can_xx << 2)));
+}
+
+// history bit + 1 (0: none) of call `a` by `seat` when the last bid + 1 was lb1
+__device__ __forceinline__ uint32_t lean_hb1(uint32_t lb1, uint32_t seat, uint32_t a) {
+  const bool is_pass = a == 0u, is_bid = a >= 3u, is_x = a == 1u;
+  const uint32_t b = a - 3u;
+  const uint32_t hb_bid = 9u + 12u * b + seat;
+  const uint32_t hb_dbl = 9u + 12u * (lb1 - 1u) + (is_x ? 4u : 8u) + seat;  // lb1 > 0 when X / XX is legal
+  const uint32_t hb_pass = (lb1 == 0u) ? 5u + seat : 0u;
+  return is_bid ? hb_bid : (is_pass ? hb_pass : hb_dbl);
+}
+
 }  // namespace brl

@@ -10,7 +10,10 @@
 //   * every follower consumes slot s as soon as it is posted, at its own pace (it polls `posted` only when it has caught up);
 //   * <= 11 boards per table can be dealt in <= 40 sub-steps, so the 12-entry board ring never wraps: the loader fetches
 //     all 12 boards of every table up front (two per pass, one in each half of the wave), publishes `ring_count`, and
-//     then turns into the wave that writes the legal-mask rows.
+//     then turns into the wave that writes the legal-mask rows;
+//   * the logic wave runs nothing but the chain (draw -> call -> scalars, ~90 instructions per sub-step): what the
+//     followers need besides (legal mask, n_legal, history bit, observer seat) is recomputed from its raw posts by a
+//     PREP wave, two slots per pass.
 // Why (profiles/r02/r02_rollout_experiments.txt §5): with the output going to HBM the launch is  T = (time until the
 // stores start and are never starved) + (store time of 140 MB).  A store-only probe paced like this hand-off
 // (scripts/micro/store_test4.hip) needs 24-25 us; paced like k_rollout_ws's batches (1,3,4,8,8,..) 29-31 us.
@@ -24,19 +27,25 @@
 #pragma once
 
 constexpr int FS_TPB = 32;
-constexpr int FS_NW = 11;          // logic, loader/mask, scorer, 8 emit
+constexpr int FS_NW = 12;          // logic, loader/mask, scorer, 8 emit, prep
 constexpr int FS_MAX_TOTAL = 40;   // sub-steps per launch
 constexpr int FS_RING = 12;
 constexpr int FS_CHUNK = 8;        // scorer: slots per pass
+#ifndef FS_EXP
+#define FS_EXP 0                   // timing experiments (scripts/timing_fs.py, FLAGS=-DFS_EXP=8): 8 = no observation stores
+#endif
 
+// (explicit LDS address space: a volatile access through a generic pointer becomes a FLAT load whose wait, vmcnt(0), also
+// waits for every store the wave has in flight)
+typedef __attribute__((address_space(3))) volatile int fs_lds_int;
 __device__ __forceinline__ int fs_flag_read(const int *p) {
-  int v = *reinterpret_cast<const volatile int *>(p);
+  int v = *(fs_lds_int *)p;
   asm volatile("" ::: "memory");
   return __builtin_amdgcn_readfirstlane(v);
 }
 __device__ __forceinline__ void fs_flag_write(int *p, int v) {
   asm volatile("" ::: "memory");  // everything written before stays before (same-wave LDS order does the rest)
-  *reinterpret_cast<volatile int *>(p) = v;
+  *(fs_lds_int *)p = v;
 }
 // wait until slot s is posted; `avail` caches the last value seen
 __device__ __forceinline__ void fs_wait(const int *flag, int s, int &avail) {
@@ -49,7 +58,7 @@ __device__ __forceinline__ void fs_wait(const int *flag, int s, int &avail) {
 }
 
 #ifdef BRL_TIMING
-#define FS_STAMP(k) do { if (fs_nst < 16) { fs_t[fs_nst++] = __builtin_amdgcn_s_memtime() - t_begin; } } while (0)
+#define FS_STAMP(k) do { if (c.lane == 0 && A.terminated_count) fs_dump[2 * (k)] = __builtin_amdgcn_s_memtime() - t_begin; } while (0)
 #else
 #define FS_STAMP(k) do { } while (0)
 #endif
@@ -58,8 +67,7 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
   constexpr int TPB = FS_TPB, NW = FS_NW;
 #ifdef BRL_TIMING
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-  unsigned long long fs_t[16];
-  int fs_nst = 0;
+  const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
   unsigned long long t_wait = 0;
 #endif
   __shared__ __attribute__((aligned(16))) uint8_t img[TPB * TABLE_BYTES];
@@ -67,7 +75,11 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
   __shared__ __attribute__((aligned(16))) uint32_t ring[TPB][FS_RING][RING_WORDS];
   __shared__ uint32_t udraw[FS_MAX_TOTAL + 4][TPB];
   __shared__ float s_neglog[BRL_NUM_ACTIONS + 2];
-  __shared__ int posted, ring_count;
+  __shared__ __attribute__((aligned(16))) uint32_t raw[FS_MAX_TOTAL + 1][TPB][4];  // logic -> prep (see the logic wave)
+  __shared__ int posted, raw_posted, ring_count;
+  // emit waves: the packed observation of each table AS SEEN BY each of the four seats (15 dwords: vulnerability nibble,
+  // history rotated to that observer, its hand), kept up to date call by call: a row is a copy of one of them
+  __shared__ __attribute__((aligned(16))) uint32_t oimg[TPB][4][16];
   __shared__ __attribute__((aligned(16))) uint32_t ev[3 * TPB][4];       // scorer: finished boards of a chunk (<= 3 per table)
   __shared__ __attribute__((aligned(16))) int acc[FS_CHUNK][TPB][4];      // scorer: reward by player id per slot of a chunk
   __shared__ __attribute__((aligned(16))) uint32_t minfo[FS_CHUNK][TPB];  // scorer: actor, action, n_legal, done
@@ -77,20 +89,44 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
   // hardware wave w runs on SIMD w % 4: SIMD 3 hosts only two waves, the scorer takes hardware wave 3 there
   const int wave = (hw_wave == 2) ? 3 : ((hw_wave == 3) ? 2 : hw_wave);
   const LaneConst c = make_lane_const();
+#ifdef BRL_TIMING  // stamps go straight to the dump area behind the per-wave summary (terminated_count doubles as dump buffer)
+  unsigned long long *fs_dump = A.terminated_count + (size_t)gridDim.x * NW * 2 + ((size_t)blockIdx.x * NW + wave) * 32;
+#endif
   const int64_t table0 = xcd_block((int64_t)blockIdx.x, (int64_t)gridDim.x) * TPB;
   const int total = A.T;  // substeps == 1: sub-step s == macro-step s; command slots 0..total
   uint64_t *img64 = reinterpret_cast<uint64_t *>(img);
-  for (int i = tid; i < TPB * 16; i += NW * 64) img64[i] = A.state[table0 * 16 + i];
-  if (tid <= BRL_NUM_ACTIONS) s_neglog[tid] = A.neg_log_n[tid];
+  // Prologue: every global load of the workgroup is issued before anything waits (one memory round trip), the Philox
+  // draws run while the loads are in flight.
+  static_assert(TPB * 16 <= NW * 64 && TPB * 64 <= 3 * NW * 64, "one table word and <= 3 image dwords per thread");
+  const uint64_t st_word = (tid < TPB * 16) ? A.state[table0 * 16 + tid] : 0ull;
   const int lt = c.lane & (TPB - 1);
   uint64_t ctr_word = 0;
-  if (wave == 1) ctr_word = A.state[(table0 + lt) * 16 + W_CTR];  // issued now, needed after the barrier
+  if (wave == 1) ctr_word = A.state[(table0 + lt) * 16 + W_CTR];
+  // observer images from the packed tables (words 0..6 history with absolute seats, 7..10 hand words, 11 scalars):
+  // image dword (table t, observer o, dword q) = task 64 t + 16 o + q (q = 15: padding)
+  uint32_t oi_a[3], oi_sc[3];
+  uint64_t oi_h[3];
+  {
+    const uint32_t *st32 = reinterpret_cast<const uint32_t *>(A.state + table0 * 16);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int task = tid + k * NW * 64;
+      const int tk = (task < TPB * 64) ? task : 0;
+      const int t = tk >> 6, o = (tk >> 4) & 3, q = tk & 15;
+      oi_a[k] = st32[t * 32 + ((q < 13) ? q : 13)];
+      oi_h[k] = A.state[(table0 + t) * 16 + W_HAND + o];
+      oi_sc[k] = st32[t * 32 + 2 * W_SC];
+    }
+  }
+  if (tid <= BRL_NUM_ACTIONS) s_neglog[tid] = A.neg_log_n[tid];
   {
     // every action draw of the launch (Philox is state-independent): draw d = draw_base + s lives in word d & 3 of block
     // d >> 2 (counter arithmetic mod 2^32, like k_rollout_random); one (table, block) per thread
     const uint32_t fb = A.draw_base >> 2;
     const int nblk = (total > 0) ? (int)(((A.draw_base & 3u) + (uint32_t)total + 3u) >> 2) : 0;
-    for (int task = tid; task < TPB * nblk; task += NW * 64) {
+    // (tasks start at hardware wave 4: one Philox wave per SIMD before any SIMD gets a second one, none on the waves
+    //  of the logic / loader / scorer roles — the multiplies are quarter-rate and the barrier waits for the slowest wave)
+    for (int task = (hw_wave >= 4) ? tid - 4 * 64 : TPB * nblk; task < TPB * nblk; task += (NW - 4) * 64) {
       const int tb = task & (TPB - 1);
       const uint32_t blk = (fb + (uint32_t)(task >> 5)) & 0x3FFFFFFFu;
       const uint64_t eid = A.env_offset + (uint64_t)(table0 + tb);
@@ -103,14 +139,37 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
       }
     }
   }
+  FS_STAMP(9);   // Philox done
+  if (tid < TPB * 16) img64[tid] = st_word;
+  FS_STAMP(10);  // first global load back
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int task = tid + k * NW * 64;
+    if (task < TPB * 64) {
+      const int t = task >> 6, o = (task >> 4) & 3, q = task & 15;
+      const uint32_t a = oi_a[k];
+      const uint64_t H = oi_h[k];
+      const uint32_t m16 = __umul24(0xFu >> o, 0x1111u), m1 = m16 | (m16 << 16);  // nibble mask 0xF >> o in every nibble
+      const uint32_t rot = ((a >> o) & m1) | ((a << (4 - o)) & ~m1);  // relative seat = (caller - observer) mod 4
+      uint32_t v = (q < 13) ? rot : ((q == 13) ? ((rot & 0xFFFu) | (uint32_t)(H << 8)) : ((q == 14) ? (uint32_t)(H >> 24) : 0u));
+      v |= (q == 0) ? vul_nibble_sc(oi_sc[k], o) : 0u;
+      oimg[t][o][q] = v;
+    }
+  }
   if (tid == 0) {
     posted = 0;
+    raw_posted = 0;
     ring_count = 0;
   }
+  FS_STAMP(11);  // images built
   __syncthreads();  // images, draws and the two counters are in LDS
+  FS_STAMP(12);
 
   if (wave == 0) {
     // ------------------------------------------------------------------ logic wave: lane = table, lanes 32..63 mirror 0..31
+    // Only what feeds the chain: state s -> call -> state s+1 (+ re-deal).  It posts raw[s][table] = (sc, sch of state s,
+    // call of sub-step s-1 | dealt << 8 | ring entry << 16, sc right after sub-step s-1) and publishes raw_posted; the prep
+    // wave turns that into the followers' command (legal mask, n_legal, history bit, observer seat, vulnerability).
     const int tl = lt;
     uint32_t sc, sch, lut, bctr;
     {
@@ -122,46 +181,40 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
     uint2 nxt = make_uint2(0u, 0u);  // (LUT row, fresh scalars) of this table's next board, read one deal ahead
     bool have_nxt = false;
     int ring_seen = 0, kub = 0;      // ring passes known complete; deals of any one table so far (upper bound)
-    uint32_t pend = 0, pend_act = 0, pend_sc = 0;
+    uint32_t kt = 0;                 // boards this table has dealt in this launch = ring entry of its next board
+    uint32_t pa = 0, psc = 0;
     uint32_t un = udraw[0][tl];
     for (int s = 0;; s++) {
-      const uint32_t u = un;
-      un = udraw[(s + 1 < total) ? s + 1 : s][tl];  // next sub-step's draw, off the chain
-      uint32_t nsc = sc, nsch = sch;
-      const LeanStep st = lean_random_step(nsc, nsch, u);
-      if (c.lane < TPB) {  // command slot s: what sub-step s-1 did + how state s looks
-        uint32_t w0 = pend | ((uint32_t)st.seat << 10) | (vul_nibble_sc(sc, st.seat) << 12);
-        uint32_t w3 = ((uint32_t)(st.legal >> 32) & 63u) | (pend_act << 8);
-        *reinterpret_cast<uint4 *>(&cmd[s][tl][0]) = make_uint4(w0, pend_sc, (uint32_t)st.legal, w3);
-      }
-      if (c.lane == 0) fs_flag_write(&posted, s + 1);
-      if ((s & 7) == 0) FS_STAMP(s);
+      if (c.lane < TPB) *reinterpret_cast<uint4 *>(&raw[s][tl][0]) = make_uint4(sc, sch, pa, psc);
+      if (c.lane == 0) fs_flag_write(&raw_posted, s + 1);
+      if ((s & 7) == 0) FS_STAMP(s >> 3);
       if (s == total) break;
-      sc = nsc;
-      sch = nsch;
-      pend_sc = sc;
-      pend_act = (uint32_t)st.action;
-      const bool deal = st.term != 0u;
-      const uint32_t slot = (bctr + 1u) % FS_RING;
-      pend = st.hb1 | ((uint32_t)deal << 9) | (slot << 16) | ((uint32_t)st.seat << 21) | ((uint32_t)st.n_legal << 23);
-      if (__any(deal)) {
-        // the j-th sub-step with a deal reads ring entries of passes <= j (entry of the deal + the one read ahead)
+      const uint32_t u = un;
+      un = udraw[(s + 2 < total) ? s + 1 : total - 1][tl];  // next sub-step's draw, off the chain
+      const uint32_t seat = lean_seat(sc, sch), lb1 = bits(sc, SC_LB1, 6);
+      const uint32_t a = lean_pick(sc, seat, lb1, u);
+      const uint32_t term = lean_apply(sc, sch, a, seat, lb1);
+      psc = sc;
+      pa = a | (term << 8) | (kt << 16);
+      if (__any(term != 0u)) {
+        // the j-th sub-step with a deal reads ring entries <= j (entry of the deal + the one read ahead)
         kub++;
         const int need = (kub + 1 < FS_RING) ? kub + 1 : FS_RING;
         while (ring_seen < need) {
           ring_seen = fs_flag_read(&ring_count);
           if (ring_seen < need) __builtin_amdgcn_s_sleep(1);
         }
-        if (!have_nxt) {
-          nxt = *reinterpret_cast<const uint2 *>(&ring[tl][(bctr + 1u) % FS_RING][12]);
+        if (!have_nxt) {  // (no table has dealt yet: kt == 0 everywhere)
+          nxt = *reinterpret_cast<const uint2 *>(&ring[tl][0][12]);
           have_nxt = true;
         }
-        if (deal) {  // A5 post-step half of auto_reset (src/utils.py:45-55): next board from the ring
+        if (term) {  // A5 post-step half of auto_reset (src/utils.py:45-55): next board from the ring
           sc = nxt.y | (sc & ((1u << SC_TERM) | (1u << SC_ILLEGAL)));
           sch = 0;
           lut = nxt.x;
           bctr += 1u;
-          nxt = *reinterpret_cast<const uint2 *>(&ring[tl][(bctr + 1u) % FS_RING][12]);
+          kt += 1u;
+          nxt = *reinterpret_cast<const uint2 *>(&ring[tl][(kt < FS_RING) ? kt : FS_RING - 1][12]);
         }
       }
     }
@@ -169,6 +222,34 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
       uint2 *p = reinterpret_cast<uint2 *>(img + tl * TABLE_BYTES);
       p[W_SC] = make_uint2(sc, sch);
       p[W_CTR] = make_uint2(lut, bctr);
+    }
+  } else if (wave == NW - 1) {
+    // ------------------------------------------------------------------ prep wave: raw -> command, two slots per pass
+    // (lanes 0..31: slot s, lanes 32..63: slot s + 1 when it is already there).  Command format: brl_kernels.hip (k_rollout_ws).
+    int avail = 0;
+    int s = 0;
+    while (s <= total) {
+      fs_wait(&raw_posted, s, avail);
+      const bool two = (s + 1 < avail);  // (avail <= total + 1)
+      const int ms = s + ((two && c.lane >= TPB) ? 1 : 0);
+      if (two || c.lane < TPB) {
+        const uint4 cur = *reinterpret_cast<const uint4 *>(&raw[ms][lt][0]);
+        const uint2 prv = *reinterpret_cast<const uint2 *>(&raw[(ms > 0) ? ms - 1 : 0][lt][0]);
+        const uint32_t seat = lean_seat(cur.x, cur.y);
+        uint32_t nl_cur, nl_prv;
+        const uint64_t legal = lean_legal(cur.x, seat, nl_cur);
+        const uint32_t seatp = lean_seat(prv.x, prv.y);
+        (void)lean_legal(prv.x, seatp, nl_prv);
+        const uint32_t a = cur.z & 63u;
+        const uint32_t hb1 = lean_hb1(bits(prv.x, SC_LB1, 6), seatp, a);
+        uint32_t pend = hb1 | (((cur.z >> 8) & 1u) << 9) | (((cur.z >> 16) & 15u) << 16) | (seatp << 21) | (nl_prv << 23);
+        pend = (ms > 0) ? pend : 0u;
+        const uint32_t w0 = pend | (seat << 10);
+        const uint32_t w3 = ((uint32_t)(legal >> 32) & 63u) | (a << 8);
+        *reinterpret_cast<uint4 *>(&cmd[ms][lt][0]) = make_uint4(w0, cur.w, (uint32_t)legal, w3);
+      }
+      s += two ? 2 : 1;
+      if (c.lane == 0) fs_flag_write(&posted, s);
     }
   } else if (wave == 1) {
     // ------------------------------------------------------------------ loader, then mask wave
@@ -186,7 +267,7 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
         pv[i] = reinterpret_cast<const brl_u32x4 *>(A.lut.values)[pidx[i]];
       };
       auto commit = [&](int i) {
-        uint4 *dst = reinterpret_cast<uint4 *>(&ring[lt][(nb0 + (uint32_t)(2 * i + half)) % FS_RING][0]);
+        uint4 *dst = reinterpret_cast<uint4 *>(&ring[lt][2 * i + half][0]);  // entry j = the j-th board dealt in this launch
         brl_u32x4 *dv = reinterpret_cast<brl_u32x4 *>(dst);
         dv[0] = pha[i];
         dv[1] = phb[i];
@@ -201,7 +282,7 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
         commit(i);
         if (i + 2 < NP) issue(i + 2);
       }
-      FS_STAMP(0);
+      FS_STAMP(8);
     }
     // The 32 legal-mask rows of a slot are 1216 contiguous bytes = 76 chunks of 16 B: lane l writes chunk l, lanes < 12
     // also chunk 64 + l.  A chunk holds the bytes of table ta (from action `off` on) and possibly of ta + 1.
@@ -232,6 +313,7 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
         uint32_t d[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) d[i] = __umul24((bits16 >> (4 * i)) & 0xFu, 0x204081u) & 0x01010101u;
+        // (plain stores: the rows of neighbouring workgroups share 128-B lines, L2 merges them; non-temporal: +1.0 us)
         *reinterpret_cast<uint4 *>(dstrow + 16 * (c.lane + 64 * q)) = make_uint4(d[0], d[1], d[2], d[3]);
       }
     }
@@ -358,22 +440,23 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
   } else {
     // ------------------------------------------------------------------ emit waves: wave 3 + g owns tables 4 g .. 4 g + 3
     // lane L < 60 holds 16-byte piece L of rows 0-1 (960 contiguous bytes) and piece L of rows 2-3: piece L is half
-    // L & 1 of packed dword q = (L >> 1) % 15 of row r = (L >> 1) / 15 (and of row r + 2)
+    // L & 1 of packed dword q = (L >> 1) % 15 of row r = (L >> 1) / 15 (and of row r + 2): 16 bits of the acting seat's
+    // observer image, one ds_read_u16.  Lanes 0..7 (rows 0, 2) and 30..37 (rows 1, 3) also keep the images up to date:
+    // lane (row, observer o) sets the call's history bit at relative seat (caller - o) mod 4.
     const int g = wave - 3;
-    uint8_t *img_g = img + 4 * g * TABLE_BYTES;
     const int L = c.lane;
     const bool active = L < 60;
     const int pq = active ? (L >> 1) : 29;
     const int r = pq / 15, q = pq - 15 * r;
     const int half = L & 1;
-    const uint32_t keep_hist = (q < 13) ? 0xFFFFFFFFu : ((q == 13) ? 0x00000FFFu : 0u);
-    const uint32_t keep_hand = (q < 13) ? 0u : 0xFFFFFFFFu;
-    const uint32_t keep_vul = (q == 0) ? 0xFu : 0u;
-    const int hist_off = r * TABLE_BYTES + 4 * ((q < 13) ? q : 13);
-    const int hand_off = r * TABLE_BYTES + W_HAND * 8;
-    const bool head = active && (q == 0);  // lanes 0, 1, 30, 31: bookkeeping of rows 0, 2, 1, 3
-    const int hrow = r + 2 * half;
-    const int sh16 = 16 * half;
+    const int hl = (L < 30) ? L : L - 30;
+    const bool head = active && hl < 8;
+    const int hsel = head ? (hl >> 2) : 0;  // 0: the lane's row r, 1: its row r + 2
+    const uint32_t ho = (uint32_t)(hl & 3);
+    uint8_t *og = reinterpret_cast<uint8_t *>(&oimg[4 * g][0][0]);  // this group's 4 x 4 images, 64 B each
+    uint32_t *oh = reinterpret_cast<uint32_t *>(og + ((r + 2 * hsel) * 4 + (int)ho) * 64);
+    const int rd_off = r * 256 + q * 4 + half * 2;
+    const int dl_o = active ? L / 15 : 3, dl_q = active ? L - 15 * (L / 15) : 15;  // deals: lane = (observer, dword)
     uint8_t *optr = A.out.obs + (table0 + 4 * g) * BRL_OBS_SIZE + 16 * L;
     const int64_t ostep = A.n * BRL_OBS_SIZE;
     int avail = 0;
@@ -384,49 +467,45 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
       fs_wait(&posted, s, avail);
 #ifdef BRL_TIMING
       t_wait += __builtin_amdgcn_s_memtime() - tw0;
-      if ((s & 7) == 0) FS_STAMP(s);
+      if ((s & 7) == 0) FS_STAMP(s >> 3);
 #endif
       const uint32_t(*cs)[CMD_WORDS] = cmd[s];
       const uint32_t w0a = cs[4 * g + r][0], w0b = cs[4 * g + r + 2][0];
-      const uint32_t wh = half ? w0b : w0a;
-      // apply sub-step s-1 to the images: one history bit, or a freshly dealt board
+      const uint32_t wh = hsel ? w0b : w0a;
+      // apply sub-step s-1 to the images: one history bit per observer, or a freshly dealt board
       if (head && !(wh & 0x200u) && (wh & 0x1FFu)) {
-        const int hb = (int)(wh & 0x1FFu) - 1;
-        atomicOr(reinterpret_cast<uint32_t *>(img_g + hrow * TABLE_BYTES) + (hb >> 5), 1u << (hb & 31));
+        const uint32_t hb = (wh & 0x1FFu) - 1u;
+        const uint32_t bit = (hb & ~3u) | ((hb - ho) & 3u);
+        atomicOr(oh + (bit >> 5), 1u << (bit & 31u));
       }
-      uint64_t dealm = __ballot(head && (wh & 0x200u));
+      uint64_t dealm = __ballot(head && ho == 0u && (wh & 0x200u));
       while (dealm) {  // rare: ~1 table in 25 per sub-step
-        const int l = __ffsll((unsigned long long)dealm) - 1;
+        const int l = __ffsll((unsigned long long)dealm) - 1;  // lanes 0, 4, 30, 34: rows 0, 2, 1, 3
         dealm &= dealm - 1ull;
-        const int row = ((l >= 30) ? 1 : 0) + 2 * (l & 1);
+        const int row = (l >= 30) ? 1 + ((l - 30) >> 2) * 2 : (l >> 2) * 2;
         const uint32_t wq = __builtin_amdgcn_readlane(wh, l);
-        deal_hands(img_g + row * TABLE_BYTES, &ring[4 * g + row][(wq >> 16) & 15u][0], c);
+        const uint32_t *re = &ring[4 * g + row][(wq >> 16) & 15u][0];
+        const uint64_t H = *reinterpret_cast<const uint64_t *>(re + 2 * dl_o);
+        const uint32_t v = (dl_q == 0) ? vul_nibble_sc(re[13], dl_o)
+                                       : ((dl_q == 13) ? (uint32_t)(H << 8) : ((dl_q == 14) ? (uint32_t)(H >> 24) : 0u));
+        if (active) oimg[4 * g + row][dl_o][dl_q] = v;
       }
       wave_lds_order();
-      const int seat0 = (int)((w0a >> 10) & 3u), seat1 = (int)((w0b >> 10) & 3u);
-      const uint32_t a0 = *reinterpret_cast<const uint32_t *>(img_g + hist_off);
-      const uint32_t a1 = *reinterpret_cast<const uint32_t *>(img_g + hist_off + 2 * TABLE_BYTES);
-      const uint64_t H0 = *reinterpret_cast<const uint64_t *>(img_g + hand_off + seat0 * 8);
-      const uint64_t H1 = *reinterpret_cast<const uint64_t *>(img_g + hand_off + 2 * TABLE_BYTES + seat1 * 8);
+      const uint32_t v0 = *reinterpret_cast<const uint16_t *>(og + rd_off + (int)((w0a >> 10) & 3u) * 64);
+      const uint32_t v1 = *reinterpret_cast<const uint16_t *>(og + rd_off + 512 + (int)((w0b >> 10) & 3u) * 64);
       uint8_t *dst = (s < total) ? optr : ((A.last_obs != nullptr) ? A.last_obs + (table0 + 4 * g) * BRL_OBS_SIZE + 16 * L : nullptr);
       optr += ostep;
       if (active && dst != nullptr) {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-          const uint32_t a = k ? a1 : a0;
-          const uint64_t H = k ? H1 : H0;
-          const int seat = k ? seat1 : seat0;
-          const uint32_t vul = ((k ? w0b : w0a) >> 12) & 15u;
-          const uint32_t m1 = (0xFu >> seat) * 0x11111111u;
-          const uint32_t rot = ((a >> seat) & m1) | ((a << (4 - seat)) & ~m1);
-          const uint32_t hv = (q == 13) ? (uint32_t)(H << 8) : (uint32_t)(H >> 24);
-          const uint32_t word = ((rot & keep_hist) | (hv & keep_hand) | (vul & keep_vul)) >> sh16;
+          const uint32_t word = k ? v1 : v0;
           brl_u32x4 d;
           d.x = __umul24(word & 0xFu, 0x204081u) & 0x01010101u;
           d.y = __umul24((word >> 4) & 0xFu, 0x204081u) & 0x01010101u;
           d.z = __umul24((word >> 8) & 0xFu, 0x204081u) & 0x01010101u;
-          d.w = __umul24((word >> 12) & 0xFu, 0x204081u) & 0x01010101u;
-          __builtin_nontemporal_store(d, reinterpret_cast<brl_u32x4 *>(dst + 960 * k));
+          d.w = __umul24(word >> 12, 0x204081u) & 0x01010101u;
+          if (!(FS_EXP & 8)) __builtin_nontemporal_store(d, reinterpret_cast<brl_u32x4 *>(dst + 960 * k));
+          else if (d.x == 0x12345678u) __builtin_nontemporal_store(d, reinterpret_cast<brl_u32x4 *>(dst + 960 * k));  // timing experiment: no stores
         }
       }
     }
@@ -436,10 +515,26 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
     unsigned long long *d = A.terminated_count + ((size_t)blockIdx.x * NW + wave) * 2;
     d[0] = __builtin_amdgcn_s_memtime() - t_begin;
     d[1] = t_wait;
-    unsigned long long *tl = A.terminated_count + (size_t)gridDim.x * NW * 2 + ((size_t)blockIdx.x * NW + wave) * 32;
-    for (int k = 0; k < 16; k++) { tl[2 * k] = (k < fs_nst) ? fs_t[k] : 0; tl[2 * k + 1] = (k < fs_nst) ? fs_t[k] : 0; }
+    fs_dump[30] = __builtin_amdgcn_s_memrealtime() - rt_begin;  // 100 MHz ticks
   }
 #endif
   __syncthreads();
-  for (int i = tid; i < TPB * 16; i += NW * 64) A.state[table0 * 16 + i] = img64[i];
+  // packed tables back: history (words 0..6) = the image of observer 0 without its vulnerability nibble and hand bits,
+  // hand words (7..10) from each observer's image, words 11..15 from the scalar image
+  for (int i = tid; i < TPB * 16; i += NW * 64) {
+    const int t = i >> 4, w = i & 15;
+    uint64_t v;
+    if (w < 7) {
+      uint32_t lo = oimg[t][0][2 * w], hi = oimg[t][0][2 * w + 1];
+      lo = (w == 0) ? (lo & ~0xFu) : lo;
+      hi = (w == 6) ? (hi & 0xFFFu) : hi;
+      v = (uint64_t)lo | ((uint64_t)hi << 32);
+    } else if (w < 11) {
+      const uint32_t d13 = oimg[t][w - 7][13], d14 = oimg[t][w - 7][14];
+      v = ((uint64_t)d14 << 24) | (uint64_t)((d13 >> 8) & 0xFFFFF0u);
+    } else {
+      v = img64[i];
+    }
+    A.state[table0 * 16 + i] = v;
+  }
 }
