@@ -119,6 +119,35 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
     }
   }
   if (tid <= BRL_NUM_ACTIONS) s_neglog[tid] = A.neg_log_n[tid];
+  // (loader) board pass i: lanes 0..31 fetch board nb0 + 2 i of their table, lanes 32..63 board nb0 + 2 i + 1 (Philox ->
+  // LUT row -> packed hand words + DDS values, 48 B) into ring entries 2 i, 2 i + 1.  Passes 0 and 1 are ISSUED HERE, before
+  // the workgroup's barrier: the logic wave needs the first two entries of every table at its first deal, a few hundred
+  // cycles after the barrier, and waits for them otherwise (~1.7 k cycles in its first 8 sub-steps).
+  constexpr int LP = FS_RING / 2;
+  brl_u32x4 ld_ha[LP], ld_hb[LP], ld_v[LP];
+  uint32_t ld_idx[LP], ld_scb[LP];
+  const int ld_half = c.lane >> 5;
+  auto ld_issue = [&](int i) {
+    const uint64_t eid = A.env_offset + (uint64_t)(table0 + lt);
+    const uint32_t nb0 = (uint32_t)(ctr_word >> 32) + 1u;
+    board_params(A.g, eid, nb0 + (uint32_t)(2 * i + ld_half), A.lut.len, ld_idx[i], ld_scb[i]);
+    ld_ha[i] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)ld_idx[i]];
+    ld_hb[i] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)ld_idx[i] + 1];
+    ld_v[i] = reinterpret_cast<const brl_u32x4 *>(A.lut.values)[ld_idx[i]];
+  };
+  auto ld_commit = [&](int i) {
+    uint4 *dst = reinterpret_cast<uint4 *>(&ring[lt][2 * i + ld_half][0]);  // entry j = the j-th board dealt in this launch
+    brl_u32x4 *dv = reinterpret_cast<brl_u32x4 *>(dst);
+    dv[0] = ld_ha[i];
+    dv[1] = ld_hb[i];
+    dv[2] = ld_v[i];
+    dst[3] = make_uint4(ld_idx[i], ld_scb[i], 0u, 0u);
+    if (c.lane == 0) fs_flag_write(&ring_count, 2 * i + 2);
+  };
+  if (wave == 1) {
+    ld_issue(0);
+    ld_issue(1);
+  }
   {
     // every action draw of the launch (Philox is state-independent): draw d = draw_base + s lives in word d & 3 of block
     // d >> 2 (counter arithmetic mod 2^32, like k_rollout_random); one (table, block) per thread
@@ -253,37 +282,13 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
     }
   } else if (wave == 1) {
     // ------------------------------------------------------------------ loader, then mask wave
-    {
-      const int half = c.lane >> 5;
-      const uint64_t eid = A.env_offset + (uint64_t)(table0 + lt);
-      const uint32_t nb0 = (uint32_t)(ctr_word >> 32) + 1u;
-      constexpr int NP = FS_RING / 2;  // passes: lanes 0..31 fetch board nb0 + 2 i, lanes 32..63 board nb0 + 2 i + 1
-      brl_u32x4 pha[NP], phb[NP], pv[NP];
-      uint32_t pidx[NP], pscb[NP];
-      auto issue = [&](int i) {
-        board_params(A.g, eid, nb0 + (uint32_t)(2 * i + half), A.lut.len, pidx[i], pscb[i]);
-        pha[i] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)pidx[i]];
-        phb[i] = reinterpret_cast<const brl_u32x4 *>(A.lut.hands)[2 * (size_t)pidx[i] + 1];
-        pv[i] = reinterpret_cast<const brl_u32x4 *>(A.lut.values)[pidx[i]];
-      };
-      auto commit = [&](int i) {
-        uint4 *dst = reinterpret_cast<uint4 *>(&ring[lt][2 * i + half][0]);  // entry j = the j-th board dealt in this launch
-        brl_u32x4 *dv = reinterpret_cast<brl_u32x4 *>(dst);
-        dv[0] = pha[i];
-        dv[1] = phb[i];
-        dv[2] = pv[i];
-        dst[3] = make_uint4(pidx[i], pscb[i], 0u, 0u);
-        if (c.lane == 0) fs_flag_write(&ring_count, 2 * i + 2);
-      };
-      issue(0);
-      issue(1);
+    // (passes 0 and 1 were issued in the prologue; each commit publishes two more ring entries per table)
 #pragma unroll
-      for (int i = 0; i < NP; i++) {
-        commit(i);
-        if (i + 2 < NP) issue(i + 2);
-      }
-      FS_STAMP(8);
+    for (int i = 0; i < LP; i++) {
+      ld_commit(i);
+      if (i + 2 < LP) ld_issue(i + 2);
     }
+    FS_STAMP(8);
     // The 32 legal-mask rows of a slot are 1216 contiguous bytes = 76 chunks of 16 B: lane l writes chunk l, lanes < 12
     // also chunk 64 + l.  A chunk holds the bytes of table ta (from action `off` on) and possibly of ta + 1.
     uint32_t ta[2], tb[2], off[2];
