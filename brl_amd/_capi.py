@@ -84,6 +84,12 @@ def lib() -> C.CDLL:
         "brl_eval_reduce": [_vp, i64, C.POINTER(TableInfoPtrs), C.POINTER(TableInfoPtrs), _vp, _vp, _vp, _vp],
         "brl_ppo_loss": [i32, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, i64, f32, f32, f32, i32, i32, _vp, _vp, _vp, _vp, _vp],
         "brl_ppo_stats": [i32, _vp, i64, _vp, f32, f32, _vp, _vp],
+        "brl_ppo_loss_heads": [i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, i64, f32, f32, f32, i32, i32, _vp, _vp, _vp, _vp],
+        "brl_mb_gather": [i32, C.POINTER(TransitionPtrs), _vp, _vp, _vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+        "brl_relu_bwd_colsum": [i32, _vp, _vp, i64, i64, i64, _vp, _vp, _vp],
+        "brl_bias_finalize": [i32, i32, _vp, _vp, _vp, i64, _vp],
+        "brl_ppo_stats_at": [i32, _vp, i64, _vp, f32, f32, _vp, _vp, _vp],
+        "brl_adam_clip": [i32, _vp, _vp, _vp, _vp, i64, _vp, f32, f32, f32, f32, f32, _vp, _vp, _vp, _vp],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)
@@ -96,7 +102,8 @@ def lib() -> C.CDLL:
 EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_destroy", "brl_set_rng",
            "brl_init_random", "brl_init_from_deals", "brl_step", "brl_observe", "brl_get_fields",
            "brl_rollout_random", "brl_policy_step", "brl_policy_step_at", "brl_obs_cast", "brl_gae", "brl_imp_reward", "brl_duplicate_step",
-           "brl_eval_step", "brl_eval_reduce", "brl_ppo_loss", "brl_ppo_stats"]
+           "brl_eval_step", "brl_eval_reduce", "brl_ppo_loss", "brl_ppo_stats", "brl_ppo_loss_heads", "brl_mb_gather",
+           "brl_relu_bwd_colsum", "brl_adam_clip", "brl_bias_finalize", "brl_ppo_stats_at"]
 
 
 def check(rc: int) -> None:

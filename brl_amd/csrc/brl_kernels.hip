@@ -1502,6 +1502,7 @@ struct PpoArgs {
   float clip_eps, vf_coef, ent_coef;
   int masked, value_clipping;
   float *dlogits, *dvalue, *partials, *illp;
+  int64_t vs, dls, dvs;  // strides of value, dlogits (row), dvalue: 1, 38, 1 for separate arrays; 39 each for the merged head
 };
 
 __device__ __forceinline__ float wave_sum_f(float v) {
@@ -1548,7 +1549,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss(PpoArgs A) {
   const float dratio = ((a1 < a2) || inside) ? -g : 0.0f;  // d(-min(a1, a2)) / d ratio (ties: both branches agree)
   const float dlp = dratio * ratio * invB;
   // value loss (src/update.py:48-60)
-  const float v = A.value[bb], ov = A.old_value[bb], t = A.tgt[bb];
+  const float v = A.value[bb * A.vs], ov = A.old_value[bb], t = A.tgt[bb];
   float vl, dv;
   if (A.value_clipping) {
     const float dcl = fminf(fmaxf(v - ov, -eps), eps);
@@ -1568,11 +1569,11 @@ __global__ __launch_bounds__(256) void k_ppo_loss(PpoArgs A) {
   const bool live = A.masked ? legal : in;
   const float dz = (live ? dlp * (onehot - psel) : 0.0f) - A.ent_coef * invB * dH;
   if (valid && in) {
-    A.dlogits[b * BRL_NUM_ACTIONS + lane] = dz;
+    A.dlogits[b * A.dls + lane] = dz;
     if (A.illp) A.illp[b * BRL_NUM_ACTIONS + lane] = legal ? 0.0f : p2;
   }
   if (lane == 0) {
-    if (valid) A.dvalue[b] = A.vf_coef * dv * invB;
+    if (valid) A.dvalue[b * A.dvs] = A.vf_coef * dv * invB;
     part[wave][0] = valid ? vl : 0.0f;
     part[wave][1] = valid ? la : 0.0f;
     part[wave][2] = valid ? H : 0.0f;
@@ -1594,7 +1595,8 @@ __global__ __launch_bounds__(256) void k_ppo_loss(PpoArgs A) {
 // (src/update.py:138-141) without an SVD.
 //   out[0] total  [1] value_loss  [2] loss_actor  [3] entropy  [4] approx_kl  [5] clipfrac  [6] illegal-action norm / 2
 __global__ __launch_bounds__(512) void k_ppo_stats(const float *partials, int64_t nblk, int64_t batch, const float *G,
-                                                   float vf_coef, float ent_coef, float *out) {
+                                                   float vf_coef, float ent_coef, float *out, const int32_t *row_index) {
+  if (row_index != nullptr) out += 8 * (int64_t)(*row_index);  // a log of [steps, 8] rows, indexed from device memory
   constexpr int D = BRL_NUM_ACTIONS, DD = D * D;
   __shared__ float g[DD], m[DD], t[DD], vec[D], red[2], st[8];
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1651,6 +1653,8 @@ __global__ __launch_bounds__(512) void k_ppo_stats(const float *partials, int64_
     }
   }
 }
+
+#include "ppo_update.hpp"  // k_mb_gather, k_relu_bwd_colsum, k_adam_norm / k_adam_apply
 
 // =====================================================================================
 // C-ABI
@@ -2070,8 +2074,83 @@ extern "C" int brl_ppo_loss(int device, const float *logits, int64_t logits_stri
   NEED(logits_stride >= BRL_NUM_ACTIONS, "logits_stride");
   HIP_TRY(hipSetDevice(device));
   PpoArgs A{logits, logits_stride, value, mask, action, old_value, old_log_prob, gae, targets, batch, clip_eps, vf_coef,
-            ent_coef, masked, value_clipping, dlogits, dvalue, partials, illegal_probs};
+            ent_coef, masked, value_clipping, dlogits, dvalue, partials, illegal_probs, 1, BRL_NUM_ACTIONS, 1};
   hipLaunchKernelGGL(k_ppo_loss, dim3(thread_grid(batch, 4)), dim3(256), 0, (hipStream_t)stream, A);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_ppo_loss_heads(int device, const float *heads, const uint8_t *mask, const int32_t *action,
+                                  const float *old_value, const float *old_log_prob, const float *gae, const float *targets,
+                                  int64_t batch, float clip_eps, float vf_coef, float ent_coef, int masked, int value_clipping,
+                                  float *dheads, float *partials, float *illegal_probs, void *stream) {
+  NEED(batch > 0, "batch");
+  NEED(heads && mask && action && old_value && old_log_prob && gae && targets, "NULL input array");
+  NEED(dheads && partials, "NULL output array");
+  HIP_TRY(hipSetDevice(device));
+  constexpr int64_t HS = BRL_NUM_ACTIONS + 1;  // [batch, 39]: 38 logits, then the value
+  PpoArgs A{heads, HS, heads + BRL_NUM_ACTIONS, mask, action, old_value, old_log_prob, gae, targets, batch, clip_eps, vf_coef,
+            ent_coef, masked, value_clipping, dheads, dheads + BRL_NUM_ACTIONS, partials, illegal_probs, HS, HS, HS};
+  hipLaunchKernelGGL(k_ppo_loss, dim3(thread_grid(batch, 4)), dim3(256), 0, (hipStream_t)stream, A);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_mb_gather(int device, const brl_transition *flat, const float *adv, const float *targets, const int64_t *perm,
+                             const int32_t *mb_index, int64_t mbs, float *x0, uint8_t *mask, int32_t *action, float *old_value,
+                             float *old_log_prob, float *gae_out, float *targets_out, void *stream) {
+  NEED(flat && flat->obs && flat->legal_action_mask && flat->action && flat->value && flat->log_prob, "trajectory");
+  NEED(adv && targets && perm && mb_index && mbs > 0, "adv / targets / perm / mb_index / mbs");
+  NEED(x0 && mask && action && old_value && old_log_prob && gae_out && targets_out, "NULL output array");
+  HIP_TRY(hipSetDevice(device));
+  GatherArgs A{flat->obs, flat->legal_action_mask, flat->action, flat->value, flat->log_prob, adv, targets, perm, mb_index, mbs,
+               x0, mask, action, old_value, old_log_prob, gae_out, targets_out};
+  hipLaunchKernelGGL(k_mb_gather, dim3((unsigned)mbs), dim3(128), 0, (hipStream_t)stream, A);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_relu_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, float *db,
+                                   float *scratch, void *stream) {
+  NEED(dh && scratch && rows > 0 && cols > 0 && ld >= cols, "dh / scratch / rows / cols / ld");
+  HIP_TRY(hipSetDevice(device));
+  const int64_t tiles = (rows + 63) / 64;
+  hipLaunchKernelGGL(k_relu_bwd_tiles, dim3((unsigned)((cols + 63) / 64), (unsigned)tiles), dim3(256), 0, (hipStream_t)stream, dh,
+                     h, rows, cols, ld, scratch);
+  if (db != nullptr) {
+    BiasSegs S{};
+    S.n = 1; S.tiles = tiles; S.partials[0] = scratch; S.cols[0] = cols; S.db[0] = db;
+    hipLaunchKernelGGL(k_bias_finalize, dim3((unsigned)((cols + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream, S);
+  }
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_bias_finalize(int device, int nseg, const float *const *scratch, const int64_t *cols, float *const *db,
+                                 int64_t rows, void *stream) {
+  NEED(nseg >= 1 && nseg <= BIAS_MAX_SEGS && scratch && cols && db && rows > 0, "nseg / scratch / cols / db / rows");
+  HIP_TRY(hipSetDevice(device));
+  BiasSegs S{};
+  S.n = nseg; S.tiles = (rows + 63) / 64;
+  int64_t maxc = 0;
+  for (int i = 0; i < nseg; i++) {
+    NEED(scratch[i] && db[i] && cols[i] > 0, "segment");
+    S.partials[i] = scratch[i]; S.cols[i] = cols[i]; S.db[i] = db[i];
+    maxc = cols[i] > maxc ? cols[i] : maxc;
+  }
+  hipLaunchKernelGGL(k_bias_finalize, dim3((unsigned)((maxc + 255) / 256), (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, S);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr, float beta1,
+                             float beta2, float eps, float max_norm, float *scratch, int32_t *mb_index, float *norm_out,
+                             void *stream) {
+  NEED(p && g && m && v && step && scratch && n > 0 && n % 4 == 0, "p / g / m / v / step / scratch / n (a multiple of 4)");
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(k_adam_norm, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, g, n, scratch, step);
+  hipLaunchKernelGGL(k_adam_apply, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, p, g, m, v, n, scratch, step, lr,
+                     beta1, beta2, eps, max_norm, mb_index, norm_out);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }
@@ -2081,7 +2160,17 @@ extern "C" int brl_ppo_stats(int device, const float *partials, int64_t batch, c
   NEED(partials && out && batch > 0, "partials / out / batch");
   HIP_TRY(hipSetDevice(device));
   hipLaunchKernelGGL(k_ppo_stats, dim3(1), dim3(512), 0, (hipStream_t)stream, partials, (int64_t)thread_grid(batch, 4), batch,
-                     gram, vf_coef, ent_coef, out);
+                     gram, vf_coef, ent_coef, out, (const int32_t *)nullptr);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_ppo_stats_at(int device, const float *partials, int64_t batch, const float *gram, float vf_coef,
+                                float ent_coef, float *out_rows, const int32_t *row_index, void *stream) {
+  NEED(partials && out_rows && row_index && batch > 0, "partials / out_rows / row_index / batch");
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(k_ppo_stats, dim3(1), dim3(512), 0, (hipStream_t)stream, partials, (int64_t)thread_grid(batch, 4), batch,
+                     gram, vf_coef, ent_coef, out_rows, row_index);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

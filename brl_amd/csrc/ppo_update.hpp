@@ -1,0 +1,161 @@
+// ppo_update.hpp — the non-GEMM half of one PPO minibatch step (src/update.py:74-242) as a handful of launches:
+// minibatch gather, ReLU backward + bias gradient, global-norm clip + Adam on flat buffers.  The GEMMs (5 forward, 9
+// backward) stay with hipBLASLt / rocBLAS through torch; brl_amd/update.py::FusedMinibatch strings them together and
+// captures the whole step in one hipGraph.  Included by brl_kernels.hip (C-ABI at the end of this file).
+#pragma once
+
+// ---- minibatch gather: row perm[mb * B + b] of the flattened [T*N] trajectory -> static minibatch buffers, observation
+// bytes -> float (`take(batch, permutation)` + one minibatch slice, src/update.py:193-206; G5: obs.astype(float32)).
+// One 128-thread block per sample.  `mb_index` lives in device memory (advanced by k_adam_apply), so a captured graph walks
+// through the epoch's minibatches by itself.
+struct GatherArgs {
+  const uint8_t *obs, *mask;
+  const int32_t *action;
+  const float *value, *log_prob, *adv, *tgt;
+  const int64_t *perm;
+  const int32_t *mb_index;
+  int64_t B;
+  float *x0;
+  uint8_t *o_mask;
+  int32_t *o_action;
+  float *o_value, *o_log_prob, *o_adv, *o_tgt;
+};
+
+__global__ __launch_bounds__(128) void k_mb_gather(GatherArgs A) {
+  const int64_t b = blockIdx.x;
+  const int64_t row = A.perm[(int64_t)(*A.mb_index) * A.B + b];
+  const int t = (int)threadIdx.x;
+  if (t < 120) {  // 4 observation bytes -> 4 floats
+    const uint32_t w = reinterpret_cast<const uint32_t *>(A.obs + row * BRL_OBS_SIZE)[t];
+    reinterpret_cast<float4 *>(A.x0 + b * BRL_OBS_SIZE)[t] =
+        make_float4((float)(w & 0xFFu), (float)((w >> 8) & 0xFFu), (float)((w >> 16) & 0xFFu), (float)(w >> 24));
+  }
+  if (t < BRL_NUM_ACTIONS) A.o_mask[b * BRL_NUM_ACTIONS + t] = A.mask[row * BRL_NUM_ACTIONS + t];
+  if (t == 64) A.o_action[b] = A.action[row];
+  if (t == 65) A.o_value[b] = A.value[row];
+  if (t == 66) A.o_log_prob[b] = A.log_prob[row];
+  if (t == 67) A.o_adv[b] = A.adv[row];
+  if (t == 68) A.o_tgt[b] = A.tgt[row];
+}
+
+// ---- ReLU backward + bias gradient of one hidden layer, two launches: k_relu_bwd_tiles: dz = dh * (h > 0) in place and
+// the column sums of every 64-row tile (h == NULL: no ReLU — the head: column sums of d(out)); k_bias_finalize: db[c] = sum
+// over the row tiles in index order (deterministic; no atomics, no cross-block hand-off inside a launch).
+__global__ __launch_bounds__(256) void k_relu_bwd_tiles(float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld,
+                                                         float *partials) {
+  __shared__ float part[4][64];
+  const int c = (int)(threadIdx.x & 63u), rg = (int)(threadIdx.x >> 6);
+  const int64_t col = (int64_t)blockIdx.x * 64 + c, r0 = (int64_t)blockIdx.y * 64 + rg;
+  float d[16], hv[16];
+  const bool cv = col < cols;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int64_t r = r0 + 4 * k;
+    const bool v = cv && r < rows;
+    d[k] = v ? dh[r * ld + col] : 0.0f;
+    hv[k] = (v && h != nullptr) ? h[r * ld + col] : 1.0f;
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int64_t r = r0 + 4 * k;
+    const float z = (hv[k] > 0.0f) ? d[k] : 0.0f;
+    if (h != nullptr && cv && r < rows) dh[r * ld + col] = z;
+    s += z;
+  }
+  part[rg][c] = s;
+  __syncthreads();
+  if (rg == 0 && cv) partials[(int64_t)blockIdx.y * cols + col] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+}
+
+constexpr int BIAS_MAX_SEGS = 8;
+struct BiasSegs {  // up to 8 layers finalised by one launch (blockIdx.y = layer)
+  int n;
+  int64_t tiles;
+  const float *partials[BIAS_MAX_SEGS];
+  int64_t cols[BIAS_MAX_SEGS];
+  float *db[BIAS_MAX_SEGS];
+};
+
+__global__ __launch_bounds__(256) void k_bias_finalize(BiasSegs S) {
+  const int seg = (int)blockIdx.y;
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x, cols = S.cols[seg];
+  if (col >= cols) return;
+  const float *p = S.partials[seg];
+  float s = 0.0f;
+  for (int64_t t = 0; t < S.tiles; t++) s += p[t * cols + col];
+  S.db[seg][col] = s;
+}
+
+// ---- optax.chain(clip_by_global_norm(max_norm), adam(lr, eps)) (ppo.py:195-211) on flat fp32 buffers, two launches:
+// k_adam_norm: per-block partial sums of g^2 (fixed order) and the step counter; k_adam_apply: every block re-adds the
+// partials in the same order (deterministic, no cross-block hand-off), scales the gradient, updates m, v, p the way
+// torch.optim.Adam does (bias corrections 1 - beta^t, denominator sqrt(v) / sqrt(bc2) + eps).
+constexpr int ADAM_BLOCKS = 1024, ADAM_THREADS = 256;  // n is a multiple of 4 (the caller pads its flat buffers)
+
+__global__ __launch_bounds__(ADAM_THREADS) void k_adam_norm(const float *g, int64_t n, float *partials, float *step) {
+  __shared__ float red[ADAM_THREADS / 64];
+  const int64_t n4 = n >> 2;
+  const int64_t chunk = (n4 + ADAM_BLOCKS - 1) / ADAM_BLOCKS;
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n4) ? lo + chunk : n4;
+  float s = 0.0f;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += ADAM_THREADS) {
+    const float4 x = reinterpret_cast<const float4 *>(g)[i];
+    s += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+  }
+  s = wave_sum_f(s);
+  if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (blockIdx.x == 0) *step += 1.0f;  // read by k_adam_apply (next launch)
+  }
+}
+
+__global__ __launch_bounds__(ADAM_THREADS) void k_adam_apply(float *p, const float *g, float *m, float *v, int64_t n,
+                                                             const float *partials, const float *step, float lr, float b1,
+                                                             float b2, float eps, float max_norm, int32_t *mb_index,
+                                                             float *norm_out) {
+  __shared__ float red[ADAM_THREADS / 64];
+  __shared__ float s_scale;
+  {
+    float s = 0.0f;
+    for (int i = (int)threadIdx.x; i < ADAM_BLOCKS; i += ADAM_THREADS) s += partials[i];
+    s = wave_sum_f(s);
+    if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+      // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
+      const float coef = (max_norm > 0.0f) ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+      s_scale = coef;
+      if (blockIdx.x == 0) {
+        if (norm_out) *norm_out = norm;
+        if (mb_index) *mb_index += 1;  // the next replay's gather reads the next minibatch
+      }
+    }
+    __syncthreads();
+  }
+  const float scale = s_scale;
+  const float t = *step;
+  const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+  const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+  const int64_t n4 = n >> 2;
+  const int64_t chunk = (n4 + ADAM_BLOCKS - 1) / ADAM_BLOCKS;
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n4) ? lo + chunk : n4;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += ADAM_THREADS) {
+    const float4 g4 = reinterpret_cast<const float4 *>(g)[i];
+    float4 m4 = reinterpret_cast<float4 *>(m)[i], v4 = reinterpret_cast<float4 *>(v)[i], p4 = reinterpret_cast<float4 *>(p)[i];
+    const float gs[4] = {g4.x * scale, g4.y * scale, g4.z * scale, g4.w * scale};
+    float ms[4] = {m4.x, m4.y, m4.z, m4.w}, vs[4] = {v4.x, v4.y, v4.z, v4.w}, ps[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      ms[k] = ms[k] + (gs[k] - ms[k]) * (1.0f - b1);            // exp_avg.lerp_(grad, 1 - beta1)
+      vs[k] = vs[k] * b2 + gs[k] * gs[k] * (1.0f - b2);          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+      ps[k] -= step_size * (ms[k] / (sqrtf(vs[k]) / bc2_sqrt + eps));
+    }
+    reinterpret_cast<float4 *>(m)[i] = make_float4(ms[0], ms[1], ms[2], ms[3]);
+    reinterpret_cast<float4 *>(v)[i] = make_float4(vs[0], vs[1], vs[2], vs[3]);
+    reinterpret_cast<float4 *>(p)[i] = make_float4(ps[0], ps[1], ps[2], ps[3]);
+  }
+}

@@ -168,6 +168,7 @@ class GraphedMinibatch:
 
     def __init__(self, config, actor_forward_pass, params, opt, mbs: int, device):
         self.cfg, self.fp, self.params, self.opt = config, actor_forward_pass, params, opt
+        self.mbs = int(mbs)
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)  # noqa: E731
         self.mb = Transition(z((mbs,), torch.bool), z((mbs,), torch.int32), z((mbs,), torch.float32),
                              z((mbs,), torch.float32), z((mbs,), torch.float32), z((mbs, 480), torch.bool),
@@ -225,6 +226,204 @@ class GraphedMinibatch:
         return self.out[0].clone(), self.out[1].clone()
 
 
+class FusedMinibatch:
+    """One PPO minibatch step of the "DeepMind" ReLU MLP with NOTHING but its 14 GEMMs left to torch: the loss and its
+    output gradients (``brl_ppo_loss_heads``), ReLU backward + bias gradients (``brl_relu_bwd_colsum``), global-norm
+    clipping + Adam on flat parameter / gradient / moment buffers (``brl_adam_clip``) are single HIP launches, the
+    backward pass is written out (no autograd), the whole step is ONE hipGraph, and the minibatch is gathered from the
+    un-shuffled trajectory by ``brl_mb_gather`` (no per-epoch ``take`` of the 126 MB observation buffer, no per-
+    minibatch copies).  ~24 launches per step instead of ~75 (``profiles/r02``: 0.55 ms -> see DESIGN.md §4.2).
+
+    The module's parameters and the optimizer's moments become VIEWS of the flat buffers, so ``params``, ``state_dict``
+    checkpoints and the eager path keep working on the same memory.  Mirrors torch.optim.Adam's arithmetic and
+    ``clip_grad_norm_``; checked against the float64 numpy restatement and the eager path (tests/test_gpu_parity.py)."""
+
+    @staticmethod
+    def supports(config, params) -> bool:
+        return (bool(config.get("fused_update", True)) and str(getattr(params, "model", "")).startswith("DeepMind")
+                and getattr(params, "act", None) is torch.relu and not config.get("illegal_action_l2norm_coef", 0.0)
+                and not config.get("reward_scaling", False)
+                and next(params.parameters()).is_cuda and next(params.parameters()).dtype == torch.float32)
+
+    def __init__(self, config, params, opt, mbs: int, device):
+        from . import _capi
+        self.cfg, self.params, self.opt, self.mbs, self.dev = config, params, opt, int(mbs), device
+        f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)  # noqa: E731
+        body = list(params.body)
+        # flat layout: (W, b) of every hidden layer, then actor.weight | critic.weight (one [39,1024] matrix), then
+        # actor.bias | critic.bias
+        plist = [q for lin in body for q in (lin.weight, lin.bias)] + [params.actor.weight, params.critic.weight,
+                                                                      params.actor.bias, params.critic.bias]
+        assert len(plist) == len(list(params.parameters()))
+        sizes = [q.numel() for q in plist]
+        self.n = n = (sum(sizes) + 3) // 4 * 4  # brl_adam_clip works on float4s: zero padding at the end
+        self.P, self.G, self.M, self.V = f(n), f(n), f(n), f(n)
+        self.step = torch.zeros((), dtype=torch.float32, device=device)
+        self.plist = plist
+        off = 0
+        views = {}
+        with torch.no_grad():
+            for q, k in zip(plist, sizes):
+                sl = slice(off, off + k)
+                self.P[sl].copy_(q.detach().reshape(-1))
+                st = opt.state.get(q, {})
+                if "exp_avg" in st:  # built after eager steps / from a loaded optimizer: continue from that state
+                    self.M[sl].copy_(st["exp_avg"].reshape(-1))
+                    self.V[sl].copy_(st["exp_avg_sq"].reshape(-1))
+                q.data = self.P[sl].view(q.shape)
+                q.grad = self.G[sl].view(q.shape)
+                st_step = st.get("step")
+                opt.state[q] = {"step": st_step.to(device=device, dtype=torch.float32).reshape(()) if torch.is_tensor(st_step)
+                                else torch.zeros((), dtype=torch.float32, device=device),
+                                "exp_avg": self.M[sl].view(q.shape), "exp_avg_sq": self.V[sl].view(q.shape)}
+                views[q] = sl
+                off += k
+        self.views = views
+        H = body[0].weight.shape[0]
+        K = params.actor.weight.shape[0] + 1
+        self.W = [lin.weight for lin in body]                      # [out, in] views of P
+        self.b = [lin.bias for lin in body]
+        self.GW = [self.G[views[lin.weight]].view(lin.weight.shape) for lin in body]
+        self.Gb = [self.G[views[lin.bias]] for lin in body]
+        wa = views[params.actor.weight]
+        self.Wh = self.P[wa.start:wa.start + K * H].view(K, H)     # actor rows, then the critic row
+        self.GWh = self.G[wa.start:wa.start + K * H].view(K, H)
+        ba = views[params.actor.bias]
+        self.bh = self.P[ba.start:ba.start + K]
+        self.Gbh = self.G[ba.start:ba.start + K]
+        B = self.mbs
+        self.x0 = f(B, 480)
+        self.mask = torch.zeros((B, 38), dtype=torch.uint8, device=device)
+        self.mask[:, 0] = 1  # a valid dummy batch for the warm-up iterations
+        self.action = torch.zeros(B, dtype=torch.int32, device=device)
+        self.old_v, self.old_lp, self.adv, self.tgt = f(B), f(B), f(B), f(B)
+        self.dheads = f(B, K)
+        self.partials = f((B + 3) // 4, 8)
+        self.illp = f(B, 38)
+        self.out = f(8)
+        self.scratch = f(1024)
+        tiles = (B + 63) // 64
+        self.tile_sums = [f(tiles * H) for _ in body] + [f(tiles * K)]   # per-layer partial column sums (bias gradients)
+        import ctypes as C
+        nseg = len(body) + 1
+        self._seg_scratch = (C.c_void_p * nseg)(*[t.data_ptr() for t in self.tile_sums])
+        self._seg_cols = (C.c_int64 * nseg)(*([H] * len(body) + [K]))
+        self._seg_db = (C.c_void_p * nseg)(*([g.data_ptr() for g in self.Gb] + [self.Gbh.data_ptr()]))
+        self._nseg = nseg
+        self._log_cap = int(config.get("update_log_capacity", 16384))   # minibatch steps of one update_step call
+        self.log = f(self._log_cap, 8)                                  # static: the captured statistics launch writes row mb_index
+        self.side = torch.cuda.Stream(device=device)
+        self.norm = f(1)
+        self.mb_index = torch.zeros(1, dtype=torch.int32, device=device)  # minibatch step within the current update
+        self.perm = None  # static int64 [epochs * T*N]: every epoch's permutation, filled by begin_update
+        self.lib, self.capi = _capi.lib(), _capi
+        d0 = opt.defaults
+        self.lr, (self.b1, self.b2), self.eps = float(d0["lr"]), d0["betas"], float(d0["eps"])
+        self.max_norm = float(config["max_grad_norm"]) if config.get("global_gradient_clipping", True) else 0.0
+        # warm-up and capture run real steps on the dummy batch: put parameters, moments and counters back afterwards
+        saved = [t.clone() for t in (self.P, self.M, self.V, self.step, self.mb_index)]
+        self.graph = None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(3):
+                    self._step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph), torch.no_grad():
+                self._step()
+            self.graph = graph
+        finally:
+            with torch.no_grad():
+                for t, q in zip((self.P, self.M, self.V, self.step, self.mb_index), saved):
+                    t.copy_(q)
+
+    def _step(self):
+        L, chk, B = self.lib, self.capi.check, self.mbs
+        s = torch.cuda.current_stream().cuda_stream
+        di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        cfg = self.cfg
+        hs, x = [], self.x0
+        for W, b in zip(self.W, self.b):                          # forward: bias + ReLU in the GEMM epilogue
+            x = torch._addmm_activation(b, x, W.t(), use_gelu=False)
+            hs.append(x)
+        heads = torch.addmm(self.bh, x, self.Wh.t())              # [B, 39]: 38 logits, value
+        chk(L.brl_ppo_loss_heads(di, heads.data_ptr(), self.mask.data_ptr(), self.action.data_ptr(), self.old_v.data_ptr(),
+                                 self.old_lp.data_ptr(), self.adv.data_ptr(), self.tgt.data_ptr(), B, float(cfg["clip_eps"]),
+                                 float(cfg["vf_coef"]), float(cfg["ent_coef"]),
+                                 int(bool(cfg.get("actor_illegal_action_mask", True))),
+                                 int(bool(cfg.get("value_clipping", True))), self.dheads.data_ptr(), self.partials.data_ptr(),
+                                 self.illp.data_ptr(), s))
+        # the logged statistics (src/update.py:136-167) on a side stream: in the captured graph a parallel branch beside
+        # the backward pass (k_ppo_stats is one block, 33 us)
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            gram = self.illp.t() @ self.illp
+            chk(L.brl_ppo_stats_at(di, self.partials.data_ptr(), B, gram.data_ptr(), float(cfg["vf_coef"]),
+                                   float(cfg["ent_coef"]), self.log.data_ptr(), self.mb_index.data_ptr(),
+                                   self.side.cuda_stream))
+        # backward, written out: dW = dz^T h_prev, db = column sums of dz (finished for all layers by one launch),
+        # dh_prev = dz W
+        torch.mm(self.dheads.t(), x, out=self.GWh)
+        nl = len(self.W)
+        chk(L.brl_relu_bwd_colsum(di, self.dheads.data_ptr(), None, B, self.dheads.shape[1], self.dheads.shape[1], None,
+                                  self.tile_sums[nl].data_ptr(), s))
+        dh = torch.mm(self.dheads, self.Wh)
+        for l in range(nl - 1, -1, -1):
+            chk(L.brl_relu_bwd_colsum(di, dh.data_ptr(), hs[l].data_ptr(), B, dh.shape[1], dh.shape[1], None,
+                                      self.tile_sums[l].data_ptr(), s))
+            torch.mm(dh.t(), hs[l - 1] if l > 0 else self.x0, out=self.GW[l])
+            if l > 0:
+                dh = torch.mm(dh, self.W[l])
+        chk(L.brl_bias_finalize(di, self._nseg, self._seg_scratch, self._seg_cols, self._seg_db, B, s))
+        cur.wait_stream(self.side)  # the statistics read mb_index, which the Adam launch advances
+        chk(L.brl_adam_clip(di, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), self.n,
+                            self.step.data_ptr(), self.lr, float(self.b1), float(self.b2), self.eps, self.max_norm,
+                            self.scratch.data_ptr(), self.mb_index.data_ptr(), self.norm.data_ptr(), s))
+
+    # ---- one update_step call -----------------------------------------------------------------------------------
+    def begin_update(self, flat: Transition, adv_f, tgt_f, perms):
+        """flat: the [T*N, ...] views of the trajectory; adv_f / tgt_f: [T*N]; perms: one permutation of T*N per epoch.
+        Returns the [epochs * minibatches, 8] log the replays fill (total, value_loss, loss_actor, entropy, approx_kl,
+        clipfrac, illegal-action norm / 2, 0)."""
+        tp = self.capi.TransitionPtrs()
+        self._keep = (Transition(*[x.contiguous() for x in flat]), adv_f.contiguous(), tgt_f.contiguous())
+        fl, self._adv, self._tgt = self._keep
+        for name in self.capi.TransitionPtrs._names:
+            t = getattr(fl, name)
+            setattr(tp, name, (t.view(torch.uint8) if t.dtype == torch.bool else t).data_ptr())
+        self._tp = tp
+        steps = sum(p.numel() for p in perms) // self.mbs
+        with torch.no_grad():
+            if steps > self._log_cap:
+                raise RuntimeError("FusedMinibatch: more minibatch steps per update than config['update_log_capacity']")
+            allp = torch.cat(perms)
+            if self.perm is None or self.perm.numel() != allp.numel():
+                self.perm = torch.empty_like(allp)
+            self.perm.copy_(allp)
+            self.mb_index.zero_()
+            self.step.copy_(self.opt.state[self.plist[0]]["step"])  # the optimizer may have been stepped eagerly / loaded
+        return self.log[:steps]
+
+    def run_mb(self):
+        import ctypes as C
+        s = torch.cuda.current_stream().cuda_stream
+        di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        self.capi.check(self.lib.brl_mb_gather(di, C.byref(self._tp), self._adv.data_ptr(), self._tgt.data_ptr(),
+                                               self.perm.data_ptr(), self.mb_index.data_ptr(), self.mbs, self.x0.data_ptr(),
+                                               self.mask.data_ptr(), self.action.data_ptr(), self.old_v.data_ptr(),
+                                               self.old_lp.data_ptr(), self.adv.data_ptr(), self.tgt.data_ptr(), s))
+        self.graph.replay()
+
+    def end_update(self):
+        with torch.no_grad():  # every parameter's step counter (torch keeps one per parameter)
+            for q in self.plist:
+                self.opt.state[q]["step"].copy_(self.step)
+        self._keep = self._tp = None
+
+
 def make_update_step(config, actor_forward_pass, optimizer=None):
     """``make_update_step(config, actor_forward_pass, optimizer)`` (src/update.py:9); returns
     ``update_step(runner_state, traj_batch, advantages, targets) -> (runner_state, loss_info)`` (:74,242).
@@ -248,15 +447,31 @@ def make_update_step(config, actor_forward_pass, optimizer=None):
         totals, auxes = [], []
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         graphed = None
+        fused = None
         if config.get("graph_update", True) and adv_f.is_cuda and not multi and sched is None:
             graphed = opt_state.get("graphed")
-            if graphed is None or graphed.params is not params or graphed.gae.shape[0] != mbs:
+            want_fused = FusedMinibatch.supports(config, params)
+            if graphed is None or graphed.params is not params or graphed.mbs != mbs or isinstance(graphed, FusedMinibatch) != want_fused:
                 try:
-                    graphed = GraphedMinibatch(config, actor_forward_pass, params, opt, mbs, adv_f.device)
+                    graphed = (FusedMinibatch if want_fused else GraphedMinibatch)(config, *( (params, opt) if want_fused
+                               else (actor_forward_pass, params, opt)), mbs, adv_f.device)
                 except Exception as e:  # capture is an optimisation, never a requirement
                     graphed = False
                     opt_state["graph_error"] = repr(e)
                 opt_state["graphed"] = graphed
+            if isinstance(graphed, FusedMinibatch):
+                fused = graphed
+        if fused is not None:
+            # minibatches are gathered straight from the un-shuffled buffer by index: no per-epoch take(), no copies
+            perms = [torch.randperm(batch_size, device=adv_f.device, generator=gen)            # src/update.py:193
+                     for _ in range(int(config["update_epochs"]))]
+            log = fused.begin_update(flat, adv_f, tgt_f, perms)
+            for _ in range(int(config["update_epochs"]) * num_mb):
+                fused.run_mb()
+            fused.end_update()
+            log = log.clone().reshape(int(config["update_epochs"]), num_mb, 8)
+            loss_info = (log[..., 0], tuple(log[..., 1 + i] for i in range(6)))
+            return (params, opt_state, env_state, last_obs, terminated_count, int(rng) + 1), loss_info
         for _ in range(int(config["update_epochs"])):
             perm = torch.randperm(batch_size, device=adv_f.device, generator=gen)   # src/update.py:193
             # shuffled_batch = take(x, permutation) once per epoch, minibatches are then contiguous views

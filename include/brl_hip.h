@@ -257,6 +257,47 @@ int brl_ppo_loss(int device, const float *logits, int64_t logits_stride, const f
 int brl_ppo_stats(int device, const float *partials, int64_t batch, const float *gram, float vf_coef, float ent_coef,
                   float *out, void *stream);
 
+/* ---- one PPO minibatch step without the small launches (src/update.py:74-242; brl_amd/update.py::FusedMinibatch strings
+ * these together with the 14 GEMMs of the 4 x 1024 MLP and captures the step in one hipGraph) ---------------------------- */
+
+/* brl_ppo_loss on the MERGED head output: heads float [batch,39] = 38 logits then the value (one GEMM for both heads);
+ * dheads float [batch,39] receives d(total)/d(heads).  Everything else as brl_ppo_loss. */
+int brl_ppo_loss_heads(int device, const float *heads, const uint8_t *mask, const int32_t *action, const float *old_value,
+                       const float *old_log_prob, const float *gae, const float *targets, int64_t batch, float clip_eps,
+                       float vf_coef, float ent_coef, int masked, int value_clipping, float *dheads, float *partials,
+                       float *illegal_probs, void *stream);
+
+/* `shuffled = take(batch, permutation)` + the slice of minibatch *mb_index (src/update.py:193-206) in one launch: row
+ * perm[*mb_index * mbs + b] of the flattened [T*N] trajectory `flat` (and of adv / targets) -> the static minibatch
+ * buffers; x0 float [mbs,480] = obs.astype(float32) (src/update.py:95).  mb_index is DEVICE memory (brl_adam_clip advances
+ * it), so a captured graph walks through an epoch by itself. */
+int brl_mb_gather(int device, const brl_transition *flat, const float *adv, const float *targets, const int64_t *perm,
+                  const int32_t *mb_index, int64_t mbs, float *x0, uint8_t *mask, int32_t *action, float *old_value,
+                  float *old_log_prob, float *gae_out, float *targets_out, void *stream);
+
+/* Backward of `h = relu(z)` plus the bias gradient of that layer: dh [rows,ld] *= (h > 0) in place and the column sums
+ * of every 64-row tile into scratch (float [ceil(rows / 64) * cols]); db != NULL: a second launch adds the tiles in index
+ * order, db[c] = sum_r dh[r,c] (deterministic).  h == NULL: column sums only (the head's bias gradient).
+ * db == NULL: tiles only — brl_bias_finalize then finishes several layers with one launch. */
+int brl_relu_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, float *db,
+                        float *scratch, void *stream);
+
+/* db[i][c] = sum over the tiles of scratch[i] (as written by brl_relu_bwd_colsum for `rows` rows) for nseg <= 8 layers. */
+int brl_bias_finalize(int device, int nseg, const float *const *scratch, const int64_t *cols, float *const *db, int64_t rows,
+                      void *stream);
+
+/* brl_ppo_stats writing row *row_index (device memory) of out_rows float [steps,8]: the loss log of a whole update. */
+int brl_ppo_stats_at(int device, const float *partials, int64_t batch, const float *gram, float vf_coef, float ent_coef,
+                     float *out_rows, const int32_t *row_index, void *stream);
+
+/* optax.chain(clip_by_global_norm(max_norm), adam(lr, eps)) (ppo.py:195-211) on flat fp32 buffers of n elements, two
+ * launches (n a multiple of 4: pad the buffers with zeros): *step (device float) += 1; g scaled by
+ * min(1, max_norm / (|g| + 1e-6)) (max_norm <= 0: no clipping); m, v, p updated with torch.optim.Adam's arithmetic.
+ * scratch: float [1024].  mb_index (may be NULL): advanced by one.
+ * norm_out (may be NULL): |g| before clipping. */
+int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr, float beta1,
+                  float beta2, float eps, float max_norm, float *scratch, int32_t *mb_index, float *norm_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

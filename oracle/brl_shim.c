@@ -306,3 +306,36 @@ int brl_ppo_stats(int device, const float *pt, int64_t b, const float *gram, flo
   (void)device; (void)pt; (void)b; (void)gram; (void)vc; (void)ec; (void)out; (void)s;
   NOT_HERE("brl_ppo_stats");
 }
+/* the fused PPO minibatch step (GEMM-side helpers of brl_amd/update.py::FusedMinibatch): GPU library only; the float64
+ * restatement the update tests compare with is tests/ppo_numpy.py */
+int brl_ppo_loss_heads(int device, const float *hd, const uint8_t *m, const int32_t *a, const float *ov, const float *olp,
+                       const float *g, const float *t, int64_t b, float ce, float vc, float ec, int mk, int vcl, float *dh,
+                       float *pt, float *ip, void *s) {
+  (void)device; (void)hd; (void)m; (void)a; (void)ov; (void)olp; (void)g; (void)t; (void)b; (void)ce; (void)vc; (void)ec; (void)mk; (void)vcl; (void)dh; (void)pt; (void)ip; (void)s;
+  NOT_HERE("brl_ppo_loss_heads");
+}
+int brl_mb_gather(int device, const brl_transition *flat, const float *adv, const float *tg, const int64_t *perm,
+                  const int32_t *mbi, int64_t mbs, float *x0, uint8_t *m, int32_t *a, float *ov, float *olp, float *go, float *to,
+                  void *s) {
+  (void)device; (void)flat; (void)adv; (void)tg; (void)perm; (void)mbi; (void)mbs; (void)x0; (void)m; (void)a; (void)ov; (void)olp; (void)go; (void)to; (void)s;
+  NOT_HERE("brl_mb_gather");
+}
+int brl_relu_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, float *db, float *scr,
+                        void *s) {
+  (void)device; (void)dh; (void)h; (void)rows; (void)cols; (void)ld; (void)db; (void)scr; (void)s;
+  NOT_HERE("brl_relu_bwd_colsum");
+}
+int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr, float b1, float b2,
+                  float eps, float mn, float *scratch, int32_t *mbi, float *no, void *s) {
+  (void)device; (void)p; (void)g; (void)m; (void)v; (void)n; (void)step; (void)lr; (void)b1; (void)b2; (void)eps; (void)mn; (void)scratch; (void)mbi; (void)no; (void)s;
+  NOT_HERE("brl_adam_clip");
+}
+int brl_bias_finalize(int device, int nseg, const float *const *scr, const int64_t *cols, float *const *db, int64_t rows, void *s) {
+  (void)device; (void)nseg; (void)scr; (void)cols; (void)db; (void)rows; (void)s;
+  NOT_HERE("brl_bias_finalize");
+}
+int brl_ppo_stats_at(int device, const float *pt, int64_t b, const float *gram, float vc, float ec, float *out, const int32_t *ri,
+                     void *s) {
+  (void)device; (void)pt; (void)b; (void)gram; (void)vc; (void)ec; (void)out; (void)ri; (void)s;
+  NOT_HERE("brl_ppo_stats_at");
+}

@@ -884,23 +884,39 @@ def test_lut_rotation_reinitialises_envs(dds, oracle):
 
 
 def test_graphed_update_matches_eager_update():
-    """The hipGraph-captured minibatch step must produce the same parameters as the eager one."""
+    """The hipGraph-captured minibatch steps must produce the same parameters as the eager one: the autograd graph
+    (fused_update=False) runs the very same kernels — equal to rounding; the written-out backward + HIP Adam
+    (FusedMinibatch) differs from eager by fp32 summation order only: 1e-6 after one epoch; over more steps PPO's clip
+    boundaries amplify such differences for a few weights (a sample's ratio crossing 1 +- clip_eps switches its
+    gradient off), so two epochs are compared on average and in their losses."""
     from brl_amd.models import make_forward_pass
-    from brl_amd.update import make_update_step
+    from brl_amd.update import FusedMinibatch, GraphedMinibatch, make_update_step
     from tests.test_update_cpu import CFG, fake_batch
     tb, adv, tgt = fake_batch(4, 256, seed=3)
     tb = type(tb)(*[x.cuda() for x in tb]); adv, tgt = adv.cuda(), tgt.cuda()
     fp = make_forward_pass("relu", "DeepMind")
-    outs = []
-    for graph in (False, True):
-        net = fp.init(11, device="cuda")
-        cfg = dict(CFG, minibatch_size=256, update_epochs=2, graph_update=graph)
-        rs, (total, aux) = make_update_step(cfg, fp)((net, None, None, None, 0, 5), tb, adv, tgt)
-        if graph:
-            assert rs[1].get("graphed"), rs[1].get("graph_error")
-        outs.append((torch.cat([p.detach().reshape(-1) for p in net.parameters()]), total))
-    assert torch.allclose(outs[0][1], outs[1][1], atol=1e-5)            # same losses (fp32 reduction order may differ)
-    assert torch.allclose(outs[0][0], outs[1][0], atol=1e-5, rtol=1e-4)  # same updated parameters
+    for epochs in (1, 2):
+        outs = {}
+        for mode in ("eager", "autograd-graph", "fused"):
+            net = fp.init(11, device="cuda")
+            cfg = dict(CFG, minibatch_size=256, update_epochs=epochs, graph_update=mode != "eager", fused_update=mode == "fused")
+            rs, (total, aux) = make_update_step(cfg, fp)((net, None, None, None, 0, 5), tb, adv, tgt)
+            if mode != "eager":
+                assert isinstance(rs[1].get("graphed"), FusedMinibatch if mode == "fused" else GraphedMinibatch), rs[1].get("graph_error")
+            assert total.shape == (epochs, 4) and all(a.shape == (epochs, 4) for a in aux)
+            outs[mode] = (torch.cat([p.detach().reshape(-1) for p in net.parameters()]), total, aux)
+        e = outs["eager"]
+        assert torch.allclose(e[1], outs["autograd-graph"][1], atol=1e-5)
+        assert torch.allclose(e[0], outs["autograd-graph"][0], atol=1e-5, rtol=1e-4)
+        f = outs["fused"]
+        if epochs == 1:
+            assert torch.allclose(e[1], f[1], atol=1e-6) and torch.allclose(e[0], f[0], atol=1e-6, rtol=1e-5)
+            for a, b in zip(e[2], f[2]):
+                assert torch.allclose(a, b, atol=1e-5)
+        else:
+            assert torch.allclose(e[1], f[1], atol=1e-4)
+            d = (e[0] - f[0]).abs()
+            assert float(d.mean()) < 2e-5 and float(d.max()) < 2 * cfg["lr"]
 
 
 def test_state_replace_board_fields(env, oracle, dds):
@@ -1013,9 +1029,11 @@ def test_fused_ppo_loss_kernel_matches_numpy(masked, vclip, B):
     assert abs(float(t2) - float(total)) < 2e-5
 
 
-def test_graphed_update_built_after_eager_steps_keeps_adam_state():
+@pytest.mark.parametrize("fused", [False, True])
+def test_graphed_update_built_after_eager_steps_keeps_adam_state(fused):
     """A hipGraph minibatch step captured AFTER eager steps (optimizer moments / step counts already live) must continue
-    from that state: same parameters as staying eager."""
+    from that state: same parameters as staying eager (autograd graph: to rounding; FusedMinibatch, which adopts the
+    moments into its flat buffers: on average — see test_graphed_update_matches_eager_update for why not element-wise)."""
     from brl_amd.models import make_forward_pass
     from brl_amd.update import make_update_step
     from tests.test_update_cpu import CFG, fake_batch
@@ -1027,14 +1045,77 @@ def test_graphed_update_built_after_eager_steps_keeps_adam_state():
         for it in range(3):
             tb, adv, tgt = fake_batch(4, 256, seed=20 + it)
             tb = type(tb)(*[x.cuda() for x in tb])
-            cfg = dict(CFG, minibatch_size=256, update_epochs=1, graph_update=(late_graph and it >= 1))
+            cfg = dict(CFG, minibatch_size=256, update_epochs=1, graph_update=(late_graph and it >= 1), fused_update=fused)
             rs, _ = make_update_step(cfg, fp)(rs, tb, adv.cuda(), tgt.cuda())
         if late_graph:
             assert rs[1].get("graphed"), rs[1].get("graph_error")
         outs.append(torch.cat([p.detach().reshape(-1) for p in net.parameters()]))
         steps = {int(st["step"]) for st in rs[1]["opt"].state.values()}
         assert steps == {12}   # 3 updates x 4 minibatches, none lost to the capture's warm-up
-    assert torch.allclose(outs[0], outs[1], atol=1e-5, rtol=1e-4)
+    if fused:
+        d = (outs[0] - outs[1]).abs()
+        assert float(d.mean()) < 2e-5 and float(d.max()) < 2 * CFG["lr"]
+    else:
+        assert torch.allclose(outs[0], outs[1], atol=1e-5, rtol=1e-4)
+
+
+def test_fused_update_helpers_match_torch():
+    """brl_mb_gather, brl_relu_bwd_colsum (+ brl_bias_finalize) and brl_adam_clip against their torch counterparts."""
+    import ctypes as C
+    from brl_amd import _capi
+    L, dev = _capi.lib(), torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(1)
+    # ReLU backward + bias gradient, ragged sizes
+    for rows, cols in ((1024, 1024), (300, 39), (64, 100)):
+        dh = torch.randn(rows, cols, device=dev, generator=g)
+        h = torch.randn(rows, cols, device=dev, generator=g)
+        want_dz = dh * (h > 0)
+        db = torch.empty(cols, device=dev)
+        scratch = torch.empty(((rows + 63) // 64) * cols, device=dev)
+        got = dh.clone()
+        _capi.check(L.brl_relu_bwd_colsum(0, got.data_ptr(), h.data_ptr(), rows, cols, cols, db.data_ptr(), scratch.data_ptr(), s))
+        assert torch.equal(got, want_dz) and torch.allclose(db, want_dz.sum(0), atol=1e-3, rtol=1e-5)
+        got2 = dh.clone()
+        _capi.check(L.brl_relu_bwd_colsum(0, got2.data_ptr(), None, rows, cols, cols, db.data_ptr(), scratch.data_ptr(), s))
+        assert torch.equal(got2, dh) and torch.allclose(db, dh.sum(0), atol=1e-3, rtol=1e-5)
+    # clip + Adam, three steps, against torch.optim.Adam + clip_grad_norm_
+    n = 4096 + 8
+    p0 = torch.randn(n, device=dev, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, eps=1e-5)
+    p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    step, scratch, idx, norm = torch.zeros((), device=dev), torch.empty(1024, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), torch.empty(1, device=dev)
+    for it in range(3):
+        grad = torch.randn(n, device=dev, generator=g) * (0.001 if it == 1 else 1.0)   # one step below the clip threshold
+        ref.grad = grad.clone()
+        want_norm = torch.nn.utils.clip_grad_norm_([ref], 0.5)
+        opt.step()
+        _capi.check(L.brl_adam_clip(0, p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, step.data_ptr(), 1e-3, 0.9,
+                                    0.999, 1e-5, 0.5, scratch.data_ptr(), idx.data_ptr(), norm.data_ptr(), s))
+        assert torch.allclose(norm[0], want_norm, rtol=1e-5)
+        assert torch.allclose(p, ref.detach(), atol=2e-6), float((p - ref.detach()).abs().max())
+    assert int(idx.item()) == 3 and float(step.item()) == 3.0
+    # minibatch gather
+    from tests.test_update_cpu import fake_batch
+    tb, adv, tgt = fake_batch(4, 64, seed=5)
+    flat = type(tb)(*[x.reshape((256,) + x.shape[2:]).cuda() for x in tb])
+    adv, tgt = adv.reshape(-1).cuda(), tgt.reshape(-1).cuda()
+    perm = torch.randperm(256, device=dev, generator=g)
+    tp = _capi.TransitionPtrs()
+    for name in _capi.TransitionPtrs._names:
+        t = getattr(flat, name)
+        setattr(tp, name, (t.view(torch.uint8) if t.dtype == torch.bool else t).data_ptr())
+    B = 64
+    x0, mask, act = torch.empty(B, 480, device=dev), torch.empty(B, 38, dtype=torch.uint8, device=dev), torch.empty(B, dtype=torch.int32, device=dev)
+    ov, olp, ga, tg = (torch.empty(B, device=dev) for _ in range(4))
+    mbi = torch.full((1,), 2, dtype=torch.int32, device=dev)
+    _capi.check(L.brl_mb_gather(0, C.byref(tp), adv.data_ptr(), tgt.data_ptr(), perm.data_ptr(), mbi.data_ptr(), B, x0.data_ptr(),
+                                mask.data_ptr(), act.data_ptr(), ov.data_ptr(), olp.data_ptr(), ga.data_ptr(), tg.data_ptr(), s))
+    rows = perm[2 * B:3 * B]
+    assert torch.equal(x0, flat.obs[rows].float()) and torch.equal(mask.bool(), flat.legal_action_mask[rows])
+    assert torch.equal(act, flat.action[rows]) and torch.equal(ov, flat.value[rows]) and torch.equal(olp, flat.log_prob[rows])
+    assert torch.equal(ga, adv[rows]) and torch.equal(tg, tgt[rows])
 
 
 def test_longest_auction_319_calls(env, oracle, dds):
