@@ -93,14 +93,15 @@ __global__ __launch_bounds__(256) void k_bias_finalize(BiasSegs S) {
 // torch.optim.Adam does (bias corrections 1 - beta^t, denominator sqrt(v) / sqrt(bc2) + eps).
 constexpr int ADAM_BLOCKS = 1024, ADAM_THREADS = 256;  // n is a multiple of 4 (the caller pads its flat buffers)
 
-__global__ __launch_bounds__(ADAM_THREADS) void k_adam_norm(const float *g, int64_t n, float *partials, float *step) {
+__global__ __launch_bounds__(ADAM_THREADS) void k_adam_norm(const float *g, int64_t n, float gscale, float *partials, float *step) {
   __shared__ float red[ADAM_THREADS / 64];
   const int64_t n4 = n >> 2;
   const int64_t chunk = (n4 + ADAM_BLOCKS - 1) / ADAM_BLOCKS;
   const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n4) ? lo + chunk : n4;
   float s = 0.0f;
   for (int64_t i = lo + threadIdx.x; i < hi; i += ADAM_THREADS) {
-    const float4 x = reinterpret_cast<const float4 *>(g)[i];
+    float4 x = reinterpret_cast<const float4 *>(g)[i];
+    x.x *= gscale; x.y *= gscale; x.z *= gscale; x.w *= gscale;  // (the all-reduced SUM of the ranks' gradients -> their mean)
     s += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
   }
   s = wave_sum_f(s);
@@ -114,8 +115,8 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_norm(const float *g, int6
 
 __global__ __launch_bounds__(ADAM_THREADS) void k_adam_apply(float *p, const float *g, float *m, float *v, int64_t n,
                                                              const float *partials, const float *step, float lr, float b1,
-                                                             float b2, float eps, float max_norm, int32_t *mb_index,
-                                                             float *norm_out) {
+                                                             float b2, float eps, float max_norm, float gscale,
+                                                             int32_t *mb_index, float *norm_out) {
   __shared__ float red[ADAM_THREADS / 64];
   __shared__ float s_scale;
   {
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_apply(float *p, const flo
     }
     __syncthreads();
   }
-  const float scale = s_scale;
+  const float scale = s_scale * gscale;
   const float t = *step;
   const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
   const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);

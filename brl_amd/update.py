@@ -245,9 +245,12 @@ class FusedMinibatch:
                 and not config.get("reward_scaling", False)
                 and next(params.parameters()).is_cuda and next(params.parameters()).dtype == torch.float32)
 
-    def __init__(self, config, params, opt, mbs: int, device):
+    def __init__(self, config, params, opt, mbs: int, device, world: int = 1):
         from . import _capi
         self.cfg, self.params, self.opt, self.mbs, self.dev = config, params, opt, int(mbs), device
+        # world > 1: TWO graphs (forward + backward | clip + Adam) around the eager all-reduce of the flat gradient —
+        # RCCL over xGMI on MI355X: one 14.7 MB collective per minibatch (ppo.py's pmean)
+        self.world = int(world)
         f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)  # noqa: E731
         body = list(params.body)
         # flat layout: (W, b) of every hidden layer, then actor.weight | critic.weight (one [39,1024] matrix), then
@@ -322,24 +325,32 @@ class FusedMinibatch:
         self.max_norm = float(config["max_grad_norm"]) if config.get("global_gradient_clipping", True) else 0.0
         # warm-up and capture run real steps on the dummy batch: put parameters, moments and counters back afterwards
         saved = [t.clone() for t in (self.P, self.M, self.V, self.step, self.mb_index)]
-        self.graph = None
+        self.graph = self.graph_opt = None
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side), torch.no_grad():
                 for _ in range(3):
-                    self._step()
+                    self._fwd_bwd()
+                    self._opt()
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph), torch.no_grad():
-                self._step()
+                self._fwd_bwd()
+                if self.world == 1:
+                    self._opt()
+            if self.world > 1:
+                graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_opt), torch.no_grad():
+                    self._opt()
+                self.graph_opt = graph_opt
             self.graph = graph
         finally:
             with torch.no_grad():
                 for t, q in zip((self.P, self.M, self.V, self.step, self.mb_index), saved):
                     t.copy_(q)
 
-    def _step(self):
+    def _fwd_bwd(self):
         L, chk, B = self.lib, self.capi.check, self.mbs
         s = torch.cuda.current_stream().cuda_stream
         di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
@@ -379,9 +390,14 @@ class FusedMinibatch:
                 dh = torch.mm(dh, self.W[l])
         chk(L.brl_bias_finalize(di, self._nseg, self._seg_scratch, self._seg_cols, self._seg_db, B, s))
         cur.wait_stream(self.side)  # the statistics read mb_index, which the Adam launch advances
-        chk(L.brl_adam_clip(di, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), self.n,
-                            self.step.data_ptr(), self.lr, float(self.b1), float(self.b2), self.eps, self.max_norm,
-                            self.scratch.data_ptr(), self.mb_index.data_ptr(), self.norm.data_ptr(), s))
+
+    def _opt(self):
+        s = torch.cuda.current_stream().cuda_stream
+        di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        self.capi.check(self.lib.brl_adam_clip(di, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
+                                               self.n, self.step.data_ptr(), self.lr, float(self.b1), float(self.b2), self.eps,
+                                               self.max_norm, 1.0 / self.world, self.scratch.data_ptr(),
+                                               self.mb_index.data_ptr(), self.norm.data_ptr(), s))
 
     # ---- one update_step call -----------------------------------------------------------------------------------
     def begin_update(self, flat: Transition, adv_f, tgt_f, perms):
@@ -416,6 +432,9 @@ class FusedMinibatch:
                                                self.mask.data_ptr(), self.action.data_ptr(), self.old_v.data_ptr(),
                                                self.old_lp.data_ptr(), self.adv.data_ptr(), self.tgt.data_ptr(), s))
         self.graph.replay()
+        if self.world > 1:
+            dist.all_reduce(self.G, op=dist.ReduceOp.SUM)   # brl_adam_clip divides by world (grad_scale)
+            self.graph_opt.replay()
 
     def end_update(self):
         with torch.no_grad():  # every parameter's step counter (torch keeps one per parameter)
@@ -448,13 +467,15 @@ def make_update_step(config, actor_forward_pass, optimizer=None):
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         graphed = None
         fused = None
-        if config.get("graph_update", True) and adv_f.is_cuda and not multi and sched is None:
+        want_fused = adv_f.is_cuda and FusedMinibatch.supports(config, params)
+        if config.get("graph_update", True) and adv_f.is_cuda and sched is None and (want_fused or not multi):
             graphed = opt_state.get("graphed")
-            want_fused = FusedMinibatch.supports(config, params)
-            if graphed is None or graphed.params is not params or graphed.mbs != mbs or isinstance(graphed, FusedMinibatch) != want_fused:
+            world = dist.get_world_size() if multi else 1
+            if graphed is None or graphed.params is not params or graphed.mbs != mbs or isinstance(graphed, FusedMinibatch) != want_fused \
+                    or getattr(graphed, "world", 1) != world:
                 try:
-                    graphed = (FusedMinibatch if want_fused else GraphedMinibatch)(config, *( (params, opt) if want_fused
-                               else (actor_forward_pass, params, opt)), mbs, adv_f.device)
+                    graphed = FusedMinibatch(config, params, opt, mbs, adv_f.device, world) if want_fused \
+                        else GraphedMinibatch(config, actor_forward_pass, params, opt, mbs, adv_f.device)
                 except Exception as e:  # capture is an optimisation, never a requirement
                     graphed = False
                     opt_state["graph_error"] = repr(e)

@@ -291,12 +291,14 @@ int brl_ppo_stats_at(int device, const float *partials, int64_t batch, const flo
                      float *out_rows, const int32_t *row_index, void *stream);
 
 /* optax.chain(clip_by_global_norm(max_norm), adam(lr, eps)) (ppo.py:195-211) on flat fp32 buffers of n elements, two
- * launches (n a multiple of 4: pad the buffers with zeros): *step (device float) += 1; g scaled by
- * min(1, max_norm / (|g| + 1e-6)) (max_norm <= 0: no clipping); m, v, p updated with torch.optim.Adam's arithmetic.
+ * launches (n a multiple of 4: pad the buffers with zeros): *step (device float) += 1; the gradient is grad_scale * g
+ * (1 / world_size after a SUM all-reduce: the ranks' mean, ppo.py's pmean; 1 otherwise), scaled by
+ * min(1, max_norm / (|gradient| + 1e-6)) (max_norm <= 0: no clipping); m, v, p updated with torch.optim.Adam's arithmetic.
  * scratch: float [1024].  mb_index (may be NULL): advanced by one.
  * norm_out (may be NULL): |g| before clipping. */
 int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr, float beta1,
-                  float beta2, float eps, float max_norm, float *scratch, int32_t *mb_index, float *norm_out, void *stream);
+                  float beta2, float eps, float max_norm, float grad_scale, float *scratch, int32_t *mb_index, float *norm_out,
+                  void *stream);
 
 #ifdef __cplusplus
 }

@@ -1059,6 +1059,49 @@ def test_graphed_update_built_after_eager_steps_keeps_adam_state(fused):
         assert torch.allclose(outs[0], outs[1], atol=1e-5, rtol=1e-4)
 
 
+def _fused_rank(rank, world, port, out_dir):
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from brl_amd.models import make_forward_pass
+    from brl_amd.update import FusedMinibatch, make_update_step
+    from tests.test_update_cpu import CFG, fake_batch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU of the box
+    fp = make_forward_pass("relu", "DeepMind")
+    net = fp.init(11, device="cuda")
+    tb, adv, tgt = fake_batch(4, 256, seed=3)                       # the SAME shard on both ranks: mean gradient == own gradient
+    tb = type(tb)(*[x.cuda() for x in tb])
+    cfg = dict(CFG, minibatch_size=256, update_epochs=1)
+    rs, (total, _) = make_update_step(cfg, fp)((net, None, None, None, 0, 5), tb, adv.cuda(), tgt.cuda())
+    assert isinstance(rs[1].get("graphed"), FusedMinibatch) and rs[1]["graphed"].world == world, rs[1].get("graph_error")
+    torch.save((torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu(), total.cpu()),
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fused_update_with_gradient_allreduce_two_ranks(tmp_path):
+    """FusedMinibatch under a process group (forward+backward graph | all-reduce | clip+Adam graph with grad_scale
+    1/world): two ranks on the same shard end with the parameters of the single-process step (gloo here; RCCL on a node)."""
+    import socket
+    import torch.multiprocessing as mp
+    from brl_amd.models import make_forward_pass
+    from brl_amd.update import make_update_step
+    from tests.test_update_cpu import CFG, fake_batch
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mp.start_processes(_fused_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(r0[0], r1[0])
+    fp = make_forward_pass("relu", "DeepMind")
+    net = fp.init(11, device="cuda")
+    tb, adv, tgt = fake_batch(4, 256, seed=3)
+    tb = type(tb)(*[x.cuda() for x in tb])
+    _, (total, _) = make_update_step(dict(CFG, minibatch_size=256, update_epochs=1), fp)((net, None, None, None, 0, 5), tb, adv.cuda(), tgt.cuda())
+    single = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()
+    assert torch.allclose(total.cpu(), r0[1], atol=1e-6) and torch.allclose(single, r0[0], atol=1e-6, rtol=1e-5)
+
+
 def test_fused_update_helpers_match_torch():
     """brl_mb_gather, brl_relu_bwd_colsum (+ brl_bias_finalize) and brl_adam_clip against their torch counterparts."""
     import ctypes as C
@@ -1092,7 +1135,7 @@ def test_fused_update_helpers_match_torch():
         want_norm = torch.nn.utils.clip_grad_norm_([ref], 0.5)
         opt.step()
         _capi.check(L.brl_adam_clip(0, p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, step.data_ptr(), 1e-3, 0.9,
-                                    0.999, 1e-5, 0.5, scratch.data_ptr(), idx.data_ptr(), norm.data_ptr(), s))
+                                    0.999, 1e-5, 0.5, 1.0, scratch.data_ptr(), idx.data_ptr(), norm.data_ptr(), s))
         assert torch.allclose(norm[0], want_norm, rtol=1e-5)
         assert torch.allclose(p, ref.detach(), atol=2e-6), float((p - ref.detach()).abs().max())
     assert int(idx.item()) == 3 and float(step.item()) == 3.0
