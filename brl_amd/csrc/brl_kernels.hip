@@ -2114,12 +2114,16 @@ extern "C" int brl_relu_bwd_colsum(int device, float *dh, const float *h, int64_
                                    float *scratch, void *stream) {
   NEED(dh && scratch && rows > 0 && cols > 0 && ld >= cols, "dh / scratch / rows / cols / ld");
   HIP_TRY(hipSetDevice(device));
-  const int64_t tiles = (rows + 63) / 64;
-  hipLaunchKernelGGL(k_relu_bwd_tiles, dim3((unsigned)((cols + 63) / 64), (unsigned)tiles), dim3(256), 0, (hipStream_t)stream, dh,
-                     h, rows, cols, ld, scratch);
+  const int64_t tr = relu_tile_rows(cols, ld), tiles = (rows + tr - 1) / tr;
+  if (tr == 16)
+    hipLaunchKernelGGL(k_relu_bwd_tiles4, dim3((unsigned)((cols + 255) / 256), (unsigned)tiles), dim3(256), 0, (hipStream_t)stream,
+                       dh, h, rows, cols, ld, scratch);
+  else
+    hipLaunchKernelGGL(k_relu_bwd_tiles, dim3((unsigned)((cols + 63) / 64), (unsigned)tiles), dim3(256), 0, (hipStream_t)stream, dh,
+                       h, rows, cols, ld, scratch);
   if (db != nullptr) {
     BiasSegs S{};
-    S.n = 1; S.tiles = tiles; S.partials[0] = scratch; S.cols[0] = cols; S.db[0] = db;
+    S.n = 1; S.tiles[0] = tiles; S.partials[0] = scratch; S.cols[0] = cols; S.db[0] = db;
     hipLaunchKernelGGL(k_bias_finalize, dim3((unsigned)((cols + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream, S);
   }
   HIP_TRY(hipGetLastError());
@@ -2131,10 +2135,12 @@ extern "C" int brl_bias_finalize(int device, int nseg, const float *const *scrat
   NEED(nseg >= 1 && nseg <= BIAS_MAX_SEGS && scratch && cols && db && rows > 0, "nseg / scratch / cols / db / rows");
   HIP_TRY(hipSetDevice(device));
   BiasSegs S{};
-  S.n = nseg; S.tiles = (rows + 63) / 64;
+  S.n = nseg;
   int64_t maxc = 0;
   for (int i = 0; i < nseg; i++) {
     NEED(scratch[i] && db[i] && cols[i] > 0, "segment");
+    const int64_t tr = relu_tile_rows(cols[i], cols[i]);  // (dense rows: ld == cols, as brl_relu_bwd_colsum was called)
+    S.tiles[i] = (rows + tr - 1) / tr;
     S.partials[i] = scratch[i]; S.cols[i] = cols[i]; S.db[i] = db[i];
     maxc = cols[i] > maxc ? cols[i] : maxc;
   }

@@ -305,7 +305,7 @@ class FusedMinibatch:
         self.illp = f(B, 38)
         self.out = f(8)
         self.scratch = f(1024)
-        tiles = (B + 63) // 64
+        tiles = (B + 15) // 16
         self.tile_sums = [f(tiles * H) for _ in body] + [f(tiles * K)]   # per-layer partial column sums (bias gradients)
         import ctypes as C
         nseg = len(body) + 1
@@ -413,6 +413,7 @@ class FusedMinibatch:
         self._tp = tp
         steps = sum(p.numel() for p in perms) // self.mbs
         with torch.no_grad():
+            self._readopt()
             if steps > self._log_cap:
                 raise RuntimeError("FusedMinibatch: more minibatch steps per update than config['update_log_capacity']")
             allp = torch.cat(perms)
@@ -422,6 +423,27 @@ class FusedMinibatch:
             self.mb_index.zero_()
             self.step.copy_(self.opt.state[self.plist[0]]["step"])  # the optimizer may have been stepped eagerly / loaded
         return self.log[:steps]
+
+    def _readopt(self):
+        """`opt.load_state_dict` (resume) or a foreign `p.data = ...` replaces tensors that were views of the flat buffers:
+        copy their contents in and point them back at the buffers (addresses are baked into the graph)."""
+        for q in self.plist:
+            sl = self.views[q]
+            if q.data.data_ptr() != self.P[sl].data_ptr():
+                self.P[sl].copy_(q.data.reshape(-1))
+                q.data = self.P[sl].view(q.shape)
+            st = self.opt.state.get(q)
+            if st is None or "exp_avg" not in st:
+                self.M[sl].zero_(); self.V[sl].zero_()
+                self.opt.state[q] = {"step": torch.zeros((), dtype=torch.float32, device=self.dev),
+                                     "exp_avg": self.M[sl].view(q.shape), "exp_avg_sq": self.V[sl].view(q.shape)}
+                continue
+            if st["exp_avg"].data_ptr() != self.M[sl].data_ptr():
+                self.M[sl].copy_(st["exp_avg"].reshape(-1))
+                self.V[sl].copy_(st["exp_avg_sq"].reshape(-1))
+                st["exp_avg"], st["exp_avg_sq"] = self.M[sl].view(q.shape), self.V[sl].view(q.shape)
+            if not torch.is_tensor(st["step"]) or st["step"].device != self.P.device:
+                st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=self.dev).reshape(())
 
     def run_mb(self):
         import ctypes as C

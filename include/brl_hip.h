@@ -276,13 +276,15 @@ int brl_mb_gather(int device, const brl_transition *flat, const float *adv, cons
                   float *old_log_prob, float *gae_out, float *targets_out, void *stream);
 
 /* Backward of `h = relu(z)` plus the bias gradient of that layer: dh [rows,ld] *= (h > 0) in place and the column sums
- * of every 64-row tile into scratch (float [ceil(rows / 64) * cols]); db != NULL: a second launch adds the tiles in index
+ * of every row tile (16 rows when cols and ld are multiples of 4, else 64) into scratch (float [ceil(rows / 16) * cols]
+ * is always enough); db != NULL: a second launch adds the tiles in index
  * order, db[c] = sum_r dh[r,c] (deterministic).  h == NULL: column sums only (the head's bias gradient).
  * db == NULL: tiles only — brl_bias_finalize then finishes several layers with one launch. */
 int brl_relu_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, float *db,
                         float *scratch, void *stream);
 
-/* db[i][c] = sum over the tiles of scratch[i] (as written by brl_relu_bwd_colsum for `rows` rows) for nseg <= 8 layers. */
+/* db[i][c] = sum over the tiles of scratch[i] (as written by brl_relu_bwd_colsum for `rows` dense rows, ld == cols[i])
+ * for nseg <= 8 layers. */
 int brl_bias_finalize(int device, int nseg, const float *const *scratch, const int64_t *cols, float *const *db, int64_t rows,
                       void *stream);
 

@@ -1102,6 +1102,36 @@ def test_fused_update_with_gradient_allreduce_two_ranks(tmp_path):
     assert torch.allclose(total.cpu(), r0[1], atol=1e-6) and torch.allclose(single, r0[0], atol=1e-6, rtol=1e-5)
 
 
+def test_fused_update_follows_a_reloaded_optimizer_state():
+    """opt.load_state_dict between two updates replaces the moment tensors FusedMinibatch had made views of its flat
+    buffers: the next update must continue from the LOADED state (a resumed run), not from stale moments."""
+    import copy
+    from brl_amd.models import make_forward_pass
+    from brl_amd.update import make_update_step
+    from tests.test_update_cpu import CFG, fake_batch
+    fp = make_forward_pass("relu", "DeepMind")
+    cfg = dict(CFG, minibatch_size=256, update_epochs=1)
+    upd = make_update_step(cfg, fp)
+    data = []
+    for seed in (31, 32):
+        tb, adv, tgt = fake_batch(4, 256, seed=seed)
+        data.append((type(tb)(*[x.cuda() for x in tb]), adv.cuda(), tgt.cuda()))
+    net = fp.init(3, device="cuda")
+    rs, _ = upd((net, None, None, None, 0, 5), *data[0])
+    snap_w = copy.deepcopy(net.state_dict())
+    snap_o = copy.deepcopy(rs[1]["opt"].state_dict())
+    rs, _ = upd(rs, *data[1])
+    want = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+    rs, _ = upd(rs, *data[0])                       # move on, then rewind weights AND optimizer and redo the second update
+    net.load_state_dict(snap_w)
+    rs[1]["opt"].load_state_dict(snap_o)
+    rs = (net, rs[1], None, None, 0, 6)
+    rs, _ = upd(rs, *data[1])
+    got = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    assert torch.allclose(got, want, atol=1e-7, rtol=1e-6), float((got - want).abs().max())
+    assert {int(st["step"]) for st in rs[1]["opt"].state.values()} == {8}
+
+
 def test_fused_update_helpers_match_torch():
     """brl_mb_gather, brl_relu_bwd_colsum (+ brl_bias_finalize) and brl_adam_clip against their torch counterparts."""
     import ctypes as C
@@ -1110,12 +1140,12 @@ def test_fused_update_helpers_match_torch():
     s = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device="cuda").manual_seed(1)
     # ReLU backward + bias gradient, ragged sizes
-    for rows, cols in ((1024, 1024), (300, 39), (64, 100)):
+    for rows, cols in ((1024, 1024), (300, 39), (64, 100), (250, 1024), (7, 8)):
         dh = torch.randn(rows, cols, device=dev, generator=g)
         h = torch.randn(rows, cols, device=dev, generator=g)
         want_dz = dh * (h > 0)
         db = torch.empty(cols, device=dev)
-        scratch = torch.empty(((rows + 63) // 64) * cols, device=dev)
+        scratch = torch.empty(((rows + 15) // 16) * cols, device=dev)
         got = dh.clone()
         _capi.check(L.brl_relu_bwd_colsum(0, got.data_ptr(), h.data_ptr(), rows, cols, cols, db.data_ptr(), scratch.data_ptr(), s))
         assert torch.equal(got, want_dz) and torch.allclose(db, want_dz.sum(0), atol=1e-3, rtol=1e-5)
