@@ -32,6 +32,12 @@ class TableInfoPtrs(C.Structure):
     _fields_ = [(n, _vp) for n in _names]
 
 
+class MacroExt(C.Structure):
+    _fields_ = [("first", C.c_int32), ("last", C.c_int32), ("value_in", _vp), ("value_stride", C.c_int64), ("value_out", _vp),
+                ("done_out", _vp), ("reward_out", _vp), ("actor", _vp), ("reward_scale", C.c_float), ("obs_fmt", C.c_int32),
+                ("terminated_count", _vp), ("obs_cast", _vp)]
+
+
 class EvalStatsPtrs(C.Structure):
     _names = ["illegal_prob_sum", "step_count", "pass_count", "bid_count"]
     _fields_ = [(n, _vp) for n in _names]
@@ -74,6 +80,8 @@ def lib() -> C.CDLL:
         "brl_rollout_random": [_vp, _vp, i64, i32, i32, u32, f32, C.POINTER(TransitionPtrs), _vp, _vp, _vp, _vp],
         "brl_policy_step": [_vp, _vp, _vp, i64, _vp, i32, u32, i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
         "brl_policy_step_at": [_vp, _vp, _vp, i64, _vp, i64, i32, _vp, u32, i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+        "brl_policy_step_ex": [_vp, _vp, _vp, i64, _vp, i64, i32, _vp, u32, i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               C.POINTER(MacroExt), _vp],
         "brl_obs_cast": [_vp, _vp, i64, _vp, i32, _vp],
         "brl_gae": [_vp, _vp, _vp, _vp, _vp, f32, f32, i32, i64, _vp, _vp, _vp],
         "brl_imp_reward": [_vp, _vp, _vp, _vp, i64, _vp],
@@ -103,7 +111,7 @@ EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_de
            "brl_init_random", "brl_init_from_deals", "brl_step", "brl_observe", "brl_get_fields",
            "brl_rollout_random", "brl_policy_step", "brl_policy_step_at", "brl_obs_cast", "brl_gae", "brl_imp_reward", "brl_duplicate_step",
            "brl_eval_step", "brl_eval_reduce", "brl_ppo_loss", "brl_ppo_stats", "brl_ppo_loss_heads", "brl_mb_gather",
-           "brl_relu_bwd_colsum", "brl_adam_clip", "brl_bias_finalize", "brl_ppo_stats_at"]
+           "brl_relu_bwd_colsum", "brl_adam_clip", "brl_bias_finalize", "brl_ppo_stats_at", "brl_policy_step_ex"]
 
 
 def check(rc: int) -> None:

@@ -343,6 +343,34 @@ __device__ __forceinline__ void emit_obs_row(const uint8_t *img, int seat, uint3
   if (c.lane < 60) *reinterpret_cast<uint2 *>(dst_row + c.lane * 8) = make_uint2(lo, hi);
 }
 
+// The same row as the network's input: 480 values 0.0 / 1.0 in float (fmt 0), bf16 (1) or fp16 (2) — what
+// `obs.astype(float32)` (src/roll_out.py:75) or a low-precision cast would produce from the bytes, written by the launch that
+// produces the observation (no separate cast launch per forward).  Lane l: values [8l, 8l+8).
+__device__ __forceinline__ void emit_obs_row_cast(const uint8_t *img, int seat, uint32_t vulnib, void *dst_row, int fmt,
+                                                  const LaneConst &c) {
+  uint32_t a = img[c.hist_idx];
+  uint32_t h = img[W_HAND * 8 + seat * 8 + c.hand_off];
+  uint32_t m1 = (0xFu >> seat) * 0x11u;
+  uint32_t rot = ((a >> seat) & m1) | ((a << (4 - seat)) & (m1 ^ 0xFFu));
+  uint32_t byte = (rot & c.hist_keep) | (h & c.hand_keep);
+  byte |= (c.lane == 0) ? vulnib : 0u;
+  if (c.lane >= 60) return;
+  if (fmt == 0) {
+    uint32_t d[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = ((byte >> i) & 1u) ? 0x3F800000u : 0u;
+    uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<float *>(dst_row) + c.lane * 8);
+    dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
+    dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
+  } else {
+    const uint32_t one = (fmt == 1) ? 0x3F80u : 0x3C00u;
+    uint32_t d[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) d[i] = (((byte >> (2 * i)) & 1u) ? one : 0u) | (((byte >> (2 * i + 1)) & 1u) ? (one << 16) : 0u);
+    *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(dst_row) + c.lane * 8) = make_uint4(d[0], d[1], d[2], d[3]);
+  }
+}
+
 // ---- 4 rows per wave-instruction ------------------------------------------------------------
 // 15 lanes per row, each lane turns ONE dword of the packed image (8 nibbles = 32 observation
 // bits) into 32 output bytes (2 x 16-B stores): a wave writes the 4 x 480-B rows of 4 consecutive

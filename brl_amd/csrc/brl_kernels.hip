@@ -1063,6 +1063,7 @@ struct PolicyArgs {
   int32_t *action;
   float *log_prob;
   StepOut o;  // o.rewards / o.terminated are ACCUMULATED
+  brl_macro_ext x;  // optional per-macro-step bookkeeping (brl_policy_step_ex); all-zero otherwise
 };
 
 // Masked categorical of one table on the 64 / K lanes that share it (lane l: table l % K, slot l / K): slot s holds the
@@ -1175,16 +1176,50 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
   if (A.autoreset) wave_reset<K>(w, t, w.valid && term, cx.g, cx.env_offset, cx.lut, t.bctr + 1u);
   int oseat = cur_seat(t);
   wave_emit<K>(w, A.n, oseat, vul_nibble(t, oseat), legal_mask(t), A.o.obs, A.o.mask, w.table0);
+  if (A.x.obs_cast != nullptr) {  // the same observation as the next forward's input (float / bf16 / fp16)
+    const uint32_t pack = (uint32_t)oseat | (vul_nibble(t, oseat) << 2);
+    const int esz = (A.x.obs_fmt == 0) ? 4 : 2;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      if (w.table0 + j < A.n) {
+        const uint32_t p = __builtin_amdgcn_readlane(pack, j);
+        emit_obs_row_cast(w.wimg + j * TABLE_BYTES, (int)(p & 3u), p >> 2,
+                          reinterpret_cast<uint8_t *>(A.x.obs_cast) + (w.table0 + j) * BRL_OBS_SIZE * esz, A.x.obs_fmt, w.c);
+      }
+    }
+  }
+  uint32_t tacc = 0;
   if (w.c.lane < K && w.valid) {
     if (A.action) A.action[w.table] = act;
     if (A.log_prob) A.log_prob[w.table] = lp;
+    float4 tot = rw;
     if (A.o.rewards) {
       float4 *p = reinterpret_cast<float4 *>(A.o.rewards) + w.table;
-      float4 old = *p;
-      *p = make_float4(old.x + rw.x, old.y + rw.y, old.z + rw.z, old.w + rw.w);
+      if (!A.x.first) {
+        const float4 old = *p;
+        tot = make_float4(old.x + rw.x, old.y + rw.y, old.z + rw.z, old.w + rw.w);
+      }
+      *p = tot;
     }
-    if (A.o.terminated) A.o.terminated[w.table] |= (uint8_t)term;
+    tacc = term;
+    if (A.o.terminated) {
+      if (!A.x.first) tacc |= A.o.terminated[w.table];
+      A.o.terminated[w.table] = (uint8_t)tacc;
+    }
     if (A.o.current_player) A.o.current_player[w.table] = cur_player(t);
+    if (A.x.value_out) A.x.value_out[w.table] = A.x.value_in[w.table * A.x.value_stride];   // src/roll_out.py:76
+    if (A.x.last) {
+      if (A.x.done_out) A.x.done_out[w.table] = (uint8_t)tacc;                                // G2
+      if (A.x.reward_out) {                                                                  // G1, src/roll_out.py:90
+        const int a = A.x.actor[w.table] & 3;
+        const float r = (a == 0) ? tot.x : ((a == 1) ? tot.y : ((a == 2) ? tot.z : tot.w));
+        A.x.reward_out[w.table] = r / A.x.reward_scale;
+      }
+    }
+  }
+  if (A.x.last && A.x.terminated_count) {                                                    // src/roll_out.py:85
+    const uint64_t m = __ballot(tacc != 0u);
+    if (w.c.lane == 0 && m) atomicAdd(reinterpret_cast<unsigned long long *>(A.x.terminated_count), (unsigned long long)__popcll(m));
   }
   wave_end<K>(w, t, A.state_out, A.n);
 }
@@ -1912,7 +1947,7 @@ static int policy_step_impl(brl_handle *h, const uint64_t *state_in, uint64_t *s
                             const float *logits, int64_t logits_stride, int mode, const uint32_t *draw_dev, uint32_t draw,
                             int autoreset,
                             int32_t *action, float *log_prob, uint8_t *obs, uint8_t *mask, float *rewards_acc,
-                            uint8_t *terminated_acc, int32_t *current_player, void *stream) {
+                            uint8_t *terminated_acc, int32_t *current_player, void *stream, const brl_macro_ext *ext = nullptr) {
   COMMON(h, n);
   NEED(state_in && state_out && logits, "NULL state / logits");
   NEED(mode >= 0 && mode <= 3, "mode");
@@ -1925,6 +1960,14 @@ static int policy_step_impl(brl_handle *h, const uint64_t *state_in, uint64_t *s
   A.autoreset = autoreset; A.ctx = h->ctx_dev;
   A.action = action; A.log_prob = log_prob;
   A.o = StepOut{obs, mask, rewards_acc, terminated_acc, current_player};
+  memset(&A.x, 0, sizeof(A.x));
+  if (ext != nullptr) {
+    A.x = *ext;
+    NEED(!ext->value_out || (ext->value_in && ext->value_stride >= 1), "ext: value_in / value_stride");
+    NEED(!ext->last || !ext->reward_out || (ext->actor && rewards_acc && ext->reward_scale != 0.0f), "ext: reward_out needs actor, rewards_acc, reward_scale");
+    NEED(!ext->last || !(ext->done_out || ext->terminated_count) || terminated_acc, "ext: done_out / terminated_count need terminated_acc");
+    NEED(!ext->obs_cast || (ext->obs_fmt >= 0 && ext->obs_fmt <= 2), "ext: obs_fmt");
+  }
   LAUNCH_K(h, k_policy_step, n, stream, A);
   return BRL_OK;
 }
@@ -1944,6 +1987,15 @@ extern "C" int brl_policy_step_at(brl_handle *h, const uint64_t *state_in, uint6
                                   void *stream) {
   return policy_step_impl(h, state_in, state_out, n, logits, logits_stride, mode, draw_base, draw_offset, autoreset,
                           action, log_prob, obs, mask, rewards_acc, terminated_acc, current_player, stream);
+}
+
+extern "C" int brl_policy_step_ex(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                                  const float *logits, int64_t logits_stride, int mode, const uint32_t *draw_base,
+                                  uint32_t draw_offset, int autoreset, int32_t *action, float *log_prob, uint8_t *obs,
+                                  uint8_t *mask, float *rewards_acc, uint8_t *terminated_acc, int32_t *current_player,
+                                  const brl_macro_ext *ext, void *stream) {
+  return policy_step_impl(h, state_in, state_out, n, logits, logits_stride, mode, draw_base, draw_offset, autoreset,
+                          action, log_prob, obs, mask, rewards_acc, terminated_acc, current_player, stream, ext);
 }
 
 // observation bytes (0/1) -> the network's input dtype: 16 bytes in, 16 elements out per thread

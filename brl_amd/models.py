@@ -110,10 +110,12 @@ class InferenceSnapshot:
             return x
         return obs.to(self.dtype)
 
-    def heads(self, obs):
+    def heads(self, obs, x=None):
         """obs: [n, 480] bool / float -> f32 [n, 39]: the 38 logits and the value as ONE matrix (row stride 39; the
-        kernels take the logits as a strided slice of it)"""
-        x = self._input(obs)
+        kernels take the logits as a strided slice of it).  ``x``: the observation already in ``self.dtype`` (written
+        by the step kernel that produced it, brl_macro_ext.obs_cast) — then ``obs`` is not read."""
+        if x is None:
+            x = self._input(obs)
         fused = hasattr(torch, "_addmm_activation")
         for w, b in self.body:
             x = torch._addmm_activation(b, x, w, use_gelu=False) if fused else torch.addmm(b, x, w).relu_()

@@ -108,8 +108,10 @@ class _PolicyRollout:
         self.racc = e((n, 4), torch.float32)
         self.tacc = e(n, torch.bool)
         self.sub_actions = e((T, 3, n), torch.int32)
-        self.draw = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.draw = torch.zeros(1, dtype=torch.int32, device=dev)   # the rollout's first draw index (device: graph replays)
         self.tc = torch.zeros(1, dtype=torch.int64, device=dev)
+        # the step kernels also write each new observation in the networks' input dtype (brl_macro_ext.obs_cast)
+        self.xin = e((n, OBS_SIZE), self.infer_dtype or torch.float32)
         # a TENSOR divisor: torch turns `x / python_float` into x * (1 / float) on the GPU, which is not the correctly
         # rounded quotient `rewards / config["reward_scale"]` (src/roll_out.py:90) that the fused kernel and the oracle compute
         self.scale = torch.tensor(self.reward_scale, dtype=torch.float32, device=dev)
@@ -129,31 +131,41 @@ class _PolicyRollout:
             self.snap_opp = self.snap_actor if opp_params is params else InferenceSnapshot.make(opp_params, self.infer_dtype)
         self.params, self.opp_params = params, opp_params
 
-    def _forward(self, is_opp, obs_bool):
+    _FMT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+    def _forward(self, is_opp, obs_bool, x=None):
+        """-> f32 [n, 39] heads (38 logits + value; DeepMind ReLU nets: fused epilogues, merged heads) or, for the other
+        architectures, (logits, value).  ``x``: obs_bool already cast by the step kernel."""
         snap = self.snap_opp if is_opp else self.snap_actor
-        if snap is not None:  # "DeepMind" ReLU MLP: fused epilogues, merged heads (fp32 by default)
-            return snap(obs_bool)
+        if snap is not None:
+            out = snap.heads(obs_bool, x)
+            return out[:, :snap.n_actions], out[:, snap.n_actions]
         fp, pr = (self.opp_fp, self.opp_params) if is_opp else (self.actor_fp, self.params)
         if self.infer_dtype is None:
-            return fp.apply(pr, obs_bool.to(torch.float32))
+            return fp.apply(pr, obs_bool.to(torch.float32) if x is None else x)
         with torch.autocast("cuda", dtype=self.infer_dtype):
-            lg, v = fp.apply(pr, obs_bool.to(self.infer_dtype))
+            lg, v = fp.apply(pr, obs_bool.to(self.infer_dtype) if x is None else x)
         return lg.float(), v.float()
 
     # ---- one scan step ------------------------------------------------------------------------------------------
     def _macro_step(self, t):
+        """Per macro-step: 4 forwards + 4 ``brl_policy_step_ex`` launches and nothing else — value copy, accumulator reset,
+        done / reward / terminated_count and the cast of every new observation ride on the sub-step launches."""
         env, traj, packed, cur = self.env, self.traj, self.packed, self.cur
         racc, tacc, T = self.racc, self.tacc, self.T
         competitive = self.game_mode == "competitive"
+        MX = _capi.MacroExt
+        fmt = self._FMT[self.xin.dtype]
         actor = cur[t & 1]                                              # src/roll_out.py:72
-        logits, value = self._forward(False, traj.obs[t])               # :73-76
-        traj.value[t].copy_(value)
-        racc.zero_()
-        tacc.zero_()
+        # the first forward of a rollout reads the loaded observation; later ones the cast written by the previous launch
+        logits, value = self._forward(False, traj.obs[t], None if t == 0 else self.xin)   # :73-76
+        value = value.to(torch.float32)
         # sub-step 1: the actor samples from the (un)masked Categorical (src/roll_out.py:27-39,79-84)
-        policy_step(env, packed, packed, logits, SAMPLE if self.masked else SAMPLE | UNMASKED, 0, True,
+        policy_step(env, packed, packed, logits, SAMPLE if self.masked else SAMPLE | UNMASKED, 4 * t, True,
                     action=traj.action[t], log_prob=traj.log_prob[t], obs=self.scratch_obs, rewards_acc=racc,
-                    terminated_acc=tacc, draw_base=self.draw)
+                    terminated_acc=tacc, draw_base=self.draw,
+                    ext=MX(first=1, value_in=value.data_ptr(), value_stride=value.stride(0), value_out=traj.value[t].data_ptr(),
+                           obs_cast=self.xin.data_ptr(), obs_fmt=fmt))
         last = t + 1 == T
         obs_out = self.final_obs if last else traj.obs[t + 1]
         mask_out = self.final_mask if last else traj.legal_action_mask[t + 1]
@@ -162,16 +174,16 @@ class _PolicyRollout:
             if not competitive and is_opp:                              # free-run: opponents pass (src/utils.py:205-246)
                 lg, m = _pass_logits(env, self.n), MODE
             else:
-                lg, _ = self._forward(is_opp, self.scratch_obs)
+                lg, _ = self._forward(is_opp, self.scratch_obs, self.xin)
                 m = SAMPLE if competitive else MODE
             fin = k == 3
-            policy_step(env, packed, packed, lg, m, k, True, action=self.sub_actions[t, k - 1],
+            ext = MX(obs_cast=self.xin.data_ptr(), obs_fmt=fmt)
+            if fin:                                                     # G2 / G1 / :85 by the same launch
+                ext.last, ext.done_out, ext.reward_out = 1, traj.done[t].data_ptr(), traj.reward[t].data_ptr()
+                ext.actor, ext.reward_scale, ext.terminated_count = actor.data_ptr(), self.reward_scale, self.tc.data_ptr()
+            policy_step(env, packed, packed, lg, m, 4 * t + k, True, action=self.sub_actions[t, k - 1],
                         obs=obs_out if fin else self.scratch_obs, mask=mask_out if fin else None, rewards_acc=racc,
-                        terminated_acc=tacc, current_player=cur[(t + 1) & 1] if fin else None, draw_base=self.draw)
-        self.draw.add_(4)
-        traj.done[t].copy_(tacc)                                                                          # G2
-        torch.div(racc.gather(1, actor.to(torch.int64)[:, None])[:, 0], self.scale, out=traj.reward[t])      # G1, :90
-        self.tc.add_(tacc.sum())                                                                          # :85
+                        terminated_acc=tacc, current_player=cur[(t + 1) & 1] if fin else None, draw_base=self.draw, ext=ext)
 
     def _capture(self):
         # warm-up on a side stream (allocator, hipBLASLt heuristics), then one capture per scan step

@@ -52,15 +52,25 @@ class SubstepBuffers:
 
 def policy_step(env: BridgeBidding, packed_in, packed_out, logits, mode: int, draw: int, autoreset: bool, *,
                 action=None, log_prob=None, obs=None, mask=None, rewards_acc=None, terminated_acc=None,
-                current_player=None, draw_base=None):
+                current_player=None, draw_base=None, ext=None):
     """One launch of ``brl_policy_step`` (include/brl_hip.h).  With ``draw_base`` (a 1-element int32/uint32 device
-    tensor) the draw index is ``draw_base[0] + draw``, read on the device (``brl_policy_step_at``: hipGraph replays)."""
+    tensor) the draw index is ``draw_base[0] + draw``, read on the device (``brl_policy_step_at``: hipGraph replays).
+    ``ext`` (a ``_capi.MacroExt``): the macro-step bookkeeping of src/roll_out.py:72-103 done by the same launch
+    (``brl_policy_step_ex``)."""
     n = packed_in.shape[0]
     logits = logits.to(torch.float32)
     assert logits.shape == (n, NUM_ACTIONS)
     strided = logits.stride(1) == 1 and logits.stride(0) >= NUM_ACTIONS  # e.g. the first 38 columns of a [n,39] matrix
     if not strided:
         logits = logits.contiguous()
+    if ext is not None:
+        import ctypes as C
+        check(_capi.lib().brl_policy_step_ex(env._h, ptr(packed_in), ptr(packed_out), n, logits.data_ptr(),
+                                             logits.stride(0), int(mode), ptr(draw_base), int(draw) & 0xFFFFFFFF,
+                                             int(bool(autoreset)), ptr(action), ptr(log_prob), ptr(obs), ptr(mask),
+                                             ptr(rewards_acc), ptr(terminated_acc), ptr(current_player), C.byref(ext),
+                                             _stream()))
+        return
     if draw_base is not None or logits.stride(0) != NUM_ACTIONS:
         check(_capi.lib().brl_policy_step_at(env._h, ptr(packed_in), ptr(packed_out), n, logits.data_ptr(),
                                              logits.stride(0), int(mode), ptr(draw_base), int(draw) & 0xFFFFFFFF,

@@ -170,6 +170,30 @@ int brl_policy_step_at(brl_handle *h, const uint64_t *state_in, uint64_t *state_
                        uint8_t *mask, float *rewards_acc, uint8_t *terminated_acc, int32_t *current_player,
                        void *stream);
 
+/* Per-macro-step bookkeeping folded into a sub-step launch (every member optional: zero / NULL = off) — what the scan body
+ * of src/roll_out.py:63-103 does around the four sub-steps of src/utils.py:69-128, without a launch of its own. */
+typedef struct brl_macro_ext {
+  int32_t first;             /* != 0: first sub-step of a macro-step: rewards_acc / terminated_acc are OVERWRITTEN */
+  int32_t last;              /* != 0: last sub-step: the members below marked (last) are written after accumulation */
+  const float *value_in;     /* value_out[i] = value_in[i * value_stride]: the critic output -> Transition.value[t] (:76) */
+  int64_t value_stride;
+  float *value_out;
+  uint8_t *done_out;         /* (last) [n]  = terminated_acc                                   (src/roll_out.py:85, G2) */
+  float *reward_out;         /* (last) [n]  = rewards_acc[i, actor[i]] / reward_scale          (src/roll_out.py:90, G1) */
+  const int32_t *actor;      /*        [n]  player id that acted in sub-step 1 (src/roll_out.py:72) */
+  float reward_scale;
+  int32_t obs_fmt;           /* obs_cast element type: 0 float, 1 bf16, 2 fp16 */
+  int64_t *terminated_count; /* (last) [1] += sum_i terminated_acc[i]                           (src/roll_out.py:85) */
+  void *obs_cast;            /* [n,480]: the new observation as the next forward's input (`astype`, src/roll_out.py:75) */
+} brl_macro_ext;
+
+/* brl_policy_step_at + brl_macro_ext (ext may be NULL). */
+int brl_policy_step_ex(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
+                       const float *logits, int64_t logits_stride, int mode, const uint32_t *draw_base,
+                       uint32_t draw_offset, int autoreset, int32_t *action, float *log_prob, uint8_t *obs,
+                       uint8_t *mask, float *rewards_acc, uint8_t *terminated_acc, int32_t *current_player,
+                       const brl_macro_ext *ext, void *stream);
+
 /* Observation bytes -> network input: `last_obs.astype(jnp.float32)` (src/roll_out.py:75) and its low-precision
  * variants.  obs uint8 [n,480] (0/1); out [n,480] of float (fmt 0), bf16 (fmt 1) or fp16 (fmt 2). */
 int brl_obs_cast(brl_handle *h, const uint8_t *obs, int64_t n, void *out, int fmt, void *stream);

@@ -339,3 +339,9 @@ int brl_ppo_stats_at(int device, const float *pt, int64_t b, const float *gram, 
   (void)device; (void)pt; (void)b; (void)gram; (void)vc; (void)ec; (void)out; (void)ri; (void)s;
   NOT_HERE("brl_ppo_stats_at");
 }
+int brl_policy_step_ex(brl_handle *h, const uint64_t *si, uint64_t *so, int64_t n, const float *lg, int64_t ls, int mode,
+                       const uint32_t *db, uint32_t dof, int ar, int32_t *a, float *lp, uint8_t *obs, uint8_t *m, float *ra,
+                       uint8_t *ta, int32_t *cp, const brl_macro_ext *ext, void *s) {
+  (void)h; (void)si; (void)so; (void)n; (void)lg; (void)ls; (void)mode; (void)db; (void)dof; (void)ar; (void)a; (void)lp; (void)obs; (void)m; (void)ra; (void)ta; (void)cp; (void)ext; (void)s;
+  NOT_HERE("brl_policy_step_ex");
+}

@@ -625,6 +625,24 @@ def test_flag_synchronised_rollout_equals_barrier_kernel_at_full_size():
     assert int(outs[0][-1][-1].item()) > 0
 
 
+def test_fused_rollout_kernels_agree_across_the_draw_counter_wrap(dds, oracle):
+    """The action-draw index is a uint32 that wraps: k_rollout_fs precomputes the launch's draws per 4-draw Philox block,
+    k_rollout_ws / k_rollout_random step through them — all three (and the oracle) must agree across 2^32."""
+    import brl_amd
+    outs = []
+    for ws in (None, "ws", "0"):
+        env = make_env(dds, 4, ws)
+        roll = brl_amd.make_random_roll_out({"num_steps": 16}, env)
+        rs, traj = roll((None, None, env.init(12, num_envs=64), None, 0, 2 ** 32 - 7))
+        outs.append([t.clone() for t in traj] + [rs[2].packed.clone()])
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            assert torch.equal(x, y)
+    ref = oracle.init_random(64, seed=12)
+    want = oracle.rollout_random(ref, 16, seed=12, draw_base=2 ** 32 - 7)
+    assert np.array_equal(to_np(outs[0][1]), want["action"]) and np.array_equal(to_np(outs[0][5]), want["obs"])
+
+
 @pytest.mark.parametrize("n", [640, 8192])   # 8192 = BASELINE.json configs[2] (num_envs=8192 duplicate self-play)
 def test_simple_duplicate_evaluate_replays_through_oracle(env, oracle, n):
     """Config 3 driver (src/evaluation.py:69-204): record the greedy actions the two MLPs chose on the
