@@ -97,7 +97,7 @@ def lib() -> C.CDLL:
         "brl_relu_bwd_colsum": [i32, _vp, _vp, i64, i64, i64, _vp, _vp, _vp],
         "brl_bias_finalize": [i32, i32, _vp, _vp, _vp, i64, _vp],
         "brl_ppo_stats_at": [i32, _vp, i64, _vp, f32, f32, _vp, _vp, _vp],
-        "brl_adam_clip": [i32, _vp, _vp, _vp, _vp, i64, _vp, f32, f32, f32, f32, f32, f32, _vp, _vp, _vp, _vp],
+        "brl_adam_clip": [i32, _vp, _vp, _vp, _vp, i64, _vp, f32, _vp, f32, f32, f32, f32, f32, _vp, _vp, _vp, _vp],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)

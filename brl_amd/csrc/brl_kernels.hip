@@ -2201,14 +2201,14 @@ extern "C" int brl_bias_finalize(int device, int nseg, const float *const *scrat
   return BRL_OK;
 }
 
-extern "C" int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr, float beta1,
-                             float beta2, float eps, float max_norm, float grad_scale, float *scratch, int32_t *mb_index,
-                             float *norm_out, void *stream) {
+extern "C" int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
+                             const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale,
+                             float *scratch, int32_t *mb_index, float *norm_out, void *stream) {
   NEED(p && g && m && v && step && scratch && n > 0 && n % 4 == 0, "p / g / m / v / step / scratch / n (a multiple of 4)");
   HIP_TRY(hipSetDevice(device));
   hipLaunchKernelGGL(k_adam_norm, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, g, n, grad_scale, scratch, step);
   hipLaunchKernelGGL(k_adam_apply, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, p, g, m, v, n, scratch, step, lr,
-                     beta1, beta2, eps, max_norm, grad_scale, mb_index, norm_out);
+                     lr_dev, beta1, beta2, eps, max_norm, grad_scale, mb_index, norm_out);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

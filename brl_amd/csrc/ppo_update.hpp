@@ -101,9 +101,9 @@ __global__ __launch_bounds__(256) void k_relu_bwd_tiles4(float *dh, const float 
   }
 }
 
-constexpr int BIAS_MAX_SEGS = 8;
+constexpr int BIAS_MAX_SEGS = 12;  // DeepMind_8: 8 hidden layers + the head
 __host__ __device__ inline int64_t relu_tile_rows(int64_t cols, int64_t ld) { return (cols % 4 == 0 && ld % 4 == 0) ? 16 : 64; }
-struct BiasSegs {  // up to 8 layers finalised by one launch (blockIdx.y = layer)
+struct BiasSegs {  // up to 12 layers finalised by one launch (blockIdx.y = layer)
   int n;
   int64_t tiles[BIAS_MAX_SEGS];
   const float *partials[BIAS_MAX_SEGS];
@@ -148,7 +148,8 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_norm(const float *g, int6
 }
 
 __global__ __launch_bounds__(ADAM_THREADS) void k_adam_apply(float *p, const float *g, float *m, float *v, int64_t n,
-                                                             const float *partials, const float *step, float lr, float b1,
+                                                             const float *partials, const float *step, float lr_arg,
+                                                             const float *lr_dev, float b1,
                                                              float b2, float eps, float max_norm, float gscale,
                                                              int32_t *mb_index, float *norm_out) {
   __shared__ float red[ADAM_THREADS / 64];
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_apply(float *p, const flo
   }
   const float scale = s_scale * gscale;
   const float t = *step;
+  const float lr = (lr_dev != nullptr) ? *lr_dev : lr_arg;  // device-resident: a captured launch follows the lr schedule
   const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
   const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
   const int64_t n4 = n >> 2;

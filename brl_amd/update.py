@@ -322,6 +322,7 @@ class FusedMinibatch:
         self.lib, self.capi = _capi.lib(), _capi
         d0 = opt.defaults
         self.lr, (self.b1, self.b2), self.eps = float(d0["lr"]), d0["betas"], float(d0["eps"])
+        self.lr_dev = torch.full((1,), float(opt.param_groups[0]["lr"]), dtype=torch.float32, device=device)
         self.max_norm = float(config["max_grad_norm"]) if config.get("global_gradient_clipping", True) else 0.0
         # warm-up and capture run real steps on the dummy batch: put parameters, moments and counters back afterwards
         saved = [t.clone() for t in (self.P, self.M, self.V, self.step, self.mb_index)]
@@ -395,7 +396,8 @@ class FusedMinibatch:
         s = torch.cuda.current_stream().cuda_stream
         di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         self.capi.check(self.lib.brl_adam_clip(di, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
-                                               self.n, self.step.data_ptr(), self.lr, float(self.b1), float(self.b2), self.eps,
+                                               self.n, self.step.data_ptr(), self.lr, self.lr_dev.data_ptr(), float(self.b1),
+                                               float(self.b2), self.eps,
                                                self.max_norm, 1.0 / self.world, self.scratch.data_ptr(),
                                                self.mb_index.data_ptr(), self.norm.data_ptr(), s))
 
@@ -422,6 +424,7 @@ class FusedMinibatch:
             self.perm.copy_(allp)
             self.mb_index.zero_()
             self.step.copy_(self.opt.state[self.plist[0]]["step"])  # the optimizer may have been stepped eagerly / loaded
+            self.lr_dev.fill_(float(self.opt.param_groups[0]["lr"]))  # constant within an update (ppo.py:186-192)
         return self.log[:steps]
 
     def _readopt(self):
@@ -490,7 +493,7 @@ def make_update_step(config, actor_forward_pass, optimizer=None):
         graphed = None
         fused = None
         want_fused = adv_f.is_cuda and FusedMinibatch.supports(config, params)
-        if config.get("graph_update", True) and adv_f.is_cuda and sched is None and (want_fused or not multi):
+        if config.get("graph_update", True) and adv_f.is_cuda and (want_fused or (sched is None and not multi)):
             graphed = opt_state.get("graphed")
             world = dist.get_world_size() if multi else 1
             if graphed is None or graphed.params is not params or graphed.mbs != mbs or isinstance(graphed, FusedMinibatch) != want_fused \
@@ -512,6 +515,12 @@ def make_update_step(config, actor_forward_pass, optimizer=None):
             for _ in range(int(config["update_epochs"]) * num_mb):
                 fused.run_mb()
             fused.end_update()
+            if sched is not None:   # ppo.py:186-192: the rate changes between updates only (count // per_update)
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")   # "lr_scheduler.step() before optimizer.step()": Adam ran in HIP
+                    for _ in range(int(config["update_epochs"]) * num_mb):
+                        sched.step()
             log = log.clone().reshape(int(config["update_epochs"]), num_mb, 8)
             loss_info = (log[..., 0], tuple(log[..., 1 + i] for i in range(6)))
             return (params, opt_state, env_state, last_obs, terminated_count, int(rng) + 1), loss_info

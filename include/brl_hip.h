@@ -308,7 +308,7 @@ int brl_relu_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int
                         float *scratch, void *stream);
 
 /* db[i][c] = sum over the tiles of scratch[i] (as written by brl_relu_bwd_colsum for `rows` dense rows, ld == cols[i])
- * for nseg <= 8 layers. */
+ * for nseg <= 12 layers. */
 int brl_bias_finalize(int device, int nseg, const float *const *scratch, const int64_t *cols, float *const *db, int64_t rows,
                       void *stream);
 
@@ -320,11 +320,12 @@ int brl_ppo_stats_at(int device, const float *partials, int64_t batch, const flo
  * launches (n a multiple of 4: pad the buffers with zeros): *step (device float) += 1; the gradient is grad_scale * g
  * (1 / world_size after a SUM all-reduce: the ranks' mean, ppo.py's pmean; 1 otherwise), scaled by
  * min(1, max_norm / (|gradient| + 1e-6)) (max_norm <= 0: no clipping); m, v, p updated with torch.optim.Adam's arithmetic.
- * scratch: float [1024].  mb_index (may be NULL): advanced by one.
+ * lr_dev (may be NULL): the learning rate in device memory, used instead of `lr` (a captured launch then follows
+ * ppo.py:186-192's linear schedule).  scratch: float [1024].  mb_index (may be NULL): advanced by one.
  * norm_out (may be NULL): |g| before clipping. */
-int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr, float beta1,
-                  float beta2, float eps, float max_norm, float grad_scale, float *scratch, int32_t *mb_index, float *norm_out,
-                  void *stream);
+int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
+                  const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale, float *scratch,
+                  int32_t *mb_index, float *norm_out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -325,9 +325,10 @@ int brl_relu_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int
   (void)device; (void)dh; (void)h; (void)rows; (void)cols; (void)ld; (void)db; (void)scr; (void)s;
   NOT_HERE("brl_relu_bwd_colsum");
 }
-int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr, float b1, float b2,
+int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr, const float *lrd,
+                  float b1, float b2,
                   float eps, float mn, float gs, float *scratch, int32_t *mbi, float *no, void *s) {
-  (void)gs; (void)device; (void)p; (void)g; (void)m; (void)v; (void)n; (void)step; (void)lr; (void)b1; (void)b2; (void)eps; (void)mn; (void)scratch; (void)mbi; (void)no; (void)s;
+  (void)gs; (void)lrd; (void)device; (void)p; (void)g; (void)m; (void)v; (void)n; (void)step; (void)lr; (void)b1; (void)b2; (void)eps; (void)mn; (void)scratch; (void)mbi; (void)no; (void)s;
   NOT_HERE("brl_adam_clip");
 }
 int brl_bias_finalize(int device, int nseg, const float *const *scr, const int64_t *cols, float *const *db, int64_t rows, void *s) {

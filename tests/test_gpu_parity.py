@@ -1120,6 +1120,31 @@ def test_fused_update_with_gradient_allreduce_two_ranks(tmp_path):
     assert torch.allclose(total.cpu(), r0[1], atol=1e-6) and torch.allclose(single, r0[0], atol=1e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("variant", ["DeepMind_6", "anneal_lr"])
+def test_fused_update_variants_match_eager(variant):
+    """FusedMinibatch on the 6-layer MLP of wb5/models.py, and under ppo.py:186-192's linear learning-rate schedule (the
+    rate lives in device memory, so the captured Adam launch follows it): two updates of one epoch vs the eager path."""
+    from brl_amd.models import make_forward_pass
+    from brl_amd.update import FusedMinibatch, make_optimizer, make_update_step
+    from tests.test_update_cpu import CFG, fake_batch
+    fp = make_forward_pass("relu", "DeepMind_6" if variant == "DeepMind_6" else "DeepMind")
+    cfg0 = dict(CFG, minibatch_size=256, update_epochs=1, num_minibatches=4, num_updates=4, anneal_lr=variant == "anneal_lr")
+    outs = []
+    for fused in (False, True):
+        net = fp.init(7, device="cuda")
+        cfg = dict(cfg0, graph_update=fused)
+        rs = (net, make_optimizer(cfg, net), None, None, 0, 5)
+        for it in range(2):
+            tb, adv, tgt = fake_batch(4, 256, seed=40 + it)
+            rs, _ = make_update_step(cfg, fp)(rs, type(tb)(*[x.cuda() for x in tb]), adv.cuda(), tgt.cuda())
+        if fused:
+            assert isinstance(rs[1].get("graphed"), FusedMinibatch), rs[1].get("graph_error")
+        outs.append((torch.cat([p.detach().reshape(-1) for p in net.parameters()]), rs[1]["opt"].param_groups[0]["lr"]))
+    assert abs(outs[0][1] - outs[1][1]) < 1e-12 and (variant != "anneal_lr" or abs(outs[0][1] - 0.5 * CFG["lr"]) < 1e-12)
+    d = (outs[0][0] - outs[1][0]).abs()
+    assert float(d.mean()) < 1e-5 and float(d.max()) < 2 * CFG["lr"], (float(d.mean()), float(d.max()))
+
+
 def test_fused_update_follows_a_reloaded_optimizer_state():
     """opt.load_state_dict between two updates replaces the moment tensors FusedMinibatch had made views of its flat
     buffers: the next update must continue from the LOADED state (a resumed run), not from stale moments."""
@@ -1177,13 +1202,14 @@ def test_fused_update_helpers_match_torch():
     opt = torch.optim.Adam([ref], lr=1e-3, eps=1e-5)
     p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
     step, scratch, idx, norm = torch.zeros((), device=dev), torch.empty(1024, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), torch.empty(1, device=dev)
+    lr_dev = torch.full((1,), 1e-3, device=dev)   # the third step reads the learning rate from device memory
     for it in range(3):
         grad = torch.randn(n, device=dev, generator=g) * (0.001 if it == 1 else 1.0)   # one step below the clip threshold
         ref.grad = grad.clone()
         want_norm = torch.nn.utils.clip_grad_norm_([ref], 0.5)
         opt.step()
-        _capi.check(L.brl_adam_clip(0, p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, step.data_ptr(), 1e-3, 0.9,
-                                    0.999, 1e-5, 0.5, 1.0, scratch.data_ptr(), idx.data_ptr(), norm.data_ptr(), s))
+        _capi.check(L.brl_adam_clip(0, p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, step.data_ptr(), 1e-3,
+                                    lr_dev.data_ptr() if it == 2 else None, 0.9, 0.999, 1e-5, 0.5, 1.0, scratch.data_ptr(), idx.data_ptr(), norm.data_ptr(), s))
         assert torch.allclose(norm[0], want_norm, rtol=1e-5)
         assert torch.allclose(p, ref.detach(), atol=2e-6), float((p - ref.detach()).abs().max())
     assert int(idx.item()) == 3 and float(step.item()) == 3.0
