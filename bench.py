@@ -321,6 +321,10 @@ def bench_ppo(args, torch, dev, rank, world, barrier, max_over_ranks):
     from brl_amd.train import DEFAULTS
     from brl_amd.update import make_optimizer, make_update_step
 
+    if os.environ.get("BRL_TUNABLEOP") == "1":  # experiment: let torch pick the fastest rocBLAS / hipBLASLt solution per GEMM shape
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.tuning_enable(True)
+        torch.cuda.tunable.set_max_tuning_duration(30)
     cfg = dict(DEFAULTS, num_envs=NUM_ENVS, num_steps=NUM_STEPS, minibatch_size=1024, update_epochs=10,
                inference_dtype=os.environ.get("BRL_INFER_DTYPE", "bf16"), graph_rollout=True)
     cfg["num_minibatches"] = cfg["num_envs"] * cfg["num_steps"] // cfg["minibatch_size"]

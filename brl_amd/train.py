@@ -42,6 +42,7 @@ DEFAULTS = dict(  # ppo.py:122-180 (PPOConfig), same names and defaults
     illegal_action_l2norm_coef=0.0,
     # build-side knobs (not in the reference)
     lut_len=100_000, synthetic_lut_files=3, inference_dtype=None, graph_rollout=False, evaluate=True,
+    tunable_gemm=False,  # torch TunableOp: time every rocBLAS / hipBLASLt solution once per GEMM shape (update: -5 %)
 )
 
 
@@ -131,6 +132,10 @@ def train(config, log=print):
                                     make_simple_evaluate)
     from brl_amd.models import make_forward_pass
     from brl_amd.update import make_optimizer, make_update_step
+    if config.get("tunable_gemm") and torch.cuda.is_available():
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.tuning_enable(True)
+        torch.cuda.tunable.set_max_tuning_duration(30)
 
     rank, world = rank_world()
     if world > 1 and not dist.is_initialized():
