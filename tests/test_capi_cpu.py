@@ -55,6 +55,20 @@ def test_struct_layouts_match_header():
         assert members == cls._names, name
 
 
+def test_macro_ext_layout_matches_header():
+    """brl_macro_ext mixes ints, floats and pointers: member order and C types against the ctypes mirror."""
+    from brl_amd import _capi
+    text = open(os.path.join(ROOT, "include", "brl_hip.h")).read()
+    body = re.search(r"typedef struct brl_macro_ext \{(.*?)\} brl_macro_ext;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    decl = re.findall(r"([A-Za-z_0-9 ]+?[ \*]+)([a-z_]+)\s*;", body)
+    want = [(n, "ptr" if "*" in t else t.split()[-1]) for t, n in decl]
+    kinds = {ctypes.c_int32: "int32_t", ctypes.c_int64: "int64_t", ctypes.c_float: "float", ctypes.c_void_p: "ptr"}
+    got = [(n, kinds[t]) for n, t in _capi.MacroExt._fields_]
+    assert got == want
+    assert ctypes.sizeof(_capi.MacroExt) == 80
+
+
 def test_bad_arguments_are_reported_not_crashed(built_lib):
     from brl_amd import _capi
     L = _capi.lib()
