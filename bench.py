@@ -144,9 +144,15 @@ def main():
     import torch
 
     dist = None
+    # BRL_BENCH_BACKEND=gloo: rehearsal of the N-rank path on a box with fewer GPUs than ranks (ranks share the devices
+    # round-robin, the control plane runs over gloo); the driver's runs use RCCL, one GPU per rank
+    backend = os.environ.get("BRL_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
         if FAKE:
+            dist.init_process_group("gloo")
+        elif backend == "gloo":
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
             dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local_rank)
@@ -154,6 +160,7 @@ def main():
     elif not FAKE:
         torch.cuda.set_device(0)
     dev = torch.device("cpu") if FAKE else torch.device("cuda", torch.cuda.current_device())
+    ctl_dev = torch.device("cpu") if (FAKE or backend == "gloo") else dev   # where the timing all-reduce lives
 
     def barrier():
         if dist is not None:
@@ -164,7 +171,7 @@ def main():
     def max_over_ranks(x: float) -> float:
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
