@@ -14,15 +14,15 @@ rng = np.random.default_rng(0)
 t_end = time.time() + budget
 launches = checks = 0
 while time.time() < t_end:
-    n = int(rng.choice([1, 31, 32, 33, 500, 2048, 8192]))
-    T = int(rng.choice([1, 7, 32, 33, 64]))
+    n = int(rng.choice([1, 31, 32, 33, 64, 96, 500, 2048, 4096, 8192]))   # multiples of 32 with T <= 40, substeps 1: k_rollout_fs
+    T = int(rng.choice([1, 7, 16, 32, 33, 40, 64]))
     sub = int(rng.choice([1, 1, 1, 4]))
     seed = int(rng.integers(1 << 30))
     env.set_rng(seed) if hasattr(env, "set_rng") else None
     roll = brl_amd.make_random_roll_out({"num_steps": T, "substeps": sub, "game_mode": "competitive" if sub == 4 else "normal"}, env)
     st = env.init(seed, num_envs=n)
     rs = (None, None, st, None, 0, 0)
-    check = n <= 2048 and (checks < 400 or rng.random() < 0.03)  # keep checking (sparsely) for the whole run
+    check = n <= 4096 and (checks < 400 or rng.random() < 0.03)  # keep checking (sparsely) for the whole run
     ref = orc.init_random(n, seed=seed) if check else None
     draw = 0
     for rep in range(int(rng.integers(1, 40))):
@@ -37,4 +37,4 @@ while time.time() < t_end:
             checks += 1
         draw += T * sub
     torch.cuda.synchronize()
-print(f"soak ok: {launches} launches, {checks} oracle checks, pipe={os.environ.get('BRL_ROLLOUT_PIPE', 'off')}")
+print(f"soak ok: {launches} launches, {checks} oracle checks, BRL_ROLLOUT_FS={os.environ.get('BRL_ROLLOUT_FS', 'default')}")
