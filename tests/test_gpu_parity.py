@@ -197,7 +197,8 @@ def test_rollout_terminated_count_accumulates(env, oracle):
 def test_gae_bit_exact(env, oracle):
     from brl_amd.gae import gae_scan
     rng = np.random.default_rng(2)
-    for (T, N, gamma, lam) in ((32, 8192, 1.0, 0.95), (7, 130, 0.99, 0.9), (1, 1, 1.0, 1.0)):
+    for (T, N, gamma, lam) in ((32, 8192, 1.0, 0.95), (7, 130, 0.99, 0.9), (1, 1, 1.0, 1.0), (33, 1000, 0.97, 0.9),
+                               (64, 17, 1.0, 0.95), (65, 40, 0.99, 0.95), (5, 16, 1.0, 0.95), (3, 64, 0.9, 0.8)):
         done = rng.random((T, N)) < 0.07
         value = rng.standard_normal((T, N)).astype(np.float32)
         reward = (rng.standard_normal((T, N)) * 0.2).astype(np.float32)
