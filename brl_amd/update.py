@@ -248,15 +248,16 @@ class FusedMinibatch:
     def __init__(self, config, params, opt, mbs: int, device, world: int = 1):
         from . import _capi
         self.cfg, self.params, self.opt, self.mbs, self.dev = config, params, opt, int(mbs), device
-        # world > 1: TWO graphs (forward + backward | clip + Adam) around the eager all-reduce of the flat gradient —
-        # RCCL over xGMI on MI355X: one 14.7 MB collective per minibatch (ppo.py's pmean)
+        # world > 1: the step is captured in segments, one per all-reduce bucket (see the capture below): ppo.py's pmean as
+        # collectives of <= 4.2 MB that overlap with the rest of the backward pass (RCCL over xGMI on MI355X)
         self.world = int(world)
         f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)  # noqa: E731
         body = list(params.body)
-        # flat layout: (W, b) of every hidden layer, then actor.weight | critic.weight (one [39,1024] matrix), then
-        # actor.bias | critic.bias
-        plist = [q for lin in body for q in (lin.weight, lin.bias)] + [params.actor.weight, params.critic.weight,
-                                                                      params.actor.bias, params.critic.bias]
+        # flat layout: every hidden layer's W, then actor.weight | critic.weight (one [39,1024] matrix), then the biases
+        # (hidden layers, actor | critic): a layer's weight gradient is one contiguous slice (all-reduce buckets), all bias
+        # gradients — finished by one launch at the end of the backward pass — another
+        plist = [lin.weight for lin in body] + [params.actor.weight, params.critic.weight] \
+            + [lin.bias for lin in body] + [params.actor.bias, params.critic.bias]
         assert len(plist) == len(list(params.parameters()))
         sizes = [q.numel() for q in plist]
         self.n = n = (sum(sizes) + 3) // 4 * 4  # brl_adam_clip works on float4s: zero padding at the end
@@ -294,7 +295,14 @@ class FusedMinibatch:
         ba = views[params.actor.bias]
         self.bh = self.P[ba.start:ba.start + K]
         self.Gbh = self.G[ba.start:ba.start + K]
+        self.G_bias = self.G[views[body[0].bias].start:ba.start + K]   # every bias gradient, contiguous
         B = self.mbs
+        # world > 1: the backward pass is captured as several graphs, so the activations and the two dh buffers they hand
+        # to each other are static; one graph (world == 1) lets the capture allocate them (out= variants of the fused
+        # bias+ReLU GEMM are slower: 885 vs 834 ms per configs[3] update)
+        self.static = self.world > 1
+        self.h = [f(B, H) for _ in body] if self.static else [None] * len(body)
+        self.dhb = [f(B, H), f(B, H)] if self.static else [None, None]
         self.x0 = f(B, 480)
         self.mask = torch.zeros((B, 38), dtype=torch.uint8, device=device)
         self.mask[:, 0] = 1  # a valid dummy batch for the warm-up iterations
@@ -326,7 +334,7 @@ class FusedMinibatch:
         self.max_norm = float(config["max_grad_norm"]) if config.get("global_gradient_clipping", True) else 0.0
         # warm-up and capture run real steps on the dummy batch: put parameters, moments and counters back afterwards
         saved = [t.clone() for t in (self.P, self.M, self.V, self.step, self.mb_index)]
-        self.graph = self.graph_opt = None
+        self.graph = self.segs = None
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -335,31 +343,50 @@ class FusedMinibatch:
                     self._fwd_bwd()
                     self._opt()
             torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph), torch.no_grad():
-                self._fwd_bwd()
-                if self.world == 1:
+            nl = len(self.W)
+            if self.world == 1:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph), torch.no_grad():
+                    self._fwd_bwd()
                     self._opt()
-            if self.world > 1:
-                graph_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_opt), torch.no_grad():
-                    self._opt()
-                self.graph_opt = graph_opt
-            self.graph = graph
+                self.graph = graph
+            else:
+                # one graph per all-reduce bucket: forward + loss + head backward | each hidden layer's backward | bias
+                # gradients | clip + Adam; the bucket's all-reduce is issued (async) behind its graph and overlaps with
+                # the graphs that follow (RCCL over xGMI: five collectives of <= 4.2 MB beside ~0.2 ms of backward GEMMs)
+                pool = torch.cuda.graph_pool_handle()
+                self.segs = []
+                for seg in [lambda: self._seg_head()] + [(lambda l=l: self._seg_layer(l)) for l in range(nl - 1, -1, -1)] \
+                        + [lambda: self._seg_fin(), lambda: self._opt()]:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool), torch.no_grad():
+                        seg()
+                    self.segs.append(g)
+                self.buckets = [self.GWh] + [self.GW[l] for l in range(nl - 1, -1, -1)] + [self.G_bias]
+                self.graph = self.segs[0]
         finally:
             with torch.no_grad():
                 for t, q in zip((self.P, self.M, self.V, self.step, self.mb_index), saved):
                     t.copy_(q)
 
     def _fwd_bwd(self):
+        self._seg_head()
+        for l in range(len(self.W) - 1, -1, -1):
+            self._seg_layer(l)
+        self._seg_fin()
+
+    def _seg_head(self):
+        """forward, loss + output gradients, the logged statistics (parallel branch), backward of the merged head"""
         L, chk, B = self.lib, self.capi.check, self.mbs
         s = torch.cuda.current_stream().cuda_stream
         di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         cfg = self.cfg
-        hs, x = [], self.x0
-        for W, b in zip(self.W, self.b):                          # forward: bias + ReLU in the GEMM epilogue
-            x = torch._addmm_activation(b, x, W.t(), use_gelu=False)
-            hs.append(x)
+        x = self.x0
+        for l, (W, b) in enumerate(zip(self.W, self.b)):          # forward: bias + ReLU in the GEMM epilogue
+            if self.static:
+                x = torch._addmm_activation(b, x, W.t(), use_gelu=False, out=self.h[l])
+            else:
+                x = self.h[l] = torch._addmm_activation(b, x, W.t(), use_gelu=False)
         heads = torch.addmm(self.bh, x, self.Wh.t())              # [B, 39]: 38 logits, value
         chk(L.brl_ppo_loss_heads(di, heads.data_ptr(), self.mask.data_ptr(), self.action.data_ptr(), self.old_v.data_ptr(),
                                  self.old_lp.data_ptr(), self.adv.data_ptr(), self.tgt.data_ptr(), B, float(cfg["clip_eps"]),
@@ -367,30 +394,60 @@ class FusedMinibatch:
                                  int(bool(cfg.get("actor_illegal_action_mask", True))),
                                  int(bool(cfg.get("value_clipping", True))), self.dheads.data_ptr(), self.partials.data_ptr(),
                                  self.illp.data_ptr(), s))
-        # the logged statistics (src/update.py:136-167) on a side stream: in the captured graph a parallel branch beside
-        # the backward pass (k_ppo_stats is one block, 33 us)
-        cur = torch.cuda.current_stream()
-        self.side.wait_stream(cur)
-        with torch.cuda.stream(self.side):
-            gram = self.illp.t() @ self.illp
-            chk(L.brl_ppo_stats_at(di, self.partials.data_ptr(), B, gram.data_ptr(), float(cfg["vf_coef"]),
-                                   float(cfg["ent_coef"]), self.log.data_ptr(), self.mb_index.data_ptr(),
-                                   self.side.cuda_stream))
+        if not self.static:
+            self._stats_fork()   # one graph: a branch beside the whole backward pass, joined before Adam (_seg_fin)
         # backward, written out: dW = dz^T h_prev, db = column sums of dz (finished for all layers by one launch),
         # dh_prev = dz W
         torch.mm(self.dheads.t(), x, out=self.GWh)
         nl = len(self.W)
         chk(L.brl_relu_bwd_colsum(di, self.dheads.data_ptr(), None, B, self.dheads.shape[1], self.dheads.shape[1], None,
                                   self.tile_sums[nl].data_ptr(), s))
-        dh = torch.mm(self.dheads, self.Wh)
-        for l in range(nl - 1, -1, -1):
-            chk(L.brl_relu_bwd_colsum(di, dh.data_ptr(), hs[l].data_ptr(), B, dh.shape[1], dh.shape[1], None,
-                                      self.tile_sums[l].data_ptr(), s))
-            torch.mm(dh.t(), hs[l - 1] if l > 0 else self.x0, out=self.GW[l])
-            if l > 0:
-                dh = torch.mm(dh, self.W[l])
-        chk(L.brl_bias_finalize(di, self._nseg, self._seg_scratch, self._seg_cols, self._seg_db, B, s))
-        cur.wait_stream(self.side)  # the statistics read mb_index, which the Adam launch advances
+        if self.static:
+            torch.mm(self.dheads, self.Wh, out=self.dhb[(nl - 1) & 1])
+        else:
+            self.dhb[(nl - 1) & 1] = torch.mm(self.dheads, self.Wh)
+
+    def _stats_fork(self):
+        """the logged statistics (src/update.py:136-167) on a side stream: in a captured graph a parallel branch (k_ppo_stats
+        is one block, 33-50 us) beside the GEMMs issued until _stats_join"""
+        cfg, B = self.cfg, self.mbs
+        di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            gram = self.illp.t() @ self.illp
+            self.capi.check(self.lib.brl_ppo_stats_at(di, self.partials.data_ptr(), B, gram.data_ptr(), float(cfg["vf_coef"]),
+                                                      float(cfg["ent_coef"]), self.log.data_ptr(), self.mb_index.data_ptr(),
+                                                      self.side.cuda_stream))
+
+    def _stats_join(self):
+        torch.cuda.current_stream().wait_stream(self.side)  # the statistics read mb_index, which the Adam launch advances
+
+    def _seg_layer(self, l):
+        """backward of hidden layer l: dh (in self.dhb[l & 1]) -> dz in place, tile sums, dW_l, dh of the layer below"""
+        L, chk, B = self.lib, self.capi.check, self.mbs
+        s = torch.cuda.current_stream().cuda_stream
+        di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        top = self.static and l == len(self.W) - 1
+        if top:
+            self._stats_fork()   # several graphs: the branch lives (and is joined) inside the first layer's graph
+        dh = self.dhb[l & 1]
+        chk(L.brl_relu_bwd_colsum(di, dh.data_ptr(), self.h[l].data_ptr(), B, dh.shape[1], dh.shape[1], None,
+                                  self.tile_sums[l].data_ptr(), s))
+        torch.mm(dh.t(), self.h[l - 1] if l > 0 else self.x0, out=self.GW[l])
+        if l > 0:
+            if self.static:
+                torch.mm(dh, self.W[l], out=self.dhb[(l - 1) & 1])
+            else:
+                self.dhb[(l - 1) & 1] = torch.mm(dh, self.W[l])
+        if top:
+            self._stats_join()
+
+    def _seg_fin(self):
+        s = torch.cuda.current_stream().cuda_stream
+        di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        self.capi.check(self.lib.brl_bias_finalize(di, self._nseg, self._seg_scratch, self._seg_cols, self._seg_db, self.mbs, s))
+        if not self.static:
+            self._stats_join()
 
     def _opt(self):
         s = torch.cuda.current_stream().cuda_stream
@@ -456,10 +513,16 @@ class FusedMinibatch:
                                                self.perm.data_ptr(), self.mb_index.data_ptr(), self.mbs, self.x0.data_ptr(),
                                                self.mask.data_ptr(), self.action.data_ptr(), self.old_v.data_ptr(),
                                                self.old_lp.data_ptr(), self.adv.data_ptr(), self.tgt.data_ptr(), s))
-        self.graph.replay()
-        if self.world > 1:
-            dist.all_reduce(self.G, op=dist.ReduceOp.SUM)   # brl_adam_clip divides by world (grad_scale)
-            self.graph_opt.replay()
+        if self.world == 1:
+            self.graph.replay()
+            return
+        works = []
+        for g, bucket in zip(self.segs[:-1], self.buckets):      # brl_adam_clip divides by world (grad_scale)
+            g.replay()
+            works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
+        self.segs[-1].replay()
 
     def end_update(self):
         with torch.no_grad():  # every parameter's step counter (torch keeps one per parameter)
