@@ -1071,9 +1071,19 @@ struct PolicyArgs {
 // table.  `cand`: the actions the distribution ranges over — the legal ones (masked policy, src/roll_out.py:27-29) or
 // all 38 (unmasked / illegal-action-penalty policy, src/roll_out.py:33-39).
 //   mode bit 0: 0 = pi.sample (inverse CDF in action order with the 24-bit uniform of `u32`), 1 = pi.mode (first max)
+// network outputs as the GEMM wrote them: float (fmt 0), bf16 (1) or fp16 (2) -> float (exact conversions)
+__device__ __forceinline__ float net_out(const void *base, int64_t idx, int fmt) {
+  if (fmt == 0) return reinterpret_cast<const float *>(base)[idx];
+  const uint16_t h = reinterpret_cast<const uint16_t *>(base)[idx];
+  if (fmt == 1) return __uint_as_float((uint32_t)h << 16);
+  _Float16 f16;
+  __builtin_memcpy(&f16, &h, 2);
+  return (float)f16;
+}
+
 template <int K>
-__device__ __forceinline__ int categorical(const float *logits_row, bool valid, uint64_t cand, int mode, uint32_t u32,
-                                           int lane, float &log_prob) {
+__device__ __forceinline__ int categorical(const void *logits, int64_t row_off, int fmt, bool valid, uint64_t cand, int mode,
+                                           uint32_t u32, int lane, float &log_prob) {
   constexpr int LPT = 64 / K;
   constexpr int NI = (BRL_NUM_ACTIONS + LPT - 1) / LPT;
   const int tl = lane % K, slot = lane / K;
@@ -1085,7 +1095,7 @@ __device__ __forceinline__ int categorical(const float *logits_row, bool valid, 
   for (int i = 0; i < NI; i++) {
     const int a = slot * NI + i;
     const bool in = a < BRL_NUM_ACTIONS;
-    lg[i] = (in && valid) ? logits_row[a] : 0.0f;
+    lg[i] = (in && valid) ? net_out(logits, row_off + a, fmt) : 0.0f;
     ok[i] = in && ((cand >> (a & 63)) & 1ull);
     if (ok[i] && lg[i] > mx) {  // first maximum wins, like argmax
       mx = lg[i];
@@ -1165,7 +1175,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
     u32 = (sel == 0) ? r[0] : ((sel == 1) ? r[1] : ((sel == 2) ? r[2] : r[3]));
   }
   float lp;
-  const int act = categorical<K>(A.logits + (w.valid ? w.table : 0) * A.logits_stride, w.valid, cand, A.mode, u32,
+  const int act = categorical<K>(A.logits, (w.valid ? w.table : 0) * A.logits_stride, A.x.in_fmt, w.valid, cand, A.mode, u32,
                                  w.c.lane, lp);
   if (A.autoreset) auto_reset_clear(t);
   int hb = table_step(t, act);
@@ -1207,7 +1217,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
       A.o.terminated[w.table] = (uint8_t)tacc;
     }
     if (A.o.current_player) A.o.current_player[w.table] = cur_player(t);
-    if (A.x.value_out) A.x.value_out[w.table] = A.x.value_in[w.table * A.x.value_stride];   // src/roll_out.py:76
+    if (A.x.value_out) A.x.value_out[w.table] = net_out(A.x.value_in, w.table * A.x.value_stride, A.x.in_fmt);   // src/roll_out.py:76
     if (A.x.last) {
       if (A.x.done_out) A.x.done_out[w.table] = (uint8_t)tacc;                                // G2
       if (A.x.reward_out) {                                                                  // G1, src/roll_out.py:90
@@ -1309,7 +1319,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_eval_step(EvalArgs A) {
     const int64_t tb = w.valid ? w.table : 0;
     const float *row = team ? A.logits2 + tb * A.stride2 : A.logits1 + tb * A.stride1;
     float lp;
-    a = categorical<K>(row, w.valid, legal, 1, 0u, w.c.lane, lp);  // masked_pi.mode()
+    a = categorical<K>(row, 0, 0, w.valid, legal, 1, 0u, w.c.lane, lp);  // masked_pi.mode()
     if (A.S.illegal_prob_sum) mass = illegal_mass<K>(row, w.valid, legal, w.c.lane);
   }
   if (w.c.lane < K && w.valid && !was_term) {  // make_step_log: finished boards log nothing (src/evaluation.py:736-748)
@@ -1967,6 +1977,7 @@ static int policy_step_impl(brl_handle *h, const uint64_t *state_in, uint64_t *s
     NEED(!ext->last || !ext->reward_out || (ext->actor && rewards_acc && ext->reward_scale != 0.0f), "ext: reward_out needs actor, rewards_acc, reward_scale");
     NEED(!ext->last || !(ext->done_out || ext->terminated_count) || terminated_acc, "ext: done_out / terminated_count need terminated_acc");
     NEED(!ext->obs_cast || (ext->obs_fmt >= 0 && ext->obs_fmt <= 2), "ext: obs_fmt");
+    NEED(ext->in_fmt >= 0 && ext->in_fmt <= 2, "ext: in_fmt");
   }
   LAUNCH_K(h, k_policy_step, n, stream, A);
   return BRL_OK;

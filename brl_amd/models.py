@@ -110,16 +110,18 @@ class InferenceSnapshot:
             return x
         return obs.to(self.dtype)
 
-    def heads(self, obs, x=None):
+    def heads(self, obs, x=None, raw=False):
         """obs: [n, 480] bool / float -> f32 [n, 39]: the 38 logits and the value as ONE matrix (row stride 39; the
         kernels take the logits as a strided slice of it).  ``x``: the observation already in ``self.dtype`` (written
-        by the step kernel that produced it, brl_macro_ext.obs_cast) — then ``obs`` is not read."""
+        by the step kernel that produced it, brl_macro_ext.obs_cast) — then ``obs`` is not read.  ``raw``: the matrix in
+        ``self.dtype`` as the GEMM wrote it (brl_policy_step_ex converts while reading: brl_macro_ext.in_fmt)."""
         if x is None:
             x = self._input(obs)
         fused = hasattr(torch, "_addmm_activation")
         for w, b in self.body:
             x = torch._addmm_activation(b, x, w, use_gelu=False) if fused else torch.addmm(b, x, w).relu_()
-        return torch.addmm(self.head_b, x, self.head_w).float()
+        out = torch.addmm(self.head_b, x, self.head_w)
+        return out if raw else out.float()
 
     def __call__(self, obs):
         """obs: [n, 480] bool / float -> (logits f32 [n, 38], value f32 [n])"""

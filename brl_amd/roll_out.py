@@ -137,8 +137,8 @@ class _PolicyRollout:
         """-> f32 [n, 39] heads (38 logits + value; DeepMind ReLU nets: fused epilogues, merged heads) or, for the other
         architectures, (logits, value).  ``x``: obs_bool already cast by the step kernel."""
         snap = self.snap_opp if is_opp else self.snap_actor
-        if snap is not None:
-            out = snap.heads(obs_bool, x)
+        if snap is not None:   # low precision: the heads stay in the GEMM's dtype, the step kernel converts while reading
+            out = snap.heads(obs_bool, x, raw=True)
             return out[:, :snap.n_actions], out[:, snap.n_actions]
         fp, pr = (self.opp_fp, self.opp_params) if is_opp else (self.actor_fp, self.params)
         if self.infer_dtype is None:
@@ -159,13 +159,13 @@ class _PolicyRollout:
         actor = cur[t & 1]                                              # src/roll_out.py:72
         # the first forward of a rollout reads the loaded observation; later ones the cast written by the previous launch
         logits, value = self._forward(False, traj.obs[t], None if t == 0 else self.xin)   # :73-76
-        value = value.to(torch.float32)
+        ifmt = self._FMT[logits.dtype]
         # sub-step 1: the actor samples from the (un)masked Categorical (src/roll_out.py:27-39,79-84)
         policy_step(env, packed, packed, logits, SAMPLE if self.masked else SAMPLE | UNMASKED, 4 * t, True,
                     action=traj.action[t], log_prob=traj.log_prob[t], obs=self.scratch_obs, rewards_acc=racc,
                     terminated_acc=tacc, draw_base=self.draw,
                     ext=MX(first=1, value_in=value.data_ptr(), value_stride=value.stride(0), value_out=traj.value[t].data_ptr(),
-                           obs_cast=self.xin.data_ptr(), obs_fmt=fmt))
+                           obs_cast=self.xin.data_ptr(), obs_fmt=fmt, in_fmt=ifmt))
         last = t + 1 == T
         obs_out = self.final_obs if last else traj.obs[t + 1]
         mask_out = self.final_mask if last else traj.legal_action_mask[t + 1]
@@ -177,7 +177,7 @@ class _PolicyRollout:
                 lg, _ = self._forward(is_opp, self.scratch_obs, self.xin)
                 m = SAMPLE if competitive else MODE
             fin = k == 3
-            ext = MX(obs_cast=self.xin.data_ptr(), obs_fmt=fmt)
+            ext = MX(obs_cast=self.xin.data_ptr(), obs_fmt=fmt, in_fmt=self._FMT[lg.dtype])
             if fin:                                                     # G2 / G1 / :85 by the same launch
                 ext.last, ext.done_out, ext.reward_out = 1, traj.done[t].data_ptr(), traj.reward[t].data_ptr()
                 ext.actor, ext.reward_scale, ext.terminated_count = actor.data_ptr(), self.reward_scale, self.tc.data_ptr()

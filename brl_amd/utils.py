@@ -58,7 +58,8 @@ def policy_step(env: BridgeBidding, packed_in, packed_out, logits, mode: int, dr
     ``ext`` (a ``_capi.MacroExt``): the macro-step bookkeeping of src/roll_out.py:72-103 done by the same launch
     (``brl_policy_step_ex``)."""
     n = packed_in.shape[0]
-    logits = logits.to(torch.float32)
+    if ext is None or not ext.in_fmt:
+        logits = logits.to(torch.float32)
     assert logits.shape == (n, NUM_ACTIONS)
     strided = logits.stride(1) == 1 and logits.stride(0) >= NUM_ACTIONS  # e.g. the first 38 columns of a [n,39] matrix
     if not strided:

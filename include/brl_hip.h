@@ -175,7 +175,7 @@ int brl_policy_step_at(brl_handle *h, const uint64_t *state_in, uint64_t *state_
 typedef struct brl_macro_ext {
   int32_t first;             /* != 0: first sub-step of a macro-step: rewards_acc / terminated_acc are OVERWRITTEN */
   int32_t last;              /* != 0: last sub-step: the members below marked (last) are written after accumulation */
-  const float *value_in;     /* value_out[i] = value_in[i * value_stride]: the critic output -> Transition.value[t] (:76) */
+  const void *value_in;      /* value_out[i] = value_in[i * value_stride]: the critic output -> Transition.value[t] (:76) */
   int64_t value_stride;
   float *value_out;
   uint8_t *done_out;         /* (last) [n]  = terminated_acc                                   (src/roll_out.py:85, G2) */
@@ -185,6 +185,9 @@ typedef struct brl_macro_ext {
   int32_t obs_fmt;           /* obs_cast element type: 0 float, 1 bf16, 2 fp16 */
   int64_t *terminated_count; /* (last) [1] += sum_i terminated_acc[i]                           (src/roll_out.py:85) */
   void *obs_cast;            /* [n,480]: the new observation as the next forward's input (`astype`, src/roll_out.py:75) */
+  int32_t in_fmt;            /* element type of `logits` AND value_in as the GEMM wrote them: 0 float, 1 bf16, 2 fp16 (with 1 / 2
+                                the `logits` argument points at 2-byte elements; strides stay in elements) */
+  int32_t reserved;
 } brl_macro_ext;
 
 /* brl_policy_step_at + brl_macro_ext (ext may be NULL). */
