@@ -89,6 +89,8 @@ def lib() -> C.CDLL:
                                _vp, _vp, _vp, _vp, _vp, _vp],
         "brl_eval_step": [_vp, _vp, _vp, i64, _vp, i64, _vp, i64, C.POINTER(TableInfoPtrs), C.POINTER(TableInfoPtrs),
                           C.POINTER(EvalStatsPtrs), i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+        "brl_eval_step_team": [_vp, _vp, _vp, i64, _vp, i64, i32, C.POINTER(TableInfoPtrs), C.POINTER(TableInfoPtrs),
+                               C.POINTER(EvalStatsPtrs), i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
         "brl_eval_reduce": [_vp, i64, C.POINTER(TableInfoPtrs), C.POINTER(TableInfoPtrs), _vp, _vp, _vp, _vp],
         "brl_ppo_loss": [i32, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, i64, f32, f32, f32, i32, i32, _vp, _vp, _vp, _vp, _vp],
         "brl_ppo_stats": [i32, _vp, i64, _vp, f32, f32, _vp, _vp],
@@ -111,7 +113,8 @@ EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_de
            "brl_init_random", "brl_init_from_deals", "brl_step", "brl_observe", "brl_get_fields",
            "brl_rollout_random", "brl_policy_step", "brl_policy_step_at", "brl_obs_cast", "brl_gae", "brl_imp_reward", "brl_duplicate_step",
            "brl_eval_step", "brl_eval_reduce", "brl_ppo_loss", "brl_ppo_stats", "brl_ppo_loss_heads", "brl_mb_gather",
-           "brl_relu_bwd_colsum", "brl_adam_clip", "brl_bias_finalize", "brl_ppo_stats_at", "brl_policy_step_ex"]
+           "brl_relu_bwd_colsum", "brl_adam_clip", "brl_bias_finalize", "brl_ppo_stats_at", "brl_policy_step_ex",
+           "brl_eval_step_team"]
 
 
 def check(rc: int) -> None:

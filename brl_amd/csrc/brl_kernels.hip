@@ -1300,6 +1300,8 @@ struct EvalArgs {
   float *rewards_sum;     // [n,4] += rewards (src/evaluation.py:400; single-table evaluator)
   int32_t *action_out;    // [n] the call made
   StepOut o;
+  int acting_team;        // -1: every board acts (the reference's loop); 0 / 1: only the boards whose turn it is for THAT team
+                          // act, the others wait (finished boards always take their no-op step) — brl_eval_step_team
 };
 
 template <int K>
@@ -1309,6 +1311,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_eval_step(EvalArgs A) {
   Wave<K> w = wave_begin<K>(lds, A.state_in, A.n, t);
   const bool was_term = bits(t.sc, SC_TERM, 1);
   const int team = cur_player(t) >> 1;  // 0: players {0,1}
+  const bool idle = (A.acting_team >= 0) && !was_term && (team != A.acting_team);  // waits for its team's iteration
   const uint64_t legal = legal_mask(t);
   uint32_t bad = 0;
   int a;
@@ -1322,7 +1325,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_eval_step(EvalArgs A) {
     a = categorical<K>(row, 0, 0, w.valid, legal, 1, 0u, w.c.lane, lp);  // masked_pi.mode()
     if (A.S.illegal_prob_sum) mass = illegal_mass<K>(row, w.valid, legal, w.c.lane);
   }
-  if (w.c.lane < K && w.valid && !was_term) {  // make_step_log: finished boards log nothing (src/evaluation.py:736-748)
+  if (w.c.lane < K && w.valid && !was_term && !idle) {  // make_step_log: finished boards log nothing (src/evaluation.py:736-748)
     const int64_t st = w.table * 2 + team;
     if (A.S.illegal_prob_sum) A.S.illegal_prob_sum[st] += mass;
     if (A.S.step_count) A.S.step_count[st] += 1;
@@ -1332,12 +1335,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_eval_step(EvalArgs A) {
       *bc = A.bid_set ? 1 : *bc + 1;
     }
   }
-  int hb = table_step(t, a);  // src/duplicate.py:149
-  if (bad && !was_term) t.sc |= (1u << SC_TERM) | (1u << SC_ILLEGAL) | (1u << SC_MASKALL);
+  int hb = idle ? -1 : table_step(t, a);  // src/duplicate.py:149
+  if (bad && !was_term && !idle) t.sc |= (1u << SC_TERM) | (1u << SC_ILLEGAL) | (1u << SC_MASKALL);
   wave_or_hist<K>(w, hb);
   wave_lds_fence();
   if (A.duplicate) {
-    bool term = bits(t.sc, SC_TERM, 1);
+    bool term = !idle && bits(t.sc, SC_TERM, 1);
     bool a_done = w.valid ? (A.TA.terminated[w.table] != 0) : true;
     bool b_done = w.valid ? (A.TB.terminated[w.table] != 0) : true;
     bool to_b = w.valid && !a_done && term;                // table A just ended -> replay the board seat-swapped
@@ -1357,7 +1360,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_eval_step(EvalArgs A) {
       float4 ar = reinterpret_cast<const float4 *>(A.TA.rewards)[w.table];
       float4 v = imp_vector(ar.x, rw.x);  // src/duplicate.py:157-160
       set_rewards(t, (int)v.x, (int)v.y, (int)v.z, (int)v.w);
-    } else {
+    } else if (!idle) {
       t.r01 = 0;  // src/duplicate.py:162
       t.r23 = 0;
     }
@@ -1379,9 +1382,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_eval_step(EvalArgs A) {
     }
   }
   if (w.c.lane < K && w.valid) {
-    if (A.action_out) A.action_out[w.table] = a;
-    if (A.cum_return) A.cum_return[w.table] += (float)reward_of(t, 0);
-    if (A.rewards_sum) {
+    if (A.action_out) A.action_out[w.table] = idle ? -1 : a;
+    if (A.cum_return && !idle) A.cum_return[w.table] += (float)reward_of(t, 0);
+    if (A.rewards_sum && !idle) {
       float4 *p = reinterpret_cast<float4 *>(A.rewards_sum) + w.table;
       const float4 old = *p, rw = rewards_f32(t);
       *p = make_float4(old.x + rw.x, old.y + rw.y, old.z + rw.z, old.w + rw.w);
@@ -2090,6 +2093,7 @@ extern "C" int brl_duplicate_step(brl_handle *h, const uint64_t *state_in, uint6
   A.state_in = state_in; A.state_out = state_out; A.n = n; A.action = action; A.duplicate = 1;
   A.TA = *table_a; A.TB = *table_b;
   A.o = StepOut{obs, mask, rewards, terminated, current_player};
+  A.acting_team = -1;
   return eval_step_impl(h, A, stream);
 }
 
@@ -2111,6 +2115,30 @@ extern "C" int brl_eval_step(brl_handle *h, const uint64_t *state_in, uint64_t *
   if (stats) A.S = *stats;
   A.bid_set = bid_set; A.cum_return = cum_return; A.rewards_sum = rewards_sum; A.action_out = action_out;
   A.o = StepOut{obs, mask, rewards, terminated, current_player};
+  A.acting_team = -1;
+  return eval_step_impl(h, A, stream);
+}
+
+extern "C" int brl_eval_step_team(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n, const float *logits,
+                                  int64_t stride, int acting_team, const brl_table_info *table_a,
+                                  const brl_table_info *table_b, const brl_eval_stats *stats, int bid_set, float *cum_return,
+                                  float *rewards_sum, int32_t *action_out, uint8_t *obs, uint8_t *mask, float *rewards,
+                                  uint8_t *terminated, int32_t *current_player, void *stream) {
+  COMMON(h, n);
+  NEED(state_in && state_out && logits, "NULL state / logits");
+  NEED(stride >= BRL_NUM_ACTIONS, "logits stride");
+  NEED(acting_team == 0 || acting_team == 1, "acting_team");
+  NEED((table_a == nullptr) == (table_b == nullptr), "table_a and table_b go together");
+  if (table_a) NEED(table_info_ok(table_a) && table_info_ok(table_b), "table_a / table_b has NULL members");
+  EvalArgs A{};
+  A.state_in = state_in; A.state_out = state_out; A.n = n;
+  A.logits1 = logits; A.logits2 = logits; A.stride1 = stride; A.stride2 = stride;
+  A.duplicate = table_a != nullptr;
+  if (table_a) { A.TA = *table_a; A.TB = *table_b; }
+  if (stats) A.S = *stats;
+  A.bid_set = bid_set; A.cum_return = cum_return; A.rewards_sum = rewards_sum; A.action_out = action_out;
+  A.o = StepOut{obs, mask, rewards, terminated, current_player};
+  A.acting_team = acting_team;
   return eval_step_impl(h, A, stream);
 }
 

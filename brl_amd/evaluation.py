@@ -7,7 +7,7 @@
   and ``make_evaluate_log`` (:1035-1115), the flat ``eval/...`` dict ppo.py logs every ``num_eval_step`` iterations.
 * ``make_simple_evaluate`` — the single-table deterministic evaluator of src/evaluation.py:11-66.
 
-Every loop iteration is two (merged) GEMM forwards in PyTorch-ROCm plus ONE ``brl_eval_step`` launch: team selection,
+Every loop iteration is one or two (merged) GEMM forwards in PyTorch-ROCm plus ONE ``brl_eval_step`` launch: team selection,
 masked arg-max, the step log (illegal-action probability mass, step / pass / bid counters), ``duplicate_step`` and the
 return accumulators all happen in that kernel; the end-of-run histograms come from ``brl_eval_reduce`` as exact integer
 counts.  The loop condition ``~state.terminated.all()`` is read back every ``sync_every`` iterations (finished boards
@@ -77,14 +77,34 @@ def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward,
     ps = stats.ptrs() if stats is not None else None
     packed = state.packed
     count = 0
+    # Two different networks: the reference evaluates BOTH on every board and selects by team (src/evaluation.py:146-151);
+    # here the teams take turns — iteration i runs ONE forward (team i & 1's network) and only the boards whose player to
+    # act is on that team make their call (brl_eval_step_team).  Calls are deterministic arg-maxes and a board's teams
+    # alternate call by call, so every board plays exactly the same auction; it waits at most one iteration at its start
+    # and one at the table switch.  Half the GEMM work per board.  (Recording runs — the tests' oracle replays — keep the
+    # reference's lock-step loop.)
+    alternate = (fwd2 is not fwd1) and record_actions is None and record_logits is None
     while True:
         x = obs.to(torch.float32)
+        nobs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=dev)
+        if alternate:
+            team = count & 1
+            lg = (fwd2 if team else fwd1)(obs, x)
+            check(_capi.lib().brl_eval_step_team(
+                env._h, ptr(packed), ptr(packed), n, lg.data_ptr(), lg.stride(0), team,
+                C.byref(pa) if pa is not None else None, C.byref(pb) if pb is not None else None,
+                C.byref(ps) if ps is not None else None, int(bid_set),
+                ptr(cum_return), ptr(rewards_sum), ptr(action), ptr(nobs), None, None, ptr(term), None, _stream()))
+            obs = nobs
+            count += 1
+            if count % sync_every == 0 and bool(term.all()):
+                break
+            continue
         l1 = fwd1(obs, x)
         l2 = fwd2(obs, x) if fwd2 is not fwd1 else l1   # G10: the reference evaluates both networks and selects
         if record_logits is not None:
             team1 = (State(env, packed).current_player < 2)[:, None]
             record_logits.append(torch.where(team1, l1[:, :NUM_ACTIONS], l2[:, :NUM_ACTIONS]).clone())
-        nobs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=dev)
         check(_capi.lib().brl_eval_step(
             env._h, ptr(packed), ptr(packed), n, l1.data_ptr(), l1.stride(0), l2.data_ptr(), l2.stride(0),
             C.byref(pa) if pa is not None else None, C.byref(pb) if pb is not None else None,

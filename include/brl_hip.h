@@ -248,6 +248,18 @@ int brl_eval_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, 
                   int bid_set, float *cum_return, float *rewards_sum, int32_t *action_out, uint8_t *obs,
                   uint8_t *mask, float *rewards, uint8_t *terminated, int32_t *current_player, void *stream);
 
+/* brl_eval_step with ONE network per launch: only the boards whose player to act belongs to `acting_team` (0: players
+ * {0,1}, 1: players {2,3}) take their greedy call from `logits`; the other unfinished boards wait (state, statistics and
+ * accumulators untouched, action_out = -1), finished boards take their no-op step as always.  Alternating the team from
+ * launch to launch plays every board exactly as brl_eval_step does (the calls are deterministic arg-maxes) with ONE forward
+ * per iteration instead of the two the reference evaluates and selects from (src/evaluation.py:146-151): a board's teams
+ * alternate call by call, so it waits at most one launch at its start and one at the table switch. */
+int brl_eval_step_team(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n, const float *logits,
+                       int64_t stride, int acting_team, const brl_table_info *table_a, const brl_table_info *table_b,
+                       const brl_eval_stats *stats, int bid_set, float *cum_return, float *rewards_sum, int32_t *action_out,
+                       uint8_t *obs, uint8_t *mask, float *rewards, uint8_t *terminated, int32_t *current_player,
+                       void *stream);
+
 /* End-of-run histograms behind make_evaluate's log_info — src/evaluation.py:841-1031 (make_terminated_log,
  * make_contract_log) — as exact integer counts.  out: device int64 [BRL_EVAL_COUNTS], zeroed by the call:
  *   out[t*80 + 0] pass-outs at table t (0 = A, 1 = B; table_b may be NULL)

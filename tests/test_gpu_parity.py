@@ -739,6 +739,43 @@ def test_duplicate_evaluate_with_statistics_matches_oracle(env, oracle, n, game_
         assert d["eval/opp_pass_ratio"] == 1.0 and d["eval/opp_illegal_action_probs"] == 0.0
 
 
+@pytest.mark.parametrize("n,game_mode,duplicate", [(640, "competitive", True), (2048, "competitive", True),
+                                                   (300, "free-run", True), (640, "competitive", False)])
+def test_team_alternating_evaluation_equals_lockstep_evaluation(env, n, game_mode, duplicate):
+    """With two different networks the evaluators run ONE forward per iteration and let the teams take turns
+    (brl_eval_step_team); a recording run keeps the reference's lock-step loop (two forwards, every board steps), which
+    the tests above replay through the oracle.  Both must produce the same Table_info snapshots and the same log_info."""
+    from brl_amd.evaluation import make_evaluate, make_simple_duplicate_evaluate
+    from brl_amd.models import make_forward_pass
+    fp = make_forward_pass("relu", "DeepMind")
+    actor, opp = fp.init(3, device="cuda"), fp.init(4, device="cuda")
+    outs = []
+    for rec in (None, []):
+        ev = make_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", opp, n, game_mode=game_mode, duplicate=duplicate,
+                           sync_every=8, record_actions=rec)
+        outs.append(ev(actor, 321))
+    torch.cuda.synchronize()
+    if duplicate:
+        (la, A1, B1), (lb, A2, B2) = outs
+        for T1, T2 in ((A1, A2), (B1, B2)):
+            for f in ("terminated", "rewards", "last_bid", "last_bidder", "call_x", "call_xx"):
+                assert torch.equal(getattr(T1, f), getattr(T2, f)), f
+    else:
+        (_, la), (_, lb) = outs
+    assert len(la) == len(lb)
+    for x, y in zip(la, lb):
+        assert torch.equal(torch.as_tensor(x), torch.as_tensor(y))
+    if duplicate and game_mode == "competitive":   # the simple duplicate evaluator (mean IMP, standard error, win rate)
+        res = []
+        for rec in (None, []):
+            sd = make_simple_duplicate_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", n, record_actions=rec)
+            res.append(sd(actor, opp, 99))
+        for x, y in zip(res[0][0], res[1][0]):
+            assert torch.equal(x, y)
+        for f in ("rewards", "last_bid", "last_bidder"):
+            assert torch.equal(getattr(res[0][2], f), getattr(res[1][2], f))
+
+
 def test_single_table_evaluate_with_statistics_matches_oracle(env, oracle):
     """make_evaluate(duplicate=False) (src/evaluation.py:229-605): 19-entry log_info, rewards accumulated on the state."""
     from brl_amd.evaluation import make_evaluate
