@@ -48,3 +48,16 @@ def broadcast_int(value: int, device=None, src: int = 0) -> int:
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)
     dist.broadcast(t, src=src)
     return int(t.item())
+
+
+def broadcast_parameters(module, src: int = 0) -> None:
+    """rank `src`'s weights on every rank, once at start: the ranks build the same network from the same seed
+    or file already; this makes the invariant explicit before the first all-reduced update."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    with torch.no_grad():
+        for p in module.parameters():
+            dist.broadcast(p.data, src=src)

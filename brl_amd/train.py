@@ -127,7 +127,7 @@ def train(config, log=print):
     import brl_amd
     from brl_amd import checkpoint as ckpt
     from brl_amd.bridge_bidding import load_dds_table
-    from brl_amd.dist import broadcast_int, rank_world, shard_offset, sum_over_ranks
+    from brl_amd.dist import broadcast_int, broadcast_parameters, rank_world, shard_offset, sum_over_ranks
     from brl_amd.evaluation import (make_evaluate, make_evaluate_log, make_simple_duplicate_evaluate,
                                     make_simple_evaluate)
     from brl_amd.models import make_forward_pass
@@ -171,6 +171,7 @@ def train(config, log=print):
     params = actor_fp.init(config["seed"], device=dev)               # same weights on every rank
     if config["load_initial_model"]:                                  # ppo.py:246-248
         params = ckpt.load_params(config["initial_model_path"], config["actor_activation"], config["actor_model_type"], dev)
+    broadcast_parameters(params)                                      # one broadcast at start
     opt_state = make_optimizer(config, params)
 
     def load_opponent(path, activation, model_type):
