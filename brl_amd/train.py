@@ -139,11 +139,15 @@ def train(config, log=print):
 
     rank, world = rank_world()
     if world > 1 and not dist.is_initialized():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        # BRL_DIST_BACKEND=gloo: rehearsal on a box with fewer GPUs than ranks (ranks share the devices round-robin)
+        backend = os.environ.get("BRL_DIST_BACKEND", "nccl")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+        dist.init_process_group(backend)
     dev = torch.device("cuda", torch.cuda.current_device())
     config = dict(DEFAULTS, **config)
-    config["num_updates"] = config["total_timesteps"] // config["num_steps"] // config["num_envs"]     # ppo.py:225-227
+    # ppo.py:225-227; under a process group num_envs is PER RANK (each rank owns its env shard: weak scaling), so an update
+    # consumes world * num_envs * num_steps of the total_timesteps
+    config["num_updates"] = config["total_timesteps"] // config["num_steps"] // (config["num_envs"] * world)
     config["num_minibatches"] = config["num_envs"] * config["num_steps"] // config["minibatch_size"]  # ppo.py:228-230
     host_rng = np.random.RandomState(config["seed"])  # the reference uses numpy's global RNG for the pool / shuffles
 

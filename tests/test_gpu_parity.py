@@ -835,6 +835,40 @@ def test_ppo_loop_runs_end_to_end(env, tmp_path):
         assert torch.equal(a, b)
 
 
+def _train_rank(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), BRL_DIST_BACKEND="gloo")
+    from brl_amd.train import DEFAULTS, train
+    cfg = dict(DEFAULTS, num_envs=256, num_steps=8, total_timesteps=world * 256 * 8 * 3, minibatch_size=512, update_epochs=2,
+               lut_len=2000, synthetic_lut_files=2, hash_size=100_000, num_eval_envs=128, num_prioritized_envs=64,
+               num_eval_step=2, lr=1e-4, ratio_model_zoo=1.0, log_path=out_dir, exp_name="t",   # ONE pool directory: rank 0 saves
+               graph_rollout=True)
+    rs, hist = train(cfg, log=lambda *_: None)
+    flat = torch.cat([p.detach().reshape(-1) for p in rs[0].parameters()]).cpu()
+    torch.save((flat, [h["train/total_loss"] for h in hist], type(rs[1].get("graphed")).__name__,
+                getattr(rs[1].get("graphed"), "world", None)), os.path.join(out_dir, f"rank{rank}.pt"))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ppo_loop_two_ranks(tmp_path):
+    """BASELINE config 5 at toy size: the ppo.py loop on two ranks (own env shard each via env_offset, gradient all-reduce
+    inside FusedMinibatch's bucketed graphs, the pool's opponent index broadcast from rank 0; gloo on this one-GPU box,
+    RCCL on a node): both ranks end with IDENTICAL parameters although their shards differ."""
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mp.start_processes(_train_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert r0[2] == "FusedMinibatch" and r0[3] == 2
+    assert len(r0[1]) == 3 and all(np.isfinite(x) for x in r0[1] + r1[1])
+    assert r0[1] != r1[1]                      # different shards: different losses ...
+    assert torch.equal(r0[0], r1[0])           # ... same parameters (all-reduced gradients)
+
+
 def test_ppo_iteration_at_config3_size(tmp_path):
     """BASELINE.json configs[3] at ITS size: one ppo.py iteration with num_envs=8192, num_steps=32, minibatch 1024,
     10 epochs (2560 minibatch steps), DeepMind MLP, hipGraph rollout + update — finite statistics, every env-step
