@@ -3,7 +3,7 @@
 //
 // Same roles as k_rollout_ws — one workgroup owns 32 consecutive tables; a LOGIC wave runs the per-table dependency chain,
 // a LOADER fetches boards, a SCORER writes the scalar Transition columns, EMIT waves write observations — but NO workgroup
-// barrier inside the launch:
+// barrier between the prologue's and the one before the state write-back:
 //   * the whole launch's commands fit in LDS (one 16-byte command per table and slot, <= 41 slots = 21 KB), so the logic
 //     wave never waits for a follower: it posts slot s and publishes `posted = s + 1` with a plain LDS store (LDS
 //     operations of one wave are performed in order, so a reader that sees the counter sees the commands);
@@ -20,7 +20,9 @@
 // The probe also says HOW to store: fully contiguous 960-byte wave instructions, non-temporal (each instruction writes
 // whole 64-byte pieces, nothing to merge in L2): 25.7 us for the launch's bytes against 30.7 us for 2 x 16 B per lane at a
 // 32-byte stride through L2.  So an emit lane here expands 16 observation bits into ONE 16-byte piece of two rows
-// (rows r and r + 2 of its group: the two instructions cover rows 0-1 and rows 2-3).
+// (rows r and r + 2 of its group: the two instructions cover rows 0-1 and rows 2-3).  Everything else the launch writes
+// (mask rows, scalar columns) goes out write-through (store_wt16): plain stores would leave 15 MB of dirty L2 lines to be
+// written back after the last wave has ended (27.4 -> 25.1 us).
 //
 // Serves substeps == 1, T <= 40, n % 32 == 0 with every Transition column requested (the BASELINE configuration);
 // everything else takes k_rollout_ws / k_rollout_random.  Bit-identical outputs (tests/test_gpu_parity.py).
