@@ -231,8 +231,20 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks):
         gl = float(torch.tensor(1.0 * 0.95, dtype=torch.float32))  # gamma * gae_lambda as ppo.py forms it
         box = {"draw": 0}
 
+        # The step is ONE launch (brl_rollout_random_gae): the rollout kernel's scorer wave also runs calc_gae's reverse scan
+        # over the trajectory it has just written (value == 0 for the random policy; last_val is an input).
+        # BRL_BENCH_FUSED_GAE=0: the two-launch step of earlier rounds (brl_rollout_random, then brl_gae).
+        fused_gae = os.environ.get("BRL_BENCH_FUSED_GAE", "1") != "0" and not overlap
+
         def one_step(i):
             k = i % NBUF
+            if fused_gae:
+                _capi.check(lib.brl_rollout_random_gae(h, packed.data_ptr(), NUM_ENVS, NUM_STEPS, box["draw"] & 0xFFFFFFFF, 7600.0,
+                                                       C.byref(ptrs[k]), last_obs.data_ptr(), last_mask.data_ptr(), tc.data_ptr(),
+                                                       last_val.data_ptr(), 1.0, gl, advs[k].data_ptr(), tgts[k].data_ptr(),
+                                                       main.cuda_stream))
+                box["draw"] += NUM_STEPS
+                return
             if overlap:
                 main.wait_event(gae_done[k])          # buffer k's previous GAE has read it
             _capi.check(lib.brl_rollout_random(h, packed.data_ptr(), NUM_ENVS, NUM_STEPS, 1, box["draw"] & 0xFFFFFFFF, 7600.0,
@@ -263,7 +275,13 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks):
         draw = box["draw"]
         stream = main
 
-        def launch(i):
+        def launch(i):  # the same launch as the step's
+            if fused_gae:
+                _capi.check(lib.brl_rollout_random_gae(h, packed.data_ptr(), NUM_ENVS, NUM_STEPS, (draw + i * NUM_STEPS) & 0xFFFFFFFF,
+                                                       7600.0, C.byref(ptrs[i % NBUF]), last_obs.data_ptr(), last_mask.data_ptr(),
+                                                       tc.data_ptr(), last_val.data_ptr(), 1.0, gl, advs[i % NBUF].data_ptr(),
+                                                       tgts[i % NBUF].data_ptr(), stream.cuda_stream))
+                return
             _capi.check(lib.brl_rollout_random(h, packed.data_ptr(), NUM_ENVS, NUM_STEPS, 1, (draw + i * NUM_STEPS) & 0xFFFFFFFF,
                                                7600.0, C.byref(ptrs[i % NBUF]), last_obs.data_ptr(), last_mask.data_ptr(),
                                                tc.data_ptr(), stream.cuda_stream))
@@ -299,8 +317,12 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks):
         "data": "FAKE (launcher self-test, no compute)" if FAKE else "synthetic",
         "config": {"workload": "configs[1]: num_envs=8192 num_steps=32 random-policy rollout + DDS reward (fused "
                                "kernel) + last_obs + GAE scan", "num_envs_per_gpu": NUM_ENVS, "num_steps": NUM_STEPS,
+                   "launches_per_step": 2 if (FAKE or os.environ.get("BRL_BENCH_FUSED_GAE", "1") == "0"
+                                              or os.environ.get("BRL_BENCH_OVERLAP", "0") == "1") else 1,
                    "lut_len": LUT_LEN, "env_steps_per_macro_step": 1, "transition_buffers_in_rotation": NBUF,
-                   "gae": "second stream, beside the next step's rollout" if os.environ.get("BRL_BENCH_OVERLAP", "0") == "1" else "same stream",
+                   "gae": "second stream, beside the next step's rollout" if os.environ.get("BRL_BENCH_OVERLAP", "0") == "1"
+                   else ("brl_gae, same stream" if os.environ.get("BRL_BENCH_FUSED_GAE", "1") == "0"
+                         else "by the rollout launch's scorer wave (brl_rollout_random_gae)"),
                    "env_offsets": [r * NUM_ENVS for r in range(world)],
                    "parallelism": f"env-shard x{world}, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -78,6 +78,8 @@ def lib() -> C.CDLL:
         "brl_observe": [_vp, _vp, i64, _vp, _vp, _vp, _vp],
         "brl_get_fields": [_vp, _vp, i64, C.POINTER(Fields), _vp],
         "brl_rollout_random": [_vp, _vp, i64, i32, i32, u32, f32, C.POINTER(TransitionPtrs), _vp, _vp, _vp, _vp],
+        "brl_rollout_random_gae": [_vp, _vp, i64, i32, u32, f32, C.POINTER(TransitionPtrs), _vp, _vp, _vp, _vp, f32, f32, _vp, _vp,
+                                   _vp],
         "brl_policy_step": [_vp, _vp, _vp, i64, _vp, i32, u32, i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
         "brl_policy_step_at": [_vp, _vp, _vp, i64, _vp, i64, i32, _vp, u32, i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
         "brl_policy_step_ex": [_vp, _vp, _vp, i64, _vp, i64, i32, _vp, u32, i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -114,7 +116,7 @@ EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_de
            "brl_rollout_random", "brl_policy_step", "brl_policy_step_at", "brl_obs_cast", "brl_gae", "brl_imp_reward", "brl_duplicate_step",
            "brl_eval_step", "brl_eval_reduce", "brl_ppo_loss", "brl_ppo_stats", "brl_ppo_loss_heads", "brl_mb_gather",
            "brl_relu_bwd_colsum", "brl_adam_clip", "brl_bias_finalize", "brl_ppo_stats_at", "brl_policy_step_ex",
-           "brl_eval_step_team"]
+           "brl_eval_step_team", "brl_rollout_random_gae"]
 
 
 def check(rc: int) -> None:

@@ -289,6 +289,11 @@ struct RolloutArgs {
   uint8_t *last_mask;  // [n,38]
   unsigned long long *terminated_count;
   int debug;  // timing experiments only (BRL_DEBUG): 1 = emit waves idle, 2 = loader idle
+  // optional (k_rollout_fs only, brl_rollout_random_gae): calc_gae of THIS trajectory by the same launch — with the random
+  // policy value == 0, so everything the scan of src/gae.py:20-39 needs besides last_val is produced here
+  const float *gae_last_val;
+  float gae_gamma, gae_gamma_lambda;
+  float *gae_adv, *gae_tgt;  // [T,n]; gae_adv == NULL: off
 };
 
 template <int K>
@@ -1935,6 +1940,7 @@ extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int
   A.reward_scale = reward_scale; A.g = rng_of(h); A.env_offset = h->env_offset; A.lut = lut_of(h);
   A.neg_log_n = h->neg_log_n; A.out = *out; A.terminated_count = (unsigned long long *)terminated_count;
   A.last_obs = last_obs; A.last_mask = last_mask;
+  A.gae_last_val = nullptr; A.gae_gamma = 0.0f; A.gae_gamma_lambda = 0.0f; A.gae_adv = nullptr; A.gae_tgt = nullptr;
 #ifdef BRL_TIMING  // experiment switches (some of them change the outputs): timing builds only (scripts/timing.py)
   A.debug = getenv("BRL_DEBUG") ? atoi(getenv("BRL_DEBUG")) : 0;
 #else
@@ -1952,6 +1958,28 @@ extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int
     LAUNCH_K(h, k_rollout_random, n, stream, A);
     return BRL_OK;
   }
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_rollout_random_gae(brl_handle *h, uint64_t *state, int64_t n, int num_steps, uint32_t draw_base,
+                                      float reward_scale, const brl_transition *out, uint8_t *last_obs, uint8_t *last_mask,
+                                      int64_t *terminated_count, const float *last_val, float gamma, float gamma_lambda,
+                                      float *advantages, float *targets, void *stream) {
+  COMMON(h, n);
+  NEED(state && out && last_val && advantages && targets, "state / out / last_val / advantages / targets");
+  NEED(num_steps >= 1 && num_steps <= FS_MAX_TOTAL, "num_steps (1..40)");
+  NEED(n % FS_TPB == 0, "n must be a multiple of 32");
+  NEED(out->obs && out->legal_action_mask && out->done && out->action && out->value && out->reward && out->log_prob,
+       "every Transition column");
+  if (h->lut_len == 0) return fail(BRL_E_NOLUT, "brl_rollout_random_gae auto-resets and needs a LUT%s", "");
+  RolloutArgs A;
+  A.state = state; A.n = n; A.T = num_steps; A.substeps = 1; A.draw_base = draw_base;
+  A.reward_scale = reward_scale; A.g = rng_of(h); A.env_offset = h->env_offset; A.lut = lut_of(h);
+  A.neg_log_n = h->neg_log_n; A.out = *out; A.terminated_count = (unsigned long long *)terminated_count;
+  A.last_obs = last_obs; A.last_mask = last_mask; A.debug = 0;
+  A.gae_last_val = last_val; A.gae_gamma = gamma; A.gae_gamma_lambda = gamma_lambda; A.gae_adv = advantages; A.gae_tgt = targets;
+  hipLaunchKernelGGL(k_rollout_fs, dim3((unsigned)(n / FS_TPB)), dim3(FS_NW * 64), 0, (hipStream_t)stream, A);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

@@ -78,13 +78,15 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
   __shared__ uint32_t udraw[FS_MAX_TOTAL + 4][TPB];
   __shared__ float s_neglog[BRL_NUM_ACTIONS + 2];
   __shared__ __attribute__((aligned(16))) uint32_t raw[FS_MAX_TOTAL + 1][TPB][4];  // logic -> prep (see the logic wave)
-  __shared__ int posted, raw_posted, ring_count;
+  __shared__ int posted, raw_posted, ring_count, gae_ready;
   // emit waves: the packed observation of each table AS SEEN BY each of the four seats (15 dwords: vulnerability nibble,
   // history rotated to that observer, its hand), kept up to date call by call: a row is a copy of one of them
   __shared__ __attribute__((aligned(16))) uint32_t oimg[TPB][4][16];
   __shared__ __attribute__((aligned(16))) uint32_t ev[3 * TPB][4];       // scorer: finished boards of a chunk (<= 3 per table)
   __shared__ __attribute__((aligned(16))) int acc[FS_CHUNK][TPB][4];      // scorer: reward by player id per slot of a chunk
   __shared__ __attribute__((aligned(16))) uint32_t minfo[FS_CHUNK][TPB];  // scorer: actor, action, n_legal, done
+  __shared__ __attribute__((aligned(16))) float g_rew[FS_MAX_TOTAL][TPB];  // scorer, optional GAE: reward / done of every slot
+  __shared__ __attribute__((aligned(16))) float g_done[FS_MAX_TOTAL][TPB];
 
   const int tid = (int)threadIdx.x;
   const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
     posted = 0;
     raw_posted = 0;
     ring_count = 0;
+    gae_ready = 0;
   }
   FS_STAMP(11);  // images built
   __syncthreads();  // images, draws and the two counters are in LDS
@@ -253,6 +256,46 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
       uint2 *p = reinterpret_cast<uint2 *>(img + tl * TABLE_BYTES);
       p[W_SC] = make_uint2(sc, sch);
       p[W_CTR] = make_uint2(lut, bctr);
+    }
+    if (A.gae_adv != nullptr) {
+      // optional: calc_gae of this trajectory (src/gae.py:20-39; the same operations in the same order as k_gae, with the
+      // value column this launch writes: 0).  This wave (highest issue priority) is done ~10 k cycles before the emit waves,
+      // so the scan (lane = table, reverse over the rewards / dones the scorer left in LDS) hides in their tail.
+      const float gae_lv = A.gae_last_val[table0 + lt];
+      while (fs_flag_read(&gae_ready) == 0) __builtin_amdgcn_s_sleep(1);
+      if (c.lane < TPB) {
+        float gae = 0.0f, next_value = gae_lv;
+        for (int t1 = total; t1 > 0; t1 -= 8) {  // blocks of 8 steps: their 16 LDS values are fetched together
+          float rr[8], dd[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const int t = t1 - 1 - k;
+            rr[k] = g_rew[(t >= 0) ? t : 0][lt];
+            dd[k] = g_done[(t >= 0) ? t : 0][lt];
+          }
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const int t = t1 - 1 - k;
+            if (t >= 0) {
+              const float vl = 0.0f, nd = 1.0f - dd[k];
+              const float delta = rr[k] + A.gae_gamma * next_value * nd - vl;  // src/gae.py:28
+              gae = delta + A.gae_gamma_lambda * nd * gae;                      // src/gae.py:29
+              g_rew[t][lt] = gae;                                               // advantages
+              g_done[t][lt] = gae + vl;                                         // targets, src/gae.py:39
+              next_value = vl;
+            }
+          }
+        }
+      }
+      wave_lds_order();
+      // the whole wave writes them: lane l — 4 consecutive tables of step l / 8 (+ 8, 16, ..), 16-byte write-through stores
+      const int q = c.lane >> 3, t4 = 4 * (c.lane & 7);
+      for (int t = q; t < total; t += 8) {
+        const int64_t i = (int64_t)t * A.n + table0 + t4;
+        const float4 a = *reinterpret_cast<const float4 *>(&g_rew[t][t4]), b = *reinterpret_cast<const float4 *>(&g_done[t][t4]);
+        store_wt16(A.gae_adv + i, brl_u32x4{__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w)});
+        store_wt16(A.gae_tgt + i, brl_u32x4{__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), __float_as_uint(b.w)});
+      }
     }
   } else if (wave == NW - 1) {
     // ------------------------------------------------------------------ prep wave: raw -> command, two slots per pass
@@ -330,6 +373,9 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
     // board: contract -> DDS tricks -> score -> reward vector (A4); 3. the scalar Transition columns, 16-byte stores
     const int tl = lt;
     const bool mine = c.lane < TPB;
+    // with the GAE tail the scorer is on the launch's critical path (the reverse scan starts when its LAST slot is done):
+    // it then gets issue priority over the emit wave that shares its SIMD (the emit waves are throttled by HBM anyway)
+    if (A.gae_adv != nullptr) __builtin_amdgcn_s_setprio(2);
     Tbl ts;
     load_scalars(ts, img + tl * TABLE_BYTES);
     uint32_t tcount = 0;
@@ -420,11 +466,17 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
           store_wt16(A.out.reward + rw, brl_u32x4{__float_as_uint(rew[0]), __float_as_uint(rew[1]), __float_as_uint(rew[2]), __float_as_uint(rew[3])});
           store_wt16(A.out.log_prob + rw, brl_u32x4{__float_as_uint(lgp[0]), __float_as_uint(lgp[1]), __float_as_uint(lgp[2]), __float_as_uint(lgp[3])});
           *reinterpret_cast<uint32_t *>(A.out.done + rw) = dn;  // G2 (4-byte pieces: plain; write-through no faster)
+          if (A.gae_adv != nullptr) {  // kept for the scan behind the loop
+            *reinterpret_cast<float4 *>(&g_rew[s - 1 + q][t4]) = make_float4(rew[0], rew[1], rew[2], rew[3]);
+            *reinterpret_cast<float4 *>(&g_done[s - 1 + q][t4]) =
+                make_float4((float)(dn & 1u), (float)((dn >> 8) & 1u), (float)((dn >> 16) & 1u), (float)((dn >> 24) & 1u));
+          }
         }
       }
       wave_lds_order();  // pass 3's reads of acc / minfo precede the next chunk's writes (same-wave LDS order)
       s = c1;
     }
+    if (A.gae_adv != nullptr && c.lane == 0) fs_flag_write(&gae_ready, 1);  // every slot's reward / done is in LDS: the prep wave scans
     set_rewards(ts, last_acc.x, last_acc.y, last_acc.z, last_acc.w);  // rewards of the last macro-step (src/utils.py:126)
     if (A.terminated_count != nullptr) {  // src/roll_out.py:85
       uint32_t v = tcount;

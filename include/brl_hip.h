@@ -144,6 +144,16 @@ int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int num_steps,
                        uint32_t draw_base, float reward_scale, const brl_transition *out,
                        uint8_t *last_obs, uint8_t *last_mask, int64_t *terminated_count, void *stream);
 
+/* brl_rollout_random (substeps 1) + brl_gae of the SAME trajectory in ONE launch: with the random policy the value column
+ * is 0, so the scan of src/gae.py:20-39 needs nothing the launch does not produce itself besides last_val float [n]
+ * (the critic's value of the post-rollout observation: zeros for a policy without a critic).  advantages / targets float
+ * [num_steps,n], bit-identical to brl_gae on the Transition this call writes.  Requires 1 <= num_steps <= 40,
+ * n % 32 == 0 and every Transition column. */
+int brl_rollout_random_gae(brl_handle *h, uint64_t *state, int64_t n, int num_steps, uint32_t draw_base,
+                           float reward_scale, const brl_transition *out, uint8_t *last_obs, uint8_t *last_mask,
+                           int64_t *terminated_count, const float *last_val, float gamma, float gamma_lambda,
+                           float *advantages, float *targets, void *stream);
+
 /* One policy sub-step: masked categorical over `logits` float [n,38] for the current
  * player (mode bit 0 clear: sample, src/roll_out.py:79-81 / src/utils.py:83-85; set: arg-max,
  * src/utils.py:157,174 / src/evaluation.py:135; mode bit 1 set: the UNMASKED categorical of the

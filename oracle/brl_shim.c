@@ -352,3 +352,10 @@ int brl_eval_step_team(brl_handle *h, const uint64_t *si, uint64_t *so, int64_t 
   (void)h; (void)si; (void)so; (void)n; (void)lg; (void)st; (void)team; (void)ta; (void)tb; (void)es; (void)bs; (void)cr; (void)rs; (void)ao; (void)obs; (void)m; (void)rw; (void)tm; (void)cp; (void)s;
   NOT_HERE("brl_eval_step_team");
 }
+int brl_rollout_random_gae(brl_handle *h, uint64_t *state, int64_t n, int T, uint32_t draw_base, float reward_scale,
+                           const brl_transition *out, uint8_t *last_obs, uint8_t *last_mask, int64_t *tc, const float *last_val,
+                           float gamma, float gl, float *adv, float *tgt, void *s) {
+  int rc = brl_rollout_random(h, state, n, T, 1, draw_base, reward_scale, out, last_obs, last_mask, tc, s);
+  if (rc != 0) return rc;
+  return brl_gae(h, out->done, out->value, out->reward, last_val, gamma, gl, T, n, adv, tgt, s);
+}

@@ -28,8 +28,13 @@ for traj in trajs:
 nblk = N // 32
 dump = torch.zeros(nblk * NW * 2 + nblk * NW * 32, dtype=torch.int64, device=env.device)
 lo = torch.empty((N, 480), dtype=torch.bool, device=env.device); lm = torch.empty((N, 38), dtype=torch.bool, device=env.device)
+GAE = os.environ.get("GAE") == "1"   # brl_rollout_random_gae: the prep wave also scans the trajectory (calc_gae)
+lv = torch.zeros(N, device=env.device); adv = torch.empty((T, N), device=env.device); tgt = torch.empty((T, N), device=env.device)
 for i in range(4 * NB + 1):
-    _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, i * T, 7600.0, C.byref(ps[i % NB]), _capi.ptr(lo), _capi.ptr(lm), _capi.ptr(dump), _stream()))
+    if GAE:
+        _capi.check(_capi.lib().brl_rollout_random_gae(env._h, _capi.ptr(st.packed), N, T, i * T, 7600.0, C.byref(ps[i % NB]), _capi.ptr(lo), _capi.ptr(lm), _capi.ptr(dump), _capi.ptr(lv), 1.0, 0.95, _capi.ptr(adv), _capi.ptr(tgt), _stream()))
+    else:
+        _capi.check(_capi.lib().brl_rollout_random(env._h, _capi.ptr(st.packed), N, T, 1, i * T, 7600.0, C.byref(ps[i % NB]), _capi.ptr(lo), _capi.ptr(lm), _capi.ptr(dump), _stream()))
 torch.cuda.synchronize()
 full = dump.cpu().numpy()
 d = full[:nblk * NW * 2].reshape(nblk, NW, 2)

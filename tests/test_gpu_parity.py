@@ -194,6 +194,49 @@ def test_rollout_terminated_count_accumulates(env, oracle):
     assert int(rs[4].item()) == a + b and a > 0
 
 
+@pytest.mark.parametrize("n,T,gamma,lam", [(8192, 32, 1.0, 0.95), (64, 7, 0.99, 0.9), (32, 1, 1.0, 1.0), (2048, 40, 0.97, 0.8)])
+def test_rollout_random_gae_in_one_launch(env, oracle, dds, n, T, gamma, lam):
+    """brl_rollout_random_gae: the Transition of brl_rollout_random AND calc_gae's advantages / targets of that very
+    trajectory from one launch — every column and the final state equal to the two-launch path, advantages / targets
+    bit-identical to brl_gae and to the oracle's scan."""
+    import ctypes as C
+    import brl_amd
+    from brl_amd import _capi
+    from brl_amd.gae import gae_scan
+    from brl_amd.roll_out import alloc_transition
+    e = make_env(dds, 4)
+    dev = e.device
+    rng = np.random.default_rng(n + T)
+    last_val = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(dev)
+    gl = float(torch.tensor(gamma * lam, dtype=torch.float32))
+    outs = []
+    for fused in (False, True):
+        st = e.init(77, num_envs=n)
+        traj = alloc_transition(T, n, dev)
+        p = _capi.TransitionPtrs()
+        for f in _capi.TransitionPtrs._names:
+            setattr(p, f, getattr(traj, f).data_ptr())
+        lo = torch.empty((n, 480), dtype=torch.bool, device=dev); lm = torch.empty((n, 38), dtype=torch.bool, device=dev)
+        tc = torch.zeros(1, dtype=torch.int64, device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+        if fused:
+            adv = torch.empty((T, n), device=dev); tgt = torch.empty((T, n), device=dev)
+            _capi.check(_capi.lib().brl_rollout_random_gae(e._h, st.packed.data_ptr(), n, T, 5, 7600.0, C.byref(p), lo.data_ptr(),
+                                                           lm.data_ptr(), tc.data_ptr(), last_val.data_ptr(), gamma, gl,
+                                                           adv.data_ptr(), tgt.data_ptr(), s))
+        else:
+            _capi.check(_capi.lib().brl_rollout_random(e._h, st.packed.data_ptr(), n, T, 1, 5, 7600.0, C.byref(p), lo.data_ptr(),
+                                                       lm.data_ptr(), tc.data_ptr(), s))
+            adv, tgt = gae_scan(e, traj.done, traj.value, traj.reward, last_val, gamma, lam)
+        torch.cuda.synchronize()
+        outs.append(list(traj) + [lo, lm, tc, st.packed, adv, tgt])
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    want_adv, want_tgt = oracle.gae(to_np(outs[1][0]).astype(np.uint8), to_np(outs[1][2]), to_np(outs[1][3]), to_np(last_val), gamma, lam)
+    assert np.array_equal(to_np(outs[1][-2]), want_adv) and np.array_equal(to_np(outs[1][-1]), want_tgt)
+    assert n * T < 4096 or (bool(outs[1][0].any()) and float(outs[1][-2].abs().max()) > 0)
+
+
 def test_gae_bit_exact(env, oracle):
     from brl_amd.gae import gae_scan
     rng = np.random.default_rng(2)
