@@ -9,7 +9,8 @@
 One "step" = one pass of the hot path over one batch: the T=32-step random-policy rollout of
 num_envs=8192 tables (BASELINE.json configs[1]: ONE fused kernel launch writing the full
 time-major Transition buffer, auto-reset + DDS reward included), the observation of the
-post-rollout state (runner_state's last_obs, written by the same launch) and the GAE(lambda) reverse scan.
+post-rollout state (runner_state's last_obs) and the GAE(lambda) reverse scan over that trajectory — all by the same
+launch (brl_rollout_random_gae; BRL_BENCH_FUSED_GAE=0: brl_rollout_random, then brl_gae, as in earlier rounds).
 Inputs (table states, LUT) are resident in HBM before the timed region; the Transition buffer rotates over
 NBUF = 3 allocations (433 MB > the 256 MB Infinity Cache), so the stores have to reach HBM.  With N > 1 every rank
 runs its own 8192-table shard (weak scaling, no data-path collective — SURVEY §8e); `value` is the whole-job
@@ -231,8 +232,9 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks):
         gl = float(torch.tensor(1.0 * 0.95, dtype=torch.float32))  # gamma * gae_lambda as ppo.py forms it
         box = {"draw": 0}
 
-        # The step is ONE launch (brl_rollout_random_gae): the rollout kernel's scorer wave also runs calc_gae's reverse scan
-        # over the trajectory it has just written (value == 0 for the random policy; last_val is an input).
+        # The step is ONE launch (brl_rollout_random_gae): the rollout kernel also runs calc_gae's reverse scan over the
+        # trajectory it has just written (value == 0 for the random policy; last_val is an input) — on its logic wave, which
+        # is done ~10 k cycles before the emit waves.
         # BRL_BENCH_FUSED_GAE=0: the two-launch step of earlier rounds (brl_rollout_random, then brl_gae).
         fused_gae = os.environ.get("BRL_BENCH_FUSED_GAE", "1") != "0" and not overlap
 
@@ -322,7 +324,7 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks):
                    "lut_len": LUT_LEN, "env_steps_per_macro_step": 1, "transition_buffers_in_rotation": NBUF,
                    "gae": "second stream, beside the next step's rollout" if os.environ.get("BRL_BENCH_OVERLAP", "0") == "1"
                    else ("brl_gae, same stream" if os.environ.get("BRL_BENCH_FUSED_GAE", "1") == "0"
-                         else "by the rollout launch's scorer wave (brl_rollout_random_gae)"),
+                         else "inside the rollout launch: its logic wave scans the trajectory once the scorer is done (brl_rollout_random_gae)"),
                    "env_offsets": [r * NUM_ENVS for r in range(world)],
                    "parallelism": f"env-shard x{world}, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -334,7 +336,8 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks):
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "obs_path": {"bytes_per_launch": OBS_BYTES * rows, "achieved": achieved_obs,
                                   "frac": achieved_obs / HBM_PEAK_GBS},
-                     "not_counted_bytes_per_launch": LAST_ROW_BYTES * NUM_ENVS + 2 * 128 * NUM_ENVS},
+                     "not_counted_bytes_per_launch": LAST_ROW_BYTES * NUM_ENVS + 2 * 128 * NUM_ENVS
+                                                     + (8 * rows if (not FAKE and fused_gae) else 0)},  # + advantages / targets
     }
     if rank == 0:
         out["cpu_baseline"] = cpu_baseline(keys, values) if (world == 1 and not args.no_cpu_baseline and not FAKE) else None
