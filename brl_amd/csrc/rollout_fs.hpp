@@ -443,11 +443,11 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
       if (mine) last_acc = *reinterpret_cast<const int4 *>(&acc[m - 1][tl][0]);
       {
         const int q = c.lane >> 3, t4 = 4 * (c.lane & 7);
+        float rew[4] = {0.f, 0.f, 0.f, 0.f}, lgp[4] = {0.f, 0.f, 0.f, 0.f};
+        uint32_t act[4] = {0u, 0u, 0u, 0u}, dn = 0;
         if (q < m) {
           const uint4 info4 = *reinterpret_cast<const uint4 *>(&minfo[q][t4]);
           const uint32_t inf[4] = {info4.x, info4.y, info4.z, info4.w};
-          float rew[4], lgp[4];
-          uint32_t act[4], dn = 0;
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const int4 r = *reinterpret_cast<const int4 *>(&acc[q][t4 + k][0]);
@@ -460,23 +460,27 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
             dn |= done << (8 * k);
             tcount += done;
           }
+          if (A.gae_adv != nullptr) {  // kept for the scan behind the loop — and BEFORE the column stores: the scan of the
+                                       // logic wave (gae_ready, below) starts when the last slot's reward is in LDS
+            *reinterpret_cast<float4 *>(&g_rew[s - 1 + q][t4]) = make_float4(rew[0], rew[1], rew[2], rew[3]);
+            *reinterpret_cast<float4 *>(&g_done[s - 1 + q][t4]) =
+                make_float4((float)(dn & 1u), (float)((dn >> 8) & 1u), (float)((dn >> 16) & 1u), (float)((dn >> 24) & 1u));
+          }
+        }
+        if (A.gae_adv != nullptr && c1 > total && c.lane == 0) fs_flag_write(&gae_ready, 1);  // every slot's reward / done is in LDS
+        if (q < m) {
           const int64_t rw = (int64_t)(s - 1 + q) * A.n + table0 + t4;
           store_wt16(A.out.action + rw, brl_u32x4{act[0], act[1], act[2], act[3]});
           store_wt16(A.out.value + rw, brl_u32x4{0u, 0u, 0u, 0u});
           store_wt16(A.out.reward + rw, brl_u32x4{__float_as_uint(rew[0]), __float_as_uint(rew[1]), __float_as_uint(rew[2]), __float_as_uint(rew[3])});
           store_wt16(A.out.log_prob + rw, brl_u32x4{__float_as_uint(lgp[0]), __float_as_uint(lgp[1]), __float_as_uint(lgp[2]), __float_as_uint(lgp[3])});
           *reinterpret_cast<uint32_t *>(A.out.done + rw) = dn;  // G2 (4-byte pieces: plain; write-through no faster)
-          if (A.gae_adv != nullptr) {  // kept for the scan behind the loop
-            *reinterpret_cast<float4 *>(&g_rew[s - 1 + q][t4]) = make_float4(rew[0], rew[1], rew[2], rew[3]);
-            *reinterpret_cast<float4 *>(&g_done[s - 1 + q][t4]) =
-                make_float4((float)(dn & 1u), (float)((dn >> 8) & 1u), (float)((dn >> 16) & 1u), (float)((dn >> 24) & 1u));
-          }
         }
       }
       wave_lds_order();  // pass 3's reads of acc / minfo precede the next chunk's writes (same-wave LDS order)
       s = c1;
     }
-    if (A.gae_adv != nullptr && c.lane == 0) fs_flag_write(&gae_ready, 1);  // every slot's reward / done is in LDS: the prep wave scans
+    if (A.gae_adv != nullptr && total == 0 && c.lane == 0) fs_flag_write(&gae_ready, 1);  // (nothing to scan)
     set_rewards(ts, last_acc.x, last_acc.y, last_acc.z, last_acc.w);  // rewards of the last macro-step (src/utils.py:126)
     if (A.terminated_count != nullptr) {  // src/roll_out.py:85
       uint32_t v = tcount;
