@@ -13,7 +13,11 @@
 //     then turns into the wave that writes the legal-mask rows;
 //   * the logic wave runs nothing but the chain (draw -> call -> scalars, ~90 instructions per sub-step): what the
 //     followers need besides (legal mask, n_legal, history bit, observer seat) is recomputed from its raw posts by a
-//     PREP wave, two slots per pass.
+//     PREP wave, two slots per pass;
+//   * scoring is split by what is serial: SCORER A (lane = table) follows the commands slot by slot (first denominations,
+//     who acted, which boards ended) and queues the finished boards; SCORER B scores them one lane per board and writes
+//     the scalar columns 8 slots at a time.  B is done ~6 k cycles after the logic wave, so the optional calc_gae scan
+//     (brl_rollout_random_gae: on the logic wave, once B has every slot's reward in LDS) ends before the emit waves do.
 // Why (profiles/r02/r02_rollout_experiments.txt §5): with the output going to HBM the launch is  T = (time until the
 // stores start and are never starved) + (store time of 140 MB).  A store-only probe paced like this hand-off
 // (scripts/micro/store_test4.hip) needs 24-25 us; paced like k_rollout_ws's batches (1,3,4,8,8,..) 29-31 us.
@@ -29,7 +33,7 @@
 #pragma once
 
 constexpr int FS_TPB = 32;
-constexpr int FS_NW = 12;          // logic, loader/mask, scorer, 8 emit, prep
+constexpr int FS_NW = 13;          // logic, loader/mask, scorer A, 8 emit, scorer B, prep
 constexpr int FS_MAX_TOTAL = 40;   // sub-steps per launch
 constexpr int FS_RING = 12;
 constexpr int FS_CHUNK = 8;        // scorer: slots per pass
@@ -82,15 +86,18 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
   // emit waves: the packed observation of each table AS SEEN BY each of the four seats (15 dwords: vulnerability nibble,
   // history rotated to that observer, its hand), kept up to date call by call: a row is a copy of one of them
   __shared__ __attribute__((aligned(16))) uint32_t oimg[TPB][4][16];
-  __shared__ __attribute__((aligned(16))) uint32_t ev[3 * TPB][4];       // scorer: finished boards of a chunk (<= 3 per table)
-  __shared__ __attribute__((aligned(16))) int acc[FS_CHUNK][TPB][4];      // scorer: reward by player id per slot of a chunk
-  __shared__ __attribute__((aligned(16))) uint32_t minfo[FS_CHUNK][TPB];  // scorer: actor, action, n_legal, done
-  __shared__ __attribute__((aligned(16))) float g_rew[FS_MAX_TOTAL][TPB];  // scorer, optional GAE: reward / done of every slot
-  __shared__ __attribute__((aligned(16))) float g_done[FS_MAX_TOTAL][TPB];
+  // scorer A -> scorer B: the launch's finished boards in slot order (<= 11 per table), per-slot info (actor, action,
+  // n_legal, done), and B's results: reward of the acting player per slot and table (zero unless a board ended there)
+  __shared__ __attribute__((aligned(16))) uint32_t evq[FS_RING * TPB][4];
+  __shared__ __attribute__((aligned(16))) uint32_t minfo[FS_MAX_TOTAL][TPB];
+  __shared__ __attribute__((aligned(16))) float frew[FS_MAX_TOTAL][TPB];
+  __shared__ __attribute__((aligned(16))) float g_tgt[FS_MAX_TOTAL][TPB];   // optional GAE tail: targets (advantages go into frew)
+  __shared__ __attribute__((aligned(16))) uint32_t last_rw[TPB][4];  // final (fd, ring entry) from A; rewards words of a board that ended in the LAST slot
+  __shared__ int scored, ev_count;
 
   const int tid = (int)threadIdx.x;
   const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // hardware wave w runs on SIMD w % 4: SIMD 3 hosts only two waves, the scorer takes hardware wave 3 there
+  // hardware wave w runs on SIMD w % 4: scorer A takes hardware wave 3 (the SIMD of two emit waves and scorer B)
   const int wave = (hw_wave == 2) ? 3 : ((hw_wave == 3) ? 2 : hw_wave);
   const LaneConst c = make_lane_const();
 #ifdef BRL_TIMING  // stamps go straight to the dump area behind the per-wave summary (terminated_count doubles as dump buffer)
@@ -189,11 +196,15 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
       oimg[t][o][q] = v;
     }
   }
+  for (int i = tid; i < FS_MAX_TOTAL * TPB; i += NW * 64) (&frew[0][0])[i] = 0.0f;
+  if (tid < TPB * 4) (&last_rw[0][0])[tid] = 0u;
   if (tid == 0) {
     posted = 0;
     raw_posted = 0;
     ring_count = 0;
     gae_ready = 0;
+    scored = 0;
+    ev_count = 0;
   }
   FS_STAMP(11);  // images built
   __syncthreads();  // images, draws and the two counters are in LDS
@@ -270,8 +281,8 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
 #pragma unroll
           for (int k = 0; k < 8; k++) {
             const int t = t1 - 1 - k;
-            rr[k] = g_rew[(t >= 0) ? t : 0][lt];
-            dd[k] = g_done[(t >= 0) ? t : 0][lt];
+            rr[k] = frew[(t >= 0) ? t : 0][lt];
+            dd[k] = (float)((minfo[(t >= 0) ? t : 0][lt] >> 14) & 1u);
           }
 #pragma unroll
           for (int k = 0; k < 8; k++) {
@@ -280,8 +291,8 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
               const float vl = 0.0f, nd = 1.0f - dd[k];
               const float delta = rr[k] + A.gae_gamma * next_value * nd - vl;  // src/gae.py:28
               gae = delta + A.gae_gamma_lambda * nd * gae;                      // src/gae.py:29
-              g_rew[t][lt] = gae;                                               // advantages
-              g_done[t][lt] = gae + vl;                                         // targets, src/gae.py:39
+              frew[t][lt] = gae;                                                // advantages (the reward column is written)
+              g_tgt[t][lt] = gae + vl;                                          // targets, src/gae.py:39
               next_value = vl;
             }
           }
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
       const int q = c.lane >> 3, t4 = 4 * (c.lane & 7);
       for (int t = q; t < total; t += 8) {
         const int64_t i = (int64_t)t * A.n + table0 + t4;
-        const float4 a = *reinterpret_cast<const float4 *>(&g_rew[t][t4]), b = *reinterpret_cast<const float4 *>(&g_done[t][t4]);
+        const float4 a = *reinterpret_cast<const float4 *>(&frew[t][t4]), b = *reinterpret_cast<const float4 *>(&g_tgt[t][t4]);
         store_wt16(A.gae_adv + i, brl_u32x4{__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w)});
         store_wt16(A.gae_tgt + i, brl_u32x4{__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), __float_as_uint(b.w)});
       }
@@ -368,62 +379,71 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
       }
     }
   } else if (wave == 2) {
-    // ------------------------------------------------------------------ scorer wave: lane = table (lanes 32..63 idle in
-    // pass 1); chunks of <= 8 posted slots: 1. first denominations, queue finished boards; 2. one lane per finished
-    // board: contract -> DDS tricks -> score -> reward vector (A4); 3. the scalar Transition columns, 16-byte stores
+    // ------------------------------------------------------------------ scorer A: lane = table (lanes 32..63 idle).  The
+    // part of the scoring that is SERIAL per table: first denominations, who acted, which boards ended (queued for
+    // scorer B with the scalars they ended on), which ring entry a table plays.  ~500 cycles per slot: it stays right behind
+    // the commands.  Publishes ev_count, then scored (slots done).
     const int tl = lt;
     const bool mine = c.lane < TPB;
-    // with the GAE tail the scorer is on the launch's critical path (the reverse scan starts when its LAST slot is done):
-    // it then gets issue priority over the emit wave that shares its SIMD (the emit waves are throttled by HBM anyway)
-    if (A.gae_adv != nullptr) __builtin_amdgcn_s_setprio(2);
     Tbl ts;
     load_scalars(ts, img + tl * TABLE_BYTES);
-    uint32_t tcount = 0;
     uint32_t vslot = NO_SLOT;  // ring slot of the table's current board; NO_SLOT: the board it came in with
-    int4 last_acc = make_int4(reward_of(ts, 0), reward_of(ts, 1), reward_of(ts, 2), reward_of(ts, 3));
-    int avail = 0;
-    int s = 1;  // slot s describes sub-step s - 1 = macro-step s - 1
-    while (s <= total) {
-      fs_wait(&posted, s, avail);
-      const int c1 = (avail < s + FS_CHUNK) ? avail : s + FS_CHUNK;  // slots [s, c1)
-      const int m = c1 - s;
-      // ---- pass 1
-      int nev = 0;
-      uint4 wn = *reinterpret_cast<const uint4 *>(&cmd[s][tl][0]);
-      for (int j = 0; j < m; j++) {
-        const uint4 w = wn;
-        wn = *reinterpret_cast<const uint4 *>(&cmd[(j + 1 < m) ? s + j + 1 : s + j][tl][0]);
-        const int a = (int)((w.w >> 8) & 63u);
-        const int seat = (int)((w.x >> 21) & 3u);
-        ts.sc = w.y;
-        // the acting player (src/roll_out.py:72), its action, n_legal
-        uint32_t info = (uint32_t)player_at(ts, seat) | ((uint32_t)a << 2) | (((w.x >> 23) & 63u) << 8);
-        note_first_denomination(ts.fd, seat, a);
-        const bool fin = mine && bits(ts.sc, SC_TERM, 1);
-        const uint64_t fm = __ballot(fin);
-        if (fm) {  // queue the finished boards, compacted over the tables: one lane per board in pass 2
-          if (fin) {
-            const int pos = nev + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
-            *reinterpret_cast<uint4 *>(&ev[pos][0]) = make_uint4(ts.sc, ts.fd, (uint32_t)j | ((uint32_t)tl << 8), vslot);
-            info |= 1u << 14;  // done (G2)
-          }
-          nev += __popcll(fm);
-        }
-        const bool dealt = (w.x & 0x200u) != 0u;  // re-dealt: no strain named yet; DDS values stay in the ring entry
-        vslot = dealt ? ((w.x >> 16) & 15u) : vslot;
-        ts.fd = dealt ? 0u : ts.fd;
-        if (mine) {
-          minfo[j][tl] = info;
-          *reinterpret_cast<int4 *>(&acc[j][tl][0]) = make_int4(0, 0, 0, 0);
-        }
+    int avail = 0, nev = 0;
+    uint4 wn = make_uint4(0u, 0u, 0u, 0u);
+    for (int s = 1; s <= total; s++) {  // slot s describes sub-step s - 1 = macro-step s - 1
+      if (s >= avail) {
+        fs_wait(&posted, s, avail);
+        wn = *reinterpret_cast<const uint4 *>(&cmd[s][tl][0]);
       }
-      // ---- pass 2
-      wave_lds_order();
-      for (int e0 = 0; e0 < nev; e0 += 64) {
+      const uint4 w = wn;
+      if (s + 1 < avail) wn = *reinterpret_cast<const uint4 *>(&cmd[s + 1][tl][0]);  // (uniform) next command, off the chain
+      const int a = (int)((w.w >> 8) & 63u);
+      const int seat = (int)((w.x >> 21) & 3u);
+      ts.sc = w.y;
+      // the acting player (src/roll_out.py:72), its action, n_legal
+      uint32_t info = (uint32_t)player_at(ts, seat) | ((uint32_t)a << 2) | (((w.x >> 23) & 63u) << 8);
+      note_first_denomination(ts.fd, seat, a);
+      const bool fin = mine && bits(ts.sc, SC_TERM, 1);
+      const uint64_t fm = __ballot(fin);
+      if (fm) {  // queue the finished boards, compacted over the tables: one lane per board in scorer B
+        if (fin) {
+          const int pos = nev + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+          *reinterpret_cast<uint4 *>(&evq[pos][0]) = make_uint4(ts.sc, ts.fd, (uint32_t)(s - 1) | ((uint32_t)tl << 8), vslot);
+          info |= 1u << 14;  // done (G2)
+        }
+        nev += __popcll(fm);
+      }
+      const bool dealt = (w.x & 0x200u) != 0u;  // re-dealt: no strain named yet; DDS values stay in the ring entry
+      vslot = dealt ? ((w.x >> 16) & 15u) : vslot;
+      ts.fd = dealt ? 0u : ts.fd;
+      if (mine) {
+        minfo[s - 1][tl] = info;
+        if (s == total) *reinterpret_cast<uint2 *>(&last_rw[tl][0]) = make_uint2(ts.fd, vslot);  // for B's write-back
+      }
+      if (c.lane == 0) {
+        fs_flag_write(&ev_count, nev);
+        fs_flag_write(&scored, s);
+      }
+      if ((s & 7) == 0) FS_STAMP(s >> 3);
+    }
+  } else if (wave == 11) {
+    // ------------------------------------------------------------------ scorer B: what is PARALLEL — one lane per finished
+    // board: contract -> DDS tricks -> score -> reward of the acting player (A4, G1) into frew[slot][table]; then the scalar
+    // Transition columns of up to 8 slots, 16-byte write-through stores (lane l: 4 consecutive tables of slot l / 8).
+    // A chunk costs ~3 k cycles whatever its length, so this wave is the one that runs in chunks.
+    const int tl = lt;
+    uint32_t tcount = 0;
+    int b0 = 0, seen = 0, ev_done = 0;  // slots [0, b0) written; scorer A's counters as last read
+    while (b0 < total) {
+      fs_wait(&scored, b0, seen);
+      const int evs = fs_flag_read(&ev_count);  // (read AFTER scored: every board that ended in a slot < seen is queued)
+      const int c1 = (seen < b0 + FS_CHUNK) ? seen : b0 + FS_CHUNK;  // slots [b0, c1)
+      const int m = c1 - b0;
+      for (int e0 = ev_done; e0 < evs; e0 += 64) {
         const int e = e0 + c.lane;
-        if (e < nev) {
-          const uint4 q = *reinterpret_cast<const uint4 *>(&ev[e][0]);
-          const uint32_t tt = (q.z >> 8) & 63u;
+        if (e < evs) {
+          const uint4 q = *reinterpret_cast<const uint4 *>(&evq[e][0]);
+          const uint32_t tt = (q.z >> 8) & 63u, sl = q.z & 0xFFu;
           Tbl tb;
           tb.sc = q.x; tb.fd = q.y;
           if (q.w != NO_SLOT) {  // a board dealt in this launch: DDS values from its ring entry
@@ -435,53 +455,43 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
             tb.t0 = tr.x; tb.t1 = tr.y; tb.t2 = fdw.y;
           }
           terminal_reward(tb);  // A4
-          *reinterpret_cast<int4 *>(&acc[q.z & 7u][tt][0]) = make_int4(reward_of(tb, 0), reward_of(tb, 1), reward_of(tb, 2), reward_of(tb, 3));
+          const int actor = (int)(minfo[sl][tt] & 3u);
+          frew[sl][tt] = (float)reward_of(tb, actor) / A.reward_scale;  // G1, src/roll_out.py:90
+          if ((int)sl == total - 1) *reinterpret_cast<uint2 *>(&last_rw[tt][2]) = make_uint2(tb.r01, tb.r23);
         }
       }
-      // ---- pass 3: lane l writes 4 consecutive tables of slot s + l / 8: one 16-byte store per lane and float column
+      ev_done = evs;
       wave_lds_order();
-      if (mine) last_acc = *reinterpret_cast<const int4 *>(&acc[m - 1][tl][0]);
       {
         const int q = c.lane >> 3, t4 = 4 * (c.lane & 7);
-        float rew[4] = {0.f, 0.f, 0.f, 0.f}, lgp[4] = {0.f, 0.f, 0.f, 0.f};
-        uint32_t act[4] = {0u, 0u, 0u, 0u}, dn = 0;
         if (q < m) {
-          const uint4 info4 = *reinterpret_cast<const uint4 *>(&minfo[q][t4]);
+          const uint4 info4 = *reinterpret_cast<const uint4 *>(&minfo[b0 + q][t4]);
           const uint32_t inf[4] = {info4.x, info4.y, info4.z, info4.w};
+          const float4 rew = *reinterpret_cast<const float4 *>(&frew[b0 + q][t4]);
+          float lgp[4];
+          uint32_t act[4], dn = 0;
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            const int4 r = *reinterpret_cast<const int4 *>(&acc[q][t4 + k][0]);
-            const int actor = (int)(inf[k] & 3u);
-            const int ra = (actor == 0) ? r.x : ((actor == 1) ? r.y : ((actor == 2) ? r.z : r.w));
-            rew[k] = (float)ra / A.reward_scale;  // G1, src/roll_out.py:90
             lgp[k] = s_neglog[(inf[k] >> 8) & 63u];
             act[k] = (inf[k] >> 2) & 63u;
             const uint32_t done = (inf[k] >> 14) & 1u;
             dn |= done << (8 * k);
             tcount += done;
           }
-          if (A.gae_adv != nullptr) {  // kept for the scan behind the loop — and BEFORE the column stores: the scan of the
-                                       // logic wave (gae_ready, below) starts when the last slot's reward is in LDS
-            *reinterpret_cast<float4 *>(&g_rew[s - 1 + q][t4]) = make_float4(rew[0], rew[1], rew[2], rew[3]);
-            *reinterpret_cast<float4 *>(&g_done[s - 1 + q][t4]) =
-                make_float4((float)(dn & 1u), (float)((dn >> 8) & 1u), (float)((dn >> 16) & 1u), (float)((dn >> 24) & 1u));
-          }
-        }
-        if (A.gae_adv != nullptr && c1 > total && c.lane == 0) fs_flag_write(&gae_ready, 1);  // every slot's reward / done is in LDS
-        if (q < m) {
-          const int64_t rw = (int64_t)(s - 1 + q) * A.n + table0 + t4;
+          const int64_t rw = (int64_t)(b0 + q) * A.n + table0 + t4;
           store_wt16(A.out.action + rw, brl_u32x4{act[0], act[1], act[2], act[3]});
           store_wt16(A.out.value + rw, brl_u32x4{0u, 0u, 0u, 0u});
-          store_wt16(A.out.reward + rw, brl_u32x4{__float_as_uint(rew[0]), __float_as_uint(rew[1]), __float_as_uint(rew[2]), __float_as_uint(rew[3])});
+          store_wt16(A.out.reward + rw, brl_u32x4{__float_as_uint(rew.x), __float_as_uint(rew.y), __float_as_uint(rew.z), __float_as_uint(rew.w)});
           store_wt16(A.out.log_prob + rw, brl_u32x4{__float_as_uint(lgp[0]), __float_as_uint(lgp[1]), __float_as_uint(lgp[2]), __float_as_uint(lgp[3])});
           *reinterpret_cast<uint32_t *>(A.out.done + rw) = dn;  // G2 (4-byte pieces: plain; write-through no faster)
         }
       }
-      wave_lds_order();  // pass 3's reads of acc / minfo precede the next chunk's writes (same-wave LDS order)
-      s = c1;
+      b0 = c1;
+      if ((b0 & 7) == 0) FS_STAMP(b0 >> 3);
+      // (frew of every slot < b0 is final: a board that ended in slot sl was queued before `scored` passed sl)
+      if (A.gae_adv != nullptr && b0 == total && c.lane == 0) fs_flag_write(&gae_ready, 1);
     }
     if (A.gae_adv != nullptr && total == 0 && c.lane == 0) fs_flag_write(&gae_ready, 1);  // (nothing to scan)
-    set_rewards(ts, last_acc.x, last_acc.y, last_acc.z, last_acc.w);  // rewards of the last macro-step (src/utils.py:126)
     if (A.terminated_count != nullptr) {  // src/roll_out.py:85
       uint32_t v = tcount;
 #pragma unroll
@@ -490,15 +500,21 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
       if (c.lane == 0 && v) atomicAdd(A.terminated_count, (unsigned long long)v);
 #endif
     }
-    if (mine) {
-      if (vslot != NO_SLOT) {
-        const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tl][vslot][8]);
-        pack_tricks(ts, vv.x, vv.y, vv.z, vv.w);
-      }
+    if (total > 0 && c.lane < TPB) {
+      // scalar words of the table's final state: first denominations and the DDS values of its current board (scorer A
+      // left fd and the ring entry), rewards of the last macro-step (src/utils.py:126): its board's, or zero
+      const uint4 f = *reinterpret_cast<const uint4 *>(&last_rw[tl][0]);
       uint2 *p = reinterpret_cast<uint2 *>(img + tl * TABLE_BYTES);
-      p[W_FD] = make_uint2(ts.fd, ts.t2);
-      p[W_TR] = make_uint2(ts.t0, ts.t1);
-      p[W_REW] = make_uint2(ts.r01, ts.r23);
+      if (f.y != NO_SLOT) {
+        Tbl tb;
+        const uint4 vv = *reinterpret_cast<const uint4 *>(&ring[tl][f.y][8]);
+        pack_tricks(tb, vv.x, vv.y, vv.z, vv.w);
+        p[W_FD] = make_uint2(f.x, tb.t2);
+        p[W_TR] = make_uint2(tb.t0, tb.t1);
+      } else {
+        p[W_FD] = make_uint2(f.x, p[W_FD].y);
+      }
+      p[W_REW] = make_uint2(f.z, f.w);
     }
   } else {
     // ------------------------------------------------------------------ emit waves: wave 3 + g owns tables 4 g .. 4 g + 3

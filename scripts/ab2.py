@@ -63,7 +63,22 @@ for rep in range(3):  # the bench's step: rollout + GAE alternating, 128 steps p
         launch(2000 + rep * 128 + i); tb = trajs[i % NB]; gae_scan(env, tb.done, tb.value, tb.reward, lv, 1.0, 0.95)
     e1.record(s); torch.cuda.synchronize()
     mix.append(e0.elapsed_time(e1) / 128 * 1e3)
-print(json.dumps({"us": round(float(np.median(ts)), 2), "min": round(min(ts), 2), "iso": round(float(np.median(iso)), 2),
+fus = []
+if hasattr(_capi.lib(), "brl_rollout_random_gae"):  # the bench's step as ONE launch (rollout + calc_gae's scan)
+    advs = [torch.empty((T, N), dtype=torch.float32, device=env.device) for _ in range(NB)]; tgts = [torch.empty_like(a) for a in advs]
+    def launch_gae(i):
+        _capi.check(_capi.lib().brl_rollout_random_gae(env._h, st.packed.data_ptr(), N, T, (i * T) & 0xFFFFFFFF, 7600.0, C.byref(ptrs[i % NB]),
+                                                       lo.data_ptr(), lm.data_ptr(), tc.data_ptr(), lv.data_ptr(), 1.0, 0.95,
+                                                       advs[i % NB].data_ptr(), tgts[i % NB].data_ptr(), s.cuda_stream))
+    for i in range(10): launch_gae(3000 + i)
+    for rep in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record(s)
+        for i in range(128): launch_gae(3010 + rep * 128 + i)
+        e1.record(s); torch.cuda.synchronize()
+        fus.append(e0.elapsed_time(e1) / 128 * 1e3)
+    h.update(advs[0].cpu().numpy().tobytes()); h.update(tgts[0].cpu().numpy().tobytes())
+print(json.dumps({"fused": round(float(np.median(fus)), 2) if fus else None, "us": round(float(np.median(ts)), 2), "min": round(min(ts), 2), "iso": round(float(np.median(iso)), 2),
                   "step": round(float(np.median(mix)), 2), "sha": h.hexdigest()[:12]}))
 '''
 
@@ -89,12 +104,12 @@ def main():
                 r = subprocess.run(["timeout", "-k", "5", "90", sys.executable, "-c", code], capture_output=True, text=True, env=envv)
                 try:
                     d = json.loads(r.stdout.strip().splitlines()[-1])
-                    res[name].append(d["us"]); sha[name] = d["sha"]; extra.setdefault(name, []).append((d["iso"], d["step"]))
+                    res[name].append(d["us"]); sha[name] = d["sha"]; extra.setdefault(name, []).append((d["iso"], d["step"], d.get("fused")))
                 except Exception:
                     print(name, "FAILED", r.stderr[-800:])
         base = sha.get(variants[0][0])
         for name, _ in variants:
             v = sorted(res[name])
-            print(f"{name:14s} median {v[len(v)//2] if v else None}  all {v}  isolated/step(rollout+gae) {extra.get(name)}  {'same-bytes' if sha.get(name) == base else 'DIFFERENT OUTPUT'}")
+            print(f"{name:14s} median {v[len(v)//2] if v else None}  all {v}  isolated / step(rollout+gae) / one-launch step {extra.get(name)}  {'same-bytes' if sha.get(name) == base else 'DIFFERENT OUTPUT'}")
 
 main()
