@@ -97,8 +97,14 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
 
   const int tid = (int)threadIdx.x;
   const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // hardware wave w runs on SIMD w % 4: scorer A takes hardware wave 3 (the SIMD of two emit waves and scorer B)
-  const int wave = (hw_wave == 2) ? 3 : ((hw_wave == 3) ? 2 : hw_wave);
+  // Hardware wave w runs on SIMD w % 4, and within a SIMD the older wave wins the issue arbitration.  SIMD 0 (hardware
+  // waves 0, 4, 8, 12) hosts the logic wave and the three light followers (prep, scorer A, scorer B): an emit wave there lost
+  // ~15 % of its pace to the logic wave (priority 3) and ended 5-8 k cycles after the others.  Loader / mask = hardware
+  // wave 3 (it must start early); the 8 emit waves are 3 + 3 + 2 on SIMDs 1, 2, 3.
+  //                                  hw: 0  1  2  3  4   5  6  7  8  9  10 11  12
+  constexpr uint64_t ROLE_OF_HW = 0x0ull | (3ull << 4) | (4ull << 8) | (1ull << 12) | (12ull << 16) | (5ull << 20) | (6ull << 24) |
+                                  (7ull << 28) | (2ull << 32) | (8ull << 36) | (9ull << 40) | (10ull << 44) | (11ull << 48);
+  const int wave = (int)((ROLE_OF_HW >> (4 * hw_wave)) & 15ull);
   const LaneConst c = make_lane_const();
 #ifdef BRL_TIMING  // stamps go straight to the dump area behind the per-wave summary (terminated_count doubles as dump buffer)
   unsigned long long *fs_dump = A.terminated_count + (size_t)gridDim.x * NW * 2 + ((size_t)blockIdx.x * NW + wave) * 32;
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
         store_wt16(A.gae_tgt + i, brl_u32x4{__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), __float_as_uint(b.w)});
       }
     }
-  } else if (wave == NW - 1) {
+  } else if (wave == 12) {
     // ------------------------------------------------------------------ prep wave: raw -> command, two slots per pass
     // (lanes 0..31: slot s, lanes 32..63: slot s + 1 when it is already there).  Command format: brl_kernels.hip (k_rollout_ws).
     int avail = 0;
@@ -462,6 +468,8 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
       }
       ev_done = evs;
       wave_lds_order();
+      // (frew of every slot < c1 is final: a board that ended in slot sl was queued before `scored` passed sl)
+      if (A.gae_adv != nullptr && c1 == total && c.lane == 0) fs_flag_write(&gae_ready, 1);
       {
         const int q = c.lane >> 3, t4 = 4 * (c.lane & 7);
         if (q < m) {
@@ -488,8 +496,6 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
       }
       b0 = c1;
       if ((b0 & 7) == 0) FS_STAMP(b0 >> 3);
-      // (frew of every slot < b0 is final: a board that ended in slot sl was queued before `scored` passed sl)
-      if (A.gae_adv != nullptr && b0 == total && c.lane == 0) fs_flag_write(&gae_ready, 1);
     }
     if (A.gae_adv != nullptr && total == 0 && c.lane == 0) fs_flag_write(&gae_ready, 1);  // (nothing to scan)
     if (A.terminated_count != nullptr) {  // src/roll_out.py:85
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
       }
       p[W_REW] = make_uint2(f.z, f.w);
     }
-  } else {
+  } else if (wave <= 10) {
     // ------------------------------------------------------------------ emit waves: wave 3 + g owns tables 4 g .. 4 g + 3
     // lane L < 60 holds 16-byte piece L of rows 0-1 (960 contiguous bytes) and piece L of rows 2-3: piece L is half
     // L & 1 of packed dword q = (L >> 1) % 15 of row r = (L >> 1) / 15 (and of row r + 2): 16 bits of the acting seat's
@@ -548,6 +554,13 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
       t_wait += __builtin_amdgcn_s_memtime() - tw0;
       if ((s & 7) == 0) FS_STAMP(s >> 3);
 #endif
+      if (s == (total >> 1)) {
+        // The emit waves of a SIMD do the same work, but the oldest is served first and ends ~8 k cycles before the
+        // youngest — while the stores of the last ones no longer fill HBM.  From here on the younger go first: they all
+        // end within ~1 k cycles of each other (launch -0.5 us).
+        if (hw_wave >= 8) __builtin_amdgcn_s_setprio(2);
+        else if (hw_wave >= 4) __builtin_amdgcn_s_setprio(1);
+      }
       const uint32_t(*cs)[CMD_WORDS] = cmd[s];
       const uint32_t w0a = cs[4 * g + r][0], w0b = cs[4 * g + r + 2][0];
       const uint32_t wh = hsel ? w0b : w0a;

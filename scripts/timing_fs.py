@@ -13,7 +13,7 @@ import brl_amd
 from brl_amd.roll_out import alloc_transition
 from brl_amd.bridge_bidding import _stream
 from bench import synthetic_lut
-N, T, NW = 8192, 32, 13
+N, T, NW = 8192, 32, int(os.environ.get("NW", "13"))
 keys, values = synthetic_lut(100000, 0)
 env = brl_amd.BridgeBidding(lut=(keys, values))
 NB = int(os.environ.get("NBUF", "3"))
@@ -39,7 +39,7 @@ torch.cuda.synchronize()
 full = dump.cpu().numpy()
 d = full[:nblk * NW * 2].reshape(nblk, NW, 2)
 tl = full[nblk * NW * 2:].reshape(nblk, NW, 16, 2)[..., 0]
-names = ["logic", "loader/mask", "scorerA"] + [f"emit{g}" for g in range(8)] + ["scorerB", "prep"]
+names = ["logic", "loader/mask", "scorerA"] + [f"emit{g}" for g in range(8)] + ["scorerB", "prep"] + ["prologue-only"] * (NW - 13)
 print("role          total(mean/p95)   wait(mean)   stamps (mean over workgroups, cycles/100)")
 for w in range(NW):
     m = tl[:, w].mean(0)
