@@ -131,6 +131,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="rollout", choices=["rollout", "ppo"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--device-warmup-ms", type=float, default=80.0,
+                    help="untimed: the same step back to back for this long BEFORE the --warmup steps, so that the timed steps see "
+                         "the device's steady-state clocks (a launch takes 26.4 us in the first milliseconds after idle, 25.0 us "
+                         "from ~50 ms on; 20 timed steps last 0.5 ms)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -262,6 +266,14 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks):
             if overlap:
                 gae_done[k].record(side)
 
+    ramp_steps = 0
+    if not FAKE and args.device_warmup_ms > 0:
+        t_ramp = time.perf_counter() + args.device_warmup_ms * 1e-3
+        while time.perf_counter() < t_ramp:  # (host-timed, in blocks: the queue stays a few hundred launches deep at most)
+            for i in range(256):
+                one_step(ramp_steps + i)
+            ramp_steps += 256
+            torch.cuda.synchronize()
     for i in range(args.warmup):
         one_step(i)
     barrier()
@@ -326,6 +338,7 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks):
                    else ("brl_gae, same stream" if os.environ.get("BRL_BENCH_FUSED_GAE", "1") == "0"
                          else "inside the rollout launch: its logic wave scans the trajectory once the scorer is done (brl_rollout_random_gae)"),
                    "env_offsets": [r * NUM_ENVS for r in range(world)],
+                   "device_warmup": f"{ramp_steps} untimed steps ({args.device_warmup_ms:g} ms) before the --warmup steps: steady-state clocks",
                    "parallelism": f"env-shard x{world}, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
