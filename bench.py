@@ -280,8 +280,12 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks):
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
+    if not FAKE:
+        torch.cuda.synchronize()
+    local = time.perf_counter() - t0  # this rank's K steps, from the common start to its own last store
     barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    elapsed = max_over_ranks(local)   # the job's K steps = the slowest rank's (the closing barrier's own latency — one RCCL
+                                      # all-reduce, ~0.1 ms, a fifth of 20 steps — is not part of anybody's steps)
 
     if not FAKE:
         # the dominant kernel alone: KERNEL_LAUNCHES launches of k_rollout_fs between ONE HIP-event pair on the
