@@ -89,9 +89,11 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
   // scorer A -> scorer B: the launch's finished boards in slot order (<= 11 per table), per-slot info (actor, action,
   // n_legal, done), and B's results: reward of the acting player per slot and table (zero unless a board ended there)
   __shared__ __attribute__((aligned(16))) uint32_t evq[FS_RING * TPB][4];
-  __shared__ __attribute__((aligned(16))) uint32_t minfo[FS_MAX_TOTAL][TPB];
-  __shared__ __attribute__((aligned(16))) float frew[FS_MAX_TOTAL][TPB];
-  __shared__ __attribute__((aligned(16))) float g_tgt[FS_MAX_TOTAL][TPB];   // optional GAE tail: targets (advantages go into frew)
+  // (8 rows in front of each: the GAE scan works in blocks of 8 steps and lets the last block run over the start)
+  __shared__ __attribute__((aligned(16))) uint32_t minfo_s[8 + FS_MAX_TOTAL][TPB];
+  __shared__ __attribute__((aligned(16))) float frew_s[8 + FS_MAX_TOTAL][TPB];
+  uint32_t(*const minfo)[TPB] = minfo_s + 8;
+  float(*const frew)[TPB] = frew_s + 8;
   __shared__ __attribute__((aligned(16))) uint32_t last_rw[TPB][4];  // final (fd, ring entry) from A; rewards words of a board that ended in the LAST slot
   __shared__ int scored, ev_count;
 
@@ -280,36 +282,38 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
       // so the scan (lane = table, reverse over the rewards / dones the scorer left in LDS) hides in their tail.
       const float gae_lv = A.gae_last_val[table0 + lt];
       while (fs_flag_read(&gae_ready) == 0) __builtin_amdgcn_s_sleep(1);
+      FS_STAMP(5);  // rewards complete
       if (c.lane < TPB) {
         float gae = 0.0f, next_value = gae_lv;
-        for (int t1 = total; t1 > 0; t1 -= 8) {  // blocks of 8 steps: their 16 LDS values are fetched together
-          float rr[8], dd[8];
+        const float g0 = A.gae_gamma * 0.0f;  // gamma * next_value for every step but the last one (value column == 0)
+        for (int t1 = total; t1 > 0; t1 -= 8) {
+          // blocks of 8 steps, their 16 LDS values fetched together; no branch and no index clamp per step: the steps t < 0
+          // of the last block come AFTER every real step of the chain and live in the rows in front of the arrays
+          float rr[8];
+          uint32_t mi[8];
 #pragma unroll
           for (int k = 0; k < 8; k++) {
-            const int t = t1 - 1 - k;
-            rr[k] = frew[(t >= 0) ? t : 0][lt];
-            dd[k] = (float)((minfo[(t >= 0) ? t : 0][lt] >> 14) & 1u);
+            rr[k] = frew[t1 - 1 - k][lt];
+            mi[k] = minfo[t1 - 1 - k][lt];
           }
 #pragma unroll
           for (int k = 0; k < 8; k++) {
-            const int t = t1 - 1 - k;
-            if (t >= 0) {
-              const float vl = 0.0f, nd = 1.0f - dd[k];
-              const float delta = rr[k] + A.gae_gamma * next_value * nd - vl;  // src/gae.py:28
-              gae = delta + A.gae_gamma_lambda * nd * gae;                      // src/gae.py:29
-              frew[t][lt] = gae;                                                // advantages (the reward column is written)
-              g_tgt[t][lt] = gae + vl;                                          // targets, src/gae.py:39
-              next_value = vl;
-            }
+            const float nd = ((mi[k] >> 14) & 1u) ? 0.0f : 1.0f;                                   // 1 - done, src/gae.py:27
+            const float gnv = (k == 0 && t1 == total) ? A.gae_gamma * next_value : g0;
+            const float delta = rr[k] + gnv * nd - 0.0f;                                           // src/gae.py:28 (value == 0)
+            gae = delta + A.gae_gamma_lambda * nd * gae;                                           // src/gae.py:29
+            frew[t1 - 1 - k][lt] = gae;  // advantages (the reward column is written); targets = gae + value: in the store loop
           }
         }
       }
+      FS_STAMP(6);  // scan done
       wave_lds_order();
       // the whole wave writes them: lane l — 4 consecutive tables of step l / 8 (+ 8, 16, ..), 16-byte write-through stores
       const int q = c.lane >> 3, t4 = 4 * (c.lane & 7);
       for (int t = q; t < total; t += 8) {
         const int64_t i = (int64_t)t * A.n + table0 + t4;
-        const float4 a = *reinterpret_cast<const float4 *>(&frew[t][t4]), b = *reinterpret_cast<const float4 *>(&g_tgt[t][t4]);
+        const float4 a = *reinterpret_cast<const float4 *>(&frew[t][t4]);
+        const float4 b = make_float4(a.x + 0.0f, a.y + 0.0f, a.z + 0.0f, a.w + 0.0f);  // targets = advantages + value, src/gae.py:39
         store_wt16(A.gae_adv + i, brl_u32x4{__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w)});
         store_wt16(A.gae_tgt + i, brl_u32x4{__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), __float_as_uint(b.w)});
       }
