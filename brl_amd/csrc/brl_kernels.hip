@@ -1949,9 +1949,31 @@ extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int
   // the wave-specialised kernel serves a macro-step that spans <= 2 command batches; longer ones (and BRL_ROLLOUT_WS=0)
   // take the K-tables-per-wave kernel
   const bool all_cols = out->obs && out->legal_action_mask && out->done && out->action && out->value && out->reward && out->log_prob;
-  if (h->ws && h->fs && substeps == 1 && num_steps <= FS_MAX_TOTAL && n % FS_TPB == 0 && all_cols) {
-    // the BASELINE shape: flag-synchronised kernel (rollout_fs.hpp)
-    hipLaunchKernelGGL(k_rollout_fs, dim3((unsigned)(n / FS_TPB)), dim3(FS_NW * 64), 0, (hipStream_t)stream, A);
+  if (h->ws && h->fs && substeps == 1 && n % FS_TPB == 0 && all_cols) {
+    // the BASELINE shape: flag-synchronised kernel (rollout_fs.hpp).  It holds a whole launch's commands in LDS (<= 40 steps):
+    // a longer rollout is the same thing in pieces — every piece continues from the state, the draw counter and the
+    // terminated count the one before left (the pieces are of near-equal length: 64 -> 32 + 32, 100 -> 34 + 33 + 33)
+    const int pieces = (num_steps + FS_MAX_TOTAL - 1) / FS_MAX_TOTAL;
+    int t0 = 0;
+    for (int i = 0; i < pieces || (pieces == 0 && i == 0); i++) {
+      const int len = (pieces > 0) ? (num_steps - t0 + (pieces - i) - 1) / (pieces - i) : 0;
+      const int64_t rows = (int64_t)t0 * n;
+      RolloutArgs P = A;
+      P.T = len;
+      P.draw_base = draw_base + (uint32_t)t0;
+      P.out.obs = out->obs + rows * BRL_OBS_SIZE;
+      P.out.legal_action_mask = out->legal_action_mask + rows * BRL_NUM_ACTIONS;
+      P.out.done = out->done + rows;
+      P.out.action = out->action + rows;
+      P.out.value = out->value + rows;
+      P.out.reward = out->reward + rows;
+      P.out.log_prob = out->log_prob + rows;
+      const bool last = (i + 1 >= pieces);
+      P.last_obs = last ? last_obs : nullptr;
+      P.last_mask = last ? last_mask : nullptr;
+      hipLaunchKernelGGL(k_rollout_fs, dim3((unsigned)(n / FS_TPB)), dim3(FS_NW * 64), 0, (hipStream_t)stream, P);
+      t0 += len;
+    }
   } else if (h->ws && substeps <= WS_BATCH) {
     hipLaunchKernelGGL((k_rollout_ws<32, 12, 1>), dim3((unsigned)((n + 31) / 32)), dim3(12 * 64), 0, (hipStream_t)stream, A);
   } else {

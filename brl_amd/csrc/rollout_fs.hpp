@@ -28,7 +28,8 @@
 // (mask rows, scalar columns) goes out write-through (store_wt16): plain stores would leave 15 MB of dirty L2 lines to be
 // written back after the last wave has ended (27.4 -> 25.1 us).
 //
-// Serves substeps == 1, T <= 40, n % 32 == 0 with every Transition column requested (the BASELINE configuration);
+// Serves substeps == 1, n % 32 == 0 with every Transition column requested (the BASELINE configuration), <= 40 steps per
+// launch (brl_rollout_random runs a longer rollout as pieces);
 // everything else takes k_rollout_ws / k_rollout_random.  Bit-identical outputs (tests/test_gpu_parity.py).
 #pragma once
 

@@ -14,7 +14,7 @@ rng = np.random.default_rng(0)
 t_end = time.time() + budget
 launches = checks = 0
 while time.time() < t_end:
-    n = int(rng.choice([1, 31, 32, 33, 64, 96, 500, 2048, 4096, 8192]))   # multiples of 32 with T <= 40, substeps 1: k_rollout_fs
+    n = int(rng.choice([1, 31, 32, 33, 64, 96, 500, 2048, 4096, 8192]))   # multiples of 32 with substeps 1: k_rollout_fs (T > 40: in pieces)
     T = int(rng.choice([1, 7, 16, 32, 33, 40, 64]))
     sub = int(rng.choice([1, 1, 1, 4]))
     seed = int(rng.integers(1 << 30))

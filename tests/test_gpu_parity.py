@@ -669,6 +669,28 @@ def test_flag_synchronised_rollout_equals_barrier_kernel_at_full_size():
     assert int(outs[0][-1][-1].item()) > 0
 
 
+@pytest.mark.parametrize("T", [41, 64, 100])
+def test_long_rollouts_run_as_pieces_of_the_flag_synchronised_kernel(dds, oracle, T):
+    """T > 40 does not fit k_rollout_fs's command buffer: brl_rollout_random launches it in pieces that continue from each
+    other's state / draw counter / terminated count.  Same bytes as k_rollout_ws in one launch, and as the oracle."""
+    import brl_amd
+    outs = []
+    for ws in (None, "ws"):
+        env = make_env(dds, 4, ws)
+        roll = brl_amd.make_random_roll_out({"num_steps": T}, env)
+        rs = (None, None, env.init(21, num_envs=96), None, 0, 5)
+        rs, traj = roll(rs)
+        rs, traj2 = roll(rs)
+        outs.append([t.clone() for t in traj] + [t.clone() for t in traj2] + [rs[2].packed.clone(), rs[3].clone(), rs[4].clone()])
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    ref = oracle.init_random(96, seed=21)
+    want = oracle.rollout_random(ref, T, seed=21, draw_base=5)
+    for i, name in enumerate(brl_amd.Transition._fields):
+        g = to_np(outs[0][i])
+        assert np.array_equal(g.astype(want[name].dtype), want[name]), name
+
+
 def test_fused_rollout_kernels_agree_across_the_draw_counter_wrap(dds, oracle):
     """The action-draw index is a uint32 that wraps: k_rollout_fs precomputes the launch's draws per 4-draw Philox block,
     k_rollout_ws / k_rollout_random step through them — all three (and the oracle) must agree across 2^32."""
