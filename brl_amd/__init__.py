@@ -9,10 +9,11 @@ environment without the built library raises.
 from .bridge_bidding import BridgeBidding, State, _observe, _player_position  # noqa: F401
 from .duplicate import Table_info, duplicate_init, duplicate_step, _imp_reward  # noqa: F401
 from .gae import make_calc_gae  # noqa: F401
-from .roll_out import Transition, make_roll_out, make_random_roll_out  # noqa: F401
+from .roll_out import Transition, make_roll_out, make_random_roll_out, make_random_roll_out_with_gae  # noqa: F401
 
 __all__ = [
     "BridgeBidding", "State", "_observe", "_player_position", "Table_info", "duplicate_init",
     "duplicate_step", "_imp_reward", "make_calc_gae", "Transition", "make_roll_out",
     "make_random_roll_out",
+    "make_random_roll_out_with_gae",
 ]

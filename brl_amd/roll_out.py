@@ -73,6 +73,41 @@ def make_random_roll_out(config, env: BridgeBidding):
     return roll_out
 
 
+def make_random_roll_out_with_gae(config, env: BridgeBidding):
+    """``roll_out`` followed by ``calc_gae`` (ppo.py's _update_step: src/roll_out.py:49-108, then src/gae.py:20-39) for the
+    uniform-random policy in ONE launch (``brl_rollout_random_gae``): the value column of that policy is 0, so the scan
+    needs only what the launch itself produces and ``last_val``.  normal_step only (1 env.step per scan step),
+    ``num_steps <= 40``, ``num_envs % 32 == 0``.  Returns ``(runner_state, traj_batch, advantages, targets)`` — the same
+    bytes as ``make_random_roll_out`` + ``gae.gae_scan``."""
+    T = int(config["num_steps"])
+    reward_scale = float(config.get("reward_scale", 7600))
+    gamma = float(config.get("gamma", 1.0))
+    # config["gamma"] * config["gae_lambda"] is a Python-float product before it meets an array (as in gae.gae_scan)
+    gl = float(torch.tensor(gamma * float(config.get("gae_lambda", 0.95)), dtype=torch.float32))
+
+    def roll_out(runner_state, last_val=None, out: Transition = None):
+        params, opt_state, env_state, last_obs, terminated_count, rng = runner_state
+        n = env_state.num_envs
+        traj = out if out is not None else alloc_transition(T, n, env.device)
+        tc = _count_tensor(terminated_count, env.device)
+        p = _capi.TransitionPtrs()
+        for name in _capi.TransitionPtrs._names:
+            setattr(p, name, ptr(getattr(traj, name)))
+        last_obs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=env.device)
+        last_mask = torch.empty((n, NUM_ACTIONS), dtype=torch.bool, device=env.device)
+        lv = (torch.zeros(n, dtype=torch.float32, device=env.device) if last_val is None
+              else last_val.to(device=env.device, dtype=torch.float32).contiguous())
+        adv = torch.empty((T, n), dtype=torch.float32, device=env.device)
+        tgt = torch.empty_like(adv)
+        check(_capi.lib().brl_rollout_random_gae(env._h, ptr(env_state.packed), n, T, int(rng) & 0xFFFFFFFF, reward_scale,
+                                                 C.byref(p), ptr(last_obs), ptr(last_mask), ptr(tc), ptr(lv), gamma, gl,
+                                                 ptr(adv), ptr(tgt), _stream()))
+        new_state = State(env, env_state.packed, {"observation": last_obs, "legal_action_mask": last_mask})
+        return (params, opt_state, new_state, last_obs, tc, int(rng) + T), traj, adv, tgt
+
+    return roll_out
+
+
 class _PolicyRollout:
     """``_env_step`` (src/roll_out.py:63-103) with torch MLPs in the loop — ONE implementation for the eager scan and
     for the hipGraph scan (config["graph_rollout"]: every macro-step captured once and replayed; the eager loop issues

@@ -237,6 +237,25 @@ def test_rollout_random_gae_in_one_launch(env, oracle, dds, n, T, gamma, lam):
     assert n * T < 4096 or (bool(outs[1][0].any()) and float(outs[1][-2].abs().max()) > 0)
 
 
+def test_host_mirror_of_the_one_launch_rollout_with_gae(dds):
+    """brl_amd.make_random_roll_out_with_gae == make_random_roll_out followed by gae_scan (runner state included), twice in a row."""
+    import brl_amd
+    from brl_amd.gae import gae_scan
+    cfg = {"num_steps": 16, "gamma": 0.99, "gae_lambda": 0.9}
+    e1, e2 = make_env(dds, 4), make_env(dds, 4)
+    r1, r2 = brl_amd.make_random_roll_out(cfg, e1), brl_amd.make_random_roll_out_with_gae(cfg, e2)
+    rs1 = (None, None, e1.init(3, num_envs=128), None, 0, 9)
+    rs2 = (None, None, e2.init(3, num_envs=128), None, 0, 9)
+    lv = torch.linspace(-2.0, 2.0, 128, device=e1.device)
+    for _ in range(2):
+        rs1, t1 = r1(rs1)
+        a1, g1 = gae_scan(e1, t1.done, t1.value, t1.reward, lv, 0.99, 0.9)
+        rs2, t2, a2, g2 = r2(rs2, lv)
+        for x, y in zip(list(t1) + [a1, g1, rs1[2].packed, rs1[3], rs1[4]], list(t2) + [a2, g2, rs2[2].packed, rs2[3], rs2[4]]):
+            assert torch.equal(x, y)
+        assert rs1[5] == rs2[5]
+
+
 def test_gae_bit_exact(env, oracle):
     from brl_amd.gae import gae_scan
     rng = np.random.default_rng(2)
