@@ -41,7 +41,7 @@ ROW_BYTES = 535            # obs 480 + mask 38 + action 4 + value 4 + reward 4 +
 OBS_BYTES = 480            # the observation path alone
 LAST_ROW_BYTES = 518       # last_obs 480 + its legal mask 38, written once per table by the same launch (not counted)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-NBUF = 3                   # Transition buffers in rotation: 3 x 144 MB > 256 MB Infinity Cache
+NBUF = int(os.environ.get("BRL_BENCH_NBUF", "3"))  # Transition buffers in rotation: 3 x 144 MB > 256 MB Infinity Cache
 KERNEL_LAUNCHES = 128      # launches between the one event pair of the kernel-only loop
 METRIC = "env-steps/sec at num_envs=8192, 32-step rollout, 1/2/4/8 MI355X"
 FAKE = os.environ.get("BRL_BENCH_FAKE") == "1"  # launcher self-test (tests/test_bench_launcher.py): gloo, no GPU, no compute
