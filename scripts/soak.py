@@ -20,13 +20,21 @@ while time.time() < t_end:
     seed = int(rng.integers(1 << 30))
     env.set_rng(seed) if hasattr(env, "set_rng") else None
     roll = brl_amd.make_random_roll_out({"num_steps": T, "substeps": sub, "game_mode": "competitive" if sub == 4 else "normal"}, env)
+    one_launch = sub == 1 and T <= 40 and n % 32 == 0 and rng.random() < 0.5   # rollout + calc_gae in one launch
+    gamma, lam = float(rng.choice([1.0, 0.99, 0.9])), float(rng.choice([0.95, 1.0, 0.5]))
+    if one_launch:
+        roll_g = brl_amd.make_random_roll_out_with_gae({"num_steps": T, "gamma": gamma, "gae_lambda": lam}, env)
+        lv = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(env.device)
     st = env.init(seed, num_envs=n)
     rs = (None, None, st, None, 0, 0)
     check = n <= 4096 and (checks < 400 or rng.random() < 0.03)  # keep checking (sparsely) for the whole run
     ref = orc.init_random(n, seed=seed) if check else None
     draw = 0
     for rep in range(int(rng.integers(1, 40))):
-        rs, traj = roll(rs)
+        if one_launch:
+            rs, traj, adv, tgt = roll_g(rs, lv)
+        else:
+            rs, traj = roll(rs)
         launches += 1
         if check and rep < 3:
             want = orc.rollout_random(ref, T, seed=seed, substeps=sub, draw_base=draw)
@@ -34,6 +42,9 @@ while time.time() < t_end:
             for name in ("obs", "legal_action_mask", "action", "done", "reward"):
                 g = getattr(traj, name).cpu().numpy()
                 assert np.array_equal(g.astype(want[name].dtype), want[name]), (name, n, T, sub, seed, rep)
+            if one_launch:
+                wa, wt = orc.gae(want["done"], want["value"], want["reward"], lv.cpu().numpy(), gamma, lam)
+                assert np.array_equal(adv.cpu().numpy(), wa) and np.array_equal(tgt.cpu().numpy(), wt), ("gae", n, T, seed, rep)
             checks += 1
         draw += T * sub
     torch.cuda.synchronize()
