@@ -2265,7 +2265,7 @@ extern "C" int brl_relu_bwd_colsum(int device, float *dh, const float *h, int64_
   if (db != nullptr) {
     BiasSegs S{};
     S.n = 1; S.tiles[0] = tiles; S.partials[0] = scratch; S.cols[0] = cols; S.db[0] = db;
-    hipLaunchKernelGGL(k_bias_finalize, dim3((unsigned)((cols + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream, S);
+    hipLaunchKernelGGL(k_bias_finalize, dim3((unsigned)((cols + 63) / 64), 1), dim3(256), 0, (hipStream_t)stream, S);
   }
   HIP_TRY(hipGetLastError());
   return BRL_OK;
@@ -2285,7 +2285,7 @@ extern "C" int brl_bias_finalize(int device, int nseg, const float *const *scrat
     S.partials[i] = scratch[i]; S.cols[i] = cols[i]; S.db[i] = db[i];
     maxc = cols[i] > maxc ? cols[i] : maxc;
   }
-  hipLaunchKernelGGL(k_bias_finalize, dim3((unsigned)((maxc + 255) / 256), (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, S);
+  hipLaunchKernelGGL(k_bias_finalize, dim3((unsigned)((maxc + 63) / 64), (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, S);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

@@ -111,14 +111,20 @@ struct BiasSegs {  // up to 12 layers finalised by one launch (blockIdx.y = laye
   float *db[BIAS_MAX_SEGS];
 };
 
+// (64 columns per block, 4 threads per column: thread group g adds tiles g, g + 4, ... in order, then (g0 + g1) + (g2 + g3):
+//  a fixed order, and 16 loads per thread instead of a 64-long chain — 17 -> ~5 us for five 1024-column layers)
 __global__ __launch_bounds__(256) void k_bias_finalize(BiasSegs S) {
+  __shared__ float part[4][64];
   const int seg = (int)blockIdx.y;
-  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x, cols = S.cols[seg];
-  if (col >= cols) return;
+  const int c = (int)(threadIdx.x & 63u), g = (int)(threadIdx.x >> 6);
+  const int64_t col = (int64_t)blockIdx.x * 64 + c, cols = S.cols[seg];
   const float *p = S.partials[seg];
   float s = 0.0f;
-  for (int64_t t = 0; t < S.tiles[seg]; t++) s += p[t * cols + col];
-  S.db[seg][col] = s;
+  if (col < cols)
+    for (int64_t t = g; t < S.tiles[seg]; t += 4) s += p[t * cols + col];
+  part[g][c] = s;
+  __syncthreads();
+  if (g == 0 && col < cols) S.db[seg][col] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
 
 // ---- optax.chain(clip_by_global_norm(max_norm), adam(lr, eps)) (ppo.py:195-211) on flat fp32 buffers, two launches:
