@@ -137,7 +137,6 @@ class _PolicyRollout:
         self.traj = alloc_transition(T, n, dev)
         self.packed = e((n, 16), torch.int64)
         self.cur = [e(n, torch.int32) for _ in range(2)]
-        self.scratch_obs = e((n, OBS_SIZE), torch.bool)
         self.final_obs = e((n, OBS_SIZE), torch.bool)
         self.final_mask = e((n, NUM_ACTIONS), torch.bool)
         self.racc = e((n, 4), torch.float32)
@@ -197,7 +196,7 @@ class _PolicyRollout:
         ifmt = self._FMT[logits.dtype]
         # sub-step 1: the actor samples from the (un)masked Categorical (src/roll_out.py:27-39,79-84)
         policy_step(env, packed, packed, logits, SAMPLE if self.masked else SAMPLE | UNMASKED, 4 * t, True,
-                    action=traj.action[t], log_prob=traj.log_prob[t], obs=self.scratch_obs, rewards_acc=racc,
+                    action=traj.action[t], log_prob=traj.log_prob[t], rewards_acc=racc,
                     terminated_acc=tacc, draw_base=self.draw,
                     ext=MX(first=1, value_in=value.data_ptr(), value_stride=value.stride(0), value_out=traj.value[t].data_ptr(),
                            obs_cast=self.xin.data_ptr(), obs_fmt=fmt, in_fmt=ifmt))
@@ -209,7 +208,7 @@ class _PolicyRollout:
             if not competitive and is_opp:                              # free-run: opponents pass (src/utils.py:205-246)
                 lg, m = _pass_logits(env, self.n), MODE
             else:
-                lg, _ = self._forward(is_opp, self.scratch_obs, self.xin)
+                lg, _ = self._forward(is_opp, None, self.xin)  # (the observation comes as the cast the previous launch wrote)
                 m = SAMPLE if competitive else MODE
             fin = k == 3
             ext = MX(obs_cast=self.xin.data_ptr(), obs_fmt=fmt, in_fmt=self._FMT[lg.dtype])
@@ -217,7 +216,7 @@ class _PolicyRollout:
                 ext.last, ext.done_out, ext.reward_out = 1, traj.done[t].data_ptr(), traj.reward[t].data_ptr()
                 ext.actor, ext.reward_scale, ext.terminated_count = actor.data_ptr(), self.reward_scale, self.tc.data_ptr()
             policy_step(env, packed, packed, lg, m, 4 * t + k, True, action=self.sub_actions[t, k - 1],
-                        obs=obs_out if fin else self.scratch_obs, mask=mask_out if fin else None, rewards_acc=racc,
+                        obs=obs_out if fin else None, mask=mask_out if fin else None, rewards_acc=racc,
                         terminated_acc=tacc, current_player=cur[(t + 1) & 1] if fin else None, draw_base=self.draw, ext=ext)
 
     def _capture(self):
