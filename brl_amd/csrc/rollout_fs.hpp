@@ -173,8 +173,9 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
     // d >> 2 (counter arithmetic mod 2^32, like k_rollout_random); one (table, block) per thread
     const uint32_t fb = A.draw_base >> 2;
     const int nblk = (total > 0) ? (int)(((A.draw_base & 3u) + (uint32_t)total + 3u) >> 2) : 0;
-    // (tasks start at hardware wave 4: one Philox wave per SIMD before any SIMD gets a second one, none on the waves
-    //  of the logic / loader / scorer roles — the multiplies are quarter-rate and the barrier waits for the slowest wave)
+    // (tasks start at hardware wave 4: one Philox wave per SIMD before any SIMD gets a second one, none on hardware
+    //  waves 0..3 (logic, loader, the two oldest emit waves) — the multiplies are quarter-rate and the barrier waits
+    //  for the slowest wave)
     for (int task = (hw_wave >= 4) ? tid - 4 * 64 : TPB * nblk; task < TPB * nblk; task += (NW - 4) * 64) {
       const int tb = task & (TPB - 1);
       const uint32_t blk = (fb + (uint32_t)(task >> 5)) & 0x3FFFFFFFu;
@@ -392,8 +393,9 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
   } else if (wave == 2) {
     // ------------------------------------------------------------------ scorer A: lane = table (lanes 32..63 idle).  The
     // part of the scoring that is SERIAL per table: first denominations, who acted, which boards ended (queued for
-    // scorer B with the scalars they ended on), which ring entry a table plays.  ~500 cycles per slot: it stays right behind
-    // the commands.  Publishes ev_count, then scored (slots done).
+    // scorer B with the scalars they ended on), which ring entry a table plays.  ~600 cycles per slot when it has a SIMD's
+    // issue slots; beside the logic wave (SIMD 0) it falls ~5 k cycles behind and catches up when that wave is done.
+    // Publishes ev_count, then scored (slots done).
     const int tl = lt;
     const bool mine = c.lane < TPB;
     Tbl ts;
