@@ -313,6 +313,20 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks):
         e1.record(stream)
         torch.cuda.synchronize()
         kern_ms = e0.elapsed_time(e1) / KERNEL_LAUNCHES
+        # the chip's own store ceiling on THIS box, for scale: a plain fill of the bytes one launch writes, same rotating buffers
+        # (untimed w.r.t. the metric; 128 fills between one event pair)
+        written = ROW_BYTES * NUM_ENVS * NUM_STEPS + LAST_ROW_BYTES * NUM_ENVS + 128 * NUM_ENVS + (8 * NUM_ENVS * NUM_STEPS if fused_gae else 0)
+        fills = [torch.empty(written, dtype=torch.uint8, device=dev) for _ in range(NBUF)]
+        for i in range(16):
+            fills[i % NBUF].fill_(1)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for i in range(KERNEL_LAUNCHES):
+            fills[i % NBUF].fill_(1)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        fill_ms = e0.elapsed_time(e1) / KERNEL_LAUNCHES
+        del fills
 
     rows = NUM_ENVS * NUM_STEPS
     alg_bytes = ROW_BYTES * rows                      # 535 B per macro-step row x rows per launch
@@ -356,6 +370,10 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks):
                      "not_counted_bytes_per_launch": LAST_ROW_BYTES * NUM_ENVS + 2 * 128 * NUM_ENVS
                                                      + (8 * rows if (not FAKE and fused_gae) else 0)},  # + advantages / targets
     }
+    if not FAKE:
+        out["roofline"]["plain_fill"] = {"bytes": written, "ms": fill_ms, "GB/s": written / (fill_ms * 1e-3) / 1e9,
+                                         "kernel_over_fill": kern_ms / fill_ms,
+                                         "what": "torch fill_ of the bytes one launch writes, same box, same rotation: the device's store ceiling"}
     if rank == 0:
         out["cpu_baseline"] = cpu_baseline(keys, values) if (world == 1 and not args.no_cpu_baseline and not FAKE) else None
     return out
