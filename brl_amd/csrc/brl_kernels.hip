@@ -1990,11 +1990,18 @@ extern "C" int brl_rollout_random_gae(brl_handle *h, uint64_t *state, int64_t n,
                                       float *advantages, float *targets, void *stream) {
   COMMON(h, n);
   NEED(state && out && last_val && advantages && targets, "state / out / last_val / advantages / targets");
-  NEED(num_steps >= 1 && num_steps <= FS_MAX_TOTAL, "num_steps (1..40)");
-  NEED(n % FS_TPB == 0, "n must be a multiple of 32");
-  NEED(out->obs && out->legal_action_mask && out->done && out->action && out->value && out->reward && out->log_prob,
-       "every Transition column");
+  NEED(num_steps >= 1, "num_steps");
+  NEED(out->done && out->value && out->reward, "the done / value / reward columns");
   if (h->lut_len == 0) return fail(BRL_E_NOLUT, "brl_rollout_random_gae auto-resets and needs a LUT%s", "");
+  const bool all_cols = out->obs && out->legal_action_mask && out->action && out->log_prob;
+  if (!(h->ws && h->fs && num_steps <= FS_MAX_TOTAL && n % FS_TPB == 0 && all_cols)) {
+    // shapes the one-launch kernel does not serve (more than 40 steps, n not a multiple of 32, a column left out): the same
+    // results from the rollout launch(es) followed by the scan of their columns
+    const int rc = brl_rollout_random(h, state, n, num_steps, 1, draw_base, reward_scale, out, last_obs, last_mask,
+                                      terminated_count, stream);
+    if (rc != BRL_OK) return rc;
+    return brl_gae(h, out->done, out->value, out->reward, last_val, gamma, gamma_lambda, num_steps, n, advantages, targets, stream);
+  }
   RolloutArgs A;
   A.state = state; A.n = n; A.T = num_steps; A.substeps = 1; A.draw_base = draw_base;
   A.reward_scale = reward_scale; A.g = rng_of(h); A.env_offset = h->env_offset; A.lut = lut_of(h);

@@ -76,8 +76,8 @@ def make_random_roll_out(config, env: BridgeBidding):
 def make_random_roll_out_with_gae(config, env: BridgeBidding):
     """``roll_out`` followed by ``calc_gae`` (ppo.py's _update_step: src/roll_out.py:49-108, then src/gae.py:20-39) for the
     uniform-random policy in ONE launch (``brl_rollout_random_gae``): the value column of that policy is 0, so the scan
-    needs only what the launch itself produces and ``last_val``.  normal_step only (1 env.step per scan step),
-    ``num_steps <= 40``, ``num_envs % 32 == 0``.  Returns ``(runner_state, traj_batch, advantages, targets)`` — the same
+    needs only what the launch itself produces and ``last_val``.  normal_step only (1 env.step per scan step); one launch
+    for ``num_steps <= 40`` and ``num_envs % 32 == 0``, the rollout launch(es) + ``brl_gae`` otherwise.  Returns ``(runner_state, traj_batch, advantages, targets)`` — the same
     bytes as ``make_random_roll_out`` + ``gae.gae_scan``."""
     T = int(config["num_steps"])
     reward_scale = float(config.get("reward_scale", 7600))

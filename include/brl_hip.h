@@ -147,8 +147,9 @@ int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int num_steps,
 /* brl_rollout_random (substeps 1) + brl_gae of the SAME trajectory in ONE launch: with the random policy the value column
  * is 0, so the scan of src/gae.py:20-39 needs nothing the launch does not produce itself besides last_val float [n]
  * (the critic's value of the post-rollout observation: zeros for a policy without a critic).  advantages / targets float
- * [num_steps,n], bit-identical to brl_gae on the Transition this call writes.  Requires 1 <= num_steps <= 40,
- * n % 32 == 0 and every Transition column. */
+ * [num_steps,n], bit-identical to brl_gae on the Transition this call writes.  One launch for 1 <= num_steps <= 40,
+ * n % 32 == 0 and every Transition column; any other shape (done / value / reward columns required) runs as
+ * brl_rollout_random followed by brl_gae on the same stream. */
 int brl_rollout_random_gae(brl_handle *h, uint64_t *state, int64_t n, int num_steps, uint32_t draw_base,
                            float reward_scale, const brl_transition *out, uint8_t *last_obs, uint8_t *last_mask,
                            int64_t *terminated_count, const float *last_val, float gamma, float gamma_lambda,

@@ -194,7 +194,8 @@ def test_rollout_terminated_count_accumulates(env, oracle):
     assert int(rs[4].item()) == a + b and a > 0
 
 
-@pytest.mark.parametrize("n,T,gamma,lam", [(8192, 32, 1.0, 0.95), (64, 7, 0.99, 0.9), (32, 1, 1.0, 1.0), (2048, 40, 0.97, 0.8)])
+@pytest.mark.parametrize("n,T,gamma,lam", [(8192, 32, 1.0, 0.95), (64, 7, 0.99, 0.9), (32, 1, 1.0, 1.0), (2048, 40, 0.97, 0.8),
+                                           (96, 64, 0.99, 0.95), (50, 12, 1.0, 0.9)])  # the last two: the two-launch shapes
 def test_rollout_random_gae_in_one_launch(env, oracle, dds, n, T, gamma, lam):
     """brl_rollout_random_gae: the Transition of brl_rollout_random AND calc_gae's advantages / targets of that very
     trajectory from one launch — every column and the final state equal to the two-launch path, advantages / targets
