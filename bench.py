@@ -266,6 +266,11 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks):
             if overlap:
                 gae_done[k].record(side)
 
+    # ranks finish their set-up (LUT build, allocations) up to seconds apart: line them up BEFORE the device warm-up — and run
+    # both kinds of collective once — so that the barrier in front of the timed region finds every rank already there and no
+    # GPU sits idle (and clocks down) while it waits for the others
+    barrier()
+    max_over_ranks(0.0)
     ramp_steps = 0
     if not FAKE and args.device_warmup_ms > 0:
         t_ramp = time.perf_counter() + args.device_warmup_ms * 1e-3
