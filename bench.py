@@ -16,8 +16,12 @@ NBUF = 3 allocations (433 MB > the 256 MB Infinity Cache), so the stores have to
 runs its own 8192-table shard (weak scaling, no data-path collective — SURVEY §8e); `value` is the whole-job
 macro-steps/s = N * 8192 * 32 * K / max-over-ranks time.  Prints ONE JSON line on rank 0.
 
+Protocol: ranks lined up -> untimed device warm-up (--device-warmup-ms of the same step: steady-state clocks) -> W untimed
+warm-up steps -> barrier + synchronize -> K steps -> synchronize = the rank's time -> barrier -> MAX over ranks.
+
 `roofline` is measured in THIS run: after the timed region, KERNEL_LAUNCHES back-to-back launches of the rollout kernel
-alone (same rotating buffers, the C-ABI called directly) between ONE pair of HIP events on the launch stream.
+alone (same rotating buffers, the C-ABI called directly) between ONE pair of HIP events on the launch stream;
+`roofline.plain_fill`: a plain fill of the bytes one launch writes, timed the same way (the box's store ceiling).
 """
 from __future__ import annotations
 
