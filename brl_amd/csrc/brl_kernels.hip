@@ -1086,6 +1086,15 @@ __device__ __forceinline__ float net_out(const void *base, int64_t idx, int fmt)
   return (float)f16;
 }
 
+__device__ __forceinline__ float net_cvt(uint32_t raw, int fmt) {  // what net_out makes of the bits it loaded
+  if (fmt == 0) return __uint_as_float(raw);
+  if (fmt == 1) return __uint_as_float(raw << 16);
+  const uint16_t h = (uint16_t)raw;
+  _Float16 f16;
+  __builtin_memcpy(&f16, &h, 2);
+  return (float)f16;
+}
+
 template <int K>
 __device__ __forceinline__ int categorical(const void *logits, int64_t row_off, int fmt, bool valid, uint64_t cand, int mode,
                                            uint32_t u32, int lane, float &log_prob) {
@@ -1096,11 +1105,22 @@ __device__ __forceinline__ int categorical(const void *logits, int64_t row_off, 
   bool ok[NI];
   float mx = -INFINITY;
   int amax = 64;
+  // the lane's NI logits: unconditional loads (clamped index), the format decided ONCE around all of them — a select or a
+  // format branch per element makes hipcc branch around every load and wait for each one (NI memory round trips)
+  uint32_t raw[NI];
+  const int64_t ro = valid ? row_off : 0;
+  if (fmt == 0) {
+#pragma unroll
+    for (int i = 0; i < NI; i++) raw[i] = reinterpret_cast<const uint32_t *>(logits)[ro + min(slot * NI + i, BRL_NUM_ACTIONS - 1)];
+  } else {
+#pragma unroll
+    for (int i = 0; i < NI; i++) raw[i] = reinterpret_cast<const uint16_t *>(logits)[ro + min(slot * NI + i, BRL_NUM_ACTIONS - 1)];
+  }
 #pragma unroll
   for (int i = 0; i < NI; i++) {
     const int a = slot * NI + i;
     const bool in = a < BRL_NUM_ACTIONS;
-    lg[i] = (in && valid) ? net_out(logits, row_off + a, fmt) : 0.0f;
+    lg[i] = (in && valid) ? net_cvt(raw[i], fmt) : 0.0f;
     ok[i] = in && ((cand >> (a & 63)) & 1ull);
     if (ok[i] && lg[i] > mx) {  // first maximum wins, like argmax
       mx = lg[i];
@@ -1170,6 +1190,19 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
   const DevCtx cx = *A.ctx;
   const uint64_t legal = legal_mask(t);
   const uint64_t cand = (A.mode & 2) ? ALL_ACTIONS : legal;  // bit 1: the unmasked policy
+  // what the epilogue adds to / copies (accumulators of the macro-step, the critic's value, the acting player): fetched
+  // now, next to the logits, instead of as three more memory round trips in front of the last stores
+  const bool owner = w.c.lane < K && w.valid;
+  const int64_t otab = owner ? w.table : 0;
+  float4 old_rw = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t old_term = 0, val_raw = 0, actor_id = 0;
+  if (A.o.rewards && !A.x.first) old_rw = reinterpret_cast<const float4 *>(A.o.rewards)[otab];
+  if (A.o.terminated && !A.x.first) old_term = A.o.terminated[otab];
+  if (A.x.value_out) {
+    if (A.x.in_fmt == 0) val_raw = reinterpret_cast<const uint32_t *>(A.x.value_in)[otab * A.x.value_stride];
+    else val_raw = reinterpret_cast<const uint16_t *>(A.x.value_in)[otab * A.x.value_stride];
+  }
+  if (A.x.last && A.x.reward_out) actor_id = (uint32_t)A.x.actor[otab];
   uint32_t u32 = 0;
   if (!(A.mode & 1)) {
     uint32_t r[4];
@@ -1209,24 +1242,20 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
     if (A.log_prob) A.log_prob[w.table] = lp;
     float4 tot = rw;
     if (A.o.rewards) {
-      float4 *p = reinterpret_cast<float4 *>(A.o.rewards) + w.table;
-      if (!A.x.first) {
-        const float4 old = *p;
-        tot = make_float4(old.x + rw.x, old.y + rw.y, old.z + rw.z, old.w + rw.w);
-      }
-      *p = tot;
+      if (!A.x.first) tot = make_float4(old_rw.x + rw.x, old_rw.y + rw.y, old_rw.z + rw.z, old_rw.w + rw.w);
+      reinterpret_cast<float4 *>(A.o.rewards)[w.table] = tot;
     }
     tacc = term;
     if (A.o.terminated) {
-      if (!A.x.first) tacc |= A.o.terminated[w.table];
+      if (!A.x.first) tacc |= old_term;
       A.o.terminated[w.table] = (uint8_t)tacc;
     }
     if (A.o.current_player) A.o.current_player[w.table] = cur_player(t);
-    if (A.x.value_out) A.x.value_out[w.table] = net_out(A.x.value_in, w.table * A.x.value_stride, A.x.in_fmt);   // src/roll_out.py:76
+    if (A.x.value_out) A.x.value_out[w.table] = net_cvt(val_raw, A.x.in_fmt);                 // src/roll_out.py:76
     if (A.x.last) {
       if (A.x.done_out) A.x.done_out[w.table] = (uint8_t)tacc;                                // G2
       if (A.x.reward_out) {                                                                  // G1, src/roll_out.py:90
-        const int a = A.x.actor[w.table] & 3;
+        const int a = (int)(actor_id & 3u);
         const float r = (a == 0) ? tot.x : ((a == 1) ? tot.y : ((a == 2) ? tot.z : tot.w));
         A.x.reward_out[w.table] = r / A.x.reward_scale;
       }
