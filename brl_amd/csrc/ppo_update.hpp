@@ -31,11 +31,18 @@ __global__ __launch_bounds__(128) void k_mb_gather(GatherArgs A) {
         make_float4((float)(w & 0xFFu), (float)((w >> 8) & 0xFFu), (float)((w >> 16) & 0xFFu), (float)(w >> 24));
   }
   if (t < BRL_NUM_ACTIONS) A.o_mask[b * BRL_NUM_ACTIONS + t] = A.mask[row * BRL_NUM_ACTIONS + t];
-  if (t == 64) A.o_action[b] = A.action[row];
-  if (t == 65) A.o_value[b] = A.value[row];
-  if (t == 66) A.o_log_prob[b] = A.log_prob[row];
-  if (t == 67) A.o_adv[b] = A.adv[row];
-  if (t == 68) A.o_tgt[b] = A.tgt[row];
+  if (t >= 64 && t < 69) {  // the five 4-byte scalars of the sample: ONE load instruction (lane = column), not five with a wait each
+    const int k = t - 64;
+    const uint32_t *src = (k == 0) ? reinterpret_cast<const uint32_t *>(A.action)
+                        : (k == 1) ? reinterpret_cast<const uint32_t *>(A.value)
+                        : (k == 2) ? reinterpret_cast<const uint32_t *>(A.log_prob)
+                        : (k == 3) ? reinterpret_cast<const uint32_t *>(A.adv) : reinterpret_cast<const uint32_t *>(A.tgt);
+    uint32_t *dst = (k == 0) ? reinterpret_cast<uint32_t *>(A.o_action)
+                  : (k == 1) ? reinterpret_cast<uint32_t *>(A.o_value)
+                  : (k == 2) ? reinterpret_cast<uint32_t *>(A.o_log_prob)
+                  : (k == 3) ? reinterpret_cast<uint32_t *>(A.o_adv) : reinterpret_cast<uint32_t *>(A.o_tgt);
+    dst[b] = src[row];
+  }
 }
 
 // ---- ReLU backward + bias gradient of one hidden layer, two launches: k_relu_bwd_tiles: dz = dh * (h > 0) in place and
@@ -48,18 +55,29 @@ __global__ __launch_bounds__(256) void k_relu_bwd_tiles(float *dh, const float *
   const int64_t col = (int64_t)blockIdx.x * 64 + c, r0 = (int64_t)blockIdx.y * 64 + rg;
   float d[16], hv[16];
   const bool cv = col < cols;
+  // (unconditional loads from clamped addresses, the h == NULL case decided once: a guard per element makes the compiler
+  //  branch around every load and wait for each — 32 memory round trips instead of one)
+  const int64_t cc = cv ? col : cols - 1;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    const int64_t r = r0 + 4 * k;
-    const bool v = cv && r < rows;
-    d[k] = v ? dh[r * ld + col] : 0.0f;
-    hv[k] = (v && h != nullptr) ? h[r * ld + col] : 1.0f;
+    const int64_t r = r0 + 4 * k, rc = (r < rows) ? r : rows - 1;
+    d[k] = dh[rc * ld + cc];
+  }
+  if (h != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int64_t r = r0 + 4 * k, rc = (r < rows) ? r : rows - 1;
+      hv[k] = h[rc * ld + cc];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; k++) hv[k] = 1.0f;
   }
   float s = 0.0f;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     const int64_t r = r0 + 4 * k;
-    const float z = (hv[k] > 0.0f) ? d[k] : 0.0f;
+    const float z = (cv && r < rows && hv[k] > 0.0f) ? d[k] : 0.0f;
     if (h != nullptr && cv && r < rows) dh[r * ld + col] = z;
     s += z;
   }
@@ -76,19 +94,29 @@ __global__ __launch_bounds__(256) void k_relu_bwd_tiles4(float *dh, const float 
   const int64_t col = ((int64_t)blockIdx.x * 64 + cg) * 4, r0 = (int64_t)blockIdx.y * 16 + rg;
   const bool cv = col < cols;
   float4 d[4], hv[4];
+  const int64_t cc = cv ? col : cols - 4;  // (cols % 4 == 0: see relu_tile_rows)
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int64_t r = r0 + 4 * k;
-    const bool v = cv && r < rows;
-    d[k] = v ? *reinterpret_cast<const float4 *>(dh + r * ld + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-    hv[k] = (v && h != nullptr) ? *reinterpret_cast<const float4 *>(h + r * ld + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+  for (int k = 0; k < 4; k++) {  // unconditional loads from clamped addresses (see k_relu_bwd_tiles)
+    const int64_t r = r0 + 4 * k, rc = (r < rows) ? r : rows - 1;
+    d[k] = *reinterpret_cast<const float4 *>(dh + rc * ld + cc);
+  }
+  if (h != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int64_t r = r0 + 4 * k, rc = (r < rows) ? r : rows - 1;
+      hv[k] = *reinterpret_cast<const float4 *>(h + rc * ld + cc);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) hv[k] = make_float4(1.f, 1.f, 1.f, 1.f);
   }
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int64_t r = r0 + 4 * k;
-    const float4 z = make_float4(hv[k].x > 0.f ? d[k].x : 0.f, hv[k].y > 0.f ? d[k].y : 0.f, hv[k].z > 0.f ? d[k].z : 0.f,
-                                 hv[k].w > 0.f ? d[k].w : 0.f);
+    const bool v = cv && r < rows;
+    const float4 z = make_float4((v && hv[k].x > 0.f) ? d[k].x : 0.f, (v && hv[k].y > 0.f) ? d[k].y : 0.f,
+                                 (v && hv[k].z > 0.f) ? d[k].z : 0.f, (v && hv[k].w > 0.f) ? d[k].w : 0.f);
     if (h != nullptr && cv && r < rows) *reinterpret_cast<float4 *>(dh + r * ld + col) = z;
     s.x += z.x; s.y += z.y; s.z += z.z; s.w += z.w;
   }
