@@ -1462,11 +1462,21 @@ __global__ __launch_bounds__(256) void k_eval_reduce(int64_t n, brl_table_info T
         add(base + ((r0 >= 0.0f) ? 5 : 7) + team, 1);
       }
     }
-    if (bid_count)
-      for (int i = 0; i < 70; i++) {
-        const int32_t c = bid_count[e * 70 + i];
-        if (c) add(2 * EV_TABLE + i, c);
+    if (bid_count) {
+      // 70 counters per board = 35 aligned 8-byte pairs, fetched 7 pairs at a time and only then added (a load + a
+      // conditional add per element compiles to 70 dependent memory round trips)
+      const int2 *bc = reinterpret_cast<const int2 *>(bid_count + e * 70);
+      for (int i0 = 0; i0 < 35; i0 += 7) {
+        int2 c[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) c[k] = bc[i0 + k];
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+          if (c[k].x) add(2 * EV_TABLE + 2 * (i0 + k), c[k].x);
+          if (c[k].y) add(2 * EV_TABLE + 2 * (i0 + k) + 1, c[k].y);
+        }
       }
+    }
     if (state) add(2 * EV_TABLE + 70, (long long)bits((uint32_t)(state[e * BRL_STATE_WORDS + W_SC] >> 32), SCH_STEP, 10));
   }
   __syncthreads();
