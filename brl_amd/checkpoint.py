@@ -9,7 +9,10 @@
   them WITHOUT jax by resolving jax's array-reconstruction hook to a numpy constructor.  [RECALL — jax 0.4.23's
   ``ArrayImpl.__reduce__`` returns ``(jax._src.array._reconstruct_array, (fun, args, arr_state, aval_state))`` with
   ``(fun, args, arr_state)`` the wrapped numpy array's own reduce triple; no published pickle is available offline, the
-  tests exercise a pickle written with that protocol.]
+  tests exercise a pickle written with that protocol.  Checked against: that layout only (jax 0.4.23, float32 leaves);
+  pickles of newer jax versions or with bf16 / ml_dtypes leaves raise ``UnpicklingError`` rather than load.]  Globals are
+  resolved from an allow-list (numpy array reconstruction, plain containers, the jax / haiku stand-ins); anything else —
+  ``os.system``, ``builtins.eval`` ... — is refused.
 """
 from __future__ import annotations
 
@@ -87,7 +90,17 @@ class _HaikuUnpickler(pickle.Unpickler):
             return _FlatMapping
         if module.startswith("jax") or module.startswith("haiku") or module.startswith("jaxlib"):
             raise pickle.UnpicklingError(f"cannot resolve {module}.{name} without jax / haiku")
-        return super().find_class(module, name)
+        # allow-list: a parameter tree needs numpy's array reconstruction and plain containers, nothing else — a pickle
+        # is a program, and model files (initial_model_path, eval_opp_model_path, pool files) may come from third parties
+        if (module, name) in _SAFE_GLOBALS:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"refusing to resolve {module}.{name}: not part of a Haiku parameter tree")
+
+
+_SAFE_GLOBALS = frozenset(
+    [(m, n) for m in ("numpy.core.multiarray", "numpy._core.multiarray") for n in ("_reconstruct", "scalar")]
+    + [("numpy", "ndarray"), ("numpy", "dtype"), ("collections", "OrderedDict"), ("builtins", "dict"), ("builtins", "list"),
+       ("builtins", "tuple"), ("builtins", "set"), ("builtins", "frozenset")])
 
 
 def load_haiku_pickle(path_or_bytes) -> dict:

@@ -1966,11 +1966,23 @@ extern "C" int brl_get_fields(brl_handle *h, const uint64_t *state, int64_t n, c
   return BRL_OK;
 }
 
+// The fused rollout kernels store 16 bytes per lane (observation pieces, mask chunks, four tables of a scalar column) and
+// 4 bytes of `done` at a time: every output array must start on such a boundary (any hipMalloc / torch allocation does;
+// an odd view into one does not).
+static inline bool aligned_to(const void *p, uintptr_t a) { return ((uintptr_t)p & (a - 1)) == 0; }
+static bool transition_aligned(const brl_transition *o, const void *last_obs, const void *last_mask, const void *adv, const void *tgt) {
+  return aligned_to(o->obs, 16) && aligned_to(o->legal_action_mask, 16) && aligned_to(o->action, 16) && aligned_to(o->value, 16) &&
+         aligned_to(o->reward, 16) && aligned_to(o->log_prob, 16) && aligned_to(o->done, 4) && aligned_to(last_obs, 16) &&
+         aligned_to(last_mask, 16) && aligned_to(adv, 16) && aligned_to(tgt, 16);
+}
+
 extern "C" int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int num_steps, int substeps,
                                   uint32_t draw_base, float reward_scale, const brl_transition *out,
                                   uint8_t *last_obs, uint8_t *last_mask, int64_t *terminated_count, void *stream) {
   COMMON(h, n);
   NEED(state && out, "state / out");
+  NEED(aligned_to(state, 16) && transition_aligned(out, last_obs, last_mask, nullptr, nullptr),
+       "output arrays must be 16-byte aligned (done: 4-byte)");
   NEED(num_steps >= 0, "num_steps");
   NEED(substeps >= 1 && substeps <= 16, "substeps");
   if (h->lut_len == 0) return fail(BRL_E_NOLUT, "brl_rollout_random auto-resets and needs a LUT%s", "");
@@ -2031,6 +2043,8 @@ extern "C" int brl_rollout_random_gae(brl_handle *h, uint64_t *state, int64_t n,
   NEED(state && out && last_val && advantages && targets, "state / out / last_val / advantages / targets");
   NEED(num_steps >= 1, "num_steps");
   NEED(out->done && out->value && out->reward, "the done / value / reward columns");
+  NEED(aligned_to(state, 16) && transition_aligned(out, last_obs, last_mask, advantages, targets),
+       "output arrays must be 16-byte aligned (done: 4-byte)");
   if (h->lut_len == 0) return fail(BRL_E_NOLUT, "brl_rollout_random_gae auto-resets and needs a LUT%s", "");
   const bool all_cols = out->obs && out->legal_action_mask && out->action && out->log_prob;
   if (!(h->ws && h->fs && num_steps <= FS_MAX_TOTAL && n % FS_TPB == 0 && all_cols)) {

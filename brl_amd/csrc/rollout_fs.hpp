@@ -304,7 +304,7 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
             const float gnv = (k == 0 && t1 == total) ? A.gae_gamma * next_value : g0;
             const float delta = rr[k] + gnv * nd - 0.0f;                                           // src/gae.py:28 (value == 0)
             gae = delta + A.gae_gamma_lambda * nd * gae;                                           // src/gae.py:29
-            frew[t1 - 1 - k][lt] = gae;  // advantages (the reward column is written); targets = gae + value: in the store loop
+            frew[t1 - 1 - k][lt] = gae;  // advantages in place (scorer B read its last chunk's rewards BEFORE raising gae_ready); targets = gae + value: in the store loop
           }
         }
       }
@@ -476,13 +476,21 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
       ev_done = evs;
       wave_lds_order();
       // (frew of every slot < c1 is final: a board that ended in slot sl was queued before `scored` passed sl)
-      if (A.gae_adv != nullptr && c1 == total && c.lane == 0) fs_flag_write(&gae_ready, 1);
       {
         const int q = c.lane >> 3, t4 = 4 * (c.lane & 7);
+        // This chunk's rewards / infos are READ before gae_ready is raised: the GAE scan overwrites frew in place (advantages),
+        // starting with the last slots — the ones this chunk still has to store as Transition.reward.  LDS operations of
+        // one wave are performed in issue order, so reads issued before the flag store see the rewards, not the scan's values.
+        uint4 info4 = make_uint4(0u, 0u, 0u, 0u);
+        float4 rew = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < m) {
-          const uint4 info4 = *reinterpret_cast<const uint4 *>(&minfo[b0 + q][t4]);
+          info4 = *reinterpret_cast<const uint4 *>(&minfo[b0 + q][t4]);
+          rew = *reinterpret_cast<const float4 *>(&frew[b0 + q][t4]);
+        }
+        wave_lds_order();
+        if (A.gae_adv != nullptr && c1 == total && c.lane == 0) fs_flag_write(&gae_ready, 1);
+        if (q < m) {
           const uint32_t inf[4] = {info4.x, info4.y, info4.z, info4.w};
-          const float4 rew = *reinterpret_cast<const float4 *>(&frew[b0 + q][t4]);
           float lgp[4];
           uint32_t act[4], dn = 0;
 #pragma unroll

@@ -85,20 +85,27 @@ def make_random_roll_out_with_gae(config, env: BridgeBidding):
     # config["gamma"] * config["gae_lambda"] is a Python-float product before it meets an array (as in gae.gae_scan)
     gl = float(torch.tensor(gamma * float(config.get("gae_lambda", 0.95)), dtype=torch.float32))
 
-    def roll_out(runner_state, last_val=None, out: Transition = None):
+    def roll_out(runner_state, last_val=None, out: Transition = None, out_adv=None, out_tgt=None, out_last=None):
+        """``out`` / ``out_adv`` / ``out_tgt`` / ``out_last = (last_obs, last_mask)``: caller-owned output buffers (a loop
+        that rotates its buffers allocates nothing per call); default: fresh tensors, like a JAX function's results."""
         params, opt_state, env_state, last_obs, terminated_count, rng = runner_state
         n = env_state.num_envs
         traj = out if out is not None else alloc_transition(T, n, env.device)
-        tc = _count_tensor(terminated_count, env.device)
+        tc = terminated_count if (torch.is_tensor(terminated_count) and terminated_count.dtype == torch.int64
+                                  and terminated_count.device == env.device and terminated_count.numel() == 1) \
+            else _count_tensor(terminated_count, env.device)   # (a count tensor that is already in place is accumulated into)
         p = _capi.TransitionPtrs()
         for name in _capi.TransitionPtrs._names:
             setattr(p, name, ptr(getattr(traj, name)))
-        last_obs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=env.device)
-        last_mask = torch.empty((n, NUM_ACTIONS), dtype=torch.bool, device=env.device)
+        if out_last is not None:
+            last_obs, last_mask = out_last
+        else:
+            last_obs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=env.device)
+            last_mask = torch.empty((n, NUM_ACTIONS), dtype=torch.bool, device=env.device)
         lv = (torch.zeros(n, dtype=torch.float32, device=env.device) if last_val is None
               else last_val.to(device=env.device, dtype=torch.float32).contiguous())
-        adv = torch.empty((T, n), dtype=torch.float32, device=env.device)
-        tgt = torch.empty_like(adv)
+        adv = out_adv if out_adv is not None else torch.empty((T, n), dtype=torch.float32, device=env.device)
+        tgt = out_tgt if out_tgt is not None else torch.empty_like(adv)
         check(_capi.lib().brl_rollout_random_gae(env._h, ptr(env_state.packed), n, T, int(rng) & 0xFFFFFFFF, reward_scale,
                                                  C.byref(p), ptr(last_obs), ptr(last_mask), ptr(tc), ptr(lv), gamma, gl,
                                                  ptr(adv), ptr(tgt), _stream()))
@@ -243,7 +250,10 @@ class _PolicyRollout:
         traj.obs[0].copy_(env_state.observation if last_obs is None else last_obs)
         traj.legal_action_mask[0].copy_(env_state.legal_action_mask)
         self.tc.copy_(_count_tensor(terminated_count, self.env.device))
-        self.draw.fill_(int(rng) & 0x7FFFFFFF)
+        # ONE convention for the action-draw counter everywhere: it wraps mod 2^32 (the fused kernels' uint32 arithmetic,
+        # `int(rng) & 0xFFFFFFFF` at the C-ABI); the device word is the same 32 bits held in an int32 tensor
+        d = int(rng) & 0xFFFFFFFF
+        self.draw.fill_(d - (1 << 32) if d >= (1 << 31) else d)
 
     def run(self, runner_state, opp_params):
         params, opt_state, env_state, last_obs, terminated_count, rng = runner_state

@@ -142,7 +142,10 @@ def train(config, log=print):
         # BRL_DIST_BACKEND=gloo: rehearsal on a box with fewer GPUs than ranks (ranks share the devices round-robin)
         backend = os.environ.get("BRL_DIST_BACKEND", "nccl")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
-        dist.init_process_group(backend)
+        if backend == "nccl":   # RCCL: one GPU per rank, bound to the communicator from the start (no lazy device guess)
+            dist.init_process_group(backend, device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", torch.cuda.current_device())
     config = dict(DEFAULTS, **config)
     # ppo.py:225-227; under a process group num_envs is PER RANK (each rank owns its env shard: weak scaling), so an update
@@ -181,6 +184,22 @@ def train(config, log=print):
     def load_opponent(path, activation, model_type):
         return ckpt.load_params(path, activation, model_type, dev)
 
+    latest_snapshot = {}
+
+    def snapshot_latest(params):
+        """The "latest" opponent = the learner's weights AS THEY ARE NOW (ppo.py:455-460: an immutable pytree that stays at
+        the pre-update weights).  `params` is a live module that update_step changes in place, so the opponent is a copy
+        in a persistent module of its own (14.7 MB, once per iteration) — never an alias."""
+        net = latest_snapshot.get("net")
+        if net is None:
+            net = latest_snapshot["net"] = actor_fp.init(0, device=dev)
+            for q in net.parameters():
+                q.requires_grad_(False)
+        with torch.no_grad():
+            for q, src in zip(net.parameters(), params.parameters()):
+                q.copy_(src.detach())
+        return net
+
     eval_opp = (load_opponent(config["eval_opp_model_path"], config["eval_opp_activation"], config["eval_opp_model_type"])
                 if config["eval_opp_model_path"] else
                 make_forward_pass(config["eval_opp_activation"], config["eval_opp_model_type"]).init(config["seed"] + 1, device=dev))
@@ -207,7 +226,7 @@ def train(config, log=print):
                                    config["opp_activation"], config["opp_model_type"]) \
             if (config["opp_model_path"] or config["eval_opp_model_path"]) else eval_opp
     else:
-        opp_params = params
+        opp_params = snapshot_latest(params)
     pool_dir = os.path.join(config["log_path"], config["exp_name"], config["save_model_path"])
     if config["save_model"] and rank == 0:
         os.makedirs(pool_dir, exist_ok=True)                                                         # ppo.py:339-346
@@ -246,7 +265,7 @@ def train(config, log=print):
                 opp_name = params_list[code]
                 opp_params = load_opponent(os.path.join(pool_dir, opp_name), config["actor_activation"], config["actor_model_type"])
             elif code == -1:
-                opp_params = params
+                opp_params = snapshot_latest(params)
             else:
                 opp_name = "unchanged"
         imp_before = float(simple_duplicate_evaluate(params, opp_params, eval_rng)[0][0]) if do_eval else float("nan")  # :461
@@ -270,7 +289,10 @@ def train(config, log=print):
             "train/lr": float(linear_schedule(config, (i + 1) * config["update_epochs"] * config["num_minibatches"])),
             "train/imp_opp_before": imp_before, "train/imp_opp_after": imp_after, "board_num": board_num, "steps": steps,
             # build-side extras
-            "update": i, "opponent": opp_name, "hash_table": train_files[rotation.current],
+            "update": i, "opponent": opp_name,
+            "opp_weight_delta": max(float((a.detach() - b.detach()).abs().max()) for a, b in
+                                    zip(runner_state[0].parameters(), opp_params.parameters()))
+            if opp_params is not runner_state[0] and config["actor_model_type"] == config["opp_model_type"] else float("nan"), "hash_table": train_files[rotation.current],
             "eval_s": t0 - t_eval, "rollout_s": t1 - t0, "gae_s": t2 - t1, "update_s": t3 - t2,
             "macro_steps_per_s": config["num_envs"] * config["num_steps"] * world / (t3 - t0)})
         if rotation.advance(board_num):                                                               # ppo.py:525-549 (G14)

@@ -550,7 +550,7 @@ def make_update_step(config, actor_forward_pass, optimizer=None):
         flat = Transition(*[x.reshape((batch_size,) + x.shape[2:]) for x in traj_batch])  # G7
         adv_f, tgt_f = advantages.reshape(batch_size), targets.reshape(batch_size)
         gen = torch.Generator(device=adv_f.device)
-        gen.manual_seed(int(rng) & 0x7FFFFFFF)
+        gen.manual_seed(int(rng) & 0xFFFFFFFF)   # (the same mod-2^32 convention as the action-draw counter)
         totals, auxes = [], []
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         graphed = None
@@ -559,14 +559,30 @@ def make_update_step(config, actor_forward_pass, optimizer=None):
         if config.get("graph_update", True) and adv_f.is_cuda and (want_fused or (sched is None and not multi)):
             graphed = opt_state.get("graphed")
             world = dist.get_world_size() if multi else 1
-            if graphed is None or graphed.params is not params or graphed.mbs != mbs or isinstance(graphed, FusedMinibatch) != want_fused \
-                    or getattr(graphed, "world", 1) != world:
+            # (False = an earlier capture failed, on this or — under a process group — any rank: stay eager, do not retry)
+            if graphed is None or (graphed is not False and (
+                    graphed.params is not params or graphed.mbs != mbs or isinstance(graphed, FusedMinibatch) != want_fused
+                    or getattr(graphed, "world", 1) != world)):
                 try:
                     graphed = FusedMinibatch(config, params, opt, mbs, adv_f.device, world) if want_fused \
                         else GraphedMinibatch(config, actor_forward_pass, params, opt, mbs, adv_f.device)
-                except Exception as e:  # capture is an optimisation, never a requirement
+                except Exception as e:  # capture is an optimisation, never a requirement — but never a SILENT ~1.7x cliff
                     graphed = False
                     opt_state["graph_error"] = repr(e)
+                    import warnings
+                    warnings.warn(f"brl_amd.update: hipGraph capture of the minibatch step failed ({e!r}); this update runs "
+                                  f"on the eager path (~1.7x slower).  opt_state['graph_error'] holds the error.", RuntimeWarning)
+                if multi:
+                    # every rank must issue the SAME collective sequence: a rank whose capture failed would run ONE flat
+                    # all-reduce per minibatch while the others run FusedMinibatch's bucketed ones, and RCCL would hang
+                    # until its timeout.  Agree (MIN over ranks): all fused, or all eager.
+                    ok = torch.tensor([1 if isinstance(graphed, FusedMinibatch) else 0], dtype=torch.int32, device=adv_f.device)
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                    if int(ok.item()) == 0 and isinstance(graphed, FusedMinibatch):
+                        opt_state["graph_error"] = "another rank failed to capture the minibatch step: all ranks run eager"
+                        import warnings
+                        warnings.warn("brl_amd.update: " + opt_state["graph_error"], RuntimeWarning)
+                        graphed = False
                 opt_state["graphed"] = graphed
             if isinstance(graphed, FusedMinibatch):
                 fused = graphed

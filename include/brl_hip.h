@@ -139,7 +139,9 @@ typedef struct brl_transition {
  * draw_base: index of the first action draw (advance by T*substeps between calls).
  * last_obs uint8 [n,480] / last_mask uint8 [n,38]: observation and legal mask of the post-rollout
  * state, i.e. runner_state's last_obs of src/roll_out.py:95-102 (either may be NULL).
- * terminated_count: device int64 accumulated like src/roll_out.py:85 (may be NULL). */
+ * terminated_count: device int64 accumulated like src/roll_out.py:85 (may be NULL).
+ * Alignment: state and every output array 16-byte aligned (done: 4-byte) — the kernels store 16 bytes per lane;
+ * BRL_E_ARG otherwise (also for brl_rollout_random_gae's advantages / targets). */
 int brl_rollout_random(brl_handle *h, uint64_t *state, int64_t n, int num_steps, int substeps,
                        uint32_t draw_base, float reward_scale, const brl_transition *out,
                        uint8_t *last_obs, uint8_t *last_mask, int64_t *terminated_count, void *stream);

@@ -68,6 +68,36 @@ def build(force: bool = False) -> str:
     return out
 
 
+NATIVE_FLAGS = ["-O3", "-march=native", "-fopenmp", "-fPIC", "-std=c11"]
+
+
+def build_native():
+    """bench.py's cpu_baseline leg: the same oracle compiled `-O3 -march=native -fopenmp` ON THE BOX that
+    times it (a -march=native object must not travel between machines: it is rebuilt whenever the host CPU differs from
+    the one recorded beside it).  Returns (path, flags string); falls back to the portable test build if gcc fails."""
+    src = os.path.join(_HERE, "bridge_oracle.c")
+    out = os.path.join(_HERE, "_build", "liboracle_native.so")
+    tag = out + ".host"
+    host = ""
+    try:
+        host = next(l for l in open("/proc/cpuinfo") if l.startswith("model name")).strip()
+    except (OSError, StopIteration):
+        pass
+    try:
+        fresh = os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src) and open(tag).read() == host
+    except OSError:
+        fresh = False
+    if not fresh:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        try:
+            subprocess.check_call([os.environ.get("CC", "gcc")] + NATIVE_FLAGS + ["-shared", "-o", out, src, "-lm"])
+            with open(tag, "w") as f:
+                f.write(host)
+        except (subprocess.CalledProcessError, OSError):
+            return build(), "-O2 -ffp-contract=off -fopenmp (portable test build: the native build failed)"
+    return out, " ".join(NATIVE_FLAGS)
+
+
 def _p(a, ctype=None):
     if a is None:
         return None
@@ -77,9 +107,9 @@ def _p(a, ctype=None):
 class Oracle:
     """Thin numpy-facing wrapper.  States are numpy structured arrays of STATE_DTYPE."""
 
-    def __init__(self, lut_keys: np.ndarray | None = None, lut_values: np.ndarray | None = None):
+    def __init__(self, lut_keys: np.ndarray | None = None, lut_values: np.ndarray | None = None, lib_file: str | None = None):
         build()
-        self.lib = C.CDLL(lib_path())
+        self.lib = C.CDLL(lib_file or lib_path())
         L = self.lib
         assert L.orc_sizeof_state() == STATE_DTYPE.itemsize, (L.orc_sizeof_state(), STATE_DTYPE.itemsize)
         assert L.orc_sizeof_table_info() == TABLE_INFO_DTYPE.itemsize

@@ -29,6 +29,9 @@ def test_gpus_2_starts_two_ranks_and_prints_one_line():
     assert abs(out["value"] - 2 * 8192 * 32 * 5 / (out["ms_per_step"] * 5e-3)) < 1e-6 * out["value"]
     assert out["ms_per_step"] >= 2.0  # the fake step sleeps 2 ms
     assert out["cpu_baseline"] is None and "FAKE" in out["data"]
+    # one record per rank (device identity, its own step time): the proof of N distinct devices in an RCCL run
+    assert [r["rank"] for r in out["ranks"]] == [0, 1] and len({r["pid"] for r in out["ranks"]}) == 2
+    assert max(r["local_ms_per_step"] for r in out["ranks"]) == out["ms_per_step"]
 
 
 def test_single_rank_default_and_world_size_mismatch():

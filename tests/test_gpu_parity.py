@@ -667,6 +667,51 @@ def test_full_size_properties(dds):
         assert torch.equal(a, b)
 
 
+def test_bench_configuration_against_the_oracle():
+    """The benchmark's OWN step (bench.py: brl_rollout_random_gae at num_envs=8192, num_steps=32 on
+    bench.synthetic_lut(100_000, 0), the ppo.py:128 table size) against oracle.rollout_random + oracle.gae: all seven
+    Transition columns, last_obs / mask, every field of the packed state, terminated_count, advantages / targets —
+    bit-exact, for two consecutive steps (state, draw counter and count carry over like the bench's)."""
+    import ctypes as C
+    import brl_amd
+    from bench import LUT_LEN, NUM_ENVS, NUM_STEPS, synthetic_lut as bench_lut
+    from brl_amd import _capi
+    from brl_amd.bridge_bidding import State
+    from brl_amd.roll_out import alloc_transition
+    from oracle import Oracle
+    keys, values = bench_lut(LUT_LEN, 0)
+    e = brl_amd.BridgeBidding(lut=(keys, values))
+    orc = Oracle(keys, values)
+    n, T, dev = NUM_ENVS, NUM_STEPS, e.device
+    st = e.init(0, num_envs=n)
+    ref = orc.init_random(n, seed=0)
+    traj = alloc_transition(T, n, dev)
+    p = _capi.TransitionPtrs()
+    for f in _capi.TransitionPtrs._names:
+        setattr(p, f, getattr(traj, f).data_ptr())
+    lo = torch.empty((n, 480), dtype=torch.bool, device=dev); lm = torch.empty((n, 38), dtype=torch.bool, device=dev)
+    tc = torch.zeros(1, dtype=torch.int64, device=dev)
+    adv = torch.empty((T, n), device=dev); tgt = torch.empty((T, n), device=dev)
+    gl = float(torch.tensor(1.0 * 0.95, dtype=torch.float32))
+    last_val = torch.zeros(n, dtype=torch.float32, device=dev)
+    total = 0
+    for step in range(2):
+        _capi.check(_capi.lib().brl_rollout_random_gae(e._h, st.packed.data_ptr(), n, T, step * T, 7600.0, C.byref(p),
+                                                       lo.data_ptr(), lm.data_ptr(), tc.data_ptr(), last_val.data_ptr(), 1.0, gl,
+                                                       adv.data_ptr(), tgt.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        want = orc.rollout_random(ref, T, seed=0, draw_base=step * T)
+        for name in brl_amd.Transition._fields:
+            assert np.array_equal(to_np(getattr(traj, name)).astype(want[name].dtype), want[name]), f"step {step}: {name}"
+        assert np.array_equal(to_np(lo), ref["observation"]) and np.array_equal(to_np(lm), ref["legal_action_mask"])
+        assert_state_equal(State(e, st.packed), ref, where=f"bench step {step}: packed state")
+        total += want["terminated_count"]
+        assert int(tc.item()) == total
+        wa, wt = orc.gae(want["done"], want["value"], want["reward"], np.zeros(n, np.float32), 1.0, 0.95)
+        assert np.array_equal(to_np(adv), wa) and np.array_equal(to_np(tgt), wt), f"step {step}: advantages / targets"
+    assert total > 2 * 8192 and float(adv.abs().max()) > 0
+
+
 def test_flag_synchronised_rollout_equals_barrier_kernel_at_full_size():
     """k_rollout_fs (default at the BASELINE shape) and k_rollout_ws write the same bytes: 8192 x 32, 100 000-row LUT,
     three back-to-back rollouts (state, draw counter and terminated_count carry over)."""
@@ -727,6 +772,32 @@ def test_fused_rollout_kernels_agree_across_the_draw_counter_wrap(dds, oracle):
     ref = oracle.init_random(64, seed=12)
     want = oracle.rollout_random(ref, 16, seed=12, draw_base=2 ** 32 - 7)
     assert np.array_equal(to_np(outs[0][1]), want["action"]) and np.array_equal(to_np(outs[0][5]), want["obs"])
+
+
+@pytest.mark.parametrize("rng0", [2 ** 31 + 3, 2 ** 32 - 6])
+def test_policy_rollout_draw_counter_wraps_mod_2_32(env, rng0):
+    """ONE convention for the action-draw counter (include/brl_hip.h: uint32, wraps): the policy-in-the-loop rollout's
+    device-resident counter holds `rng & 0xFFFFFFFF` — its first sampled actions equal a direct brl_policy_step call
+    with that host draw index, also above 2^31 and across 2^32."""
+    import brl_amd
+    from brl_amd.models import make_forward_pass
+    from brl_amd.utils import SAMPLE, policy_step
+    n, T = 256, 3
+    fp = make_forward_pass("relu", "DeepMind")
+    actor = fp.init(0, device="cuda")
+    roll = brl_amd.make_roll_out(dict(POLICY_CFG, num_steps=T, graph_rollout=False), env, fp, fp)
+    st = env.init(77, num_envs=n)
+    packed0 = st.packed.clone()
+    with torch.no_grad():
+        logits, _ = actor(st.observation.float())
+    rs, traj = roll((actor, None, st, st.observation, 0, rng0), actor)
+    action = torch.empty(n, dtype=torch.int32, device="cuda")
+    policy_step(env, packed0, torch.empty_like(packed0), logits, SAMPLE, rng0 & 0xFFFFFFFF, True, action=action)
+    torch.cuda.synchronize()
+    # (the rollout's forward uses fused-epilogue GEMMs: a draw within ~1e-6 of a CDF boundary may fall the other way; a
+    #  WRONG draw index agrees on well under half of the tables)
+    assert float((action == traj.action[0]).float().mean()) >= 0.98
+    assert rs[5] == rng0 + 4 * T
 
 
 @pytest.mark.parametrize("n", [640, 8192])   # 8192 = BASELINE.json configs[2] (num_envs=8192 duplicate self-play)
@@ -920,11 +991,34 @@ def test_ppo_loop_runs_end_to_end(env, tmp_path):
         assert torch.equal(a, b)
 
 
-def _train_rank(rank, world, port, out_dir):
+def test_latest_opponent_is_a_snapshot_not_the_live_learner(tmp_path):
+    """ppo.py:455-460: the "latest" opponent keeps the PRE-update weights (an immutable pytree in the reference), so
+    imp_opp_after compares new against old.  With the opponent aliased to the live module it is identically 0 and the
+    threshold_model_zoo gate can never trigger."""
+    from brl_amd.train import DEFAULTS, train
+    cfg = dict(DEFAULTS, num_envs=256, num_steps=8, total_timesteps=256 * 8 * 3, minibatch_size=512, update_epochs=4,
+               lut_len=2000, synthetic_lut_files=1, num_eval_envs=64, num_prioritized_envs=1024, num_eval_step=100,
+               lr=3e-3, ratio_model_zoo=0.0, log_path=str(tmp_path), exp_name="s", save_model=False)
+    rs, hist = train(cfg, log=lambda s: None)
+    assert all(h["opponent"] == "latest" for h in hist)
+    assert all(h["opp_weight_delta"] > 0 for h in hist)               # the update moved the learner away from its opponent
+    assert any(h["train/imp_opp_after"] != 0.0 for h in hist)          # new vs old on 1024 boards: not a self-match
+    assert all(h["train/imp_opp_before"] == 0.0 for h in hist)         # a fresh snapshot against itself: every board ties
+
+
+def _two_gpus_or_skip():
+    """RCCL needs one GPU per rank.  torch.cuda.device_count() does not initialise the GPU, so the spawned ranks are still
+    the first to touch their devices."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f"RCCL path needs >= 2 GPUs (one per rank); this box has {n} — covered with gloo ranks sharing the device")
+
+
+def _train_rank(rank, world, port, out_dir, backend="gloo"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
-                      WORLD_SIZE=str(world), BRL_DIST_BACKEND="gloo")
+                      WORLD_SIZE=str(world), BRL_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     from brl_amd.train import DEFAULTS, train
     cfg = dict(DEFAULTS, num_envs=256, num_steps=8, total_timesteps=world * 256 * 8 * 3, minibatch_size=512, update_epochs=2,
                lut_len=2000, synthetic_lut_files=2, hash_size=100_000, num_eval_envs=128, num_prioritized_envs=64,
@@ -933,7 +1027,7 @@ def _train_rank(rank, world, port, out_dir):
     rs, hist = train(cfg, log=lambda *_: None)
     flat = torch.cat([p.detach().reshape(-1) for p in rs[0].parameters()]).cpu()
     torch.save((flat, [h["train/total_loss"] for h in hist], type(rs[1].get("graphed")).__name__,
-                getattr(rs[1].get("graphed"), "world", None)), os.path.join(out_dir, f"rank{rank}.pt"))
+                getattr(rs[1].get("graphed"), "world", None), torch.cuda.current_device()), os.path.join(out_dir, f"rank{rank}.pt"))
     import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()
@@ -952,6 +1046,21 @@ def test_ppo_loop_two_ranks(tmp_path):
     assert len(r0[1]) == 3 and all(np.isfinite(x) for x in r0[1] + r1[1])
     assert r0[1] != r1[1]                      # different shards: different losses ...
     assert torch.equal(r0[0], r1[0])           # ... same parameters (all-reduced gradients)
+
+
+def test_ppo_loop_two_ranks_rccl(tmp_path):
+    """The same loop over RCCL ("nccl"), one GPU per rank — BASELINE configs[4]'s collective path (bucketed gradient
+    all-reduces behind FusedMinibatch's graph segments, opponent-index broadcast, summed counters) on real xGMI links.
+    SKIPPED with a reason on a box with fewer than 2 GPUs."""
+    _two_gpus_or_skip()
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mp.start_processes(_train_rank, args=(2, port, str(tmp_path), "nccl"), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert r0[2] == "FusedMinibatch" and r0[3] == 2 and (r0[4], r1[4]) == (0, 1)   # one device per rank
+    assert len(r0[1]) == 3 and all(np.isfinite(x) for x in r0[1] + r1[1]) and r0[1] != r1[1]
+    assert torch.equal(r0[0], r1[0])
 
 
 def test_ppo_iteration_at_config3_size(tmp_path):
@@ -1234,15 +1343,20 @@ def test_graphed_update_built_after_eager_steps_keeps_adam_state(fused):
         assert torch.allclose(outs[0], outs[1], atol=1e-5, rtol=1e-4)
 
 
-def _fused_rank(rank, world, port, out_dir):
+def _fused_rank(rank, world, port, out_dir, backend="gloo"):
     import sys
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from brl_amd.models import make_forward_pass
     from brl_amd.update import FusedMinibatch, make_update_step
     from tests.test_update_cpu import CFG, fake_batch
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU of the box
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "nccl":                                           # RCCL: one GPU per rank
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU of the box
     fp = make_forward_pass("relu", "DeepMind")
     net = fp.init(11, device="cuda")
     tb, adv, tgt = fake_batch(4, 256, seed=3)                       # the SAME shard on both ranks: mean gradient == own gradient
@@ -1266,6 +1380,28 @@ def test_fused_update_with_gradient_allreduce_two_ranks(tmp_path):
     from tests.test_update_cpu import CFG, fake_batch
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     mp.start_processes(_fused_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(r0[0], r1[0])
+    fp = make_forward_pass("relu", "DeepMind")
+    net = fp.init(11, device="cuda")
+    tb, adv, tgt = fake_batch(4, 256, seed=3)
+    tb = type(tb)(*[x.cuda() for x in tb])
+    _, (total, _) = make_update_step(dict(CFG, minibatch_size=256, update_epochs=1), fp)((net, None, None, None, 0, 5), tb, adv.cuda(), tgt.cuda())
+    single = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()
+    assert torch.allclose(total.cpu(), r0[1], atol=1e-6) and torch.allclose(single, r0[0], atol=1e-6, rtol=1e-5)
+
+
+def test_fused_update_with_gradient_allreduce_two_ranks_rccl(tmp_path):
+    """The same over RCCL ("nccl"), one GPU per rank: the bucketed all-reduces really cross xGMI.  SKIPPED with a reason
+    below 2 GPUs."""
+    _two_gpus_or_skip()
+    import socket
+    import torch.multiprocessing as mp
+    from brl_amd.models import make_forward_pass
+    from brl_amd.update import make_update_step
+    from tests.test_update_cpu import CFG, fake_batch
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mp.start_processes(_fused_rank, args=(2, port, str(tmp_path), "nccl"), nprocs=2, join=True, start_method="spawn")
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert torch.equal(r0[0], r1[0])
     fp = make_forward_pass("relu", "DeepMind")

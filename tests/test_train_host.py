@@ -133,6 +133,20 @@ def test_haiku_pickle_is_read_without_jax(tmp_path, monkeypatch, model, activati
         ckpt.haiku_to_torch(tree, activation, "FAIR" if model == "DeepMind" else "DeepMind")
 
 
+def test_haiku_pickle_reader_refuses_foreign_globals(tmp_path):
+    """A model file is a program: the reader resolves numpy's array reconstruction and plain containers only."""
+    class _Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    for payload in (_Evil(), {"actor_critic/linear": {"w": _Evil()}}):
+        with pytest.raises(pickle.UnpicklingError, match="refusing"):
+            ckpt.load_haiku_pickle(pickle.dumps(payload))
+    # a plain numpy tree (what a jax-free writer would dump) still loads
+    tree = {"actor_critic/linear": {"w": np.ones((480, 4), np.float32), "b": np.zeros(4, np.float32)}}
+    back = ckpt.load_haiku_pickle(pickle.dumps(tree))
+    assert np.array_equal(back["actor_critic/linear"]["w"], tree["actor_critic/linear"]["w"])
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
