@@ -102,6 +102,12 @@ def lib() -> C.CDLL:
         "brl_bias_finalize": [i32, i32, _vp, _vp, _vp, i64, _vp],
         "brl_ppo_stats_at": [i32, _vp, i64, _vp, f32, f32, _vp, _vp, _vp],
         "brl_adam_clip": [i32, _vp, _vp, _vp, _vp, i64, _vp, f32, _vp, f32, f32, f32, f32, f32, _vp, _vp, _vp, _vp],
+        "brl_ppo_heads_loss": [i32, _vp, i64, _vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, i64, f32, f32, f32, i32, i32, i32,
+                               _vp, _vp, _vp, _vp, _vp],
+        "brl_ppo_heads_bwd": [i32, _vp, _vp, i64, _vp, i64, i64, i32, i32, _vp, _vp, _vp, _vp, _vp],
+        "brl_ppo_stats_gram": [i32, _vp, i64, i64, _vp, i64, f32, f32, _vp, _vp, _vp, _vp],
+        "brl_act_bwd_colsum": [i32, _vp, _vp, i64, i64, i64, i32, _vp, _vp],
+        "brl_bias_finalize_ex": [i32, i32, _vp, _vp, _vp, _vp, _vp],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)
@@ -116,7 +122,8 @@ EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_de
            "brl_rollout_random", "brl_policy_step", "brl_policy_step_at", "brl_obs_cast", "brl_gae", "brl_imp_reward", "brl_duplicate_step",
            "brl_eval_step", "brl_eval_reduce", "brl_ppo_loss", "brl_ppo_stats", "brl_ppo_loss_heads", "brl_mb_gather",
            "brl_relu_bwd_colsum", "brl_adam_clip", "brl_bias_finalize", "brl_ppo_stats_at", "brl_policy_step_ex",
-           "brl_eval_step_team", "brl_rollout_random_gae"]
+           "brl_eval_step_team", "brl_rollout_random_gae", "brl_ppo_heads_loss", "brl_ppo_heads_bwd", "brl_ppo_stats_gram",
+           "brl_act_bwd_colsum", "brl_bias_finalize_ex"]
 
 
 def check(rc: int) -> None:

@@ -1608,14 +1608,13 @@ __device__ __forceinline__ float wave_max_f(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void k_ppo_loss(PpoArgs A) {
-  __shared__ float part[4][8];
-  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
-  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
-  const bool valid = b < A.B;
+// One sample (= one wave, lane a = action a): `lg` = the lane's logit (lanes >= 38: ignored), `v` = the critic's value, `g` =
+// the advantage (already normalised when reward_scaling is on).  Writes dlogits / dvalue / illp of the sample and
+// returns its five statistics terms in st[0..4] (valid on every lane).  `illp_lane` = this lane's illegal-action probability.
+__device__ __forceinline__ void ppo_loss_sample(const PpoArgs &A, int64_t b, bool valid, int lane, float lg, float v, float g,
+                                                float (&st)[5], float &illp_lane) {
   const bool in = lane < BRL_NUM_ACTIONS;
   const int64_t bb = valid ? b : 0;
-  const float lg = in ? A.logits[bb * A.ls + lane] : 0.0f;
   const bool legal = in && A.mask[bb * BRL_NUM_ACTIONS + lane] != 0;
   const float invB = 1.0f / (float)A.B;
   // masked policy (src/update.py:12-16, 132-135): log-softmax over the legal actions
@@ -1633,7 +1632,6 @@ __global__ __launch_bounds__(256) void k_ppo_loss(PpoArgs A) {
   const float lp = __shfl(lsel, act & 63, 64);
   const float logratio = lp - A.old_logp[bb];
   const float ratio = expf(logratio);
-  const float g = A.gae[bb];
   const float eps = A.clip_eps;
   const float a1 = ratio * g, a2 = fminf(fmaxf(ratio, 1.0f - eps), 1.0f + eps) * g;
   const float la = -fminf(a1, a2);
@@ -1641,7 +1639,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss(PpoArgs A) {
   const float dratio = ((a1 < a2) || inside) ? -g : 0.0f;  // d(-min(a1, a2)) / d ratio (ties: both branches agree)
   const float dlp = dratio * ratio * invB;
   // value loss (src/update.py:48-60)
-  const float v = A.value[bb * A.vs], ov = A.old_value[bb], t = A.tgt[bb];
+  const float ov = A.old_value[bb], t = A.tgt[bb];
   float vl, dv;
   if (A.value_clipping) {
     const float dcl = fminf(fmaxf(v - ov, -eps), eps);
@@ -1660,17 +1658,31 @@ __global__ __launch_bounds__(256) void k_ppo_loss(PpoArgs A) {
   const float onehot = (lane == act) ? 1.0f : 0.0f;
   const bool live = A.masked ? legal : in;
   const float dz = (live ? dlp * (onehot - psel) : 0.0f) - A.ent_coef * invB * dH;
+  illp_lane = legal ? 0.0f : p2;
   if (valid && in) {
     A.dlogits[b * A.dls + lane] = dz;
-    if (A.illp) A.illp[b * BRL_NUM_ACTIONS + lane] = legal ? 0.0f : p2;
+    if (A.illp) A.illp[b * BRL_NUM_ACTIONS + lane] = illp_lane;
   }
+  if (lane == 0 && valid) A.dvalue[b * A.dvs] = A.vf_coef * dv * invB;
+  st[0] = valid ? vl : 0.0f;
+  st[1] = valid ? la : 0.0f;
+  st[2] = valid ? H : 0.0f;
+  st[3] = valid ? (ratio - 1.0f) - logratio : 0.0f;
+  st[4] = (valid && fabsf(ratio - 1.0f) > eps) ? 1.0f : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_ppo_loss(PpoArgs A) {
+  __shared__ float part[4][8];
+  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  const bool valid = b < A.B;
+  const int64_t bb = valid ? b : 0;
+  const float lg = (lane < BRL_NUM_ACTIONS) ? A.logits[bb * A.ls + lane] : 0.0f;
+  float st[5], ill;
+  ppo_loss_sample(A, b, valid, lane, lg, A.value[bb * A.vs], A.gae[bb], st, ill);
   if (lane == 0) {
-    if (valid) A.dvalue[b * A.dvs] = A.vf_coef * dv * invB;
-    part[wave][0] = valid ? vl : 0.0f;
-    part[wave][1] = valid ? la : 0.0f;
-    part[wave][2] = valid ? H : 0.0f;
-    part[wave][3] = valid ? (ratio - 1.0f) - logratio : 0.0f;
-    part[wave][4] = (valid && fabsf(ratio - 1.0f) > eps) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 5; k++) part[wave][k] = st[k];
   }
   __syncthreads();
   if (threadIdx.x < 8) {  // per-block partial sums in a fixed order (deterministic statistics)
@@ -1747,6 +1759,7 @@ __global__ __launch_bounds__(512) void k_ppo_stats(const float *partials, int64_
 }
 
 #include "ppo_update.hpp"  // k_mb_gather, k_relu_bwd_colsum, k_adam_norm / k_adam_apply
+#include "ppo_heads.hpp"   // k_heads_loss, k_heads_bwd, k_ppo_stats2: the 39-column head products and what hangs on them
 
 // =====================================================================================
 // C-ABI
@@ -2346,6 +2359,87 @@ extern "C" int brl_bias_finalize(int device, int nseg, const float *const *scrat
     maxc = cols[i] > maxc ? cols[i] : maxc;
   }
   hipLaunchKernelGGL(k_bias_finalize, dim3((unsigned)((maxc + 63) / 64), (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, S);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_act_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, int act,
+                                  float *scratch, void *stream) {
+  NEED(dh && h && scratch && rows > 0 && cols > 0 && ld >= cols, "dh / h / scratch / rows / cols / ld");
+  NEED(cols % 4 == 0 && ld % 4 == 0, "cols and ld multiples of 4");
+  NEED(act == 0 || act == 1, "act (0 ReLU, 1 tanh)");
+  HIP_TRY(hipSetDevice(device));
+  const int64_t tiles = (rows + 15) / 16;
+  hipLaunchKernelGGL(k_relu_bwd_tiles4, dim3((unsigned)((cols + 255) / 256), (unsigned)tiles), dim3(256), 0, (hipStream_t)stream,
+                     dh, h, rows, cols, ld, scratch, act);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_bias_finalize_ex(int device, int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles,
+                                    float *const *out, void *stream) {
+  NEED(nseg >= 1 && nseg <= BIAS_MAX_SEGS && partials && cols && tiles && out, "nseg / partials / cols / tiles / out");
+  HIP_TRY(hipSetDevice(device));
+  BiasSegs S{};
+  S.n = nseg;
+  int64_t maxc = 0;
+  for (int i = 0; i < nseg; i++) {
+    NEED(partials[i] && out[i] && cols[i] > 0 && tiles[i] > 0, "segment");
+    S.tiles[i] = tiles[i]; S.partials[i] = partials[i]; S.cols[i] = cols[i]; S.db[i] = out[i];
+    maxc = cols[i] > maxc ? cols[i] : maxc;
+  }
+  hipLaunchKernelGGL(k_bias_finalize, dim3((unsigned)((maxc + 63) / 64), (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, S);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_ppo_heads_loss(int device, const float *h, int64_t ldh, const float *head_w, const float *head_b, int64_t hidden,
+                                  const uint8_t *mask, const int32_t *action, const float *old_value, const float *old_log_prob,
+                                  const float *gae, const float *targets, int64_t batch, float clip_eps, float vf_coef,
+                                  float ent_coef, int masked, int value_clipping, int reward_scaling, float *heads_out,
+                                  float *dheads, float *partials, float *gram_partials, void *stream) {
+  NEED(batch > 0 && hidden > 0 && hidden % 16 == 0 && ldh >= hidden && ldh % 4 == 0, "batch / hidden (a multiple of 16) / ldh");
+  NEED(h && head_w && head_b && mask && action && old_value && old_log_prob && gae && targets, "NULL input array");
+  NEED(dheads && partials, "NULL output array");
+  HIP_TRY(hipSetDevice(device));
+  constexpr int64_t HS = BRL_NUM_ACTIONS + 1;
+  HeadsLossArgs A{};
+  A.h = h; A.ldh = ldh; A.Wh = head_w; A.bh = head_b; A.H = (int)hidden;
+  A.P = PpoArgs{nullptr, HS, nullptr, mask, action, old_value, old_log_prob, gae, targets, batch, clip_eps, vf_coef,
+                ent_coef, masked, value_clipping, dheads, dheads + BRL_NUM_ACTIONS, partials, nullptr, HS, HS, HS};
+  A.heads_out = heads_out; A.gram_partials = gram_partials; A.reward_scaling = reward_scaling;
+  hipLaunchKernelGGL(k_heads_loss, dim3((unsigned)((batch + HD_ROWS - 1) / HD_ROWS)), dim3(HD_WAVES * 64), 0, (hipStream_t)stream, A);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_ppo_heads_bwd(int device, const float *dheads, const float *h, int64_t ldh, const float *head_w, int64_t batch,
+                                 int64_t hidden, int act, int nsplit, float *dw_partials, float *db_partials, float *dh,
+                                 float *tile_sums, void *stream) {
+  NEED(batch > 0 && hidden > 0 && hidden % 256 == 0 && ldh >= hidden && ldh % 4 == 0, "batch / hidden (a multiple of 256) / ldh");
+  NEED(dheads && h && head_w && dw_partials && db_partials && dh && tile_sums, "NULL array");
+  NEED(act == 0 || act == 1, "act (0 ReLU, 1 tanh)");
+  NEED(nsplit >= 1 && (batch + nsplit - 1) / nsplit <= 64, "nsplit: at most 64 rows per split");
+  HIP_TRY(hipSetDevice(device));
+  HeadsBwdArgs A{};
+  A.dheads = dheads; A.h = h; A.ldh = ldh; A.Wh = head_w; A.B = batch; A.H = (int)hidden; A.act = act; A.nsplit = nsplit;
+  A.rows_per_split = (int)((batch + nsplit - 1) / nsplit);
+  A.dWh_partials = dw_partials; A.dbh_partials = db_partials; A.dh = dh; A.tile_sums = tile_sums;
+  A.blocks_a = (int)(hidden / HB_JT) * nsplit;
+  const int64_t blocks_b = (hidden / 256) * ((batch + HB_ROWS - 1) / HB_ROWS);
+  hipLaunchKernelGGL(k_heads_bwd, dim3((unsigned)(A.blocks_a + blocks_b)), dim3(256), 0, (hipStream_t)stream, A);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_ppo_stats_gram(int device, const float *partials, int64_t npartials, int64_t batch, const float *gram_partials,
+                                  int64_t ngram, float vf_coef, float ent_coef, float *out_rows, const int32_t *row_index,
+                                  float *vec_out, void *stream) {
+  NEED(partials && out_rows && npartials > 0 && batch > 0, "partials / out_rows / npartials / batch");
+  NEED(gram_partials && ngram > 0, "gram_partials / ngram");
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(k_ppo_stats2, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, npartials, batch, gram_partials, ngram,
+                     vf_coef, ent_coef, out_rows, row_index, vec_out);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

@@ -1,0 +1,381 @@
+// ppo_heads.hpp — the 39-column head of the actor-critic (38 logits + 1 value: src/models.py:30-33) inside one PPO minibatch
+// step (src/update.py:90-167).  Its three products are ~80 MFLOP each — nothing for the matrix cores of a 256-CU chip — yet
+// as library GEMMs (N = 39 or K = 39) they cost 9.5-13 us apiece plus the launches around them (loss 5 us, Gram matrix 5.6 us,
+// head column sums 5.3 us, top layer's ReLU backward 6.2 us: profiles/r02/r02w_policy_path_kernel_stats.txt).  Here:
+//   k_heads_loss  heads = h W_h^T + b_h (16 samples per workgroup, the K = 1024 sum split over 8 waves of v_mfma_f32_16x16x4_f32,
+//                 partial sums meet in LDS) -> `_loss_fn` of those samples (ppo_loss_sample: one wave per sample) -> d(loss)/d(heads),
+//                 the statistics partials and the workgroup's 38 x 38 Gram-matrix partial of the illegal-action probabilities;
+//   k_heads_bwd   role A: dW_h = d(heads)^T h and db_h = column sums of d(heads), per batch split (deterministic partials,
+//                 summed by k_bias_finalize);  role B: dh = d(heads) W_h, times the top layer's activation derivative, with
+//                 that layer's bias-gradient column sums per 16-row tile;
+//   k_ppo_stats2  the logged statistics + the illegal-action spectral norm from the Gram partials (4 squarings by the whole block
+//                 + 16 power-iteration steps by one wave = G^256 v, like k_ppo_stats' 8 squarings, in ~3 us instead of 62).
+// Included by brl_kernels.hip after ppo_update.hpp.
+#pragma once
+
+constexpr int HD_ROWS = 16;    // samples per workgroup of k_heads_loss
+constexpr int HD_WAVES = 8;    // waves per workgroup = K splits
+constexpr int HD_NOUT = BRL_NUM_ACTIONS + 1;   // 39
+constexpr int HD_GRAM = BRL_NUM_ACTIONS * BRL_NUM_ACTIONS;   // 1444
+
+typedef float hd_f32x4 __attribute__((ext_vector_type(4)));
+
+struct HeadsLossArgs {
+  const float *h;       // [B, H] the last hidden layer's output
+  int64_t ldh;
+  const float *Wh;      // [39, H]: actor rows, then the critic row
+  const float *bh;      // [39]
+  int H;                // % 16 == 0
+  PpoArgs P;            // .logits / .value unused (computed here); outputs in the merged [B, 39] layout
+  float *heads_out;     // [B, 39] or NULL
+  float *gram_partials; // [ceil(B / 16)][1444] or NULL
+  int reward_scaling;   // src/update.py:31-44: advantages normalised over the minibatch (jnp std: ddof = 0)
+};
+
+__global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
+  __shared__ float red[HD_WAVES][3][4][64];            // K-split partial sums (24 KB)
+  __shared__ float illp_s[HD_ROWS][BRL_NUM_ACTIONS + 2];
+  __shared__ float part_s[HD_ROWS][8];
+  __shared__ float rs_red[HD_WAVES], rs_stat[2];
+  const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t B = A.P.B, row0 = (int64_t)blockIdx.x * HD_ROWS;
+
+  // ---- optional: mean / std of the minibatch's advantages (every workgroup computes them itself, in the same fixed
+  // order: identical on all of them, no cross-workgroup hand-off)
+  float adv_mean = 0.0f, adv_inv = 1.0f;
+  if (A.reward_scaling) {
+    float s = 0.0f;
+    for (int64_t i = tid; i < B; i += HD_WAVES * 64) s += A.P.gae[i];
+    s = wave_sum_f(s);
+    if (lane == 0) rs_red[w] = s;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.0f;
+      for (int k = 0; k < HD_WAVES; k++) t += rs_red[k];
+      rs_stat[0] = t / (float)B;
+    }
+    __syncthreads();
+    adv_mean = rs_stat[0];
+    float q = 0.0f;
+    for (int64_t i = tid; i < B; i += HD_WAVES * 64) {
+      const float d = A.P.gae[i] - adv_mean;
+      q += d * d;
+    }
+    q = wave_sum_f(q);
+    __syncthreads();
+    if (lane == 0) rs_red[w] = q;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.0f;
+      for (int k = 0; k < HD_WAVES; k++) t += rs_red[k];
+      rs_stat[1] = 1.0f / (sqrtf(t / (float)B) + 1e-8f);
+    }
+    __syncthreads();
+    adv_inv = rs_stat[1];
+  }
+
+  // ---- heads of 16 samples: D[sample][n] = sum_k h[sample][k] W_h[n][k]; wave w takes the 16-deep K groups w, w + 8, ..
+  // lane (r, kq): A row = sample r, B column = head n = 16 nb + r, K = 16 g + 4 kq + s in MFMA step s (the K order inside a
+  // group is permuted the same way for both operands)
+  const int r = lane & 15, kq = lane >> 4;
+  const int64_t arow = (row0 + r < B) ? row0 + r : B - 1;
+  const float *ap = A.h + arow * A.ldh + 4 * kq;
+  const float *bp[3];
+  bool bok[3];
+#pragma unroll
+  for (int nb = 0; nb < 3; nb++) {
+    const int n = 16 * nb + r;
+    bok[nb] = n < HD_NOUT;
+    bp[nb] = A.Wh + (int64_t)(bok[nb] ? n : 0) * A.H + 4 * kq;
+  }
+  hd_f32x4 acc[3];
+#pragma unroll
+  for (int nb = 0; nb < 3; nb++) acc[nb] = hd_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ngroups = A.H / 16;
+  for (int g0 = w; g0 < ngroups; g0 += 4 * HD_WAVES) {   // 4 groups per pass: 16 loads in flight per lane
+    hd_f32x4 av[4], bv[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int g = g0 + u * HD_WAVES;
+      const int gc = (g < ngroups) ? g : g0;
+      av[u] = *reinterpret_cast<const hd_f32x4 *>(ap + 16 * gc);
+#pragma unroll
+      for (int nb = 0; nb < 3; nb++) bv[u][nb] = *reinterpret_cast<const hd_f32x4 *>(bp[nb] + 16 * gc);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (g0 + u * HD_WAVES >= ngroups) break;
+#pragma unroll
+      for (int nb = 0; nb < 3; nb++) {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][s], bok[nb] ? bv[u][nb][s] : 0.0f, acc[nb], 0, 0, 0);
+      }
+    }
+  }
+  // accumulator register q of lane (c, rq): D[sample 4 rq + q][head 16 nb + c]
+#pragma unroll
+  for (int nb = 0; nb < 3; nb++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) red[w][nb][q][lane] = acc[nb][q];
+  __syncthreads();
+
+  // ---- `_loss_fn` (src/update.py:90-167): wave w takes samples 2 w and 2 w + 1; lane a = head a
+  for (int sl = 2 * w; sl < 2 * w + 2; sl++) {
+    const int64_t b = row0 + sl;
+    const bool valid = b < B;
+    float hv = 0.0f;
+    if (lane < HD_NOUT) {
+      const int nb = lane >> 4, c = lane & 15, q = sl & 3, rq = sl >> 2;
+      hv = A.bh[lane];
+#pragma unroll
+      for (int k = 0; k < HD_WAVES; k++) hv += red[k][nb][q][16 * rq + c];   // fixed order
+      if (valid && A.heads_out) A.heads_out[b * HD_NOUT + lane] = hv;
+    }
+    const float v = __shfl(hv, BRL_NUM_ACTIONS, 64);
+    const int64_t bb = valid ? b : 0;
+    const float g = A.reward_scaling ? (A.P.gae[bb] - adv_mean) * adv_inv : A.P.gae[bb];
+    float st[5], ill;
+    ppo_loss_sample(A.P, b, valid, lane, hv, v, g, st, ill);
+    if (lane < BRL_NUM_ACTIONS) illp_s[sl][lane] = valid ? ill : 0.0f;
+    if (lane == 0) {   // (st is wave-uniform)
+#pragma unroll
+      for (int k = 0; k < 8; k++) part_s[sl][k] = (k < 5) ? st[k] : 0.0f;
+    }
+  }
+  __syncthreads();
+  if (tid < 8) {   // per-workgroup partial sums over its 16 samples, in order (deterministic statistics)
+    float s = 0.0f;
+    for (int k = 0; k < HD_ROWS; k++) s += part_s[k][tid];
+    A.P.partials[(int64_t)blockIdx.x * 8 + tid] = s;
+  }
+  if (A.gram_partials != nullptr) {   // G_wg[i][j] = sum over the workgroup's samples of illp[i] illp[j]
+    for (int e = tid; e < HD_GRAM; e += HD_WAVES * 64) {
+      const int i = e / BRL_NUM_ACTIONS, j = e - i * BRL_NUM_ACTIONS;
+      float s = 0.0f;
+#pragma unroll
+      for (int k = 0; k < HD_ROWS; k++) s += illp_s[k][i] * illp_s[k][j];
+      A.gram_partials[(int64_t)blockIdx.x * HD_GRAM + e] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward of the head.  act: 0 = ReLU (derivative 1 where the layer's output > 0), 1 = tanh (1 - output^2)
+constexpr int HB_JT = 64;       // role A: columns of h per workgroup
+constexpr int HB_NG = 10;       // role A: heads per thread (4 groups of 10 >= 39)
+constexpr int HB_ROWS = 16;     // role B: rows per workgroup (= the tile of the bias-gradient column sums)
+
+struct HeadsBwdArgs {
+  const float *dheads;   // [B, 39]
+  const float *h;        // [B, H] the last hidden layer's output
+  int64_t ldh;
+  const float *Wh;       // [39, H]
+  int64_t B;
+  int H;                 // % 256 == 0
+  int act;
+  int nsplit;            // role A: batch splits
+  int rows_per_split;    // ceil(B / nsplit) <= 64
+  float *dWh_partials;   // [nsplit][39 * H]
+  float *dbh_partials;   // [nsplit][39]
+  float *dh;             // [B, H]: d(loss)/d(pre-activation of the last hidden layer)
+  float *tile_sums;      // [ceil(B / 16)][H]: its column sums per 16-row tile (bias gradient)
+  int blocks_a;          // (H / 64) * nsplit
+};
+
+__global__ __launch_bounds__(256) void k_heads_bwd(HeadsBwdArgs A) {
+  __shared__ __attribute__((aligned(16))) float dh_s[64][HD_NOUT + 1];   // d(heads) rows of this workgroup (pad: 40 floats)
+  __shared__ float4 cs_s[4][64];
+  const int tid = (int)threadIdx.x;
+  if ((int)blockIdx.x < A.blocks_a) {
+    // ---- role A: dW_h[n][j] = sum_b d(heads)[b][n] h[b][j] over this split's rows; thread = (column j, head group ng)
+    const int jt = (int)blockIdx.x % (A.H / HB_JT), sp = (int)blockIdx.x / (A.H / HB_JT);
+    const int64_t b0 = (int64_t)sp * A.rows_per_split;
+    const int64_t left = A.B - b0;
+    const int nb = (int)((left < A.rows_per_split) ? (left > 0 ? left : 0) : A.rows_per_split);
+    for (int e = tid; e < nb * HD_NOUT; e += 256) {
+      const int rr = e / HD_NOUT, c = e - rr * HD_NOUT;
+      dh_s[rr][c] = A.dheads[(b0 + rr) * HD_NOUT + c];
+    }
+    if (tid < 64) dh_s[tid][HD_NOUT] = 0.0f;   // the 40th "head" (group 3 has 9 real ones)
+    __syncthreads();
+    const int j = tid & 63, ng = tid >> 6;
+    float acc[HB_NG];
+#pragma unroll
+    for (int q = 0; q < HB_NG; q++) acc[q] = 0.0f;
+    const float *hp = A.h + b0 * A.ldh + jt * HB_JT + j;
+    for (int rr = 0; rr < nb; rr += 4) {   // 4 rows of h in flight
+      float hv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) hv[u] = hp[(int64_t)((rr + u < nb) ? rr + u : rr) * A.ldh];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (rr + u >= nb) break;
+        const float2 *dp = reinterpret_cast<const float2 *>(&dh_s[rr + u][ng * HB_NG]);   // (40-float rows, 10-float groups: 8-byte aligned)
+#pragma unroll
+        for (int q = 0; q < HB_NG / 2; q++) {
+          const float2 d = dp[q];
+          acc[2 * q] += d.x * hv[u];
+          acc[2 * q + 1] += d.y * hv[u];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < HB_NG; q++) {
+      const int n = ng * HB_NG + q;
+      if (n < HD_NOUT) A.dWh_partials[(int64_t)sp * HD_NOUT * A.H + (int64_t)n * A.H + jt * HB_JT + j] = acc[q];
+    }
+    if (jt == 0 && tid < HD_NOUT) {   // db_h partial: column sums of d(heads) over the split, in row order
+      float s = 0.0f;
+      for (int rr = 0; rr < nb; rr++) s += dh_s[rr][tid];
+      A.dbh_partials[sp * HD_NOUT + tid] = s;
+    }
+    return;
+  }
+  // ---- role B: dh[b][j] = act'(h[b][j]) * sum_n d(heads)[b][n] W_h[n][j]; workgroup = 16 rows x 256 columns,
+  // thread = (4 columns c4, rows rg, rg + 4, rg + 8, rg + 12)
+  const int bb = (int)blockIdx.x - A.blocks_a;
+  const int ct = bb % (A.H / 256), rt = bb / (A.H / 256);
+  const int64_t r0 = (int64_t)rt * HB_ROWS;
+  for (int e = tid; e < HB_ROWS * HD_NOUT; e += 256) {
+    const int rr = e / HD_NOUT, c = e - rr * HD_NOUT;
+    dh_s[rr][c] = (r0 + rr < A.B) ? A.dheads[(r0 + rr) * HD_NOUT + c] : 0.0f;
+  }
+  __syncthreads();
+  const int c4 = tid & 63, rg = tid >> 6;
+  const int col = ct * 256 + 4 * c4;
+  float4 acc[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 hv[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {   // the gate's operand, issued before the product
+    const int64_t rw = r0 + rg + 4 * u;
+    hv[u] = *reinterpret_cast<const float4 *>(A.h + ((rw < A.B) ? rw : A.B - 1) * A.ldh + col);
+  }
+  const float *wp = A.Wh + col;
+#pragma unroll 3
+  for (int n = 0; n < HD_NOUT; n++) {
+    const float4 wv = *reinterpret_cast<const float4 *>(wp + (int64_t)n * A.H);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const float d = dh_s[rg + 4 * u][n];
+      acc[u].x += d * wv.x; acc[u].y += d * wv.y; acc[u].z += d * wv.z; acc[u].w += d * wv.w;
+    }
+  }
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int64_t rw = r0 + rg + 4 * u;
+    float4 z;
+    if (A.act == 0) {
+      z = make_float4(hv[u].x > 0.f ? acc[u].x : 0.f, hv[u].y > 0.f ? acc[u].y : 0.f, hv[u].z > 0.f ? acc[u].z : 0.f,
+                      hv[u].w > 0.f ? acc[u].w : 0.f);
+    } else {
+      z = make_float4(acc[u].x * (1.0f - hv[u].x * hv[u].x), acc[u].y * (1.0f - hv[u].y * hv[u].y),
+                      acc[u].z * (1.0f - hv[u].z * hv[u].z), acc[u].w * (1.0f - hv[u].w * hv[u].w));
+    }
+    if (rw < A.B) {
+      *reinterpret_cast<float4 *>(A.dh + rw * (int64_t)A.H + col) = z;
+      cs.x += z.x; cs.y += z.y; cs.z += z.z; cs.w += z.w;
+    }
+  }
+  cs_s[rg][c4] = cs;
+  __syncthreads();
+  if (rg == 0) {
+    const float4 a = cs_s[0][c4], b = cs_s[1][c4], c = cs_s[2][c4], e = cs_s[3][c4];
+    *reinterpret_cast<float4 *>(A.tile_sums + (int64_t)rt * A.H + col) =
+        make_float4((a.x + b.x) + (c.x + e.x), (a.y + b.y) + (c.y + e.y), (a.z + b.z) + (c.z + e.z), (a.w + b.w) + (c.w + e.w));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The logged statistics of one minibatch step from k_heads_loss's per-workgroup partials, one block of 256 threads:
+//   out[0] total  [1] value_loss  [2] loss_actor  [3] entropy  [4] approx_kl  [5] clipfrac  [6] illegal-action norm / 2  [7] 0
+// The norm = largest singular value / 2 of the non-negative [B, 38] matrix P of illegal-action probabilities
+// (`jnp.linalg.norm(..., ord=2) / 2`, src/update.py:138-141) = sqrt(top eigenvalue of G = P^T P) / 2 with G the sum of the
+// workgroups' Gram partials: M = G / trace, squared 4 times by the whole block (M symmetric: (M^2)[i][j] = sum_k M[k][i] M[k][j]
+// — lane-contiguous, conflict-free LDS reads — rescaled by ONE reciprocal of the trace per squaring), then 16 steps of
+// v <- M^16 v / |.| by one wave (= G^256 v, the Perron vector to (l2 / l1)^256), Rayleigh quotient with the original G.
+// v1 and the norm are also written to `vec_out` [40] (v1[0..37], sigma_1, 0) when given: the gradient of the norm needs them.
+__global__ __launch_bounds__(256) void k_ppo_stats2(const float *partials, int64_t nblk, int64_t batch, const float *gram_partials,
+                                                    int64_t ngram, float vf_coef, float ent_coef, float *out, const int32_t *row_index,
+                                                    float *vec_out) {
+  if (row_index != nullptr) out += 8 * (int64_t)(*row_index);
+  constexpr int D = BRL_NUM_ACTIONS, DD = D * D;
+  __shared__ float g[DD], m[DD], t[DD], vec[64], st[8], tr_s;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (wv == 3) {   // wave 3: the five statistics, one after the other — lane l adds rows l, l + 64, ... in order, then a fixed butterfly
+    for (int k = 0; k < 5; k++) {
+      float s = 0.0f;
+      for (int64_t i = lane; i < nblk; i += 64) s += partials[i * 8 + k];
+      s = wave_sum_f(s);
+      if (lane == 0) st[k] = s / (float)batch;
+    }
+  }
+  for (int e = tid; e < DD; e += 256) {   // G = sum of the Gram partials, in workgroup order; 8 loads in flight
+    float s = 0.0f;
+    int64_t i = 0;
+    for (; i + 8 <= ngram; i += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = gram_partials[(i + u) * DD + e];
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; i < ngram; i++) s += gram_partials[i * DD + e];
+    g[e] = s;
+  }
+  __syncthreads();
+  auto trace_of = [&](const float *x) {   // wave 0, fixed butterfly -> 1 / max(trace, tiny) for everybody
+    if (wv == 0) {
+      const float s = wave_sum_f((lane < D) ? x[lane * D + lane] : 0.0f);
+      if (lane == 0) tr_s = 1.0f / fmaxf(s, 1.17549435e-38f);
+    }
+    __syncthreads();
+    return tr_s;
+  };
+  float inv = trace_of(g);
+  for (int e = tid; e < DD; e += 256) m[e] = g[e] * inv;
+  __syncthreads();
+  for (int it = 0; it < 4; it++) {
+    for (int e = tid; e < DD; e += 256) {
+      const int i = e / D, j = e - i * D;
+      float s = 0.0f;
+#pragma unroll 2
+      for (int k = 0; k < D; k++) s += m[k * D + i] * m[k * D + j];
+      t[e] = s;
+    }
+    __syncthreads();
+    inv = trace_of(t);
+    for (int e = tid; e < DD; e += 256) m[e] = t[e] * inv;
+    __syncthreads();
+  }
+  if (wv == 0) {   // v <- M v / |M v| sixteen times, M = (G / trace)^16; lane i owns v[i]; M symmetric: row i = column i
+    float v = (lane < D) ? 1.0f : 0.0f;
+    for (int it = 0; it < 16; it++) {
+      vec[lane] = v;
+      wave_lds_order();
+      float s = 0.0f;
+      if (lane < D)
+        for (int k = 0; k < D; k++) s += m[k * D + lane] * vec[k];
+      const float nrm = wave_sum_f(s * s);
+      v = (nrm > 0.0f) ? s * (1.0f / sqrtf(nrm)) : v;
+      wave_lds_order();
+    }
+    vec[lane] = v;
+    wave_lds_order();
+    float gv = 0.0f;
+    if (lane < D)
+      for (int k = 0; k < D; k++) gv += g[k * D + lane] * vec[k];
+    const float num = wave_sum_f(v * gv), den = wave_sum_f(v * v);
+    const float sigma = sqrtf(fmaxf(num / fmaxf(den, 1.17549435e-38f), 0.0f));
+    if (vec_out != nullptr && lane < D + 2) vec_out[lane] = (lane < D) ? v * (1.0f / sqrtf(fmaxf(den, 1.17549435e-38f))) : ((lane == D) ? sigma : 0.0f);
+    if (lane == 0) {
+      out[6] = 0.5f * sigma;
+      out[0] = st[1] + vf_coef * st[0] - ent_coef * st[2];
+      out[1] = st[0]; out[2] = st[1]; out[3] = st[2]; out[4] = st[3]; out[5] = st[4];
+      out[7] = 0.0f;
+    }
+  }
+}

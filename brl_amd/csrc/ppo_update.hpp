@@ -87,8 +87,9 @@ __global__ __launch_bounds__(256) void k_relu_bwd_tiles(float *dh, const float *
 }
 
 // the same for cols % 4 == 0 (the hidden layers): float4 accesses, 16-row tiles, a block covers 256 columns
+// act: 0 = ReLU (dz = dh where h > 0), 1 = tanh (dz = dh * (1 - h^2): src/models.py:16 `activation == "tanh"`)
 __global__ __launch_bounds__(256) void k_relu_bwd_tiles4(float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld,
-                                                          float *partials) {
+                                                          float *partials, int act = 0) {
   __shared__ float4 part[4][64];
   const int cg = (int)(threadIdx.x & 63u), rg = (int)(threadIdx.x >> 6);
   const int64_t col = ((int64_t)blockIdx.x * 64 + cg) * 4, r0 = (int64_t)blockIdx.y * 16 + rg;
@@ -115,8 +116,11 @@ __global__ __launch_bounds__(256) void k_relu_bwd_tiles4(float *dh, const float 
   for (int k = 0; k < 4; k++) {
     const int64_t r = r0 + 4 * k;
     const bool v = cv && r < rows;
-    const float4 z = make_float4((v && hv[k].x > 0.f) ? d[k].x : 0.f, (v && hv[k].y > 0.f) ? d[k].y : 0.f,
-                                 (v && hv[k].z > 0.f) ? d[k].z : 0.f, (v && hv[k].w > 0.f) ? d[k].w : 0.f);
+    const float4 z = (act == 0 || h == nullptr)
+        ? make_float4((v && hv[k].x > 0.f) ? d[k].x : 0.f, (v && hv[k].y > 0.f) ? d[k].y : 0.f,
+                      (v && hv[k].z > 0.f) ? d[k].z : 0.f, (v && hv[k].w > 0.f) ? d[k].w : 0.f)
+        : make_float4(v ? d[k].x * (1.f - hv[k].x * hv[k].x) : 0.f, v ? d[k].y * (1.f - hv[k].y * hv[k].y) : 0.f,
+                      v ? d[k].z * (1.f - hv[k].z * hv[k].z) : 0.f, v ? d[k].w * (1.f - hv[k].w * hv[k].w) : 0.f);
     if (h != nullptr && cv && r < rows) *reinterpret_cast<float4 *>(dh + r * ld + col) = z;
     s.x += z.x; s.y += z.y; s.z += z.z; s.w += z.w;
   }

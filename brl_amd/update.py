@@ -240,9 +240,11 @@ class FusedMinibatch:
 
     @staticmethod
     def supports(config, params) -> bool:
+        # the DeepMind MLPs (4 / 6 / 8 x 1024) with either activation (src/models.py:16), reward_scaling included; a non-zero
+        # illegal_action_l2norm_coef (the spectral norm then needs a gradient) and the FAIR net take the autograd path
         return (bool(config.get("fused_update", True)) and str(getattr(params, "model", "")).startswith("DeepMind")
-                and getattr(params, "act", None) is torch.relu and not config.get("illegal_action_l2norm_coef", 0.0)
-                and not config.get("reward_scaling", False)
+                and getattr(params, "act", None) in (torch.relu, torch.tanh) and not config.get("illegal_action_l2norm_coef", 0.0)
+                and params.body[0].weight.shape[0] % 256 == 0
                 and next(params.parameters()).is_cuda and next(params.parameters()).dtype == torch.float32)
 
     def __init__(self, config, params, opt, mbs: int, device, world: int = 1):
@@ -309,17 +311,26 @@ class FusedMinibatch:
         self.action = torch.zeros(B, dtype=torch.int32, device=device)
         self.old_v, self.old_lp, self.adv, self.tgt = f(B), f(B), f(B), f(B)
         self.dheads = f(B, K)
-        self.partials = f((B + 3) // 4, 8)
-        self.illp = f(B, 38)
+        self.H, self.K = H, K
+        self.act = 0 if params.act is torch.relu else 1
+        groups = (B + 15) // 16                        # 16-sample groups of brl_ppo_heads_loss / 16-row tiles of the column sums
+        self.groups = groups
+        self.partials = f(groups, 8)
+        self.gram_partials = f(groups, 38 * 38)
         self.out = f(8)
         self.scratch = f(1024)
-        tiles = (B + 15) // 16
-        self.tile_sums = [f(tiles * H) for _ in body] + [f(tiles * K)]   # per-layer partial column sums (bias gradients)
+        self.nsplit = (B + 63) // 64                   # batch splits of the head's weight / bias gradient (brl_ppo_heads_bwd)
+        self.dwh_partials = f(self.nsplit, K * H)
+        self.dbh_partials = f(self.nsplit, K)
+        self.tile_sums = [f(groups * H) for _ in body]   # per-layer partial column sums (bias gradients)
         import ctypes as C
-        nseg = len(body) + 1
-        self._seg_scratch = (C.c_void_p * nseg)(*[t.data_ptr() for t in self.tile_sums])
-        self._seg_cols = (C.c_int64 * nseg)(*([H] * len(body) + [K]))
-        self._seg_db = (C.c_void_p * nseg)(*([g.data_ptr() for g in self.Gb] + [self.Gbh.data_ptr()]))
+        # one launch finishes every sum of partials: the hidden layers' bias gradients, the head's bias and weight gradients
+        nseg = len(body) + 2
+        self._seg_scratch = (C.c_void_p * nseg)(*([t.data_ptr() for t in self.tile_sums]
+                                                  + [self.dbh_partials.data_ptr(), self.dwh_partials.data_ptr()]))
+        self._seg_cols = (C.c_int64 * nseg)(*([H] * len(body) + [K, K * H]))
+        self._seg_tiles = (C.c_int64 * nseg)(*([groups] * len(body) + [self.nsplit, self.nsplit]))
+        self._seg_db = (C.c_void_p * nseg)(*([g.data_ptr() for g in self.Gb] + [self.Gbh.data_ptr(), self.GWh.data_ptr()]))
         self._nseg = nseg
         self._log_cap = int(config.get("update_log_capacity", 16384))   # minibatch steps of one update_step call
         self.log = f(self._log_cap, 8)                                  # static: the captured statistics launch writes row mb_index
@@ -362,7 +373,8 @@ class FusedMinibatch:
                     with torch.cuda.graph(g, pool=pool), torch.no_grad():
                         seg()
                     self.segs.append(g)
-                self.buckets = [self.GWh] + [self.GW[l] for l in range(nl - 1, -1, -1)] + [self.G_bias]
+                # (the head's weight gradient is finished by _seg_fin, beside the bias gradients: contiguous in the flat buffer)
+                self.buckets = [None] + [self.GW[l] for l in range(nl - 1, -1, -1)] + [self.G[wa.start:ba.start + K]]
                 self.graph = self.segs[0]
         finally:
             with torch.no_grad():
@@ -376,76 +388,84 @@ class FusedMinibatch:
         self._seg_fin()
 
     def _seg_head(self):
-        """forward, loss + output gradients, the logged statistics (parallel branch), backward of the merged head"""
+        """forward, heads + loss + output gradients (one launch), the logged statistics (parallel branch), backward of the
+        merged head down to the top hidden layer's pre-activation (one launch)"""
         L, chk, B = self.lib, self.capi.check, self.mbs
         s = torch.cuda.current_stream().cuda_stream
         di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         cfg = self.cfg
         x = self.x0
-        for l, (W, b) in enumerate(zip(self.W, self.b)):          # forward: bias + ReLU in the GEMM epilogue
-            if self.static:
-                x = torch._addmm_activation(b, x, W.t(), use_gelu=False, out=self.h[l])
+        for l, (W, b) in enumerate(zip(self.W, self.b)):          # forward: bias + activation
+            if self.act == 0:                                     # ReLU in the GEMM epilogue
+                if self.static:
+                    x = torch._addmm_activation(b, x, W.t(), use_gelu=False, out=self.h[l])
+                else:
+                    x = self.h[l] = torch._addmm_activation(b, x, W.t(), use_gelu=False)
             else:
-                x = self.h[l] = torch._addmm_activation(b, x, W.t(), use_gelu=False)
-        heads = torch.addmm(self.bh, x, self.Wh.t())              # [B, 39]: 38 logits, value
-        chk(L.brl_ppo_loss_heads(di, heads.data_ptr(), self.mask.data_ptr(), self.action.data_ptr(), self.old_v.data_ptr(),
-                                 self.old_lp.data_ptr(), self.adv.data_ptr(), self.tgt.data_ptr(), B, float(cfg["clip_eps"]),
-                                 float(cfg["vf_coef"]), float(cfg["ent_coef"]),
-                                 int(bool(cfg.get("actor_illegal_action_mask", True))),
-                                 int(bool(cfg.get("value_clipping", True))), self.dheads.data_ptr(), self.partials.data_ptr(),
-                                 self.illp.data_ptr(), s))
+                if self.static:
+                    x = torch.addmm(b, x, W.t(), out=self.h[l]).tanh_()
+                else:
+                    x = self.h[l] = torch.addmm(b, x, W.t()).tanh_()
+        chk(L.brl_ppo_heads_loss(di, x.data_ptr(), x.stride(0), self.Wh.data_ptr(), self.bh.data_ptr(), self.H,
+                                 self.mask.data_ptr(), self.action.data_ptr(), self.old_v.data_ptr(), self.old_lp.data_ptr(),
+                                 self.adv.data_ptr(), self.tgt.data_ptr(), B, float(cfg["clip_eps"]), float(cfg["vf_coef"]),
+                                 float(cfg["ent_coef"]), int(bool(cfg.get("actor_illegal_action_mask", True))),
+                                 int(bool(cfg.get("value_clipping", True))), int(bool(cfg.get("reward_scaling", False))), None,
+                                 self.dheads.data_ptr(), self.partials.data_ptr(), self.gram_partials.data_ptr(), s))
         if not self.static:
             self._stats_fork()   # one graph: a branch beside the whole backward pass, joined before Adam (_seg_fin)
-        # backward, written out: dW = dz^T h_prev, db = column sums of dz (finished for all layers by one launch),
-        # dh_prev = dz W
-        torch.mm(self.dheads.t(), x, out=self.GWh)
+        # backward of the head, written out: dW_h / db_h partials per batch split, dz of the top hidden layer (activation
+        # derivative applied) and its bias-gradient tile sums
         nl = len(self.W)
-        chk(L.brl_relu_bwd_colsum(di, self.dheads.data_ptr(), None, B, self.dheads.shape[1], self.dheads.shape[1], None,
-                                  self.tile_sums[nl].data_ptr(), s))
-        if self.static:
-            torch.mm(self.dheads, self.Wh, out=self.dhb[(nl - 1) & 1])
-        else:
-            self.dhb[(nl - 1) & 1] = torch.mm(self.dheads, self.Wh)
+        top = (nl - 1) & 1
+        if not self.static:
+            self.dhb[top] = torch.empty((B, self.H), dtype=torch.float32, device=self.dev)
+        chk(L.brl_ppo_heads_bwd(di, self.dheads.data_ptr(), x.data_ptr(), x.stride(0), self.Wh.data_ptr(), B, self.H, self.act,
+                                self.nsplit, self.dwh_partials.data_ptr(), self.dbh_partials.data_ptr(),
+                                self.dhb[top].data_ptr(), self.tile_sums[nl - 1].data_ptr(), s))
+
+    def _stats(self, stream):
+        cfg = self.cfg
+        di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        self.capi.check(self.lib.brl_ppo_stats_gram(di, self.partials.data_ptr(), self.groups, self.mbs,
+                                                    self.gram_partials.data_ptr(), self.groups, float(cfg["vf_coef"]),
+                                                    float(cfg["ent_coef"]), self.log.data_ptr(), self.mb_index.data_ptr(), None,
+                                                    stream))
 
     def _stats_fork(self):
-        """the logged statistics (src/update.py:136-167) on a side stream: in a captured graph a parallel branch (k_ppo_stats
-        is one block, 33-50 us) beside the GEMMs issued until _stats_join"""
-        cfg, B = self.cfg, self.mbs
-        di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        """the logged statistics (src/update.py:136-167) on a side stream: in a captured graph a parallel branch beside the
+        GEMMs issued until _stats_join"""
         self.side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
-            gram = self.illp.t() @ self.illp
-            self.capi.check(self.lib.brl_ppo_stats_at(di, self.partials.data_ptr(), B, gram.data_ptr(), float(cfg["vf_coef"]),
-                                                      float(cfg["ent_coef"]), self.log.data_ptr(), self.mb_index.data_ptr(),
-                                                      self.side.cuda_stream))
+            self._stats(self.side.cuda_stream)
 
     def _stats_join(self):
         torch.cuda.current_stream().wait_stream(self.side)  # the statistics read mb_index, which the Adam launch advances
 
     def _seg_layer(self, l):
-        """backward of hidden layer l: dh (in self.dhb[l & 1]) -> dz in place, tile sums, dW_l, dh of the layer below"""
+        """backward of hidden layer l: dz (in self.dhb[l & 1]; below the top layer: dh -> dz in place + tile sums), dW_l,
+        dh of the layer below"""
         L, chk, B = self.lib, self.capi.check, self.mbs
         s = torch.cuda.current_stream().cuda_stream
         di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
-        top = self.static and l == len(self.W) - 1
-        if top:
-            self._stats_fork()   # several graphs: the branch lives (and is joined) inside the first layer's graph
         dh = self.dhb[l & 1]
-        chk(L.brl_relu_bwd_colsum(di, dh.data_ptr(), self.h[l].data_ptr(), B, dh.shape[1], dh.shape[1], None,
-                                  self.tile_sums[l].data_ptr(), s))
+        if l != len(self.W) - 1:   # (the top layer's activation derivative and tile sums came with brl_ppo_heads_bwd)
+            chk(L.brl_act_bwd_colsum(di, dh.data_ptr(), self.h[l].data_ptr(), B, dh.shape[1], dh.shape[1], self.act,
+                                     self.tile_sums[l].data_ptr(), s))
         torch.mm(dh.t(), self.h[l - 1] if l > 0 else self.x0, out=self.GW[l])
         if l > 0:
             if self.static:
                 torch.mm(dh, self.W[l], out=self.dhb[(l - 1) & 1])
             else:
                 self.dhb[(l - 1) & 1] = torch.mm(dh, self.W[l])
-        if top:
-            self._stats_join()
 
     def _seg_fin(self):
         s = torch.cuda.current_stream().cuda_stream
         di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
-        self.capi.check(self.lib.brl_bias_finalize(di, self._nseg, self._seg_scratch, self._seg_cols, self._seg_db, self.mbs, s))
+        if self.static:
+            self._stats(s)   # several graphs: ~3 us on the main stream here, NOT inside a layer's segment (critical path there)
+        self.capi.check(self.lib.brl_bias_finalize_ex(di, self._nseg, self._seg_scratch, self._seg_cols, self._seg_tiles,
+                                                      self._seg_db, s))
         if not self.static:
             self._stats_join()
 
@@ -519,7 +539,8 @@ class FusedMinibatch:
         works = []
         for g, bucket in zip(self.segs[:-1], self.buckets):      # brl_adam_clip divides by world (grad_scale)
             g.replay()
-            works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
+            if bucket is not None:
+                works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
         for w in works:
             w.wait()
         self.segs[-1].replay()

@@ -355,6 +355,51 @@ int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int6
                   const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale, float *scratch,
                   int32_t *mb_index, float *norm_out, void *stream);
 
+/* ---- the 39-column head (38 logits + value, src/models.py:30-33) of one PPO minibatch step as three launches instead of four
+ * library GEMMs with N or K = 39 and five small kernels (brl_amd/csrc/ppo_heads.hpp) ------------------------------------- */
+
+/* heads = h head_w^T + head_b (h float [batch, ldh >= hidden], the last hidden layer's output; head_w float [39, hidden] = actor
+ * rows then the critic row; head_b float [39]; hidden % 16 == 0), then `_loss_fn` (src/update.py:90-167) exactly as
+ * brl_ppo_loss_heads on that matrix: dheads float [batch,39] = d(total)/d(heads); partials float [ceil(batch / 16) * 8] for
+ * brl_ppo_stats_gram; gram_partials (may be NULL) float [ceil(batch / 16) * 1444]: per 16-sample group, P^T P of its
+ * illegal-action probabilities (src/update.py:136-141).  reward_scaling != 0: the advantages are normalised over the
+ * minibatch first, (gae - mean) / (std + 1e-8) with jnp's ddof = 0 (src/update.py:31-44,118).  heads_out (may be NULL):
+ * float [batch,39]. */
+int brl_ppo_heads_loss(int device, const float *h, int64_t ldh, const float *head_w, const float *head_b, int64_t hidden,
+                       const uint8_t *mask, const int32_t *action, const float *old_value, const float *old_log_prob,
+                       const float *gae, const float *targets, int64_t batch, float clip_eps, float vf_coef, float ent_coef,
+                       int masked, int value_clipping, int reward_scaling, float *heads_out, float *dheads, float *partials,
+                       float *gram_partials, void *stream);
+
+/* Backward of the head in one launch (what autograd does for `actor(x), critic(x)` and the activation under them):
+ * dw_partials float [nsplit, 39 * hidden] and db_partials float [nsplit, 39]: d(heads)^T h and the column sums of d(heads)
+ * per batch split of <= 64 rows (brl_bias_finalize_ex adds the splits in order: deterministic); dh float [batch, hidden] =
+ * (d(heads) head_w) * act'(h) — act 0: ReLU (h > 0), 1: tanh (1 - h^2), src/models.py:16 —, i.e. the gradient w.r.t. the
+ * last hidden layer's pre-activation, and tile_sums float [ceil(batch / 16), hidden]: its column sums per 16-row tile
+ * (that layer's bias gradient, same layout as brl_relu_bwd_colsum's scratch).  hidden % 256 == 0. */
+int brl_ppo_heads_bwd(int device, const float *dheads, const float *h, int64_t ldh, const float *head_w, int64_t batch,
+                      int64_t hidden, int act, int nsplit, float *dw_partials, float *db_partials, float *dh, float *tile_sums,
+                      void *stream);
+
+/* brl_ppo_stats_at from brl_ppo_heads_loss's outputs: partials float [npartials, 8], gram_partials float [ngram, 1444] (summed
+ * in order).  The illegal-action norm comes from 4 squarings of G / trace by the whole block and 16 power-iteration steps with
+ * that matrix (G^256 v, as brl_ppo_stats).  row_index may be NULL (row 0).  vec_out (may be NULL): float [40] = the top right
+ * singular vector v1 [38], sigma_1, 0 — what the gradient of the norm needs (d sigma_1 / dP = u1 v1^T). */
+int brl_ppo_stats_gram(int device, const float *partials, int64_t npartials, int64_t batch, const float *gram_partials,
+                       int64_t ngram, float vf_coef, float ent_coef, float *out_rows, const int32_t *row_index, float *vec_out,
+                       void *stream);
+
+/* brl_relu_bwd_colsum's tile pass for either activation: dh [rows,ld] *= act'(h) in place (act 0: ReLU, 1: tanh) and the
+ * column sums of every 16-row tile into scratch float [ceil(rows / 16), cols]; cols and ld multiples of 4. */
+int brl_act_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, int act, float *scratch,
+                       void *stream);
+
+/* brl_bias_finalize with the tile count of every segment given: out[i][c] = sum_{t < tiles[i]} partials[i][t * cols[i] + c],
+ * in order, for nseg <= 12 segments (bias gradients of the layers, and the head's weight / bias gradients from
+ * brl_ppo_heads_bwd's batch splits). */
+int brl_bias_finalize_ex(int device, int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles,
+                         float *const *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

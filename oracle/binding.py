@@ -63,8 +63,14 @@ def build(force: bool = False) -> str:
     """Compile the C oracle with gcc (a few hundred ms)."""
     src = os.path.join(_HERE, "bridge_oracle.c")
     out = lib_path()
-    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "--no-print-directory"] + (["-B"] if force else []))
+    shim = os.path.join(_HERE, "_build", "liboracle_brl.so")
+    deps = [src, os.path.join(_HERE, "brl_shim.c"), os.path.join(_HERE, "Makefile"),
+            os.path.join(os.path.dirname(_HERE), "include", "brl_hip.h")]
+    # (checked here, without starting a process: a test session calls this once per Oracle(), often with the GPU runtime up)
+    stale = force or not (os.path.exists(out) and os.path.exists(shim)) or \
+        min(os.path.getmtime(out), os.path.getmtime(shim)) < max(os.path.getmtime(d) for d in deps)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "--no-print-directory", "-s"] + (["-B"] if force else []))
     return out
 
 

@@ -359,3 +359,29 @@ int brl_rollout_random_gae(brl_handle *h, uint64_t *state, int64_t n, int T, uin
   if (rc != 0) return rc;
   return brl_gae(h, out->done, out->value, out->reward, last_val, gamma, gl, T, n, adv, tgt, s);
 }
+/* the head kernels of the fused PPO minibatch step (brl_amd/csrc/ppo_heads.hpp): GPU library only, like the entries above */
+int brl_ppo_heads_loss(int device, const float *h, int64_t ldh, const float *hw, const float *hb, int64_t hidden, const uint8_t *m,
+                       const int32_t *a, const float *ov, const float *olp, const float *g, const float *t, int64_t b, float ce,
+                       float vc, float ec, int mk, int vcl, int rs, float *ho, float *dh, float *pt, float *gp, void *s) {
+  (void)device; (void)h; (void)ldh; (void)hw; (void)hb; (void)hidden; (void)m; (void)a; (void)ov; (void)olp; (void)g; (void)t; (void)b; (void)ce; (void)vc; (void)ec; (void)mk; (void)vcl; (void)rs; (void)ho; (void)dh; (void)pt; (void)gp; (void)s;
+  NOT_HERE("brl_ppo_heads_loss");
+}
+int brl_ppo_heads_bwd(int device, const float *dheads, const float *h, int64_t ldh, const float *hw, int64_t b, int64_t hidden,
+                      int act, int nsplit, float *dwp, float *dbp, float *dh, float *ts, void *s) {
+  (void)device; (void)dheads; (void)h; (void)ldh; (void)hw; (void)b; (void)hidden; (void)act; (void)nsplit; (void)dwp; (void)dbp; (void)dh; (void)ts; (void)s;
+  NOT_HERE("brl_ppo_heads_bwd");
+}
+int brl_ppo_stats_gram(int device, const float *pt, int64_t np, int64_t b, const float *gp, int64_t ng, float vc, float ec,
+                       float *out, const int32_t *ri, float *vec, void *s) {
+  (void)device; (void)pt; (void)np; (void)b; (void)gp; (void)ng; (void)vc; (void)ec; (void)out; (void)ri; (void)vec; (void)s;
+  NOT_HERE("brl_ppo_stats_gram");
+}
+int brl_act_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, int act, float *scr, void *s) {
+  (void)device; (void)dh; (void)h; (void)rows; (void)cols; (void)ld; (void)act; (void)scr; (void)s;
+  NOT_HERE("brl_act_bwd_colsum");
+}
+int brl_bias_finalize_ex(int device, int nseg, const float *const *parts, const int64_t *cols, const int64_t *tiles,
+                         float *const *out, void *s) {
+  (void)device; (void)nseg; (void)parts; (void)cols; (void)tiles; (void)out; (void)s;
+  NOT_HERE("brl_bias_finalize_ex");
+}

@@ -1413,15 +1413,17 @@ def test_fused_update_with_gradient_allreduce_two_ranks_rccl(tmp_path):
     assert torch.allclose(total.cpu(), r0[1], atol=1e-6) and torch.allclose(single, r0[0], atol=1e-6, rtol=1e-5)
 
 
-@pytest.mark.parametrize("variant", ["DeepMind_6", "anneal_lr"])
+@pytest.mark.parametrize("variant", ["DeepMind_6", "anneal_lr", "tanh", "reward_scaling"])
 def test_fused_update_variants_match_eager(variant):
-    """FusedMinibatch on the 6-layer MLP of wb5/models.py, and under ppo.py:186-192's linear learning-rate schedule (the
-    rate lives in device memory, so the captured Adam launch follows it): two updates of one epoch vs the eager path."""
+    """FusedMinibatch on the 6-layer MLP of wb5/models.py, under ppo.py:186-192's linear learning-rate schedule (the
+    rate lives in device memory, so the captured Adam launch follows it), with the tanh activation (src/models.py:16) and
+    with reward_scaling (src/update.py:31-44,118): two updates of one epoch vs the eager autograd path."""
     from brl_amd.models import make_forward_pass
     from brl_amd.update import FusedMinibatch, make_optimizer, make_update_step
     from tests.test_update_cpu import CFG, fake_batch
-    fp = make_forward_pass("relu", "DeepMind_6" if variant == "DeepMind_6" else "DeepMind")
-    cfg0 = dict(CFG, minibatch_size=256, update_epochs=1, num_minibatches=4, num_updates=4, anneal_lr=variant == "anneal_lr")
+    fp = make_forward_pass("tanh" if variant == "tanh" else "relu", "DeepMind_6" if variant == "DeepMind_6" else "DeepMind")
+    cfg0 = dict(CFG, minibatch_size=256, update_epochs=1, num_minibatches=4, num_updates=4, anneal_lr=variant == "anneal_lr",
+                reward_scaling=variant == "reward_scaling")
     outs = []
     for fused in (False, True):
         net = fp.init(7, device="cuda")
@@ -1526,6 +1528,86 @@ def test_fused_update_helpers_match_torch():
     assert torch.equal(x0, flat.obs[rows].float()) and torch.equal(mask.bool(), flat.legal_action_mask[rows])
     assert torch.equal(act, flat.action[rows]) and torch.equal(ov, flat.value[rows]) and torch.equal(olp, flat.log_prob[rows])
     assert torch.equal(ga, adv[rows]) and torch.equal(tg, tgt[rows])
+
+
+@pytest.mark.parametrize("B,H,act", [(1024, 1024, 0), (1000, 1024, 1), (48, 256, 0), (17, 512, 1)])
+def test_head_kernels_match_torch_and_the_separate_launches(B, H, act):
+    """brl_ppo_heads_loss / brl_ppo_heads_bwd / brl_ppo_stats_gram / brl_bias_finalize_ex (the 39-column head of one PPO
+    minibatch step as three launches) against float64 torch and against the launches they replace: heads = h W^T + b;
+    d(heads), statistics partials and the illegal-action Gram matrix equal to brl_ppo_loss_heads / brl_ppo_stats on the SAME
+    heads (bit-identical d(heads)); dW_h, db_h, dh * act'(h) and its column sums vs torch; the illegal-action norm vs an SVD."""
+    from brl_amd import _capi
+    L, dev = _capi.lib(), torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(B + H)
+    rn = lambda *shape: torch.randn(*shape, device=dev, generator=g)  # noqa: E731
+    h = rn(B, H).relu_() if act == 0 else rn(B, H).tanh_()
+    Wh, bh = rn(39, H) / H ** 0.5, rn(39) * 0.1
+    mask = (torch.rand(B, 38, device=dev, generator=g) < 0.6).to(torch.uint8)
+    mask[:, 0] = 1
+    action = torch.multinomial(mask.float(), 1, generator=g)[:, 0].to(torch.int32)
+    old_v, old_lp, gae, tgt = rn(B) * 0.3, -rn(B).abs() - 0.1, rn(B), rn(B) * 0.3
+    groups = (B + 15) // 16
+    heads, dheads = torch.empty(B, 39, device=dev), torch.empty(B, 39, device=dev)
+    partials, gram_p = torch.empty(groups, 8, device=dev), torch.empty(groups, 1444, device=dev)
+    for rscale in (0, 1):
+        _capi.check(L.brl_ppo_heads_loss(0, h.data_ptr(), H, Wh.data_ptr(), bh.data_ptr(), H, mask.data_ptr(), action.data_ptr(),
+                                         old_v.data_ptr(), old_lp.data_ptr(), gae.data_ptr(), tgt.data_ptr(), B, 0.2, 0.5, 0.001, 1, 1,
+                                         rscale, heads.data_ptr(), dheads.data_ptr(), partials.data_ptr(), gram_p.data_ptr(), s))
+        want = (h.double() @ Wh.double().t() + bh.double())
+        assert float((heads.double() - want).abs().max()) < 2e-5          # fp32 sum of 1024 products
+        # the loss of those heads by the separate launch (same device function: bit-identical gradients)
+        adv = (gae - gae.mean()) / (gae.std(unbiased=False) + 1e-8) if rscale else gae
+        dh2, p2, illp = torch.empty(B, 39, device=dev), torch.empty((B + 3) // 4, 8, device=dev), torch.empty(B, 38, device=dev)
+        _capi.check(L.brl_ppo_loss_heads(0, heads.data_ptr(), mask.data_ptr(), action.data_ptr(), old_v.data_ptr(), old_lp.data_ptr(),
+                                         adv.contiguous().data_ptr(), tgt.data_ptr(), B, 0.2, 0.5, 0.001, 1, 1, dh2.data_ptr(),
+                                         p2.data_ptr(), illp.data_ptr(), s))
+        if rscale == 0:
+            assert torch.equal(dheads, dh2)
+        else:   # the in-kernel mean / std differ from torch's in the last bits
+            assert torch.allclose(dheads, dh2, rtol=1e-4, atol=1e-9)
+        assert torch.allclose(partials.sum(0), p2.sum(0), rtol=1e-4, atol=1e-5)
+        gram = illp.double().t() @ illp.double()
+        assert torch.allclose(gram_p.sum(0).double().reshape(38, 38), gram, rtol=1e-4, atol=1e-7)
+        out_new, out_old, vec = torch.zeros(8, device=dev), torch.zeros(8, device=dev), torch.zeros(40, device=dev)
+        _capi.check(L.brl_ppo_stats_gram(0, partials.data_ptr(), groups, B, gram_p.data_ptr(), groups, 0.5, 0.001, out_new.data_ptr(),
+                                         None, vec.data_ptr(), s))
+        gram32 = gram.float().contiguous()
+        _capi.check(L.brl_ppo_stats(0, p2.data_ptr(), B, gram32.data_ptr(), 0.5, 0.001, out_old.data_ptr(), s))
+        assert torch.allclose(out_new, out_old, rtol=2e-4, atol=1e-6), (out_new, out_old)
+        sv = torch.linalg.svdvals(illp.double())[0]
+        assert abs(float(out_new[6]) - float(sv) / 2) < 1e-4 * float(sv) + 1e-7     # jnp.linalg.norm(P, ord=2) / 2
+        u, sg, vt = torch.linalg.svd(illp.double(), full_matrices=False)
+        v1 = vt[0] * torch.sign(vt[0].sum())
+        assert abs(float(vec[38]) - float(sg[0])) < 1e-4 * float(sg[0]) + 1e-7
+        assert float((vec[:38].double() - v1).abs().max()) < 2e-3                      # (l2 / l1)^256 away from the Perron vector
+    # backward of the head
+    nsplit = (B + 63) // 64
+    dwp, dbp = torch.empty(nsplit, 39 * H, device=dev), torch.empty(nsplit, 39, device=dev)
+    dh, ts = torch.empty(B, H, device=dev), torch.empty(groups, H, device=dev)
+    _capi.check(L.brl_ppo_heads_bwd(0, dheads.data_ptr(), h.data_ptr(), H, Wh.data_ptr(), B, H, act, nsplit, dwp.data_ptr(),
+                                    dbp.data_ptr(), dh.data_ptr(), ts.data_ptr(), s))
+    import ctypes as C
+    gW, gb, gbias = torch.empty(39, H, device=dev), torch.empty(39, device=dev), torch.empty(H, device=dev)
+    parts = (C.c_void_p * 3)(dwp.data_ptr(), dbp.data_ptr(), ts.data_ptr())
+    cols, tiles = (C.c_int64 * 3)(39 * H, 39, H), (C.c_int64 * 3)(nsplit, nsplit, groups)
+    outs = (C.c_void_p * 3)(gW.data_ptr(), gb.data_ptr(), gbias.data_ptr())
+    _capi.check(L.brl_bias_finalize_ex(0, 3, parts, cols, tiles, outs, s))
+    d64, h64 = dheads.double(), h.double()
+    scale = float(d64.abs().max())
+    assert float((gW.double() - d64.t() @ h64).abs().max()) < 1e-4 * scale * 32
+    assert float((gb.double() - d64.sum(0)).abs().max()) < 1e-4 * scale * 32
+    deriv = (h64 > 0).double() if act == 0 else 1 - h64 * h64
+    want_dh = (d64 @ Wh.double()) * deriv
+    assert float((dh.double() - want_dh).abs().max()) < 1e-5 * scale * 8
+    assert float((gbias.double() - dh.double().sum(0)).abs().max()) < 1e-4 * scale * 32
+    # the activation-derivative pass of the layers below, both activations
+    dz = rn(B, H)
+    want = dz * ((h > 0).float() if act == 0 else 1 - h * h)
+    got = dz.clone()
+    _capi.check(L.brl_act_bwd_colsum(0, got.data_ptr(), h.data_ptr(), B, H, H, act, ts.data_ptr(), s))
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(ts.sum(0), want.sum(0), rtol=1e-4, atol=1e-3)
 
 
 def test_longest_auction_319_calls(env, oracle, dds):
