@@ -2324,6 +2324,29 @@ extern "C" int brl_mb_gather(int device, const brl_transition *flat, const float
   return BRL_OK;
 }
 
+extern "C" int brl_mb_gather_bind(int device, const brl_transition *flat, const float *adv, const float *targets, const int64_t *perm,
+                                  const int32_t *mb_index, int64_t mbs, float *x0, uint8_t *mask, int32_t *action, float *old_value,
+                                  float *old_log_prob, float *gae_out, float *targets_out, void *args_dev, void *stream) {
+  NEED(flat && flat->obs && flat->legal_action_mask && flat->action && flat->value && flat->log_prob, "trajectory");
+  NEED(adv && targets && perm && mb_index && mbs > 0, "adv / targets / perm / mb_index / mbs");
+  NEED(x0 && mask && action && old_value && old_log_prob && gae_out && targets_out && args_dev, "NULL output array / args_dev");
+  HIP_TRY(hipSetDevice(device));
+  static_assert(sizeof(GatherArgs) <= 256, "args_dev is 256 bytes");
+  GatherArgs A{flat->obs, flat->legal_action_mask, flat->action, flat->value, flat->log_prob, adv, targets, perm, mb_index, mbs,
+               x0, mask, action, old_value, old_log_prob, gae_out, targets_out};
+  hipLaunchKernelGGL(k_mb_gather_bind, dim3(1), dim3(64), 0, (hipStream_t)stream, A, (GatherArgs *)args_dev);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_mb_gather_dev(int device, const void *args_dev, int64_t mbs, void *stream) {
+  NEED(args_dev && mbs > 0, "args_dev / mbs");
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(k_mb_gather_dev, dim3((unsigned)mbs), dim3(128), 0, (hipStream_t)stream, (const GatherArgs *)args_dev);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
 extern "C" int brl_relu_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, float *db,
                                    float *scratch, void *stream) {
   NEED(dh && scratch && rows > 0 && cols > 0 && ld >= cols, "dh / scratch / rows / cols / ld");
@@ -2415,7 +2438,8 @@ extern "C" int brl_ppo_heads_loss(int device, const float *h, int64_t ldh, const
 
 extern "C" int brl_ppo_heads_bwd(int device, const float *dheads, const float *h, int64_t ldh, const float *head_w, int64_t batch,
                                  int64_t hidden, int act, int nsplit, float *dw_partials, float *db_partials, float *dh,
-                                 float *tile_sums, void *stream) {
+                                 float *tile_sums, const float *loss_partials, const float *gram_partials, int64_t ngroups,
+                                 const int32_t *row_index, float *stat_sums, float *gram_sums, void *stream) {
   NEED(batch > 0 && hidden > 0 && hidden % 256 == 0 && ldh >= hidden && ldh % 4 == 0, "batch / hidden (a multiple of 256) / ldh");
   NEED(dheads && h && head_w && dw_partials && db_partials && dh && tile_sums, "NULL array");
   NEED(act == 0 || act == 1, "act (0 ReLU, 1 tanh)");
@@ -2426,8 +2450,14 @@ extern "C" int brl_ppo_heads_bwd(int device, const float *dheads, const float *h
   A.rows_per_split = (int)((batch + nsplit - 1) / nsplit);
   A.dWh_partials = dw_partials; A.dbh_partials = db_partials; A.dh = dh; A.tile_sums = tile_sums;
   A.blocks_a = (int)(hidden / HB_JT) * nsplit;
+  const bool sums = gram_sums != nullptr;
+  NEED(!sums || (loss_partials && gram_partials && ngroups > 0 && row_index && stat_sums), "statistics sums: partials / ngroups / row_index / stat_sums");
+  A.loss_partials = loss_partials; A.gram_partials = gram_partials; A.ngroups = (int)ngroups; A.row_index = row_index;
+  A.stat_sums = stat_sums; A.gram_sums = gram_sums;
   const int64_t blocks_b = (hidden / 256) * ((batch + HB_ROWS - 1) / HB_ROWS);
-  hipLaunchKernelGGL(k_heads_bwd, dim3((unsigned)(A.blocks_a + blocks_b)), dim3(256), 0, (hipStream_t)stream, A);
+  // two launches (independent: back to back on the stream): the weight-gradient partials and the activation gradient
+  hipLaunchKernelGGL(k_heads_bwd_dh, dim3((unsigned)blocks_b), dim3(256), 0, (hipStream_t)stream, A);
+  hipLaunchKernelGGL(k_heads_bwd_dw, dim3((unsigned)(A.blocks_a + (sums ? HB_GRAM_BLOCKS : 0))), dim3(256), 0, (hipStream_t)stream, A);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }
@@ -2438,8 +2468,18 @@ extern "C" int brl_ppo_stats_gram(int device, const float *partials, int64_t npa
   NEED(partials && out_rows && npartials > 0 && batch > 0, "partials / out_rows / npartials / batch");
   NEED(gram_partials && ngram > 0, "gram_partials / ngram");
   HIP_TRY(hipSetDevice(device));
-  hipLaunchKernelGGL(k_ppo_stats2, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, npartials, batch, gram_partials, ngram,
+  hipLaunchKernelGGL(k_ppo_stats2, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, npartials, batch, gram_partials, ngram,
                      vf_coef, ent_coef, out_rows, row_index, vec_out);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_ppo_stats_rows(int device, const float *stat_sums, const float *gram_sums, int64_t rows, int64_t batch, float vf_coef,
+                                  float ent_coef, float *out_rows, void *stream) {
+  NEED(stat_sums && gram_sums && out_rows && rows > 0 && batch > 0, "stat_sums / gram_sums / out_rows / rows / batch");
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(k_ppo_stats2, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, stat_sums, (int64_t)1, batch, gram_sums,
+                     (int64_t)1, vf_coef, ent_coef, out_rows, (const int32_t *)nullptr, (float *)nullptr);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

@@ -14,7 +14,7 @@
 #pragma once
 
 constexpr int HD_ROWS = 16;    // samples per workgroup of k_heads_loss
-constexpr int HD_WAVES = 8;    // waves per workgroup = K splits
+constexpr int HD_WAVES = 16;   // waves per workgroup = K splits = samples per workgroup (one wave finishes one sample)
 constexpr int HD_NOUT = BRL_NUM_ACTIONS + 1;   // 39
 constexpr int HD_GRAM = BRL_NUM_ACTIONS * BRL_NUM_ACTIONS;   // 1444
 
@@ -33,7 +33,7 @@ struct HeadsLossArgs {
 };
 
 __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
-  __shared__ float red[HD_WAVES][3][4][64];            // K-split partial sums (24 KB)
+  __shared__ float red[HD_WAVES][3][4][64];            // K-split partial sums (48 KB)
   __shared__ float illp_s[HD_ROWS][BRL_NUM_ACTIONS + 2];
   __shared__ float part_s[HD_ROWS][8];
   __shared__ float rs_red[HD_WAVES], rs_stat[2];
@@ -92,10 +92,13 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
 #pragma unroll
   for (int nb = 0; nb < 3; nb++) acc[nb] = hd_f32x4{0.f, 0.f, 0.f, 0.f};
   const int ngroups = A.H / 16;
-  for (int g0 = w; g0 < ngroups; g0 += 4 * HD_WAVES) {   // 4 groups per pass: 16 loads in flight per lane
-    hd_f32x4 av[4], bv[4][3];
+  // (latency-bound: 64 workgroups, every operand read once — so ALL of a wave's loads are in flight before the first MFMA:
+  //  4 groups per pass = 4 + 12 16-byte loads per lane = the whole K range of the wave at H = 1024)
+  constexpr int GP = 4;
+  for (int g0 = w; g0 < ngroups; g0 += GP * HD_WAVES) {
+    hd_f32x4 av[GP], bv[GP][3];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < GP; u++) {
       const int g = g0 + u * HD_WAVES;
       const int gc = (g < ngroups) ? g : g0;
       av[u] = *reinterpret_cast<const hd_f32x4 *>(ap + 16 * gc);
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
       for (int nb = 0; nb < 3; nb++) bv[u][nb] = *reinterpret_cast<const hd_f32x4 *>(bp[nb] + 16 * gc);
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < GP; u++) {
       if (g0 + u * HD_WAVES >= ngroups) break;
 #pragma unroll
       for (int nb = 0; nb < 3; nb++) {
@@ -120,8 +123,9 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
     for (int q = 0; q < 4; q++) red[w][nb][q][lane] = acc[nb][q];
   __syncthreads();
 
-  // ---- `_loss_fn` (src/update.py:90-167): wave w takes samples 2 w and 2 w + 1; lane a = head a
-  for (int sl = 2 * w; sl < 2 * w + 2; sl++) {
+  // ---- `_loss_fn` (src/update.py:90-167): wave w takes sample w; lane a = head a
+  static_assert(HD_WAVES == HD_ROWS, "one wave per sample");
+  for (int sl = w; sl < w + 1; sl++) {
     const int64_t b = row0 + sl;
     const bool valid = b < B;
     float hv = 0.0f;
@@ -181,43 +185,89 @@ struct HeadsBwdArgs {
   float *dh;             // [B, H]: d(loss)/d(pre-activation of the last hidden layer)
   float *tile_sums;      // [ceil(B / 16)][H]: its column sums per 16-row tile (bias gradient)
   int blocks_a;          // (H / 64) * nsplit
+  // optional (gram_sums != NULL): the step's statistics inputs reduced HERE, by extra workgroups of the dW launch, into row
+  // *row_index of per-update buffers — brl_ppo_stats_rows turns all rows of an update into log rows with one launch at its end
+  const float *loss_partials;   // [ngroups][8]   from k_heads_loss
+  const float *gram_partials;   // [ngroups][1444]
+  int ngroups;
+  const int32_t *row_index;
+  float *stat_sums;             // [rows][8]
+  float *gram_sums;             // [rows][1444]
 };
+constexpr int HB_GRAM_BLOCKS = 6;   // 6 x 256 threads >= 1444 Gram entries
 
-__global__ __launch_bounds__(256) void k_heads_bwd(HeadsBwdArgs A) {
+__global__ __launch_bounds__(256) void k_heads_bwd_dw(HeadsBwdArgs A) {
   __shared__ __attribute__((aligned(16))) float dh_s[64][HD_NOUT + 1];   // d(heads) rows of this workgroup (pad: 40 floats)
-  __shared__ float4 cs_s[4][64];
+  __shared__ __attribute__((aligned(16))) float h_s[64][64];             // the split's tile of h
   const int tid = (int)threadIdx.x;
-  if ((int)blockIdx.x < A.blocks_a) {
+  if ((int)blockIdx.x >= A.blocks_a) {
+    // ---- extra workgroups: Gram matrix and statistics sums of this step, in workgroup order (deterministic); 16 loads in flight
+    const int64_t row = *A.row_index;
+    const int e = ((int)blockIdx.x - A.blocks_a) * 256 + tid;
+    if (e < HD_GRAM) {
+      float s = 0.0f;
+      for (int i = 0; i < A.ngroups; i += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = A.gram_partials[(int64_t)((i + u < A.ngroups) ? i + u : i) * HD_GRAM + e];
+#pragma unroll
+        for (int u = 0; u < 16; u++) s += (i + u < A.ngroups) ? v[u] : 0.0f;
+      }
+      A.gram_sums[row * HD_GRAM + e] = s;
+    } else if (e < HD_GRAM + 8) {
+      const int k = e - HD_GRAM;
+      float s = 0.0f;
+      for (int i = 0; i < A.ngroups; i++) s += A.loss_partials[(int64_t)i * 8 + k];
+      A.stat_sums[row * 8 + k] = s;
+    }
+    return;
+  }
+  {
     // ---- role A: dW_h[n][j] = sum_b d(heads)[b][n] h[b][j] over this split's rows; thread = (column j, head group ng)
     const int jt = (int)blockIdx.x % (A.H / HB_JT), sp = (int)blockIdx.x / (A.H / HB_JT);
     const int64_t b0 = (int64_t)sp * A.rows_per_split;
     const int64_t left = A.B - b0;
     const int nb = (int)((left < A.rows_per_split) ? (left > 0 ? left : 0) : A.rows_per_split);
-    for (int e = tid; e < nb * HD_NOUT; e += 256) {
-      const int rr = e / HD_NOUT, c = e - rr * HD_NOUT;
-      dh_s[rr][c] = A.dheads[(b0 + rr) * HD_NOUT + c];
+    // the split's 64 x 64 tile of h and its d(heads) rows go through LDS; ALL of the thread's global loads are issued
+    // before anything waits (each byte is read once: the kernel is bound by load latency, not by bytes)
+    float4 hv4[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int rr = (tid >> 4) + 16 * u;   // 16 threads per row of 64 floats
+      hv4[u] = *reinterpret_cast<const float4 *>(A.h + (b0 + ((rr < nb) ? rr : 0)) * A.ldh + jt * HB_JT + 4 * (tid & 15));
+    }
+    constexpr int DPT = (64 * HD_NOUT + 255) / 256;   // d(heads) elements per thread
+    float dv[DPT];
+#pragma unroll
+    for (int k = 0; k < DPT; k++) {
+      const int e = tid + 256 * k;
+      dv[k] = (e < nb * HD_NOUT) ? A.dheads[b0 * HD_NOUT + e] : 0.0f;   // (the split's rows are contiguous)
+    }
+#pragma unroll
+    for (int k = 0; k < DPT; k++) {
+      const int e = tid + 256 * k;
+      if (e < 64 * HD_NOUT) {
+        const int rr = e / HD_NOUT, c = e - rr * HD_NOUT;
+        dh_s[rr][c] = dv[k];   // rows past the split's end: zeros
+      }
     }
     if (tid < 64) dh_s[tid][HD_NOUT] = 0.0f;   // the 40th "head" (group 3 has 9 real ones)
+#pragma unroll
+    for (int u = 0; u < 4; u++) *reinterpret_cast<float4 *>(&h_s[(tid >> 4) + 16 * u][4 * (tid & 15)]) = hv4[u];
     __syncthreads();
     const int j = tid & 63, ng = tid >> 6;
     float acc[HB_NG];
 #pragma unroll
     for (int q = 0; q < HB_NG; q++) acc[q] = 0.0f;
-    const float *hp = A.h + b0 * A.ldh + jt * HB_JT + j;
-    for (int rr = 0; rr < nb; rr += 4) {   // 4 rows of h in flight
-      float hv[4];
+#pragma unroll 8
+    for (int rr = 0; rr < nb; rr++) {
+      const float hu = h_s[rr][j];
+      const float2 *dp = reinterpret_cast<const float2 *>(&dh_s[rr][ng * HB_NG]);   // (40-float rows, 10-float groups: 8-byte aligned)
 #pragma unroll
-      for (int u = 0; u < 4; u++) hv[u] = hp[(int64_t)((rr + u < nb) ? rr + u : rr) * A.ldh];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        if (rr + u >= nb) break;
-        const float2 *dp = reinterpret_cast<const float2 *>(&dh_s[rr + u][ng * HB_NG]);   // (40-float rows, 10-float groups: 8-byte aligned)
-#pragma unroll
-        for (int q = 0; q < HB_NG / 2; q++) {
-          const float2 d = dp[q];
-          acc[2 * q] += d.x * hv[u];
-          acc[2 * q + 1] += d.y * hv[u];
-        }
+      for (int q = 0; q < HB_NG / 2; q++) {
+        const float2 d = dp[q];
+        acc[2 * q] += d.x * hu;
+        acc[2 * q + 1] += d.y * hu;
       }
     }
 #pragma unroll
@@ -230,11 +280,16 @@ __global__ __launch_bounds__(256) void k_heads_bwd(HeadsBwdArgs A) {
       for (int rr = 0; rr < nb; rr++) s += dh_s[rr][tid];
       A.dbh_partials[sp * HD_NOUT + tid] = s;
     }
-    return;
   }
+}
+
+__global__ __launch_bounds__(256) void k_heads_bwd_dh(HeadsBwdArgs A) {
+  __shared__ __attribute__((aligned(16))) float dh_s[HB_ROWS][HD_NOUT + 1];
+  __shared__ float4 cs_s[4][64];
+  const int tid = (int)threadIdx.x;
   // ---- role B: dh[b][j] = act'(h[b][j]) * sum_n d(heads)[b][n] W_h[n][j]; workgroup = 16 rows x 256 columns,
   // thread = (4 columns c4, rows rg, rg + 4, rg + 8, rg + 12)
-  const int bb = (int)blockIdx.x - A.blocks_a;
+  const int bb = (int)blockIdx.x;
   const int ct = bb % (A.H / 256), rt = bb / (A.H / 256);
   const int64_t r0 = (int64_t)rt * HB_ROWS;
   for (int e = tid; e < HB_ROWS * HD_NOUT; e += 256) {
@@ -254,13 +309,19 @@ __global__ __launch_bounds__(256) void k_heads_bwd(HeadsBwdArgs A) {
     hv[u] = *reinterpret_cast<const float4 *>(A.h + ((rw < A.B) ? rw : A.B - 1) * A.ldh + col);
   }
   const float *wp = A.Wh + col;
-#pragma unroll 3
-  for (int n = 0; n < HD_NOUT; n++) {
-    const float4 wv = *reinterpret_cast<const float4 *>(wp + (int64_t)n * A.H);
+  static_assert(HD_NOUT == 39, "three batches of 13 head rows");
+#pragma unroll 1
+  for (int n0 = 0; n0 < HD_NOUT; n0 += 13) {   // 13 rows of W_h in flight (L2-resident, shared by every workgroup)
+    float4 wv[13];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const float d = dh_s[rg + 4 * u][n];
-      acc[u].x += d * wv.x; acc[u].y += d * wv.y; acc[u].z += d * wv.z; acc[u].w += d * wv.w;
+    for (int k = 0; k < 13; k++) wv[k] = *reinterpret_cast<const float4 *>(wp + (int64_t)(n0 + k) * A.H);
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const float d = dh_s[rg + 4 * u][n0 + k];
+        acc[u].x += d * wv[k].x; acc[u].y += d * wv[k].y; acc[u].z += d * wv[k].z; acc[u].w += d * wv[k].w;
+      }
     }
   }
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -290,7 +351,7 @@ __global__ __launch_bounds__(256) void k_heads_bwd(HeadsBwdArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The logged statistics of one minibatch step from k_heads_loss's per-workgroup partials, one block of 256 threads:
+// The logged statistics of one minibatch step from k_heads_loss's per-workgroup partials, one block of 1024 threads:
 //   out[0] total  [1] value_loss  [2] loss_actor  [3] entropy  [4] approx_kl  [5] clipfrac  [6] illegal-action norm / 2  [7] 0
 // The norm = largest singular value / 2 of the non-negative [B, 38] matrix P of illegal-action probabilities
 // (`jnp.linalg.norm(..., ord=2) / 2`, src/update.py:138-141) = sqrt(top eigenvalue of G = P^T P) / 2 with G the sum of the
@@ -298,32 +359,36 @@ __global__ __launch_bounds__(256) void k_heads_bwd(HeadsBwdArgs A) {
 // — lane-contiguous, conflict-free LDS reads — rescaled by ONE reciprocal of the trace per squaring), then 16 steps of
 // v <- M^16 v / |.| by one wave (= G^256 v, the Perron vector to (l2 / l1)^256), Rayleigh quotient with the original G.
 // v1 and the norm are also written to `vec_out` [40] (v1[0..37], sigma_1, 0) when given: the gradient of the norm needs them.
-__global__ __launch_bounds__(256) void k_ppo_stats2(const float *partials, int64_t nblk, int64_t batch, const float *gram_partials,
+__global__ __launch_bounds__(1024) void k_ppo_stats2(const float *partials, int64_t nblk, int64_t batch, const float *gram_partials,
                                                     int64_t ngram, float vf_coef, float ent_coef, float *out, const int32_t *row_index,
                                                     float *vec_out) {
   if (row_index != nullptr) out += 8 * (int64_t)(*row_index);
+  // (brl_ppo_stats_rows: one block per row of per-update buffers — already reduced to one partial row each)
+  out += 8 * (int64_t)blockIdx.x;
+  partials += (int64_t)blockIdx.x * nblk * 8;
+  gram_partials += (int64_t)blockIdx.x * ngram * (BRL_NUM_ACTIONS * BRL_NUM_ACTIONS);
   constexpr int D = BRL_NUM_ACTIONS, DD = D * D;
   __shared__ float g[DD], m[DD], t[DD], vec[64], st[8], tr_s;
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (wv == 3) {   // wave 3: the five statistics, one after the other — lane l adds rows l, l + 64, ... in order, then a fixed butterfly
-    for (int k = 0; k < 5; k++) {
-      float s = 0.0f;
-      for (int64_t i = lane; i < nblk; i += 64) s += partials[i * 8 + k];
-      s = wave_sum_f(s);
-      if (lane == 0) st[k] = s / (float)batch;
-    }
-  }
-  for (int e = tid; e < DD; e += 256) {   // G = sum of the Gram partials, in workgroup order; 8 loads in flight
+  const int NT = (int)blockDim.x;   // 1024 (one step, latency-bound) or 256 (brl_ppo_stats_rows: one block per row)
+  const int w0 = (NT >= 1024) ? 8 : 3;   // waves w0..: one statistic each (wave 3 takes all five in a 256-thread block)
+  for (int k = (wv >= w0) ? wv - w0 : 5; k < 5; k += (NT >= 1024) ? 5 : 1) {   // lane l adds rows l, l + 64, ... in order, then a fixed butterfly
     float s = 0.0f;
-    int64_t i = 0;
-    for (; i + 8 <= ngram; i += 8) {
-      float v[8];
+    for (int64_t i = lane; i < nblk; i += 64) s += partials[i * 8 + k];
+    s = wave_sum_f(s);
+    if (lane == 0) st[k] = s / (float)batch;
+  }
+  // G = sum of the Gram partials, in workgroup order.  One block sums 1444 x ngram floats: latency, not bandwidth — so
+  // 16 loads are in flight per thread (2 threads' worth of entries per thread at 1024 threads)
+  for (int e = tid; e < DD; e += NT) {
+    float s = 0.0f;
+    for (int64_t i = 0; i < ngram; i += 32) {
+      float v[32];
 #pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = gram_partials[(i + u) * DD + e];
+      for (int u = 0; u < 32; u++) v[u] = gram_partials[((i + u < ngram) ? i + u : i) * DD + e];
 #pragma unroll
-      for (int u = 0; u < 8; u++) s += v[u];
+      for (int u = 0; u < 32; u++) s += (i + u < ngram) ? v[u] : 0.0f;
     }
-    for (; i < ngram; i++) s += gram_partials[i * DD + e];
     g[e] = s;
   }
   __syncthreads();
@@ -336,10 +401,10 @@ __global__ __launch_bounds__(256) void k_ppo_stats2(const float *partials, int64
     return tr_s;
   };
   float inv = trace_of(g);
-  for (int e = tid; e < DD; e += 256) m[e] = g[e] * inv;
+  for (int e = tid; e < DD; e += NT) m[e] = g[e] * inv;
   __syncthreads();
   for (int it = 0; it < 4; it++) {
-    for (int e = tid; e < DD; e += 256) {
+    for (int e = tid; e < DD; e += NT) {
       const int i = e / D, j = e - i * D;
       float s = 0.0f;
 #pragma unroll 2
@@ -348,26 +413,26 @@ __global__ __launch_bounds__(256) void k_ppo_stats2(const float *partials, int64
     }
     __syncthreads();
     inv = trace_of(t);
-    for (int e = tid; e < DD; e += 256) m[e] = t[e] * inv;
+    for (int e = tid; e < DD; e += NT) m[e] = t[e] * inv;
     __syncthreads();
   }
-  if (wv == 0) {   // v <- M v / |M v| sixteen times, M = (G / trace)^16; lane i owns v[i]; M symmetric: row i = column i
+  if (wv == 0) {   // v <- M v / |M v| sixteen times, M = (G / trace)^16; lane i owns v[i] and column i of M (= row i: M symmetric)
+    float mc[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) mc[k] = (lane < D) ? m[k * D + lane] : 0.0f;
     float v = (lane < D) ? 1.0f : 0.0f;
     for (int it = 0; it < 16; it++) {
-      vec[lane] = v;
-      wave_lds_order();
       float s = 0.0f;
-      if (lane < D)
-        for (int k = 0; k < D; k++) s += m[k * D + lane] * vec[k];
+#pragma unroll
+      for (int k = 0; k < D; k++)   // v[k] of lane k as a scalar: v_readlane, no LDS round trip
+        s += mc[k] * __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), k));
       const float nrm = wave_sum_f(s * s);
       v = (nrm > 0.0f) ? s * (1.0f / sqrtf(nrm)) : v;
-      wave_lds_order();
     }
-    vec[lane] = v;
-    wave_lds_order();
     float gv = 0.0f;
-    if (lane < D)
-      for (int k = 0; k < D; k++) gv += g[k * D + lane] * vec[k];
+#pragma unroll
+    for (int k = 0; k < D; k++)
+      gv += ((lane < D) ? g[k * D + lane] : 0.0f) * __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), k));
     const float num = wave_sum_f(v * gv), den = wave_sum_f(v * v);
     const float sigma = sqrtf(fmaxf(num / fmaxf(den, 1.17549435e-38f), 0.0f));
     if (vec_out != nullptr && lane < D + 2) vec_out[lane] = (lane < D) ? v * (1.0f / sqrtf(fmaxf(den, 1.17549435e-38f))) : ((lane == D) ? sigma : 0.0f);

@@ -21,7 +21,21 @@ struct GatherArgs {
   float *o_value, *o_log_prob, *o_adv, *o_tgt;
 };
 
-__global__ __launch_bounds__(128) void k_mb_gather(GatherArgs A) {
+__device__ __forceinline__ void mb_gather_row(const GatherArgs &A);
+
+__global__ __launch_bounds__(128) void k_mb_gather(GatherArgs A) { mb_gather_row(A); }
+
+// the same launch with its arguments in DEVICE memory (written by k_mb_gather_bind once per update): the captured minibatch
+// step starts with its own gather and stays valid when the next update brings another trajectory / permutation
+__global__ __launch_bounds__(128) void k_mb_gather_dev(const GatherArgs *Ad) {
+  const GatherArgs A = *Ad;
+  mb_gather_row(A);
+}
+__global__ void k_mb_gather_bind(GatherArgs A, GatherArgs *dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = A;
+}
+
+__device__ __forceinline__ void mb_gather_row(const GatherArgs &A) {
   const int64_t b = blockIdx.x;
   const int64_t row = A.perm[(int64_t)(*A.mb_index) * A.B + b];
   const int t = (int)threadIdx.x;

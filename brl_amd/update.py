@@ -332,13 +332,27 @@ class FusedMinibatch:
         self._seg_tiles = (C.c_int64 * nseg)(*([groups] * len(body) + [self.nsplit, self.nsplit]))
         self._seg_db = (C.c_void_p * nseg)(*([g.data_ptr() for g in self.Gb] + [self.Gbh.data_ptr(), self.GWh.data_ptr()]))
         self._nseg = nseg
-        self._log_cap = int(config.get("update_log_capacity", 16384))   # minibatch steps of one update_step call
-        self.log = f(self._log_cap, 8)                                  # static: the captured statistics launch writes row mb_index
-        self.side = torch.cuda.Stream(device=device)
+        # The logged statistics (src/update.py:136-167) are NOT formed step by step: every step leaves its sums — 8 floats and
+        # the 38 x 38 Gram matrix of the illegal-action probabilities, reduced by spare workgroups of the head-backward
+        # launch — in row mb_index of these buffers, and ONE launch at the end of the update turns all rows into log rows
+        # (a per-step statistics kernel on a parallel graph branch cost ~20 us of fork / join per step, 7 % of the update).
+        self._log_cap = int(config.get("update_log_capacity", 4096))    # minibatch steps of one update_step call
+        self.log = f(self._log_cap, 8)
+        self.stat_sums = f(self._log_cap, 8)
+        self.gram_sums = f(self._log_cap, 38 * 38)
         self.norm = f(1)
         self.mb_index = torch.zeros(1, dtype=torch.int32, device=device)  # minibatch step within the current update
         self.perm = None  # static int64 [epochs * T*N]: every epoch's permutation, filled by begin_update
         self.lib, self.capi = _capi.lib(), _capi
+        # the step's own gather reads ITS arguments from device memory (brl_mb_gather_bind, once per update): the captured
+        # step needs no eager launch in front of it.  Until the first update: a dummy trajectory of mbs valid rows.
+        self.gargs = torch.zeros(256, dtype=torch.uint8, device=device)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)  # noqa: E731
+        dmask = z((B, 38), torch.bool)
+        dmask[:, 0] = True
+        self._dummy = (Transition(z((B,), torch.bool), z((B,), torch.int32), f(B), f(B), f(B), z((B, 480), torch.bool), dmask),
+                       f(B), f(B), (torch.arange(8 * B, device=device) % B).to(torch.int64))
+        self._bind_gather(*self._dummy)
         d0 = opt.defaults
         self.lr, (self.b1, self.b2), self.eps = float(d0["lr"]), d0["betas"], float(d0["eps"])
         self.lr_dev = torch.full((1,), float(opt.param_groups[0]["lr"]), dtype=torch.float32, device=device)
@@ -361,6 +375,17 @@ class FusedMinibatch:
                     self._fwd_bwd()
                     self._opt()
                 self.graph = graph
+                # ... and the same step K times in ONE graph: a replay boundary costs ~5 us (graph launch behind the last
+                # kernel), the step ~0.3 ms; mb_index lives in device memory, so the K copies walk K minibatches
+                self.multi = int(config.get("update_graph_steps", 8))
+                self.graph_multi = None
+                if self.multi > 1:
+                    gm = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gm), torch.no_grad():
+                        for _ in range(self.multi):
+                            self._fwd_bwd()
+                            self._opt()
+                    self.graph_multi = gm
             else:
                 # one graph per all-reduce bucket: forward + loss + head backward | each hidden layer's backward | bias
                 # gradients | clip + Adam; the bucket's all-reduce is issued (async) behind its graph and overlaps with
@@ -381,6 +406,19 @@ class FusedMinibatch:
                 for t, q in zip((self.P, self.M, self.V, self.step, self.mb_index), saved):
                     t.copy_(q)
 
+    def _bind_gather(self, fl: Transition, adv, tgt, perm):
+        import ctypes as C
+        tp = self.capi.TransitionPtrs()
+        for name in self.capi.TransitionPtrs._names:
+            t = getattr(fl, name)
+            setattr(tp, name, (t.view(torch.uint8) if t.dtype == torch.bool else t).data_ptr())
+        di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        self.capi.check(self.lib.brl_mb_gather_bind(di, C.byref(tp), adv.data_ptr(), tgt.data_ptr(), perm.data_ptr(),
+                                                    self.mb_index.data_ptr(), self.mbs, self.x0.data_ptr(), self.mask.data_ptr(),
+                                                    self.action.data_ptr(), self.old_v.data_ptr(), self.old_lp.data_ptr(),
+                                                    self.adv.data_ptr(), self.tgt.data_ptr(), self.gargs.data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream))
+
     def _fwd_bwd(self):
         self._seg_head()
         for l in range(len(self.W) - 1, -1, -1):
@@ -394,6 +432,7 @@ class FusedMinibatch:
         s = torch.cuda.current_stream().cuda_stream
         di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         cfg = self.cfg
+        chk(L.brl_mb_gather_dev(di, self.gargs.data_ptr(), B, s))   # minibatch *mb_index of the bound trajectory -> x0, mask, ...
         x = self.x0
         for l, (W, b) in enumerate(zip(self.W, self.b)):          # forward: bias + activation
             if self.act == 0:                                     # ReLU in the GEMM epilogue
@@ -412,8 +451,6 @@ class FusedMinibatch:
                                  float(cfg["ent_coef"]), int(bool(cfg.get("actor_illegal_action_mask", True))),
                                  int(bool(cfg.get("value_clipping", True))), int(bool(cfg.get("reward_scaling", False))), None,
                                  self.dheads.data_ptr(), self.partials.data_ptr(), self.gram_partials.data_ptr(), s))
-        if not self.static:
-            self._stats_fork()   # one graph: a branch beside the whole backward pass, joined before Adam (_seg_fin)
         # backward of the head, written out: dW_h / db_h partials per batch split, dz of the top hidden layer (activation
         # derivative applied) and its bias-gradient tile sums
         nl = len(self.W)
@@ -422,25 +459,9 @@ class FusedMinibatch:
             self.dhb[top] = torch.empty((B, self.H), dtype=torch.float32, device=self.dev)
         chk(L.brl_ppo_heads_bwd(di, self.dheads.data_ptr(), x.data_ptr(), x.stride(0), self.Wh.data_ptr(), B, self.H, self.act,
                                 self.nsplit, self.dwh_partials.data_ptr(), self.dbh_partials.data_ptr(),
-                                self.dhb[top].data_ptr(), self.tile_sums[nl - 1].data_ptr(), s))
-
-    def _stats(self, stream):
-        cfg = self.cfg
-        di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
-        self.capi.check(self.lib.brl_ppo_stats_gram(di, self.partials.data_ptr(), self.groups, self.mbs,
-                                                    self.gram_partials.data_ptr(), self.groups, float(cfg["vf_coef"]),
-                                                    float(cfg["ent_coef"]), self.log.data_ptr(), self.mb_index.data_ptr(), None,
-                                                    stream))
-
-    def _stats_fork(self):
-        """the logged statistics (src/update.py:136-167) on a side stream: in a captured graph a parallel branch beside the
-        GEMMs issued until _stats_join"""
-        self.side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.side):
-            self._stats(self.side.cuda_stream)
-
-    def _stats_join(self):
-        torch.cuda.current_stream().wait_stream(self.side)  # the statistics read mb_index, which the Adam launch advances
+                                self.dhb[top].data_ptr(), self.tile_sums[nl - 1].data_ptr(), self.partials.data_ptr(),
+                                self.gram_partials.data_ptr(), self.groups, self.mb_index.data_ptr(), self.stat_sums.data_ptr(),
+                                self.gram_sums.data_ptr(), s))
 
     def _seg_layer(self, l):
         """backward of hidden layer l: dz (in self.dhb[l & 1]; below the top layer: dh -> dz in place + tile sums), dW_l,
@@ -462,12 +483,8 @@ class FusedMinibatch:
     def _seg_fin(self):
         s = torch.cuda.current_stream().cuda_stream
         di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
-        if self.static:
-            self._stats(s)   # several graphs: ~3 us on the main stream here, NOT inside a layer's segment (critical path there)
         self.capi.check(self.lib.brl_bias_finalize_ex(di, self._nseg, self._seg_scratch, self._seg_cols, self._seg_tiles,
                                                       self._seg_db, s))
-        if not self.static:
-            self._stats_join()
 
     def _opt(self):
         s = torch.cuda.current_stream().cuda_stream
@@ -481,19 +498,13 @@ class FusedMinibatch:
     # ---- one update_step call -----------------------------------------------------------------------------------
     def begin_update(self, flat: Transition, adv_f, tgt_f, perms):
         """flat: the [T*N, ...] views of the trajectory; adv_f / tgt_f: [T*N]; perms: one permutation of T*N per epoch.
-        Returns the [epochs * minibatches, 8] log the replays fill (total, value_loss, loss_actor, entropy, approx_kl,
-        clipfrac, illegal-action norm / 2, 0)."""
-        tp = self.capi.TransitionPtrs()
+        Binds the step's gather to them (device-resident arguments) and resets the minibatch counter."""
         self._keep = (Transition(*[x.contiguous() for x in flat]), adv_f.contiguous(), tgt_f.contiguous())
-        fl, self._adv, self._tgt = self._keep
-        for name in self.capi.TransitionPtrs._names:
-            t = getattr(fl, name)
-            setattr(tp, name, (t.view(torch.uint8) if t.dtype == torch.bool else t).data_ptr())
-        self._tp = tp
-        steps = sum(p.numel() for p in perms) // self.mbs
+        fl, adv_c, tgt_c = self._keep
+        self._steps = sum(p.numel() for p in perms) // self.mbs
         with torch.no_grad():
             self._readopt()
-            if steps > self._log_cap:
+            if self._steps > self._log_cap:
                 raise RuntimeError("FusedMinibatch: more minibatch steps per update than config['update_log_capacity']")
             allp = torch.cat(perms)
             if self.perm is None or self.perm.numel() != allp.numel():
@@ -502,7 +513,7 @@ class FusedMinibatch:
             self.mb_index.zero_()
             self.step.copy_(self.opt.state[self.plist[0]]["step"])  # the optimizer may have been stepped eagerly / loaded
             self.lr_dev.fill_(float(self.opt.param_groups[0]["lr"]))  # constant within an update (ppo.py:186-192)
-        return self.log[:steps]
+            self._bind_gather(fl, adv_c, tgt_c, self.perm)
 
     def _readopt(self):
         """`opt.load_state_dict` (resume) or a foreign `p.data = ...` replaces tensors that were views of the flat buffers:
@@ -525,31 +536,39 @@ class FusedMinibatch:
             if not torch.is_tensor(st["step"]) or st["step"].device != self.P.device:
                 st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=self.dev).reshape(())
 
-    def run_mb(self):
-        import ctypes as C
-        s = torch.cuda.current_stream().cuda_stream
-        di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
-        self.capi.check(self.lib.brl_mb_gather(di, C.byref(self._tp), self._adv.data_ptr(), self._tgt.data_ptr(),
-                                               self.perm.data_ptr(), self.mb_index.data_ptr(), self.mbs, self.x0.data_ptr(),
-                                               self.mask.data_ptr(), self.action.data_ptr(), self.old_v.data_ptr(),
-                                               self.old_lp.data_ptr(), self.adv.data_ptr(), self.tgt.data_ptr(), s))
+    def run_steps(self, n: int):
+        """the next n minibatch steps of the bound update"""
         if self.world == 1:
-            self.graph.replay()
+            k = self.multi if self.graph_multi is not None else 0
+            while k and n >= k:
+                self.graph_multi.replay()
+                n -= k
+            for _ in range(n):
+                self.graph.replay()
             return
-        works = []
-        for g, bucket in zip(self.segs[:-1], self.buckets):      # brl_adam_clip divides by world (grad_scale)
-            g.replay()
-            if bucket is not None:
-                works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
-        for w in works:
-            w.wait()
-        self.segs[-1].replay()
+        for _ in range(n):
+            works = []
+            for g, bucket in zip(self.segs[:-1], self.buckets):      # brl_adam_clip divides by world (grad_scale)
+                g.replay()
+                if bucket is not None:
+                    works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
+            for w in works:
+                w.wait()
+            self.segs[-1].replay()
 
     def end_update(self):
+        """-> the [steps, 8] log of the update (total, value_loss, loss_actor, entropy, approx_kl, clipfrac, illegal-action
+        norm / 2, 0): ONE launch over the sums the steps left behind"""
+        di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         with torch.no_grad():  # every parameter's step counter (torch keeps one per parameter)
             for q in self.plist:
                 self.opt.state[q]["step"].copy_(self.step)
-        self._keep = self._tp = None
+            self.capi.check(self.lib.brl_ppo_stats_rows(di, self.stat_sums.data_ptr(), self.gram_sums.data_ptr(), self._steps,
+                                                        self.mbs, float(self.cfg["vf_coef"]), float(self.cfg["ent_coef"]),
+                                                        self.log.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            self._bind_gather(*self._dummy)   # (the trajectory may be freed by the caller now)
+        self._keep = None
+        return self.log[:self._steps]
 
 
 def make_update_step(config, actor_forward_pass, optimizer=None):
@@ -611,10 +630,9 @@ def make_update_step(config, actor_forward_pass, optimizer=None):
             # minibatches are gathered straight from the un-shuffled buffer by index: no per-epoch take(), no copies
             perms = [torch.randperm(batch_size, device=adv_f.device, generator=gen)            # src/update.py:193
                      for _ in range(int(config["update_epochs"]))]
-            log = fused.begin_update(flat, adv_f, tgt_f, perms)
-            for _ in range(int(config["update_epochs"]) * num_mb):
-                fused.run_mb()
-            fused.end_update()
+            fused.begin_update(flat, adv_f, tgt_f, perms)
+            fused.run_steps(int(config["update_epochs"]) * num_mb)
+            log = fused.end_update()
             if sched is not None:   # ppo.py:186-192: the rate changes between updates only (count // per_update)
                 import warnings
                 with warnings.catch_warnings():

@@ -376,10 +376,14 @@ int brl_ppo_heads_loss(int device, const float *h, int64_t ldh, const float *hea
  * per batch split of <= 64 rows (brl_bias_finalize_ex adds the splits in order: deterministic); dh float [batch, hidden] =
  * (d(heads) head_w) * act'(h) — act 0: ReLU (h > 0), 1: tanh (1 - h^2), src/models.py:16 —, i.e. the gradient w.r.t. the
  * last hidden layer's pre-activation, and tile_sums float [ceil(batch / 16), hidden]: its column sums per 16-row tile
- * (that layer's bias gradient, same layout as brl_relu_bwd_colsum's scratch).  hidden % 256 == 0. */
+ * (that layer's bias gradient, same layout as brl_relu_bwd_colsum's scratch).  hidden % 256 == 0.
+ * gram_sums != NULL: the same launches also add up brl_ppo_heads_loss's loss_partials float [ngroups,8] and gram_partials float
+ * [ngroups,1444] (in group order) into row *row_index (device memory) of stat_sums float [rows,8] / gram_sums float [rows,1444]:
+ * the statistics of a whole update are then formed by ONE brl_ppo_stats_rows at its end instead of a launch per step. */
 int brl_ppo_heads_bwd(int device, const float *dheads, const float *h, int64_t ldh, const float *head_w, int64_t batch,
                       int64_t hidden, int act, int nsplit, float *dw_partials, float *db_partials, float *dh, float *tile_sums,
-                      void *stream);
+                      const float *loss_partials, const float *gram_partials, int64_t ngroups, const int32_t *row_index,
+                      float *stat_sums, float *gram_sums, void *stream);
 
 /* brl_ppo_stats_at from brl_ppo_heads_loss's outputs: partials float [npartials, 8], gram_partials float [ngram, 1444] (summed
  * in order).  The illegal-action norm comes from 4 squarings of G / trace by the whole block and 16 power-iteration steps with
@@ -388,6 +392,19 @@ int brl_ppo_heads_bwd(int device, const float *dheads, const float *h, int64_t l
 int brl_ppo_stats_gram(int device, const float *partials, int64_t npartials, int64_t batch, const float *gram_partials,
                        int64_t ngram, float vf_coef, float ent_coef, float *out_rows, const int32_t *row_index, float *vec_out,
                        void *stream);
+
+/* The log rows of `rows` minibatch steps at once (one block per row): stat_sums / gram_sums as accumulated by
+ * brl_ppo_heads_bwd; out_rows float [rows,8] as brl_ppo_stats_gram writes one. */
+int brl_ppo_stats_rows(int device, const float *stat_sums, const float *gram_sums, int64_t rows, int64_t batch, float vf_coef,
+                       float ent_coef, float *out_rows, void *stream);
+
+/* brl_mb_gather with its arguments in DEVICE memory: brl_mb_gather_bind writes them into args_dev (256 bytes, stream-ordered:
+ * a one-thread launch, no host copy) once per update; brl_mb_gather_dev(args_dev) is then a launch whose parameters never
+ * change, so it can live inside the captured minibatch step and follow a new trajectory / permutation (src/update.py:193-206). */
+int brl_mb_gather_bind(int device, const brl_transition *flat, const float *adv, const float *targets, const int64_t *perm,
+                       const int32_t *mb_index, int64_t mbs, float *x0, uint8_t *mask, int32_t *action, float *old_value,
+                       float *old_log_prob, float *gae_out, float *targets_out, void *args_dev, void *stream);
+int brl_mb_gather_dev(int device, const void *args_dev, int64_t mbs, void *stream);
 
 /* brl_relu_bwd_colsum's tile pass for either activation: dh [rows,ld] *= act'(h) in place (act 0: ReLU, 1: tanh) and the
  * column sums of every 16-row tile into scratch float [ceil(rows / 16), cols]; cols and ld multiples of 4. */

@@ -367,8 +367,9 @@ int brl_ppo_heads_loss(int device, const float *h, int64_t ldh, const float *hw,
   NOT_HERE("brl_ppo_heads_loss");
 }
 int brl_ppo_heads_bwd(int device, const float *dheads, const float *h, int64_t ldh, const float *hw, int64_t b, int64_t hidden,
-                      int act, int nsplit, float *dwp, float *dbp, float *dh, float *ts, void *s) {
-  (void)device; (void)dheads; (void)h; (void)ldh; (void)hw; (void)b; (void)hidden; (void)act; (void)nsplit; (void)dwp; (void)dbp; (void)dh; (void)ts; (void)s;
+                      int act, int nsplit, float *dwp, float *dbp, float *dh, float *ts, const float *lp, const float *gp, int64_t ng,
+                      const int32_t *ri, float *ss, float *gs, void *s) {
+  (void)lp; (void)gp; (void)ng; (void)ri; (void)ss; (void)gs; (void)device; (void)dheads; (void)h; (void)ldh; (void)hw; (void)b; (void)hidden; (void)act; (void)nsplit; (void)dwp; (void)dbp; (void)dh; (void)ts; (void)s;
   NOT_HERE("brl_ppo_heads_bwd");
 }
 int brl_ppo_stats_gram(int device, const float *pt, int64_t np, int64_t b, const float *gp, int64_t ng, float vc, float ec,
@@ -384,4 +385,17 @@ int brl_bias_finalize_ex(int device, int nseg, const float *const *parts, const 
                          float *const *out, void *s) {
   (void)device; (void)nseg; (void)parts; (void)cols; (void)tiles; (void)out; (void)s;
   NOT_HERE("brl_bias_finalize_ex");
+}
+int brl_ppo_stats_rows(int device, const float *ss, const float *gs, int64_t rows, int64_t b, float vc, float ec, float *out, void *s) {
+  (void)device; (void)ss; (void)gs; (void)rows; (void)b; (void)vc; (void)ec; (void)out; (void)s;
+  NOT_HERE("brl_ppo_stats_rows");
+}
+int brl_mb_gather_bind(int device, const brl_transition *flat, const float *adv, const float *tg, const int64_t *perm, const int32_t *mbi,
+                       int64_t mbs, float *x0, uint8_t *m, int32_t *a, float *ov, float *olp, float *go, float *to, void *ad, void *s) {
+  (void)device; (void)flat; (void)adv; (void)tg; (void)perm; (void)mbi; (void)mbs; (void)x0; (void)m; (void)a; (void)ov; (void)olp; (void)go; (void)to; (void)ad; (void)s;
+  NOT_HERE("brl_mb_gather_bind");
+}
+int brl_mb_gather_dev(int device, const void *ad, int64_t mbs, void *s) {
+  (void)device; (void)ad; (void)mbs; (void)s;
+  NOT_HERE("brl_mb_gather_dev");
 }

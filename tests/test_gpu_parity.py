@@ -1528,6 +1528,18 @@ def test_fused_update_helpers_match_torch():
     assert torch.equal(x0, flat.obs[rows].float()) and torch.equal(mask.bool(), flat.legal_action_mask[rows])
     assert torch.equal(act, flat.action[rows]) and torch.equal(ov, flat.value[rows]) and torch.equal(olp, flat.log_prob[rows])
     assert torch.equal(ga, adv[rows]) and torch.equal(tg, tgt[rows])
+    # the same gather with its arguments bound in device memory (what the captured minibatch step launches)
+    gargs = torch.zeros(256, dtype=torch.uint8, device=dev)
+    for t in (x0, mask, act, ov, olp, ga, tg):
+        t.zero_()
+    _capi.check(L.brl_mb_gather_bind(0, C.byref(tp), adv.data_ptr(), tgt.data_ptr(), perm.data_ptr(), mbi.data_ptr(), B, x0.data_ptr(),
+                                     mask.data_ptr(), act.data_ptr(), ov.data_ptr(), olp.data_ptr(), ga.data_ptr(), tg.data_ptr(),
+                                     gargs.data_ptr(), s))
+    mbi.fill_(1)   # read by the launch, not by the bind
+    _capi.check(L.brl_mb_gather_dev(0, gargs.data_ptr(), B, s))
+    rows = perm[B:2 * B]
+    assert torch.equal(x0, flat.obs[rows].float()) and torch.equal(mask.bool(), flat.legal_action_mask[rows])
+    assert torch.equal(act, flat.action[rows]) and torch.equal(ga, adv[rows]) and torch.equal(tg, tgt[rows])
 
 
 @pytest.mark.parametrize("B,H,act", [(1024, 1024, 0), (1000, 1024, 1), (48, 256, 0), (17, 512, 1)])
@@ -1585,8 +1597,15 @@ def test_head_kernels_match_torch_and_the_separate_launches(B, H, act):
     nsplit = (B + 63) // 64
     dwp, dbp = torch.empty(nsplit, 39 * H, device=dev), torch.empty(nsplit, 39, device=dev)
     dh, ts = torch.empty(B, H, device=dev), torch.empty(groups, H, device=dev)
+    # (with the step's statistics sums accumulated by the same launches, into row 2 of per-update buffers)
+    row = torch.full((1,), 2, dtype=torch.int32, device=dev)
+    ssum, gsum, rows_out = torch.zeros(4, 8, device=dev), torch.zeros(4, 1444, device=dev), torch.zeros(4, 8, device=dev)
     _capi.check(L.brl_ppo_heads_bwd(0, dheads.data_ptr(), h.data_ptr(), H, Wh.data_ptr(), B, H, act, nsplit, dwp.data_ptr(),
-                                    dbp.data_ptr(), dh.data_ptr(), ts.data_ptr(), s))
+                                    dbp.data_ptr(), dh.data_ptr(), ts.data_ptr(), partials.data_ptr(), gram_p.data_ptr(), groups,
+                                    row.data_ptr(), ssum.data_ptr(), gsum.data_ptr(), s))
+    _capi.check(L.brl_ppo_stats_rows(0, ssum.data_ptr(), gsum.data_ptr(), 4, B, 0.5, 0.001, rows_out.data_ptr(), s))
+    assert torch.allclose(rows_out[2], out_new, rtol=1e-5, atol=1e-7), (rows_out[2], out_new)   # the per-step launch's row
+    assert float(ssum[[0, 1, 3]].abs().max()) == 0 and float(gsum[[0, 1, 3]].abs().max()) == 0
     import ctypes as C
     gW, gb, gbias = torch.empty(39, H, device=dev), torch.empty(39, device=dev), torch.empty(H, device=dev)
     parts = (C.c_void_p * 3)(dwp.data_ptr(), dbp.data_ptr(), ts.data_ptr())
