@@ -627,6 +627,8 @@ def bench_ppo(args, torch, dev, rank, world, barrier, max_over_ranks):
         torch.cuda.tunable.enable(True)
         torch.cuda.tunable.tuning_enable(True)
         torch.cuda.tunable.set_max_tuning_duration(30)
+        if os.environ.get("BRL_TUNABLEOP_FILE"):
+            torch.cuda.tunable.set_filename(os.environ["BRL_TUNABLEOP_FILE"])
     cfg = dict(DEFAULTS, num_envs=NUM_ENVS, num_steps=NUM_STEPS, minibatch_size=1024, update_epochs=10,
                inference_dtype=os.environ.get("BRL_INFER_DTYPE", "bf16"), graph_rollout=True)
     cfg["num_minibatches"] = cfg["num_envs"] * cfg["num_steps"] // cfg["minibatch_size"]

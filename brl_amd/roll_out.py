@@ -300,6 +300,9 @@ def make_roll_out(config, env: BridgeBidding, actor_forward_pass, opp_forward_pa
     # in the PPO ratio by bf16 rounding (SURVEY §7 "Hard parts") — opt-in, never the default.
     infer_dtype = {None: None, "fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}[config.get("inference_dtype")]
     engines = {}  # (n, static) -> _PolicyRollout
+    if config.get("tuned_gemm", True):   # committed TunableOp solutions for the forwards' GEMM shapes (brl_amd/tuned): lookups only
+        from . import tuned
+        tuned.enable()
 
     def roll_out(runner_state, opp_params):
         params, env_state = runner_state[0], runner_state[2]

@@ -253,6 +253,9 @@ class FusedMinibatch:
         # world > 1: the step is captured in segments, one per all-reduce bucket (see the capture below): ppo.py's pmean as
         # collectives of <= 4.2 MB that overlap with the rest of the backward pass (RCCL over xGMI on MI355X)
         self.world = int(world)
+        if config.get("tuned_gemm", True):   # committed TunableOp solutions for the step's GEMM shapes (brl_amd/tuned): lookups only
+            from . import tuned
+            tuned.enable()
         f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)  # noqa: E731
         body = list(params.body)
         # flat layout: every hidden layer's W, then actor.weight | critic.weight (one [39,1024] matrix), then the biases
@@ -299,12 +302,17 @@ class FusedMinibatch:
         self.Gbh = self.G[ba.start:ba.start + K]
         self.G_bias = self.G[views[body[0].bias].start:ba.start + K]   # every bias gradient, contiguous
         B = self.mbs
-        # world > 1: the backward pass is captured as several graphs, so the activations and the two dh buffers they hand
-        # to each other are static; one graph (world == 1) lets the capture allocate them (out= variants of the fused
-        # bias+ReLU GEMM are slower: 885 vs 834 ms per configs[3] update)
-        self.static = self.world > 1
-        self.h = [f(B, H) for _ in body] if self.static else [None] * len(body)
-        self.dhb = [f(B, H), f(B, H)] if self.static else [None, None]
+        # Activations and the gradients w.r.t. the pre-activations live in STACKED static buffers (out= costs the fused
+        # bias + ReLU GEMM nothing: scripts/fwd_probe.py): segments of a multi-rank step hand them to each other, and the
+        # single-rank step forms the hidden layers' weight gradients as ONE batched product at the end of the backward chain.
+        nl = len(body)
+        self.hs = f(nl, B, H)                       # h_l = act(h_{l-1} W_l^T + b_l)
+        self.dzs = f(nl, B, H)                      # d(loss) / d(pre-activation of layer l)
+        self.h = [self.hs[l] for l in range(nl)]
+        self.dhb = [self.dzs[l] for l in range(nl)]   # (indexed by layer)
+        # W_1 .. W_{nl-1} are consecutive [H, H] blocks of the flat buffer: their gradients as one [nl - 1, H, H] tensor
+        w1 = views[body[1].weight] if nl > 1 else None
+        self.GW_hidden = self.G[w1.start:w1.start + (nl - 1) * H * H].view(nl - 1, H, H) if nl > 1 else None
         self.x0 = f(B, 480)
         self.mask = torch.zeros((B, 38), dtype=torch.uint8, device=device)
         self.mask[:, 0] = 1  # a valid dummy batch for the warm-up iterations
@@ -421,8 +429,11 @@ class FusedMinibatch:
 
     def _fwd_bwd(self):
         self._seg_head()
-        for l in range(len(self.W) - 1, -1, -1):
-            self._seg_layer(l)
+        if self.world == 1:
+            self._backward_chain()
+        else:
+            for l in range(len(self.W) - 1, -1, -1):
+                self._seg_layer(l)
         self._seg_fin()
 
     def _seg_head(self):
@@ -436,15 +447,9 @@ class FusedMinibatch:
         x = self.x0
         for l, (W, b) in enumerate(zip(self.W, self.b)):          # forward: bias + activation
             if self.act == 0:                                     # ReLU in the GEMM epilogue
-                if self.static:
-                    x = torch._addmm_activation(b, x, W.t(), use_gelu=False, out=self.h[l])
-                else:
-                    x = self.h[l] = torch._addmm_activation(b, x, W.t(), use_gelu=False)
+                x = torch._addmm_activation(b, x, W.t(), use_gelu=False, out=self.h[l])
             else:
-                if self.static:
-                    x = torch.addmm(b, x, W.t(), out=self.h[l]).tanh_()
-                else:
-                    x = self.h[l] = torch.addmm(b, x, W.t()).tanh_()
+                x = torch.addmm(b, x, W.t(), out=self.h[l]).tanh_()
         chk(L.brl_ppo_heads_loss(di, x.data_ptr(), x.stride(0), self.Wh.data_ptr(), self.bh.data_ptr(), self.H,
                                  self.mask.data_ptr(), self.action.data_ptr(), self.old_v.data_ptr(), self.old_lp.data_ptr(),
                                  self.adv.data_ptr(), self.tgt.data_ptr(), B, float(cfg["clip_eps"]), float(cfg["vf_coef"]),
@@ -454,9 +459,7 @@ class FusedMinibatch:
         # backward of the head, written out: dW_h / db_h partials per batch split, dz of the top hidden layer (activation
         # derivative applied) and its bias-gradient tile sums
         nl = len(self.W)
-        top = (nl - 1) & 1
-        if not self.static:
-            self.dhb[top] = torch.empty((B, self.H), dtype=torch.float32, device=self.dev)
+        top = nl - 1
         chk(L.brl_ppo_heads_bwd(di, self.dheads.data_ptr(), x.data_ptr(), x.stride(0), self.Wh.data_ptr(), B, self.H, self.act,
                                 self.nsplit, self.dwh_partials.data_ptr(), self.dbh_partials.data_ptr(),
                                 self.dhb[top].data_ptr(), self.tile_sums[nl - 1].data_ptr(), self.partials.data_ptr(),
@@ -464,21 +467,33 @@ class FusedMinibatch:
                                 self.gram_sums.data_ptr(), s))
 
     def _seg_layer(self, l):
-        """backward of hidden layer l: dz (in self.dhb[l & 1]; below the top layer: dh -> dz in place + tile sums), dW_l,
-        dh of the layer below"""
+        """backward of hidden layer l (multi-rank form: one segment per all-reduce bucket): dz_l (below the top layer: dh -> dz
+        in place + tile sums), dW_l, dh of the layer below"""
         L, chk, B = self.lib, self.capi.check, self.mbs
         s = torch.cuda.current_stream().cuda_stream
         di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
-        dh = self.dhb[l & 1]
+        dz = self.dzs[l]
         if l != len(self.W) - 1:   # (the top layer's activation derivative and tile sums came with brl_ppo_heads_bwd)
-            chk(L.brl_act_bwd_colsum(di, dh.data_ptr(), self.h[l].data_ptr(), B, dh.shape[1], dh.shape[1], self.act,
+            chk(L.brl_act_bwd_colsum(di, dz.data_ptr(), self.h[l].data_ptr(), B, self.H, self.H, self.act,
                                      self.tile_sums[l].data_ptr(), s))
-        torch.mm(dh.t(), self.h[l - 1] if l > 0 else self.x0, out=self.GW[l])
+        torch.mm(dz.t(), self.h[l - 1] if l > 0 else self.x0, out=self.GW[l])
         if l > 0:
-            if self.static:
-                torch.mm(dh, self.W[l], out=self.dhb[(l - 1) & 1])
-            else:
-                self.dhb[(l - 1) & 1] = torch.mm(dh, self.W[l])
+            torch.mm(dz, self.W[l], out=self.dzs[l - 1])
+
+    def _backward_chain(self):
+        """single-rank form: the dh chain first (dz_l for every layer), then the weight gradients — layers 1.. as ONE batched
+        product (three 1024^3 products: 58 us instead of 66, scripts/bmm_probe.py), layer 0 (K = 480 columns) beside it"""
+        L, chk, B = self.lib, self.capi.check, self.mbs
+        s = torch.cuda.current_stream().cuda_stream
+        di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        nl = len(self.W)
+        for l in range(nl - 1, 0, -1):
+            torch.mm(self.dzs[l], self.W[l], out=self.dzs[l - 1])
+            chk(L.brl_act_bwd_colsum(di, self.dzs[l - 1].data_ptr(), self.h[l - 1].data_ptr(), B, self.H, self.H, self.act,
+                                     self.tile_sums[l - 1].data_ptr(), s))
+        if nl > 1:
+            torch.bmm(self.dzs[1:].transpose(1, 2), self.hs[:nl - 1], out=self.GW_hidden)
+        torch.mm(self.dzs[0].t(), self.x0, out=self.GW[0])
 
     def _seg_fin(self):
         s = torch.cuda.current_stream().cuda_stream
