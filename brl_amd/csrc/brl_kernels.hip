@@ -1597,25 +1597,59 @@ struct PpoArgs {
   int64_t vs, dls, dvs;  // strides of value, dlogits (row), dvalue: 1, 38, 1 for separate arrays; 39 each for the merged head
 };
 
+// Wave-wide sum / max, result on every lane.  DPP moves inside the rows of 16 lanes (quad swaps, row rotations: every lane ends
+// with its row's value), row_bcast15 / row_bcast31 across the rows, v_readlane of lane 63: 6 register-to-register moves and one
+// scalar read instead of 6 ds_bpermute round trips through the LDS crossbar (__shfl_xor) — the loss of one sample is a chain of
+// ~12 such reductions.  (The order of the additions differs from a butterfly: same value up to fp32 rounding.)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_move_f(float old, float v) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)__float_as_uint(old), (int)__float_as_uint(v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_move_f<0xB1>(0.0f, v);            // quad_perm [1,0,3,2]
+  v += dpp_move_f<0x4E>(0.0f, v);            // quad_perm [2,3,0,1]
+  v += dpp_move_f<0x124>(0.0f, v);           // row_ror:4
+  v += dpp_move_f<0x128>(0.0f, v);           // row_ror:8  -> every lane: its row's sum
+  v += dpp_move_f<0x142, 0xA>(0.0f, v);      // row_bcast15 into rows 1, 3
+  v += dpp_move_f<0x143, 0xC>(0.0f, v);      // row_bcast31 into rows 2, 3 -> lane 63: everything
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 63));
 }
 __device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
+  const float ninf = -INFINITY;
+  v = fmaxf(v, dpp_move_f<0xB1>(ninf, v));
+  v = fmaxf(v, dpp_move_f<0x4E>(ninf, v));
+  v = fmaxf(v, dpp_move_f<0x124>(ninf, v));
+  v = fmaxf(v, dpp_move_f<0x128>(ninf, v));
+  v = fmaxf(v, dpp_move_f<0x142, 0xA>(ninf, v));
+  v = fmaxf(v, dpp_move_f<0x143, 0xC>(ninf, v));
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 63));
 }
 
 // One sample (= one wave, lane a = action a): `lg` = the lane's logit (lanes >= 38: ignored), `v` = the critic's value, `g` =
 // the advantage (already normalised when reward_scaling is on).  Writes dlogits / dvalue / illp of the sample and
 // returns its five statistics terms in st[0..4] (valid on every lane).  `illp_lane` = this lane's illegal-action probability.
-__device__ __forceinline__ void ppo_loss_sample(const PpoArgs &A, int64_t b, bool valid, int lane, float lg, float v, float g,
-                                                float (&st)[5], float &illp_lane) {
-  const bool in = lane < BRL_NUM_ACTIONS;
+// (the sample's inputs are loaded by ppo_sample_load — callers issue it BEFORE whatever produces the logits, so that no global
+//  load sits behind the barrier / GEMM in front of the loss)
+struct PpoSampleIn {
+  bool legal;           // this lane's action is legal
+  int act;              // the action taken
+  float old_logp, old_value, tgt, gae;
+};
+__device__ __forceinline__ PpoSampleIn ppo_sample_load(const PpoArgs &A, int64_t b, bool valid, int lane) {
   const int64_t bb = valid ? b : 0;
-  const bool legal = in && A.mask[bb * BRL_NUM_ACTIONS + lane] != 0;
+  PpoSampleIn S;
+  S.legal = (lane < BRL_NUM_ACTIONS) && A.mask[bb * BRL_NUM_ACTIONS + ((lane < BRL_NUM_ACTIONS) ? lane : 0)] != 0;
+  S.act = A.action[bb];
+  S.old_logp = A.old_logp[bb];
+  S.old_value = A.old_value[bb];
+  S.tgt = A.tgt[bb];
+  S.gae = A.gae[bb];
+  return S;
+}
+__device__ __forceinline__ void ppo_loss_sample(const PpoArgs &A, const PpoSampleIn &S, int64_t b, bool valid, int lane, float lg, float v,
+                                                float g, float (&st)[5], float &illp_lane) {
+  const bool in = lane < BRL_NUM_ACTIONS;
+  const bool legal = S.legal;
   const float invB = 1.0f / (float)A.B;
   // masked policy (src/update.py:12-16, 132-135): log-softmax over the legal actions
   const float mx = wave_max_f(legal ? lg : -INFINITY);
@@ -1627,10 +1661,10 @@ __device__ __forceinline__ void ppo_loss_sample(const PpoArgs &A, int64_t b, boo
   const float lse2 = logf(wave_sum_f(in ? expf(lg - mx2) : 0.0f));
   const float lsm2 = in ? (lg - mx2) - lse2 : 0.0f;
   const float p2 = in ? expf(lsm2) : 0.0f;
-  const int act = A.action[bb];
+  const int act = S.act;
   const float lsel = A.masked ? lsm : lsm2, psel = A.masked ? p : p2;
   const float lp = __shfl(lsel, act & 63, 64);
-  const float logratio = lp - A.old_logp[bb];
+  const float logratio = lp - S.old_logp;
   const float ratio = expf(logratio);
   const float eps = A.clip_eps;
   const float a1 = ratio * g, a2 = fminf(fmaxf(ratio, 1.0f - eps), 1.0f + eps) * g;
@@ -1639,7 +1673,7 @@ __device__ __forceinline__ void ppo_loss_sample(const PpoArgs &A, int64_t b, boo
   const float dratio = ((a1 < a2) || inside) ? -g : 0.0f;  // d(-min(a1, a2)) / d ratio (ties: both branches agree)
   const float dlp = dratio * ratio * invB;
   // value loss (src/update.py:48-60)
-  const float ov = A.old_value[bb], t = A.tgt[bb];
+  const float ov = S.old_value, t = S.tgt;
   float vl, dv;
   if (A.value_clipping) {
     const float dcl = fminf(fmaxf(v - ov, -eps), eps);
@@ -1678,8 +1712,9 @@ __global__ __launch_bounds__(256) void k_ppo_loss(PpoArgs A) {
   const bool valid = b < A.B;
   const int64_t bb = valid ? b : 0;
   const float lg = (lane < BRL_NUM_ACTIONS) ? A.logits[bb * A.ls + lane] : 0.0f;
+  const PpoSampleIn S = ppo_sample_load(A, b, valid, lane);
   float st[5], ill;
-  ppo_loss_sample(A, b, valid, lane, lg, A.value[bb * A.vs], A.gae[bb], st, ill);
+  ppo_loss_sample(A, S, b, valid, lane, lg, A.value[bb * A.vs], S.gae, st, ill);
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < 5; k++) part[wave][k] = st[k];

@@ -13,8 +13,8 @@
 // Included by brl_kernels.hip after ppo_update.hpp.
 #pragma once
 
-constexpr int HD_ROWS = 16;    // samples per workgroup of k_heads_loss
-constexpr int HD_WAVES = 16;   // waves per workgroup = K splits = samples per workgroup (one wave finishes one sample)
+constexpr int HD_ROWS = 4;     // samples per workgroup of k_heads_loss (of the 16 rows of an MFMA tile; see the kernel)
+constexpr int HD_WAVES = 8;    // waves per workgroup = K splits; waves 0..3 finish one sample each
 constexpr int HD_NOUT = BRL_NUM_ACTIONS + 1;   // 39
 constexpr int HD_GRAM = BRL_NUM_ACTIONS * BRL_NUM_ACTIONS;   // 1444
 
@@ -28,12 +28,21 @@ struct HeadsLossArgs {
   int H;                // % 16 == 0
   PpoArgs P;            // .logits / .value unused (computed here); outputs in the merged [B, 39] layout
   float *heads_out;     // [B, 39] or NULL
-  float *gram_partials; // [ceil(B / 16)][1444] or NULL
+  float *gram_partials; // [ceil(B / 4)][1444] or NULL
   int reward_scaling;   // src/update.py:31-44: advantages normalised over the minibatch (jnp std: ddof = 0)
 };
 
+#ifdef HD_TIMING   // scripts/time_heads.py --stamps (a -DHD_TIMING build): shader cycles at 6 points of workgroup 0..63, wave 0, into heads_out
+#define HD_STAMP(k) do { if (tid == 0) hd_st[k] = (float)(__builtin_amdgcn_s_memtime() - hd_t0); } while (0)
+#else
+#define HD_STAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
-  __shared__ float red[HD_WAVES][3][4][64];            // K-split partial sums (48 KB)
+#ifdef HD_TIMING
+  const unsigned long long hd_t0 = __builtin_amdgcn_s_memtime();
+  float hd_st[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#endif
+  __shared__ float red[HD_WAVES][3][4][16];            // K-split partial sums of tile rows 0..3 (6 KB)
   __shared__ float illp_s[HD_ROWS][BRL_NUM_ACTIONS + 2];
   __shared__ float part_s[HD_ROWS][8];
   __shared__ float rs_red[HD_WAVES], rs_stat[2];
@@ -74,11 +83,20 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
     adv_inv = rs_stat[1];
   }
 
+  // everything the loss of this wave's sample reads from global memory, issued NOW (consumed behind the barrier below)
+  const int64_t my_b = row0 + ((w < HD_ROWS) ? w : 0);
+  const bool my_valid = w < HD_ROWS && my_b < B;
+  const PpoSampleIn my_in = ppo_sample_load(A.P, my_b, my_valid, lane);
+  const float my_bias = (lane < HD_NOUT) ? A.bh[lane] : 0.0f;
+
   // ---- heads of 16 samples: D[sample][n] = sum_k h[sample][k] W_h[n][k]; wave w takes the 16-deep K groups w, w + 8, ..
   // lane (r, kq): A row = sample r, B column = head n = 16 nb + r, K = 16 g + 4 kq + s in MFMA step s (the K order inside a
   // group is permuted the same way for both operands)
+  // Only FOUR of the tile's 16 rows are real samples (the others repeat them): the heads product is ~80 MFLOP — nothing —, but the
+  // loss behind it is ~900 VALU instructions per sample, and with 16 samples per workgroup only 64 CUs would share them, four
+  // waves deep on every SIMD (measured: 14 k cycles of 25 k).  256 workgroups x 4 samples: one loss wave per SIMD, every CU busy.
   const int r = lane & 15, kq = lane >> 4;
-  const int64_t arow = (row0 + r < B) ? row0 + r : B - 1;
+  const int64_t arow = (row0 + (r & (HD_ROWS - 1)) < B) ? row0 + (r & (HD_ROWS - 1)) : B - 1;
   const float *ap = A.h + arow * A.ldh + 4 * kq;
   const float *bp[3];
   bool bok[3];
@@ -93,8 +111,8 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
   for (int nb = 0; nb < 3; nb++) acc[nb] = hd_f32x4{0.f, 0.f, 0.f, 0.f};
   const int ngroups = A.H / 16;
   // (latency-bound: 64 workgroups, every operand read once — so ALL of a wave's loads are in flight before the first MFMA:
-  //  4 groups per pass = 4 + 12 16-byte loads per lane = the whole K range of the wave at H = 1024)
-  constexpr int GP = 4;
+  //  8 groups per pass = 8 + 24 16-byte loads per lane = the whole K range of the wave at H = 1024)
+  constexpr int GP = 8;
   for (int g0 = w; g0 < ngroups; g0 += GP * HD_WAVES) {
     hd_f32x4 av[GP], bv[GP][3];
 #pragma unroll
@@ -105,6 +123,10 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
 #pragma unroll
       for (int nb = 0; nb < 3; nb++) bv[u][nb] = *reinterpret_cast<const hd_f32x4 *>(bp[nb] + 16 * gc);
     }
+#ifdef HD_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HD_STAMP(1);   // operands have arrived
+#endif
 #pragma unroll
     for (int u = 0; u < GP; u++) {
       if (g0 + u * HD_WAVES >= ngroups) break;
@@ -116,38 +138,43 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
       }
     }
   }
+  HD_STAMP(0);   // loads + MFMAs done
   // accumulator register q of lane (c, rq): D[sample 4 rq + q][head 16 nb + c]
+  static_assert(HD_ROWS == 4, "tile rows 0..3 = registers 0..3 of lanes 0..15");
+  if (lane < 16) {
 #pragma unroll
-  for (int nb = 0; nb < 3; nb++)
+    for (int nb = 0; nb < 3; nb++)
 #pragma unroll
-    for (int q = 0; q < 4; q++) red[w][nb][q][lane] = acc[nb][q];
+      for (int q = 0; q < 4; q++) red[w][nb][q][lane] = acc[nb][q];
+  }
   __syncthreads();
 
-  // ---- `_loss_fn` (src/update.py:90-167): wave w takes sample w; lane a = head a
-  static_assert(HD_WAVES == HD_ROWS, "one wave per sample");
-  for (int sl = w; sl < w + 1; sl++) {
-    const int64_t b = row0 + sl;
-    const bool valid = b < B;
+  // ---- `_loss_fn` (src/update.py:90-167): wave w < 4 takes sample w; lane a = head a
+  if (w < HD_ROWS) {
+    const int sl = w;
+    const int64_t b = my_b;
+    const bool valid = my_valid;
     float hv = 0.0f;
     if (lane < HD_NOUT) {
-      const int nb = lane >> 4, c = lane & 15, q = sl & 3, rq = sl >> 2;
-      hv = A.bh[lane];
+      const int nb = lane >> 4, c = lane & 15;
+      hv = my_bias;
 #pragma unroll
-      for (int k = 0; k < HD_WAVES; k++) hv += red[k][nb][q][16 * rq + c];   // fixed order
+      for (int k = 0; k < HD_WAVES; k++) hv += red[k][nb][sl][c];   // fixed order
       if (valid && A.heads_out) A.heads_out[b * HD_NOUT + lane] = hv;
     }
     const float v = __shfl(hv, BRL_NUM_ACTIONS, 64);
-    const int64_t bb = valid ? b : 0;
-    const float g = A.reward_scaling ? (A.P.gae[bb] - adv_mean) * adv_inv : A.P.gae[bb];
+    const float g = A.reward_scaling ? (my_in.gae - adv_mean) * adv_inv : my_in.gae;
     float st[5], ill;
-    ppo_loss_sample(A.P, b, valid, lane, hv, v, g, st, ill);
+    ppo_loss_sample(A.P, my_in, b, valid, lane, hv, v, g, st, ill);
     if (lane < BRL_NUM_ACTIONS) illp_s[sl][lane] = valid ? ill : 0.0f;
     if (lane == 0) {   // (st is wave-uniform)
 #pragma unroll
       for (int k = 0; k < 8; k++) part_s[sl][k] = (k < 5) ? st[k] : 0.0f;
     }
   }
+  HD_STAMP(2);   // this wave's loss done
   __syncthreads();
+  HD_STAMP(3);   // everybody's loss done
   if (tid < 8) {   // per-workgroup partial sums over its 16 samples, in order (deterministic statistics)
     float s = 0.0f;
     for (int k = 0; k < HD_ROWS; k++) s += part_s[k][tid];
@@ -162,6 +189,13 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
       A.gram_partials[(int64_t)blockIdx.x * HD_GRAM + e] = s;
     }
   }
+#ifdef HD_TIMING
+  __syncthreads();
+  HD_STAMP(4);
+  if (tid == 0 && A.heads_out) {   // (row 1023's columns 0..4 of workgroup-indexed scratch: heads_out must be [B + 64, 39] in the timing script)
+    for (int k = 0; k < 5; k++) A.heads_out[(A.P.B + blockIdx.x) * HD_NOUT + k] = hd_st[k];
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -194,31 +228,42 @@ struct HeadsBwdArgs {
   float *stat_sums;             // [rows][8]
   float *gram_sums;             // [rows][1444]
 };
-constexpr int HB_GRAM_BLOCKS = 6;   // 6 x 256 threads >= 1444 Gram entries
+constexpr int HB_GRAM_BLOCKS = 91;  // 91 x 256 threads >= 16 x (1444 Gram entries + 8 statistics)
 
 __global__ __launch_bounds__(256) void k_heads_bwd_dw(HeadsBwdArgs A) {
   __shared__ __attribute__((aligned(16))) float dh_s[64][HD_NOUT + 1];   // d(heads) rows of this workgroup (pad: 40 floats)
   __shared__ __attribute__((aligned(16))) float h_s[64][64];             // the split's tile of h
   const int tid = (int)threadIdx.x;
   if ((int)blockIdx.x >= A.blocks_a) {
-    // ---- extra workgroups: Gram matrix and statistics sums of this step, in workgroup order (deterministic); 16 loads in flight
+    // ---- extra workgroups: Gram matrix and statistics sums of this step.  Latency-bound (256 partial rows per entry at batch
+    // 1024), so every entry is summed by SIXTEEN threads (a sixteenth of the rows each, all loads in flight), combined in a
+    // fixed order: deterministic
+    __shared__ float gs_part[256];
     const int64_t row = *A.row_index;
-    const int e = ((int)blockIdx.x - A.blocks_a) * 256 + tid;
+    const int gid = ((int)blockIdx.x - A.blocks_a) * 256 + tid;
+    const int e = gid >> 4, part = gid & 15;
+    const int chunk = (A.ngroups + 15) / 16, i0 = part * chunk, i1 = (i0 + chunk < A.ngroups) ? i0 + chunk : A.ngroups;
+    float s = 0.0f;
     if (e < HD_GRAM) {
-      float s = 0.0f;
-      for (int i = 0; i < A.ngroups; i += 16) {
+      for (int i = i0; i < i1; i += 16) {
         float v[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) v[u] = A.gram_partials[(int64_t)((i + u < A.ngroups) ? i + u : i) * HD_GRAM + e];
+        for (int u = 0; u < 16; u++) v[u] = A.gram_partials[(int64_t)((i + u < i1) ? i + u : i0) * HD_GRAM + e];
 #pragma unroll
-        for (int u = 0; u < 16; u++) s += (i + u < A.ngroups) ? v[u] : 0.0f;
+        for (int u = 0; u < 16; u++) s += (i + u < i1) ? v[u] : 0.0f;
       }
-      A.gram_sums[row * HD_GRAM + e] = s;
     } else if (e < HD_GRAM + 8) {
       const int k = e - HD_GRAM;
-      float s = 0.0f;
-      for (int i = 0; i < A.ngroups; i++) s += A.loss_partials[(int64_t)i * 8 + k];
-      A.stat_sums[row * 8 + k] = s;
+      for (int i = i0; i < i1; i++) s += A.loss_partials[(int64_t)i * 8 + k];
+    }
+    gs_part[tid] = s;
+    __syncthreads();
+    if (part == 0) {
+      float tot = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; k++) tot += gs_part[tid + k];   // fixed order
+      if (e < HD_GRAM) A.gram_sums[row * HD_GRAM + e] = tot;
+      else if (e < HD_GRAM + 8) A.stat_sums[row * 8 + (e - HD_GRAM)] = tot;
     }
     return;
   }
@@ -235,6 +280,7 @@ __global__ __launch_bounds__(256) void k_heads_bwd_dw(HeadsBwdArgs A) {
     for (int u = 0; u < 4; u++) {
       const int rr = (tid >> 4) + 16 * u;   // 16 threads per row of 64 floats
       hv4[u] = *reinterpret_cast<const float4 *>(A.h + (b0 + ((rr < nb) ? rr : 0)) * A.ldh + jt * HB_JT + 4 * (tid & 15));
+      if (rr >= nb) hv4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     constexpr int DPT = (64 * HD_NOUT + 255) / 256;   // d(heads) elements per thread
     float dv[DPT];
@@ -255,26 +301,31 @@ __global__ __launch_bounds__(256) void k_heads_bwd_dw(HeadsBwdArgs A) {
 #pragma unroll
     for (int u = 0; u < 4; u++) *reinterpret_cast<float4 *>(&h_s[(tid >> 4) + 16 * u][4 * (tid & 15)]) = hv4[u];
     __syncthreads();
-    const int j = tid & 63, ng = tid >> 6;
-    float acc[HB_NG];
+    // D[n][j] = sum_b d(heads)[b][n] h[b][j] on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32): wave w owns columns
+    // 16 w .. 16 w + 15 of the tile and all three 16-head blocks; lane (c, kq): A row / B column c, K = 4 s + kq in step s.
+    // (As plain FMAs with the operands broadcast from LDS this role was LDS-bound: 6 LDS reads per 10 FMAs.)
+    const int lane = tid & 63, w = tid >> 6, c = lane & 15, kq = lane >> 4;
+    hd_f32x4 acc[3];
 #pragma unroll
-    for (int q = 0; q < HB_NG; q++) acc[q] = 0.0f;
-#pragma unroll 8
-    for (int rr = 0; rr < nb; rr++) {
-      const float hu = h_s[rr][j];
-      const float2 *dp = reinterpret_cast<const float2 *>(&dh_s[rr][ng * HB_NG]);   // (40-float rows, 10-float groups: 8-byte aligned)
+    for (int nbk = 0; nbk < 3; nbk++) acc[nbk] = hd_f32x4{0.f, 0.f, 0.f, 0.f};
+    int ncol[3];
 #pragma unroll
-      for (int q = 0; q < HB_NG / 2; q++) {
-        const float2 d = dp[q];
-        acc[2 * q] += d.x * hu;
-        acc[2 * q + 1] += d.y * hu;
+    for (int nbk = 0; nbk < 3; nbk++) ncol[nbk] = (16 * nbk + c < HD_NOUT) ? 16 * nbk + c : HD_NOUT;   // (column 39 = the zero pad)
+#pragma unroll 4
+    for (int st = 0; st < 16; st++) {   // rows past the split's end are zero in both images
+      const float bval = h_s[4 * st + kq][16 * w + c];
+#pragma unroll
+      for (int nbk = 0; nbk < 3; nbk++)
+        acc[nbk] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh_s[4 * st + kq][ncol[nbk]], bval, acc[nbk], 0, 0, 0);
+    }
+    // accumulator register q of lane (c, rq): D[head 16 nbk + 4 rq + q][column 16 w + c]
+#pragma unroll
+    for (int nbk = 0; nbk < 3; nbk++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int n = 16 * nbk + 4 * kq + q;
+        if (n < HD_NOUT) A.dWh_partials[(int64_t)sp * HD_NOUT * A.H + (int64_t)n * A.H + jt * HB_JT + 16 * w + c] = acc[nbk][q];
       }
-    }
-#pragma unroll
-    for (int q = 0; q < HB_NG; q++) {
-      const int n = ng * HB_NG + q;
-      if (n < HD_NOUT) A.dWh_partials[(int64_t)sp * HD_NOUT * A.H + (int64_t)n * A.H + jt * HB_JT + j] = acc[q];
-    }
     if (jt == 0 && tid < HD_NOUT) {   // db_h partial: column sums of d(heads) over the split, in row order
       float s = 0.0f;
       for (int rr = 0; rr < nb; rr++) s += dh_s[rr][tid];

@@ -321,10 +321,11 @@ class FusedMinibatch:
         self.dheads = f(B, K)
         self.H, self.K = H, K
         self.act = 0 if params.act is torch.relu else 1
-        groups = (B + 15) // 16                        # 16-sample groups of brl_ppo_heads_loss / 16-row tiles of the column sums
+        groups = (B + 15) // 16                        # 16-row tiles of the bias-gradient column sums
         self.groups = groups
-        self.partials = f(groups, 8)
-        self.gram_partials = f(groups, 38 * 38)
+        self.lgroups = (B + 3) // 4                    # 4-sample groups of brl_ppo_heads_loss (statistics / Gram partials)
+        self.partials = f(self.lgroups, 8)
+        self.gram_partials = f(self.lgroups, 38 * 38)
         self.out = f(8)
         self.scratch = f(1024)
         self.nsplit = (B + 63) // 64                   # batch splits of the head's weight / bias gradient (brl_ppo_heads_bwd)
@@ -463,7 +464,7 @@ class FusedMinibatch:
         chk(L.brl_ppo_heads_bwd(di, self.dheads.data_ptr(), x.data_ptr(), x.stride(0), self.Wh.data_ptr(), B, self.H, self.act,
                                 self.nsplit, self.dwh_partials.data_ptr(), self.dbh_partials.data_ptr(),
                                 self.dhb[top].data_ptr(), self.tile_sums[nl - 1].data_ptr(), self.partials.data_ptr(),
-                                self.gram_partials.data_ptr(), self.groups, self.mb_index.data_ptr(), self.stat_sums.data_ptr(),
+                                self.gram_partials.data_ptr(), self.lgroups, self.mb_index.data_ptr(), self.stat_sums.data_ptr(),
                                 self.gram_sums.data_ptr(), s))
 
     def _seg_layer(self, l):

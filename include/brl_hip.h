@@ -360,8 +360,8 @@ int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int6
 
 /* heads = h head_w^T + head_b (h float [batch, ldh >= hidden], the last hidden layer's output; head_w float [39, hidden] = actor
  * rows then the critic row; head_b float [39]; hidden % 16 == 0), then `_loss_fn` (src/update.py:90-167) exactly as
- * brl_ppo_loss_heads on that matrix: dheads float [batch,39] = d(total)/d(heads); partials float [ceil(batch / 16) * 8] for
- * brl_ppo_stats_gram; gram_partials (may be NULL) float [ceil(batch / 16) * 1444]: per 16-sample group, P^T P of its
+ * brl_ppo_loss_heads on that matrix: dheads float [batch,39] = d(total)/d(heads); partials float [ceil(batch / 4) * 8] for
+ * brl_ppo_stats_gram; gram_partials (may be NULL) float [ceil(batch / 4) * 1444]: per 4-sample group, P^T P of its
  * illegal-action probabilities (src/update.py:136-141).  reward_scaling != 0: the advantages are normalised over the
  * minibatch first, (gae - mean) / (std + 1e-8) with jnp's ddof = 0 (src/update.py:31-44,118).  heads_out (may be NULL):
  * float [batch,39]. */

@@ -20,12 +20,14 @@ mask = (torch.rand(B, 38, device=dev, generator=g) < 0.6).to(torch.uint8)
 mask[:, 0] = 1
 action = torch.multinomial(mask.float(), 1, generator=g)[:, 0].to(torch.int32)
 old_v, old_lp, gae, tgt = rn(B) * 0.3, -rn(B).abs() - 0.1, rn(B), rn(B) * 0.3
-groups, nsplit = B // 16, B // 64
+groups, lgroups, nsplit = B // 16, B // 4, B // 64
 dheads = torch.empty(B, 39, device=dev)
-partials, gram_p = torch.empty(groups, 8, device=dev), torch.empty(groups, 1444, device=dev)
+partials, gram_p = torch.empty(lgroups, 8, device=dev), torch.empty(lgroups, 1444, device=dev)
 dwp, dbp = torch.empty(nsplit, 39 * H, device=dev), torch.empty(nsplit, 39, device=dev)
 dh, ts = torch.empty(B, H, device=dev), torch.empty(groups, H, device=dev)
 out = torch.zeros(8, device=dev)
+row = torch.zeros(1, dtype=torch.int32, device=dev)
+ssum, gsum, rows_out = torch.zeros(2560, 8, device=dev), torch.zeros(2560, 1444, device=dev), torch.zeros(2560, 8, device=dev)
 gW, gb, gbias = torch.empty(39, H, device=dev), torch.empty(39, device=dev), torch.empty(H, device=dev)
 parts = (C.c_void_p * 3)(dwp.data_ptr(), dbp.data_ptr(), ts.data_ptr())
 cols, tiles = (C.c_int64 * 3)(39 * H, 39, H), (C.c_int64 * 3)(nsplit, nsplit, groups)
@@ -40,11 +42,16 @@ def loss():
 
 def bwd():
     _capi.check(L.brl_ppo_heads_bwd(0, dheads.data_ptr(), h.data_ptr(), H, Wh.data_ptr(), B, H, 0, nsplit, dwp.data_ptr(), dbp.data_ptr(),
-                                    dh.data_ptr(), ts.data_ptr(), s))
+                                    dh.data_ptr(), ts.data_ptr(), partials.data_ptr(), gram_p.data_ptr(), lgroups, row.data_ptr(),
+                                    ssum.data_ptr(), gsum.data_ptr(), s))
 
 
 def stats():
-    _capi.check(L.brl_ppo_stats_gram(0, partials.data_ptr(), groups, B, gram_p.data_ptr(), groups, 0.5, 0.001, out.data_ptr(), None, None, s))
+    _capi.check(L.brl_ppo_stats_gram(0, partials.data_ptr(), lgroups, B, gram_p.data_ptr(), lgroups, 0.5, 0.001, out.data_ptr(), None, None, s))
+
+
+def stats_rows():
+    _capi.check(L.brl_ppo_stats_rows(0, ssum.data_ptr(), gsum.data_ptr(), 2560, B, 0.5, 0.001, rows_out.data_ptr(), s))
 
 
 def fin():
@@ -55,7 +62,7 @@ def act_bwd():
     _capi.check(L.brl_act_bwd_colsum(0, dh.data_ptr(), h.data_ptr(), B, H, H, 0, ts.data_ptr(), s))
 
 
-for name, fn in (("brl_ppo_heads_loss", loss), ("brl_ppo_heads_bwd", bwd), ("brl_ppo_stats_gram", stats), ("brl_bias_finalize_ex (3 segments)", fin),
+for name, fn in (("brl_ppo_heads_loss", loss), ("brl_ppo_heads_bwd", bwd), ("brl_ppo_stats_gram", stats), ("brl_ppo_stats_rows (2560 rows)", stats_rows), ("brl_bias_finalize_ex (3 segments)", fin),
                  ("brl_act_bwd_colsum", act_bwd)):
     for _ in range(20):
         fn()

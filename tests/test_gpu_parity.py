@@ -1559,9 +1559,9 @@ def test_head_kernels_match_torch_and_the_separate_launches(B, H, act):
     mask[:, 0] = 1
     action = torch.multinomial(mask.float(), 1, generator=g)[:, 0].to(torch.int32)
     old_v, old_lp, gae, tgt = rn(B) * 0.3, -rn(B).abs() - 0.1, rn(B), rn(B) * 0.3
-    groups = (B + 15) // 16
+    groups, lgroups = (B + 15) // 16, (B + 3) // 4     # 16-row tiles of the column sums; 4-sample groups of the loss launch
     heads, dheads = torch.empty(B, 39, device=dev), torch.empty(B, 39, device=dev)
-    partials, gram_p = torch.empty(groups, 8, device=dev), torch.empty(groups, 1444, device=dev)
+    partials, gram_p = torch.empty(lgroups, 8, device=dev), torch.empty(lgroups, 1444, device=dev)
     for rscale in (0, 1):
         _capi.check(L.brl_ppo_heads_loss(0, h.data_ptr(), H, Wh.data_ptr(), bh.data_ptr(), H, mask.data_ptr(), action.data_ptr(),
                                          old_v.data_ptr(), old_lp.data_ptr(), gae.data_ptr(), tgt.data_ptr(), B, 0.2, 0.5, 0.001, 1, 1,
@@ -1582,7 +1582,7 @@ def test_head_kernels_match_torch_and_the_separate_launches(B, H, act):
         gram = illp.double().t() @ illp.double()
         assert torch.allclose(gram_p.sum(0).double().reshape(38, 38), gram, rtol=1e-4, atol=1e-7)
         out_new, out_old, vec = torch.zeros(8, device=dev), torch.zeros(8, device=dev), torch.zeros(40, device=dev)
-        _capi.check(L.brl_ppo_stats_gram(0, partials.data_ptr(), groups, B, gram_p.data_ptr(), groups, 0.5, 0.001, out_new.data_ptr(),
+        _capi.check(L.brl_ppo_stats_gram(0, partials.data_ptr(), lgroups, B, gram_p.data_ptr(), lgroups, 0.5, 0.001, out_new.data_ptr(),
                                          None, vec.data_ptr(), s))
         gram32 = gram.float().contiguous()
         _capi.check(L.brl_ppo_stats(0, p2.data_ptr(), B, gram32.data_ptr(), 0.5, 0.001, out_old.data_ptr(), s))
@@ -1601,7 +1601,7 @@ def test_head_kernels_match_torch_and_the_separate_launches(B, H, act):
     row = torch.full((1,), 2, dtype=torch.int32, device=dev)
     ssum, gsum, rows_out = torch.zeros(4, 8, device=dev), torch.zeros(4, 1444, device=dev), torch.zeros(4, 8, device=dev)
     _capi.check(L.brl_ppo_heads_bwd(0, dheads.data_ptr(), h.data_ptr(), H, Wh.data_ptr(), B, H, act, nsplit, dwp.data_ptr(),
-                                    dbp.data_ptr(), dh.data_ptr(), ts.data_ptr(), partials.data_ptr(), gram_p.data_ptr(), groups,
+                                    dbp.data_ptr(), dh.data_ptr(), ts.data_ptr(), partials.data_ptr(), gram_p.data_ptr(), lgroups,
                                     row.data_ptr(), ssum.data_ptr(), gsum.data_ptr(), s))
     _capi.check(L.brl_ppo_stats_rows(0, ssum.data_ptr(), gsum.data_ptr(), 4, B, 0.5, 0.001, rows_out.data_ptr(), s))
     assert torch.allclose(rows_out[2], out_new, rtol=1e-5, atol=1e-7), (rows_out[2], out_new)   # the per-step launch's row
