@@ -28,6 +28,42 @@ from .utils import single_play_step_two_policy_commpetitive_deterministic
 _NEG = torch.finfo(torch.float32).min
 
 
+class _Shard:
+    """This rank's share of the ``num_eval_envs`` boards of one evaluation (ppo.py:366-381,461-484 runs 3-4 evaluators of
+    10 000 boards per iteration; with every rank evaluating all of them a node would do the work 8 times).  Boards are
+    GLOBAL indices: rank r plays the contiguous range [offset, offset + n) — the env handle's ``env_offset``, so each board
+    is dealt exactly as in a single-process evaluation — and the results are sums that are all-reduced once
+    (float64 / int64: IMPs, counts and wins are integers, so every rank gets the single-process numbers).
+    ``shard``: None / False = no sharding; True = torch.distributed's (rank, world) when a process group exists;
+    (rank, world) = explicit."""
+
+    def __init__(self, n_global: int, shard):
+        import torch.distributed as dist
+        if shard is True:
+            shard = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else None
+        self.rank, self.world = (0, 1) if not shard else (int(shard[0]), int(shard[1]))
+        base, extra = divmod(int(n_global), self.world)
+        self.n_global = int(n_global)
+        self.n = base + (1 if self.rank < extra else 0)
+        self.offset = self.rank * base + min(self.rank, extra)
+
+    @property
+    def active(self) -> bool:
+        return self.world > 1
+
+    def init(self, env: BridgeBidding, rng_key) -> State:
+        if self.active:
+            env.env_offset = self.offset      # (env.init re-keys the handle with its current env_offset)
+        return env.init(rng_key, num_envs=self.n)
+
+    def allsum(self, t: torch.Tensor) -> torch.Tensor:
+        """element-wise sum over the ranks (float64 / int64), same result on every rank"""
+        if self.active:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+
 def masked_mode(logits: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     """``Categorical(logits + finfo.min * ~mask).mode()``: arg-max over the legal actions."""
     return torch.where(mask, logits, torch.full_like(logits, _NEG)).argmax(dim=-1).to(torch.int32)
@@ -120,23 +156,32 @@ def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward,
 
 
 def make_simple_duplicate_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_type, team2_activation,
-                                   team2_model_type, num_eval_envs, sync_every: int = 16, record_actions=None):
+                                   team2_model_type, num_eval_envs, sync_every: int = 16, record_actions=None, shard=None):
     """src/evaluation.py:69-204.  ``record_actions``: optional list that receives each iteration's action tensor
-    (tests replay them through the oracle)."""
+    (tests replay them through the oracle).  ``shard`` (see _Shard): the boards are split over the ranks, (mean IMP,
+    standard error, win rate) are those of all ``num_eval_envs`` boards on every rank; the Table_info are this rank's."""
     team1_forward_pass = make_forward_pass(team1_activation, team1_model_type)
     team2_forward_pass = make_forward_pass(team2_activation, team2_model_type)
 
     def duplicate_evaluate(team1_params, team2_params, rng_key):
+        sh = _Shard(num_eval_envs, shard)
         with torch.no_grad():
-            state = eval_env.init(rng_key, num_envs=num_eval_envs)  # src/evaluation.py:93-95
+            state = sh.init(eval_env, rng_key)                       # src/evaluation.py:93-95
             table_a_info = Table_info.from_state(state)              # :96-103
             table_b_info = Table_info.from_state(state)              # :104-111
-            cum_return = torch.zeros(num_eval_envs, dtype=torch.float32, device=eval_env.device)
+            cum_return = torch.zeros(sh.n, dtype=torch.float32, device=eval_env.device)
             fwd1 = _Forward(team1_forward_pass, team1_params)
             fwd2 = fwd1 if team2_params is team1_params else _Forward(team2_forward_pass, team2_params)
             _eval_loop(eval_env, state, fwd1, fwd2, (table_a_info, table_b_info), None, 0, cum_return, None,
                        sync_every, record_actions)                   # :120-197; cum_return += rewards[:, 0] (G8)
             n = float(num_eval_envs)
+            if sh.active:   # sums over every rank's boards (IMPs are integers: exact in float64)
+                x = cum_return.to(torch.float64)
+                t = sh.allsum(torch.stack([x.sum(), (x * x).sum(), (x > 0).sum().to(torch.float64)]))
+                mean = t[0] / n
+                var = ((t[1] - n * mean * mean) / (n - 1.0)).clamp_min(0.0)
+                log_info = (mean.to(torch.float32), (var.sqrt() / (n ** 0.5)).to(torch.float32), (t[2] / n).to(torch.float32))
+                return log_info, table_a_info, table_b_info
             std_error = cum_return.std(unbiased=True) / (n ** 0.5)   # :199
             win_rate = (cum_return > 0).sum() / n                    # :200
             log_info = (cum_return.mean(), std_error, win_rate)
@@ -147,7 +192,7 @@ def make_simple_duplicate_evaluate(eval_env: BridgeBidding, team1_activation, te
 
 def make_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_type, team2_activation, team2_model_type,
                   team2_params, num_eval_envs, game_mode="competitive", duplicate=False, sync_every: int = 16,
-                  record_actions=None, record_logits=None):
+                  record_actions=None, record_logits=None, shard=None):
     """``make_evaluate`` (src/evaluation.py:207-1032).  ``team2_params`` replaces the reference's pickle path.
     Returns ``duplicate_evaluate(actor_params, rng_key) -> (log_info, table_a_info, table_b_info)`` (23-entry
     log_info, :985-1031) or, with ``duplicate=False``, ``evaluate(actor_params, rng_key) -> (state, log_info)``
@@ -171,9 +216,10 @@ def make_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_type, t
             return self.lg
 
     def run(actor_params, rng_key, dup):
-        n, dev = num_eval_envs, eval_env.device
+        sh = _Shard(num_eval_envs, shard)   # (shard: the statistics below are those of all boards, on every rank; the
+        n, dev = sh.n, eval_env.device      #  returned Table_info / State are this rank's boards)
         with torch.no_grad():
-            state = eval_env.init(rng_key, num_envs=n)
+            state = sh.init(eval_env, rng_key)
             tables = (Table_info.from_state(state), Table_info.from_state(state)) if dup else None
             cum_return = torch.zeros(n, dtype=torch.float32, device=dev)
             rewards_sum = None if dup else torch.zeros((n, 4), dtype=torch.float32, device=dev)
@@ -191,11 +237,23 @@ def make_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_type, t
             pb = tables[1]._ptrs() if dup else None
             check(_capi.lib().brl_eval_reduce(eval_env._h, n, C.byref(pa), C.byref(pb) if pb is not None else None,
                                               ptr(stats.bid_count), ptr(state.packed), ptr(counts), _stream()))
-            c = counts.to(torch.float64)
-            fn = float(n)
+            c = sh.allsum(counts).to(torch.float64)   # (exact integer counts: the histograms of all ranks' boards)
+            fn = float(sh.n_global)
             steps = stats.step_count.to(torch.float32)
-            illegal = (stats.illegal_prob_sum / steps).mean(dim=0)          # :857-862 (x / y per board, then mean)
-            passes = (stats.pass_count.to(torch.float32) / steps).mean(dim=0)  # :1029-1030
+            if sh.active:   # per-board ratios are averaged over all boards: all-reduce their sums
+                ratio = sh.allsum(torch.cat([(stats.illegal_prob_sum / steps).to(torch.float64).sum(dim=0),
+                                             (stats.pass_count.to(torch.float32) / steps).to(torch.float64).sum(dim=0)]))
+                illegal, passes = (ratio[:2] / fn).to(torch.float32), (ratio[2:] / fn).to(torch.float32)
+                x = cum_return.to(torch.float64)
+                cr = sh.allsum(torch.stack([x.sum(), (x * x).sum()]))
+                cr_mean = cr[0] / fn
+                cr_se = (((cr[1] - fn * cr_mean * cr_mean) / (fn - 1.0)).clamp_min(0.0).sqrt() / (fn ** 0.5)).to(torch.float32)
+                cr_mean = cr_mean.to(torch.float32)
+            else:
+                illegal = (stats.illegal_prob_sum / steps).mean(dim=0)          # :857-862 (x / y per board, then mean)
+                passes = (stats.pass_count.to(torch.float32) / steps).mean(dim=0)  # :1029-1030
+                cr_mean = cum_return.mean()
+                cr_se = cum_return.std(unbiased=True) / (fn ** 0.5) if dup else None   # :984
             ntab = 2.0 if dup else 1.0
 
             def both(i):  # (table A + table B) / 2 of a per-table ratio count / n  (:985-1028)
@@ -213,12 +271,11 @@ def make_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_type, t
                       (c[45:80].sum() + (c[125:160].sum() if dup else 0.0)).div(fn * ntab).to(torch.float32),
                       both(1), both(2), both(3), both(4), both(5), both(6), both(7), both(8), both(0))
             if dup:
-                std_error = cum_return.std(unbiased=True) / (fn ** 0.5)      # :984
                 score = ((c[9] / fn + c[89] / fn) / 2).to(torch.float32)      # :988
-                log_info = (cum_return.mean(), std_error, score) + common + (passes[0], passes[1])
+                log_info = (cr_mean, cr_se, score) + common + (passes[0], passes[1])
                 return log_info, tables[0], tables[1]
             final = State(eval_env, state.packed).replace(rewards=rewards_sum)  # :582
-            return final, (cum_return.mean(),) + common
+            return final, (cr_mean,) + common
 
     def duplicate_evaluate(actor_params, rng_key):
         return run(actor_params, rng_key, True)
@@ -263,7 +320,7 @@ def make_evaluate_log(log_info):
 
 
 def make_simple_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_type, team2_activation,
-                         team2_model_type, team2_params, num_eval_envs, sync_every: int = 8):
+                         team2_model_type, team2_params, num_eval_envs, sync_every: int = 8, shard=None):
     """src/evaluation.py:11-66: actor (greedy) vs a fixed opponent (greedy) on single tables, no
     auto-reset; returns the mean total reward of the acting player.  ``team2_params`` replaces the
     reference's pickle path (model files are torch modules here)."""
@@ -274,9 +331,10 @@ def make_simple_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_
         step_fn = single_play_step_two_policy_commpetitive_deterministic(
             step_fn=eval_env.step, actor_forward_pass=actor_forward_pass, actor_params=actor_params,
             opp_forward_pass=opp_forward_pass, opp_params=team2_params)
+        sh = _Shard(num_eval_envs, shard)
         with torch.no_grad():
-            state = eval_env.init(rng, num_envs=num_eval_envs)
-            R = torch.zeros(num_eval_envs, dtype=torch.float32, device=eval_env.device)
+            state = sh.init(eval_env, rng)
+            R = torch.zeros(sh.n, dtype=torch.float32, device=eval_env.device)
             it = 0
             while True:
                 actor = state.current_player.to(torch.int64)
@@ -287,6 +345,8 @@ def make_simple_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_
                 it += 1
                 if it % sync_every == 0 and bool(state.terminated.all()):
                     break
+        if sh.active:   # (scores are integers: the float64 sum over the ranks is exact)
+            return (sh.allsum(R.to(torch.float64).sum().reshape(1))[0] / float(num_eval_envs)).to(torch.float32)
         return R.mean()
 
     return simple_evaluate

@@ -73,18 +73,33 @@ def pfsp_probabilities(imp_list, prior_t: float):
     return e / np.sum(e, axis=-1, keepdims=True)
 
 
+PFSP = -3   # opponent_draw: "draw from the league with PFSP weights" — the league evaluation comes first
+
+
+def opponent_draw(config, imp_opp: float, n_pool: int, rng: np.random.RandomState):
+    """First half of the decision tree of ppo.py:381-460, the part that needs no evaluation: None = keep the current
+    opponent (below the threshold), -1 = "latest", an index = uniform FSP draw, PFSP = a prioritised draw follows."""
+    if imp_opp < config["threshold_model_zoo"]:
+        return None
+    if n_pool != 0 and rng.binomial(size=1, n=1, p=config["ratio_model_zoo"])[0]:
+        if config["prioritized_fictitious"]:
+            return PFSP
+        return int(rng.choice(n_pool))
+    return -1
+
+
+def pfsp_draw(config, imps, rng: np.random.RandomState) -> int:
+    """Second half (ppo.py:399-435): checkpoint k with probability softmax(-imp_k / prior_t)."""
+    probabilities = pfsp_probabilities(imps, config["prior_t"])
+    return int(rng.choice(len(probabilities), p=probabilities))
+
+
 def choose_opponent(config, imp_opp: float, params_list, rng: np.random.RandomState, league_imps=None):
     """The decision tree of ppo.py:381-460.  Returns the index into ``params_list`` of the checkpoint to play against,
     -1 for "latest" (the current weights), or None for "keep the current opponent" (below the threshold).
     ``league_imps``: callable returning the IMP of the learner against every checkpoint (PFSP only)."""
-    if imp_opp < config["threshold_model_zoo"]:
-        return None
-    if len(params_list) != 0 and rng.binomial(size=1, n=1, p=config["ratio_model_zoo"])[0]:
-        if config["prioritized_fictitious"]:
-            probabilities = pfsp_probabilities(league_imps(), config["prior_t"])
-            return int(rng.choice(len(probabilities), p=probabilities))
-        return int(rng.choice(len(params_list)))
-    return -1
+    d = opponent_draw(config, imp_opp, len(params_list), rng)
+    return pfsp_draw(config, league_imps(), rng) if d == PFSP else d
 
 
 class LutRotation:
@@ -169,9 +184,12 @@ def train(config, log=print):
         eval_lut = synthetic_lut(config["lut_len"], 10_000)
     rotation = LutRotation(len(luts), config["hash_size"], host_rng)
     env = brl_amd.BridgeBidding(lut=luts[rotation.current], device=dev, env_offset=shard_offset(rank, config["num_envs"]))
-    # evaluation has its OWN handle: env.init(seed) re-keys a handle's RNG, which must not leak into the training tables;
-    # every rank evaluates the same boards (env_offset 0), so the pool decisions agree without communication
+    # evaluation has its OWN handle: env.init(seed) re-keys a handle's RNG, which must not leak into the training tables.
+    # Under a process group every evaluation is SHARDED: rank r plays num_eval_envs / world of the boards (the same global
+    # boards a single process would deal) and the sums are all-reduced, so every rank holds the same statistics and the pool
+    # decisions agree (ppo.py:366-381,461-484 runs 3-4 evaluations of 10 000 boards per iteration)
     eval_env = brl_amd.BridgeBidding(lut=eval_lut, device=dev)
+    sharded = world > 1
 
     actor_fp = make_forward_pass(config["actor_activation"], config["actor_model_type"])
     opp_fp = make_forward_pass(config["opp_activation"], config["opp_model_type"])
@@ -206,13 +224,14 @@ def train(config, log=print):
     do_eval = bool(config["evaluate"])
     simple_evaluate = make_simple_evaluate(eval_env, config["actor_activation"], config["actor_model_type"],
                                            config["eval_opp_activation"], config["eval_opp_model_type"], eval_opp,
-                                           config["num_eval_envs"])                                   # ppo.py:253-261
+                                           config["num_eval_envs"], shard=sharded)                    # ppo.py:253-261
     simple_duplicate_evaluate = make_simple_duplicate_evaluate(
         eval_env, config["actor_activation"], config["actor_model_type"], config["actor_activation"],
-        config["actor_model_type"], config["num_prioritized_envs"])                                 # ppo.py:262-269
+        config["actor_model_type"], config["num_prioritized_envs"], shard=sharded)                  # ppo.py:262-269
     duplicate_evaluate = make_evaluate(eval_env, config["actor_activation"], config["actor_model_type"],
                                        config["eval_opp_activation"], config["eval_opp_model_type"], eval_opp,
-                                       config["num_eval_envs"], game_mode=config["game_mode"], duplicate=True)  # :270-280
+                                       config["num_eval_envs"], game_mode=config["game_mode"], duplicate=True,
+                                       shard=sharded)                                                # :270-280
     eval_rng = config["seed"] + 12345
 
     roll_out = brl_amd.make_roll_out(config, env, actor_fp, opp_fp)
@@ -258,9 +277,13 @@ def train(config, log=print):
                     imps[k] = float(simple_duplicate_evaluate(params, other, eval_rng)[0][0])
                 return imps
 
-            choice = choose_opponent(config, float(imp_opp), params_list, host_rng, league_imps) if rank == 0 else None
-            code = {None: -2}.get(choice, choice)
-            code = broadcast_int(code if rank == 0 else 0, dev)     # every rank plays the opponent rank 0 drew
+            # rank 0 draws (its host RNG is the run's), every rank follows; a PFSP draw needs the league evaluation first,
+            # which all ranks run together (sharded boards, one all-reduce per checkpoint)
+            draw = opponent_draw(config, float(imp_opp), len(params_list), host_rng) if rank == 0 else None
+            code = broadcast_int({None: -2}.get(draw, draw) if rank == 0 else 0, dev)
+            if code == PFSP:
+                imps = league_imps()
+                code = broadcast_int(pfsp_draw(config, imps, host_rng) if rank == 0 else 0, dev)
             if code >= 0:
                 opp_name = params_list[code]
                 opp_params = load_opponent(os.path.join(pool_dir, opp_name), config["actor_activation"], config["actor_model_type"])

@@ -932,6 +932,57 @@ def test_team_alternating_evaluation_equals_lockstep_evaluation(env, n, game_mod
             assert torch.equal(getattr(res[0][2], f), getattr(res[1][2], f))
 
 
+def _sharded_eval_rank(rank, world, port, out_dir, backend="gloo"):
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU of the box
+    out = _run_evaluators(shard=True)
+    torch.save(out, os.path.join(out_dir, f"eval{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_evaluators(shard):
+    """the three evaluators of the ppo.py loop on 1001 boards (an uneven split over two ranks), two different networks"""
+    import brl_amd
+    from brl_amd.evaluation import make_evaluate, make_simple_duplicate_evaluate, make_simple_evaluate
+    from brl_amd.models import make_forward_pass
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wb5_dds_1000.npz"))
+    env = brl_amd.BridgeBidding(lut=(d["keys"], d["values"]))
+    fp = make_forward_pass("relu", "DeepMind")
+    a, b = fp.init(0, device="cuda"), fp.init(1, device="cuda")
+    n = 1001
+    (imp, se, win), _, _ = make_simple_duplicate_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", n, shard=shard)(a, b, 5)
+    log_info, _, _ = make_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", b, n, duplicate=True, shard=shard)(a, 6)
+    score = make_simple_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", b, n, shard=shard)(a, 7)
+    flat = [float(imp), float(se), float(win), float(score)]
+    for x in log_info:
+        flat += [float(v) for v in torch.as_tensor(x).reshape(-1).cpu()]
+    return flat
+
+
+def test_sharded_evaluators_equal_the_single_process_evaluation(tmp_path):
+    """ppo.py:366-381,461-484: under a process group the evaluators split their boards over the ranks (global board indices:
+    the same deals) and all-reduce sums — every rank ends with the single-process statistics (mean IMP, SE, win rate, the 23
+    log_info entries, the single-table score).  Two gloo ranks on this box's GPU; 1001 boards = 501 + 500."""
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mp.start_processes(_sharded_eval_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(tmp_path / "eval0.pt"), torch.load(tmp_path / "eval1.pt")
+    want = _run_evaluators(shard=None)
+    assert r0 == r1                                            # all-reduced: identical on both ranks
+    assert len(want) == len(r0) and np.allclose(r0, want, rtol=2e-5, atol=1e-6), np.abs(np.array(r0) - np.array(want)).max()
+    assert r0[0] == pytest.approx(want[0], abs=1e-6) and want[1] > 0
+
+
 def test_single_table_evaluate_with_statistics_matches_oracle(env, oracle):
     """make_evaluate(duplicate=False) (src/evaluation.py:229-605): 19-entry log_info, rewards accumulated on the state."""
     from brl_amd.evaluation import make_evaluate
