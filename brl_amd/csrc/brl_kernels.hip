@@ -2498,23 +2498,33 @@ extern "C" int brl_ppo_heads_bwd(int device, const float *dheads, const float *h
 }
 
 extern "C" int brl_ppo_stats_gram(int device, const float *partials, int64_t npartials, int64_t batch, const float *gram_partials,
-                                  int64_t ngram, float vf_coef, float ent_coef, float *out_rows, const int32_t *row_index,
-                                  float *vec_out, void *stream) {
+                                  int64_t ngram, float vf_coef, float ent_coef, float illegal_coef, float *out_rows,
+                                  const int32_t *row_index, float *vec_out, void *stream) {
   NEED(partials && out_rows && npartials > 0 && batch > 0, "partials / out_rows / npartials / batch");
   NEED(gram_partials && ngram > 0, "gram_partials / ngram");
   HIP_TRY(hipSetDevice(device));
   hipLaunchKernelGGL(k_ppo_stats2, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, npartials, batch, gram_partials, ngram,
-                     vf_coef, ent_coef, out_rows, row_index, vec_out);
+                     vf_coef, ent_coef, illegal_coef, out_rows, row_index, vec_out);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_ppo_illegal_grad(int device, const float *heads, const uint8_t *mask, const float *vec, float illegal_coef,
+                                    int64_t batch, float *dheads, void *stream) {
+  NEED(heads && mask && vec && dheads && batch > 0, "heads / mask / vec / dheads / batch");
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(k_illegal_grad, dim3(thread_grid(batch, 4)), dim3(256), 0, (hipStream_t)stream, heads, mask, vec, illegal_coef,
+                     batch, dheads);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }
 
 extern "C" int brl_ppo_stats_rows(int device, const float *stat_sums, const float *gram_sums, int64_t rows, int64_t batch, float vf_coef,
-                                  float ent_coef, float *out_rows, void *stream) {
+                                  float ent_coef, float illegal_coef, float *out_rows, void *stream) {
   NEED(stat_sums && gram_sums && out_rows && rows > 0 && batch > 0, "stat_sums / gram_sums / out_rows / rows / batch");
   HIP_TRY(hipSetDevice(device));
   hipLaunchKernelGGL(k_ppo_stats2, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, stat_sums, (int64_t)1, batch, gram_sums,
-                     (int64_t)1, vf_coef, ent_coef, out_rows, (const int32_t *)nullptr, (float *)nullptr);
+                     (int64_t)1, vf_coef, ent_coef, illegal_coef, out_rows, (const int32_t *)nullptr, (float *)nullptr);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

@@ -411,8 +411,8 @@ __global__ __launch_bounds__(256) void k_heads_bwd_dh(HeadsBwdArgs A) {
 // v <- M^16 v / |.| by one wave (= G^256 v, the Perron vector to (l2 / l1)^256), Rayleigh quotient with the original G.
 // v1 and the norm are also written to `vec_out` [40] (v1[0..37], sigma_1, 0) when given: the gradient of the norm needs them.
 __global__ __launch_bounds__(1024) void k_ppo_stats2(const float *partials, int64_t nblk, int64_t batch, const float *gram_partials,
-                                                    int64_t ngram, float vf_coef, float ent_coef, float *out, const int32_t *row_index,
-                                                    float *vec_out) {
+                                                    int64_t ngram, float vf_coef, float ent_coef, float ill_coef, float *out,
+                                                    const int32_t *row_index, float *vec_out) {
   if (row_index != nullptr) out += 8 * (int64_t)(*row_index);
   // (brl_ppo_stats_rows: one block per row of per-update buffers — already reduced to one partial row each)
   out += 8 * (int64_t)blockIdx.x;
@@ -489,9 +489,30 @@ __global__ __launch_bounds__(1024) void k_ppo_stats2(const float *partials, int6
     if (vec_out != nullptr && lane < D + 2) vec_out[lane] = (lane < D) ? v * (1.0f / sqrtf(fmaxf(den, 1.17549435e-38f))) : ((lane == D) ? sigma : 0.0f);
     if (lane == 0) {
       out[6] = 0.5f * sigma;
-      out[0] = st[1] + vf_coef * st[0] - ent_coef * st[2];
+      out[0] = st[1] + vf_coef * st[0] - ent_coef * st[2] + ill_coef * (0.5f * sigma);   // src/update.py:146-152
       out[1] = st[0]; out[2] = st[1]; out[3] = st[2]; out[4] = st[3]; out[5] = st[4];
       out[7] = 0.0f;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// illegal_action_l2norm_coef != 0 (src/update.py:136-152): the loss gains coef * sigma_1(P) / 2 with P[b][a] = softmax(logits)[b][a]
+// on the illegal actions.  d sigma_1 / dP = u1 v1^T (top singular pair), u1 = P v1 / sigma_1, so with q_b = (P v1)[b]:
+//     d loss / d logit[b][j] += (coef / 2) (q_b / sigma_1) p[b][j] (illegal[b][j] v1[j] - q_b)
+// One wave per sample, lane = action; v1 / sigma_1 from k_ppo_stats2's vec_out of THIS step; added to dheads in place.
+__global__ __launch_bounds__(256) void k_illegal_grad(const float *heads, const uint8_t *mask, const float *vec, float coef, int64_t B,
+                                                      float *dheads) {
+  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const bool in = lane < BRL_NUM_ACTIONS;
+  const float lg = in ? heads[b * HD_NOUT + lane] : 0.0f;
+  const bool illegal = in && mask[b * BRL_NUM_ACTIONS + lane] == 0;
+  const float v1 = in ? vec[lane] : 0.0f, sigma = vec[BRL_NUM_ACTIONS];
+  const float mx = wave_max_f(in ? lg : -INFINITY);
+  const float ex = in ? expf(lg - mx) : 0.0f;
+  const float p = ex / wave_sum_f(ex);
+  const float q = wave_sum_f(illegal ? p * v1 : 0.0f);
+  if (in && sigma > 0.0f) dheads[b * HD_NOUT + lane] += (0.5f * coef) * (q / sigma) * p * ((illegal ? v1 : 0.0f) - q);
 }

@@ -240,10 +240,10 @@ class FusedMinibatch:
 
     @staticmethod
     def supports(config, params) -> bool:
-        # the DeepMind MLPs (4 / 6 / 8 x 1024) with either activation (src/models.py:16), reward_scaling included; a non-zero
-        # illegal_action_l2norm_coef (the spectral norm then needs a gradient) and the FAIR net take the autograd path
+        # the DeepMind MLPs (4 / 6 / 8 x 1024) with either activation (src/models.py:16), reward_scaling and a non-zero
+        # illegal_action_l2norm_coef included; the FAIR net takes the autograd path
         return (bool(config.get("fused_update", True)) and str(getattr(params, "model", "")).startswith("DeepMind")
-                and getattr(params, "act", None) in (torch.relu, torch.tanh) and not config.get("illegal_action_l2norm_coef", 0.0)
+                and getattr(params, "act", None) in (torch.relu, torch.tanh)
                 and params.body[0].weight.shape[0] % 256 == 0
                 and next(params.parameters()).is_cuda and next(params.parameters()).dtype == torch.float32)
 
@@ -319,6 +319,9 @@ class FusedMinibatch:
         self.action = torch.zeros(B, dtype=torch.int32, device=device)
         self.old_v, self.old_lp, self.adv, self.tgt = f(B), f(B), f(B), f(B)
         self.dheads = f(B, K)
+        self.ill_coef = float(config.get("illegal_action_l2norm_coef", 0.0) or 0.0)
+        self.heads = f(B, K) if self.ill_coef else None      # the gradient of the illegal-action norm re-reads the logits
+        self.vec = f(40) if self.ill_coef else None          # v1 [38], sigma_1 of the step's illegal-action matrix
         self.H, self.K = H, K
         self.act = 0 if params.act is torch.relu else 1
         groups = (B + 15) // 16                        # 16-row tiles of the bias-gradient column sums
@@ -455,8 +458,17 @@ class FusedMinibatch:
                                  self.mask.data_ptr(), self.action.data_ptr(), self.old_v.data_ptr(), self.old_lp.data_ptr(),
                                  self.adv.data_ptr(), self.tgt.data_ptr(), B, float(cfg["clip_eps"]), float(cfg["vf_coef"]),
                                  float(cfg["ent_coef"]), int(bool(cfg.get("actor_illegal_action_mask", True))),
-                                 int(bool(cfg.get("value_clipping", True))), int(bool(cfg.get("reward_scaling", False))), None,
+                                 int(bool(cfg.get("value_clipping", True))), int(bool(cfg.get("reward_scaling", False))),
+                                 self.heads.data_ptr() if self.ill_coef else None,
                                  self.dheads.data_ptr(), self.partials.data_ptr(), self.gram_partials.data_ptr(), s))
+        if self.ill_coef:
+            # src/update.py:146-152: + coef * sigma_1(P) / 2 — its gradient needs the step's top singular pair NOW (the logged
+            # statistics otherwise wait for the end of the update): one stats launch on the critical path of this configuration
+            chk(L.brl_ppo_stats_gram(di, self.partials.data_ptr(), self.lgroups, B, self.gram_partials.data_ptr(), self.lgroups,
+                                     float(cfg["vf_coef"]), float(cfg["ent_coef"]), self.ill_coef, self.out.data_ptr(), None,
+                                     self.vec.data_ptr(), s))
+            chk(L.brl_ppo_illegal_grad(di, self.heads.data_ptr(), self.mask.data_ptr(), self.vec.data_ptr(), self.ill_coef, B,
+                                       self.dheads.data_ptr(), s))
         # backward of the head, written out: dW_h / db_h partials per batch split, dz of the top hidden layer (activation
         # derivative applied) and its bias-gradient tile sums
         nl = len(self.W)
@@ -581,7 +593,8 @@ class FusedMinibatch:
                 self.opt.state[q]["step"].copy_(self.step)
             self.capi.check(self.lib.brl_ppo_stats_rows(di, self.stat_sums.data_ptr(), self.gram_sums.data_ptr(), self._steps,
                                                         self.mbs, float(self.cfg["vf_coef"]), float(self.cfg["ent_coef"]),
-                                                        self.log.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                                                        self.ill_coef, self.log.data_ptr(),
+                                                        torch.cuda.current_stream().cuda_stream))
             self._bind_gather(*self._dummy)   # (the trajectory may be freed by the caller now)
         self._keep = None
         return self.log[:self._steps]

@@ -387,16 +387,22 @@ int brl_ppo_heads_bwd(int device, const float *dheads, const float *h, int64_t l
 
 /* brl_ppo_stats_at from brl_ppo_heads_loss's outputs: partials float [npartials, 8], gram_partials float [ngram, 1444] (summed
  * in order).  The illegal-action norm comes from 4 squarings of G / trace by the whole block and 16 power-iteration steps with
- * that matrix (G^256 v, as brl_ppo_stats).  row_index may be NULL (row 0).  vec_out (may be NULL): float [40] = the top right
+ * that matrix (G^256 v, as brl_ppo_stats).  total_loss includes illegal_coef * norm / 2.  row_index may be NULL (row 0).  vec_out (may be NULL): float [40] = the top right
  * singular vector v1 [38], sigma_1, 0 — what the gradient of the norm needs (d sigma_1 / dP = u1 v1^T). */
 int brl_ppo_stats_gram(int device, const float *partials, int64_t npartials, int64_t batch, const float *gram_partials,
-                       int64_t ngram, float vf_coef, float ent_coef, float *out_rows, const int32_t *row_index, float *vec_out,
-                       void *stream);
+                       int64_t ngram, float vf_coef, float ent_coef, float illegal_coef, float *out_rows, const int32_t *row_index,
+                       float *vec_out, void *stream);
+
+/* illegal_action_l2norm_coef != 0 (src/update.py:146-152): adds d(illegal_coef * sigma_1(P) / 2) / d(logits) to dheads float
+ * [batch,39] in place — heads float [batch,39] as brl_ppo_heads_loss wrote them (heads_out), vec = brl_ppo_stats_gram's vec_out of
+ * the same minibatch (the top right singular vector and sigma_1: d sigma_1 / dP = u1 v1^T with u1 = P v1 / sigma_1). */
+int brl_ppo_illegal_grad(int device, const float *heads, const uint8_t *mask, const float *vec, float illegal_coef, int64_t batch,
+                         float *dheads, void *stream);
 
 /* The log rows of `rows` minibatch steps at once (one block per row): stat_sums / gram_sums as accumulated by
  * brl_ppo_heads_bwd; out_rows float [rows,8] as brl_ppo_stats_gram writes one. */
 int brl_ppo_stats_rows(int device, const float *stat_sums, const float *gram_sums, int64_t rows, int64_t batch, float vf_coef,
-                       float ent_coef, float *out_rows, void *stream);
+                       float ent_coef, float illegal_coef, float *out_rows, void *stream);
 
 /* brl_mb_gather with its arguments in DEVICE memory: brl_mb_gather_bind writes them into args_dev (256 bytes, stream-ordered:
  * a one-thread launch, no host copy) once per update; brl_mb_gather_dev(args_dev) is then a launch whose parameters never

@@ -372,9 +372,9 @@ int brl_ppo_heads_bwd(int device, const float *dheads, const float *h, int64_t l
   (void)lp; (void)gp; (void)ng; (void)ri; (void)ss; (void)gs; (void)device; (void)dheads; (void)h; (void)ldh; (void)hw; (void)b; (void)hidden; (void)act; (void)nsplit; (void)dwp; (void)dbp; (void)dh; (void)ts; (void)s;
   NOT_HERE("brl_ppo_heads_bwd");
 }
-int brl_ppo_stats_gram(int device, const float *pt, int64_t np, int64_t b, const float *gp, int64_t ng, float vc, float ec,
+int brl_ppo_stats_gram(int device, const float *pt, int64_t np, int64_t b, const float *gp, int64_t ng, float vc, float ec, float ic,
                        float *out, const int32_t *ri, float *vec, void *s) {
-  (void)device; (void)pt; (void)np; (void)b; (void)gp; (void)ng; (void)vc; (void)ec; (void)out; (void)ri; (void)vec; (void)s;
+  (void)ic; (void)device; (void)pt; (void)np; (void)b; (void)gp; (void)ng; (void)vc; (void)ec; (void)out; (void)ri; (void)vec; (void)s;
   NOT_HERE("brl_ppo_stats_gram");
 }
 int brl_act_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, int act, float *scr, void *s) {
@@ -386,8 +386,9 @@ int brl_bias_finalize_ex(int device, int nseg, const float *const *parts, const 
   (void)device; (void)nseg; (void)parts; (void)cols; (void)tiles; (void)out; (void)s;
   NOT_HERE("brl_bias_finalize_ex");
 }
-int brl_ppo_stats_rows(int device, const float *ss, const float *gs, int64_t rows, int64_t b, float vc, float ec, float *out, void *s) {
-  (void)device; (void)ss; (void)gs; (void)rows; (void)b; (void)vc; (void)ec; (void)out; (void)s;
+int brl_ppo_stats_rows(int device, const float *ss, const float *gs, int64_t rows, int64_t b, float vc, float ec, float ic, float *out,
+                       void *s) {
+  (void)ic; (void)device; (void)ss; (void)gs; (void)rows; (void)b; (void)vc; (void)ec; (void)out; (void)s;
   NOT_HERE("brl_ppo_stats_rows");
 }
 int brl_mb_gather_bind(int device, const brl_transition *flat, const float *adv, const float *tg, const int64_t *perm, const int32_t *mbi,
@@ -398,4 +399,8 @@ int brl_mb_gather_bind(int device, const brl_transition *flat, const float *adv,
 int brl_mb_gather_dev(int device, const void *ad, int64_t mbs, void *s) {
   (void)device; (void)ad; (void)mbs; (void)s;
   NOT_HERE("brl_mb_gather_dev");
+}
+int brl_ppo_illegal_grad(int device, const float *hd, const uint8_t *m, const float *vec, float ic, int64_t b, float *dh, void *s) {
+  (void)device; (void)hd; (void)m; (void)vec; (void)ic; (void)b; (void)dh; (void)s;
+  NOT_HERE("brl_ppo_illegal_grad");
 }

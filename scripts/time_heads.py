@@ -47,11 +47,11 @@ def bwd():
 
 
 def stats():
-    _capi.check(L.brl_ppo_stats_gram(0, partials.data_ptr(), lgroups, B, gram_p.data_ptr(), lgroups, 0.5, 0.001, out.data_ptr(), None, None, s))
+    _capi.check(L.brl_ppo_stats_gram(0, partials.data_ptr(), lgroups, B, gram_p.data_ptr(), lgroups, 0.5, 0.001, 0.0, out.data_ptr(), None, None, s))
 
 
 def stats_rows():
-    _capi.check(L.brl_ppo_stats_rows(0, ssum.data_ptr(), gsum.data_ptr(), 2560, B, 0.5, 0.001, rows_out.data_ptr(), s))
+    _capi.check(L.brl_ppo_stats_rows(0, ssum.data_ptr(), gsum.data_ptr(), 2560, B, 0.5, 0.001, 0.0, rows_out.data_ptr(), s))
 
 
 def fin():

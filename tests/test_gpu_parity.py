@@ -1464,7 +1464,7 @@ def test_fused_update_with_gradient_allreduce_two_ranks_rccl(tmp_path):
     assert torch.allclose(total.cpu(), r0[1], atol=1e-6) and torch.allclose(single, r0[0], atol=1e-6, rtol=1e-5)
 
 
-@pytest.mark.parametrize("variant", ["DeepMind_6", "anneal_lr", "tanh", "reward_scaling"])
+@pytest.mark.parametrize("variant", ["DeepMind_6", "anneal_lr", "tanh", "reward_scaling", "illegal_coef"])
 def test_fused_update_variants_match_eager(variant):
     """FusedMinibatch on the 6-layer MLP of wb5/models.py, under ppo.py:186-192's linear learning-rate schedule (the
     rate lives in device memory, so the captured Adam launch follows it), with the tanh activation (src/models.py:16) and
@@ -1474,7 +1474,8 @@ def test_fused_update_variants_match_eager(variant):
     from tests.test_update_cpu import CFG, fake_batch
     fp = make_forward_pass("tanh" if variant == "tanh" else "relu", "DeepMind_6" if variant == "DeepMind_6" else "DeepMind")
     cfg0 = dict(CFG, minibatch_size=256, update_epochs=1, num_minibatches=4, num_updates=4, anneal_lr=variant == "anneal_lr",
-                reward_scaling=variant == "reward_scaling")
+                reward_scaling=variant == "reward_scaling",
+                illegal_action_l2norm_coef=0.5 if variant == "illegal_coef" else 0.0)   # src/update.py:146-152
     outs = []
     for fused in (False, True):
         net = fp.init(7, device="cuda")
@@ -1633,7 +1634,7 @@ def test_head_kernels_match_torch_and_the_separate_launches(B, H, act):
         gram = illp.double().t() @ illp.double()
         assert torch.allclose(gram_p.sum(0).double().reshape(38, 38), gram, rtol=1e-4, atol=1e-7)
         out_new, out_old, vec = torch.zeros(8, device=dev), torch.zeros(8, device=dev), torch.zeros(40, device=dev)
-        _capi.check(L.brl_ppo_stats_gram(0, partials.data_ptr(), lgroups, B, gram_p.data_ptr(), lgroups, 0.5, 0.001, out_new.data_ptr(),
+        _capi.check(L.brl_ppo_stats_gram(0, partials.data_ptr(), lgroups, B, gram_p.data_ptr(), lgroups, 0.5, 0.001, 0.0, out_new.data_ptr(),
                                          None, vec.data_ptr(), s))
         gram32 = gram.float().contiguous()
         _capi.check(L.brl_ppo_stats(0, p2.data_ptr(), B, gram32.data_ptr(), 0.5, 0.001, out_old.data_ptr(), s))
@@ -1644,6 +1645,13 @@ def test_head_kernels_match_torch_and_the_separate_launches(B, H, act):
         v1 = vt[0] * torch.sign(vt[0].sum())
         assert abs(float(vec[38]) - float(sg[0])) < 1e-4 * float(sg[0]) + 1e-7
         assert float((vec[:38].double() - v1).abs().max()) < 2e-3                      # (l2 / l1)^256 away from the Perron vector
+    # gradient of the illegal-action norm (src/update.py:146-152) from the power iteration's v1 / sigma_1 vs autograd through an SVD
+    lg = heads[:, :38].detach().clone().requires_grad_(True)
+    (0.7 * torch.linalg.matrix_norm(torch.softmax(lg, -1) * (mask == 0), ord=2) / 2).backward()
+    add = torch.zeros(B, 39, device=dev)
+    _capi.check(L.brl_ppo_illegal_grad(0, heads.data_ptr(), mask.data_ptr(), vec.data_ptr(), 0.7, B, add.data_ptr(), s))
+    assert float(add[:, 38].abs().max()) == 0 and float(lg.grad.abs().max()) > 0
+    assert float((add[:, :38] - lg.grad).abs().max()) < 2e-3 * float(lg.grad.abs().max())
     # backward of the head
     nsplit = (B + 63) // 64
     dwp, dbp = torch.empty(nsplit, 39 * H, device=dev), torch.empty(nsplit, 39, device=dev)
@@ -1654,7 +1662,7 @@ def test_head_kernels_match_torch_and_the_separate_launches(B, H, act):
     _capi.check(L.brl_ppo_heads_bwd(0, dheads.data_ptr(), h.data_ptr(), H, Wh.data_ptr(), B, H, act, nsplit, dwp.data_ptr(),
                                     dbp.data_ptr(), dh.data_ptr(), ts.data_ptr(), partials.data_ptr(), gram_p.data_ptr(), lgroups,
                                     row.data_ptr(), ssum.data_ptr(), gsum.data_ptr(), s))
-    _capi.check(L.brl_ppo_stats_rows(0, ssum.data_ptr(), gsum.data_ptr(), 4, B, 0.5, 0.001, rows_out.data_ptr(), s))
+    _capi.check(L.brl_ppo_stats_rows(0, ssum.data_ptr(), gsum.data_ptr(), 4, B, 0.5, 0.001, 0.0, rows_out.data_ptr(), s))
     assert torch.allclose(rows_out[2], out_new, rtol=1e-5, atol=1e-7), (rows_out[2], out_new)   # the per-step launch's row
     assert float(ssum[[0, 1, 3]].abs().max()) == 0 and float(gsum[[0, 1, 3]].abs().max()) == 0
     import ctypes as C
