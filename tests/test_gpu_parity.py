@@ -156,7 +156,10 @@ def test_observe_any_player(env, oracle):
     (4, None, 8, 130, 5), (4, None, 9, 130, 3),
     # the same shapes as the k_rollout_fs cases above (128x32, 2048x32), forced onto k_rollout_ws; more k_rollout_fs shapes
     (4, "ws", 1, 128, 32), (4, "ws", 1, 2048, 32), (4, None, 1, 32, 1), (4, None, 1, 64, 40), (4, None, 1, 96, 3),
-    (4, None, 1, 4096, 33), (4, None, 1, 160, 9), (4, None, 1, 8192, 32)])
+    (4, None, 1, 4096, 33), (4, None, 1, 160, 9), (4, None, 1, 8192, 32),
+    # the competitive macro-step with every seat random (src/utils.py:69-128) at the BASELINE size and at block-sized shapes
+    (4, None, 4, 8192, 32), (4, None, 4, 32, 1), (4, None, 4, 96, 11), (4, None, 4, 64, 10), (4, None, 2, 64, 7),
+    (4, None, 2, 4096, 21)])
 def test_fused_random_rollout_matches_oracle(dds, oracle, k, ws, substeps, n, T):
     import brl_amd
     env = make_env(dds, k, ws)
