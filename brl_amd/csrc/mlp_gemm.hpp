@@ -1,6 +1,7 @@
 // mlp_gemm.hpp — the fp32 MFMA GEMMs of one PPO minibatch step (src/update.py:74-242: forward, dW = dz^T h_prev, dh = dz W),
-// hand-written for gfx950.  Included by brl_kernels.hip (C-ABI: brl_mlp_gemm / brl_mlp_gemm2 at its end) and by
-// scripts/micro/gemm_f32_test.hip (stand-alone check + timing).
+// hand-written for gfx950.  EXPERIMENTAL: built and checked by scripts/micro/gemm_f32_test.hip only — not part of
+// libbrl_hip.so (86 TFLOP/s per launch against the library GEMM's 107 on the step's 1024^3 products:
+// profiles/r03/r03_experiments.txt).
 //
 // Why not the library GEMM: at minibatch 1024 every product of the step is ~1024^3.  hipBLASLt's heuristic picks 128 x 128
 // tiles = 64 workgroups on a 256-CU chip (20 us = 107 TFLOP/s for 2.1 GFLOP, profiles/r02w), and leaves ReLU backward,
