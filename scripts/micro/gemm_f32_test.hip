@@ -1,4 +1,4 @@
-// Stand-alone check + timing of brl_amd/csrc/mlp_gemm.hpp (the fp32 MFMA GEMMs of the PPO minibatch step).
+// Stand-alone check + timing of scripts/micro/mlp_gemm.hpp (the fp32 MFMA GEMMs of the PPO minibatch step).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scripts/micro/gemm_f32_test scripts/micro/gemm_f32_test.hip
 //   ./scripts/micro/gemm_f32_test            # every layout / shape of the step vs a float64 CPU reference, then timings
 #include <hip/hip_runtime.h>
@@ -8,7 +8,7 @@
 #include <stdlib.h>
 #include <vector>
 
-#include "../../brl_amd/csrc/mlp_gemm.hpp"
+#include "mlp_gemm.hpp"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
