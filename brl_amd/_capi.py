@@ -35,7 +35,9 @@ class TableInfoPtrs(C.Structure):
 class MacroExt(C.Structure):
     _fields_ = [("first", C.c_int32), ("last", C.c_int32), ("value_in", _vp), ("value_stride", C.c_int64), ("value_out", _vp),
                 ("done_out", _vp), ("reward_out", _vp), ("actor", _vp), ("reward_scale", C.c_float), ("obs_fmt", C.c_int32),
-                ("terminated_count", _vp), ("obs_cast", _vp), ("in_fmt", C.c_int32), ("reserved", C.c_int32)]
+                ("terminated_count", _vp), ("obs_cast", _vp), ("in_fmt", C.c_int32), ("reserved", C.c_int32),
+                ("head_h", _vp), ("head_ldh", C.c_int64), ("head_w", _vp), ("head_b", _vp), ("head_hidden", C.c_int32),
+                ("head_fmt", C.c_int32)]
 
 
 class EvalStatsPtrs(C.Structure):

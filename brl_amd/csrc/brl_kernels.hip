@@ -1182,11 +1182,95 @@ __device__ __forceinline__ int categorical(const void *logits, int64_t row_off, 
   return act;
 }
 
-template <int K>
+// HEADS: the 39 head outputs (38 logits + value) of the workgroup's 16 tables are formed HERE from the last hidden layer's
+// activations (A.x.head_h, bf16 / fp16) and the head weights: one 16-row MFMA tile, the K = hidden sum split over the four waves
+// (v_mfma_f32_16x16x32_bf16 / _f16, fp32 accumulation), partial sums through LDS.  Replaces the N = 39 library GEMM in front of
+// every policy sub-step (9.9 us at n = 8192 — as long as the four 1024-wide layers' share of a forward) and the round trip of
+// its output.  K == 4 only (4 waves x 4 tables = the tile's 16 rows).
+typedef short pol_b16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pol_f16x8 __attribute__((ext_vector_type(8)));
+typedef float pol_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int POL_HD = BRL_NUM_ACTIONS + 1;   // 39
+
+template <int K, bool HEADS = false>
 __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES_PER_BLOCK * K * TABLE_BYTES];
+  __shared__ float hd_red[HEADS ? 4 : 1][3][4][64];
+  __shared__ float hd_logits[HEADS ? 16 : 1][POL_HD + 1];
+  static_assert(!HEADS || K == 4, "the head tile is the workgroup's 16 tables");
+  // (HEADS) every operand of the heads product — this wave's quarter of K: 8 + 24 16-byte loads at hidden = 1024 — is requested
+  // BEFORE the table images are fetched, so that the two memory round trips overlap; the MFMAs follow wave_begin
+  constexpr int HGP = HEADS ? 8 : 1;
+  pol_b16x8 hav[HGP], hbv[HGP][3];
+  bool hbok[3] = {false, false, false};
+  int hsteps = 0;
+  if (HEADS) {
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
+    const int64_t row0 = xcd_block((int64_t)blockIdx.x, (int64_t)gridDim.x) * 16;
+    const int r = lane & 15, kq = lane >> 4;
+    const int64_t arow = (row0 + r < A.n) ? row0 + r : A.n - 1;
+    const uint16_t *ap = reinterpret_cast<const uint16_t *>(A.x.head_h) + arow * A.x.head_ldh + 8 * kq;
+    hsteps = A.x.head_hidden / 32;   // 32-deep K steps; wave wv takes steps wv, wv + 4, ...
+#pragma unroll
+    for (int nb = 0; nb < 3; nb++) hbok[nb] = 16 * nb + r < POL_HD;
+#pragma unroll
+    for (int u = 0; u < HGP; u++) {
+      const int st = (wv + 4 * u < hsteps) ? wv + 4 * u : wv;
+      hav[u] = *reinterpret_cast<const pol_b16x8 *>(ap + 32 * st);
+#pragma unroll
+      for (int nb = 0; nb < 3; nb++)
+        hbv[u][nb] = *reinterpret_cast<const pol_b16x8 *>(reinterpret_cast<const uint16_t *>(A.x.head_w) +
+                                                         (int64_t)(hbok[nb] ? 16 * nb + r : 0) * A.x.head_hidden + 8 * kq + 32 * st);
+    }
+  }
   Tbl t;
   Wave<K> w = wave_begin<K>(lds, A.state_in, A.n, t);
+  if (HEADS) {
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    pol_f32x4 acc[3];
+#pragma unroll
+    for (int nb = 0; nb < 3; nb++) acc[nb] = pol_f32x4{0.f, 0.f, 0.f, 0.f};
+    const pol_b16x8 zero8 = pol_b16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    auto mma = [&](const pol_b16x8 &a, const pol_b16x8 &b, pol_f32x4 c) {
+      return (A.x.head_fmt == 1) ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pol_f16x8, a), __builtin_bit_cast(pol_f16x8, b), c, 0, 0, 0);
+    };
+#pragma unroll
+    for (int u = 0; u < HGP; u++) {
+      if (wv + 4 * u >= hsteps) break;
+#pragma unroll
+      for (int nb = 0; nb < 3; nb++) acc[nb] = mma(hav[u], hbok[nb] ? hbv[u][nb] : zero8, acc[nb]);
+    }
+    if (hsteps > 4 * HGP) {   // hidden > 1024: the remaining steps, four in flight
+      const int64_t row0 = xcd_block((int64_t)blockIdx.x, (int64_t)gridDim.x) * 16;
+      const int64_t arow = (row0 + r < A.n) ? row0 + r : A.n - 1;
+      const uint16_t *ap = reinterpret_cast<const uint16_t *>(A.x.head_h) + arow * A.x.head_ldh + 8 * kq;
+      for (int st = wv + 4 * HGP; st < hsteps; st += 4) {
+        const pol_b16x8 a = *reinterpret_cast<const pol_b16x8 *>(ap + 32 * st);
+#pragma unroll
+        for (int nb = 0; nb < 3; nb++) {
+          const pol_b16x8 b = *reinterpret_cast<const pol_b16x8 *>(reinterpret_cast<const uint16_t *>(A.x.head_w) +
+                                                                   (int64_t)(hbok[nb] ? 16 * nb + r : 0) * A.x.head_hidden + 8 * kq + 32 * st);
+          acc[nb] = mma(a, hbok[nb] ? b : zero8, acc[nb]);
+        }
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 3; nb++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) hd_red[wv][nb][q][lane] = acc[nb][q];   // D[table 4 (lane >> 4) + q][head 16 nb + (lane & 15)]
+    __syncthreads();
+    for (int e = tid; e < 16 * POL_HD; e += BLOCK_THREADS) {
+      const int row = e / POL_HD, col = e - row * POL_HD;
+      const int nb = col >> 4, c = col & 15, q = row & 3, rq = row >> 2;
+      float v = A.x.head_b[col];
+#pragma unroll
+      for (int k = 0; k < 4; k++) v += hd_red[k][nb][q][16 * rq + c];   // fixed order
+      hd_logits[row][col] = v;
+    }
+    __syncthreads();
+  }
   const DevCtx cx = *A.ctx;
   const uint64_t legal = legal_mask(t);
   const uint64_t cand = (A.mode & 2) ? ALL_ACTIONS : legal;  // bit 1: the unmasked policy
@@ -1198,8 +1282,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
   uint32_t old_term = 0, val_raw = 0, actor_id = 0;
   if (A.o.rewards && !A.x.first) old_rw = reinterpret_cast<const float4 *>(A.o.rewards)[otab];
   if (A.o.terminated && !A.x.first) old_term = A.o.terminated[otab];
+  const int in_fmt = HEADS ? 0 : A.x.in_fmt;   // (the in-kernel heads are fp32)
   if (A.x.value_out) {
-    if (A.x.in_fmt == 0) val_raw = reinterpret_cast<const uint32_t *>(A.x.value_in)[otab * A.x.value_stride];
+    if (HEADS) val_raw = __float_as_uint(hd_logits[(int)(threadIdx.x >> 6) * K + (w.c.lane < K ? w.c.lane : 0)][BRL_NUM_ACTIONS]);
+    else if (A.x.in_fmt == 0) val_raw = reinterpret_cast<const uint32_t *>(A.x.value_in)[otab * A.x.value_stride];
     else val_raw = reinterpret_cast<const uint16_t *>(A.x.value_in)[otab * A.x.value_stride];
   }
   if (A.x.last && A.x.reward_out) actor_id = (uint32_t)A.x.actor[otab];
@@ -1213,8 +1299,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
     u32 = (sel == 0) ? r[0] : ((sel == 1) ? r[1] : ((sel == 2) ? r[2] : r[3]));
   }
   float lp;
-  const int act = categorical<K>(A.logits, (w.valid ? w.table : 0) * A.logits_stride, A.x.in_fmt, w.valid, cand, A.mode, u32,
-                                 w.c.lane, lp);
+  const int act = HEADS ? categorical<K>(&hd_logits[0][0], (int64_t)((int)(threadIdx.x >> 6) * K + w.tl) * (POL_HD + 1), 0, w.valid, cand,
+                                         A.mode, u32, w.c.lane, lp)
+                        : categorical<K>(A.logits, (w.valid ? w.table : 0) * A.logits_stride, A.x.in_fmt, w.valid, cand, A.mode, u32,
+                                         w.c.lane, lp);
   if (A.autoreset) auto_reset_clear(t);
   int hb = table_step(t, act);
   wave_or_hist<K>(w, hb);
@@ -1251,7 +1339,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
       A.o.terminated[w.table] = (uint8_t)tacc;
     }
     if (A.o.current_player) A.o.current_player[w.table] = cur_player(t);
-    if (A.x.value_out) A.x.value_out[w.table] = net_cvt(val_raw, A.x.in_fmt);                 // src/roll_out.py:76
+    if (A.x.value_out) A.x.value_out[w.table] = net_cvt(val_raw, in_fmt);                    // src/roll_out.py:76
     if (A.x.last) {
       if (A.x.done_out) A.x.done_out[w.table] = (uint8_t)tacc;                                // G2
       if (A.x.reward_out) {                                                                  // G1, src/roll_out.py:90
@@ -2120,9 +2208,10 @@ static int policy_step_impl(brl_handle *h, const uint64_t *state_in, uint64_t *s
                             int32_t *action, float *log_prob, uint8_t *obs, uint8_t *mask, float *rewards_acc,
                             uint8_t *terminated_acc, int32_t *current_player, void *stream, const brl_macro_ext *ext = nullptr) {
   COMMON(h, n);
-  NEED(state_in && state_out && logits, "NULL state / logits");
+  const bool heads = ext != nullptr && ext->head_h != nullptr;
+  NEED(state_in && state_out && (logits || heads), "NULL state / logits");
   NEED(mode >= 0 && mode <= 3, "mode");
-  NEED(logits_stride >= BRL_NUM_ACTIONS, "logits_stride");
+  NEED(heads || logits_stride >= BRL_NUM_ACTIONS, "logits_stride");
   if (autoreset && h->lut_len == 0) return fail(BRL_E_NOLUT, "auto-reset needs a LUT%s", "");
   PolicyArgs A;
   A.state_in = state_in; A.state_out = state_out; A.n = n; A.logits = logits; A.mode = mode; A.draw = draw;
@@ -2134,11 +2223,20 @@ static int policy_step_impl(brl_handle *h, const uint64_t *state_in, uint64_t *s
   memset(&A.x, 0, sizeof(A.x));
   if (ext != nullptr) {
     A.x = *ext;
-    NEED(!ext->value_out || (ext->value_in && ext->value_stride >= 1), "ext: value_in / value_stride");
+    NEED(!ext->value_out || ext->head_h || (ext->value_in && ext->value_stride >= 1), "ext: value_in / value_stride");
     NEED(!ext->last || !ext->reward_out || (ext->actor && rewards_acc && ext->reward_scale != 0.0f), "ext: reward_out needs actor, rewards_acc, reward_scale");
     NEED(!ext->last || !(ext->done_out || ext->terminated_count) || terminated_acc, "ext: done_out / terminated_count need terminated_acc");
     NEED(!ext->obs_cast || (ext->obs_fmt >= 0 && ext->obs_fmt <= 2), "ext: obs_fmt");
     NEED(ext->in_fmt >= 0 && ext->in_fmt <= 2, "ext: in_fmt");
+    if (heads) {
+      NEED(ext->head_w && ext->head_b && (ext->head_fmt == 1 || ext->head_fmt == 2), "ext: head_w / head_b / head_fmt (1 bf16, 2 fp16)");
+      NEED(ext->head_hidden > 0 && ext->head_hidden % 32 == 0 && ext->head_ldh >= ext->head_hidden && ext->head_ldh % 8 == 0,
+           "ext: head_hidden (a multiple of 32) / head_ldh (a multiple of 8)");
+      NEED(h->tables_per_wave == 4, "ext: head_h needs BRL_TABLES_PER_WAVE=4 (the head tile is a workgroup's 16 tables)");
+      hipLaunchKernelGGL((k_policy_step<4, true>), dim3(wave_grid(n, 4)), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, A);
+      HIP_TRY(hipGetLastError());
+      return BRL_OK;
+    }
   }
   LAUNCH_K(h, k_policy_step, n, stream, A);
   return BRL_OK;

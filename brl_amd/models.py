@@ -79,6 +79,10 @@ class InferenceSnapshot:
         self.head_w = torch.cat([module.actor.weight, module.critic.weight], 0).detach().to(dt).t().contiguous()
         self.head_b = torch.cat([module.actor.bias, module.critic.bias], 0).detach().to(dt)
         self.n_actions = module.actor.weight.shape[0]
+        # for the step kernel that forms the heads itself (brl_macro_ext.head_h): [39, hidden] row-major in `dtype`, the bias
+        # as float holding the SAME (rounded) values the GEMM path adds
+        self.head_wt = self.head_w.t().contiguous()
+        self.head_bf = self.head_b.float().contiguous()
 
     def refresh(self, module: "ActorCritic"):
         """Re-read the weights of `module` INTO the existing tensors (their addresses are baked into captured graphs)."""
@@ -90,6 +94,8 @@ class InferenceSnapshot:
         self.head_w[:, k:].copy_(module.critic.weight.detach().t())
         self.head_b[:k].copy_(module.actor.bias.detach())
         self.head_b[k:].copy_(module.critic.bias.detach())
+        self.head_wt.copy_(self.head_w.t())
+        self.head_bf.copy_(self.head_b)
 
     @staticmethod
     def make(module, dtype=None, env=None):
@@ -109,6 +115,15 @@ class InferenceSnapshot:
                                                  self._FMT[self.dtype], _stream()))
             return x
         return obs.to(self.dtype)
+
+    def hidden(self, obs, x=None):
+        """obs -> the last hidden layer's output [n, hidden] in ``self.dtype`` (what the heads are applied to)"""
+        if x is None:
+            x = self._input(obs)
+        fused = hasattr(torch, "_addmm_activation")
+        for w, b in self.body:
+            x = torch._addmm_activation(b, x, w, use_gelu=False) if fused else torch.addmm(b, x, w).relu_()
+        return x
 
     def heads(self, obs, x=None, raw=False):
         """obs: [n, 480] bool / float -> f32 [n, 39]: the 38 logits and the value as ONE matrix (row stride 39; the

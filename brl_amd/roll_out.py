@@ -128,8 +128,9 @@ class _PolicyRollout:
     calls are followed by the replays.  ``sub_actions`` [T,3,n] keeps the actions of sub-steps 2-4 (tests replay the
     whole rollout through the oracle)."""
 
-    def __init__(self, env, n, T, reward_scale, game_mode, masked, infer_dtype, actor_fp, opp_fp, static):
+    def __init__(self, env, n, T, reward_scale, game_mode, masked, infer_dtype, actor_fp, opp_fp, static, fuse_heads=True):
         self.env, self.n, self.T, self.reward_scale = env, n, T, reward_scale
+        self.fuse_heads = bool(fuse_heads)
         self.game_mode, self.masked, self.infer_dtype, self.static = game_mode, masked, infer_dtype, static
         self.actor_fp, self.opp_fp = actor_fp, opp_fp
         self.graphs = None
@@ -174,6 +175,18 @@ class _PolicyRollout:
 
     _FMT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
+    def _fused_heads(self, is_opp):
+        """the snapshot whose heads the step kernel forms itself (16-bit inference, 4 tables per wave), or None"""
+        import os
+        snap = self.snap_opp if is_opp else self.snap_actor
+        ok = snap is not None and self.fuse_heads and self.infer_dtype in (torch.bfloat16, torch.float16) \
+            and os.environ.get("BRL_TABLES_PER_WAVE", "4") == "4"
+        return snap if ok else None
+
+    def _head_ext(self, snap, h, **kw):
+        return _capi.MacroExt(head_h=h.data_ptr(), head_ldh=h.stride(0), head_w=snap.head_wt.data_ptr(), head_b=snap.head_bf.data_ptr(),
+                              head_hidden=h.shape[1], head_fmt=self._FMT[h.dtype], **kw)
+
     def _forward(self, is_opp, obs_bool, x=None):
         """-> f32 [n, 39] heads (38 logits + value; DeepMind ReLU nets: fused epilogues, merged heads) or, for the other
         architectures, (logits, value).  ``x``: obs_bool already cast by the step kernel."""
@@ -199,26 +212,42 @@ class _PolicyRollout:
         fmt = self._FMT[self.xin.dtype]
         actor = cur[t & 1]                                              # src/roll_out.py:72
         # the first forward of a rollout reads the loaded observation; later ones the cast written by the previous launch
-        logits, value = self._forward(False, traj.obs[t], None if t == 0 else self.xin)   # :73-76
-        ifmt = self._FMT[logits.dtype]
-        # sub-step 1: the actor samples from the (un)masked Categorical (src/roll_out.py:27-39,79-84)
-        policy_step(env, packed, packed, logits, SAMPLE if self.masked else SAMPLE | UNMASKED, 4 * t, True,
-                    action=traj.action[t], log_prob=traj.log_prob[t], rewards_acc=racc,
-                    terminated_acc=tacc, draw_base=self.draw,
-                    ext=MX(first=1, value_in=value.data_ptr(), value_stride=value.stride(0), value_out=traj.value[t].data_ptr(),
-                           obs_cast=self.xin.data_ptr(), obs_fmt=fmt, in_fmt=ifmt))
+        mode1 = SAMPLE if self.masked else SAMPLE | UNMASKED
+        snap = self._fused_heads(False)
+        if snap is not None:   # the step kernel forms logits + value from the last hidden layer itself (no N = 39 GEMM)
+            h = snap.hidden(traj.obs[t], None if t == 0 else self.xin)
+            policy_step(env, packed, packed, None, mode1, 4 * t, True, action=traj.action[t], log_prob=traj.log_prob[t],
+                        rewards_acc=racc, terminated_acc=tacc, draw_base=self.draw,
+                        ext=self._head_ext(snap, h, first=1, value_out=traj.value[t].data_ptr(), obs_cast=self.xin.data_ptr(),
+                                           obs_fmt=fmt))
+        else:
+            logits, value = self._forward(False, traj.obs[t], None if t == 0 else self.xin)   # :73-76
+            ifmt = self._FMT[logits.dtype]
+            # sub-step 1: the actor samples from the (un)masked Categorical (src/roll_out.py:27-39,79-84)
+            policy_step(env, packed, packed, logits, mode1, 4 * t, True,
+                        action=traj.action[t], log_prob=traj.log_prob[t], rewards_acc=racc,
+                        terminated_acc=tacc, draw_base=self.draw,
+                        ext=MX(first=1, value_in=value.data_ptr(), value_stride=value.stride(0), value_out=traj.value[t].data_ptr(),
+                               obs_cast=self.xin.data_ptr(), obs_fmt=fmt, in_fmt=ifmt))
         last = t + 1 == T
         obs_out = self.final_obs if last else traj.obs[t + 1]
         mask_out = self.final_mask if last else traj.legal_action_mask[t + 1]
         for k in (1, 2, 3):  # opp, partner (actor params), opp — src/utils.py:78-120; always masked
             is_opp = k != 2
+            snap = None
             if not competitive and is_opp:                              # free-run: opponents pass (src/utils.py:205-246)
                 lg, m = _pass_logits(env, self.n), MODE
             else:
-                lg, _ = self._forward(is_opp, None, self.xin)  # (the observation comes as the cast the previous launch wrote)
                 m = SAMPLE if competitive else MODE
+                snap = self._fused_heads(is_opp)
+                if snap is not None:
+                    lg = None
+                    hk = snap.hidden(None, self.xin)
+                else:
+                    lg, _ = self._forward(is_opp, None, self.xin)  # (the observation comes as the cast the previous launch wrote)
             fin = k == 3
-            ext = MX(obs_cast=self.xin.data_ptr(), obs_fmt=fmt, in_fmt=self._FMT[lg.dtype])
+            ext = self._head_ext(snap, hk, obs_cast=self.xin.data_ptr(), obs_fmt=fmt) if snap is not None \
+                else MX(obs_cast=self.xin.data_ptr(), obs_fmt=fmt, in_fmt=self._FMT[lg.dtype])
             if fin:                                                     # G2 / G1 / :85 by the same launch
                 ext.last, ext.done_out, ext.reward_out = 1, traj.done[t].data_ptr(), traj.reward[t].data_ptr()
                 ext.actor, ext.reward_scale, ext.terminated_count = actor.data_ptr(), self.reward_scale, self.tc.data_ptr()
@@ -313,7 +342,8 @@ def make_roll_out(config, env: BridgeBidding, actor_forward_pass, opp_forward_pa
         eng = engines.get((n, static))
         if eng is None:
             eng = engines[(n, static)] = _PolicyRollout(env, n, T, reward_scale, mode, masked, infer_dtype,
-                                                        actor_forward_pass, opp_forward_pass, static)
+                                                        actor_forward_pass, opp_forward_pass, static,
+                                                        fuse_heads=config.get("fuse_heads", True))
         out = eng.run(runner_state, opp_params)
         roll_out.sub_actions = eng.sub_actions
         return out

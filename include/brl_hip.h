@@ -201,6 +201,16 @@ typedef struct brl_macro_ext {
   int32_t in_fmt;            /* element type of `logits` AND value_in as the GEMM wrote them: 0 float, 1 bf16, 2 fp16 (with 1 / 2
                                 the `logits` argument points at 2-byte elements; strides stay in elements) */
   int32_t reserved;
+  /* head_h != NULL: the launch forms the 38 logits + the value ITSELF — the policy heads `actor(x), critic(x)` (src/models.py:30-33)
+   * on x = head_h [n, head_ldh] (bf16 / fp16, the last hidden layer's output), head_w [39, head_hidden] (same type: actor rows,
+   * then the critic row), head_b float [39], fp32 accumulation — instead of reading `logits` / value_in (ignored; `logits` may be
+   * NULL).  head_hidden % 32 == 0; needs 4 tables per wave (the default). */
+  const void *head_h;
+  int64_t head_ldh;
+  const void *head_w;
+  const float *head_b;
+  int32_t head_hidden;
+  int32_t head_fmt;          /* 1 bf16, 2 fp16 */
 } brl_macro_ext;
 
 /* brl_policy_step_at + brl_macro_ext (ext may be NULL). */
