@@ -1,12 +1,13 @@
-"""``src/update.py`` — the PPO-clip update, in PyTorch-ROCm.
+"""``src/update.py`` — the PPO-clip update.
 
-Dense-GEMM training work: north_star assigns it to PyTorch (rocBLAS/hipBLASLt MFMA GEMMs + autograd),
-not to a custom kernel.  The data it consumes is the time-major ``Transition`` buffer the HIP rollout
-kernels wrote; flattening is ``reshape(T*N, ...)`` -> row ``t*N+n`` (G7, src/update.py:193-206).
-Under ``torch.distributed`` the flat fp32 gradient (3 681 319 elements = 14.7 MB for the DeepMind
-MLP) is all-reduced once per minibatch — RCCL over xGMI on MI355X (backend "nccl"), gloo in the CPU
-tests.  Each rank permutes its own shard (statistically equivalent to the reference's global
-permutation, not bit-equal — SURVEY §8e caveat) and uses ``minibatch_size`` PER RANK.
+The data it consumes is the time-major ``Transition`` buffer the HIP rollout kernels wrote; flattening is ``reshape(T*N, ...)`` ->
+row ``t*N+n`` (G7, src/update.py:193-206).  Default path for the DeepMind MLPs: ``FusedMinibatch`` — the step's big GEMMs stay
+with the library (hipBLASLt / rocBLAS through torch, committed tuned solutions), everything else is hand-written HIP
+(``csrc/ppo_heads.hpp``, ``csrc/ppo_update.hpp``), eight steps per hipGraph.  Other architectures (FAIR) and CPU tensors take the
+torch autograd path (``ppo_loss``).  Under ``torch.distributed`` the fp32 gradient (3 681 319 elements = 14.7 MB for the DeepMind
+MLP) is all-reduced per minibatch — RCCL over xGMI on MI355X (backend "nccl"), gloo in the CPU tests: bucketed per layer behind
+graph segments in the fused path, one flat all-reduce otherwise.  Each rank permutes its own shard (statistically equivalent to the
+reference's global permutation, not bit-equal — SURVEY §8e caveat) and uses ``minibatch_size`` PER RANK.
 """
 from __future__ import annotations
 
@@ -227,12 +228,13 @@ class GraphedMinibatch:
 
 
 class FusedMinibatch:
-    """One PPO minibatch step of the "DeepMind" ReLU MLP with NOTHING but its 14 GEMMs left to torch: the loss and its
-    output gradients (``brl_ppo_loss_heads``), ReLU backward + bias gradients (``brl_relu_bwd_colsum``), global-norm
-    clipping + Adam on flat parameter / gradient / moment buffers (``brl_adam_clip``) are single HIP launches, the
-    backward pass is written out (no autograd), the whole step is ONE hipGraph, and the minibatch is gathered from the
-    un-shuffled trajectory by ``brl_mb_gather`` (no per-epoch ``take`` of the 126 MB observation buffer, no per-
-    minibatch copies).  ~24 launches per step instead of ~75 (``profiles/r02``: 0.55 ms -> see DESIGN.md §4.2).
+    """One PPO minibatch step of a "DeepMind" MLP with NOTHING but its big GEMMs left to torch: the minibatch
+    gather (``brl_mb_gather_dev``: device-resident arguments, first node of the captured step), the 39-column head + ``_loss_fn``
+    + its gradients (``brl_ppo_heads_loss``), the head's backward (``brl_ppo_heads_bwd``), the activation derivative + bias tile
+    sums of the layers below (``brl_act_bwd_colsum``), every sum of partials (``brl_bias_finalize_ex``), global-norm clipping +
+    Adam on flat parameter / gradient / moment buffers (``brl_adam_clip``) are single HIP launches; the backward pass is written
+    out (no autograd: dz chain, then the hidden layers' weight gradients as ONE batched product); EIGHT steps are one hipGraph;
+    the logged statistics are formed once per update from per-step sums (``brl_ppo_stats_rows``).
 
     The module's parameters and the optimizer's moments become VIEWS of the flat buffers, so ``params``, ``state_dict``
     checkpoints and the eager path keep working on the same memory.  Mirrors torch.optim.Adam's arithmetic and
