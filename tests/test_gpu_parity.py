@@ -1257,6 +1257,45 @@ def test_graphed_update_matches_eager_update():
             assert float(d.mean()) < 2e-5 and float(d.max()) < 2 * cfg["lr"]
 
 
+def test_update_epoch_at_config3_size_fused_vs_eager(dds):
+    """BASELINE.json configs[3]'s update at ITS size — a trajectory of 8192 x 32 (a real random rollout: observations,
+    masks, actions, log-probs, rewards -> GAE), minibatch 1024, one epoch = 256 minibatch steps at the reference's lr —
+    through FusedMinibatch (HIP heads / gather / Adam, graph replays) and through the eager autograd path from the same
+    weights and the same permutation: the 256 logged losses agree step by step (early steps tightly, the whole epoch on
+    average: PPO's clip boundaries amplify fp32 summation-order differences for single samples), and so do the weights."""
+    import brl_amd
+    from brl_amd.gae import gae_scan
+    from brl_amd.models import make_forward_pass
+    from brl_amd.train import DEFAULTS
+    from brl_amd.update import FusedMinibatch, make_update_step
+    env = make_env(dds, 4)
+    n, T = 8192, 32
+    roll = brl_amd.make_random_roll_out({"num_steps": T}, env)
+    rs, traj = roll((None, None, env.init(3, num_envs=n), None, 0, 0))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    value = torch.randn(T, n, device="cuda", generator=g) * 0.05          # (the random policy has no critic: any old values)
+    traj = traj._replace(value=value)
+    adv, tgt = gae_scan(env, traj.done, traj.value, traj.reward, torch.zeros(n, device="cuda"), 1.0, 0.95)
+    fp = make_forward_pass("relu", "DeepMind")
+    outs = {}
+    for mode in ("eager", "fused"):
+        net = fp.init(5, device="cuda")
+        cfg = dict(DEFAULTS, lr=1e-5, minibatch_size=1024, update_epochs=1, graph_update=mode == "fused", fused_update=mode == "fused")
+        rs2, (total, aux) = make_update_step(cfg, fp)((net, None, None, None, 0, 17), traj, adv, tgt)
+        if mode == "fused":
+            assert isinstance(rs2[1].get("graphed"), FusedMinibatch), rs2[1].get("graph_error")
+        outs[mode] = (torch.cat([p.detach().reshape(-1) for p in net.parameters()]), total.reshape(-1), [a.reshape(-1) for a in aux])
+    e, f = outs["eager"], outs["fused"]
+    assert e[1].shape == (256,) and torch.isfinite(f[1]).all()
+    assert torch.allclose(e[1][:8], f[1][:8], atol=2e-6)                   # the first steps: same arithmetic up to summation order
+    assert float((e[1] - f[1]).abs().mean()) < 1e-5 and float((e[1] - f[1]).abs().max()) < 1e-3
+    for k, (a, b) in enumerate(zip(e[2], f[2])):                           # value_loss, loss_actor, entropy, approx_kl, clipfrac, illegal norm
+        assert float((a - b).abs().mean()) < (2e-3 if k == 4 else 2e-5), k  # (clipfrac moves in steps of 1 / 1024)
+    d = (e[0] - f[0]).abs()
+    moved = float((e[0] - torch.cat([p.detach().reshape(-1) for p in fp.init(5, device="cuda").parameters()])).abs().max())
+    assert moved > 50 * 1e-5 and float(d.mean()) < 0.02 * moved and float(d.max()) < 0.5 * moved, (moved, float(d.mean()), float(d.max()))
+
+
 def test_state_replace_board_fields(env, oracle, dds):
     """``state.replace(_hand=, _dealer=, _vul_NS=, _vul_EW=, _shuffled_players=, current_player=)`` on a fresh state
     (src/duplicate.py:120-128, wb5/utils.py:69-75, wb5/vis_pgx.py:51-56) == the oracle's explicit deal; the replaced
