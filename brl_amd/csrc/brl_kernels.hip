@@ -2451,7 +2451,7 @@ extern "C" int brl_mb_gather(int device, const brl_transition *flat, const float
   NEED(x0 && mask && action && old_value && old_log_prob && gae_out && targets_out, "NULL output array");
   HIP_TRY(hipSetDevice(device));
   GatherArgs A{flat->obs, flat->legal_action_mask, flat->action, flat->value, flat->log_prob, adv, targets, perm, mb_index, mbs,
-               x0, mask, action, old_value, old_log_prob, gae_out, targets_out};
+               x0, mask, action, old_value, old_log_prob, gae_out, targets_out, (int64_t)1 << 62};
   hipLaunchKernelGGL(k_mb_gather, dim3((unsigned)mbs), dim3(128), 0, (hipStream_t)stream, A);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
@@ -2459,14 +2459,16 @@ extern "C" int brl_mb_gather(int device, const brl_transition *flat, const float
 
 extern "C" int brl_mb_gather_bind(int device, const brl_transition *flat, const float *adv, const float *targets, const int64_t *perm,
                                   const int32_t *mb_index, int64_t mbs, float *x0, uint8_t *mask, int32_t *action, float *old_value,
-                                  float *old_log_prob, float *gae_out, float *targets_out, void *args_dev, void *stream) {
+                                  float *old_log_prob, float *gae_out, float *targets_out, int64_t nsteps, void *args_dev,
+                                  void *stream) {
   NEED(flat && flat->obs && flat->legal_action_mask && flat->action && flat->value && flat->log_prob, "trajectory");
   NEED(adv && targets && perm && mb_index && mbs > 0, "adv / targets / perm / mb_index / mbs");
   NEED(x0 && mask && action && old_value && old_log_prob && gae_out && targets_out && args_dev, "NULL output array / args_dev");
   HIP_TRY(hipSetDevice(device));
   static_assert(sizeof(GatherArgs) <= 256, "args_dev is 256 bytes");
+  NEED(nsteps > 0, "nsteps (minibatches in perm)");
   GatherArgs A{flat->obs, flat->legal_action_mask, flat->action, flat->value, flat->log_prob, adv, targets, perm, mb_index, mbs,
-               x0, mask, action, old_value, old_log_prob, gae_out, targets_out};
+               x0, mask, action, old_value, old_log_prob, gae_out, targets_out, nsteps};
   hipLaunchKernelGGL(k_mb_gather_bind, dim3(1), dim3(64), 0, (hipStream_t)stream, A, (GatherArgs *)args_dev);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
@@ -2627,16 +2629,34 @@ extern "C" int brl_ppo_stats_rows(int device, const float *stat_sums, const floa
   return BRL_OK;
 }
 
+static int adam_clip_impl(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
+                          const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale,
+                          float *scratch, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t gather_rows, void *stream) {
+  NEED(p && g && m && v && step && scratch && n > 0 && n % 4 == 0, "p / g / m / v / step / scratch / n (a multiple of 4)");
+  NEED(!gather_args || (mb_index && gather_rows > 0), "gather_args needs mb_index and the minibatch size");
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(k_adam_norm, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, g, n, grad_scale, scratch, step, mb_index);
+  const unsigned extra = gather_args ? (unsigned)((gather_rows + 1) / 2) : 0u;
+  hipLaunchKernelGGL(k_adam_apply, dim3(ADAM_BLOCKS + extra), dim3(ADAM_THREADS), 0, (hipStream_t)stream, p, g, m, v, n, scratch, step, lr,
+                     lr_dev, beta1, beta2, eps, max_norm, grad_scale, norm_out, (const GatherArgs *)gather_args);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
 extern "C" int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
                              const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale,
                              float *scratch, int32_t *mb_index, float *norm_out, void *stream) {
-  NEED(p && g && m && v && step && scratch && n > 0 && n % 4 == 0, "p / g / m / v / step / scratch / n (a multiple of 4)");
-  HIP_TRY(hipSetDevice(device));
-  hipLaunchKernelGGL(k_adam_norm, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, g, n, grad_scale, scratch, step);
-  hipLaunchKernelGGL(k_adam_apply, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, p, g, m, v, n, scratch, step, lr,
-                     lr_dev, beta1, beta2, eps, max_norm, grad_scale, mb_index, norm_out);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
+  return adam_clip_impl(device, p, g, m, v, n, step, lr, lr_dev, beta1, beta2, eps, max_norm, grad_scale, scratch, mb_index, norm_out,
+                        nullptr, 0, stream);
+}
+
+extern "C" int brl_adam_clip_gather(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
+                                    const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale,
+                                    float *scratch, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs,
+                                    void *stream) {
+  NEED(gather_args != nullptr, "gather_args");
+  return adam_clip_impl(device, p, g, m, v, n, step, lr, lr_dev, beta1, beta2, eps, max_norm, grad_scale, scratch, mb_index, norm_out,
+                        gather_args, mbs, stream);
 }
 
 extern "C" int brl_ppo_stats(int device, const float *partials, int64_t batch, const float *gram, float vf_coef,

@@ -19,26 +19,25 @@ struct GatherArgs {
   uint8_t *o_mask;
   int32_t *o_action;
   float *o_value, *o_log_prob, *o_adv, *o_tgt;
+  int64_t nsteps;   // minibatches the bound permutation holds (a gather beyond the last one is skipped: k_adam_apply's blocks)
 };
 
-__device__ __forceinline__ void mb_gather_row(const GatherArgs &A);
+__device__ __forceinline__ void mb_gather_row(const GatherArgs &A, int64_t b, int t);
 
-__global__ __launch_bounds__(128) void k_mb_gather(GatherArgs A) { mb_gather_row(A); }
+__global__ __launch_bounds__(128) void k_mb_gather(GatherArgs A) { mb_gather_row(A, blockIdx.x, (int)threadIdx.x); }
 
 // the same launch with its arguments in DEVICE memory (written by k_mb_gather_bind once per update): the captured minibatch
 // step starts with its own gather and stays valid when the next update brings another trajectory / permutation
 __global__ __launch_bounds__(128) void k_mb_gather_dev(const GatherArgs *Ad) {
   const GatherArgs A = *Ad;
-  mb_gather_row(A);
+  mb_gather_row(A, blockIdx.x, (int)threadIdx.x);
 }
 __global__ void k_mb_gather_bind(GatherArgs A, GatherArgs *dst) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *dst = A;
 }
 
-__device__ __forceinline__ void mb_gather_row(const GatherArgs &A) {
-  const int64_t b = blockIdx.x;
+__device__ __forceinline__ void mb_gather_row(const GatherArgs &A, int64_t b, int t) {
   const int64_t row = A.perm[(int64_t)(*A.mb_index) * A.B + b];
-  const int t = (int)threadIdx.x;
   if (t < 120) {  // 4 observation bytes -> 4 floats
     const uint32_t w = reinterpret_cast<const uint32_t *>(A.obs + row * BRL_OBS_SIZE)[t];
     reinterpret_cast<float4 *>(A.x0 + b * BRL_OBS_SIZE)[t] =
@@ -166,8 +165,16 @@ __global__ __launch_bounds__(256) void k_bias_finalize(BiasSegs S) {
   const int64_t col = (int64_t)blockIdx.x * 64 + c, cols = S.cols[seg];
   const float *p = S.partials[seg];
   float s = 0.0f;
-  if (col < cols)
-    for (int64_t t = g; t < S.tiles[seg]; t += 4) s += p[t * cols + col];
+  if (col < cols) {   // (latency-bound: the thread's tiles are requested 16 at a time, then added in index order)
+    const int64_t nt = S.tiles[seg];
+    for (int64_t t0 = g; t0 < nt; t0 += 64) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) v[u] = p[((t0 + 4 * u < nt) ? t0 + 4 * u : t0) * cols + col];
+#pragma unroll
+      for (int u = 0; u < 16; u++) s += (t0 + 4 * u < nt) ? v[u] : 0.0f;
+    }
+  }
   part[g][c] = s;
   __syncthreads();
   if (g == 0 && col < cols) S.db[seg][col] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
@@ -179,7 +186,8 @@ __global__ __launch_bounds__(256) void k_bias_finalize(BiasSegs S) {
 // torch.optim.Adam does (bias corrections 1 - beta^t, denominator sqrt(v) / sqrt(bc2) + eps).
 constexpr int ADAM_BLOCKS = 1024, ADAM_THREADS = 256;  // n is a multiple of 4 (the caller pads its flat buffers)
 
-__global__ __launch_bounds__(ADAM_THREADS) void k_adam_norm(const float *g, int64_t n, float gscale, float *partials, float *step) {
+__global__ __launch_bounds__(ADAM_THREADS) void k_adam_norm(const float *g, int64_t n, float gscale, float *partials, float *step,
+                                                            int32_t *mb_index) {
   __shared__ float red[ADAM_THREADS / 64];
   const int64_t n4 = n >> 2;
   const int64_t chunk = (n4 + ADAM_BLOCKS - 1) / ADAM_BLOCKS;
@@ -195,7 +203,10 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_norm(const float *g, int6
   __syncthreads();
   if (threadIdx.x == 0) {
     partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-    if (blockIdx.x == 0) *step += 1.0f;  // read by k_adam_apply (next launch)
+    if (blockIdx.x == 0) {
+      *step += 1.0f;  // read by k_adam_apply (next launch)
+      if (mb_index) *mb_index += 1;  // ... and the minibatch counter: k_adam_apply's extra blocks gather the NEXT minibatch with it
+    }
   }
 }
 
@@ -203,7 +214,17 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_apply(float *p, const flo
                                                              const float *partials, const float *step, float lr_arg,
                                                              const float *lr_dev, float b1,
                                                              float b2, float eps, float max_norm, float gscale,
-                                                             int32_t *mb_index, float *norm_out) {
+                                                             float *norm_out, const GatherArgs *gather) {
+  if (blockIdx.x >= ADAM_BLOCKS) {
+    // extra blocks (gather != NULL): the NEXT minibatch's rows -> the static minibatch buffers, beside the parameter update.
+    // Nothing of this step reads those buffers any more (stream order), k_adam_norm has already advanced mb_index, and the
+    // 1024 random 535-byte rows are pure latency — 5.6 us as a launch of its own in front of the forward pass.
+    const GatherArgs A = *gather;
+    if ((int64_t)(*A.mb_index) >= A.nsteps) return;   // (the update's last step: nothing follows)
+    const int64_t b = ((int64_t)blockIdx.x - ADAM_BLOCKS) * 2 + (threadIdx.x >> 7);
+    if (b < A.B) mb_gather_row(A, b, (int)(threadIdx.x & 127u));
+    return;
+  }
   __shared__ float red[ADAM_THREADS / 64];
   __shared__ float s_scale;
   {
@@ -217,10 +238,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_apply(float *p, const flo
       // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
       const float coef = (max_norm > 0.0f) ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
       s_scale = coef;
-      if (blockIdx.x == 0) {
-        if (norm_out) *norm_out = norm;
-        if (mb_index) *mb_index += 1;  // the next replay's gather reads the next minibatch
-      }
+      if (blockIdx.x == 0 && norm_out) *norm_out = norm;
     }
     __syncthreads();
   }

@@ -420,7 +420,9 @@ class FusedMinibatch:
                 for t, q in zip((self.P, self.M, self.V, self.step, self.mb_index), saved):
                     t.copy_(q)
 
-    def _bind_gather(self, fl: Transition, adv, tgt, perm):
+    def _bind_gather(self, fl: Transition, adv, tgt, perm, first=True):
+        """binds the step's gather to a trajectory / permutation; ``first``: also gathers minibatch *mb_index now (every later
+        minibatch is gathered by the Adam launch of the step before it)"""
         import ctypes as C
         tp = self.capi.TransitionPtrs()
         for name in self.capi.TransitionPtrs._names:
@@ -430,8 +432,10 @@ class FusedMinibatch:
         self.capi.check(self.lib.brl_mb_gather_bind(di, C.byref(tp), adv.data_ptr(), tgt.data_ptr(), perm.data_ptr(),
                                                     self.mb_index.data_ptr(), self.mbs, self.x0.data_ptr(), self.mask.data_ptr(),
                                                     self.action.data_ptr(), self.old_v.data_ptr(), self.old_lp.data_ptr(),
-                                                    self.adv.data_ptr(), self.tgt.data_ptr(), self.gargs.data_ptr(),
-                                                    torch.cuda.current_stream().cuda_stream))
+                                                    self.adv.data_ptr(), self.tgt.data_ptr(), perm.numel() // self.mbs,
+                                                    self.gargs.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        if first:
+            self.capi.check(self.lib.brl_mb_gather_dev(di, self.gargs.data_ptr(), self.mbs, torch.cuda.current_stream().cuda_stream))
 
     def _fwd_bwd(self):
         self._seg_head()
@@ -449,8 +453,7 @@ class FusedMinibatch:
         s = torch.cuda.current_stream().cuda_stream
         di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         cfg = self.cfg
-        chk(L.brl_mb_gather_dev(di, self.gargs.data_ptr(), B, s))   # minibatch *mb_index of the bound trajectory -> x0, mask, ...
-        x = self.x0
+        x = self.x0   # minibatch *mb_index of the bound trajectory: gathered by the previous step's Adam launch (or by the bind)
         for l, (W, b) in enumerate(zip(self.W, self.b)):          # forward: bias + activation
             if self.act == 0:                                     # ReLU in the GEMM epilogue
                 x = torch._addmm_activation(b, x, W.t(), use_gelu=False, out=self.h[l])
@@ -519,11 +522,12 @@ class FusedMinibatch:
     def _opt(self):
         s = torch.cuda.current_stream().cuda_stream
         di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
-        self.capi.check(self.lib.brl_adam_clip(di, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
-                                               self.n, self.step.data_ptr(), self.lr, self.lr_dev.data_ptr(), float(self.b1),
-                                               float(self.b2), self.eps,
-                                               self.max_norm, 1.0 / self.world, self.scratch.data_ptr(),
-                                               self.mb_index.data_ptr(), self.norm.data_ptr(), s))
+        self.capi.check(self.lib.brl_adam_clip_gather(di, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
+                                                      self.n, self.step.data_ptr(), self.lr, self.lr_dev.data_ptr(), float(self.b1),
+                                                      float(self.b2), self.eps,
+                                                      self.max_norm, 1.0 / self.world, self.scratch.data_ptr(),
+                                                      self.mb_index.data_ptr(), self.norm.data_ptr(), self.gargs.data_ptr(),
+                                                      self.mbs, s))
 
     # ---- one update_step call -----------------------------------------------------------------------------------
     def begin_update(self, flat: Transition, adv_f, tgt_f, perms):
@@ -597,7 +601,7 @@ class FusedMinibatch:
                                                         self.mbs, float(self.cfg["vf_coef"]), float(self.cfg["ent_coef"]),
                                                         self.ill_coef, self.log.data_ptr(),
                                                         torch.cuda.current_stream().cuda_stream))
-            self._bind_gather(*self._dummy)   # (the trajectory may be freed by the caller now)
+            self._bind_gather(*self._dummy, first=False)   # (the trajectory may be freed by the caller now)
         self._keep = None
         return self.log[:self._steps]
 

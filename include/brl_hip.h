@@ -416,10 +416,11 @@ int brl_ppo_stats_rows(int device, const float *stat_sums, const float *gram_sum
 
 /* brl_mb_gather with its arguments in DEVICE memory: brl_mb_gather_bind writes them into args_dev (256 bytes, stream-ordered:
  * a one-thread launch, no host copy) once per update; brl_mb_gather_dev(args_dev) is then a launch whose parameters never
- * change, so it can live inside the captured minibatch step and follow a new trajectory / permutation (src/update.py:193-206). */
+ * change, so it can live inside the captured minibatch step and follow a new trajectory / permutation (src/update.py:193-206).
+ * nsteps = the minibatches `perm` holds: brl_adam_clip_gather's gather of a minibatch >= nsteps is skipped. */
 int brl_mb_gather_bind(int device, const brl_transition *flat, const float *adv, const float *targets, const int64_t *perm,
                        const int32_t *mb_index, int64_t mbs, float *x0, uint8_t *mask, int32_t *action, float *old_value,
-                       float *old_log_prob, float *gae_out, float *targets_out, void *args_dev, void *stream);
+                       float *old_log_prob, float *gae_out, float *targets_out, int64_t nsteps, void *args_dev, void *stream);
 int brl_mb_gather_dev(int device, const void *args_dev, int64_t mbs, void *stream);
 
 /* brl_relu_bwd_colsum's tile pass for either activation: dh [rows,ld] *= act'(h) in place (act 0: ReLU, 1: tanh) and the
@@ -432,6 +433,14 @@ int brl_act_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int6
  * brl_ppo_heads_bwd's batch splits). */
 int brl_bias_finalize_ex(int device, int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles,
                          float *const *out, void *stream);
+
+/* brl_adam_clip whose second launch ALSO gathers the NEXT minibatch (extra workgroups beside the parameter update: the rows
+ * are pure latency, 5.6 us as a launch of their own): gather_args as written by brl_mb_gather_bind, mbs its minibatch size.
+ * mb_index (required) is advanced by the FIRST launch, so the gather reads minibatch *mb_index of the bound permutation; the
+ * first minibatch of an update is gathered by one brl_mb_gather_dev after the bind. */
+int brl_adam_clip_gather(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
+                         const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale, float *scratch,
+                         int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs, void *stream);
 
 #ifdef __cplusplus
 }

@@ -392,8 +392,9 @@ int brl_ppo_stats_rows(int device, const float *ss, const float *gs, int64_t row
   NOT_HERE("brl_ppo_stats_rows");
 }
 int brl_mb_gather_bind(int device, const brl_transition *flat, const float *adv, const float *tg, const int64_t *perm, const int32_t *mbi,
-                       int64_t mbs, float *x0, uint8_t *m, int32_t *a, float *ov, float *olp, float *go, float *to, void *ad, void *s) {
-  (void)device; (void)flat; (void)adv; (void)tg; (void)perm; (void)mbi; (void)mbs; (void)x0; (void)m; (void)a; (void)ov; (void)olp; (void)go; (void)to; (void)ad; (void)s;
+                       int64_t mbs, float *x0, uint8_t *m, int32_t *a, float *ov, float *olp, float *go, float *to, int64_t ns, void *ad,
+                       void *s) {
+  (void)ns; (void)device; (void)flat; (void)adv; (void)tg; (void)perm; (void)mbi; (void)mbs; (void)x0; (void)m; (void)a; (void)ov; (void)olp; (void)go; (void)to; (void)ad; (void)s;
   NOT_HERE("brl_mb_gather_bind");
 }
 int brl_mb_gather_dev(int device, const void *ad, int64_t mbs, void *s) {
@@ -403,4 +404,10 @@ int brl_mb_gather_dev(int device, const void *ad, int64_t mbs, void *s) {
 int brl_ppo_illegal_grad(int device, const float *hd, const uint8_t *m, const float *vec, float ic, int64_t b, float *dh, void *s) {
   (void)device; (void)hd; (void)m; (void)vec; (void)ic; (void)b; (void)dh; (void)s;
   NOT_HERE("brl_ppo_illegal_grad");
+}
+int brl_adam_clip_gather(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr, const float *lrd,
+                         float b1, float b2, float eps, float mn, float gs, float *scratch, int32_t *mbi, float *no, const void *ga,
+                         int64_t mbs, void *s) {
+  (void)gs; (void)lrd; (void)device; (void)p; (void)g; (void)m; (void)v; (void)n; (void)step; (void)lr; (void)b1; (void)b2; (void)eps; (void)mn; (void)scratch; (void)mbi; (void)no; (void)ga; (void)mbs; (void)s;
+  NOT_HERE("brl_adam_clip_gather");
 }

@@ -1628,12 +1628,25 @@ def test_fused_update_helpers_match_torch():
         t.zero_()
     _capi.check(L.brl_mb_gather_bind(0, C.byref(tp), adv.data_ptr(), tgt.data_ptr(), perm.data_ptr(), mbi.data_ptr(), B, x0.data_ptr(),
                                      mask.data_ptr(), act.data_ptr(), ov.data_ptr(), olp.data_ptr(), ga.data_ptr(), tg.data_ptr(),
-                                     gargs.data_ptr(), s))
+                                     256 // B, gargs.data_ptr(), s))
     mbi.fill_(1)   # read by the launch, not by the bind
     _capi.check(L.brl_mb_gather_dev(0, gargs.data_ptr(), B, s))
     rows = perm[B:2 * B]
     assert torch.equal(x0, flat.obs[rows].float()) and torch.equal(mask.bool(), flat.legal_action_mask[rows])
     assert torch.equal(act, flat.action[rows]) and torch.equal(ga, adv[rows]) and torch.equal(tg, tgt[rows])
+    # ... and as extra workgroups of the Adam launch: the first launch advances the counter, the second gathers THAT minibatch
+    # beside the parameter update; a minibatch past the bound permutation (4 here) is skipped
+    p2, m2, v2 = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    step2 = torch.zeros((), device=dev)
+    for want_idx in (2, 3, 4):
+        grad = torch.randn(n, device=dev, generator=g)
+        _capi.check(L.brl_adam_clip_gather(0, p2.data_ptr(), grad.data_ptr(), m2.data_ptr(), v2.data_ptr(), n, step2.data_ptr(), 1e-3, None,
+                                           0.9, 0.999, 1e-5, 0.5, 1.0, scratch.data_ptr(), mbi.data_ptr(), norm.data_ptr(),
+                                           gargs.data_ptr(), B, s))
+        assert int(mbi.item()) == want_idx
+        rows = perm[min(want_idx, 3) * B:(min(want_idx, 3) + 1) * B]     # (index 4: nothing gathered, minibatch 3 stays)
+        assert torch.equal(x0, flat.obs[rows].float()) and torch.equal(act, flat.action[rows]) and torch.equal(tg, tgt[rows])
+    assert float(step2.item()) == 3.0 and not torch.equal(p2, p0)
 
 
 @pytest.mark.parametrize("B,H,act", [(1024, 1024, 0), (1000, 1024, 1), (48, 256, 0), (17, 512, 1)])
