@@ -26,7 +26,8 @@ def enable(tuning: bool = False, path: str = PATH) -> bool:
     t.tuning_enable(bool(tuning))
     if hasattr(t, "write_file_on_exit"):
         t.write_file_on_exit(bool(tuning))
-    t.set_filename(path)
+    if tuning:
+        t.set_filename(path)   # (only a tuning run may write: lookups never touch the committed file)
     if os.path.exists(path):
         try:
             t.read_file(path)
