@@ -1883,6 +1883,7 @@ __global__ __launch_bounds__(512) void k_ppo_stats(const float *partials, int64_
 
 #include "ppo_update.hpp"  // k_mb_gather, k_relu_bwd_colsum, k_adam_norm / k_adam_apply
 #include "ppo_heads.hpp"   // k_heads_loss, k_heads_bwd, k_ppo_stats2: the 39-column head products and what hangs on them
+#include "mlp_infer.hpp"   // k_linear16: one bf16 / fp16 layer of the policy MLP (inference)
 
 // =====================================================================================
 // C-ABI
@@ -2305,6 +2306,53 @@ extern "C" int brl_obs_cast(brl_handle *h, const uint8_t *obs, int64_t n, void *
   if (fmt == 0) hipLaunchKernelGGL(k_obs_cast<0>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, out, n16);
   else if (fmt == 1) hipLaunchKernelGGL(k_obs_cast<1>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, out, n16);
   else hipLaunchKernelGGL(k_obs_cast<2>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, out, n16);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+#ifdef LIN16_TIMING   // scripts/time_linear16.py --stamps: 4 shader-clock stamps per workgroup
+static unsigned long long *g_lin16_dbg = nullptr;
+extern "C" void brl_lin16_set_dbg(void *p) { g_lin16_dbg = (unsigned long long *)p; }
+#endif
+extern "C" int brl_linear_act(brl_handle *h, const void *x, int64_t ldx, const void *w, int64_t ldw, const float *bias, void *y,
+                            int64_t ldy, int64_t m, int n_out, int k, int relu, int fmt, void *stream) {
+  COMMON(h, m);
+  NEED(x && w && y, "NULL x / w / y");
+  NEED(fmt == 1 || fmt == 2, "fmt (1 = bf16, 2 = fp16)");
+  NEED(n_out > 0 && n_out % lin16::BN == 0, "n_out % 128");
+  NEED(k >= 8 && k % 8 == 0, "k % 8");
+  NEED(ldx >= k && ldw >= k && ldy >= n_out && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0, "ldx / ldw / ldy");
+  NEED((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0, "x / w / y not 16-byte aligned");
+  NEED(m * ldx * 2 < ((int64_t)1 << 32) && (int64_t)n_out * ldw * 2 < ((int64_t)1 << 32), "operand larger than 4 GB");
+  NEED(m <= (int64_t)1 << 30, "m");
+  static bool attr_done[3] = {false, false, false};
+  if (!attr_done[fmt]) {   // 144 KB of dynamic LDS: above the default 64 KB limit
+    if (fmt == 1) HIP_TRY(hipFuncSetAttribute((const void *)lin16::k_linear16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lin16::LDS_BYTES));
+    else HIP_TRY(hipFuncSetAttribute((const void *)lin16::k_linear16<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lin16::LDS_BYTES));
+    attr_done[fmt] = true;
+  }
+  lin16::Args A;
+  memset(&A, 0, sizeof(A));
+  A.x = (const uint16_t *)x; A.ldx = ldx;
+  A.w = (const uint16_t *)w; A.ldw = ldw;
+  A.bias = bias;
+  A.y = (uint16_t *)y; A.ldy = ldy;
+  A.M = (int)m; A.N = n_out; A.K = k;
+  A.relu = relu;
+  static int store_mode = -1;
+  if (store_mode < 0) {
+    // y leaves write-through by default: measured in the bf16 graph rollout, 8192 tables: 12.47 ms against 13.30 (plain
+    // stores: the dirty lines are written back when the kernel ends) and 13.01 (non-temporal); BRL_LIN16_STORE=0/1/2 for A/B
+    const char *e = getenv("BRL_LIN16_STORE");
+    store_mode = (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : 2;
+  }
+  A.store_mode = store_mode;
+#ifdef LIN16_TIMING
+  A.dbg = g_lin16_dbg;
+#endif
+  const int tiles = (int)((m + lin16::BM - 1) / lin16::BM) * (n_out / lin16::BN);
+  if (fmt == 1) hipLaunchKernelGGL(lin16::k_linear16<1>, dim3(tiles), dim3(lin16::THREADS), lin16::LDS_BYTES, (hipStream_t)stream, A);
+  else hipLaunchKernelGGL(lin16::k_linear16<2>, dim3(tiles), dim3(lin16::THREADS), lin16::LDS_BYTES, (hipStream_t)stream, A);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

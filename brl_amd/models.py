@@ -10,6 +10,7 @@ value (src/models.py:23-33; "DeepMind_6" / "DeepMind_8" = the deeper variants of
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -83,6 +84,13 @@ class InferenceSnapshot:
         # as float holding the SAME (rounded) values the GEMM path adds
         self.head_wt = self.head_w.t().contiguous()
         self.head_bf = self.head_b.float().contiguous()
+        # 16-bit inference with a library handle: the hidden layers run on the library's own kernel (brl_linear_act,
+        # csrc/mlp_infer.hpp) — nn.Linear's [out, in] layout in `dtype`, the bias as float holding the rounded values
+        self.body_nk = None
+        if env is not None and dt in (torch.bfloat16, torch.float16) and os.environ.get("BRL_LINEAR16", "1") != "0" \
+                and all(lin.weight.shape[0] % 128 == 0 and lin.weight.shape[1] % 8 == 0 for lin in module.body):
+            self.body_nk = [(lin.weight.detach().to(dt).contiguous(), lin.bias.detach().to(dt).float().contiguous())
+                            for lin in module.body]
 
     def refresh(self, module: "ActorCritic"):
         """Re-read the weights of `module` INTO the existing tensors (their addresses are baked into captured graphs)."""
@@ -96,6 +104,10 @@ class InferenceSnapshot:
         self.head_b[k:].copy_(module.critic.bias.detach())
         self.head_wt.copy_(self.head_w.t())
         self.head_bf.copy_(self.head_b)
+        if self.body_nk is not None:
+            for (w, b), lin in zip(self.body_nk, module.body):
+                w.copy_(lin.weight.detach())
+                b.copy_(lin.bias.detach().to(self.dtype))
 
     @staticmethod
     def make(module, dtype=None, env=None):
@@ -116,14 +128,28 @@ class InferenceSnapshot:
             return x
         return obs.to(self.dtype)
 
-    def hidden(self, obs, x=None):
-        """obs -> the last hidden layer's output [n, hidden] in ``self.dtype`` (what the heads are applied to)"""
-        if x is None:
-            x = self._input(obs)
+    def _body(self, x):
+        """the hidden layers: x [n, 480] in ``self.dtype`` -> [n, hidden]"""
+        if self.body_nk is not None and x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.shape[0] > 0:
+            from . import _capi
+            from .bridge_bidding import _stream
+            L, fmt, st = _capi.lib(), self._FMT[self.dtype], _stream()
+            for w, b in self.body_nk:
+                y = torch.empty((x.shape[0], w.shape[0]), dtype=self.dtype, device=x.device)
+                _capi.check(L.brl_linear_act(self.env._h, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), b.data_ptr(),
+                                           y.data_ptr(), y.stride(0), x.shape[0], w.shape[0], w.shape[1], 1, fmt, st))
+                x = y
+            return x
         fused = hasattr(torch, "_addmm_activation")
         for w, b in self.body:
             x = torch._addmm_activation(b, x, w, use_gelu=False) if fused else torch.addmm(b, x, w).relu_()
         return x
+
+    def hidden(self, obs, x=None):
+        """obs -> the last hidden layer's output [n, hidden] in ``self.dtype`` (what the heads are applied to)"""
+        if x is None:
+            x = self._input(obs)
+        return self._body(x)
 
     def heads(self, obs, x=None, raw=False):
         """obs: [n, 480] bool / float -> f32 [n, 39]: the 38 logits and the value as ONE matrix (row stride 39; the
@@ -132,9 +158,7 @@ class InferenceSnapshot:
         ``self.dtype`` as the GEMM wrote it (brl_policy_step_ex converts while reading: brl_macro_ext.in_fmt)."""
         if x is None:
             x = self._input(obs)
-        fused = hasattr(torch, "_addmm_activation")
-        for w, b in self.body:
-            x = torch._addmm_activation(b, x, w, use_gelu=False) if fused else torch.addmm(b, x, w).relu_()
+        x = self._body(x)
         out = torch.addmm(self.head_b, x, self.head_w)
         return out if raw else out.float()
 

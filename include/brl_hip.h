@@ -224,6 +224,15 @@ int brl_policy_step_ex(brl_handle *h, const uint64_t *state_in, uint64_t *state_
  * variants.  obs uint8 [n,480] (0/1); out [n,480] of float (fmt 0), bf16 (fmt 1) or fp16 (fmt 2). */
 int brl_obs_cast(brl_handle *h, const uint8_t *obs, int64_t n, void *out, int fmt, void *stream);
 
+/* One hidden layer of the policy network in 16-bit inference precision — `hk.Linear(1024)` + `jax.nn.relu`,
+ * src/models.py:23-33, as called per env.step by src/roll_out.py:73-84 / src/evaluation.py:52-60:
+ *     y[m, n_out] = act(x[m, k] w[n_out, k]^T + bias),  x / w / y bf16 (fmt 1) or fp16 (fmt 2), fp32 accumulation, bias fp32.
+ * OPT-IN precision (narrower than the reference's fp32; `inference_dtype`), fp32 stays with the library GEMM.
+ * w is nn.Linear's own [n_out, k] layout; row strides ldx / ldw / ldy in elements (% 8 == 0); n_out % 128 == 0; k % 8 == 0
+ * (k = 480 is fine: nothing beyond column k of x or w is used); relu != 0 applies max(., 0); 16-byte aligned pointers. */
+int brl_linear_act(brl_handle *h, const void *x, int64_t ldx, const void *w, int64_t ldw, const float *bias, void *y,
+                 int64_t ldy, int64_t m, int n_out, int k, int relu, int fmt, void *stream);
+
 /* calc_gae's reverse scan — src/gae.py:20-39.  done uint8 [T,n], value/reward float
  * [T,n], last_val float [n]; gamma_lambda = float32(gamma * gae_lambda). */
 int brl_gae(brl_handle *h, const uint8_t *done, const float *value, const float *reward,

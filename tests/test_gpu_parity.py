@@ -609,6 +609,59 @@ def test_obs_cast_matches_torch(env):
         assert torch.equal(out, obs.to(dt))
 
 
+@pytest.mark.parametrize("dt,fmt", [(torch.bfloat16, 1), (torch.float16, 2)])
+def test_linear16_matches_float64_product(env, dt, fmt):
+    """brl_linear_act (one hidden layer of the 16-bit inference path: hk.Linear + relu, src/models.py:23-33) against the float64
+    product of the SAME 16-bit operands, to half an ulp of the 16-bit result + accumulation slack; shapes: the MLP's own
+    (8192 x 1024 x 1024, K = 480), ragged M, K tails (480, 200, 8), a single chunk, M below one tile; strided operands; and
+    against the library GEMM the default path would have used (same fp32-accumulate class: at most one 16-bit ulp apart)."""
+    from brl_amd import _capi
+    from brl_amd.bridge_bidding import _stream
+    dev = env.device
+    g = torch.Generator(device=dev).manual_seed(5)
+
+    def run(x, w, b, y, relu):
+        _capi.check(_capi.lib().brl_linear_act(env._h, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
+                                             b.data_ptr() if b is not None else None, y.data_ptr(), y.stride(0), x.shape[0],
+                                             w.shape[0], x.shape[1], int(relu), fmt, _stream()))
+
+    eps = 2.0 ** (-8 if fmt == 1 else -11)
+    for (m, n, k) in ((8192, 1024, 1024), (8192, 1024, 480), (300, 256, 64), (257, 128, 8), (1000, 1024, 200), (5, 128, 1024),
+                      (513, 384, 136)):
+        x = (torch.rand(m, k, device=dev, generator=g) * 2 - 1).to(dt)
+        if k == 480:
+            x = (torch.rand(m, k, device=dev, generator=g) < 0.2).to(dt)   # an observation: 0 / 1
+        w = (torch.randn(n, k, device=dev, generator=g) / k ** 0.5).to(dt)
+        b = (torch.randn(n, device=dev, generator=g) * 0.1).to(dt).float()
+        for relu in (1, 0):
+            y = torch.full((m, n), float("nan"), device=dev).to(dt)
+            run(x, w, b, y, relu)
+            ref = x.double() @ w.double().t() + b.double()
+            if relu:
+                ref = ref.clamp_min(0)
+            err = (y.double() - ref).abs()
+            assert not torch.isnan(y.float()).any()
+            assert int((err > ref.abs() * eps + 1e-3).sum()) == 0, (m, n, k, relu, float(err.max()))
+        lib_y = torch.addmm(b.to(dt), x, w.t())
+        y = torch.empty((m, n), dtype=dt, device=dev)
+        run(x, w, b, y, 0)
+        assert float((y.float() - lib_y.float()).abs().max()) <= float(lib_y.float().abs().max()) * 2 * eps
+    # strided operands (row strides larger than the row), no bias
+    xs = (torch.rand(700, 640, device=dev, generator=g) * 2 - 1).to(dt)
+    ws = (torch.randn(256, 520, device=dev, generator=g) / 20).to(dt)
+    ys = torch.zeros(700, 384, dtype=dt, device=dev)
+    x, w, y = xs[:, :512], ws[:, :512], ys[:, :256]
+    run(x, w, None, y, 0)
+    ref = x.double() @ w.double().t()
+    assert int(((y.double() - ref).abs() > ref.abs() * eps + 1e-3).sum()) == 0
+    assert float(ys[:, 256:].abs().max()) == 0.0   # nothing written beyond column n_out
+    # argument checks
+    with pytest.raises(_capi.BrlError):
+        run(xs[:, :512], ws[:200, :512], None, ys[:, :256], 0)     # n_out % 128
+    with pytest.raises(_capi.BrlError):
+        run(xs[:, :516], ws[:, :516], None, ys[:, :256], 0)        # k % 8
+
+
 @pytest.mark.parametrize("dt", [None, "bf16"])
 def test_graphed_policy_rollout_matches_eager(env, dt):
     """config["graph_rollout"]: every macro-step replayed from a hipGraph (device-side draw index,
