@@ -2310,6 +2310,27 @@ extern "C" int brl_obs_cast(brl_handle *h, const uint8_t *obs, int64_t n, void *
   return BRL_OK;
 }
 
+static int lin16_attr(int fmt) {
+  static bool done[3] = {false, false, false};
+  if (!done[fmt]) {   // 144 KB of dynamic LDS: above the default 64 KB limit
+    if (fmt == 1) HIP_TRY(hipFuncSetAttribute((const void *)lin16::k_linear16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lin16::LDS_BYTES));
+    else HIP_TRY(hipFuncSetAttribute((const void *)lin16::k_linear16<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lin16::LDS_BYTES));
+    done[fmt] = true;
+  }
+  return BRL_OK;
+}
+
+static int lin16_store_mode() {
+  static int store_mode = -1;
+  if (store_mode < 0) {
+    // y leaves write-through by default: measured in the bf16 graph rollout, 8192 tables: 12.47 ms against 13.30 (plain
+    // stores: the dirty lines are written back when the kernel ends) and 13.01 (non-temporal); BRL_LIN16_STORE=0/1/2 for A/B
+    const char *e = getenv("BRL_LIN16_STORE");
+    store_mode = (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : 2;
+  }
+  return store_mode;
+}
+
 #ifdef LIN16_TIMING   // scripts/time_linear16.py --stamps: 4 shader-clock stamps per workgroup
 static unsigned long long *g_lin16_dbg = nullptr;
 extern "C" void brl_lin16_set_dbg(void *p) { g_lin16_dbg = (unsigned long long *)p; }
@@ -2325,12 +2346,7 @@ extern "C" int brl_linear_act(brl_handle *h, const void *x, int64_t ldx, const v
   NEED((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0, "x / w / y not 16-byte aligned");
   NEED(m * ldx * 2 < ((int64_t)1 << 32) && (int64_t)n_out * ldw * 2 < ((int64_t)1 << 32), "operand larger than 4 GB");
   NEED(m <= (int64_t)1 << 30, "m");
-  static bool attr_done[3] = {false, false, false};
-  if (!attr_done[fmt]) {   // 144 KB of dynamic LDS: above the default 64 KB limit
-    if (fmt == 1) HIP_TRY(hipFuncSetAttribute((const void *)lin16::k_linear16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lin16::LDS_BYTES));
-    else HIP_TRY(hipFuncSetAttribute((const void *)lin16::k_linear16<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lin16::LDS_BYTES));
-    attr_done[fmt] = true;
-  }
+  if (int rc = lin16_attr(fmt)) return rc;
   lin16::Args A;
   memset(&A, 0, sizeof(A));
   A.x = (const uint16_t *)x; A.ldx = ldx;
@@ -2339,14 +2355,7 @@ extern "C" int brl_linear_act(brl_handle *h, const void *x, int64_t ldx, const v
   A.y = (uint16_t *)y; A.ldy = ldy;
   A.M = (int)m; A.N = n_out; A.K = k;
   A.relu = relu;
-  static int store_mode = -1;
-  if (store_mode < 0) {
-    // y leaves write-through by default: measured in the bf16 graph rollout, 8192 tables: 12.47 ms against 13.30 (plain
-    // stores: the dirty lines are written back when the kernel ends) and 13.01 (non-temporal); BRL_LIN16_STORE=0/1/2 for A/B
-    const char *e = getenv("BRL_LIN16_STORE");
-    store_mode = (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : 2;
-  }
-  A.store_mode = store_mode;
+  A.store_mode = lin16_store_mode();
 #ifdef LIN16_TIMING
   A.dbg = g_lin16_dbg;
 #endif

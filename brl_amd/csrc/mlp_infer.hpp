@@ -86,21 +86,11 @@ __device__ __forceinline__ uint32_t pack2(const f32x2 v) {   // two floats -> tw
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h16x2));
 }
 
+// One 256 x 128 tile of y = act(x W^T + b): tile (tm, tn), by all 512 threads of the workgroup.  `lds`: LDS_BYTES, `bias_s`: BN floats.
+// The caller puts a workgroup barrier between two tiles (the output tile leaves through the stages' memory).
 template <int FMT>
-__global__ __launch_bounds__(THREADS) void k_linear16(Args G) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  __shared__ float bias_s[BN];
+__device__ __forceinline__ void linear_tile(const Args &G, char *lds, float *bias_s, const int tm, const int tn) {
   const int tid = (int)threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_m = (G.M + BM - 1) / BM, tiles_n = G.N / BN, nblk = tiles_m * tiles_n;
-  // workgroup -> tile: blocks b, b + 8, .. share an XCD; give them CONSECUTIVE logical ids (bijective for any nblk), and walk
-  // the column tiles fastest: an XCD's 32 workgroups = 4 row tiles x all 8 column tiles at N = 1024
-  int tm, tn;
-  {
-    const int b = (int)blockIdx.x, q = nblk / 8, r = nblk % 8, xcd = b % 8;
-    const int L = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
-    tm = L / tiles_n;
-    tn = L - tm * tiles_n;
-  }
   const int m0 = tm * BM, n0 = tn * BN;
   const int nchunks = (G.K + BK - 1) / BK;
   const bool ktail = (G.K % BK) != 0;
@@ -318,6 +308,23 @@ __global__ __launch_bounds__(THREADS) void k_linear16(Args G) {
     }
   }
   LIN16_STAMP(3);
+}
+
+// workgroup -> logical id: blocks b, b + 8, .. share an XCD; give them CONSECUTIVE logical ids (bijective for any grid size)
+__device__ __forceinline__ int xcd_logical_id(int b, int nblk) {
+  const int q = nblk / 8, r = nblk % 8, xcd = b % 8;
+  return ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+}
+
+template <int FMT>
+__global__ __launch_bounds__(THREADS) void k_linear16(Args G) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  __shared__ float bias_s[BN];
+  // the column tiles walk fastest: an XCD's 32 workgroups = 4 row tiles x all 8 column tiles at N = 1024 (its L2 holds W once)
+  const int tiles_n = G.N / BN;
+  const int L = xcd_logical_id((int)blockIdx.x, (int)gridDim.x);
+  const int tm = L / tiles_n;
+  linear_tile<FMT>(G, lds, bias_s, tm, L - tm * tiles_n);
 }
 
 }  // namespace lin16
