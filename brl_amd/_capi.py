@@ -37,7 +37,8 @@ class MacroExt(C.Structure):
                 ("done_out", _vp), ("reward_out", _vp), ("actor", _vp), ("reward_scale", C.c_float), ("obs_fmt", C.c_int32),
                 ("terminated_count", _vp), ("obs_cast", _vp), ("in_fmt", C.c_int32), ("reserved", C.c_int32),
                 ("head_h", _vp), ("head_ldh", C.c_int64), ("head_w", _vp), ("head_b", _vp), ("head_hidden", C.c_int32),
-                ("head_fmt", C.c_int32)]
+                ("head_fmt", C.c_int32), ("head_part", _vp), ("head_part_stride", C.c_int64), ("head_part_ld", C.c_int32),
+                ("head_nparts", C.c_int32)]
 
 
 class EvalStatsPtrs(C.Structure):
@@ -87,6 +88,7 @@ def lib() -> C.CDLL:
         "brl_policy_step_ex": [_vp, _vp, _vp, i64, _vp, i64, i32, _vp, u32, i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                C.POINTER(MacroExt), _vp],
         "brl_obs_cast": [_vp, _vp, i64, _vp, i32, _vp],
+        "brl_linear_act_heads": [_vp, _vp, i64, _vp, i64, _vp, _vp, i64, i64, i32, i32, i32, i32, _vp, i64, i32, _vp, i64, i64, _vp],
         "brl_linear_act": [_vp, _vp, i64, _vp, i64, _vp, _vp, i64, i64, i32, i32, i32, i32, _vp],
         "brl_gae": [_vp, _vp, _vp, _vp, _vp, f32, f32, i32, i64, _vp, _vp, _vp],
         "brl_imp_reward": [_vp, _vp, _vp, _vp, i64, _vp],
@@ -127,7 +129,7 @@ def lib() -> C.CDLL:
 
 EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_destroy", "brl_set_rng",
            "brl_init_random", "brl_init_from_deals", "brl_step", "brl_observe", "brl_get_fields",
-           "brl_rollout_random", "brl_policy_step", "brl_policy_step_at", "brl_obs_cast", "brl_linear_act", "brl_gae", "brl_imp_reward", "brl_duplicate_step",
+           "brl_rollout_random", "brl_policy_step", "brl_policy_step_at", "brl_obs_cast", "brl_linear_act", "brl_linear_act_heads", "brl_gae", "brl_imp_reward", "brl_duplicate_step",
            "brl_eval_step", "brl_eval_reduce", "brl_ppo_loss", "brl_ppo_stats", "brl_ppo_loss_heads", "brl_mb_gather",
            "brl_relu_bwd_colsum", "brl_adam_clip", "brl_bias_finalize", "brl_ppo_stats_at", "brl_policy_step_ex",
            "brl_eval_step_team", "brl_rollout_random_gae", "brl_ppo_heads_loss", "brl_ppo_heads_bwd", "brl_ppo_stats_gram",

@@ -1192,19 +1192,37 @@ typedef _Float16 pol_f16x8 __attribute__((ext_vector_type(8)));
 typedef float pol_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int POL_HD = BRL_NUM_ACTIONS + 1;   // 39
 
-template <int K, bool HEADS = false>
+// HEADS == 2: the heads come as PARTIAL products — head_part[p][table][head], p = the column tile of the last hidden layer
+// whose launch (brl_linear_act_heads) multiplied its 128 columns with the head weights while it held them: logits = head_b +
+// the parts in order.  The last hidden layer is then never written to memory, and this launch reads 1.2 KB per table
+// instead of the 2 KB row + its share of the head weights.
+template <int K, int HEADS = 0>
 __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES_PER_BLOCK * K * TABLE_BYTES];
-  __shared__ float hd_red[HEADS ? 4 : 1][3][4][64];
+  __shared__ float hd_red[HEADS == 1 ? 4 : 1][3][4][64];
   __shared__ float hd_logits[HEADS ? 16 : 1][POL_HD + 1];
   static_assert(!HEADS || K == 4, "the head tile is the workgroup's 16 tables");
   // (HEADS) every operand of the heads product — this wave's quarter of K: 8 + 24 16-byte loads at hidden = 1024 — is requested
   // BEFORE the table images are fetched, so that the two memory round trips overlap; the MFMAs follow wave_begin
-  constexpr int HGP = HEADS ? 8 : 1;
+  constexpr int HGP = HEADS == 1 ? 8 : 1;
   pol_b16x8 hav[HGP], hbv[HGP][3];
   bool hbok[3] = {false, false, false};
   int hsteps = 0;
-  if (HEADS) {
+  constexpr int HPE = (16 * POL_HD + BLOCK_THREADS - 1) / BLOCK_THREADS;   // head values per thread (3)
+  float hpv[HEADS == 2 ? HPE : 1][8];
+  if (HEADS == 2) {   // (requested before the table images are fetched, like the operands of HEADS == 1)
+    const int64_t row0 = xcd_block((int64_t)blockIdx.x, (int64_t)gridDim.x) * 16;
+#pragma unroll
+    for (int i = 0; i < HPE; i++) {
+      const int e = (int)threadIdx.x + BLOCK_THREADS * i;
+      const int row = (e < 16 * POL_HD) ? e / POL_HD : 0, col = (e < 16 * POL_HD) ? e - row * POL_HD : 0;
+      const int64_t tb = (row0 + row < A.n) ? row0 + row : A.n - 1;
+      const float *bp = A.x.head_part + tb * A.x.head_part_ld + col;
+#pragma unroll
+      for (int p = 0; p < 8; p++) hpv[i][p] = (p < A.x.head_nparts) ? bp[(int64_t)p * A.x.head_part_stride] : 0.0f;
+    }
+  }
+  if (HEADS == 1) {
     const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
     const int64_t row0 = xcd_block((int64_t)blockIdx.x, (int64_t)gridDim.x) * 16;
     const int r = lane & 15, kq = lane >> 4;
@@ -1225,7 +1243,26 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
   }
   Tbl t;
   Wave<K> w = wave_begin<K>(lds, A.state_in, A.n, t);
-  if (HEADS) {
+  if (HEADS == 2) {
+    const int64_t row0 = xcd_block((int64_t)blockIdx.x, (int64_t)gridDim.x) * 16;
+#pragma unroll
+    for (int i = 0; i < HPE; i++) {
+      const int e = (int)threadIdx.x + BLOCK_THREADS * i;
+      if (e < 16 * POL_HD) {
+        const int row = e / POL_HD, col = e - row * POL_HD;
+        float v = A.x.head_b[col];
+#pragma unroll
+        for (int p = 0; p < 8; p++) v += hpv[i][p];   // fixed order (absent parts are exact zeros)
+        if (A.x.head_nparts > 8) {
+          const int64_t tb = (row0 + row < A.n) ? row0 + row : A.n - 1;
+          for (int p = 8; p < A.x.head_nparts; p++) v += A.x.head_part[(int64_t)p * A.x.head_part_stride + tb * A.x.head_part_ld + col];
+        }
+        hd_logits[row][col] = v;
+      }
+    }
+    __syncthreads();
+  }
+  if (HEADS == 1) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 15, kq = lane >> 4;
     pol_f32x4 acc[3];
@@ -2209,7 +2246,7 @@ static int policy_step_impl(brl_handle *h, const uint64_t *state_in, uint64_t *s
                             int32_t *action, float *log_prob, uint8_t *obs, uint8_t *mask, float *rewards_acc,
                             uint8_t *terminated_acc, int32_t *current_player, void *stream, const brl_macro_ext *ext = nullptr) {
   COMMON(h, n);
-  const bool heads = ext != nullptr && ext->head_h != nullptr;
+  const bool heads = ext != nullptr && (ext->head_h != nullptr || ext->head_part != nullptr);
   NEED(state_in && state_out && (logits || heads), "NULL state / logits");
   NEED(mode >= 0 && mode <= 3, "mode");
   NEED(heads || logits_stride >= BRL_NUM_ACTIONS, "logits_stride");
@@ -2224,17 +2261,25 @@ static int policy_step_impl(brl_handle *h, const uint64_t *state_in, uint64_t *s
   memset(&A.x, 0, sizeof(A.x));
   if (ext != nullptr) {
     A.x = *ext;
-    NEED(!ext->value_out || ext->head_h || (ext->value_in && ext->value_stride >= 1), "ext: value_in / value_stride");
+    NEED(!ext->value_out || heads || (ext->value_in && ext->value_stride >= 1), "ext: value_in / value_stride");
     NEED(!ext->last || !ext->reward_out || (ext->actor && rewards_acc && ext->reward_scale != 0.0f), "ext: reward_out needs actor, rewards_acc, reward_scale");
     NEED(!ext->last || !(ext->done_out || ext->terminated_count) || terminated_acc, "ext: done_out / terminated_count need terminated_acc");
     NEED(!ext->obs_cast || (ext->obs_fmt >= 0 && ext->obs_fmt <= 2), "ext: obs_fmt");
     NEED(ext->in_fmt >= 0 && ext->in_fmt <= 2, "ext: in_fmt");
+    if (ext->head_part != nullptr) {
+      NEED(ext->head_b && ext->head_nparts >= 1 && ext->head_part_ld >= BRL_NUM_ACTIONS + 1 && ext->head_part_stride >= n * ext->head_part_ld,
+           "ext: head_b / head_nparts / head_part_ld (>= 39) / head_part_stride (>= n * head_part_ld)");
+      NEED(h->tables_per_wave == 4, "ext: head_part needs BRL_TABLES_PER_WAVE=4 (the head tile is a workgroup's 16 tables)");
+      hipLaunchKernelGGL((k_policy_step<4, 2>), dim3(wave_grid(n, 4)), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, A);
+      HIP_TRY(hipGetLastError());
+      return BRL_OK;
+    }
     if (heads) {
       NEED(ext->head_w && ext->head_b && (ext->head_fmt == 1 || ext->head_fmt == 2), "ext: head_w / head_b / head_fmt (1 bf16, 2 fp16)");
       NEED(ext->head_hidden > 0 && ext->head_hidden % 32 == 0 && ext->head_ldh >= ext->head_hidden && ext->head_ldh % 8 == 0,
            "ext: head_hidden (a multiple of 32) / head_ldh (a multiple of 8)");
       NEED(h->tables_per_wave == 4, "ext: head_h needs BRL_TABLES_PER_WAVE=4 (the head tile is a workgroup's 16 tables)");
-      hipLaunchKernelGGL((k_policy_step<4, true>), dim3(wave_grid(n, 4)), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, A);
+      hipLaunchKernelGGL((k_policy_step<4, 1>), dim3(wave_grid(n, 4)), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, A);
       HIP_TRY(hipGetLastError());
       return BRL_OK;
     }
@@ -2335,10 +2380,18 @@ static int lin16_store_mode() {
 static unsigned long long *g_lin16_dbg = nullptr;
 extern "C" void brl_lin16_set_dbg(void *p) { g_lin16_dbg = (unsigned long long *)p; }
 #endif
-extern "C" int brl_linear_act(brl_handle *h, const void *x, int64_t ldx, const void *w, int64_t ldw, const float *bias, void *y,
-                            int64_t ldy, int64_t m, int n_out, int k, int relu, int fmt, void *stream) {
+static int linear_act_impl(brl_handle *h, const void *x, int64_t ldx, const void *w, int64_t ldw, const float *bias, void *y,
+                           int64_t ldy, int64_t m, int n_out, int k, int relu, int fmt, const void *head_w, int64_t ld_head_w,
+                           int n_heads, float *head_part, int64_t head_part_ld, int64_t head_part_stride, void *stream) {
   COMMON(h, m);
-  NEED(x && w && y, "NULL x / w / y");
+  NEED(x && w && (y || head_part), "NULL x / w / y");
+  if (head_part) {
+    NEED(head_w && n_heads >= 1 && n_heads <= 48 && ld_head_w >= n_out && ld_head_w % 8 == 0 && (((uintptr_t)head_w) & 15) == 0,
+         "head_w / n_heads (<= 48) / ld_head_w");
+    NEED(head_part_ld >= ((n_heads + 3) & ~3) && head_part_ld % 4 == 0 && head_part_stride >= m * head_part_ld && head_part_stride % 4 == 0
+         && (((uintptr_t)head_part) & 15) == 0, "head_part (16-byte aligned) / head_part_ld (% 4, >= n_heads rounded up to 4) / head_part_stride");
+  }
+  if (!y) ldy = n_out;
   NEED(fmt == 1 || fmt == 2, "fmt (1 = bf16, 2 = fp16)");
   NEED(n_out > 0 && n_out % lin16::BN == 0, "n_out % 128");
   NEED(k >= 8 && k % 8 == 0, "k % 8");
@@ -2355,6 +2408,8 @@ extern "C" int brl_linear_act(brl_handle *h, const void *x, int64_t ldx, const v
   A.y = (uint16_t *)y; A.ldy = ldy;
   A.M = (int)m; A.N = n_out; A.K = k;
   A.relu = relu;
+  A.head_w = (const uint16_t *)head_w; A.ld_head_w = ld_head_w; A.n_heads = n_heads;
+  A.head_part = head_part; A.head_part_ld = head_part_ld; A.head_part_stride = head_part_stride;
   A.store_mode = lin16_store_mode();
 #ifdef LIN16_TIMING
   A.dbg = g_lin16_dbg;
@@ -2364,6 +2419,21 @@ extern "C" int brl_linear_act(brl_handle *h, const void *x, int64_t ldx, const v
   else hipLaunchKernelGGL(lin16::k_linear16<2>, dim3(tiles), dim3(lin16::THREADS), lin16::LDS_BYTES, (hipStream_t)stream, A);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
+}
+
+extern "C" int brl_linear_act(brl_handle *h, const void *x, int64_t ldx, const void *w, int64_t ldw, const float *bias, void *y,
+                            int64_t ldy, int64_t m, int n_out, int k, int relu, int fmt, void *stream) {
+  NEED(y != nullptr, "NULL y");
+  return linear_act_impl(h, x, ldx, w, ldw, bias, y, ldy, m, n_out, k, relu, fmt, nullptr, 0, 0, nullptr, 0, 0, stream);
+}
+
+extern "C" int brl_linear_act_heads(brl_handle *h, const void *x, int64_t ldx, const void *w, int64_t ldw, const float *bias,
+                                  void *y, int64_t ldy, int64_t m, int n_out, int k, int relu, int fmt, const void *head_w,
+                                  int64_t ld_head_w, int n_heads, float *head_part, int64_t head_part_ld,
+                                  int64_t head_part_stride, void *stream) {
+  NEED(head_part != nullptr, "NULL head_part");
+  return linear_act_impl(h, x, ldx, w, ldw, bias, y, ldy, m, n_out, k, relu, fmt, head_w, ld_head_w, n_heads, head_part,
+                         head_part_ld, head_part_stride, stream);
 }
 
 extern "C" int brl_gae(brl_handle *h, const uint8_t *done, const float *value, const float *reward,

@@ -28,7 +28,8 @@ constexpr int B_BYTES = BN * BK * 2;               // the W tile (16 KB)
 constexpr int STAGE_BYTES = A_BYTES + B_BYTES;     // 48 KB
 constexpr int LDS_BYTES = STAGES * STAGE_BYTES;    // 144 KB (+ 512 B of bias) of the CU's 160 KB
 constexpr int C_ROW_BYTES = BN * 2 + 16;           // output tile in LDS: 272-byte rows (conflict-free 8-byte writes, 16-byte aligned)
-static_assert(BM * C_ROW_BYTES <= LDS_BYTES, "the output tile reuses the stages");
+constexpr int HW_OFF = BM * C_ROW_BYTES;           // behind it: the tile's slice of the head weights, 48 rows of the same stride
+static_assert(HW_OFF + 48 * C_ROW_BYTES <= LDS_BYTES, "the output tile and the head weights reuse the stages");
 
 typedef short b16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -48,12 +49,18 @@ struct Args {
   int M, N, K;         // N % 128 == 0, K % 8 == 0, ldx / ldw / ldy % 8 == 0
   int relu;
   int store_mode;      // y stores: 0 = plain, 1 = non-temporal, 2 = write-through (sc0 sc1)
+  // the policy heads' share of this launch (brl_linear_act_heads), or head_part == NULL
+  const uint16_t *head_w;   // [n_heads][ld_head_w], same 16-bit type as y
+  int64_t ld_head_w;
+  int n_heads;              // <= 48
+  float *head_part;         // [N / 128][head_part_stride]: part p, row i, head j at p * head_part_stride + i * head_part_ld + j
+  int64_t head_part_ld, head_part_stride;
 #ifdef LIN16_TIMING
   unsigned long long *dbg;
 #endif
 };
 #ifdef LIN16_TIMING
-#define LIN16_STAMP(k) do { if (threadIdx.x == 0 && G.dbg) G.dbg[(size_t)blockIdx.x * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define LIN16_STAMP(k) do { if (threadIdx.x == 0 && G.dbg) G.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define LIN16_STAMP(k) do { } while (0)
 #endif
@@ -73,6 +80,13 @@ __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
 
 template <bool V>
 struct BoolTag { static constexpr bool value = V; };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int FMT>
+__device__ __forceinline__ f32x4 mma16(const b16x8 a, const b16x8 b, const f32x4 c) {
+  if (FMT == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
 
 template <int FMT>   // 1 = bf16, 2 = fp16
 __device__ __forceinline__ f32x16 mma(const b16x8 a, const b16x8 b, const f32x16 c) {
@@ -96,6 +110,21 @@ __device__ __forceinline__ void linear_tile(const Args &G, char *lds, float *bia
   const bool ktail = (G.K % BK) != 0;
 
   if (tid < BN) bias_s[tid] = G.bias ? G.bias[n0 + tid] : 0.0f;   // (read behind the barriers of the K loop)
+
+  // ---- the heads' share (brl_linear_act_heads): part[row][head] = sum over this tile's 128 columns of y[row][col] head_w[head][n0 +
+  // col].  The tile's slice of the head weights — 48 rows (n_heads <= 48, the rest zeros) x 256 B — is requested NOW, ahead of
+  // every DMA instruction (loads return in order: the counted vmcnt waits below still mean what they say), one or two 16-byte
+  // pieces per thread; it goes to LDS behind the K loop.  (Measured: every wave fetching its own operands in the epilogue cost
+  // 5 k cycles — 2048 waves after the same 80 KB.)
+  const bool heads = G.head_part != nullptr;
+  uint4 hwv[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+  if (heads) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int hrow = (tid >> 4) + 32 * u;   // 0..63; rows >= 48 are not kept
+      if (hrow < G.n_heads) hwv[u] = *reinterpret_cast<const uint4 *>(G.head_w + (int64_t)hrow * G.ld_head_w + n0 + 8 * (tid & 15));
+    }
+  }
 
   // ---- staging: a chunk is 48 DMA instructions of 1 KB = 8 rows x 128 B; wave w issues x rows 32 w .. 32 w + 31 (4) and
   // W rows 16 w .. 16 w + 15 (2).  LDS slot (row, p) holds the row's logical 16-byte piece p ^ ((row >> 1) & 7).
@@ -270,6 +299,14 @@ __device__ __forceinline__ void linear_tile(const Args &G, char *lds, float *bia
   // ---- epilogue.  Accumulator register r of lane (i, h) of block (mb, nb) = y[row 64 wm + 32 mb + i][column 64 wn + 32 nb +
   // 8 (r >> 2) + 4 h + (r & 3)]: four consecutive columns per register group -> one 8-byte LDS write
   __syncthreads();   // every wave is done with the stages (its last fragments are in registers; no DMA is in flight)
+  LIN16_STAMP(5);
+  if (heads) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int hrow = (tid >> 4) + 32 * u;
+      if (hrow < 48) *reinterpret_cast<uint4 *>(lds + HW_OFF + hrow * C_ROW_BYTES + 16 * (tid & 15)) = hwv[u];
+    }
+  }
   const float floor_v = G.relu ? 0.0f : -__builtin_inff();
 #pragma unroll
   for (int mb = 0; mb < 2; mb++) {
@@ -293,8 +330,10 @@ __device__ __forceinline__ void linear_tile(const Args &G, char *lds, float *bia
     }
   }
   __syncthreads();
+  LIN16_STAMP(6);
 #pragma unroll
   for (int it = 0; it < (BM * BN * 2) / (THREADS * 16); it++) {
+    if (G.y == nullptr) break;
     const int idx = it * THREADS + tid, row = idx >> 4, ch = idx & 15;
     const uint4 v = *reinterpret_cast<const uint4 *>(lds + row * C_ROW_BYTES + ch * 16);
     if ((LIN16_EXP & 8) && G.M > 0) continue;
@@ -305,6 +344,44 @@ __device__ __forceinline__ void linear_tile(const Args &G, char *lds, float *bia
       if (G.store_mode == 1) __builtin_nontemporal_store(d, dst);
       else if (G.store_mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(d) : "memory");
       else *dst = d;
+    }
+  }
+  LIN16_STAMP(4);
+  if (heads) {
+    // y as it stands in LDS (rounded to 16 bits — what a separate head product would read back).  Wave w: tile rows 32 w .. 32 w + 31 =
+    // two 16-row MFMA tiles x three 16-head blocks x four 32-deep steps of v_mfma_f32_16x16x32, formed transposed (A = head
+    // 16 nb + r, B = y row r, K pieces 32 ks + 8 kq): a lane ends up with four consecutive heads of one row = one 16-byte store
+    const int r = lane & 15, kq = lane >> 4, rq = lane >> 4;
+    float *part = G.head_part + (int64_t)tn * G.head_part_stride;
+    b16x8 hb[3][4];
+#pragma unroll
+    for (int nb = 0; nb < 3; nb++)
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++)
+        hb[nb][ks] = *reinterpret_cast<const b16x8 *>(lds + HW_OFF + (16 * nb + r) * C_ROW_BYTES + 64 * ks + 16 * kq);
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++) {
+      const char *ya = lds + (32 * w + 16 * rb + r) * C_ROW_BYTES + 16 * kq;
+      f32x4 hacc[3];
+#pragma unroll
+      for (int nb = 0; nb < 3; nb++) hacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const b16x8 yv = *reinterpret_cast<const b16x8 *>(ya + 64 * ks);
+#pragma unroll
+        for (int nb = 0; nb < 3; nb++) hacc[nb] = mma16<FMT>(hb[nb][ks], yv, hacc[nb]);
+      }
+      // accumulator register q of lane (r, rq): head 16 nb + 4 rq + q of tile row r (heads beyond n_heads: exact zeros)
+      const int m = m0 + 32 * w + 16 * rb + r;
+#pragma unroll
+      for (int nb = 0; nb < 3; nb++) {
+        const int n = 16 * nb + 4 * rq;
+        if (n < G.n_heads && m < G.M) {   // write-through like y: no dirty line is left for the end of the launch to write back
+          f32x4 *dst = reinterpret_cast<f32x4 *>(part + (int64_t)m * G.head_part_ld + n);
+          if (G.store_mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(hacc[nb]) : "memory");
+          else *dst = hacc[nb];
+        }
+      }
     }
   }
   LIN16_STAMP(3);

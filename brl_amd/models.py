@@ -70,10 +70,12 @@ class InferenceSnapshot:
     critic heads as one 39-row GEMM.  Build one per rollout / evaluation call — it does not follow later weight
     updates.  ``make`` returns None for architectures it does not cover (callers fall back to ``module(x)``)."""
 
-    def __init__(self, module: "ActorCritic", dtype=None, env=None):
-        # env: a BridgeBidding whose library converts the 0/1 observation bytes to `dtype` (brl_obs_cast: 3 us instead of
-        # 15 us of GPU time per forward, but a slower launch than torch's .to(): only worth it in hipGraph replays)
+    def __init__(self, module: "ActorCritic", dtype=None, env=None, own_cast=True):
+        # env: a BridgeBidding whose library runs the 16-bit hidden layers (brl_linear_act) and — own_cast — converts the 0/1
+        # observation bytes to `dtype` (brl_obs_cast: 3 us instead of 15 us of GPU time per forward, but a slower launch than
+        # torch's .to(): only worth it in hipGraph replays)
         self.env = env
+        self.own_cast = bool(own_cast)
         self.dtype = dtype or torch.float32
         dt = self.dtype
         self.body = [(lin.weight.detach().to(dt).t().contiguous(), lin.bias.detach().to(dt)) for lin in module.body]
@@ -110,15 +112,15 @@ class InferenceSnapshot:
                 b.copy_(lin.bias.detach().to(self.dtype))
 
     @staticmethod
-    def make(module, dtype=None, env=None):
+    def make(module, dtype=None, env=None, own_cast=True):
         if not str(getattr(module, "model", "")).startswith("DeepMind") or module.act is not torch.relu:
             return None
-        return InferenceSnapshot(module, dtype, env)
+        return InferenceSnapshot(module, dtype, env, own_cast)
 
     _FMT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
     def _input(self, obs):
-        if self.env is not None and obs.dtype in (torch.bool, torch.uint8) and obs.is_cuda and obs.is_contiguous() \
+        if self.env is not None and self.own_cast and obs.dtype in (torch.bool, torch.uint8) and obs.is_cuda and obs.is_contiguous() \
                 and self.dtype in self._FMT:
             from . import _capi
             from .bridge_bidding import _stream
@@ -144,6 +146,34 @@ class InferenceSnapshot:
         for w, b in self.body:
             x = torch._addmm_activation(b, x, w, use_gelu=False) if fused else torch.addmm(b, x, w).relu_()
         return x
+
+    HEAD_PART_LD = 40
+
+    def head_parts(self, obs, x=None):
+        """obs -> the heads as PARTIAL products f32 [hidden / 128, n, 40] (brl_linear_act_heads: the last hidden layer multiplies
+        each of its 128-column tiles with the head weights while it holds it, and is itself never written to memory);
+        ``brl_policy_step_ex`` adds the parts and the bias (brl_macro_ext.head_part).  None when the library's own layer kernel
+        does not apply (fp32, no handle, other widths): callers use ``hidden`` / ``heads``."""
+        if self.body_nk is None or os.environ.get("BRL_HEAD_PARTS", "1") == "0":
+            return None
+        if x is None:
+            x = self._input(obs)
+        if not (x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.shape[0] > 0):
+            return None
+        from . import _capi
+        from .bridge_bidding import _stream
+        L, fmt, st, n = _capi.lib(), self._FMT[self.dtype], _stream(), x.shape[0]
+        for w, b in self.body_nk[:-1]:
+            y = torch.empty((n, w.shape[0]), dtype=self.dtype, device=x.device)
+            _capi.check(L.brl_linear_act(self.env._h, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), b.data_ptr(),
+                                         y.data_ptr(), y.stride(0), n, w.shape[0], w.shape[1], 1, fmt, st))
+            x = y
+        w, b = self.body_nk[-1]
+        parts = torch.empty((w.shape[0] // 128, n, self.HEAD_PART_LD), dtype=torch.float32, device=x.device)
+        _capi.check(L.brl_linear_act_heads(self.env._h, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), b.data_ptr(), None, 0,
+                                           n, w.shape[0], w.shape[1], 1, fmt, self.head_wt.data_ptr(), self.head_wt.stride(0),
+                                           self.head_wt.shape[0], parts.data_ptr(), parts.stride(1), parts.stride(0), st))
+        return parts
 
     def hidden(self, obs, x=None):
         """obs -> the last hidden layer's output [n, hidden] in ``self.dtype`` (what the heads are applied to)"""

@@ -168,9 +168,10 @@ class _PolicyRollout:
             else:  # weights are re-read INTO the tensors whose addresses the graphs hold
                 self.snap_actor.refresh(params)
                 self.snap_opp.refresh(opp_params)
-        else:  # eager: host-bound, torch's own cast launches faster than brl_obs_cast
-            self.snap_actor = InferenceSnapshot.make(params, self.infer_dtype)
-            self.snap_opp = self.snap_actor if opp_params is params else InferenceSnapshot.make(opp_params, self.infer_dtype)
+        else:  # eager: host-bound, torch's own cast launches faster than brl_obs_cast (same layer kernels as the replayed form)
+            self.snap_actor = InferenceSnapshot.make(params, self.infer_dtype, self.env, own_cast=False)
+            self.snap_opp = self.snap_actor if opp_params is params \
+                else InferenceSnapshot.make(opp_params, self.infer_dtype, self.env, own_cast=False)
         self.params, self.opp_params = params, opp_params
 
     _FMT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
@@ -183,7 +184,16 @@ class _PolicyRollout:
             and os.environ.get("BRL_TABLES_PER_WAVE", "4") == "4"
         return snap if ok else None
 
+    def _heads_input(self, snap, obs, x):
+        """what the step kernel forms the heads from: partial products of the last hidden layer's launch (the library's own
+        layer kernel) or, failing that, the last hidden layer itself"""
+        parts = snap.head_parts(obs, x)
+        return parts if parts is not None else snap.hidden(obs, x)
+
     def _head_ext(self, snap, h, **kw):
+        if h.dtype == torch.float32:   # [parts, n, ld] partial products (models.InferenceSnapshot.head_parts)
+            return _capi.MacroExt(head_part=h.data_ptr(), head_part_stride=h.stride(0), head_part_ld=h.stride(1),
+                                  head_nparts=h.shape[0], head_b=snap.head_bf.data_ptr(), **kw)
         return _capi.MacroExt(head_h=h.data_ptr(), head_ldh=h.stride(0), head_w=snap.head_wt.data_ptr(), head_b=snap.head_bf.data_ptr(),
                               head_hidden=h.shape[1], head_fmt=self._FMT[h.dtype], **kw)
 
@@ -215,7 +225,7 @@ class _PolicyRollout:
         mode1 = SAMPLE if self.masked else SAMPLE | UNMASKED
         snap = self._fused_heads(False)
         if snap is not None:   # the step kernel forms logits + value from the last hidden layer itself (no N = 39 GEMM)
-            h = snap.hidden(traj.obs[t], None if t == 0 else self.xin)
+            h = self._heads_input(snap, traj.obs[t], None if t == 0 else self.xin)
             policy_step(env, packed, packed, None, mode1, 4 * t, True, action=traj.action[t], log_prob=traj.log_prob[t],
                         rewards_acc=racc, terminated_acc=tacc, draw_base=self.draw,
                         ext=self._head_ext(snap, h, first=1, value_out=traj.value[t].data_ptr(), obs_cast=self.xin.data_ptr(),
@@ -242,7 +252,7 @@ class _PolicyRollout:
                 snap = self._fused_heads(is_opp)
                 if snap is not None:
                     lg = None
-                    hk = snap.hidden(None, self.xin)
+                    hk = self._heads_input(snap, None, self.xin)
                 else:
                     lg, _ = self._forward(is_opp, None, self.xin)  # (the observation comes as the cast the previous launch wrote)
             fin = k == 3

@@ -58,7 +58,7 @@ def policy_step(env: BridgeBidding, packed_in, packed_out, logits, mode: int, dr
     ``ext`` (a ``_capi.MacroExt``): the macro-step bookkeeping of src/roll_out.py:72-103 done by the same launch
     (``brl_policy_step_ex``)."""
     n = packed_in.shape[0]
-    if ext is not None and ext.head_h:   # the launch forms the logits itself from the last hidden layer (brl_macro_ext.head_h)
+    if ext is not None and (ext.head_h or ext.head_part):   # the launch forms the logits itself (brl_macro_ext.head_h / head_part)
         import ctypes as C
         check(_capi.lib().brl_policy_step_ex(env._h, ptr(packed_in), ptr(packed_out), n, None, NUM_ACTIONS, int(mode), ptr(draw_base),
                                              int(draw) & 0xFFFFFFFF, int(bool(autoreset)), ptr(action), ptr(log_prob), ptr(obs),

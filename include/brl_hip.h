@@ -211,6 +211,13 @@ typedef struct brl_macro_ext {
   const float *head_b;
   int32_t head_hidden;
   int32_t head_fmt;          /* 1 bf16, 2 fp16 */
+  /* head_part != NULL (instead of head_h): the heads arrive as PARTIAL products of brl_linear_act_heads — logits / value [i][j] =
+   * head_b[j] + sum over p < head_nparts, in order, of head_part[p * head_part_stride + i * head_part_ld + j] (float);
+   * head_part_ld >= 39.  Needs 4 tables per wave (the default). */
+  const float *head_part;
+  int64_t head_part_stride;
+  int32_t head_part_ld;
+  int32_t head_nparts;
 } brl_macro_ext;
 
 /* brl_policy_step_at + brl_macro_ext (ext may be NULL). */
@@ -232,6 +239,16 @@ int brl_obs_cast(brl_handle *h, const uint8_t *obs, int64_t n, void *out, int fm
  * (k = 480 is fine: nothing beyond column k of x or w is used); relu != 0 applies max(., 0); 16-byte aligned pointers. */
 int brl_linear_act(brl_handle *h, const void *x, int64_t ldx, const void *w, int64_t ldw, const float *bias, void *y,
                  int64_t ldy, int64_t m, int n_out, int k, int relu, int fmt, void *stream);
+/* The LAST hidden layer together with its share of the policy heads `actor(x), critic(x)` (src/models.py:30-33): as
+ * brl_linear_act, and every 128-column tile p of y is multiplied, while the launch still holds it (rounded to `fmt` like the y
+ * a separate head product would read), with columns 128 p .. 128 p + 127 of head_w [n_heads, ld_head_w] (same 16-bit type; n_heads
+ * <= 48: 38 actor rows + the critic row): head_part[p * head_part_stride + i * head_part_ld + j] (float) = that partial product,
+ * i < m, j < n_heads (head_part_ld % 4 == 0 and >= n_heads rounded up to a multiple of 4: the padding columns of a row may be
+ * written, with zeros).  brl_policy_step_ex (brl_macro_ext.head_part) adds the n_out / 128 parts and the bias.  y may be NULL: the
+ * layer's output is then not written at all. */
+int brl_linear_act_heads(brl_handle *h, const void *x, int64_t ldx, const void *w, int64_t ldw, const float *bias, void *y,
+                         int64_t ldy, int64_t m, int n_out, int k, int relu, int fmt, const void *head_w, int64_t ld_head_w,
+                         int n_heads, float *head_part, int64_t head_part_ld, int64_t head_part_stride, void *stream);
 
 /* calc_gae's reverse scan — src/gae.py:20-39.  done uint8 [T,n], value/reward float
  * [T,n], last_val float [n]; gamma_lambda = float32(gamma * gae_lambda). */

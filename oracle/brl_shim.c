@@ -290,6 +290,13 @@ int brl_linear_act(brl_handle *h, const void *x, int64_t ldx, const void *w, int
   (void)h; (void)x; (void)ldx; (void)w; (void)ldw; (void)bias; (void)y; (void)ldy; (void)m; (void)n_out; (void)k; (void)relu; (void)fmt; (void)s;
   NOT_HERE("brl_linear_act");
 }
+int brl_linear_act_heads(brl_handle *h, const void *x, int64_t ldx, const void *w, int64_t ldw, const float *bias, void *y,
+                         int64_t ldy, int64_t m, int n_out, int k, int relu, int fmt, const void *head_w, int64_t ld_head_w,
+                         int n_heads, float *head_part, int64_t head_part_ld, int64_t head_part_stride, void *s) {
+  (void)h; (void)x; (void)ldx; (void)w; (void)ldw; (void)bias; (void)y; (void)ldy; (void)m; (void)n_out; (void)k; (void)relu; (void)fmt;
+  (void)head_w; (void)ld_head_w; (void)n_heads; (void)head_part; (void)head_part_ld; (void)head_part_stride; (void)s;
+  NOT_HERE("brl_linear_act_heads");
+}
 int brl_eval_step(brl_handle *h, const uint64_t *si, uint64_t *so, int64_t n, const float *l1, int64_t s1, const float *l2,
                   int64_t s2, const brl_table_info *ta, const brl_table_info *tb, const brl_eval_stats *st, int bs,
                   float *cr, float *rs, int32_t *ao, uint8_t *o, uint8_t *m, float *r, uint8_t *t, int32_t *c, void *s) {

@@ -59,11 +59,22 @@ def main():
         bf = torch.zeros(1024, device=dev)
         y = torch.empty(M, 1024, device=dev, dtype=dt)
         nblk = (M + 255) // 256 * 8
-        dbg = torch.zeros(nblk, 4, dtype=torch.int64, device=dev)
+        dbg = torch.zeros(nblk, 8, dtype=torch.int64, device=dev)
+        hw = (torch.randn(39, 1024, device=dev) / 32).to(dt)
+        parts = torch.empty(8, M, 40, device=dev)
+        with_heads = "--heads" in sys.argv
+
+        def one():
+            if with_heads:
+                _capi.check(lib.brl_linear_act_heads(env._h, x.data_ptr(), 1024, w.data_ptr(), 1024, bf.data_ptr(), y.data_ptr(), 1024, M, 1024,
+                                                     1024, 1, 1, hw.data_ptr(), 1024, 39, parts.data_ptr(), 40, M * 40, _stream()))
+            else:
+                run(x, w, bf, y, 1, 1)
+
         for _ in range(50):
-            run(x, w, bf, y, 1, 1)
+            one()
         lib.brl_lin16_set_dbg(ctypes.c_void_p(dbg.data_ptr()))
-        run(x, w, bf, y, 1, 1)
+        one()
         torch.cuda.synchronize()
         lib.brl_lin16_set_dbg(ctypes.c_void_p(0))
         d = dbg.cpu().double()
@@ -71,10 +82,48 @@ def main():
         print("shader-clock cycles, mean over workgroups (min .. max): start after the first workgroup's start | prologue "
               "(first chunk in registers) | K loop | epilogue")
         print(f"  start {float((d[:, 0] - t0).mean()):.0f} ({float((d[:, 0] - t0).min()):.0f} .. {float((d[:, 0] - t0).max()):.0f})")
-        for a, name in ((1, "prologue"), (2, "K loop"), (3, "epilogue")):
-            v = d[:, a] - d[:, a - 1]
+        for a, b_, name in ((1, 0, "prologue"), (2, 1, "K loop"), (5, 2, "wait for the other waves"), (6, 5, "pack + LDS + barrier"),
+                            (4, 6, "y stores issued"), (3, 4, "heads' share")):
+            v = d[:, a] - d[:, b_]
             print(f"  {name:9s} {float(v.mean()):.0f} ({float(v.min()):.0f} .. {float(v.max()):.0f})")
         print(f"  whole launch: first start .. last end {float(d[:, 3].max() - t0):.0f}")
+        return
+
+    if "--heads" in sys.argv:   # the last hidden layer with the policy heads' share (brl_linear_act_heads) against the plain layer
+        dt = torch.bfloat16
+        x = (torch.rand(M, 1024, device=dev) * 2 - 1).to(dt)
+        w = (torch.randn(1024, 1024, device=dev) / 32).to(dt)
+        bf = torch.zeros(1024, device=dev)
+        hw = (torch.randn(39, 1024, device=dev) / 32).to(dt)
+        y = torch.empty(M, 1024, device=dev, dtype=dt)
+        parts = torch.empty(8, M, 40, device=dev)
+
+        def plain():
+            run(x, w, bf, y, 1, 1)
+
+        def heads(store):
+            _capi.check(lib.brl_linear_act_heads(env._h, x.data_ptr(), 1024, w.data_ptr(), 1024, bf.data_ptr(), y.data_ptr() if store else None,
+                                                 1024, M, 1024, 1024, 1, 1, hw.data_ptr(), 1024, 39, parts.data_ptr(), 40, M * 40, _stream()))
+
+        fs = (("plain layer", plain), ("+ heads, y stored", lambda: heads(True)), ("+ heads, y not stored", lambda: heads(False)))
+        for _, f in fs:
+            for _ in range(20):
+                f()
+        torch.cuda.synchronize()
+        res = {k: [] for k, _ in fs}
+        for rnd in range(5):
+            for name, f in fs:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(200):
+                    f()
+                e1.record()
+                torch.cuda.synchronize()
+                res[name].append(e0.elapsed_time(e1) * 1000 / 200)
+        for name, v in res.items():
+            v.sort()
+            print(f"M {M} N 1024 K 1024  {name:22s} median {v[2]:.2f} us  min {v[0]:.2f} us")
+        return
 
     # ---- timing: the four layers' shapes
     dt = torch.bfloat16

@@ -66,7 +66,7 @@ def test_macro_ext_layout_matches_header():
     kinds = {ctypes.c_int32: "int32_t", ctypes.c_int64: "int64_t", ctypes.c_float: "float", ctypes.c_void_p: "ptr"}
     got = [(n, kinds[t]) for n, t in _capi.MacroExt._fields_]
     assert got == want
-    assert ctypes.sizeof(_capi.MacroExt) == 128   # 88 + the in-kernel heads (3 pointers, ldh, hidden, fmt)
+    assert ctypes.sizeof(_capi.MacroExt) == 152   # 88 + the in-kernel heads (3 pointers, ldh, hidden, fmt) + the partial-product heads (pointer, stride, ld, nparts)
 
 
 def test_bad_arguments_are_reported_not_crashed(built_lib):

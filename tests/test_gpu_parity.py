@@ -662,6 +662,68 @@ def test_linear16_matches_float64_product(env, dt, fmt):
         run(xs[:, :516], ws[:, :516], None, ys[:, :256], 0)        # k % 8
 
 
+@pytest.mark.parametrize("dt,fmt", [(torch.bfloat16, 1), (torch.float16, 2)])
+def test_heads_inside_the_launches_match_given_logits(env, dt, fmt):
+    """The two ways a sub-step launch forms `actor(x), critic(x)` (src/models.py:30-33) itself, against the plain path:
+      brl_macro_ext.head_part — partial products written by the last hidden layer's launch (brl_linear_act_heads, with and
+        without the layer's own output being stored): parts + bias == the float64 product of the rounded layer output with the
+        head weights (fp32 accumulation tolerance), the layer output equals brl_linear_act's bit for bit, and a sub-step launch
+        on the parts == the same launch on logits summed on the host in the kernel's order (bit-identical action, log_prob,
+        value, state, observation);
+      brl_macro_ext.head_h — the heads formed from the stored layer output: same checks (logits to fp32 tolerance)."""
+    import ctypes as C
+    from brl_amd import _capi
+    from brl_amd.bridge_bidding import _stream
+    from brl_amd.utils import policy_step, SAMPLE
+    L, dev = _capi.lib(), env.device
+    g = torch.Generator(device=dev).manual_seed(21)
+    n, hid = 1000, 1024
+    st = env.init(23, num_envs=n)
+    x = (torch.rand(n, hid, device=dev, generator=g) * 2 - 1).to(dt)
+    w = (torch.randn(hid, hid, device=dev, generator=g) / hid ** 0.5 * 1.4).to(dt)
+    b = (torch.randn(hid, device=dev, generator=g) * 0.1).to(dt).float()
+    hw = (torch.randn(39, hid, device=dev, generator=g) / hid ** 0.5 * 3).to(dt)
+    hb = (torch.randn(39, device=dev, generator=g) * 0.1).to(dt).float()
+    y0 = torch.empty(n, hid, dtype=dt, device=dev)
+    _capi.check(L.brl_linear_act(env._h, x.data_ptr(), hid, w.data_ptr(), hid, b.data_ptr(), y0.data_ptr(), hid, n, hid, hid, 1, fmt, _stream()))
+    want = y0.double() @ hw.double().t() + hb.double()
+    for store_y in (True, False):
+        y = torch.zeros(n, hid, dtype=dt, device=dev)
+        parts = torch.full((hid // 128, n, 40), float("nan"), device=dev)
+        _capi.check(L.brl_linear_act_heads(env._h, x.data_ptr(), hid, w.data_ptr(), hid, b.data_ptr(), y.data_ptr() if store_y else None,
+                                           hid, n, hid, hid, 1, fmt, hw.data_ptr(), hid, 39, parts.data_ptr(), 40, n * 40, _stream()))
+        assert torch.equal(y.view(torch.int16), (y0 if store_y else torch.zeros_like(y0)).view(torch.int16))
+        assert not torch.isnan(parts[:, :, :39]).any() and float(parts[:, :, 39].abs().max()) == 0.0   # (padding column: zeros)
+        lg = hb.clone().expand(n, 39).contiguous()
+        for p_ in range(parts.shape[0]):
+            lg = lg + parts[p_, :, :39]          # the kernel's order
+        assert float((lg.double() - want).abs().max()) < 2e-4 * float(want.abs().max())
+    # ---- a sampled sub-step on the parts / on the stored layer output / on the logits themselves
+    outs = {}
+    for how in ("logits", "parts", "hidden"):
+        o = {"state": torch.empty_like(st.packed), "action": torch.empty(n, dtype=torch.int32, device=dev),
+             "logp": torch.empty(n, device=dev), "value": torch.empty(n, device=dev),
+             "obs": torch.empty(n, 480, dtype=torch.bool, device=dev)}
+        kw = dict(value_out=o["value"].data_ptr())
+        if how == "logits":
+            ext = _capi.MacroExt(value_in=lg[:, 38].data_ptr(), value_stride=lg.stride(0), **kw)
+            policy_step(env, st.packed, o["state"], lg[:, :38], SAMPLE, 7, False, action=o["action"], log_prob=o["logp"], obs=o["obs"], ext=ext)
+        elif how == "parts":
+            ext = _capi.MacroExt(head_part=parts.data_ptr(), head_part_stride=parts.stride(0), head_part_ld=40, head_nparts=parts.shape[0],
+                                 head_b=hb.data_ptr(), **kw)
+            policy_step(env, st.packed, o["state"], None, SAMPLE, 7, False, action=o["action"], log_prob=o["logp"], obs=o["obs"], ext=ext)
+        else:
+            ext = _capi.MacroExt(head_h=y0.data_ptr(), head_ldh=hid, head_w=hw.data_ptr(), head_b=hb.data_ptr(), head_hidden=hid,
+                                 head_fmt=fmt, **kw)
+            policy_step(env, st.packed, o["state"], None, SAMPLE, 7, False, action=o["action"], log_prob=o["logp"], obs=o["obs"], ext=ext)
+        outs[how] = o
+    for k in outs["logits"]:
+        assert torch.equal(outs["parts"][k], outs["logits"][k]), k
+    # the in-launch product sums in another order: same draws, logits equal to fp32 rounding -> almost every action agrees
+    assert float((outs["hidden"]["value"] - outs["logits"]["value"]).abs().max()) < 2e-4 * float(want.abs().max())
+    assert float((outs["hidden"]["action"] == outs["logits"]["action"]).float().mean()) > 0.995
+
+
 @pytest.mark.parametrize("dt", [None, "bf16"])
 def test_graphed_policy_rollout_matches_eager(env, dt):
     """config["graph_rollout"]: every macro-step replayed from a hipGraph (device-side draw index,
