@@ -583,7 +583,9 @@ def bench_secondary(torch, dev):
             "gemm_tflops": flop / t_roll / 1e12, "mfma_peak_tflops": peak, "mfma_frac": flop / t_roll / 1e12 / peak,
             "dtype": "fp32 inference (the reference's precision)" if dt is None else
                      "bf16 inference: NARROWER than the reference's fp32 — opt-in (inference_dtype), never the default",
-            "how": "hipGraph-replayed macro-steps: 4 forwards + 4 brl_policy_step_ex launches each (competitive mode)"}
+            "how": "hipGraph-replayed macro-steps: 4 forwards + 4 brl_policy_step_ex launches each (competitive mode)"
+                   + ("" if dt is None else "; hidden layers on the library's own bf16 kernel (brl_linear_act), the heads' share inside "
+                      "the last layer's launch (brl_linear_act_heads), summed by the sub-step launch")}
         if dt is None:
             cfg32, rs32, traj32 = cfg, box["rs"], box["traj"]
         del roll_out

@@ -6,13 +6,14 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_mb_gather" in r["Kernel_Name"]]
+# a step ends with k_adam_apply (whose extra workgroups gather the next minibatch): from the kernel behind one to the kernel behind the next
+idx = [i for i, r in enumerate(rows) if "k_adam_apply" in r["Kernel_Name"]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
-a, b = idx[k], idx[k + 1]
+a, b = idx[k] + 1, idx[k + 1] + 1
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = None
 print(f"{'kernel':58s} {'start us':>9s} {'dur us':>8s} {'gap us':>8s}")
-for r in rows[a:b + 1]:
+for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     name = re.sub(r"\(.*", "", r["Kernel_Name"])[:58]
     gap = "" if prev_end is None else f"{(s - prev_end) / 1e3:8.2f}"
