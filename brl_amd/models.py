@@ -67,8 +67,11 @@ class ActorCritic(nn.Module):
 class InferenceSnapshot:
     """Inference-only copy of a "DeepMind" ReLU ActorCritic (no autograd): weights transposed (and cast to `dtype`
     when given) ONCE, bias + ReLU in the GEMM epilogue (``torch._addmm_activation`` -> hipBLASLt), the actor and
-    critic heads as one 39-row GEMM.  Build one per rollout / evaluation call — it does not follow later weight
-    updates.  ``make`` returns None for architectures it does not cover (callers fall back to ``module(x)``)."""
+    critic heads as one 39-row GEMM.  With a 16-bit `dtype` and a library handle (`env`) the hidden layers run on the
+    library's own kernel instead (``brl_linear_act``) and ``head_parts`` lets the last layer's launch compute the heads'
+    share (``brl_linear_act_heads``).  Build one per rollout / evaluation call — it does not follow later weight
+    updates (``refresh`` re-reads them in place).  ``make`` returns None for architectures it does not cover (callers fall
+    back to ``module(x)``)."""
 
     def __init__(self, module: "ActorCritic", dtype=None, env=None, own_cast=True):
         # env: a BridgeBidding whose library runs the 16-bit hidden layers (brl_linear_act) and — own_cast — converts the 0/1
