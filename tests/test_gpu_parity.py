@@ -720,6 +720,19 @@ def test_heads_inside_the_launches_match_given_logits(env, dt, fmt):
         outs[how] = o
     for k in outs["logits"]:
         assert torch.equal(outs["parts"][k], outs["logits"][k]), k
+    # more than 8 parts (a wider last layer): the launch adds parts 8.. behind the first eight, in order
+    p12 = torch.randn(12, n, 40, device=dev, generator=g) * 0.5
+    lg12 = hb.clone().expand(n, 39).contiguous()
+    for p_ in range(12):
+        lg12 = lg12 + p12[p_, :, :39]
+    a12, a_ref = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
+    lp12, lp_ref = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    scratch = torch.empty_like(st.packed)
+    policy_step(env, st.packed, scratch, None, SAMPLE, 9, False, action=a12, log_prob=lp12,
+                ext=_capi.MacroExt(head_part=p12.data_ptr(), head_part_stride=p12.stride(0), head_part_ld=40, head_nparts=12,
+                                   head_b=hb.data_ptr()))
+    policy_step(env, st.packed, scratch, lg12[:, :38], SAMPLE, 9, False, action=a_ref, log_prob=lp_ref, ext=_capi.MacroExt())
+    assert torch.equal(a12, a_ref) and torch.equal(lp12, lp_ref)
     # the in-launch product sums in another order: same draws, logits equal to fp32 rounding -> almost every action agrees
     assert float((outs["hidden"]["value"] - outs["logits"]["value"]).abs().max()) < 2e-4 * float(want.abs().max())
     assert float((outs["hidden"]["action"] == outs["logits"]["action"]).float().mean()) > 0.995
