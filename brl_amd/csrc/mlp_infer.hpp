@@ -308,6 +308,8 @@ __device__ __forceinline__ void linear_tile(const Args &G, char *lds, float *bia
     }
   }
   const float floor_v = G.relu ? 0.0f : -__builtin_inff();
+  // Two halves (mb = 0: tile rows 64 wm + 0..31, mb = 1: + 32..63): the second half is packed while the first half's stores are
+  // on their way.  Raw barriers with lgkmcnt(0) only: __syncthreads() would also wait for those stores (vmcnt(0)).
 #pragma unroll
   for (int mb = 0; mb < 2; mb++) {
     const int row = wm * 64 + mb * 32 + i;
@@ -328,22 +330,25 @@ __device__ __forceinline__ void linear_tile(const Args &G, char *lds, float *bia
         *reinterpret_cast<uint2 *>(lds + row * C_ROW_BYTES + col * 2) = pk;
       }
     }
-  }
-  __syncthreads();
-  LIN16_STAMP(6);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (mb == 0) LIN16_STAMP(6);
+    if (G.y != nullptr && !((LIN16_EXP & 8) && G.M > 0)) {
 #pragma unroll
-  for (int it = 0; it < (BM * BN * 2) / (THREADS * 16); it++) {
-    if (G.y == nullptr) break;
-    const int idx = it * THREADS + tid, row = idx >> 4, ch = idx & 15;
-    const uint4 v = *reinterpret_cast<const uint4 *>(lds + row * C_ROW_BYTES + ch * 16);
-    if ((LIN16_EXP & 8) && G.M > 0) continue;
-    if (m0 + row < G.M) {
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      u32x4 *dst = reinterpret_cast<u32x4 *>(G.y + (int64_t)(m0 + row) * G.ldy + n0 + ch * 8);
-      const u32x4 d = {v.x, v.y, v.z, v.w};
-      if (G.store_mode == 1) __builtin_nontemporal_store(d, dst);
-      else if (G.store_mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(d) : "memory");
-      else *dst = d;
+      for (int it = 0; it < (BM * BN) / (THREADS * 16); it++) {   // this half: 128 rows x 16 pieces of 16 B
+        const int idx = it * THREADS + tid, r128 = idx >> 4, ch = idx & 15;
+        const int trow = (r128 >> 5) * 64 + mb * 32 + (r128 & 31);
+        const uint4 v = *reinterpret_cast<const uint4 *>(lds + trow * C_ROW_BYTES + ch * 16);
+        if (m0 + trow < G.M) {
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          u32x4 *dst = reinterpret_cast<u32x4 *>(G.y + (int64_t)(m0 + trow) * G.ldy + n0 + ch * 8);
+          const u32x4 d = {v.x, v.y, v.z, v.w};
+          if (G.store_mode == 1) __builtin_nontemporal_store(d, dst);
+          else if (G.store_mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(d) : "memory");
+          else *dst = d;
+        }
+      }
     }
   }
   LIN16_STAMP(4);
