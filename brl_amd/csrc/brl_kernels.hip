@@ -1387,8 +1387,18 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
     }
   }
   if (A.x.last && A.x.terminated_count) {                                                    // src/roll_out.py:85
+    // one atomic per WORKGROUP: every wave adding to the one address cost this launch 20 us at 8192 tables (2048 same-address
+    // atomics, ~10 ns each); callers that can, sum `done_out` afterwards instead (brl_amd/roll_out.py does)
+    __shared__ uint32_t tc_s[WAVES_PER_BLOCK];
     const uint64_t m = __ballot(tacc != 0u);
-    if (w.c.lane == 0 && m) atomicAdd(reinterpret_cast<unsigned long long *>(A.x.terminated_count), (unsigned long long)__popcll(m));
+    if (w.c.lane == 0) tc_s[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t c = 0;
+#pragma unroll
+      for (int k = 0; k < WAVES_PER_BLOCK; k++) c += tc_s[k];
+      if (c) atomicAdd(reinterpret_cast<unsigned long long *>(A.x.terminated_count), (unsigned long long)c);
+    }
   }
   wave_end<K>(w, t, A.state_out, A.n);
 }

@@ -99,6 +99,8 @@ class InferenceSnapshot:
 
     def refresh(self, module: "ActorCritic"):
         """Re-read the weights of `module` INTO the existing tensors (their addresses are baked into captured graphs)."""
+        if self.body_nk is not None:
+            return self._refresh16(module)
         for (w, b), lin in zip(self.body, module.body):
             w.copy_(lin.weight.detach().t())
             b.copy_(lin.bias.detach())
@@ -109,10 +111,22 @@ class InferenceSnapshot:
         self.head_b[k:].copy_(module.critic.bias.detach())
         self.head_wt.copy_(self.head_w.t())
         self.head_bf.copy_(self.head_b)
-        if self.body_nk is not None:
-            for (w, b), lin in zip(self.body_nk, module.body):
-                w.copy_(lin.weight.detach())
-                b.copy_(lin.bias.detach().to(self.dtype))
+
+    def _refresh16(self, module):
+        """`refresh` of the 16-bit layout: a handful of multi-tensor copies instead of ~30 cast launches per network and
+        rollout (contiguous -> contiguous; the transposed [in, out] copies of the library-GEMM path are rebuilt only if a
+        caller falls back to it)."""
+        k = self.n_actions
+        with torch.no_grad():
+            ws = [w for w, _ in self.body_nk] + [self.head_wt[:k], self.head_wt[k:]]
+            src = [lin.weight.detach() for lin in module.body] + [module.actor.weight.detach(), module.critic.weight.detach()]
+            torch._foreach_copy_(ws, src)
+            # biases: rounded to `dtype` first — the float copies hold the SAME values a 16-bit GEMM epilogue would add
+            b16 = [b for _, b in self.body] + [self.head_b[:k], self.head_b[k:]]
+            torch._foreach_copy_(b16, [lin.bias.detach() for lin in module.body] + [module.actor.bias.detach(), module.critic.bias.detach()])
+            torch._foreach_copy_([b for _, b in self.body_nk] + [self.head_bf], [b for _, b in self.body] + [self.head_b])
+            self.head_w.copy_(self.head_wt.t())
+        self._body_stale = True   # self.body's weights ([in, out]) no longer match: rebuilt on demand (_body)
 
     @staticmethod
     def make(module, dtype=None, env=None, own_cast=True):
@@ -145,6 +159,10 @@ class InferenceSnapshot:
                                            y.data_ptr(), y.stride(0), x.shape[0], w.shape[0], w.shape[1], 1, fmt, st))
                 x = y
             return x
+        if getattr(self, "_body_stale", False):   # (only after a 16-bit refresh, and only if this path is taken at all)
+            for (w, _), (wn, _) in zip(self.body, self.body_nk):
+                w.copy_(wn.t())
+            self._body_stale = False
         fused = hasattr(torch, "_addmm_activation")
         for w, b in self.body:
             x = torch._addmm_activation(b, x, w, use_gelu=False) if fused else torch.addmm(b, x, w).relu_()

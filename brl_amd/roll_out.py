@@ -128,7 +128,9 @@ class _PolicyRollout:
     calls are followed by the replays.  ``sub_actions`` [T,3,n] keeps the actions of sub-steps 2-4 (tests replay the
     whole rollout through the oracle)."""
 
-    def __init__(self, env, n, T, reward_scale, game_mode, masked, infer_dtype, actor_fp, opp_fp, static, fuse_heads=True):
+    def __init__(self, env, n, T, reward_scale, game_mode, masked, infer_dtype, actor_fp, opp_fp, static, fuse_heads=True,
+                 graph_steps=4):
+        self.graph_steps = max(1, int(graph_steps))
         self.env, self.n, self.T, self.reward_scale = env, n, T, reward_scale
         self.fuse_heads = bool(fuse_heads)
         self.game_mode, self.masked, self.infer_dtype, self.static = game_mode, masked, infer_dtype, static
@@ -260,7 +262,9 @@ class _PolicyRollout:
                 else MX(obs_cast=self.xin.data_ptr(), obs_fmt=fmt, in_fmt=self._FMT[lg.dtype])
             if fin:                                                     # G2 / G1 / :85 by the same launch
                 ext.last, ext.done_out, ext.reward_out = 1, traj.done[t].data_ptr(), traj.reward[t].data_ptr()
-                ext.actor, ext.reward_scale, ext.terminated_count = actor.data_ptr(), self.reward_scale, self.tc.data_ptr()
+                # (terminated_count: NOT through the launch — 2048 waves adding to one address cost the last sub-step 20 us of
+                #  its 31; `run` adds traj.done.sum() once per rollout instead: the same number, src/roll_out.py:85)
+                ext.actor, ext.reward_scale = actor.data_ptr(), self.reward_scale
             policy_step(env, packed, packed, lg, m, 4 * t + k, True, action=self.sub_actions[t, k - 1],
                         obs=obs_out if fin else None, mask=mask_out if fin else None, rewards_acc=racc,
                         terminated_acc=tacc, current_player=cur[(t + 1) & 1] if fin else None, draw_base=self.draw, ext=ext)
@@ -276,10 +280,11 @@ class _PolicyRollout:
         pool = torch.cuda.graph_pool_handle()
         self.graphs = []
         with torch.no_grad():
-            for t in range(self.T):
+            for t0 in range(0, self.T, self.graph_steps):   # (a replay boundary costs ~8 us of idle GPU: several scan steps per graph)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool):
-                    self._macro_step(t)
+                    for t in range(t0, min(t0 + self.graph_steps, self.T)):
+                        self._macro_step(t)
                 self.graphs.append(g)
 
     def _load(self, env_state, last_obs, terminated_count, rng):
@@ -311,6 +316,7 @@ class _PolicyRollout:
             else:
                 for t in range(T):
                     self._macro_step(t)
+            self.tc += self.traj.done.sum(dtype=torch.int64)   # terminated_count += envs with `done`, per scan step (src/roll_out.py:85)
             own = (lambda x: x.clone()) if self.static else (lambda x: x)  # static buffers are reused by the next call
             new_state = State(self.env, own(self.packed), {"observation": own(self.final_obs),
                                                            "legal_action_mask": own(self.final_mask),
@@ -353,7 +359,8 @@ def make_roll_out(config, env: BridgeBidding, actor_forward_pass, opp_forward_pa
         if eng is None:
             eng = engines[(n, static)] = _PolicyRollout(env, n, T, reward_scale, mode, masked, infer_dtype,
                                                         actor_forward_pass, opp_forward_pass, static,
-                                                        fuse_heads=config.get("fuse_heads", True))
+                                                        fuse_heads=config.get("fuse_heads", True),
+                                                        graph_steps=config.get("rollout_graph_steps", 4))
         out = eng.run(runner_state, opp_params)
         roll_out.sub_actions = eng.sub_actions
         return out
