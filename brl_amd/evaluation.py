@@ -10,7 +10,7 @@
 Every loop iteration is one or two (merged) GEMM forwards in PyTorch-ROCm plus ONE ``brl_eval_step`` launch: team selection,
 masked arg-max, the step log (illegal-action probability mass, step / pass / bid counters), ``duplicate_step`` and the
 return accumulators all happen in that kernel; the end-of-run histograms come from ``brl_eval_reduce`` as exact integer
-counts.  The loop condition ``~state.terminated.all()`` is read back every ``sync_every`` iterations (finished boards
+counts.  The loop condition ``~state.terminated.all()`` is watched without stalling the GPU (``_DoneWatch``; finished boards
 keep receiving no-op steps, G9, so overshooting changes nothing)."""
 from __future__ import annotations
 
@@ -101,9 +101,39 @@ class EvalStats:
         return p
 
 
+class _DoneWatch:
+    """The loop condition ``~state.terminated.all()`` (src/evaluation.py:120-122) without stalling the GPU and without running
+    far past the end: after every iteration the flag is reduced on the device and copied to pinned host memory behind an
+    event; before iteration i is launched the host waits for the flag of iteration i - DEPTH — the GPU is still busy with
+    iteration i - 1 meanwhile.  The loop stops at most DEPTH iterations after the last board finished (finished boards take
+    no-op calls, G9); a blocking read every 16 iterations idled the GPU for ~120 us per read and overshot by 8 iterations
+    (of ~35) on average."""
+    DEPTH, RING = 2, 4
+
+    def __init__(self, device):
+        self.host = torch.zeros(self.RING, dtype=torch.bool).pin_memory()
+        self.events = [torch.cuda.Event() for _ in range(self.RING)]
+
+    def post(self, i: int, terminated: torch.Tensor):
+        """after iteration i's launches: publish "every board is finished" """
+        k = i % self.RING
+        self.host[k:k + 1].copy_(terminated.all().reshape(1), non_blocking=True)
+        self.events[k].record()
+
+    def finished(self, i: int) -> bool:
+        """before iteration i's launches: had every board finished by iteration i - DEPTH?"""
+        j = i - self.DEPTH
+        if j < 0:
+            return False
+        k = j % self.RING
+        self.events[k].synchronize()
+        return bool(self.host[k])
+
+
 def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward, tables, stats, bid_set, cum_return,
                rewards_sum, sync_every, record_actions=None, record_logits=None):
-    """Runs ``brl_eval_step`` until every board is finished; ``state.packed`` is advanced in place."""
+    """Runs ``brl_eval_step`` until every board is finished; ``state.packed`` is advanced in place.  (``sync_every`` — how often
+    the loop condition used to be read back — is kept in the signatures and ignored: see ``_DoneWatch``.)"""
     n, dev = state.num_envs, env.device
     obs = state.observation
     term = torch.empty(n, dtype=torch.bool, device=dev)
@@ -120,7 +150,8 @@ def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward,
     # and one at the table switch.  Half the GEMM work per board.  (Recording runs — the tests' oracle replays — keep the
     # reference's lock-step loop.)
     alternate = (fwd2 is not fwd1) and record_actions is None and record_logits is None
-    while True:
+    watch = _DoneWatch(dev)
+    while not watch.finished(count):
         x = obs.to(torch.float32)
         nobs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=dev)
         if alternate:
@@ -132,9 +163,8 @@ def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward,
                 C.byref(ps) if ps is not None else None, int(bid_set),
                 ptr(cum_return), ptr(rewards_sum), ptr(action), ptr(nobs), None, None, ptr(term), None, _stream()))
             obs = nobs
+            watch.post(count, term)
             count += 1
-            if count % sync_every == 0 and bool(term.all()):
-                break
             continue
         l1 = fwd1(obs, x)
         l2 = fwd2(obs, x) if fwd2 is not fwd1 else l1   # G10: the reference evaluates both networks and selects
@@ -149,9 +179,8 @@ def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward,
         obs = nobs
         if record_actions is not None:
             record_actions.append(action.clone())
+        watch.post(count, term)
         count += 1
-        if count % sync_every == 0 and bool(term.all()):
-            break
     return State(env, packed, {"observation": obs, "terminated": term}), count
 
 
@@ -336,15 +365,15 @@ def make_simple_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_
             state = sh.init(eval_env, rng)
             R = torch.zeros(sh.n, dtype=torch.float32, device=eval_env.device)
             it = 0
-            while True:
+            watch = _DoneWatch(eval_env.device)
+            while not watch.finished(it):
                 actor = state.current_player.to(torch.int64)
                 logits, _ = actor_forward_pass.apply(actor_params, state.observation.to(torch.float32))
                 action = masked_mode(logits, state.legal_action_mask)
                 state = step_fn(state, action, it * 4)
                 R += state.rewards.gather(1, actor[:, None])[:, 0]   # src/evaluation.py:60
+                watch.post(it, state.terminated)
                 it += 1
-                if it % sync_every == 0 and bool(state.terminated.all()):
-                    break
         if sh.active:   # (scores are integers: the float64 sum over the ranks is exact)
             return (sh.allsum(R.to(torch.float64).sum().reshape(1))[0] / float(num_eval_envs)).to(torch.float32)
         return R.mean()
