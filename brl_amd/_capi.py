@@ -88,6 +88,8 @@ def lib() -> C.CDLL:
         "brl_policy_step_ex": [_vp, _vp, _vp, i64, _vp, i64, i32, _vp, u32, i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                C.POINTER(MacroExt), _vp],
         "brl_obs_cast": [_vp, _vp, i64, _vp, i32, _vp],
+        "brl_obs_cast_rows": [_vp, _vp, _vp, i64, _vp, i32, _vp],
+        "brl_live_index": [_vp, _vp, i64, _vp, _vp, _vp],
         "brl_linear_act_heads": [_vp, _vp, i64, _vp, i64, _vp, _vp, i64, i64, i32, i32, i32, i32, _vp, i64, i32, _vp, i64, i64, _vp],
         "brl_linear_act": [_vp, _vp, i64, _vp, i64, _vp, _vp, i64, i64, i32, i32, i32, i32, _vp],
         "brl_gae": [_vp, _vp, _vp, _vp, _vp, f32, f32, i32, i64, _vp, _vp, _vp],
@@ -129,7 +131,7 @@ def lib() -> C.CDLL:
 
 EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_destroy", "brl_set_rng",
            "brl_init_random", "brl_init_from_deals", "brl_step", "brl_observe", "brl_get_fields",
-           "brl_rollout_random", "brl_policy_step", "brl_policy_step_at", "brl_obs_cast", "brl_linear_act", "brl_linear_act_heads", "brl_gae", "brl_imp_reward", "brl_duplicate_step",
+           "brl_rollout_random", "brl_policy_step", "brl_policy_step_at", "brl_obs_cast", "brl_obs_cast_rows", "brl_live_index", "brl_linear_act", "brl_linear_act_heads", "brl_gae", "brl_imp_reward", "brl_duplicate_step",
            "brl_eval_step", "brl_eval_reduce", "brl_ppo_loss", "brl_ppo_stats", "brl_ppo_loss_heads", "brl_mb_gather",
            "brl_relu_bwd_colsum", "brl_adam_clip", "brl_bias_finalize", "brl_ppo_stats_at", "brl_policy_step_ex",
            "brl_eval_step_team", "brl_rollout_random_gae", "brl_ppo_heads_loss", "brl_ppo_heads_bwd", "brl_ppo_stats_gram",

@@ -2327,10 +2327,7 @@ extern "C" int brl_policy_step_ex(brl_handle *h, const uint64_t *state_in, uint6
 // observation bytes (0/1) -> the network's input dtype: 16 bytes in, 16 elements out per thread
 // (src/roll_out.py:75 `last_obs.astype(jnp.float32)`; torch's generic bool->bf16 copy takes 15 us for 3.9 MB)
 template <int FMT>  // 0: f32, 1: bf16 (0x3F80), 2: f16 (0x3C00)
-__global__ __launch_bounds__(256) void k_obs_cast(const uint4 *in, void *out, int64_t n16) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n16) return;
-  const uint4 v = in[i];
+__device__ __forceinline__ void obs_cast16(const uint4 v, void *out, int64_t i) {
   const uint32_t w[4] = {v.x, v.y, v.z, v.w};
   if (FMT == 0) {
     float4 *o = reinterpret_cast<float4 *>(out) + 4 * i;
@@ -2352,6 +2349,24 @@ __global__ __launch_bounds__(256) void k_obs_cast(const uint4 *in, void *out, in
   }
 }
 
+template <int FMT>
+__global__ __launch_bounds__(256) void k_obs_cast(const uint4 *in, void *out, int64_t n16) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n16) return;
+  obs_cast16<FMT>(in[i], out, i);
+}
+
+// the same for the rows rows[0..m) of `in` only (out row r = in row rows[r]): the forwards of an evaluator run on the boards
+// that are still playing
+template <int FMT>
+__global__ __launch_bounds__(256) void k_obs_cast_rows(const uint4 *in, const int64_t *rows, void *out, int64_t m16) {
+  constexpr int PER_ROW = BRL_OBS_SIZE / 16;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m16) return;
+  const int64_t r = i / PER_ROW;
+  obs_cast16<FMT>(in[rows[r] * PER_ROW + (i - r * PER_ROW)], out, i);
+}
+
 extern "C" int brl_obs_cast(brl_handle *h, const uint8_t *obs, int64_t n, void *out, int fmt, void *stream) {
   COMMON(h, n);
   NEED(obs && out, "NULL obs / out");
@@ -2361,6 +2376,54 @@ extern "C" int brl_obs_cast(brl_handle *h, const uint8_t *obs, int64_t n, void *
   if (fmt == 0) hipLaunchKernelGGL(k_obs_cast<0>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, out, n16);
   else if (fmt == 1) hipLaunchKernelGGL(k_obs_cast<1>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, out, n16);
   else hipLaunchKernelGGL(k_obs_cast<2>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, out, n16);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_obs_cast_rows(brl_handle *h, const uint8_t *obs, const int64_t *rows, int64_t m, void *out, int fmt,
+                                 void *stream) {
+  COMMON(h, m);
+  NEED(obs && rows && out, "NULL obs / rows / out");
+  NEED(fmt >= 0 && fmt <= 2, "fmt");
+  const int64_t m16 = m * (BRL_OBS_SIZE / 16);
+  const dim3 grid((unsigned)((m16 + 255) / 256)), block(256);
+  if (fmt == 0) hipLaunchKernelGGL(k_obs_cast_rows<0>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, rows, out, m16);
+  else if (fmt == 1) hipLaunchKernelGGL(k_obs_cast_rows<1>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, rows, out, m16);
+  else hipLaunchKernelGGL(k_obs_cast_rows<2>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, rows, out, m16);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+// The loop condition of the evaluators, `~state.terminated.all()` (src/evaluation.py:120-122), as data: how many boards are
+// finished, and the indices of the others in ascending order at the front of `live` (the entries behind them are left as they
+// are: the caller initialises the list with 0..n-1 once, so they stay valid board indices).  One workgroup: a thread counts
+// its run of boards, the runs' offsets come from a scan in LDS — deterministic order, no atomics.
+__global__ __launch_bounds__(1024) void k_live_index(const uint8_t *terminated, int64_t n, int64_t *live, int64_t *finished) {
+  __shared__ int64_t part[1024];
+  const int tid = (int)threadIdx.x;
+  const int64_t per = (n + 1023) / 1024, a = (int64_t)tid * per, b = (a + per < n) ? a + per : n;
+  int64_t c = 0;
+  for (int64_t i = a; i < b; i++) c += terminated[i] ? 0 : 1;
+  part[tid] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan
+    const int64_t v = (tid >= off) ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int64_t pos = part[tid] - c;
+  if (live != nullptr)
+    for (int64_t i = a; i < b; i++)
+      if (!terminated[i]) live[pos++] = i;
+  if (tid == 1023 && finished != nullptr) *finished = n - part[1023];
+}
+
+extern "C" int brl_live_index(brl_handle *h, const uint8_t *terminated, int64_t n, int64_t *live, int64_t *finished,
+                              void *stream) {
+  COMMON(h, n);
+  NEED(terminated && (live || finished), "NULL terminated / outputs");
+  hipLaunchKernelGGL(k_live_index, dim3(1), dim3(1024), 0, (hipStream_t)stream, terminated, n, live, finished);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

@@ -15,6 +15,7 @@ keep receiving no-op steps, G9, so overshooting changes nothing)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -103,31 +104,74 @@ class EvalStats:
 
 class _DoneWatch:
     """The loop condition ``~state.terminated.all()`` (src/evaluation.py:120-122) without stalling the GPU and without running
-    far past the end: after every iteration the flag is reduced on the device and copied to pinned host memory behind an
-    event; before iteration i is launched the host waits for the flag of iteration i - DEPTH — the GPU is still busy with
-    iteration i - 1 meanwhile.  The loop stops at most DEPTH iterations after the last board finished (finished boards take
-    no-op calls, G9); a blocking read every 16 iterations idled the GPU for ~120 us per read and overshot by 8 iterations
-    (of ~35) on average."""
+    far past the end: after every iteration the number of finished boards is reduced on the device and copied to pinned host
+    memory behind an event; before iteration i is launched the host waits for the count of iteration i - DEPTH — the GPU is
+    still busy with iteration i - 1 meanwhile.  The loop stops at most DEPTH iterations after the last board finished (finished
+    boards take no-op calls, G9); a blocking read every 16 iterations idled the GPU for ~120 us per read and overshot by 8
+    iterations (of ~35) on average.
+    ``compact``: the same launch also leaves the indices of the boards still playing (no host round trip), so that the
+    forwards can run on those rows only — boards only ever finish, so the list of iteration i - DEPTH
+    is a superset of the boards playing at iteration i."""
     DEPTH, RING = 2, 4
 
-    def __init__(self, device):
-        self.host = torch.zeros(self.RING, dtype=torch.bool).pin_memory()
+    def __init__(self, env, n, compact=False):
+        self.env, self.n = env, n
+        self.host = torch.zeros(self.RING, dtype=torch.int64).pin_memory()
+        self.dev = torch.zeros(self.RING, dtype=torch.int64, device=env.device)
         self.events = [torch.cuda.Event() for _ in range(self.RING)]
+        self.idx = None
+        if compact:   # (entries behind the live boards stay valid board indices: initialised with 0..n-1)
+            self.idx = [torch.arange(n, dtype=torch.int64, device=env.device) for _ in range(self.RING)]
 
     def post(self, i: int, terminated: torch.Tensor):
-        """after iteration i's launches: publish "every board is finished" """
+        """after iteration i's launches: publish how many boards are finished (and which are not) — ONE launch
+        (brl_live_index) + the copy to pinned memory"""
         k = i % self.RING
-        self.host[k:k + 1].copy_(terminated.all().reshape(1), non_blocking=True)
+        check(_capi.lib().brl_live_index(self.env._h, ptr(terminated), self.n, ptr(self.idx[k]) if self.idx is not None else None,
+                                         ptr(self.dev[k:k + 1]), _stream()))
+        self.host[k:k + 1].copy_(self.dev[k:k + 1], non_blocking=True)
         self.events[k].record()
 
-    def finished(self, i: int) -> bool:
-        """before iteration i's launches: had every board finished by iteration i - DEPTH?"""
+    def poll(self, i: int):
+        """before iteration i's launches: (finished boards, indices of the others first) as of iteration i - DEPTH, or None"""
         j = i - self.DEPTH
         if j < 0:
-            return False
+            return None
         k = j % self.RING
         self.events[k].synchronize()
-        return bool(self.host[k])
+        return int(self.host[k]), (self.idx[k] if self.idx is not None else None)
+
+    def finished(self, i: int) -> bool:
+        r = self.poll(i)
+        return r is not None and r[0] >= self.n
+
+
+class _ActiveRows:
+    """Forwards on the boards still playing only.  With 8192 boards and two DeepMind MLPs 53 % of the board-iterations of a
+    duplicate evaluation belong to boards that are already finished (the last boards end at iteration ~30, half are done by
+    iteration 16): their logits are never used (no-op calls, G9).  Rows to forward = the first `m` entries of `_DoneWatch`'s
+    index list (m = boards playing, rounded up to 256: the padding entries are valid board indices — at worst a board is
+    forwarded twice, with identical results), adopted whenever that shrinks the batch by a fifth."""
+
+    def __init__(self, n):
+        self.n, self.m, self.idx, self.full = n, n, None, None
+
+    def update(self, polled):
+        if polled is None or polled[1] is None:
+            return
+        live = self.n - polled[0]
+        m = min(self.n, max(256, (live + 255) // 256 * 256))
+        if m <= 0.8 * self.m:
+            self.m, self.idx = m, polled[1][:m]
+
+    def forward(self, fwd, obs, env):
+        if self.idx is None or self.full is None:
+            self.full = fwd(obs, obs.to(torch.float32))
+            return self.full
+        x = torch.empty((self.m, OBS_SIZE), dtype=torch.float32, device=obs.device)
+        check(_capi.lib().brl_obs_cast_rows(env._h, ptr(obs), ptr(self.idx), self.m, ptr(x), 0, _stream()))   # gather + astype
+        self.full.index_copy_(0, self.idx, fwd(None, x))   # (rows of finished boards keep their last logits: never used)
+        return self.full
 
 
 def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward, tables, stats, bid_set, cum_return,
@@ -150,13 +194,18 @@ def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward,
     # and one at the table switch.  Half the GEMM work per board.  (Recording runs — the tests' oracle replays — keep the
     # reference's lock-step loop.)
     alternate = (fwd2 is not fwd1) and record_actions is None and record_logits is None
-    watch = _DoneWatch(dev)
-    while not watch.finished(count):
-        x = obs.to(torch.float32)
+    compact = record_actions is None and record_logits is None and os.environ.get("BRL_EVAL_COMPACT", "1") != "0"
+    watch = _DoneWatch(env, n, compact)
+    rows = [_ActiveRows(n), _ActiveRows(n)]   # (one logits buffer per team: their forwards alternate)
+    while True:
+        polled = watch.poll(count)
+        if polled is not None and polled[0] >= n:
+            break
         nobs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=dev)
         if alternate:
             team = count & 1
-            lg = (fwd2 if team else fwd1)(obs, x)
+            rows[team].update(polled)
+            lg = rows[team].forward(fwd2 if team else fwd1, obs, env)
             check(_capi.lib().brl_eval_step_team(
                 env._h, ptr(packed), ptr(packed), n, lg.data_ptr(), lg.stride(0), team,
                 C.byref(pa) if pa is not None else None, C.byref(pb) if pb is not None else None,
@@ -166,8 +215,15 @@ def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward,
             watch.post(count, term)
             count += 1
             continue
-        l1 = fwd1(obs, x)
-        l2 = fwd2(obs, x) if fwd2 is not fwd1 else l1   # G10: the reference evaluates both networks and selects
+        if compact:
+            rows[0].update(polled)
+            rows[1].update(polled)
+            l1 = rows[0].forward(fwd1, obs, env)
+            l2 = rows[1].forward(fwd2, obs, env) if fwd2 is not fwd1 else l1
+        else:
+            x = obs.to(torch.float32)
+            l1 = fwd1(obs, x)
+            l2 = fwd2(obs, x) if fwd2 is not fwd1 else l1   # G10: the reference evaluates both networks and selects
         if record_logits is not None:
             team1 = (State(env, packed).current_player < 2)[:, None]
             record_logits.append(torch.where(team1, l1[:, :NUM_ACTIONS], l2[:, :NUM_ACTIONS]).clone())
@@ -365,7 +421,7 @@ def make_simple_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_
             state = sh.init(eval_env, rng)
             R = torch.zeros(sh.n, dtype=torch.float32, device=eval_env.device)
             it = 0
-            watch = _DoneWatch(eval_env.device)
+            watch = _DoneWatch(eval_env, sh.n)
             while not watch.finished(it):
                 actor = state.current_player.to(torch.int64)
                 logits, _ = actor_forward_pass.apply(actor_params, state.observation.to(torch.float32))

@@ -230,6 +230,13 @@ int brl_policy_step_ex(brl_handle *h, const uint64_t *state_in, uint64_t *state_
 /* Observation bytes -> network input: `last_obs.astype(jnp.float32)` (src/roll_out.py:75) and its low-precision
  * variants.  obs uint8 [n,480] (0/1); out [n,480] of float (fmt 0), bf16 (fmt 1) or fp16 (fmt 2). */
 int brl_obs_cast(brl_handle *h, const uint8_t *obs, int64_t n, void *out, int fmt, void *stream);
+/* The same for the rows `rows[0..m)` of obs only: out [m,480], out row r = obs row rows[r] (an evaluator forwards the boards
+ * that are still playing). */
+int brl_obs_cast_rows(brl_handle *h, const uint8_t *obs, const int64_t *rows, int64_t m, void *out, int fmt, void *stream);
+/* The evaluators' loop condition `~state.terminated.all()` (src/evaluation.py:120-122, 153-178) as data, without a host round
+ * trip: *finished = number of boards with terminated != 0; live[0 .. n - *finished) = the indices of the others, ascending
+ * (entries behind them are left untouched).  Either output may be NULL. */
+int brl_live_index(brl_handle *h, const uint8_t *terminated, int64_t n, int64_t *live, int64_t *finished, void *stream);
 
 /* One hidden layer of the policy network in 16-bit inference precision — `hk.Linear(1024)` + `jax.nn.relu`,
  * src/models.py:23-33, as called per env.step by src/roll_out.py:73-84 / src/evaluation.py:52-60:

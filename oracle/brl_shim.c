@@ -297,6 +297,14 @@ int brl_linear_act_heads(brl_handle *h, const void *x, int64_t ldx, const void *
   (void)head_w; (void)ld_head_w; (void)n_heads; (void)head_part; (void)head_part_ld; (void)head_part_stride; (void)s;
   NOT_HERE("brl_linear_act_heads");
 }
+int brl_obs_cast_rows(brl_handle *h, const uint8_t *obs, const int64_t *rows, int64_t m, void *out, int fmt, void *s) {
+  (void)h; (void)obs; (void)rows; (void)m; (void)out; (void)fmt; (void)s;
+  NOT_HERE("brl_obs_cast_rows");
+}
+int brl_live_index(brl_handle *h, const uint8_t *terminated, int64_t n, int64_t *live, int64_t *finished, void *s) {
+  (void)h; (void)terminated; (void)n; (void)live; (void)finished; (void)s;
+  NOT_HERE("brl_live_index");
+}
 int brl_eval_step(brl_handle *h, const uint64_t *si, uint64_t *so, int64_t n, const float *l1, int64_t s1, const float *l2,
                   int64_t s2, const brl_table_info *ta, const brl_table_info *tb, const brl_eval_stats *st, int bs,
                   float *cr, float *rs, int32_t *ao, uint8_t *o, uint8_t *m, float *r, uint8_t *t, int32_t *c, void *s) {

@@ -738,6 +738,54 @@ def test_heads_inside_the_launches_match_given_logits(env, dt, fmt):
     assert float((outs["hidden"]["action"] == outs["logits"]["action"]).float().mean()) > 0.995
 
 
+def test_live_index_and_row_cast(env):
+    """brl_live_index (the evaluators' loop condition as data) and brl_obs_cast_rows (gather + astype of the boards still playing)
+    against torch: counts, ascending live indices, untouched tail; ragged n; every format."""
+    from brl_amd import _capi
+    from brl_amd.bridge_bidding import _stream
+    L, dev = _capi.lib(), env.device
+    g = torch.Generator(device=dev).manual_seed(3)
+    for n in (1, 5, 1023, 1024, 1025, 8192, 10000):
+        for p in (0.0, 0.3, 0.97, 1.0):
+            term = torch.rand(n, device=dev, generator=g) < p
+            live = torch.full((n,), -7, dtype=torch.int64, device=dev)
+            fin = torch.zeros(1, dtype=torch.int64, device=dev)
+            _capi.check(L.brl_live_index(env._h, term.data_ptr(), n, live.data_ptr(), fin.data_ptr(), _stream()))
+            want = (~term).nonzero().squeeze(1)
+            assert int(fin) == int(term.sum())
+            assert torch.equal(live[:want.numel()], want) and bool((live[want.numel():] == -7).all())
+            _capi.check(L.brl_live_index(env._h, term.data_ptr(), n, None, fin.data_ptr(), _stream()))   # count only
+            assert int(fin) == int(term.sum())
+    st = env.init(5, num_envs=3000)
+    obs = st.observation
+    rows = torch.randint(0, 3000, (777,), device=dev, generator=g)
+    for fmt, dt in ((0, torch.float32), (1, torch.bfloat16), (2, torch.float16)):
+        out = torch.empty((777, 480), dtype=dt, device=dev)
+        _capi.check(L.brl_obs_cast_rows(env._h, obs.data_ptr(), rows.data_ptr(), 777, out.data_ptr(), fmt, _stream()))
+        assert torch.equal(out, obs[rows].to(dt))
+
+
+def test_evaluators_on_live_rows_equal_full_batches(env, monkeypatch):
+    """The evaluators forward only the boards still playing (brl_amd/evaluation.py::_ActiveRows): every returned number equals
+    the run that forwards all boards every iteration."""
+    from brl_amd.evaluation import make_simple_duplicate_evaluate, make_evaluate, make_evaluate_log
+    from brl_amd.models import make_forward_pass
+    fp = make_forward_pass("relu", "DeepMind")
+    p1, p2 = fp.init(0, device="cuda"), fp.init(1, device="cuda")
+    n = 3000
+    res = {}
+    for compact in ("1", "0"):
+        monkeypatch.setenv("BRL_EVAL_COMPACT", compact)
+        dup = make_simple_duplicate_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", n)
+        full = make_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", p2, n, duplicate=True)
+        def flat(x):
+            if isinstance(x, (tuple, list)):
+                return [v for y in x for v in flat(y)]
+            return [float(v) for v in torch.as_tensor(x).double().reshape(-1)]
+        res[compact] = (flat(dup(p1, p2, 3)), make_evaluate_log(full(p1, 4)[0]))
+    assert res["1"] == res["0"]
+
+
 @pytest.mark.parametrize("dt", [None, "bf16"])
 def test_graphed_policy_rollout_matches_eager(env, dt):
     """config["graph_rollout"]: every macro-step replayed from a hipGraph (device-side draw index,
