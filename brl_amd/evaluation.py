@@ -150,8 +150,8 @@ class _ActiveRows:
     """Forwards on the boards still playing only.  With 8192 boards and two DeepMind MLPs 53 % of the board-iterations of a
     duplicate evaluation belong to boards that are already finished (the last boards end at iteration ~30, half are done by
     iteration 16): their logits are never used (no-op calls, G9).  Rows to forward = the first `m` entries of `_DoneWatch`'s
-    index list (m = boards playing, rounded up to 256: the padding entries are valid board indices — at worst a board is
-    forwarded twice, with identical results), adopted whenever that shrinks the batch by a fifth."""
+    index list (m = the smallest step of a short ladder of batch sizes that holds the boards playing: the padding entries are
+    valid board indices — at worst a board is forwarded twice, with identical results)."""
 
     def __init__(self, n):
         self.n, self.m, self.idx, self.full = n, n, None, None
@@ -160,11 +160,21 @@ class _ActiveRows:
         if polled is None or polled[1] is None:
             return
         live = self.n - polled[0]
-        m = min(self.n, max(256, (live + 255) // 256 * 256))
-        if m <= 0.8 * self.m:
+        # a short ladder of batch sizes (n, 3n/4, n/2, 3n/8, n/4, n/8, .. >= 256, each rounded up to 256 rows): few distinct GEMM
+        # shapes for the library's per-shape heuristics / TunableOp lookups to see (every new shape costs host time once)
+        m, f = self.n, self.n
+        while f > 256:
+            for c in (3 * f // 4, f // 2):
+                c = min(self.n, max(256, (c + 255) // 256 * 256))
+                if live <= c < m:
+                    m = c
+            f //= 2
+        if m < self.m:
             self.m, self.idx = m, polled[1][:m]
 
     def forward(self, fwd, obs, env):
+        if getattr(fwd, "constant", False):   # (the same logits whatever the observation: nothing to compute)
+            return fwd(obs, None)
         if self.idx is None or self.full is None:
             self.full = fwd(obs, obs.to(torch.float32))
             return self.full
@@ -292,6 +302,7 @@ def make_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_type, t
 
     class _PassOnly:
         """free-run opponent: probs = one-hot(Pass) (src/evaluation.py:243-247); logits with softmax == that one-hot."""
+        constant = True
 
         def __init__(self, n, device):
             self.lg = torch.full((n, NUM_ACTIONS), -1e30, dtype=torch.float32, device=device)
