@@ -783,7 +783,13 @@ def test_evaluators_on_live_rows_equal_full_batches(env, monkeypatch):
                 return [v for y in x for v in flat(y)]
             return [float(v) for v in torch.as_tensor(x).double().reshape(-1)]
         res[compact] = (flat(dup(p1, p2, 3)), make_evaluate_log(full(p1, 4)[0]))
-    assert res["1"] == res["0"]
+    # The calls are arg-maxes of logits whose per-row values could differ in the last bits with the batch size (the library may pick
+    # another GEMM kernel for another M): a tie within that noise would change ONE board's auction.  So: equal up to what one
+    # board of 3000 can move (in the runs so far every number was identical).
+    a, b = res["1"], res["0"]
+    assert len(a[0]) == len(b[0]) and all(abs(x - y) <= 0.02 + 1e-3 * abs(y) for x, y in zip(a[0], b[0])), (a[0], b[0])
+    assert a[1].keys() == b[1].keys()
+    assert all(abs(a[1][k] - b[1][k]) <= 0.02 + 1e-3 * abs(b[1][k]) for k in a[1]), {k: (a[1][k], b[1][k]) for k in a[1] if a[1][k] != b[1][k]}
 
 
 @pytest.mark.parametrize("dt", [None, "bf16"])
