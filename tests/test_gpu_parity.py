@@ -1083,10 +1083,13 @@ def test_duplicate_evaluate_with_statistics_matches_oracle(env, oracle, n, game_
 
 @pytest.mark.parametrize("n,game_mode,duplicate", [(640, "competitive", True), (2048, "competitive", True),
                                                    (300, "free-run", True), (640, "competitive", False)])
-def test_team_alternating_evaluation_equals_lockstep_evaluation(env, n, game_mode, duplicate):
+def test_team_alternating_evaluation_equals_lockstep_evaluation(env, n, game_mode, duplicate, monkeypatch):
     """With two different networks the evaluators run ONE forward per iteration and let the teams take turns
     (brl_eval_step_team); a recording run keeps the reference's lock-step loop (two forwards, every board steps), which
-    the tests above replay through the oracle.  Both must produce the same Table_info snapshots and the same log_info."""
+    the tests above replay through the oracle.  Both must produce the same Table_info snapshots and the same log_info.
+    (Full batches in both runs — BRL_EVAL_COMPACT=0 — so that every GEMM has the same shape in both and the comparison can be
+    exact; forwards on the live rows only are compared in test_evaluators_on_live_rows_equal_full_batches.)"""
+    monkeypatch.setenv("BRL_EVAL_COMPACT", "0")
     from brl_amd.evaluation import make_evaluate, make_simple_duplicate_evaluate
     from brl_amd.models import make_forward_pass
     fp = make_forward_pass("relu", "DeepMind")
