@@ -4,7 +4,8 @@
 // Opt-in precision (`inference_dtype`), never the default — the fp32 path stays with the library GEMM.
 //
 // Why not the library GEMM: at M = 8192 tables, N = K = 1024 hipBLASLt's pick runs 20.6 us = 0.83 PFLOP/s (a third of the
-// dense bf16 peak; profiles/r03/r03h_policy_rollout_bf16_graph_kernel_stats.txt), and the rollout issues 512 of them.  Here:
+// dense bf16 peak; profiles/r03/r03h_policy_rollout_bf16_graph_kernel_stats.txt), and the rollout issues 512 of them (this
+// kernel: 18.0-18.9 us averaged over the four layers, profiles/r03/r03k_policy_rollout_bf16_graph_kernel_stats.txt).  Here:
 //   * 256 (M) x 128 (N) output tile per 512-thread workgroup: 8192 x 1024 = 256 tiles = ONE per CU, all resident at once;
 //     workgroup -> tile so that an XCD owns 4 row tiles x all 8 column tiles (its L2 holds W once and 2 MB of x);
 //   * v_mfma_f32_32x32x16_bf16, 8 waves as 4 (M) x 2 (N), 64 x 64 per wave = 2 x 2 accumulators; the product is formed
@@ -14,7 +15,10 @@
 //     128-byte LDS rows whose 16-byte pieces are XOR-swizzled on the SOURCE address, so every ds_read_b128 of 32 rows is
 //     conflict-free; fragments of chunk c + 1 are read while chunk c is multiplied (two register sets);
 //   * per MFMA gap at most one DMA instruction and one or two fragment reads (the two waves of a SIMD run in step);
-//   * epilogue: + bias, ReLU, round to 16 bits, through LDS, rows stored 256 B at a time.
+//   * epilogue: + bias, ReLU, round to 16 bits (v_cvt_pk_bf16_f32), through LDS in two halves behind raw barriers, rows stored
+//     256 B at a time, write-through (no dirty L2 line is left for the end of the launch);
+//   * optionally (brl_linear_act_heads) the tile is multiplied, while it sits in LDS, with its 128 columns of the policy
+//     heads' weights: partial products per column tile, summed by brl_policy_step_ex — and y itself need not be stored;
 //   * K need not be a multiple of 64 (the observation is 480 wide): the pieces of the last chunk that lie beyond K are
 //     fetched from a 16-byte block of zeros instead.
 // Included by brl_kernels.hip.
