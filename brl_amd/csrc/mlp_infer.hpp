@@ -265,16 +265,31 @@ __device__ __forceinline__ void linear_tile(const Args &G, char *lds, float *bia
 
   b16x8 x0[2][4], w0[2][4], x1[2][4], w1[2][4];
   LIN16_STAMP(0);
-  for (int c = 0; c < STAGES && c < nchunks; c++) {   // prologue: every stage filled
+#ifndef LIN16_PROLOGUE
+#define LIN16_PROLOGUE 1   // 0: all three stages requested before the first wait (experiment)
+#endif
+  // prologue: every stage filled.  All 256 workgroups start at once and ask for 3 x 48 KB each: chunk 0 — the only one the first
+  // MFMA waits for — would share the memory system with 25 MB of chunks 1 and 2.  So chunk 2 is requested only when chunk 0
+  // has arrived (it is needed two phases later).
+  for (int c = 0; c < (LIN16_PROLOGUE ? 2 : STAGES) && c < nchunks; c++) {
     stage_any(lds + c * STAGE_BYTES);
     advance();
   }
   {
-    if (nchunks >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (nchunks == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (LIN16_PROLOGUE) {
+      if (nchunks >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (nchunks >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (nchunks == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (LIN16_PROLOGUE && nchunks >= 3) {
+      stage_any(lds + 2 * STAGE_BYTES);
+      advance();
+    }
 #pragma unroll
     for (int u = 0; u < 16; u++) { L16_RD(lds, x0, w0, u) }
   }
