@@ -117,14 +117,22 @@ class InferenceSnapshot:
         rollout (contiguous -> contiguous; the transposed [in, out] copies of the library-GEMM path are rebuilt only if a
         caller falls back to it)."""
         k = self.n_actions
+
+        def copy_all(dst, src):
+            if hasattr(torch, "_foreach_copy_"):
+                torch._foreach_copy_(dst, src)
+            else:
+                for d, s_ in zip(dst, src):
+                    d.copy_(s_)
+
         with torch.no_grad():
             ws = [w for w, _ in self.body_nk] + [self.head_wt[:k], self.head_wt[k:]]
             src = [lin.weight.detach() for lin in module.body] + [module.actor.weight.detach(), module.critic.weight.detach()]
-            torch._foreach_copy_(ws, src)
+            copy_all(ws, src)
             # biases: rounded to `dtype` first — the float copies hold the SAME values a 16-bit GEMM epilogue would add
             b16 = [b for _, b in self.body] + [self.head_b[:k], self.head_b[k:]]
-            torch._foreach_copy_(b16, [lin.bias.detach() for lin in module.body] + [module.actor.bias.detach(), module.critic.bias.detach()])
-            torch._foreach_copy_([b for _, b in self.body_nk] + [self.head_bf], [b for _, b in self.body] + [self.head_b])
+            copy_all(b16, [lin.bias.detach() for lin in module.body] + [module.actor.bias.detach(), module.critic.bias.detach()])
+            copy_all([b for _, b in self.body_nk] + [self.head_bf], [b for _, b in self.body] + [self.head_b])
             self.head_w.copy_(self.head_wt.t())
         self._body_stale = True   # self.body's weights ([in, out]) no longer match: rebuilt on demand (_body)
 
