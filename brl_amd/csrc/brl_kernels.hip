@@ -2771,6 +2771,32 @@ extern "C" int brl_ppo_heads_loss(int device, const float *h, int64_t ldh, const
   return BRL_OK;
 }
 
+extern "C" int brl_ppo_heads_loss_split(int device, const float *h, int64_t ldh, const float *head_w, const float *head_b,
+                                        int64_t hidden, const uint8_t *mask, const int32_t *action, const float *old_value,
+                                        const float *old_log_prob, const float *gae, const float *targets, int64_t batch,
+                                        float clip_eps, float vf_coef, float ent_coef, int masked, int value_clipping,
+                                        int reward_scaling, float *heads_out, float *dheads, float *partials, float *gram_partials,
+                                        float *head_parts, int ksplit, void *stream) {
+  NEED(batch > 0 && hidden > 0 && hidden % 16 == 0 && ldh >= hidden && ldh % 4 == 0, "batch / hidden (a multiple of 16) / ldh");
+  NEED(h && head_w && head_b && mask && action && old_value && old_log_prob && gae && targets, "NULL input array");
+  NEED(dheads && partials && head_parts, "NULL output array");
+  NEED(ksplit >= 1 && ksplit <= 8, "ksplit (1..8)");
+  HIP_TRY(hipSetDevice(device));
+  constexpr int64_t HS = BRL_NUM_ACTIONS + 1;
+  HeadsProductArgs G{};
+  G.h = h; G.ldh = ldh; G.Wh = head_w; G.H = (int)hidden; G.B = batch; G.ksplit = ksplit; G.parts = head_parts; G.part_stride = batch * HS;
+  hipLaunchKernelGGL(k_heads_product, dim3((unsigned)((batch + 15) / 16), (unsigned)ksplit), dim3(HD_WAVES * 64), 0, (hipStream_t)stream, G);
+  HeadsLossArgs A{};
+  A.h = h; A.ldh = ldh; A.Wh = head_w; A.bh = head_b; A.H = (int)hidden;
+  A.P = PpoArgs{nullptr, HS, nullptr, mask, action, old_value, old_log_prob, gae, targets, batch, clip_eps, vf_coef,
+                ent_coef, masked, value_clipping, dheads, dheads + BRL_NUM_ACTIONS, partials, nullptr, HS, HS, HS};
+  A.heads_out = heads_out; A.gram_partials = gram_partials; A.reward_scaling = reward_scaling;
+  A.parts = head_parts; A.nparts = ksplit; A.part_stride = batch * HS;
+  hipLaunchKernelGGL(k_heads_loss, dim3((unsigned)((batch + HD_ROWS - 1) / HD_ROWS)), dim3(HD_WAVES * 64), 0, (hipStream_t)stream, A);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
 extern "C" int brl_ppo_heads_bwd(int device, const float *dheads, const float *h, int64_t ldh, const float *head_w, int64_t batch,
                                  int64_t hidden, int act, int nsplit, float *dw_partials, float *db_partials, float *dh,
                                  float *tile_sums, const float *loss_partials, const float *gram_partials, int64_t ngroups,

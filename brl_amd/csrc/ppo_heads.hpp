@@ -30,6 +30,11 @@ struct HeadsLossArgs {
   float *heads_out;     // [B, 39] or NULL
   float *gram_partials; // [ceil(B / 4)][1444] or NULL
   int reward_scaling;   // src/update.py:31-44: advantages normalised over the minibatch (jnp std: ddof = 0)
+  // parts != NULL: the heads product has been formed by k_heads_product as `nparts` partial sums over K ranges:
+  // heads[b][n] = bh[n] + parts[0][b][n] + parts[1][b][n] + ..  (in that order); h / Wh are not read here
+  const float *parts;   // [nparts][part_stride], row b at b * 39
+  int nparts;           // <= 8
+  int64_t part_stride;
 };
 
 #ifdef HD_TIMING   // scripts/time_heads.py --stamps (a -DHD_TIMING build): shader cycles at 6 points of workgroup 0..63, wave 0, into heads_out
@@ -88,6 +93,11 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
   const bool my_valid = w < HD_ROWS && my_b < B;
   const PpoSampleIn my_in = ppo_sample_load(A.P, my_b, my_valid, lane);
   const float my_bias = (lane < HD_NOUT) ? A.bh[lane] : 0.0f;
+  const bool split = A.parts != nullptr;   // (uniform) the product comes in as partial sums
+  float my_part[8];
+#pragma unroll
+  for (int p = 0; p < 8; p++)
+    my_part[p] = (split && my_valid && lane < HD_NOUT && p < A.nparts) ? A.parts[(int64_t)p * A.part_stride + my_b * HD_NOUT + lane] : 0.0f;
 
   // ---- heads of 16 samples: D[sample][n] = sum_k h[sample][k] W_h[n][k]; wave w takes the 16-deep K groups w, w + 8, ..
   // lane (r, kq): A row = sample r, B column = head n = 16 nb + r, K = 16 g + 4 kq + s in MFMA step s (the K order inside a
@@ -95,6 +105,7 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
   // Only FOUR of the tile's 16 rows are real samples (the others repeat them): the heads product is ~80 MFLOP — nothing —, but the
   // loss behind it is ~900 VALU instructions per sample, and with 16 samples per workgroup only 64 CUs would share them, four
   // waves deep on every SIMD (measured: 14 k cycles of 25 k).  256 workgroups x 4 samples: one loss wave per SIMD, every CU busy.
+  if (!split) {
   const int r = lane & 15, kq = lane >> 4;
   const int64_t arow = (row0 + (r & (HD_ROWS - 1)) < B) ? row0 + (r & (HD_ROWS - 1)) : B - 1;
   const float *ap = A.h + arow * A.ldh + 4 * kq;
@@ -147,6 +158,7 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
 #pragma unroll
       for (int q = 0; q < 4; q++) red[w][nb][q][lane] = acc[nb][q];
   }
+  }
   __syncthreads();
 
   // ---- `_loss_fn` (src/update.py:90-167): wave w < 4 takes sample w; lane a = head a
@@ -158,8 +170,13 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
     if (lane < HD_NOUT) {
       const int nb = lane >> 4, c = lane & 15;
       hv = my_bias;
+      if (split) {
 #pragma unroll
-      for (int k = 0; k < HD_WAVES; k++) hv += red[k][nb][sl][c];   // fixed order
+        for (int p = 0; p < 8; p++) hv += my_part[p];   // fixed order (absent parts are exact zeros)
+      } else {
+#pragma unroll
+        for (int k = 0; k < HD_WAVES; k++) hv += red[k][nb][sl][c];   // fixed order
+      }
       if (valid && A.heads_out) A.heads_out[b * HD_NOUT + lane] = hv;
     }
     const float v = __shfl(hv, BRL_NUM_ACTIONS, 64);
@@ -203,6 +220,81 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
 constexpr int HB_JT = 64;       // role A: columns of h per workgroup
 constexpr int HB_NG = 10;       // role A: heads per thread (4 groups of 10 >= 39)
 constexpr int HB_ROWS = 16;     // role B: rows per workgroup (= the tile of the bias-gradient column sums)
+
+// The heads product of k_heads_loss as a launch of its own, split over K ACROSS workgroups: workgroup (rt, ks) multiplies the 16
+// samples rt * 16 .. with K groups [ks * gps, (ks + 1) * gps) of W_h (its 8 waves take every 8th group of that range) and writes
+// parts[ks][b][n] — 64 KB of operands per workgroup at H = 1024 / 4 splits instead of the 224-256 KB a whole-K workgroup pulls
+// through its CU (which was 9.3 k of k_heads_loss's 24.4 k cycles).  The loss launch adds bias + parts in order.
+struct HeadsProductArgs {
+  const float *h;
+  int64_t ldh;
+  const float *Wh;
+  int H;
+  int64_t B;
+  int ksplit;
+  float *parts;          // [ksplit][part_stride]
+  int64_t part_stride;   // >= B * 39
+};
+
+__global__ __launch_bounds__(HD_WAVES * 64) void k_heads_product(HeadsProductArgs A) {
+  __shared__ float red[HD_WAVES][3][4][64];   // 24 KB
+  const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * 16;
+  const int ks = (int)blockIdx.y;
+  const int ngroups = A.H / 16, gps = (ngroups + A.ksplit - 1) / A.ksplit;
+  const int g_lo = ks * gps, g_hi = (g_lo + gps < ngroups) ? g_lo + gps : ngroups;
+  const int r = lane & 15, kq = lane >> 4;
+  const int64_t arow = (row0 + r < A.B) ? row0 + r : A.B - 1;
+  const float *ap = A.h + arow * A.ldh + 4 * kq;
+  const float *bp[3];
+  bool bok[3];
+#pragma unroll
+  for (int nb = 0; nb < 3; nb++) {
+    const int n = 16 * nb + r;
+    bok[nb] = n < HD_NOUT;
+    bp[nb] = A.Wh + (int64_t)(bok[nb] ? n : 0) * A.H + 4 * kq;
+  }
+  hd_f32x4 acc[3];
+#pragma unroll
+  for (int nb = 0; nb < 3; nb++) acc[nb] = hd_f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int GP = 4;   // groups of a wave in flight at once
+  for (int g0 = g_lo + w; g0 < g_hi; g0 += GP * HD_WAVES) {
+    hd_f32x4 av[GP], bv[GP][3];
+#pragma unroll
+    for (int u = 0; u < GP; u++) {
+      const int g = g0 + u * HD_WAVES;
+      const int gc = (g < g_hi) ? g : g0;
+      av[u] = *reinterpret_cast<const hd_f32x4 *>(ap + 16 * gc);
+#pragma unroll
+      for (int nb = 0; nb < 3; nb++) bv[u][nb] = *reinterpret_cast<const hd_f32x4 *>(bp[nb] + 16 * gc);
+    }
+#pragma unroll
+    for (int u = 0; u < GP; u++) {
+      if (g0 + u * HD_WAVES >= g_hi) break;
+#pragma unroll
+      for (int nb = 0; nb < 3; nb++) {
+#pragma unroll
+        for (int s_ = 0; s_ < 4; s_++)
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][s_], bok[nb] ? bv[u][nb][s_] : 0.0f, acc[nb], 0, 0, 0);
+      }
+    }
+  }
+  // accumulator register q of lane (c, rq): D[sample 4 rq + q][head 16 nb + c]
+#pragma unroll
+  for (int nb = 0; nb < 3; nb++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) red[w][nb][q][lane] = acc[nb][q];
+  __syncthreads();
+  float *out = A.parts + (int64_t)ks * A.part_stride;
+  for (int e = tid; e < 16 * HD_NOUT; e += HD_WAVES * 64) {
+    const int row = e / HD_NOUT, col = e - row * HD_NOUT;
+    const int nb = col >> 4, c = col & 15, q = row & 3, rq = row >> 2;
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < HD_WAVES; k++) v += red[k][nb][q][16 * rq + c];   // fixed order
+    if (row0 + row < A.B) out[(row0 + row) * HD_NOUT + col] = v;
+  }
+}
 
 struct HeadsBwdArgs {
   const float *dheads;   // [B, 39]

@@ -323,6 +323,8 @@ class FusedMinibatch:
         self.dheads = f(B, K)
         self.ill_coef = float(config.get("illegal_action_l2norm_coef", 0.0) or 0.0)
         self.heads = f(B, K) if self.ill_coef else None      # the gradient of the illegal-action norm re-reads the logits
+        self.head_ksplit = max(1, min(4, H // 256))          # K ranges of the heads product (brl_ppo_heads_loss_split)
+        self.head_parts = f(self.head_ksplit, B, K)
         self.vec = f(40) if self.ill_coef else None          # v1 [38], sigma_1 of the step's illegal-action matrix
         self.H, self.K = H, K
         self.act = 0 if params.act is torch.relu else 1
@@ -459,13 +461,15 @@ class FusedMinibatch:
                 x = torch._addmm_activation(b, x, W.t(), use_gelu=False, out=self.h[l])
             else:
                 x = torch.addmm(b, x, W.t(), out=self.h[l]).tanh_()
-        chk(L.brl_ppo_heads_loss(di, x.data_ptr(), x.stride(0), self.Wh.data_ptr(), self.bh.data_ptr(), self.H,
-                                 self.mask.data_ptr(), self.action.data_ptr(), self.old_v.data_ptr(), self.old_lp.data_ptr(),
-                                 self.adv.data_ptr(), self.tgt.data_ptr(), B, float(cfg["clip_eps"]), float(cfg["vf_coef"]),
-                                 float(cfg["ent_coef"]), int(bool(cfg.get("actor_illegal_action_mask", True))),
-                                 int(bool(cfg.get("value_clipping", True))), int(bool(cfg.get("reward_scaling", False))),
-                                 self.heads.data_ptr() if self.ill_coef else None,
-                                 self.dheads.data_ptr(), self.partials.data_ptr(), self.gram_partials.data_ptr(), s))
+        # (two launches: the heads product split over K across workgroups, then the loss on bias + its parts)
+        chk(L.brl_ppo_heads_loss_split(di, x.data_ptr(), x.stride(0), self.Wh.data_ptr(), self.bh.data_ptr(), self.H,
+                                       self.mask.data_ptr(), self.action.data_ptr(), self.old_v.data_ptr(), self.old_lp.data_ptr(),
+                                       self.adv.data_ptr(), self.tgt.data_ptr(), B, float(cfg["clip_eps"]), float(cfg["vf_coef"]),
+                                       float(cfg["ent_coef"]), int(bool(cfg.get("actor_illegal_action_mask", True))),
+                                       int(bool(cfg.get("value_clipping", True))), int(bool(cfg.get("reward_scaling", False))),
+                                       self.heads.data_ptr() if self.ill_coef else None,
+                                       self.dheads.data_ptr(), self.partials.data_ptr(), self.gram_partials.data_ptr(),
+                                       self.head_parts.data_ptr(), self.head_ksplit, s))
         if self.ill_coef:
             # src/update.py:146-152: + coef * sigma_1(P) / 2 — its gradient needs the step's top singular pair NOW (the logged
             # statistics otherwise wait for the end of the update): one stats launch on the critical path of this configuration

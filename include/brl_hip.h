@@ -413,6 +413,15 @@ int brl_ppo_heads_loss(int device, const float *h, int64_t ldh, const float *hea
                        const float *gae, const float *targets, int64_t batch, float clip_eps, float vf_coef, float ent_coef,
                        int masked, int value_clipping, int reward_scaling, float *heads_out, float *dheads, float *partials,
                        float *gram_partials, void *stream);
+/* The same as TWO launches: the heads product split over K across workgroups (ksplit ranges, 1..8; 4 at hidden = 1024) into
+ * head_parts float [ksplit, batch, 39] (scratch), then the loss on bias + the parts added in order.  One workgroup of the
+ * one-launch form pulls all of W_h through its CU before it can start (9.3 k of its 24.4 k cycles); here a workgroup reads a
+ * ksplit-th of it.  Same results up to the order of the fp32 sums over K. */
+int brl_ppo_heads_loss_split(int device, const float *h, int64_t ldh, const float *head_w, const float *head_b, int64_t hidden,
+                       const uint8_t *mask, const int32_t *action, const float *old_value, const float *old_log_prob,
+                       const float *gae, const float *targets, int64_t batch, float clip_eps, float vf_coef, float ent_coef,
+                       int masked, int value_clipping, int reward_scaling, float *heads_out, float *dheads, float *partials,
+                       float *gram_partials, float *head_parts, int ksplit, void *stream);
 
 /* Backward of the head in one launch (what autograd does for `actor(x), critic(x)` and the activation under them):
  * dw_partials float [nsplit, 39 * hidden] and db_partials float [nsplit, 39]: d(heads)^T h and the column sums of d(heads)

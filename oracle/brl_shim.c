@@ -386,6 +386,12 @@ int brl_ppo_heads_loss(int device, const float *h, int64_t ldh, const float *hw,
   (void)device; (void)h; (void)ldh; (void)hw; (void)hb; (void)hidden; (void)m; (void)a; (void)ov; (void)olp; (void)g; (void)t; (void)b; (void)ce; (void)vc; (void)ec; (void)mk; (void)vcl; (void)rs; (void)ho; (void)dh; (void)pt; (void)gp; (void)s;
   NOT_HERE("brl_ppo_heads_loss");
 }
+int brl_ppo_heads_loss_split(int device, const float *h, int64_t ldh, const float *hw, const float *hb, int64_t hidden, const uint8_t *m,
+                       const int32_t *a, const float *ov, const float *olp, const float *g, const float *t, int64_t b, float ce,
+                       float vc, float ec, int mk, int vcl, int rs, float *ho, float *dh, float *pt, float *gp, float *hp, int ks, void *s) {
+  (void)device; (void)h; (void)ldh; (void)hw; (void)hb; (void)hidden; (void)m; (void)a; (void)ov; (void)olp; (void)g; (void)t; (void)b; (void)ce; (void)vc; (void)ec; (void)mk; (void)vcl; (void)rs; (void)ho; (void)dh; (void)pt; (void)gp; (void)hp; (void)ks; (void)s;
+  NOT_HERE("brl_ppo_heads_loss_split");
+}
 int brl_ppo_heads_bwd(int device, const float *dheads, const float *h, int64_t ldh, const float *hw, int64_t b, int64_t hidden,
                       int act, int nsplit, float *dwp, float *dbp, float *dh, float *ts, const float *lp, const float *gp, int64_t ng,
                       const int32_t *ri, float *ss, float *gs, void *s) {

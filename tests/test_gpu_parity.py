@@ -1871,6 +1871,29 @@ def test_head_kernels_match_torch_and_the_separate_launches(B, H, act):
             assert torch.equal(dheads, dh2)
         else:   # the in-kernel mean / std differ from torch's in the last bits
             assert torch.allclose(dheads, dh2, rtol=1e-4, atol=1e-9)
+        # the two-launch form (heads product split over K across workgroups, then the loss on bias + parts): the same heads up
+        # to the order of the fp32 sums, and d(heads) / partials / Gram partials equal to the separate loss launch on ITS heads
+        for ksplit in (1, 4) if H % 64 == 0 else (1, 2):
+            heads3, dheads3 = torch.empty(B, 39, device=dev), torch.empty(B, 39, device=dev)
+            partials3, gram_p3 = torch.empty(lgroups, 8, device=dev), torch.empty(lgroups, 1444, device=dev)
+            hparts = torch.full((ksplit, B, 39), float("nan"), device=dev)
+            _capi.check(L.brl_ppo_heads_loss_split(0, h.data_ptr(), H, Wh.data_ptr(), bh.data_ptr(), H, mask.data_ptr(), action.data_ptr(),
+                                                   old_v.data_ptr(), old_lp.data_ptr(), gae.data_ptr(), tgt.data_ptr(), B, 0.2, 0.5, 0.001,
+                                                   1, 1, rscale, heads3.data_ptr(), dheads3.data_ptr(), partials3.data_ptr(),
+                                                   gram_p3.data_ptr(), hparts.data_ptr(), ksplit, s))
+            assert not torch.isnan(hparts).any()
+            assert float((heads3.double() - want).abs().max()) < 2e-5
+            dh3 = torch.empty(B, 39, device=dev)
+            _capi.check(L.brl_ppo_loss_heads(0, heads3.data_ptr(), mask.data_ptr(), action.data_ptr(), old_v.data_ptr(), old_lp.data_ptr(),
+                                             adv.contiguous().data_ptr(), tgt.data_ptr(), B, 0.2, 0.5, 0.001, 1, 1, dh3.data_ptr(),
+                                             p2.data_ptr(), illp.data_ptr(), s))
+            if rscale == 0:
+                assert torch.equal(dheads3, dh3)
+            else:
+                assert torch.allclose(dheads3, dh3, rtol=1e-4, atol=1e-9)
+            assert torch.allclose(dheads3, dheads, rtol=1e-3, atol=1e-6)
+            assert torch.allclose(partials3.sum(0), partials.sum(0), rtol=1e-4, atol=1e-5)
+            assert torch.allclose(gram_p3.sum(0), gram_p.sum(0), rtol=1e-4, atol=1e-7)
         assert torch.allclose(partials.sum(0), p2.sum(0), rtol=1e-4, atol=1e-5)
         gram = illp.double().t() @ illp.double()
         assert torch.allclose(gram_p.sum(0).double().reshape(38, 38), gram, rtol=1e-4, atol=1e-7)
