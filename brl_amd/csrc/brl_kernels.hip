@@ -2857,14 +2857,22 @@ extern "C" int brl_ppo_stats_rows(int device, const float *stat_sums, const floa
 
 static int adam_clip_impl(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
                           const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale,
-                          float *scratch, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t gather_rows, void *stream) {
+                          float *scratch, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t gather_rows, void *stream,
+                          const BiasSegs *fin = nullptr, int64_t tail_lo = 0, const FinBlocks *fb = nullptr) {
   NEED(p && g && m && v && step && scratch && n > 0 && n % 4 == 0, "p / g / m / v / step / scratch / n (a multiple of 4)");
   NEED(!gather_args || (mb_index && gather_rows > 0), "gather_args needs mb_index and the minibatch size");
   HIP_TRY(hipSetDevice(device));
-  hipLaunchKernelGGL(k_adam_norm, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, g, n, grad_scale, scratch, step, mb_index);
+  int npartials = ADAM_BLOCKS;
+  if (fin != nullptr) {   // the finalize launch rides along: see k_adam_norm_fin
+    npartials += fb->off[fin->n];
+    hipLaunchKernelGGL(k_adam_norm_fin, dim3((unsigned)npartials), dim3(ADAM_THREADS), 0, (hipStream_t)stream, g, n, grad_scale, scratch,
+                       step, mb_index, *fin, tail_lo, *fb);
+  } else {
+    hipLaunchKernelGGL(k_adam_norm, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, g, n, grad_scale, scratch, step, mb_index);
+  }
   const unsigned extra = gather_args ? (unsigned)((gather_rows + 1) / 2) : 0u;
   hipLaunchKernelGGL(k_adam_apply, dim3(ADAM_BLOCKS + extra), dim3(ADAM_THREADS), 0, (hipStream_t)stream, p, g, m, v, n, scratch, step, lr,
-                     lr_dev, beta1, beta2, eps, max_norm, grad_scale, norm_out, (const GatherArgs *)gather_args);
+                     lr_dev, beta1, beta2, eps, max_norm, grad_scale, norm_out, (const GatherArgs *)gather_args, npartials);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }
@@ -2883,6 +2891,36 @@ extern "C" int brl_adam_clip_gather(int device, float *p, const float *g, float 
   NEED(gather_args != nullptr, "gather_args");
   return adam_clip_impl(device, p, g, m, v, n, step, lr, lr_dev, beta1, beta2, eps, max_norm, grad_scale, scratch, mb_index, norm_out,
                         gather_args, mbs, stream);
+}
+
+extern "C" int brl_adam_clip_fin_gather(int device, float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
+                                        const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float *scratch,
+                                        int64_t scratch_len, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs,
+                                        int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles,
+                                        float *const *out, void *stream) {
+  NEED(nseg >= 1 && nseg <= BIAS_MAX_SEGS && partials && cols && tiles && out, "nseg / partials / cols / tiles / out");
+  NEED(g != nullptr && n > 0, "g / n");
+  BiasSegs S{};
+  S.n = nseg;
+  int64_t maxc = 0, covered = 0;
+  const float *lo = g + n;
+  for (int i = 0; i < nseg; i++) {
+    NEED(partials[i] && out[i] && cols[i] > 0 && tiles[i] > 0, "segment");
+    NEED(out[i] >= g && out[i] + cols[i] <= g + n, "segment outputs must lie inside the gradient buffer");
+    S.tiles[i] = tiles[i]; S.partials[i] = partials[i]; S.cols[i] = cols[i]; S.db[i] = out[i];
+    maxc = cols[i] > maxc ? cols[i] : maxc;
+    covered += cols[i];
+    lo = (out[i] < lo) ? out[i] : lo;
+  }
+  const int64_t tail_lo = lo - g;
+  // the segments must be exactly the tail of the buffer (up to its zero padding): everything in front is square-summed as it is
+  NEED(tail_lo % 4 == 0 && covered <= n - tail_lo && n - tail_lo - covered < 4, "the finalised segments must tile the end of the gradient buffer");
+  FinBlocks FB{};
+  for (int i = 0; i < nseg; i++) FB.off[i + 1] = FB.off[i] + (int)((cols[i] + 63) / 64);
+  (void)maxc;
+  NEED(scratch_len >= ADAM_BLOCKS + (int64_t)FB.off[nseg], "scratch too small for the finalize blocks' partials");
+  return adam_clip_impl(device, p, g, m, v, n, step, lr, lr_dev, beta1, beta2, eps, max_norm, 1.0f, scratch, mb_index, norm_out,
+                        gather_args, mbs, stream, &S, tail_lo, &FB);
 }
 
 extern "C" int brl_ppo_stats(int device, const float *partials, int64_t batch, const float *gram, float vf_coef,

@@ -158,11 +158,10 @@ struct BiasSegs {  // up to 12 layers finalised by one launch (blockIdx.y = laye
 
 // (64 columns per block, 4 threads per column: thread group g adds tiles g, g + 4, ... in order, then (g0 + g1) + (g2 + g3):
 //  a fixed order, and 16 loads per thread instead of a 64-long chain — 17 -> ~5 us for five 1024-column layers)
-__global__ __launch_bounds__(256) void k_bias_finalize(BiasSegs S) {
-  __shared__ float part[4][64];
-  const int seg = (int)blockIdx.y;
+// -> (threads of group 0) the finished sum of this thread's column, already stored; 0 for the others / beyond `cols`
+__device__ __forceinline__ float bias_finalize_block(const BiasSegs &S, const int seg, const int bx, float (*part)[64]) {
   const int c = (int)(threadIdx.x & 63u), g = (int)(threadIdx.x >> 6);
-  const int64_t col = (int64_t)blockIdx.x * 64 + c, cols = S.cols[seg];
+  const int64_t col = (int64_t)bx * 64 + c, cols = S.cols[seg];
   const float *p = S.partials[seg];
   float s = 0.0f;
   if (col < cols) {   // (latency-bound: the thread's tiles are requested 16 at a time, then added in index order)
@@ -177,7 +176,17 @@ __global__ __launch_bounds__(256) void k_bias_finalize(BiasSegs S) {
   }
   part[g][c] = s;
   __syncthreads();
-  if (g == 0 && col < cols) S.db[seg][col] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+  float v = 0.0f;
+  if (g == 0 && col < cols) {
+    v = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    S.db[seg][col] = v;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_bias_finalize(BiasSegs S) {
+  __shared__ float part[4][64];
+  (void)bias_finalize_block(S, (int)blockIdx.y, (int)blockIdx.x, part);
 }
 
 // ---- optax.chain(clip_by_global_norm(max_norm), adam(lr, eps)) (ppo.py:195-211) on flat fp32 buffers, two launches:
@@ -210,11 +219,55 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_norm(const float *g, int6
   }
 }
 
+// k_adam_norm + k_bias_finalize in ONE launch (single rank: nothing sits between them).  The flat gradient buffer ends with the
+// ranges k_bias_finalize produces (the head's weight gradient and every bias gradient, floats [tail_lo, n)): blocks
+// [0, ADAM_BLOCKS) square-sum g[0, tail_lo) as k_adam_norm does; block ADAM_BLOCKS + FB.off[seg] + bx finishes 64 columns of
+// segment `seg` (the sums k_bias_finalize forms, in its order), stores them AND adds their squares to its own partial — one
+// small launch (~5 us of latency chain) less per step.
+struct FinBlocks { int off[BIAS_MAX_SEGS + 1]; };   // segment `seg` owns the finalize blocks [off[seg], off[seg + 1]): 64 columns each
+
+__global__ __launch_bounds__(ADAM_THREADS) void k_adam_norm_fin(const float *g, int64_t n, float gscale, float *partials, float *step,
+                                                                int32_t *mb_index, BiasSegs S, int64_t tail_lo, FinBlocks FB) {
+  static_assert(ADAM_THREADS == 256, "the finalize blocks are 4 x 64 threads");
+  __shared__ float red[ADAM_THREADS / 64];
+  __shared__ float part[4][64];
+  if ((int)blockIdx.x >= ADAM_BLOCKS) {
+    const int e = (int)blockIdx.x - ADAM_BLOCKS;
+    int seg = 0;
+    while (seg + 1 < S.n && e >= FB.off[seg + 1]) seg++;
+    const int bx = e - FB.off[seg];
+    float v = bias_finalize_block(S, seg, bx, part) * gscale;
+    v = wave_sum_f(v * v);   // (the stored columns live in wave 0; the other waves add zeros)
+    if (threadIdx.x == 0) partials[blockIdx.x] = v;
+    return;
+  }
+  const int64_t n4 = n >> 2, t4 = tail_lo >> 2;
+  const int64_t chunk = (n4 + ADAM_BLOCKS - 1) / ADAM_BLOCKS;
+  int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n4) ? lo + chunk : n4;
+  hi = (hi < t4) ? hi : t4;
+  float s = 0.0f;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += ADAM_THREADS) {
+    float4 x = reinterpret_cast<const float4 *>(g)[i];
+    x.x *= gscale; x.y *= gscale; x.z *= gscale; x.w *= gscale;
+    s += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+  }
+  s = wave_sum_f(s);
+  if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (blockIdx.x == 0) {
+      *step += 1.0f;
+      if (mb_index) *mb_index += 1;
+    }
+  }
+}
+
 __global__ __launch_bounds__(ADAM_THREADS) void k_adam_apply(float *p, const float *g, float *m, float *v, int64_t n,
                                                              const float *partials, const float *step, float lr_arg,
                                                              const float *lr_dev, float b1,
                                                              float b2, float eps, float max_norm, float gscale,
-                                                             float *norm_out, const GatherArgs *gather) {
+                                                             float *norm_out, const GatherArgs *gather, int npartials) {
   if (blockIdx.x >= ADAM_BLOCKS) {
     // extra blocks (gather != NULL): the NEXT minibatch's rows -> the static minibatch buffers, beside the parameter update.
     // Nothing of this step reads those buffers any more (stream order), k_adam_norm has already advanced mb_index, and the
@@ -229,7 +282,13 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_apply(float *p, const flo
   __shared__ float s_scale;
   {
     float s = 0.0f;
-    for (int i = (int)threadIdx.x; i < ADAM_BLOCKS; i += ADAM_THREADS) s += partials[i];
+    for (int i0 = (int)threadIdx.x; i0 < npartials; i0 += 8 * ADAM_THREADS) {   // (eight loads in flight: one round trip for <= 2048)
+      float pv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) pv[u] = (i0 + u * ADAM_THREADS < npartials) ? partials[i0 + u * ADAM_THREADS] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += pv[u];
+    }
     s = wave_sum_f(s);
     if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();

@@ -334,7 +334,7 @@ class FusedMinibatch:
         self.partials = f(self.lgroups, 8)
         self.gram_partials = f(self.lgroups, 38 * 38)
         self.out = f(8)
-        self.scratch = f(1024)
+        self.scratch = f(8192)   # norm partials: 1024 blocks + the finalize blocks that ride in the norm launch (single rank)
         self.nsplit = (B + 63) // 64                   # batch splits of the head's weight / bias gradient (brl_ppo_heads_bwd)
         self.dwh_partials = f(self.nsplit, K * H)
         self.dbh_partials = f(self.nsplit, K)
@@ -381,15 +381,13 @@ class FusedMinibatch:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side), torch.no_grad():
                 for _ in range(3):
-                    self._fwd_bwd()
-                    self._opt()
+                    self._step()
             torch.cuda.current_stream().wait_stream(side)
             nl = len(self.W)
             if self.world == 1:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph), torch.no_grad():
-                    self._fwd_bwd()
-                    self._opt()
+                    self._step()
                 self.graph = graph
                 # ... and the same step K times in ONE graph: a replay boundary costs ~5 us (graph launch behind the last
                 # kernel), the step ~0.3 ms; mb_index lives in device memory, so the K copies walk K minibatches
@@ -399,8 +397,7 @@ class FusedMinibatch:
                     gm = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gm), torch.no_grad():
                         for _ in range(self.multi):
-                            self._fwd_bwd()
-                            self._opt()
+                            self._step()
                     self.graph_multi = gm
             else:
                 # one graph per all-reduce bucket: forward + loss + head backward | each hidden layer's backward | bias
@@ -439,14 +436,17 @@ class FusedMinibatch:
         if first:
             self.capi.check(self.lib.brl_mb_gather_dev(di, self.gargs.data_ptr(), self.mbs, torch.cuda.current_stream().cuda_stream))
 
-    def _fwd_bwd(self):
+    def _step(self):
+        """one minibatch step on the current stream (what the graphs capture)"""
         self._seg_head()
         if self.world == 1:
             self._backward_chain()
+            self._fin_opt()       # sums of partials inside the norm launch, clip + Adam (+ the next gather)
         else:
             for l in range(len(self.W) - 1, -1, -1):
                 self._seg_layer(l)
-        self._seg_fin()
+            self._seg_fin()
+            self._opt()
 
     def _seg_head(self):
         """forward, heads + loss + output gradients (one launch), the logged statistics (parallel branch), backward of the
@@ -522,6 +522,17 @@ class FusedMinibatch:
         di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         self.capi.check(self.lib.brl_bias_finalize_ex(di, self._nseg, self._seg_scratch, self._seg_cols, self._seg_tiles,
                                                       self._seg_db, s))
+
+    def _fin_opt(self):
+        """single rank: every sum of partials is finished by extra workgroups of the norm launch (brl_adam_clip_fin_gather)"""
+        s = torch.cuda.current_stream().cuda_stream
+        di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        self.capi.check(self.lib.brl_adam_clip_fin_gather(di, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
+                                                          self.n, self.step.data_ptr(), self.lr, self.lr_dev.data_ptr(), float(self.b1),
+                                                          float(self.b2), self.eps, self.max_norm, self.scratch.data_ptr(),
+                                                          self.scratch.numel(), self.mb_index.data_ptr(), self.norm.data_ptr(),
+                                                          self.gargs.data_ptr(), self.mbs, self._nseg, self._seg_scratch, self._seg_cols,
+                                                          self._seg_tiles, self._seg_db, s))
 
     def _opt(self):
         s = torch.cuda.current_stream().cuda_stream

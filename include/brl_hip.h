@@ -483,6 +483,16 @@ int brl_bias_finalize_ex(int device, int nseg, const float *const *partials, con
 int brl_adam_clip_gather(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
                          const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale, float *scratch,
                          int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs, void *stream);
+/* brl_bias_finalize_ex + brl_adam_clip_gather as two launches instead of three (single rank: nothing sits between the finished
+ * sums and the clip): the `nseg` segments (arguments as brl_bias_finalize_ex) must be exactly the END of the gradient buffer g
+ * (the head's weight gradient + every bias gradient in FusedMinibatch's flat layout, up to the buffer's zero padding); the norm
+ * launch square-sums everything in front of them as it stands and finishes + square-sums the segments itself.  scratch: at
+ * least 1024 + sum over the segments of ceil(cols / 64) floats.  gather_args may be NULL (then mbs is ignored). */
+int brl_adam_clip_fin_gather(int device, float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
+                             const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float *scratch,
+                             int64_t scratch_len, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs,
+                             int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles, float *const *out,
+                             void *stream);
 
 #ifdef __cplusplus
 }

@@ -305,6 +305,16 @@ int brl_live_index(brl_handle *h, const uint8_t *terminated, int64_t n, int64_t 
   (void)h; (void)terminated; (void)n; (void)live; (void)finished; (void)s;
   NOT_HERE("brl_live_index");
 }
+int brl_adam_clip_fin_gather(int device, float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
+                             const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float *scratch,
+                             int64_t scratch_len, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs,
+                             int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles, float *const *out,
+                             void *s) {
+  (void)device; (void)p; (void)g; (void)m; (void)v; (void)n; (void)step; (void)lr; (void)lr_dev; (void)beta1; (void)beta2; (void)eps;
+  (void)max_norm; (void)scratch; (void)scratch_len; (void)mb_index; (void)norm_out; (void)gather_args; (void)mbs; (void)nseg;
+  (void)partials; (void)cols; (void)tiles; (void)out; (void)s;
+  NOT_HERE("brl_adam_clip_fin_gather");
+}
 int brl_eval_step(brl_handle *h, const uint64_t *si, uint64_t *so, int64_t n, const float *l1, int64_t s1, const float *l2,
                   int64_t s2, const brl_table_info *ta, const brl_table_info *tb, const brl_eval_stats *st, int bs,
                   float *cr, float *rs, int32_t *ao, uint8_t *o, uint8_t *m, float *r, uint8_t *t, int32_t *c, void *s) {
