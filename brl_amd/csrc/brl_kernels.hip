@@ -2734,6 +2734,34 @@ extern "C" int brl_act_bwd_colsum(int device, float *dh, const float *h, int64_t
   return BRL_OK;
 }
 
+extern "C" int brl_act_bwd_colsum_heads_dw(int device, float *dz, const float *hh, int64_t rows, int64_t cols, int64_t ld, int act,
+                                           float *scratch, const float *dheads, const float *h, int64_t ldh, int64_t batch,
+                                           int64_t hidden, int nsplit, float *dw_partials, float *db_partials,
+                                           const float *loss_partials, const float *gram_partials, int64_t ngroups,
+                                           const int32_t *row_index, float *stat_sums, float *gram_sums, void *stream) {
+  NEED(dz && hh && scratch && rows > 0 && cols > 0 && ld >= cols, "dz / h / scratch / rows / cols / ld");
+  NEED(cols % 4 == 0 && ld % 4 == 0, "cols and ld multiples of 4");
+  NEED(act == 0 || act == 1, "act (0 ReLU, 1 tanh)");
+  NEED(batch > 0 && hidden > 0 && hidden % 256 == 0 && ldh >= hidden && ldh % 4 == 0, "batch / hidden (a multiple of 256) / ldh");
+  NEED(dheads && h && dw_partials && db_partials, "NULL array");
+  NEED(nsplit >= 1 && (batch + nsplit - 1) / nsplit <= 64, "nsplit: at most 64 rows per split");
+  HIP_TRY(hipSetDevice(device));
+  HeadsBwdArgs A{};
+  A.dheads = dheads; A.h = h; A.ldh = ldh; A.B = batch; A.H = (int)hidden; A.act = act; A.nsplit = nsplit;
+  A.rows_per_split = (int)((batch + nsplit - 1) / nsplit);
+  A.dWh_partials = dw_partials; A.dbh_partials = db_partials;
+  A.blocks_a = (int)(hidden / HB_JT) * nsplit;
+  const bool sums = gram_sums != nullptr;
+  NEED(!sums || (loss_partials && gram_partials && ngroups > 0 && row_index && stat_sums), "statistics sums: partials / ngroups / row_index / stat_sums");
+  A.loss_partials = loss_partials; A.gram_partials = gram_partials; A.ngroups = (int)ngroups; A.row_index = row_index;
+  A.stat_sums = stat_sums; A.gram_sums = gram_sums;
+  const int gx = (int)((cols + 255) / 256), gy = (int)((rows + 15) / 16);
+  const unsigned blocks = (unsigned)(gx * gy + A.blocks_a + (sums ? HB_GRAM_BLOCKS : 0));
+  hipLaunchKernelGGL(k_relu_bwd_tiles4_heads_dw, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dz, hh, rows, cols, ld, scratch, act, gx, gy, A);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
 extern "C" int brl_bias_finalize_ex(int device, int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles,
                                     float *const *out, void *stream) {
   NEED(nseg >= 1 && nseg <= BIAS_MAX_SEGS && partials && cols && tiles && out, "nseg / partials / cols / tiles / out");
@@ -2802,7 +2830,8 @@ extern "C" int brl_ppo_heads_bwd(int device, const float *dheads, const float *h
                                  float *tile_sums, const float *loss_partials, const float *gram_partials, int64_t ngroups,
                                  const int32_t *row_index, float *stat_sums, float *gram_sums, void *stream) {
   NEED(batch > 0 && hidden > 0 && hidden % 256 == 0 && ldh >= hidden && ldh % 4 == 0, "batch / hidden (a multiple of 256) / ldh");
-  NEED(dheads && h && head_w && dw_partials && db_partials && dh && tile_sums, "NULL array");
+  NEED(dheads && h && head_w && dh && tile_sums && (!dw_partials == !db_partials), "NULL array");
+  const bool with_dw = dw_partials != nullptr;   // NULL: the weight-gradient role is launched elsewhere (brl_act_bwd_colsum_heads_dw)
   NEED(act == 0 || act == 1, "act (0 ReLU, 1 tanh)");
   NEED(nsplit >= 1 && (batch + nsplit - 1) / nsplit <= 64, "nsplit: at most 64 rows per split");
   HIP_TRY(hipSetDevice(device));
@@ -2811,14 +2840,15 @@ extern "C" int brl_ppo_heads_bwd(int device, const float *dheads, const float *h
   A.rows_per_split = (int)((batch + nsplit - 1) / nsplit);
   A.dWh_partials = dw_partials; A.dbh_partials = db_partials; A.dh = dh; A.tile_sums = tile_sums;
   A.blocks_a = (int)(hidden / HB_JT) * nsplit;
-  const bool sums = gram_sums != nullptr;
+  const bool sums = with_dw && gram_sums != nullptr;
   NEED(!sums || (loss_partials && gram_partials && ngroups > 0 && row_index && stat_sums), "statistics sums: partials / ngroups / row_index / stat_sums");
   A.loss_partials = loss_partials; A.gram_partials = gram_partials; A.ngroups = (int)ngroups; A.row_index = row_index;
   A.stat_sums = stat_sums; A.gram_sums = gram_sums;
   const int64_t blocks_b = (hidden / 256) * ((batch + HB_ROWS - 1) / HB_ROWS);
   // two launches (independent: back to back on the stream): the weight-gradient partials and the activation gradient
   hipLaunchKernelGGL(k_heads_bwd_dh, dim3((unsigned)blocks_b), dim3(256), 0, (hipStream_t)stream, A);
-  hipLaunchKernelGGL(k_heads_bwd_dw, dim3((unsigned)(A.blocks_a + (sums ? HB_GRAM_BLOCKS : 0))), dim3(256), 0, (hipStream_t)stream, A);
+  if (with_dw)
+    hipLaunchKernelGGL(k_heads_bwd_dw, dim3((unsigned)(A.blocks_a + (sums ? HB_GRAM_BLOCKS : 0))), dim3(256), 0, (hipStream_t)stream, A);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

@@ -322,17 +322,17 @@ struct HeadsBwdArgs {
 };
 constexpr int HB_GRAM_BLOCKS = 91;  // 91 x 256 threads >= 16 x (1444 Gram entries + 8 statistics)
 
-__global__ __launch_bounds__(256) void k_heads_bwd_dw(HeadsBwdArgs A) {
+__device__ __forceinline__ void heads_bwd_dw_block(const HeadsBwdArgs &A, const int block) {
   __shared__ __attribute__((aligned(16))) float dh_s[64][HD_NOUT + 1];   // d(heads) rows of this workgroup (pad: 40 floats)
   __shared__ __attribute__((aligned(16))) float h_s[64][64];             // the split's tile of h
   const int tid = (int)threadIdx.x;
-  if ((int)blockIdx.x >= A.blocks_a) {
+  if (block >= A.blocks_a) {
     // ---- extra workgroups: Gram matrix and statistics sums of this step.  Latency-bound (256 partial rows per entry at batch
     // 1024), so every entry is summed by SIXTEEN threads (a sixteenth of the rows each, all loads in flight), combined in a
     // fixed order: deterministic
     __shared__ float gs_part[256];
     const int64_t row = *A.row_index;
-    const int gid = ((int)blockIdx.x - A.blocks_a) * 256 + tid;
+    const int gid = (block - A.blocks_a) * 256 + tid;
     const int e = gid >> 4, part = gid & 15;
     const int chunk = (A.ngroups + 15) / 16, i0 = part * chunk, i1 = (i0 + chunk < A.ngroups) ? i0 + chunk : A.ngroups;
     float s = 0.0f;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void k_heads_bwd_dw(HeadsBwdArgs A) {
   }
   {
     // ---- role A: dW_h[n][j] = sum_b d(heads)[b][n] h[b][j] over this split's rows; thread = (column j, head group ng)
-    const int jt = (int)blockIdx.x % (A.H / HB_JT), sp = (int)blockIdx.x / (A.H / HB_JT);
+    const int jt = block % (A.H / HB_JT), sp = block / (A.H / HB_JT);
     const int64_t b0 = (int64_t)sp * A.rows_per_split;
     const int64_t left = A.B - b0;
     const int nb = (int)((left < A.rows_per_split) ? (left > 0 ? left : 0) : A.rows_per_split);
@@ -424,6 +424,18 @@ __global__ __launch_bounds__(256) void k_heads_bwd_dw(HeadsBwdArgs A) {
       A.dbh_partials[sp * HD_NOUT + tid] = s;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_heads_bwd_dw(HeadsBwdArgs A) { heads_bwd_dw_block(A, (int)blockIdx.x); }
+
+// The activation-derivative pass of a hidden layer (k_relu_bwd_tiles4: on the backward chain) with the head's weight-gradient
+// partials (k_heads_bwd_dw: NOT on the chain — nothing needs them before the sums at the end of the step) as extra workgroups of
+// the same launch: blocks [0, gx * gy) are the tiles of the former, the rest the blocks of the latter.
+__global__ __launch_bounds__(256) void k_relu_bwd_tiles4_heads_dw(float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld,
+                                                                   float *partials, int act, int gx, int gy, HeadsBwdArgs A) {
+  const int b = (int)blockIdx.x;
+  if (b < gx * gy) relu_bwd_tiles4_block(dh, h, rows, cols, ld, partials, act, b % gx, b / gx);
+  else heads_bwd_dw_block(A, b - gx * gy);
 }
 
 __global__ __launch_bounds__(256) void k_heads_bwd_dh(HeadsBwdArgs A) {

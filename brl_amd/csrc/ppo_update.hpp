@@ -101,11 +101,11 @@ __global__ __launch_bounds__(256) void k_relu_bwd_tiles(float *dh, const float *
 
 // the same for cols % 4 == 0 (the hidden layers): float4 accesses, 16-row tiles, a block covers 256 columns
 // act: 0 = ReLU (dz = dh where h > 0), 1 = tanh (dz = dh * (1 - h^2): src/models.py:16 `activation == "tanh"`)
-__global__ __launch_bounds__(256) void k_relu_bwd_tiles4(float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld,
-                                                          float *partials, int act = 0) {
+__device__ __forceinline__ void relu_bwd_tiles4_block(float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld,
+                                                      float *partials, int act, const int bx, const int by) {
   __shared__ float4 part[4][64];
   const int cg = (int)(threadIdx.x & 63u), rg = (int)(threadIdx.x >> 6);
-  const int64_t col = ((int64_t)blockIdx.x * 64 + cg) * 4, r0 = (int64_t)blockIdx.y * 16 + rg;
+  const int64_t col = ((int64_t)bx * 64 + cg) * 4, r0 = (int64_t)by * 16 + rg;
   const bool cv = col < cols;
   float4 d[4], hv[4];
   const int64_t cc = cv ? col : cols - 4;  // (cols % 4 == 0: see relu_tile_rows)
@@ -141,9 +141,14 @@ __global__ __launch_bounds__(256) void k_relu_bwd_tiles4(float *dh, const float 
   __syncthreads();
   if (rg == 0 && cv) {
     const float4 a = part[0][cg], b = part[1][cg], c = part[2][cg], e = part[3][cg];
-    *reinterpret_cast<float4 *>(partials + (int64_t)blockIdx.y * cols + col) =
+    *reinterpret_cast<float4 *>(partials + (int64_t)by * cols + col) =
         make_float4((a.x + b.x) + (c.x + e.x), (a.y + b.y) + (c.y + e.y), (a.z + b.z) + (c.z + e.z), (a.w + b.w) + (c.w + e.w));
   }
+}
+
+__global__ __launch_bounds__(256) void k_relu_bwd_tiles4(float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld,
+                                                          float *partials, int act = 0) {
+  relu_bwd_tiles4_block(dh, h, rows, cols, ld, partials, act, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 constexpr int BIAS_MAX_SEGS = 12;  // DeepMind_8: 8 hidden layers + the head

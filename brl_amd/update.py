@@ -482,8 +482,12 @@ class FusedMinibatch:
         # derivative applied) and its bias-gradient tile sums
         nl = len(self.W)
         top = nl - 1
+        # single rank, more than one hidden layer: the head's weight-gradient role (not on the backward chain) rides with the first
+        # activation-derivative launch of _backward_chain (brl_act_bwd_colsum_heads_dw); here only the activation-gradient role
+        self.dw_deferred = self.world == 1 and nl > 1
         chk(L.brl_ppo_heads_bwd(di, self.dheads.data_ptr(), x.data_ptr(), x.stride(0), self.Wh.data_ptr(), B, self.H, self.act,
-                                self.nsplit, self.dwh_partials.data_ptr(), self.dbh_partials.data_ptr(),
+                                self.nsplit, None if self.dw_deferred else self.dwh_partials.data_ptr(),
+                                None if self.dw_deferred else self.dbh_partials.data_ptr(),
                                 self.dhb[top].data_ptr(), self.tile_sums[nl - 1].data_ptr(), self.partials.data_ptr(),
                                 self.gram_partials.data_ptr(), self.lgroups, self.mb_index.data_ptr(), self.stat_sums.data_ptr(),
                                 self.gram_sums.data_ptr(), s))
@@ -511,6 +515,15 @@ class FusedMinibatch:
         nl = len(self.W)
         for l in range(nl - 1, 0, -1):
             torch.mm(self.dzs[l], self.W[l], out=self.dzs[l - 1])
+            if l == nl - 1 and self.dw_deferred:   # + the head's dW_h / db_h partials and the step's statistics sums
+                top = self.h[nl - 1]
+                chk(L.brl_act_bwd_colsum_heads_dw(di, self.dzs[l - 1].data_ptr(), self.h[l - 1].data_ptr(), B, self.H, self.H, self.act,
+                                                  self.tile_sums[l - 1].data_ptr(), self.dheads.data_ptr(), top.data_ptr(),
+                                                  top.stride(0), B, self.H, self.nsplit, self.dwh_partials.data_ptr(),
+                                                  self.dbh_partials.data_ptr(), self.partials.data_ptr(),
+                                                  self.gram_partials.data_ptr(), self.lgroups, self.mb_index.data_ptr(),
+                                                  self.stat_sums.data_ptr(), self.gram_sums.data_ptr(), s))
+                continue
             chk(L.brl_act_bwd_colsum(di, self.dzs[l - 1].data_ptr(), self.h[l - 1].data_ptr(), B, self.H, self.H, self.act,
                                      self.tile_sums[l - 1].data_ptr(), s))
         if nl > 1:

@@ -432,6 +432,7 @@ int brl_ppo_heads_loss_split(int device, const float *h, int64_t ldh, const floa
  * gram_sums != NULL: the same launches also add up brl_ppo_heads_loss's loss_partials float [ngroups,8] and gram_partials float
  * [ngroups,1444] (in group order) into row *row_index (device memory) of stat_sums float [rows,8] / gram_sums float [rows,1444]:
  * the statistics of a whole update are then formed by ONE brl_ppo_stats_rows at its end instead of a launch per step. */
+/* (dw_partials = db_partials = NULL: only the activation-gradient role is launched — see brl_act_bwd_colsum_heads_dw) */
 int brl_ppo_heads_bwd(int device, const float *dheads, const float *h, int64_t ldh, const float *head_w, int64_t batch,
                       int64_t hidden, int act, int nsplit, float *dw_partials, float *db_partials, float *dh, float *tile_sums,
                       const float *loss_partials, const float *gram_partials, int64_t ngroups, const int32_t *row_index,
@@ -469,6 +470,15 @@ int brl_mb_gather_dev(int device, const void *args_dev, int64_t mbs, void *strea
  * column sums of every 16-row tile into scratch float [ceil(rows / 16), cols]; cols and ld multiples of 4. */
 int brl_act_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, int act, float *scratch,
                        void *stream);
+/* brl_act_bwd_colsum of ONE hidden layer with the weight-gradient role of brl_ppo_heads_bwd (dW_h / db_h partials + the step's
+ * statistics / Gram sums; arguments as there) as extra workgroups of the same launch.  That role is not on the backward chain —
+ * nothing needs its outputs before the sums at the end of the step — so it rides with a launch that is: call brl_ppo_heads_bwd
+ * with dw_partials = db_partials = NULL (activation-gradient role only), then this for the first layer below the top. */
+int brl_act_bwd_colsum_heads_dw(int device, float *dz, const float *hh, int64_t rows, int64_t cols, int64_t ld, int act,
+                                float *scratch, const float *dheads, const float *h, int64_t ldh, int64_t batch, int64_t hidden,
+                                int nsplit, float *dw_partials, float *db_partials, const float *loss_partials,
+                                const float *gram_partials, int64_t ngroups, const int32_t *row_index, float *stat_sums,
+                                float *gram_sums, void *stream);
 
 /* brl_bias_finalize with the tile count of every segment given: out[i][c] = sum_{t < tiles[i]} partials[i][t * cols[i] + c],
  * in order, for nseg <= 12 segments (bias gradients of the layers, and the head's weight / bias gradients from

@@ -315,6 +315,16 @@ int brl_adam_clip_fin_gather(int device, float *p, float *g, float *m, float *v,
   (void)partials; (void)cols; (void)tiles; (void)out; (void)s;
   NOT_HERE("brl_adam_clip_fin_gather");
 }
+int brl_act_bwd_colsum_heads_dw(int device, float *dz, const float *hh, int64_t rows, int64_t cols, int64_t ld, int act,
+                                float *scratch, const float *dheads, const float *h, int64_t ldh, int64_t batch, int64_t hidden,
+                                int nsplit, float *dw_partials, float *db_partials, const float *loss_partials,
+                                const float *gram_partials, int64_t ngroups, const int32_t *row_index, float *stat_sums,
+                                float *gram_sums, void *s) {
+  (void)device; (void)dz; (void)hh; (void)rows; (void)cols; (void)ld; (void)act; (void)scratch; (void)dheads; (void)h; (void)ldh;
+  (void)batch; (void)hidden; (void)nsplit; (void)dw_partials; (void)db_partials; (void)loss_partials; (void)gram_partials;
+  (void)ngroups; (void)row_index; (void)stat_sums; (void)gram_sums; (void)s;
+  NOT_HERE("brl_act_bwd_colsum_heads_dw");
+}
 int brl_eval_step(brl_handle *h, const uint64_t *si, uint64_t *so, int64_t n, const float *l1, int64_t s1, const float *l2,
                   int64_t s2, const brl_table_info *ta, const brl_table_info *tb, const brl_eval_stats *st, int bs,
                   float *cr, float *rs, int32_t *ao, uint8_t *o, uint8_t *m, float *r, uint8_t *t, int32_t *c, void *s) {
