@@ -2401,9 +2401,20 @@ extern "C" int brl_obs_cast_rows(brl_handle *h, const uint8_t *obs, const int64_
 __global__ __launch_bounds__(1024) void k_live_index(const uint8_t *terminated, int64_t n, int64_t *live, int64_t *finished) {
   __shared__ int64_t part[1024];
   const int tid = (int)threadIdx.x;
-  const int64_t per = (n + 1023) / 1024, a = (int64_t)tid * per, b = (a + per < n) ? a + per : n;
+  // (a thread's run of boards, rounded up to 8 so that the flags can be read 8 at a time: one load instead of a chain of byte loads)
+  const int64_t per = ((n + 1023) / 1024 + 7) / 8 * 8, a0 = (int64_t)tid * per, a = (a0 < n) ? a0 : n, b = (a + per < n) ? a + per : n;
+  const bool wide = (reinterpret_cast<uintptr_t>(terminated) & 7u) == 0;
   int64_t c = 0;
-  for (int64_t i = a; i < b; i++) c += terminated[i] ? 0 : 1;
+  for (int64_t i = a; i < b; i += 8) {
+    if (wide && i + 8 <= b) {
+      const uint64_t f = *reinterpret_cast<const uint64_t *>(terminated + i);
+      // bytes are 0 / 1 (bool) or any non-zero: count the zero bytes
+      uint64_t nz = f | (f >> 4); nz |= nz >> 2; nz |= nz >> 1; nz &= 0x0101010101010101ull;
+      c += 8 - __popcll(nz);
+    } else {
+      for (int64_t k = i; k < b && k < i + 8; k++) c += terminated[k] ? 0 : 1;
+    }
+  }
   part[tid] = c;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan
