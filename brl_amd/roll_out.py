@@ -193,7 +193,7 @@ class _PolicyRollout:
         return parts if parts is not None else snap.hidden(obs, x)
 
     def _head_ext(self, snap, h, **kw):
-        if h.dtype == torch.float32:   # [parts, n, ld] partial products (models.InferenceSnapshot.head_parts)
+        if h.dim() == 3:   # [parts, n, ld] fp32 partial products (models.InferenceSnapshot.head_parts)
             return _capi.MacroExt(head_part=h.data_ptr(), head_part_stride=h.stride(0), head_part_ld=h.stride(1),
                                   head_nparts=h.shape[0], head_b=snap.head_bf.data_ptr(), **kw)
         return _capi.MacroExt(head_h=h.data_ptr(), head_ldh=h.stride(0), head_w=snap.head_wt.data_ptr(), head_b=snap.head_bf.data_ptr(),
