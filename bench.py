@@ -113,7 +113,36 @@ def cpu_baseline(keys, values, budget_s: float = 12.0):
             times.append(time.perf_counter() - t0)
             draw += NUM_STEPS
         med = float(np.median(times))
-        return {"value": NUM_ENVS * NUM_STEPS / med, "unit": "macro-steps/s", "cores": threads, "kind": "port",
+        # BASELINE.md §3 lists both sizes: configs[0] (num_envs=128, the reference's own CPU-runnable case) beside configs[1]
+        try:
+            n0 = 128
+            st0 = orc.init_random(n0, seed=0)
+            best0 = (float("inf"), 1)
+            for cand in sorted({c for c in (1, 2, 4, 8, 16, 32) if c <= affinity}):   # 128 tables: a small team wins
+                gomp.omp_set_num_threads(cand)
+                ts = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    orc.rollout_random(st0, NUM_STEPS, seed=0, draw_base=draw)
+                    ts.append(time.perf_counter() - t0)
+                    draw += NUM_STEPS
+                best0 = min(best0, (min(ts[1:]), cand))
+            gomp.omp_set_num_threads(best0[1])
+            t0s = []
+            t_end0 = time.perf_counter() + 2.0
+            while len(t0s) < 10 or (time.perf_counter() < t_end0 and len(t0s) < 2000):
+                t0 = time.perf_counter()
+                orc.rollout_random(st0, NUM_STEPS, seed=0, draw_base=draw)
+                t0s.append(time.perf_counter() - t0)
+                draw += NUM_STEPS
+            med0 = float(np.median(t0s))
+            config0 = {"value": n0 * NUM_STEPS / med0, "unit": "macro-steps/s", "cores": best0[1], "num_envs": n0,
+                       "num_steps": NUM_STEPS, "ms_per_rollout": med0 * 1e3,
+                       "sample": f"configs[0]: {len(t0s)} rollouts of num_envs={n0} x num_steps={NUM_STEPS}, median, same library"}
+        except Exception as e:
+            config0 = {"value": None, "sample": f"failed: {e}"}
+        gomp.omp_set_num_threads(threads)
+        return {"value": NUM_ENVS * NUM_STEPS / med, "unit": "macro-steps/s", "cores": threads, "kind": "port", "config0": config0,
                 "cpu_model": cpu_model(), "flags": flags, "cpus_in_affinity_mask": affinity,
                 "raw_env_steps_per_s": NUM_ENVS * NUM_STEPS / med,   # configs[1]: one env.step per macro-step
                 "sample": f"3 warm-ups, then {len(times)} rollouts of num_envs={NUM_ENVS} x num_steps={NUM_STEPS} (random policy, "
@@ -598,7 +627,7 @@ def bench_secondary(torch, dev):
     def do_update():
         ubox["rs"], info = update_step(ubox["rs"], traj32, adv, tgt)
         return info
-    t_upd, _ = timed(do_update, 1)
+    t_upd, _ = timed(do_update, 3)
     nmb = cfg32["update_epochs"] * cfg32["num_minibatches"]
     uflop = 3 * rows * fwd_flop * cfg32["update_epochs"]
     graphed = ubox["rs"][1].get("graphed")
@@ -607,13 +636,85 @@ def bench_secondary(torch, dev):
                         "mfma_frac": uflop / t_upd / 1e12 / 157.3, "dtype": "fp32",
                         "path": type(graphed).__name__ if graphed else "eager: " + str(ubox["rs"][1].get("graph_error")),
                         "what": "10 epochs x 256 minibatches of 1024 samples: forward + backward + global-norm clip + Adam"}
+    # ---- configs[4] rehearsal on ONE GPU: the compute side of a rank's minibatch step under a process group (world = 2
+    # semantics: graph segments, sums of partials as their own launch, grad_scale), the all-reduce replaced by a no-op with
+    # the same stream ordering (side stream waits for the segment, the Adam graph waits for the side stream)
+    try:
+        out["config4_rehearsal"] = rehearse_multirank(torch, dev, cfg32, fp, traj32, adv, tgt, phases["update"]["ms_per_minibatch"])
+    except Exception as e:
+        out["config4_rehearsal"] = {"error": repr(e)}
+
+    # ---- the evaluations ppo.py runs EVERY iteration around those three phases (ppo.py:366-381, 461-484; self_play): one
+    # simple_evaluate + three simple_duplicate_evaluate (imp_opp, imp_opp_before, imp_opp_after) at num_eval_envs = 10000, fp32
+    from brl_amd.evaluation import make_simple_evaluate
+    n_eval = int(DEFAULTS.get("num_eval_envs", 10000))
+    opp = fp.init(1, device=dev)
+    simple = make_simple_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", opp, n_eval)
+    dup_eval = make_simple_duplicate_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", n_eval)
+    t_simple, _ = timed(lambda: simple(team1, 7), 3)
+    t_dup, _ = timed(lambda: dup_eval(team1, opp, 7), 3)
+    phases["evaluators"] = {"ms": (t_simple + 3 * t_dup) * 1e3, "simple_evaluate_ms": t_simple * 1e3,
+                            "simple_duplicate_evaluate_ms": t_dup * 1e3, "num_eval_envs": n_eval, "dtype": "fp32",
+                            "what": "per iteration (ppo.py:366-381,461-484, self_play): jit_simple_evaluate + 3 x "
+                                    "jit_simple_duplicate_evaluate; the full duplicate evaluation with statistics runs every "
+                                    "num_eval_step iterations only and is not included"}
     it32 = phases["rollout_fp32"]["ms"] + phases["calc_gae"]["ms"] + phases["update"]["ms"]
     it16 = phases["rollout_bf16"]["ms"] + phases["calc_gae"]["ms"] + phases["update"]["ms"]
+    full32 = it32 + phases["evaluators"]["ms"]
     out["config3"] = dict(phases, workload="configs[3]: ppo.py iteration at num_envs=8192, num_steps=32, minibatch 1024, "
                                            "10 epochs, DeepMind MLP",
                           iteration_ms_fp32=it32, iteration_macro_steps_per_s_fp32=rows / (it32 * 1e-3),
+                          evaluators_ms=phases["evaluators"]["ms"],
+                          iteration_ms_fp32_full=full32, iteration_macro_steps_per_s_fp32_full=rows / (full32 * 1e-3),
                           iteration_ms_bf16_rollout=it16, iteration_macro_steps_per_s_bf16_rollout=rows / (it16 * 1e-3))
     return out
+
+
+def rehearse_multirank(torch, dev, cfg, fp, traj, adv, tgt, single_ms):
+    """ms per minibatch step of FusedMinibatch as a rank of a multi-GPU job runs it, measured on one GPU: both all-reduce
+    modes of config["grad_allreduce"], 256 steps (one epoch of 8192 x 32 at minibatch 1024), collectives = no-ops that keep
+    the event edges of an asynchronous RCCL collective (what crosses xGMI is NOT in this number — DESIGN §7 adds it)."""
+    from brl_amd.roll_out import Transition
+    from brl_amd.update import FusedMinibatch, make_optimizer
+    rows = NUM_ENVS * NUM_STEPS
+    flat = Transition(*[x.reshape((rows,) + x.shape[2:]) for x in traj])
+    adv_f, tgt_f = adv.reshape(rows), tgt.reshape(rows)
+    side = torch.cuda.Stream()
+
+    class _Work:
+        def wait(self):
+            torch.cuda.current_stream().wait_stream(side)
+
+    def noop_allreduce(t, async_op):
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)          # the collective starts behind the segment that produced its bucket
+        if async_op:
+            return _Work()
+        cur.wait_stream(side)          # a blocking collective: the next graph waits for it
+
+    res = {"what": "one rank's minibatch step under world = 2 semantics on one GPU, all-reduce = no-op with the same stream "
+                   "ordering; 256 steps, median of 3; ring traffic per step and rank at world 8: 2 * 7/8 * 14.7 MB = 25.8 MB",
+           "single_rank_ms_per_minibatch": single_ms}
+    for mode in ("flat", "bucketed"):
+        net = fp.init(0, device=dev)
+        opt = make_optimizer(cfg, net)["opt"]
+        fm = FusedMinibatch(dict(cfg, grad_allreduce=mode), net, opt, 1024, dev, world=2, collective=noop_allreduce)
+        ts = []
+        for rep in range(4):
+            perms = [torch.randperm(rows, device=dev)]
+            fm.begin_update(flat, adv_f, tgt_f, perms)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fm.run_steps(rows // 1024)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+            fm.end_update()
+        t = float(np.median(ts[1:]))
+        res[mode] = {"ms_per_minibatch": t / (rows // 1024) * 1e3, "graphs_per_step": len(fm.segs),
+                     "collectives_per_step": 1 if mode == "flat" else len([b for b in fm.buckets if b is not None]),
+                     "overhead_vs_single_rank_ms": t / (rows // 1024) * 1e3 - single_ms}
+        del fm, net, opt
+    return res
 
 
 def bench_ppo(args, torch, dev, rank, world, barrier, max_over_ranks):
@@ -632,7 +733,8 @@ def bench_ppo(args, torch, dev, rank, world, barrier, max_over_ranks):
         if os.environ.get("BRL_TUNABLEOP_FILE"):
             torch.cuda.tunable.set_filename(os.environ["BRL_TUNABLEOP_FILE"])
     cfg = dict(DEFAULTS, num_envs=NUM_ENVS, num_steps=NUM_STEPS, minibatch_size=1024, update_epochs=10,
-               inference_dtype=os.environ.get("BRL_INFER_DTYPE", "bf16"), graph_rollout=True)
+               inference_dtype=(os.environ.get("BRL_INFER_DTYPE", "fp32").replace("fp32", "") or None), graph_rollout=True)
+    # (default = the reference's fp32 forwards; BRL_INFER_DTYPE=bf16 / fp16 = the opt-in, narrower inference path)
     cfg["num_minibatches"] = cfg["num_envs"] * cfg["num_steps"] // cfg["minibatch_size"]
     keys, values = synthetic_lut(LUT_LEN, 0)
     env = brl_amd.BridgeBidding(lut=(keys, values), device=dev, env_offset=rank * NUM_ENVS)
@@ -675,7 +777,7 @@ def bench_ppo(args, torch, dev, rank, world, barrier, max_over_ranks):
         "metric": "ppo.py iteration macro-steps/sec at num_envs=8192, num_steps=32, minibatch 1024, 10 epochs (secondary, configs[3])",
         "value": world * rows * iters / elapsed, "unit": "macro-steps/s", "n_gpus": world, "steps": iters, "warmup": 1,
         "ms_per_step": elapsed / iters * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": f"rollout inference {cfg['inference_dtype']}, update fp32", "data": "synthetic",
+        "dtype": f"rollout inference {cfg['inference_dtype'] or 'fp32'}, update fp32", "data": "synthetic",
         "config": {"workload": "configs[3]: roll_out (policy in the loop, competitive) + calc_gae + update_step",
                    "num_envs_per_gpu": NUM_ENVS, "num_steps": NUM_STEPS, "minibatch_size": 1024, "update_epochs": 10,
                    "graph_rollout": True},

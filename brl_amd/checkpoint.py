@@ -99,6 +99,8 @@ class _HaikuUnpickler(pickle.Unpickler):
 
 _SAFE_GLOBALS = frozenset(
     [(m, n) for m in ("numpy.core.multiarray", "numpy._core.multiarray") for n in ("_reconstruct", "scalar")]
+    + [("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),   # ndarray.__reduce_ex__ under protocol 5
+       ("_codecs", "encode")]                                                           # array bytes under protocol <= 2
     + [("numpy", "ndarray"), ("numpy", "dtype"), ("collections", "OrderedDict"), ("builtins", "dict"), ("builtins", "list"),
        ("builtins", "tuple"), ("builtins", "set"), ("builtins", "frozenset")])
 

@@ -416,10 +416,12 @@ def make_evaluate_log(log_info):
 
 
 def make_simple_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_type, team2_activation,
-                         team2_model_type, team2_params, num_eval_envs, sync_every: int = 8, shard=None):
+                         team2_model_type, team2_params, num_eval_envs, sync_every: int = 8, shard=None,
+                         record_actions=None):
     """src/evaluation.py:11-66: actor (greedy) vs a fixed opponent (greedy) on single tables, no
     auto-reset; returns the mean total reward of the acting player.  ``team2_params`` replaces the
-    reference's pickle path (model files are torch modules here)."""
+    reference's pickle path (model files are torch modules here).  ``record_actions``: optional list that receives,
+    per loop iteration, the four calls of the macro-step as [4, n] (tests replay them through the oracle)."""
     actor_forward_pass = make_forward_pass(team1_activation, team1_model_type)
     opp_forward_pass = make_forward_pass(team2_activation, team2_model_type)
 
@@ -427,6 +429,8 @@ def make_simple_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_
         step_fn = single_play_step_two_policy_commpetitive_deterministic(
             step_fn=eval_env.step, actor_forward_pass=actor_forward_pass, actor_params=actor_params,
             opp_forward_pass=opp_forward_pass, opp_params=team2_params)
+        subs = [] if record_actions is not None else None
+        step_fn.record_actions = subs
         sh = _Shard(num_eval_envs, shard)
         with torch.no_grad():
             state = sh.init(eval_env, rng)
@@ -438,6 +442,9 @@ def make_simple_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_
                 logits, _ = actor_forward_pass.apply(actor_params, state.observation.to(torch.float32))
                 action = masked_mode(logits, state.legal_action_mask)
                 state = step_fn(state, action, it * 4)
+                if subs is not None:
+                    record_actions.append(torch.stack([action.to(torch.int32)] + subs))
+                    subs.clear()
                 R += state.rewards.gather(1, actor[:, None])[:, 0]   # src/evaluation.py:60
                 watch.post(it, state.terminated)
                 it += 1

@@ -278,14 +278,18 @@ class _PolicyRollout:
                 self._macro_step(t)
         torch.cuda.current_stream().wait_stream(side)
         pool = torch.cuda.graph_pool_handle()
-        self.graphs = []
+        graphs = []
+        import torch.distributed as dist
+        # (under a process group the NCCL watchdog thread touches the device while this thread captures)
+        gkw = {"capture_error_mode": "thread_local"} if (dist.is_available() and dist.is_initialized()) else {}
         with torch.no_grad():
             for t0 in range(0, self.T, self.graph_steps):   # (a replay boundary costs ~8 us of idle GPU: several scan steps per graph)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
+                with torch.cuda.graph(g, pool=pool, **gkw):
                     for t in range(t0, min(t0 + self.graph_steps, self.T)):
                         self._macro_step(t)
-                self.graphs.append(g)
+                graphs.append(g)
+        self.graphs = graphs
 
     def _load(self, env_state, last_obs, terminated_count, rng):
         traj = self.traj
@@ -308,9 +312,16 @@ class _PolicyRollout:
             self._bind(params, opp_params)
             if self.static and self.graphs is None:
                 self._load(env_state, last_obs, terminated_count, rng)
-                self._capture()
+                try:
+                    self._capture()
+                except Exception as e:   # capture is an optimisation: the same macro-steps run eagerly on the static buffers
+                    import warnings
+                    self.graphs = False
+                    self.graph_error = repr(e)
+                    warnings.warn(f"brl_amd.roll_out: hipGraph capture of the rollout failed ({e!r}); the macro-steps run "
+                                  f"eagerly (host-launch-bound, slower).", RuntimeWarning)
             self._load(env_state, last_obs, terminated_count, rng)
-            if self.static:
+            if self.static and self.graphs:
                 for g in self.graphs:
                     g.replay()
             else:

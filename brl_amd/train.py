@@ -136,6 +136,18 @@ def linear_schedule(config, count):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+def _weight_delta(a: torch.nn.Module, b) -> float:
+    """max |actor - opponent| over the parameters (a log field of this build): NaN when the two trees differ in shape (e.g. a FAIR
+    opponent of a DeepMind actor) or are the same object; ONE reduction and one host read, whatever the number of tensors"""
+    if b is a or not isinstance(b, torch.nn.Module):
+        return float("nan")
+    pa, pb = list(a.parameters()), list(b.parameters())
+    if len(pa) != len(pb) or any(x.shape != y.shape for x, y in zip(pa, pb)):
+        return float("nan")
+    with torch.no_grad():
+        return float(torch.stack([(x - y).abs().max() for x, y in zip(pa, pb)]).max())
+
+
 def train(config, log=print):
     import torch.distributed as dist
 
@@ -313,9 +325,7 @@ def train(config, log=print):
             "train/imp_opp_before": imp_before, "train/imp_opp_after": imp_after, "board_num": board_num, "steps": steps,
             # build-side extras
             "update": i, "opponent": opp_name,
-            "opp_weight_delta": max(float((a.detach() - b.detach()).abs().max()) for a, b in
-                                    zip(runner_state[0].parameters(), opp_params.parameters()))
-            if opp_params is not runner_state[0] and config["actor_model_type"] == config["opp_model_type"] else float("nan"), "hash_table": train_files[rotation.current],
+            "opp_weight_delta": _weight_delta(runner_state[0], opp_params), "hash_table": train_files[rotation.current],
             "eval_s": t0 - t_eval, "rollout_s": t1 - t0, "gae_s": t2 - t1, "update_s": t3 - t2,
             "macro_steps_per_s": config["num_envs"] * config["num_steps"] * world / (t3 - t0)})
         if rotation.advance(board_num):                                                               # ppo.py:525-549 (G14)

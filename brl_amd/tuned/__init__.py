@@ -15,7 +15,9 @@ _state = {"on": False}
 
 def enable(tuning: bool = False, path: str = PATH) -> bool:
     """Use the committed solutions for the GEMMs issued from now on (lookups only; `tuning`: also time unknown shapes once).
-    Returns False when the file is missing or TunableOp is unavailable."""
+    Returns False when the file is missing, belongs to another PyTorch / ROCm / hipBLASLt stack, or TunableOp is unavailable.
+    NOTE: TunableOp is a PROCESS-GLOBAL torch switch — once on, every GEMM of the host process (user code included) is looked
+    up in the table; shapes that are not in it keep the default heuristics (lookups only, nothing is timed or written)."""
     import torch
     if not (torch.cuda.is_available() and hasattr(torch.cuda, "tunable")) or (not tuning and not os.path.exists(path)):
         return False
@@ -30,8 +32,11 @@ def enable(tuning: bool = False, path: str = PATH) -> bool:
         t.set_filename(path)   # (only a tuning run may write: lookups never touch the committed file)
     if os.path.exists(path):
         try:
-            t.read_file(path)
-        except Exception:   # a file of another stack: ignored, the default heuristics stay
+            ok = t.read_file(path)   # False (not an exception) when the file's validators name another stack
+        except Exception:
+            ok = False
+        if not ok and not tuning:    # nothing usable: TunableOp off again, the default heuristics stay
+            t.enable(False)
             return False
     _state["on"] = True
     return True

@@ -249,12 +249,24 @@ class FusedMinibatch:
                 and params.body[0].weight.shape[0] % 256 == 0
                 and next(params.parameters()).is_cuda and next(params.parameters()).dtype == torch.float32)
 
-    def __init__(self, config, params, opt, mbs: int, device, world: int = 1):
+    def __init__(self, config, params, opt, mbs: int, device, world: int = 1, log_capacity: int = 0, collective=None):
         from . import _capi
         self.cfg, self.params, self.opt, self.mbs, self.dev = config, params, opt, int(mbs), device
-        # world > 1: the step is captured in segments, one per all-reduce bucket (see the capture below): ppo.py's pmean as
-        # collectives of <= 4.2 MB that overlap with the rest of the backward pass (RCCL over xGMI on MI355X)
+        # world > 1, config["grad_allreduce"]:
+        #   "flat" (default): the step is TWO graphs — forward + the single-rank backward chain + the sums of partials | clip +
+        #       Adam — with ONE all-reduce of the flat 14.7 MB gradient between them (ppo.py's pmean); the collective is exposed
+        #       (nothing overlaps it), the compute side keeps every single-rank fusion but the sums-inside-the-norm launch;
+        #   "bucketed": one graph per all-reduce bucket (see the capture below): collectives of <= 4.2 MB issued asynchronously
+        #       behind their segment, overlapping the rest of the backward pass (RCCL over xGMI on MI355X).  Opt-in until it has
+        #       run over RCCL on >= 2 GPUs (tests/test_gpu_parity.py::*_rccl; every box of this build so far had one GPU).
+        # `collective`: None = torch.distributed.all_reduce; a callable (tensor, async_op) -> work-or-None replaces it (bench.py's
+        # one-GPU rehearsal of the multi-rank step: a no-op with the same stream ordering).
         self.world = int(world)
+        self.allreduce_mode = str(config.get("grad_allreduce", "flat")) if self.world > 1 else "none"
+        if self.allreduce_mode not in ("none", "flat", "bucketed"):
+            raise ValueError("config['grad_allreduce'] must be 'flat' or 'bucketed'")
+        self.single_chain = self.allreduce_mode != "bucketed"   # the dz chain first, then the batched weight gradients
+        self._collective = collective
         if config.get("tuned_gemm", True):   # committed TunableOp solutions for the step's GEMM shapes (brl_amd/tuned): lookups only
             from . import tuned
             tuned.enable()
@@ -352,7 +364,8 @@ class FusedMinibatch:
         # the 38 x 38 Gram matrix of the illegal-action probabilities, reduced by spare workgroups of the head-backward
         # launch — in row mb_index of these buffers, and ONE launch at the end of the update turns all rows into log rows
         # (a per-step statistics kernel on a parallel graph branch cost ~20 us of fork / join per step, 7 % of the update).
-        self._log_cap = int(config.get("update_log_capacity", 4096))    # minibatch steps of one update_step call
+        # (rows = minibatch steps of one update_step call; update_step rebuilds this object when an update needs more)
+        self._log_cap = max(int(config.get("update_log_capacity", 4096)), int(log_capacity))
         self.log = f(self._log_cap, 8)
         self.stat_sums = f(self._log_cap, 8)
         self.gram_sums = f(self._log_cap, 38 * 38)
@@ -384,9 +397,12 @@ class FusedMinibatch:
                     self._step()
             torch.cuda.current_stream().wait_stream(side)
             nl = len(self.W)
+            # under a process group the NCCL watchdog thread queries events while this thread captures: "global" capture mode
+            # would turn that into a capture error
+            gkw = {"capture_error_mode": "thread_local"} if (dist.is_available() and dist.is_initialized()) else {}
             if self.world == 1:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph), torch.no_grad():
+                with torch.cuda.graph(graph, **gkw), torch.no_grad():
                     self._step()
                 self.graph = graph
                 # ... and the same step K times in ONE graph: a replay boundary costs ~5 us (graph launch behind the last
@@ -395,10 +411,20 @@ class FusedMinibatch:
                 self.graph_multi = None
                 if self.multi > 1:
                     gm = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gm), torch.no_grad():
+                    with torch.cuda.graph(gm, **gkw), torch.no_grad():
                         for _ in range(self.multi):
                             self._step()
                     self.graph_multi = gm
+            elif self.allreduce_mode == "flat":
+                pool = torch.cuda.graph_pool_handle()
+                self.segs = []
+                for seg in (self._grads, self._opt):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool, **gkw), torch.no_grad():
+                        seg()
+                    self.segs.append(g)
+                self.buckets = [self.G]
+                self.graph = self.segs[0]
             else:
                 # one graph per all-reduce bucket: forward + loss + head backward | each hidden layer's backward | bias
                 # gradients | clip + Adam; the bucket's all-reduce is issued (async) behind its graph and overlaps with
@@ -408,7 +434,7 @@ class FusedMinibatch:
                 for seg in [lambda: self._seg_head()] + [(lambda l=l: self._seg_layer(l)) for l in range(nl - 1, -1, -1)] \
                         + [lambda: self._seg_fin(), lambda: self._opt()]:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=pool), torch.no_grad():
+                    with torch.cuda.graph(g, pool=pool, **gkw), torch.no_grad():
                         seg()
                     self.segs.append(g)
                 # (the head's weight gradient is finished by _seg_fin, beside the bias gradients: contiguous in the flat buffer)
@@ -438,15 +464,26 @@ class FusedMinibatch:
 
     def _step(self):
         """one minibatch step on the current stream (what the graphs capture)"""
-        self._seg_head()
         if self.world == 1:
+            self._seg_head()
             self._backward_chain()
             self._fin_opt()       # sums of partials inside the norm launch, clip + Adam (+ the next gather)
+        elif self.allreduce_mode == "flat":
+            self._grads()
+            self._opt()
         else:
+            self._seg_head()
             for l in range(len(self.W) - 1, -1, -1):
                 self._seg_layer(l)
             self._seg_fin()
             self._opt()
+
+    def _grads(self):
+        """multi-rank "flat" form, first graph: everything that produces this rank's gradient — the single-rank chain with the
+        sums of partials as a launch of their own (they must exist before the all-reduce)"""
+        self._seg_head()
+        self._backward_chain()
+        self._seg_fin()
 
     def _seg_head(self):
         """forward, heads + loss + output gradients (one launch), the logged statistics (parallel branch), backward of the
@@ -484,7 +521,7 @@ class FusedMinibatch:
         top = nl - 1
         # single rank, more than one hidden layer: the head's weight-gradient role (not on the backward chain) rides with the first
         # activation-derivative launch of _backward_chain (brl_act_bwd_colsum_heads_dw); here only the activation-gradient role
-        self.dw_deferred = self.world == 1 and nl > 1
+        self.dw_deferred = self.single_chain and nl > 1
         chk(L.brl_ppo_heads_bwd(di, self.dheads.data_ptr(), x.data_ptr(), x.stride(0), self.Wh.data_ptr(), B, self.H, self.act,
                                 self.nsplit, None if self.dw_deferred else self.dwh_partials.data_ptr(),
                                 None if self.dw_deferred else self.dbh_partials.data_ptr(),
@@ -561,13 +598,15 @@ class FusedMinibatch:
     def begin_update(self, flat: Transition, adv_f, tgt_f, perms):
         """flat: the [T*N, ...] views of the trajectory; adv_f / tgt_f: [T*N]; perms: one permutation of T*N per epoch.
         Binds the step's gather to them (device-resident arguments) and resets the minibatch counter."""
+        steps = sum(p.numel() for p in perms) // self.mbs
+        if steps > self._log_cap:   # (checked before anything is touched; update_step never gets here: it rebuilds first)
+            raise RuntimeError("FusedMinibatch: more minibatch steps per update than its log holds (log_capacity)")
         self._keep = (Transition(*[x.contiguous() for x in flat]), adv_f.contiguous(), tgt_f.contiguous())
         fl, adv_c, tgt_c = self._keep
-        self._steps = sum(p.numel() for p in perms) // self.mbs
+        self._steps = steps
         with torch.no_grad():
             self._readopt()
-            if self._steps > self._log_cap:
-                raise RuntimeError("FusedMinibatch: more minibatch steps per update than config['update_log_capacity']")
+            assert self._steps <= self._log_cap, "update_step sizes the log (log_capacity) before it binds an update"
             allp = torch.cat(perms)
             if self.perm is None or self.perm.numel() != allp.numel():
                 self.perm = torch.empty_like(allp)
@@ -608,14 +647,23 @@ class FusedMinibatch:
             for _ in range(n):
                 self.graph.replay()
             return
+        ar = self._collective if self._collective is not None else \
+            (lambda t, async_op: dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op))
+        if self.allreduce_mode == "flat":
+            for _ in range(n):
+                self.segs[0].replay()
+                ar(self.G, False)                                     # brl_adam_clip divides by world (grad_scale)
+                self.segs[1].replay()
+            return
         for _ in range(n):
             works = []
             for g, bucket in zip(self.segs[:-1], self.buckets):      # brl_adam_clip divides by world (grad_scale)
                 g.replay()
                 if bucket is not None:
-                    works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
+                    works.append(ar(bucket, True))
             for w in works:
-                w.wait()
+                if w is not None:
+                    w.wait()
             self.segs[-1].replay()
 
     def end_update(self):
@@ -659,15 +707,25 @@ def make_update_step(config, actor_forward_pass, optimizer=None):
         graphed = None
         fused = None
         want_fused = adv_f.is_cuda and FusedMinibatch.supports(config, params)
+        need_log = int(config["update_epochs"]) * num_mb
+        if (adv_f.is_cuda and not want_fused and config.get("fused_update", True) and not opt_state.get("warned_unfused")
+                and not str(getattr(params, "model", "")).startswith("DeepMind")):
+            # a supported configuration on the slower path because of the network type: say so once (src/models.py:34-69)
+            import warnings
+            opt_state["warned_unfused"] = True
+            warnings.warn(f"brl_amd.update: FusedMinibatch covers the DeepMind MLPs only; model_type "
+                          f"{getattr(params, 'model', type(params).__name__)!r} takes the hipGraph-captured autograd step "
+                          f"(GraphedMinibatch: ~1.6x slower per minibatch at minibatch 1024).", RuntimeWarning)
         if config.get("graph_update", True) and adv_f.is_cuda and (want_fused or (sched is None and not multi)):
             graphed = opt_state.get("graphed")
             world = dist.get_world_size() if multi else 1
             # (False = an earlier capture failed, on this or — under a process group — any rank: stay eager, do not retry)
             if graphed is None or (graphed is not False and (
                     graphed.params is not params or graphed.mbs != mbs or isinstance(graphed, FusedMinibatch) != want_fused
-                    or getattr(graphed, "world", 1) != world)):
+                    or getattr(graphed, "world", 1) != world
+                    or (isinstance(graphed, FusedMinibatch) and graphed._log_cap < need_log))):   # e.g. minibatch 512: 5120 steps
                 try:
-                    graphed = FusedMinibatch(config, params, opt, mbs, adv_f.device, world) if want_fused \
+                    graphed = FusedMinibatch(config, params, opt, mbs, adv_f.device, world, log_capacity=need_log) if want_fused \
                         else GraphedMinibatch(config, actor_forward_pass, params, opt, mbs, adv_f.device)
                 except Exception as e:  # capture is an optimisation, never a requirement — but never a SILENT ~1.7x cliff
                     graphed = False

@@ -125,14 +125,18 @@ def _macro(step_fn, actor_forward_pass, actor_params, opp_forward_pass, opp_para
                     fp, pr = (opp_forward_pass, opp_params) if is_opp else (actor_forward_pass, actor_params)
                     logits, _ = fp.apply(pr, obs.to(torch.float32))
                     m = mode
+                rec = wrapped_step_fn.record_actions
                 policy_step(env, packed, packed, logits, m, draw + k, autoreset, obs=buf.obs, mask=buf.mask,
                             rewards_acc=buf.rewards_acc, terminated_acc=buf.terminated_acc,
-                            current_player=buf.current_player)
+                            current_player=buf.current_player, action=buf.action if rec is not None else None)
+                if rec is not None:
+                    rec.append(buf.action.clone())
                 obs = buf.obs
         out = State(env, packed, {"observation": buf.obs, "legal_action_mask": buf.mask,
                                   "current_player": buf.current_player})
         return out.replace(rewards=buf.rewards_acc, terminated=buf.terminated_acc)  # src/utils.py:128
 
+    wrapped_step_fn.record_actions = None   # tests: a list that receives the calls of sub-steps 2..4 (oracle replays)
     return wrapped_step_fn
 
 

@@ -416,6 +416,7 @@ POLICY_CFG = {"reward_scale": 7600, "game_mode": "competitive", "actor_illegal_a
 
 
 @pytest.mark.parametrize("n,T,graph,dt,calls", [(2048, 32, False, None, 2), (2048, 32, True, None, 2),
+                                                (8192, 32, True, None, 1),     # configs[3]'s rollout at the reference's fp32
                                                 (8192, 32, True, "bf16", 1), (1000, 9, False, "bf16", 2),
                                                 (1000, 9, True, "fp16", 2)])
 def test_policy_rollout_replays_through_oracle(env, oracle, n, T, graph, dt, calls):
@@ -1201,6 +1202,49 @@ def test_simple_evaluate_runs_and_is_deterministic(env):
     assert r1 == r2 and abs(r1) <= 7600.0
 
 
+@pytest.mark.parametrize("n", [512, 10000])   # 10000 = num_eval_envs of ppo.py's per-iteration evaluation (ppo.py:366)
+def test_simple_evaluate_replays_through_oracle(env, oracle, n):
+    """src/evaluation.py:11-66 (called every iteration, ppo.py:366): the greedy actor against a fixed greedy opponent on single
+    tables without auto-reset.  The four calls of every macro-step are recorded on the GPU and replayed through the oracle's
+    step: R = sum over iterations of (r1 + r2 + r3 + r4)[player to act before the macro-step] (src/evaluation.py:53-60,
+    src/utils.py:196-198) — scores are integers, so the per-board returns must be EXACT and the mean equal up to the fp32
+    reduction; finished boards keep receiving calls that must be no-ops (G9)."""
+    from brl_amd.evaluation import make_simple_evaluate
+    from brl_amd.models import make_forward_pass
+    fp = make_forward_pass("relu", "DeepMind")
+    a, o = fp.init(1, device="cuda"), fp.init(2, device="cuda")
+    rec = []
+    ev = make_simple_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", o, n, record_actions=rec)
+    got = float(ev(a, 11))
+    torch.cuda.synchronize()
+    assert got == float(make_simple_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", o, n)(a, 11))   # recording changes nothing
+    ref = oracle.init_random(n, seed=11)
+    R = np.zeros(n, np.float64)
+    rows = np.arange(n)
+    for calls in rec:
+        calls = to_np(calls)
+        actor = ref["current_player"].copy()
+        racc = np.zeros((n, 4), np.float64)
+        for k in range(4):
+            live = ref["terminated"] == 0
+            assert (ref["legal_action_mask"][rows, calls[k]][live] == 1).all(), "a greedy call is illegal"
+            oracle.step(ref, calls[k])
+            racc += ref["rewards"]
+        R += racc[rows, actor]
+    assert ref["terminated"].all() and len(rec) >= 2
+    assert np.abs(R).max() <= 7600 and (R != 0).any() and np.array_equal(R, np.round(R))
+    assert abs(got - R.mean()) <= 1e-6 * max(1.0, np.abs(R).mean()) * 8    # fp32 sum of n integers / n
+    # the play continued until every board was finished and not much longer (the loop runs <= 2 iterations past the end)
+    done_at = None
+    ref2 = oracle.init_random(n, seed=11)
+    for i, calls in enumerate(rec):
+        for k in range(4):
+            oracle.step(ref2, to_np(calls)[k])
+        if done_at is None and ref2["terminated"].all():
+            done_at = i
+    assert done_at is not None and len(rec) - 1 - done_at <= 2
+
+
 def test_ppo_loop_runs_end_to_end(env, tmp_path):
     """BASELINE config 4 at toy size — the ppo.py:348-570 loop: evaluations, FSP pool behind the threshold gate,
     roll_out -> calc_gae -> update_step, the reference's log keys, LUT rotation after hash_size boards (G14),
@@ -1303,14 +1347,15 @@ def test_ppo_loop_two_ranks_rccl(tmp_path):
     assert torch.equal(r0[0], r1[0])
 
 
-def test_ppo_iteration_at_config3_size(tmp_path):
+@pytest.mark.parametrize("infer", [None, "bf16"])   # None = the reference's fp32 forwards (the default), bf16 = the opt-in path
+def test_ppo_iteration_at_config3_size(tmp_path, infer):
     """BASELINE.json configs[3] at ITS size: one ppo.py iteration with num_envs=8192, num_steps=32, minibatch 1024,
     10 epochs (2560 minibatch steps), DeepMind MLP, hipGraph rollout + update — finite statistics, every env-step
     counted, the weights moved, the pool file written."""
     from brl_amd import checkpoint as ckpt
     from brl_amd.train import DEFAULTS, train
     cfg = dict(DEFAULTS, num_envs=8192, num_steps=32, total_timesteps=8192 * 32, minibatch_size=1024, update_epochs=10,
-               lr=1e-5, evaluate=False, log_path=str(tmp_path), exp_name="c3", graph_rollout=True, inference_dtype="bf16",
+               lr=1e-5, evaluate=False, log_path=str(tmp_path), exp_name="c3", graph_rollout=True, inference_dtype=infer,
                hash_size=50_000)
     rs, hist = train(cfg, log=lambda s: None)
     h = hist[0]
@@ -1622,7 +1667,7 @@ def test_graphed_update_built_after_eager_steps_keeps_adam_state(fused):
         assert torch.allclose(outs[0], outs[1], atol=1e-5, rtol=1e-4)
 
 
-def _fused_rank(rank, world, port, out_dir, backend="gloo"):
+def _fused_rank(rank, world, port, out_dir, backend="gloo", mode="flat"):
     import sys
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -1640,25 +1685,28 @@ def _fused_rank(rank, world, port, out_dir, backend="gloo"):
     net = fp.init(11, device="cuda")
     tb, adv, tgt = fake_batch(4, 256, seed=3)                       # the SAME shard on both ranks: mean gradient == own gradient
     tb = type(tb)(*[x.cuda() for x in tb])
-    cfg = dict(CFG, minibatch_size=256, update_epochs=1)
+    cfg = dict(CFG, minibatch_size=256, update_epochs=1, grad_allreduce=mode)
     rs, (total, _) = make_update_step(cfg, fp)((net, None, None, None, 0, 5), tb, adv.cuda(), tgt.cuda())
     assert isinstance(rs[1].get("graphed"), FusedMinibatch) and rs[1]["graphed"].world == world, rs[1].get("graph_error")
+    assert rs[1]["graphed"].allreduce_mode == mode and len(rs[1]["graphed"].segs) == (2 if mode == "flat" else 7)
     torch.save((torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu(), total.cpu()),
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_fused_update_with_gradient_allreduce_two_ranks(tmp_path):
-    """FusedMinibatch under a process group (forward+backward graph | all-reduce | clip+Adam graph with grad_scale
-    1/world): two ranks on the same shard end with the parameters of the single-process step (gloo here; RCCL on a node)."""
+@pytest.mark.parametrize("mode", ["flat", "bucketed"])
+def test_fused_update_with_gradient_allreduce_two_ranks(tmp_path, mode):
+    """FusedMinibatch under a process group — "flat" (the default: gradient graph | ONE all-reduce | clip+Adam graph with
+    grad_scale 1/world) and "bucketed" (one graph per all-reduce bucket, collectives issued asynchronously): two ranks on the
+    same shard end with the parameters of the single-process step (gloo here; RCCL on a node)."""
     import socket
     import torch.multiprocessing as mp
     from brl_amd.models import make_forward_pass
     from brl_amd.update import make_update_step
     from tests.test_update_cpu import CFG, fake_batch
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-    mp.start_processes(_fused_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    mp.start_processes(_fused_rank, args=(2, port, str(tmp_path), "gloo", mode), nprocs=2, join=True, start_method="spawn")
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert torch.equal(r0[0], r1[0])
     fp = make_forward_pass("relu", "DeepMind")
@@ -1670,9 +1718,10 @@ def test_fused_update_with_gradient_allreduce_two_ranks(tmp_path):
     assert torch.allclose(total.cpu(), r0[1], atol=1e-6) and torch.allclose(single, r0[0], atol=1e-6, rtol=1e-5)
 
 
-def test_fused_update_with_gradient_allreduce_two_ranks_rccl(tmp_path):
-    """The same over RCCL ("nccl"), one GPU per rank: the bucketed all-reduces really cross xGMI.  SKIPPED with a reason
-    below 2 GPUs."""
+@pytest.mark.parametrize("mode", ["flat", "bucketed"])
+def test_fused_update_with_gradient_allreduce_two_ranks_rccl(tmp_path, mode):
+    """The same over RCCL ("nccl"), one GPU per rank: the all-reduces really cross xGMI ("bucketed": issued behind their graph
+    segments, overlapping the rest of the backward pass).  SKIPPED with a reason below 2 GPUs."""
     _two_gpus_or_skip()
     import socket
     import torch.multiprocessing as mp
@@ -1680,7 +1729,7 @@ def test_fused_update_with_gradient_allreduce_two_ranks_rccl(tmp_path):
     from brl_amd.update import make_update_step
     from tests.test_update_cpu import CFG, fake_batch
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-    mp.start_processes(_fused_rank, args=(2, port, str(tmp_path), "nccl"), nprocs=2, join=True, start_method="spawn")
+    mp.start_processes(_fused_rank, args=(2, port, str(tmp_path), "nccl", mode), nprocs=2, join=True, start_method="spawn")
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert torch.equal(r0[0], r1[0])
     fp = make_forward_pass("relu", "DeepMind")

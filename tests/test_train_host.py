@@ -147,6 +147,33 @@ def test_haiku_pickle_reader_refuses_foreign_globals(tmp_path):
     assert np.array_equal(back["actor_critic/linear"]["w"], tree["actor_critic/linear"]["w"])
 
 
+def test_haiku_pickle_reader_accepts_every_pickle_protocol():
+    """ndarray.__reduce_ex__ emits numpy(._)core.numeric._frombuffer under protocol 5 (HIGHEST_PROTOCOL): plain numpy trees
+    written that way — opponent / initial model files of a jax-free writer — must keep loading."""
+    rs = np.random.RandomState(0)
+    tree = {"actor_critic/linear": {"w": rs.randn(480, 8).astype(np.float32), "b": rs.randn(8).astype(np.float32)},
+            "actor_critic/linear_1": {"w": np.asfortranarray(rs.randn(8, 8).astype(np.float32)), "b": np.zeros(8, np.float32)}}
+    for proto in range(2, pickle.HIGHEST_PROTOCOL + 1):
+        back = ckpt.load_haiku_pickle(pickle.dumps(tree, protocol=proto))
+        for k, v in tree.items():
+            for kk, a in v.items():
+                assert np.array_equal(back[k][kk], a), (proto, k, kk)
+
+
+def test_weight_delta_log_field():
+    """train.py's opp_weight_delta: one number; NaN (never an exception) for trees of different shape or the same object"""
+    from brl_amd.models import make_forward_pass
+    from brl_amd.train import _weight_delta
+    fp = make_forward_pass("relu", "DeepMind")
+    a, b = fp.init(0, device="cpu"), fp.init(0, device="cpu")
+    assert _weight_delta(a, b) == 0.0 and np.isnan(_weight_delta(a, a))
+    with torch.no_grad():
+        list(b.parameters())[3].view(-1)[5] += 0.25
+    assert abs(_weight_delta(a, b) - 0.25) < 1e-6
+    fair = make_forward_pass("relu", "FAIR").init(0, device="cpu")
+    assert np.isnan(_weight_delta(a, fair))
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
