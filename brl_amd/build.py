@@ -7,21 +7,28 @@ import subprocess
 import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(PKG, "csrc", "brl_kernels.hip")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
+OUT = os.path.join(PKG, "lib", "libbrl_hip.so")
+OBJ_DIR = os.path.join(PKG, "lib", "obj")   # one object per translation unit (git-ignored)
+
+# -ffp-contract=off: GAE / reward arithmetic must round like the scalar oracle (no FMA fusion)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17"]
+
+
+def units():
+    """the translation units of the library: every csrc/*.hip"""
+    import glob
+    return sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")))
+
+
+def headers():
+    import glob
+    return sorted(glob.glob(os.path.join(PKG, "csrc", "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h")))
 
 
 def deps():
     """every source the library is built from: csrc/*.hip, csrc/*.hpp, include/*.h"""
-    import glob
-    return sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.hpp"))
-                  + glob.glob(os.path.join(INCLUDE, "*.h")))
-
-
-OUT = os.path.join(PKG, "lib", "libbrl_hip.so")
-
-# -ffp-contract=off: GAE / reward arithmetic must round like the scalar oracle (no FMA fusion)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+    return units() + headers()
 
 
 def hipcc() -> str:
@@ -39,12 +46,27 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if force or needs_build():
-        os.makedirs(os.path.dirname(OUT), exist_ok=True)
-        cmd = [hipcc()] + FLAGS + ["-o", OUT, SRC]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    """compiles the translation units that changed (a header change rebuilds all of them: they are few) and links them"""
+    if not (force or needs_build()):
+        return OUT
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    newest_header = max(os.path.getmtime(h) for h in headers())
+    procs, objs = [], []
+    for src in units():
+        obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            cmd = [hipcc()] + FLAGS + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:   # (the units compile side by side)
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
     return OUT
 
 

@@ -1952,21 +1952,14 @@ struct brl_handle {
 
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char *fmt, const char *detail) {
+// (shared by every translation unit of the library through abi_common.hpp)
+int brl_fail(int code, const char *fmt, const char *detail) {
   snprintf(g_err, sizeof(g_err), fmt, detail ? detail : "");
   return code;
 }
+static int fail(int code, const char *fmt, const char *detail) { return brl_fail(code, fmt, detail); }
 
-#define HIP_TRY(expr)                                                                  \
-  do {                                                                                 \
-    hipError_t _e = (expr);                                                            \
-    if (_e != hipSuccess) return fail(BRL_E_HIP, #expr ": %s", hipGetErrorString(_e)); \
-  } while (0)
-
-#define NEED(cond, what) \
-  do {                   \
-    if (!(cond)) return fail(BRL_E_ARG, "bad argument: %s", what); \
-  } while (0)
+#include "abi_common.hpp"   // HIP_TRY, NEED
 
 extern "C" const char *brl_last_error(void) { return g_err; }
 extern "C" int brl_version(void) { return 1; }

@@ -350,6 +350,14 @@ class FusedMinibatch:
         self.nsplit = (B + 63) // 64                   # batch splits of the head's weight / bias gradient (brl_ppo_heads_bwd)
         self.dwh_partials = f(self.nsplit, K * H)
         self.dbh_partials = f(self.nsplit, K)
+        # the step's 1024^3-class products on this library's own fp32 MFMA kernel (brl_mlp_gemm, csrc/mlp_gemm.hpp) where its
+        # fused epilogue removes a launch: hidden layers' forward (bias + activation inside), dh = dz W with the activation
+        # derivative and the bias-gradient tile sums inside (replaces torch.mm + brl_act_bwd_colsum).  Layer 0 (K = 480) and the
+        # weight gradients (one batched library product) stay with the library.  config["own_gemm"]: True / False.
+        self.own_gemm = bool(config.get("own_gemm", True)) and self.single_chain and B % 4 == 0 and H % 4 == 0 and nl > 1
+        self.own_fwd = self.own_gemm and bool(config.get("own_gemm_fwd", True))   # (A/B switch: the forward layers alone)
+        groups64 = (B + 63) // 64                      # 64-row tiles of brl_mlp_gemm's column sums
+        self.tile_rows = [64 if (self.own_gemm and l < nl - 1) else 16 for l in range(nl)]
         self.tile_sums = [f(groups * H) for _ in body]   # per-layer partial column sums (bias gradients)
         import ctypes as C
         # one launch finishes every sum of partials: the hidden layers' bias gradients, the head's bias and weight gradients
@@ -357,7 +365,7 @@ class FusedMinibatch:
         self._seg_scratch = (C.c_void_p * nseg)(*([t.data_ptr() for t in self.tile_sums]
                                                   + [self.dbh_partials.data_ptr(), self.dwh_partials.data_ptr()]))
         self._seg_cols = (C.c_int64 * nseg)(*([H] * len(body) + [K, K * H]))
-        self._seg_tiles = (C.c_int64 * nseg)(*([groups] * len(body) + [self.nsplit, self.nsplit]))
+        self._seg_tiles = (C.c_int64 * nseg)(*([groups64 if r == 64 else groups for r in self.tile_rows] + [self.nsplit, self.nsplit]))
         self._seg_db = (C.c_void_p * nseg)(*([g.data_ptr() for g in self.Gb] + [self.Gbh.data_ptr(), self.GWh.data_ptr()]))
         self._nseg = nseg
         # The logged statistics (src/update.py:136-167) are NOT formed step by step: every step leaves its sums — 8 floats and
@@ -494,6 +502,11 @@ class FusedMinibatch:
         cfg = self.cfg
         x = self.x0   # minibatch *mb_index of the bound trajectory: gathered by the previous step's Adam launch (or by the bind)
         for l, (W, b) in enumerate(zip(self.W, self.b)):          # forward: bias + activation
+            if self.own_fwd and l > 0:                            # own kernel: bias + activation in its epilogue
+                chk(L.brl_mlp_gemm(di, 0, 1, x.data_ptr(), x.stride(0), W.data_ptr(), W.stride(0), self.h[l].data_ptr(),
+                                   self.h[l].stride(0), B, W.shape[0], W.shape[1], self.act, b.data_ptr(), None, 0, None, None, s))
+                x = self.h[l]
+                continue
             if self.act == 0:                                     # ReLU in the GEMM epilogue
                 x = torch._addmm_activation(b, x, W.t(), use_gelu=False, out=self.h[l])
             else:
@@ -521,7 +534,7 @@ class FusedMinibatch:
         top = nl - 1
         # single rank, more than one hidden layer: the head's weight-gradient role (not on the backward chain) rides with the first
         # activation-derivative launch of _backward_chain (brl_act_bwd_colsum_heads_dw); here only the activation-gradient role
-        self.dw_deferred = self.single_chain and nl > 1
+        self.dw_deferred = self.single_chain and nl > 1   # (it rides with the first launch of the dz chain below the top layer)
         chk(L.brl_ppo_heads_bwd(di, self.dheads.data_ptr(), x.data_ptr(), x.stride(0), self.Wh.data_ptr(), B, self.H, self.act,
                                 self.nsplit, None if self.dw_deferred else self.dwh_partials.data_ptr(),
                                 None if self.dw_deferred else self.dbh_partials.data_ptr(),
@@ -551,6 +564,21 @@ class FusedMinibatch:
         di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         nl = len(self.W)
         for l in range(nl - 1, 0, -1):
+            if self.own_gemm and l == nl - 1 and self.dw_deferred:   # + the head's dW_h / db_h partials and the step's statistics sums
+                top = self.h[nl - 1]
+                chk(L.brl_mlp_gemm_dh_heads_dw(di, self.dzs[l].data_ptr(), self.H, self.W[l].data_ptr(), self.W[l].stride(0),
+                                               self.dzs[l - 1].data_ptr(), self.H, B, self.W[l].shape[1], self.W[l].shape[0], self.act,
+                                               self.h[l - 1].data_ptr(), self.H, self.tile_sums[l - 1].data_ptr(),
+                                               self.dheads.data_ptr(), top.data_ptr(), top.stride(0), B, self.H, self.nsplit,
+                                               self.dwh_partials.data_ptr(), self.dbh_partials.data_ptr(), self.partials.data_ptr(),
+                                               self.gram_partials.data_ptr(), self.lgroups, self.mb_index.data_ptr(),
+                                               self.stat_sums.data_ptr(), self.gram_sums.data_ptr(), s))
+                continue
+            if self.own_gemm:   # dz_{l-1} = (dz_l W_l) * act'(h_{l-1}) + the 64-row tile sums of db_{l-1}: ONE launch
+                chk(L.brl_mlp_gemm(di, 1, 2, self.dzs[l].data_ptr(), self.H, self.W[l].data_ptr(), self.W[l].stride(0),
+                                   self.dzs[l - 1].data_ptr(), self.H, B, self.W[l].shape[1], self.W[l].shape[0], self.act, None,
+                                   self.h[l - 1].data_ptr(), self.H, self.tile_sums[l - 1].data_ptr(), None, s))
+                continue
             torch.mm(self.dzs[l], self.W[l], out=self.dzs[l - 1])
             if l == nl - 1 and self.dw_deferred:   # + the head's dW_h / db_h partials and the step's statistics sums
                 top = self.h[nl - 1]

@@ -504,6 +504,43 @@ int brl_adam_clip_fin_gather(int device, float *p, float *g, float *m, float *v,
                              int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles, float *const *out,
                              void *stream);
 
+/* ---- round 4: the step's fp32 GEMMs with the elementwise work of src/update.py:74-242 in their epilogues -------------------
+ * One fp32 product C[m,n] (row-major, ldc) on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, a k-ordered fma chain per
+ * output), 64 x 64 output tiles (csrc/mlp_gemm.hpp).  Layouts (what is contiguous in memory):
+ *   BRL_GEMM_NT  c = a b^T         a [m,k] (lda), b [n,k] (ldb)          the forward pass: x W^T        (src/models.py:23-33)
+ *   BRL_GEMM_NN  c = a b           a [m,k] (lda), b [k,n] (ldb)          dh = dz W                       (autograd of the same)
+ *   BRL_GEMM_TN  c = a^T b         a [k,m] (lda), b [k,n] (ldb)          dW = dz^T h
+ * Epilogues:
+ *   BRL_GEMM_EPI_NONE
+ *   BRL_GEMM_EPI_BIAS_ACT     (NT)  c = act(c + bias[n]); act 0 = ReLU, 1 = tanh                         (src/models.py:16)
+ *   BRL_GEMM_EPI_GATE_COLSUM  (NN)  c = c * act'(gate[m,n]) with gate = the layer's forward OUTPUT (ReLU: gate > 0; tanh:
+ *                                   1 - gate^2), and colsum [ceil(m / 64), n] = the column sums of every 64-row tile of what was
+ *                                   stored (the bias gradient's partials: finish with brl_bias_finalize_ex, tiles = ceil(m / 64));
+ *                                   colsum may be NULL
+ *   BRL_GEMM_EPI_SQSUM        (TN)  sqsum [ceil(m / 64) * ceil(n / 64)] = the sum of squares of every output tile
+ *                                   (clip_by_global_norm's partial sums, ppo.py:195-211)
+ * n, lda, ldb, ldc (ldg) multiples of 4; k a multiple of 4 where it is an operand's contiguous index, m where it is; operands
+ * below 2 GB.  Deterministic (no atomics).  Replaces torch.mm / torch.addmm + brl_act_bwd_colsum in FusedMinibatch. */
+#define BRL_GEMM_NT 0
+#define BRL_GEMM_NN 1
+#define BRL_GEMM_TN 2
+#define BRL_GEMM_EPI_NONE 0
+#define BRL_GEMM_EPI_BIAS_ACT 1
+#define BRL_GEMM_EPI_GATE_COLSUM 2
+#define BRL_GEMM_EPI_SQSUM 3
+int brl_mlp_gemm(int device, int layout, int epilogue, const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
+                 int64_t ldc, int64_t m, int64_t n, int64_t k, int act, const float *bias, const float *gate, int64_t ldg,
+                 float *colsum, float *sqsum, void *stream);
+
+/* brl_mlp_gemm(BRL_GEMM_NN, BRL_GEMM_EPI_GATE_COLSUM, dz, w, ...) of the hidden layer below the top with the weight-gradient
+ * role of brl_ppo_heads_bwd (arguments as brl_act_bwd_colsum_heads_dw) as extra workgroups of the same launch: call
+ * brl_ppo_heads_bwd with dw_partials = db_partials = NULL, then this as the first product of the dz chain. */
+int brl_mlp_gemm_dh_heads_dw(int device, const float *dz, int64_t lddz, const float *w, int64_t ldw, float *out, int64_t ldo,
+                             int64_t m, int64_t n, int64_t k, int act, const float *gate, int64_t ldg, float *colsum,
+                             const float *dheads, const float *h, int64_t ldh, int64_t batch, int64_t hidden, int nsplit,
+                             float *dw_partials, float *db_partials, const float *loss_partials, const float *gram_partials,
+                             int64_t ngroups, const int32_t *row_index, float *stat_sums, float *gram_sums, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

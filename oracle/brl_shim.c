@@ -305,6 +305,49 @@ int brl_live_index(brl_handle *h, const uint8_t *terminated, int64_t n, int64_t 
   (void)h; (void)terminated; (void)n; (void)live; (void)finished; (void)s;
   NOT_HERE("brl_live_index");
 }
+/* brl_mlp_gemm on the host: the plain definition (include/brl_hip.h), float64 accumulation — the checker of the MFMA kernel's
+ * fp32 fma chains for small shapes (tests compare at 2e-4 * max|ref|); same argument rules as the library. */
+int brl_mlp_gemm(int device, int layout, int epilogue, const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
+                 int64_t ldc, int64_t m, int64_t n, int64_t k, int act, const float *bias, const float *gate, int64_t ldg,
+                 float *colsum, float *sqsum, void *s) {
+  (void)device; (void)s;
+  if (!a || !b || !c || m <= 0 || n <= 0 || k <= 0 || layout < 0 || layout > 2 || n % 4 || lda % 4 || ldb % 4 || ldc % 4 ||
+      (layout != 2 && k % 4) || (act != 0 && act != 1) ||
+      !(epilogue == 0 || (epilogue == 1 && layout == 0 && bias) || (epilogue == 2 && layout == 1 && gate) ||
+        (epilogue == 3 && layout == 2 && sqsum))) {
+    snprintf(g_err, sizeof(g_err), "bad argument: brl_mlp_gemm (oracle shim)");
+    return BRL_E_ARG;
+  }
+  const int64_t tm = (m + 63) / 64, tn = (n + 63) / 64;
+  if (epilogue == 3) for (int64_t t = 0; t < tm * tn; t++) sqsum[t] = 0.0f;
+  if (epilogue == 2 && colsum) for (int64_t t = 0; t < tm * n; t++) colsum[t] = 0.0f;
+  for (int64_t i = 0; i < m; i++)
+    for (int64_t j = 0; j < n; j++) {
+      double acc = 0.0;
+      for (int64_t q = 0; q < k; q++) {
+        const double av = layout == 2 ? a[q * lda + i] : a[i * lda + q];
+        const double bv = layout == 0 ? b[j * ldb + q] : b[q * ldb + j];
+        acc += av * bv;
+      }
+      if (epilogue == 1) { acc += bias[j]; acc = act == 0 ? (acc > 0 ? acc : 0) : tanh(acc); }
+      if (epilogue == 2) { const double h = gate[i * ldg + j]; acc = act == 0 ? (h > 0 ? acc : 0) : acc * (1.0 - h * h); }
+      const float v = (float)acc;
+      c[i * ldc + j] = v;
+      if (epilogue == 2 && colsum) colsum[(i / 64) * n + j] += v;
+      if (epilogue == 3) sqsum[(i / 64) * tn + j / 64] += v * v;
+    }
+  return BRL_OK;
+}
+int brl_mlp_gemm_dh_heads_dw(int device, const float *dz, int64_t lddz, const float *w, int64_t ldw, float *out, int64_t ldo,
+                             int64_t m, int64_t n, int64_t k, int act, const float *gate, int64_t ldg, float *colsum,
+                             const float *dheads, const float *h, int64_t ldh, int64_t batch, int64_t hidden, int nsplit,
+                             float *dw_partials, float *db_partials, const float *loss_partials, const float *gram_partials,
+                             int64_t ngroups, const int32_t *row_index, float *stat_sums, float *gram_sums, void *s) {
+  (void)device; (void)dz; (void)lddz; (void)w; (void)ldw; (void)out; (void)ldo; (void)m; (void)n; (void)k; (void)act; (void)gate; (void)ldg;
+  (void)colsum; (void)dheads; (void)h; (void)ldh; (void)batch; (void)hidden; (void)nsplit; (void)dw_partials; (void)db_partials;
+  (void)loss_partials; (void)gram_partials; (void)ngroups; (void)row_index; (void)stat_sums; (void)gram_sums; (void)s;
+  NOT_HERE("brl_mlp_gemm_dh_heads_dw");
+}
 int brl_adam_clip_fin_gather(int device, float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
                              const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float *scratch,
                              int64_t scratch_len, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs,

@@ -2001,6 +2001,65 @@ def test_head_kernels_match_torch_and_the_separate_launches(B, H, act):
     assert torch.allclose(ts.sum(0), want.sum(0), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("layout,epi,M,N,K,act", [
+    (0, 1, 1024, 1024, 1024, 0), (0, 1, 1024, 1024, 480, 0), (0, 1, 200, 72, 64, 1), (0, 0, 48, 256, 480, 0),
+    (1, 2, 1024, 1024, 1024, 0), (1, 2, 100, 36, 96, 1), (1, 2, 1000, 256, 256, 0), (1, 0, 64, 64, 32, 0),
+    (2, 3, 1024, 1024, 1024, 0), (2, 3, 68, 132, 1000, 0), (2, 0, 1024, 480, 1024, 0), (2, 3, 4, 4, 4, 0)])
+def test_mlp_gemm_matches_float64(layout, epi, M, N, K, act):
+    """brl_mlp_gemm (csrc/mlp_gemm.hpp: the step's fp32 MFMA products with fused epilogues) against a float64 torch product on the
+    same operands: every layout (NT forward, NN dh, TN dW), every epilogue (bias + ReLU / tanh; activation derivative + 64-row
+    column sums; tile square sums), the step's shapes, edge tiles and a K tail.  fp32 k-ordered fma chains: 2e-4 * max|ref| at
+    K = 1024 (the same class of result as the library GEMM it replaces, src/update.py:86-178)."""
+    from brl_amd import _capi
+    L = _capi.lib()
+    g = torch.Generator(device="cuda").manual_seed(layout * 1000 + M + N + K)
+    r = lambda *sh: (torch.rand(sh, device="cuda", generator=g) * 2 - 1)  # noqa: E731
+    akc, bkc = layout != 2, layout == 0
+    A = r(M, K) if akc else r(K, M)
+    Bm = r(N, K) if bkc else r(K, N)
+    bias, gate = r(N), r(M, N)
+    C = torch.full((M, N), float("nan"), device="cuda")
+    tm, tn = (M + 63) // 64, (N + 63) // 64
+    colsum = torch.full((tm, N), float("nan"), device="cuda")
+    sqsum = torch.full((tm * tn,), float("nan"), device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    _capi.check(L.brl_mlp_gemm(0, layout, epi, A.data_ptr(), A.stride(0), Bm.data_ptr(), Bm.stride(0), C.data_ptr(), N, M, N, K, act,
+                               bias.data_ptr(), gate.data_ptr(), N, colsum.data_ptr(), sqsum.data_ptr(), s))
+    torch.cuda.synchronize()
+    a64 = A.double() if akc else A.double().t()
+    b64 = Bm.double().t() if bkc else Bm.double()
+    ref = a64 @ b64
+    if epi == 1:
+        ref = ref + bias.double()
+        ref = ref.clamp_min(0) if act == 0 else ref.tanh()
+    if epi == 2:
+        ref = ref * ((gate > 0).double() if act == 0 else (1 - gate.double() ** 2))
+    tol = 2e-4 * max(1.0, float(ref.abs().max())) * (K / 1024 + 1) ** 0.5
+    assert float((C.double() - ref).abs().max()) < tol
+    if epi == 2:   # column sums of what was STORED, per 64-row tile, in a fixed order: compare with the fp64 sums of C itself
+        want = torch.stack([C[64 * t:64 * t + 64].double().sum(0) for t in range(tm)])
+        assert float((colsum.double() - want).abs().max()) < 1e-3
+    if epi == 3:
+        assert abs(float(sqsum.double().sum()) - float((C.double() ** 2).sum())) <= 1e-5 * max(1.0, float((C.double() ** 2).sum()))
+    # a second launch gives the same bits (no atomics, fixed summation order)
+    C2 = torch.empty_like(C)
+    _capi.check(L.brl_mlp_gemm(0, layout, epi, A.data_ptr(), A.stride(0), Bm.data_ptr(), Bm.stride(0), C2.data_ptr(), N, M, N, K, act,
+                               bias.data_ptr(), gate.data_ptr(), N, colsum.data_ptr(), sqsum.data_ptr(), s))
+    assert torch.equal(C, C2)
+
+
+def test_mlp_gemm_rejects_what_it_cannot_do():
+    from brl_amd import _capi
+    L = _capi.lib()
+    x = torch.zeros(64, 64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for bad in ((0, 1, 64, 62, 64), (0, 0, 64, 64, 66), (3, 0, 64, 64, 64), (1, 1, 64, 64, 64)):   # n % 4, k % 4, layout, epilogue / layout pair
+        lay, epi, m, n, k = bad
+        assert L.brl_mlp_gemm(0, lay, epi, x.data_ptr(), 64, x.data_ptr(), 64, x.data_ptr(), 64, m, n, k, 0, x.data_ptr(), None, 0, None,
+                              None, s) == -1
+        assert b"bad argument" in L.brl_last_error()
+
+
 def test_longest_auction_319_calls(env, oracle, dds):
     """Maximum size of the domain: the 319-call auction fills every history nibble and the 9-bit turn counter."""
     from tests.test_oracle_kat import longest_auction
