@@ -126,6 +126,11 @@ def lib() -> C.CDLL:
                                         _vp, _vp, _vp, _vp],
         "brl_bias_finalize_ex": [i32, i32, _vp, _vp, _vp, _vp, _vp],
         "brl_mlp_gemm": [i32, i32, i32, _vp, i64, _vp, i64, _vp, i64, i64, i64, i64, i32, _vp, _vp, i64, _vp, _vp, _vp],
+        "brl_adam_clip_fin_gather_defer": [i32, _vp, _vp, _vp, _vp, i64, _vp, f32, _vp, f32, f32, f32, f32, _vp, i64, _vp, _vp, _vp, i64,
+                                           i32, _vp, _vp, _vp, _vp, i64, i64, _vp, _vp],
+        "brl_mlp_gemm_adam": [i32, _vp, i64, _vp, i64, _vp, i64, i64, i64, i64, i32, _vp, _vp, _vp, _vp, _vp, i64, i64, _vp, i32, _vp, f32,
+                              _vp, f32, f32, f32, f32, f32, _vp, _vp],
+        "brl_adam_apply_range": [i32, _vp, _vp, _vp, _vp, i64, i64, _vp, i32, _vp, f32, _vp, f32, f32, f32, f32, f32, _vp, i32, _vp],
         "brl_mlp_gemm_dh_heads_dw": [i32, _vp, i64, _vp, i64, _vp, i64, i64, i64, i64, i32, _vp, i64, _vp, _vp, _vp, i64, i64, i64, i32,
                                      _vp, _vp, _vp, _vp, i64, _vp, _vp, _vp, _vp],
     }
@@ -143,7 +148,8 @@ EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_de
            "brl_eval_step", "brl_eval_reduce", "brl_ppo_loss", "brl_ppo_stats", "brl_ppo_loss_heads", "brl_mb_gather",
            "brl_relu_bwd_colsum", "brl_adam_clip", "brl_bias_finalize", "brl_ppo_stats_at", "brl_policy_step_ex",
            "brl_eval_step_team", "brl_rollout_random_gae", "brl_ppo_heads_loss", "brl_ppo_heads_loss_split", "brl_ppo_heads_bwd", "brl_ppo_stats_gram",
-           "brl_act_bwd_colsum", "brl_act_bwd_colsum_heads_dw", "brl_bias_finalize_ex", "brl_ppo_stats_rows", "brl_mb_gather_bind", "brl_mb_gather_dev", "brl_ppo_illegal_grad", "brl_adam_clip_gather", "brl_adam_clip_fin_gather", "brl_mlp_gemm", "brl_mlp_gemm_dh_heads_dw"]
+           "brl_act_bwd_colsum", "brl_act_bwd_colsum_heads_dw", "brl_bias_finalize_ex", "brl_ppo_stats_rows", "brl_mb_gather_bind", "brl_mb_gather_dev", "brl_ppo_illegal_grad", "brl_adam_clip_gather", "brl_adam_clip_fin_gather", "brl_mlp_gemm", "brl_mlp_gemm_dh_heads_dw", "brl_adam_clip_fin_gather_defer", "brl_mlp_gemm_adam",
+           "brl_adam_apply_range"]
 
 
 def check(rc: int) -> None:

@@ -1,0 +1,78 @@
+// adam_role.hpp — clip_by_global_norm + Adam on a RANGE of the flat fp32 buffers (ppo.py:195-211: optax.chain(clip_by_global_norm,
+// adam); torch.optim.Adam's arithmetic), as a device function a kernel can give to its surplus workgroups.  The sweep is
+// HBM-bound (7 floats moved per parameter) and, once the step's norm partials exist, depends on nothing else: the part of it that
+// the NEXT step's forward pass does not need at once leaves the step's dependency chain and rides, layer by layer, in the forward
+// GEMM launches of the next step (csrc/brl_mlp_gemm.hip: the layer whose weights a launch updates is the layer the NEXT launch
+// multiplies with).  Every block re-adds the norm partials in the same fixed order: deterministic, no cross-block hand-off.
+#pragma once
+#include <stdint.h>
+
+struct AdamRange {
+  float *p;
+  const float *g;
+  float *m, *v;
+  int64_t lo4, hi4;            // the float4s [lo4, hi4) of the flat buffers
+  const float *partials;       // the step's square-sum partials (k_adam_norm / k_adam_norm_fin)
+  int npartials;
+  const float *step;           // Adam's step count t (already advanced by the norm launch)
+  const float *lr_dev;         // device-resident learning rate, or NULL: lr
+  float lr, b1, b2, eps, max_norm, gscale;
+  const int32_t *pending;      // NULL, or: the range is swept only where *pending != 0 (no deferred step before an update's first)
+  float *norm_out;             // NULL, or: block 0 stores the gradient norm
+};
+
+__device__ __forceinline__ float adam_wave_sum(float v) {   // (sum over the 64 lanes, every lane: fixed order)
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block `b` of `nb` blocks of 256 threads sweeps its share of the range.  red: 8 floats of LDS.
+__device__ __forceinline__ void adam_range_block(const AdamRange &A, const int b, const int nb, float *red) {
+  if (A.pending != nullptr && *A.pending == 0) return;
+  const int tid = (int)threadIdx.x;
+  {
+    float s = 0.0f;
+    for (int i0 = tid; i0 < A.npartials; i0 += 8 * 256) {   // (eight loads in flight: one round trip for <= 2048 partials)
+      float pv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) pv[u] = (i0 + u * 256 < A.npartials) ? A.partials[i0 + u * 256] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += pv[u];
+    }
+    s = adam_wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+      const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+      // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
+      red[4] = (A.max_norm > 0.0f) ? fminf(A.max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+      if (b == 0 && A.norm_out) *A.norm_out = norm;
+    }
+    __syncthreads();
+  }
+  const float scale = red[4] * A.gscale;
+  const float t = *A.step;
+  const float lr = (A.lr_dev != nullptr) ? *A.lr_dev : A.lr;  // device-resident: a captured launch follows the lr schedule
+  const float b1 = A.b1, b2 = A.b2, eps = A.eps;
+  const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+  const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+  const int64_t n4 = A.hi4 - A.lo4;
+  const int64_t chunk = (n4 + nb - 1) / nb;
+  const int64_t lo = A.lo4 + (int64_t)b * chunk, hi = (lo + chunk < A.hi4) ? lo + chunk : A.hi4;
+  for (int64_t i = lo + tid; i < hi; i += 256) {
+    const float4 g4 = reinterpret_cast<const float4 *>(A.g)[i];
+    float4 m4 = reinterpret_cast<float4 *>(A.m)[i], v4 = reinterpret_cast<float4 *>(A.v)[i], p4 = reinterpret_cast<float4 *>(A.p)[i];
+    const float gs[4] = {g4.x * scale, g4.y * scale, g4.z * scale, g4.w * scale};
+    float ms[4] = {m4.x, m4.y, m4.z, m4.w}, vs[4] = {v4.x, v4.y, v4.z, v4.w}, ps[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      ms[k] = ms[k] + (gs[k] - ms[k]) * (1.0f - b1);            // exp_avg.lerp_(grad, 1 - beta1)
+      vs[k] = vs[k] * b2 + gs[k] * gs[k] * (1.0f - b2);          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+      ps[k] -= step_size * (ms[k] / (sqrtf(vs[k]) / bc2_sqrt + eps));
+    }
+    reinterpret_cast<float4 *>(A.m)[i] = make_float4(ms[0], ms[1], ms[2], ms[3]);
+    reinterpret_cast<float4 *>(A.v)[i] = make_float4(vs[0], vs[1], vs[2], vs[3]);
+    reinterpret_cast<float4 *>(A.p)[i] = make_float4(ps[0], ps[1], ps[2], ps[3]);
+  }
+}

@@ -2889,12 +2889,27 @@ extern "C" int brl_ppo_stats_rows(int device, const float *stat_sums, const floa
   return BRL_OK;
 }
 
+static AdamRange adam_range(float *p, const float *g, float *m, float *v, int64_t lo, int64_t hi, const float *scratch, int npartials,
+                            const float *step, float lr, const float *lr_dev, float beta1, float beta2, float eps, float max_norm,
+                            float grad_scale, const int32_t *pending, float *norm_out) {
+  AdamRange R{};
+  R.p = p; R.g = g; R.m = m; R.v = v; R.lo4 = lo >> 2; R.hi4 = hi >> 2; R.partials = scratch; R.npartials = npartials; R.step = step;
+  R.lr_dev = lr_dev; R.lr = lr; R.b1 = beta1; R.b2 = beta2; R.eps = eps; R.max_norm = max_norm; R.gscale = grad_scale;
+  R.pending = pending; R.norm_out = norm_out;
+  return R;
+}
+
+// [defer_lo, defer_hi) (floats, multiples of 4; empty: nothing deferred): the part of the sweep this call leaves to
+// brl_mlp_gemm_adam / brl_adam_apply_range; *pending is then set to 1 by the apply launch
 static int adam_clip_impl(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
                           const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale,
                           float *scratch, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t gather_rows, void *stream,
-                          const BiasSegs *fin = nullptr, int64_t tail_lo = 0, const FinBlocks *fb = nullptr) {
+                          const BiasSegs *fin = nullptr, int64_t tail_lo = 0, const FinBlocks *fb = nullptr, int64_t defer_lo = 0,
+                          int64_t defer_hi = 0, int32_t *pending = nullptr) {
   NEED(p && g && m && v && step && scratch && n > 0 && n % 4 == 0, "p / g / m / v / step / scratch / n (a multiple of 4)");
   NEED(!gather_args || (mb_index && gather_rows > 0), "gather_args needs mb_index and the minibatch size");
+  NEED(defer_lo % 4 == 0 && defer_hi % 4 == 0 && defer_lo >= 0 && defer_lo <= defer_hi && defer_hi <= n, "deferred range");
+  NEED(defer_lo == defer_hi || pending, "a deferred range needs the pending flag");
   HIP_TRY(hipSetDevice(device));
   int npartials = ADAM_BLOCKS;
   if (fin != nullptr) {   // the finalize launch rides along: see k_adam_norm_fin
@@ -2905,8 +2920,14 @@ static int adam_clip_impl(int device, float *p, const float *g, float *m, float 
     hipLaunchKernelGGL(k_adam_norm, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, g, n, grad_scale, scratch, step, mb_index);
   }
   const unsigned extra = gather_args ? (unsigned)((gather_rows + 1) / 2) : 0u;
-  hipLaunchKernelGGL(k_adam_apply, dim3(ADAM_BLOCKS + extra), dim3(ADAM_THREADS), 0, (hipStream_t)stream, p, g, m, v, n, scratch, step, lr,
-                     lr_dev, beta1, beta2, eps, max_norm, grad_scale, norm_out, (const GatherArgs *)gather_args, npartials);
+  // the sweep's blocks are sized like the undivided launch's (n / 4 / ADAM_BLOCKS float4s each), per range
+  const int64_t per = (n / 4 + ADAM_BLOCKS - 1) / ADAM_BLOCKS;
+  const int64_t len1 = (defer_lo == defer_hi) ? n : defer_lo, len2 = (defer_lo == defer_hi) ? 0 : n - defer_hi;
+  const int nb1 = (int)((len1 / 4 + per - 1) / per), nb2 = (int)((len2 / 4 + per - 1) / per);
+  const AdamRange R1 = adam_range(p, g, m, v, 0, len1, scratch, npartials, step, lr, lr_dev, beta1, beta2, eps, max_norm, grad_scale, nullptr, norm_out);
+  const AdamRange R2 = adam_range(p, g, m, v, defer_hi, n, scratch, npartials, step, lr, lr_dev, beta1, beta2, eps, max_norm, grad_scale, nullptr, nullptr);
+  hipLaunchKernelGGL(k_adam_apply, dim3((unsigned)(nb1 + nb2) + extra), dim3(ADAM_THREADS), 0, (hipStream_t)stream, R1, R2, nb1, nb2,
+                     (const GatherArgs *)gather_args, (defer_lo == defer_hi) ? (int32_t *)nullptr : pending);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }
@@ -2955,6 +2976,50 @@ extern "C" int brl_adam_clip_fin_gather(int device, float *p, float *g, float *m
   NEED(scratch_len >= ADAM_BLOCKS + (int64_t)FB.off[nseg], "scratch too small for the finalize blocks' partials");
   return adam_clip_impl(device, p, g, m, v, n, step, lr, lr_dev, beta1, beta2, eps, max_norm, 1.0f, scratch, mb_index, norm_out,
                         gather_args, mbs, stream, &S, tail_lo, &FB);
+}
+
+extern "C" int brl_adam_clip_fin_gather_defer(int device, float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
+                                              const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float *scratch,
+                                              int64_t scratch_len, int32_t *mb_index, float *norm_out, const void *gather_args,
+                                              int64_t mbs, int nseg, const float *const *partials, const int64_t *cols,
+                                              const int64_t *tiles, float *const *out, int64_t defer_lo, int64_t defer_hi,
+                                              int32_t *pending, void *stream) {
+  NEED(nseg >= 1 && nseg <= BIAS_MAX_SEGS && partials && cols && tiles && out, "nseg / partials / cols / tiles / out");
+  NEED(g != nullptr && n > 0, "g / n");
+  BiasSegs S{};
+  S.n = nseg;
+  int64_t covered = 0;
+  const float *lo = g + n;
+  for (int i = 0; i < nseg; i++) {
+    NEED(partials[i] && out[i] && cols[i] > 0 && tiles[i] > 0, "segment");
+    NEED(out[i] >= g && out[i] + cols[i] <= g + n, "segment outputs must lie inside the gradient buffer");
+    S.tiles[i] = tiles[i]; S.partials[i] = partials[i]; S.cols[i] = cols[i]; S.db[i] = out[i];
+    covered += cols[i];
+    lo = (out[i] < lo) ? out[i] : lo;
+  }
+  const int64_t tail_lo = lo - g;
+  NEED(tail_lo % 4 == 0 && covered <= n - tail_lo && n - tail_lo - covered < 4, "the finalised segments must tile the end of the gradient buffer");
+  FinBlocks FB{};
+  for (int i = 0; i < nseg; i++) FB.off[i + 1] = FB.off[i] + (int)((cols[i] + 63) / 64);
+  NEED(scratch_len >= ADAM_BLOCKS + (int64_t)FB.off[nseg], "scratch too small for the finalize blocks' partials");
+  return adam_clip_impl(device, p, g, m, v, n, step, lr, lr_dev, beta1, beta2, eps, max_norm, 1.0f, scratch, mb_index, norm_out,
+                        gather_args, mbs, stream, &S, tail_lo, &FB, defer_lo, defer_hi, pending);
+}
+
+extern "C" int brl_adam_apply_range(int device, float *p, const float *g, float *m, float *v, int64_t lo, int64_t hi, const float *scratch,
+                                    int npartials, const float *step, float lr, const float *lr_dev, float beta1, float beta2, float eps,
+                                    float max_norm, float grad_scale, int32_t *pending, int clear_pending, void *stream) {
+  NEED(p && g && m && v && scratch && step && npartials > 0, "p / g / m / v / scratch / step / npartials");
+  NEED(lo % 4 == 0 && hi % 4 == 0 && lo >= 0 && lo < hi, "range (multiples of 4)");
+  NEED(!clear_pending || pending, "clear_pending needs the flag");
+  HIP_TRY(hipSetDevice(device));
+  const AdamRange R = adam_range(p, g, m, v, lo, hi, scratch, npartials, step, lr, lr_dev, beta1, beta2, eps, max_norm, grad_scale, pending, nullptr);
+  const int64_t n4 = (hi - lo) / 4;
+  const unsigned nb = (unsigned)((n4 + 1023) / 1024);   // four float4s per thread
+  hipLaunchKernelGGL(k_adam_range, dim3(nb), dim3(ADAM_THREADS), 0, (hipStream_t)stream, R);
+  if (clear_pending) hipLaunchKernelGGL(k_clear_flag, dim3(1), dim3(1), 0, (hipStream_t)stream, pending);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
 }
 
 extern "C" int brl_ppo_stats(int device, const float *partials, int64_t batch, const float *gram, float vf_coef,

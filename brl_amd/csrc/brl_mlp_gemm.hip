@@ -4,8 +4,19 @@
 #include <stdint.h>
 
 #include "abi_common.hpp"
+#include "adam_role.hpp"
 #include "heads_dw_role.hpp"
 #include "mlp_gemm.hpp"
+
+// A forward layer of step i + 1 (bias + activation in the epilogue) with the part of step i's Adam sweep that updates the NEXT
+// layer's weights as extra workgroups of the same launch (csrc/adam_role.hpp): blocks [0, tiles) are GEMM tiles — one per CU at
+// the step's shape — the rest sit beside them as a second workgroup per CU, HBM-bound beside MFMA-bound.
+__global__ __launch_bounds__(mg::THREADS) void k_gemm64_fwd_adam(mg::Args G, AdamRange R, int tiles, int riders) {
+  __shared__ __attribute__((aligned(16))) float lds[mg::LDS_FLOATS + 128];
+  const int b = (int)blockIdx.x;
+  if (b < tiles) mg::gemm_tile<true, true, mg::EPI_BIAS_ACT>(G, lds, b, tiles);
+  else adam_range_block(R, b - tiles, riders, lds);
+}
 
 // dh = (dz W) * act'(h) of the layer below the top (on the backward chain) with the head's weight-gradient role (NOT on the chain:
 // csrc/heads_dw_role.hpp) as extra workgroups of the same launch: blocks [0, tiles) are GEMM tiles — one per CU at the step's
@@ -89,6 +100,35 @@ extern "C" int brl_mlp_gemm_dh_heads_dw(int device, const float *dz, int64_t ldd
   const int tiles = (int)(((m + 63) / 64) * ((n + 63) / 64));
   const unsigned blocks = (unsigned)(tiles + A.blocks_a + (sums ? HB_GRAM_BLOCKS : 0));
   hipLaunchKernelGGL(k_gemm64_dh_heads_dw, dim3(blocks), dim3(mg::THREADS), 0, (hipStream_t)stream, G, A, tiles);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_mlp_gemm_adam(int device, const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int64_t m,
+                                 int64_t n, int64_t k, int act, const float *bias, float *p, const float *g, float *mom, float *var,
+                                 int64_t lo, int64_t hi, const float *scratch, int npartials, const float *step, float lr,
+                                 const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale,
+                                 const int32_t *pending, void *stream) {
+  NEED(a && b && c && bias && m > 0 && n > 0 && k > 0, "a / b / c / bias / m / n / k");
+  NEED(m < (1 << 24) && n < (1 << 24) && k < (1 << 24), "m / n / k below 2^24");
+  NEED(n % 4 == 0 && k % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && lda >= k && ldb >= k && ldc >= n,
+       "n, k and the leading dimensions multiples of 4");
+  NEED(m * lda < (1ll << 29) && n * ldb < (1ll << 29), "operands below 2 GB");
+  NEED(act == 0 || act == 1, "act (0 ReLU, 1 tanh)");
+  NEED(p && g && mom && var && scratch && step && pending && npartials > 0, "p / g / m / v / scratch / step / pending / npartials");
+  NEED(lo % 4 == 0 && hi % 4 == 0 && lo >= 0 && lo < hi, "range (multiples of 4)");
+  // the weights this launch READS must not be the ones it updates
+  NEED(b + n * ldb <= p + lo || b >= p + hi, "the range must not overlap the layer's own weights");
+  HIP_TRY(hipSetDevice(device));
+  mg::Args G{};
+  G.A = a; G.lda = lda; G.B = b; G.ldb = ldb; G.C = c; G.ldc = ldc; G.M = (int)m; G.N = (int)n; G.K = (int)k; G.act = act; G.bias = bias;
+  AdamRange R{};
+  R.p = p; R.g = g; R.m = mom; R.v = var; R.lo4 = lo >> 2; R.hi4 = hi >> 2; R.partials = scratch; R.npartials = npartials; R.step = step;
+  R.lr_dev = lr_dev; R.lr = lr; R.b1 = beta1; R.b2 = beta2; R.eps = eps; R.max_norm = max_norm; R.gscale = grad_scale; R.pending = pending;
+  const int tiles = (int)(((m + 63) / 64) * ((n + 63) / 64));
+  const int64_t n4 = (hi - lo) / 4;
+  const int riders = (int)((n4 + 1023) / 1024);   // four float4s per thread: 256 riders for a 1024 x 1024 layer
+  hipLaunchKernelGGL(k_gemm64_fwd_adam, dim3((unsigned)(tiles + riders)), dim3(mg::THREADS), 0, (hipStream_t)stream, G, R, tiles, riders);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

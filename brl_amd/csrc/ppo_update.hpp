@@ -268,65 +268,32 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_norm_fin(const float *g, 
   }
 }
 
-__global__ __launch_bounds__(ADAM_THREADS) void k_adam_apply(float *p, const float *g, float *m, float *v, int64_t n,
-                                                             const float *partials, const float *step, float lr_arg,
-                                                             const float *lr_dev, float b1,
-                                                             float b2, float eps, float max_norm, float gscale,
-                                                             float *norm_out, const GatherArgs *gather, int npartials) {
-  if (blockIdx.x >= ADAM_BLOCKS) {
-    // extra blocks (gather != NULL): the NEXT minibatch's rows -> the static minibatch buffers, beside the parameter update.
-    // Nothing of this step reads those buffers any more (stream order), k_adam_norm has already advanced mb_index, and the
-    // 1024 random 535-byte rows are pure latency — 5.6 us as a launch of its own in front of the forward pass.
+#include "adam_role.hpp"   // AdamRange, adam_range_block: the sweep itself (shared with the GEMM translation unit, where parts of it ride)
+
+// blocks [0, nb1): range R1; [nb1, nb1 + nb2): range R2 (nb2 may be 0: one range); the rest (gather != NULL): the NEXT minibatch's
+// rows -> the static minibatch buffers, beside the parameter update.  Nothing of this step reads those buffers any more (stream
+// order), k_adam_norm has already advanced mb_index, and the 1024 random 535-byte rows are pure latency — 5.6 us as a launch of its
+// own in front of the forward pass.  set_pending (optional): the part of the sweep this launch leaves out is owed (adam_role.hpp).
+__global__ __launch_bounds__(ADAM_THREADS) void k_adam_apply(AdamRange R1, AdamRange R2, int nb1, int nb2, const GatherArgs *gather,
+                                                             int32_t *set_pending) {
+  __shared__ float red[8];
+  const int b = (int)blockIdx.x;
+  if (b >= nb1 + nb2) {
     const GatherArgs A = *gather;
     if ((int64_t)(*A.mb_index) >= A.nsteps) return;   // (the update's last step: nothing follows)
-    const int64_t b = ((int64_t)blockIdx.x - ADAM_BLOCKS) * 2 + (threadIdx.x >> 7);
-    if (b < A.B) mb_gather_row(A, b, (int)(threadIdx.x & 127u));
+    const int64_t row = ((int64_t)b - nb1 - nb2) * 2 + (threadIdx.x >> 7);
+    if (row < A.B) mb_gather_row(A, row, (int)(threadIdx.x & 127u));
     return;
   }
-  __shared__ float red[ADAM_THREADS / 64];
-  __shared__ float s_scale;
-  {
-    float s = 0.0f;
-    for (int i0 = (int)threadIdx.x; i0 < npartials; i0 += 8 * ADAM_THREADS) {   // (eight loads in flight: one round trip for <= 2048)
-      float pv[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) pv[u] = (i0 + u * ADAM_THREADS < npartials) ? partials[i0 + u * ADAM_THREADS] : 0.0f;
-#pragma unroll
-      for (int u = 0; u < 8; u++) s += pv[u];
-    }
-    s = wave_sum_f(s);
-    if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
-      // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
-      const float coef = (max_norm > 0.0f) ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
-      s_scale = coef;
-      if (blockIdx.x == 0 && norm_out) *norm_out = norm;
-    }
-    __syncthreads();
-  }
-  const float scale = s_scale * gscale;
-  const float t = *step;
-  const float lr = (lr_dev != nullptr) ? *lr_dev : lr_arg;  // device-resident: a captured launch follows the lr schedule
-  const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
-  const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
-  const int64_t n4 = n >> 2;
-  const int64_t chunk = (n4 + ADAM_BLOCKS - 1) / ADAM_BLOCKS;
-  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n4) ? lo + chunk : n4;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += ADAM_THREADS) {
-    const float4 g4 = reinterpret_cast<const float4 *>(g)[i];
-    float4 m4 = reinterpret_cast<float4 *>(m)[i], v4 = reinterpret_cast<float4 *>(v)[i], p4 = reinterpret_cast<float4 *>(p)[i];
-    const float gs[4] = {g4.x * scale, g4.y * scale, g4.z * scale, g4.w * scale};
-    float ms[4] = {m4.x, m4.y, m4.z, m4.w}, vs[4] = {v4.x, v4.y, v4.z, v4.w}, ps[4] = {p4.x, p4.y, p4.z, p4.w};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      ms[k] = ms[k] + (gs[k] - ms[k]) * (1.0f - b1);            // exp_avg.lerp_(grad, 1 - beta1)
-      vs[k] = vs[k] * b2 + gs[k] * gs[k] * (1.0f - b2);          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-      ps[k] -= step_size * (ms[k] / (sqrtf(vs[k]) / bc2_sqrt + eps));
-    }
-    reinterpret_cast<float4 *>(m)[i] = make_float4(ms[0], ms[1], ms[2], ms[3]);
-    reinterpret_cast<float4 *>(v)[i] = make_float4(vs[0], vs[1], vs[2], vs[3]);
-    reinterpret_cast<float4 *>(p)[i] = make_float4(ps[0], ps[1], ps[2], ps[3]);
-  }
+  if (b == 0 && threadIdx.x == 0 && set_pending) *set_pending = 1;
+  if (b < nb1) adam_range_block(R1, b, nb1, red);
+  else adam_range_block(R2, b - nb1, nb2, red);
 }
+
+// a deferred range as a launch of its own (the end of an update: no forward pass follows that could carry it), and the
+// one-thread launch behind it that clears the flag
+__global__ __launch_bounds__(ADAM_THREADS) void k_adam_range(AdamRange R) {
+  __shared__ float red[8];
+  adam_range_block(R, (int)blockIdx.x, (int)gridDim.x, red);
+}
+__global__ void k_clear_flag(int32_t *flag) { *flag = 0; }

@@ -355,7 +355,22 @@ class FusedMinibatch:
         # derivative and the bias-gradient tile sums inside (replaces torch.mm + brl_act_bwd_colsum).  Layer 0 (K = 480) and the
         # weight gradients (one batched library product) stay with the library.  config["own_gemm"]: True / False.
         self.own_gemm = bool(config.get("own_gemm", True)) and self.single_chain and B % 4 == 0 and H % 4 == 0 and nl > 1
-        self.own_fwd = self.own_gemm and bool(config.get("own_gemm_fwd", True))   # (A/B switch: the forward layers alone)
+        # (the forward layers on the own kernel: opt-in — in the step it takes 19.8-20.1 us per layer where the tuned library
+        #  kernel with the same epilogue takes 19.0-19.6; profiles/r04/r04_experiments.txt)
+        self.own_fwd = self.own_gemm and bool(config.get("own_gemm_fwd", False))
+        # The Adam sweep off the dependency chain (config["adam_ride"]): the step's own clip + Adam launch updates only what the
+        # next forward pass needs at once — layers 0 and 1 and every bias; the rest is owed (self.pending) and paid by extra
+        # workgroups of the NEXT step's forward launches: layer l's launch (l = 1 .. nl - 2) updates layer l + 1's weights, the
+        # last of them also the head's (HBM-bound beside MFMA-bound); `_flush_adam` pays what the last step of a run owes.
+        # Built, bit-compatible, measured and NOT the default: the riders slow their host launches by more than the chain's launch
+        # shrinks (+ 4.5 and + 6.3 us on two forward launches for - 7.5 us of the Adam launch: 0.2359 vs 0.2337 ms per step).
+        self.adam_ride = self.own_fwd and self.world == 1 and nl >= 3 and bool(config.get("adam_ride", False))
+        self.pending = torch.zeros(1, dtype=torch.int32, device=device)
+        if self.adam_ride:
+            bias0 = views[body[0].bias].start
+            self.defer = (views[body[2].weight].start, bias0)
+            self.ride = {l: (views[body[l + 1].weight].start,
+                             views[body[l + 2].weight].start if l + 2 < nl else bias0) for l in range(1, nl - 1)}
         groups64 = (B + 63) // 64                      # 64-row tiles of brl_mlp_gemm's column sums
         self.tile_rows = [64 if (self.own_gemm and l < nl - 1) else 16 for l in range(nl)]
         self.tile_sums = [f(groups * H) for _ in body]   # per-layer partial column sums (bias gradients)
@@ -368,6 +383,7 @@ class FusedMinibatch:
         self._seg_tiles = (C.c_int64 * nseg)(*([groups64 if r == 64 else groups for r in self.tile_rows] + [self.nsplit, self.nsplit]))
         self._seg_db = (C.c_void_p * nseg)(*([g.data_ptr() for g in self.Gb] + [self.Gbh.data_ptr(), self.GWh.data_ptr()]))
         self._nseg = nseg
+        self.npartials = 1024 + sum((int(c) + 63) // 64 for c in self._seg_cols)   # k_adam_norm_fin's partial sums
         # The logged statistics (src/update.py:136-167) are NOT formed step by step: every step leaves its sums — 8 floats and
         # the 38 x 38 Gram matrix of the illegal-action probabilities, reduced by spare workgroups of the head-backward
         # launch — in row mb_index of these buffers, and ONE launch at the end of the update turns all rows into log rows
@@ -452,6 +468,7 @@ class FusedMinibatch:
             with torch.no_grad():
                 for t, q in zip((self.P, self.M, self.V, self.step, self.mb_index), saved):
                     t.copy_(q)
+                self.pending.zero_()   # (nothing is owed: the warm-up's deferred sweeps were discarded with its parameters)
 
     def _bind_gather(self, fl: Transition, adv, tgt, perm, first=True):
         """binds the step's gather to a trajectory / permutation; ``first``: also gathers minibatch *mb_index now (every later
@@ -502,6 +519,15 @@ class FusedMinibatch:
         cfg = self.cfg
         x = self.x0   # minibatch *mb_index of the bound trajectory: gathered by the previous step's Adam launch (or by the bind)
         for l, (W, b) in enumerate(zip(self.W, self.b)):          # forward: bias + activation
+            if self.adam_ride and l in self.ride:                 # + the owed Adam sweep of the next layer's weights
+                lo, hi = self.ride[l]
+                chk(L.brl_mlp_gemm_adam(di, x.data_ptr(), x.stride(0), W.data_ptr(), W.stride(0), self.h[l].data_ptr(),
+                                        self.h[l].stride(0), B, W.shape[0], W.shape[1], self.act, b.data_ptr(), self.P.data_ptr(),
+                                        self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), lo, hi, self.scratch.data_ptr(),
+                                        self.npartials, self.step.data_ptr(), self.lr, self.lr_dev.data_ptr(), float(self.b1),
+                                        float(self.b2), self.eps, self.max_norm, 1.0, self.pending.data_ptr(), s))
+                x = self.h[l]
+                continue
             if self.own_fwd and l > 0:                            # own kernel: bias + activation in its epilogue
                 chk(L.brl_mlp_gemm(di, 0, 1, x.data_ptr(), x.stride(0), W.data_ptr(), W.stride(0), self.h[l].data_ptr(),
                                    self.h[l].stride(0), B, W.shape[0], W.shape[1], self.act, b.data_ptr(), None, 0, None, None, s))
@@ -605,12 +631,30 @@ class FusedMinibatch:
         """single rank: every sum of partials is finished by extra workgroups of the norm launch (brl_adam_clip_fin_gather)"""
         s = torch.cuda.current_stream().cuda_stream
         di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        if self.adam_ride:
+            self.capi.check(self.lib.brl_adam_clip_fin_gather_defer(
+                di, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), self.n, self.step.data_ptr(), self.lr,
+                self.lr_dev.data_ptr(), float(self.b1), float(self.b2), self.eps, self.max_norm, self.scratch.data_ptr(),
+                self.scratch.numel(), self.mb_index.data_ptr(), self.norm.data_ptr(), self.gargs.data_ptr(), self.mbs, self._nseg,
+                self._seg_scratch, self._seg_cols, self._seg_tiles, self._seg_db, self.defer[0], self.defer[1],
+                self.pending.data_ptr(), s))
+            return
         self.capi.check(self.lib.brl_adam_clip_fin_gather(di, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
                                                           self.n, self.step.data_ptr(), self.lr, self.lr_dev.data_ptr(), float(self.b1),
                                                           float(self.b2), self.eps, self.max_norm, self.scratch.data_ptr(),
                                                           self.scratch.numel(), self.mb_index.data_ptr(), self.norm.data_ptr(),
                                                           self.gargs.data_ptr(), self.mbs, self._nseg, self._seg_scratch, self._seg_cols,
                                                           self._seg_tiles, self._seg_db, s))
+
+    def _flush_adam(self):
+        """pays the part of the last step's Adam sweep that no forward pass followed (adam_ride); clears the flag"""
+        if not self.adam_ride:
+            return
+        di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        self.capi.check(self.lib.brl_adam_apply_range(
+            di, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), self.defer[0], self.defer[1],
+            self.scratch.data_ptr(), self.npartials, self.step.data_ptr(), self.lr, self.lr_dev.data_ptr(), float(self.b1),
+            float(self.b2), self.eps, self.max_norm, 1.0, self.pending.data_ptr(), 1, torch.cuda.current_stream().cuda_stream))
 
     def _opt(self):
         s = torch.cuda.current_stream().cuda_stream
@@ -674,6 +718,7 @@ class FusedMinibatch:
                 n -= k
             for _ in range(n):
                 self.graph.replay()
+            self._flush_adam()
             return
         ar = self._collective if self._collective is not None else \
             (lambda t, async_op: dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op))

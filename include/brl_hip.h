@@ -541,6 +541,30 @@ int brl_mlp_gemm_dh_heads_dw(int device, const float *dz, int64_t lddz, const fl
                              float *dw_partials, float *db_partials, const float *loss_partials, const float *gram_partials,
                              int64_t ngroups, const int32_t *row_index, float *stat_sums, float *gram_sums, void *stream);
 
+/* ---- the Adam sweep off the step's dependency chain (round 4) ----------------------------------------------------------------
+ * brl_adam_clip_fin_gather whose apply launch leaves out the floats [defer_lo, defer_hi) of the flat buffers (multiples of 4) and
+ * sets *pending = 1: that part of the sweep is owed.  It is paid, layer by layer, by extra workgroups of the NEXT step's forward
+ * launches (brl_mlp_gemm_adam: the launch that multiplies with layer l's weights updates layer l + 1's) or, where no step follows,
+ * by brl_adam_apply_range.  The norm partials in `scratch`, *step and the gradients of the range stay untouched until then (the
+ * next step rewrites them only at its own end).  npartials of those calls = 1024 + sum over the segments of ceil(cols / 64). */
+int brl_adam_clip_fin_gather_defer(int device, float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
+                                   const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float *scratch,
+                                   int64_t scratch_len, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs,
+                                   int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles, float *const *out,
+                                   int64_t defer_lo, int64_t defer_hi, int32_t *pending, void *stream);
+/* brl_mlp_gemm(BRL_GEMM_NT, BRL_GEMM_EPI_BIAS_ACT, ...) — one forward layer — with clip + Adam on the floats [lo, hi) of the flat
+ * buffers as extra workgroups of the same launch, applied only where *pending != 0.  The range must not contain the weights the
+ * launch multiplies with. */
+int brl_mlp_gemm_adam(int device, const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int64_t m, int64_t n,
+                      int64_t k, int act, const float *bias, float *p, const float *g, float *mom, float *var, int64_t lo, int64_t hi,
+                      const float *scratch, int npartials, const float *step, float lr, const float *lr_dev, float beta1, float beta2,
+                      float eps, float max_norm, float grad_scale, const int32_t *pending, void *stream);
+/* The owed range as a launch of its own (pending may be NULL: unconditional); clear_pending: a one-thread launch behind it sets
+ * *pending = 0. */
+int brl_adam_apply_range(int device, float *p, const float *g, float *m, float *v, int64_t lo, int64_t hi, const float *scratch,
+                         int npartials, const float *step, float lr, const float *lr_dev, float beta1, float beta2, float eps,
+                         float max_norm, float grad_scale, int32_t *pending, int clear_pending, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

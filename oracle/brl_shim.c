@@ -348,6 +348,32 @@ int brl_mlp_gemm_dh_heads_dw(int device, const float *dz, int64_t lddz, const fl
   (void)loss_partials; (void)gram_partials; (void)ngroups; (void)row_index; (void)stat_sums; (void)gram_sums; (void)s;
   NOT_HERE("brl_mlp_gemm_dh_heads_dw");
 }
+int brl_adam_clip_fin_gather_defer(int device, float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
+                                   const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float *scratch,
+                                   int64_t scratch_len, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs,
+                                   int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles, float *const *out,
+                                   int64_t defer_lo, int64_t defer_hi, int32_t *pending, void *s) {
+  (void)device; (void)p; (void)g; (void)m; (void)v; (void)n; (void)step; (void)lr; (void)lr_dev; (void)beta1; (void)beta2; (void)eps;
+  (void)max_norm; (void)scratch; (void)scratch_len; (void)mb_index; (void)norm_out; (void)gather_args; (void)mbs; (void)nseg;
+  (void)partials; (void)cols; (void)tiles; (void)out; (void)defer_lo; (void)defer_hi; (void)pending; (void)s;
+  NOT_HERE("brl_adam_clip_fin_gather_defer");
+}
+int brl_mlp_gemm_adam(int device, const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int64_t m, int64_t n,
+                      int64_t k, int act, const float *bias, float *p, const float *g, float *mom, float *var, int64_t lo, int64_t hi,
+                      const float *scratch, int npartials, const float *step, float lr, const float *lr_dev, float beta1, float beta2,
+                      float eps, float max_norm, float grad_scale, const int32_t *pending, void *s) {
+  (void)device; (void)a; (void)lda; (void)b; (void)ldb; (void)c; (void)ldc; (void)m; (void)n; (void)k; (void)act; (void)bias; (void)p; (void)g;
+  (void)mom; (void)var; (void)lo; (void)hi; (void)scratch; (void)npartials; (void)step; (void)lr; (void)lr_dev; (void)beta1; (void)beta2;
+  (void)eps; (void)max_norm; (void)grad_scale; (void)pending; (void)s;
+  NOT_HERE("brl_mlp_gemm_adam");
+}
+int brl_adam_apply_range(int device, float *p, const float *g, float *m, float *v, int64_t lo, int64_t hi, const float *scratch,
+                         int npartials, const float *step, float lr, const float *lr_dev, float beta1, float beta2, float eps,
+                         float max_norm, float grad_scale, int32_t *pending, int clear_pending, void *s) {
+  (void)device; (void)p; (void)g; (void)m; (void)v; (void)lo; (void)hi; (void)scratch; (void)npartials; (void)step; (void)lr; (void)lr_dev;
+  (void)beta1; (void)beta2; (void)eps; (void)max_norm; (void)grad_scale; (void)pending; (void)clear_pending; (void)s;
+  NOT_HERE("brl_adam_apply_range");
+}
 int brl_adam_clip_fin_gather(int device, float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
                              const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float *scratch,
                              int64_t scratch_len, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs,
