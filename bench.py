@@ -710,7 +710,7 @@ def rehearse_multirank(torch, dev, cfg, fp, traj, adv, tgt, single_ms):
             ts.append(time.perf_counter() - t0)
             fm.end_update()
         t = float(np.median(ts[1:]))
-        res[mode] = {"ms_per_minibatch": t / (rows // 1024) * 1e3, "graphs_per_step": len(fm.segs),
+        res[mode] = {"ms_per_minibatch": t / (rows // 1024) * 1e3, "graph_replays_per_step": 1 if mode == "flat" else len(fm.segs),
                      "collectives_per_step": 1 if mode == "flat" else len([b for b in fm.buckets if b is not None]),
                      "overhead_vs_single_rank_ms": t / (rows // 1024) * 1e3 - single_ms}
         del fm, net, opt

@@ -1962,7 +1962,7 @@ static int fail(int code, const char *fmt, const char *detail) { return brl_fail
 #include "abi_common.hpp"   // HIP_TRY, NEED
 
 extern "C" const char *brl_last_error(void) { return g_err; }
-extern "C" int brl_version(void) { return 1; }
+extern "C" int brl_version(void) { return 4; }   // include/brl_hip.h: the round the exported set last changed in
 
 static inline Rng rng_of(const brl_handle *h) { return Rng{(uint32_t)h->seed, (uint32_t)(h->seed >> 32)}; }
 static inline LutRef lut_of(const brl_handle *h) { return LutRef{h->lut_keys, h->lut_values, (uint32_t)h->lut_len, h->lut_hands}; }
@@ -3032,12 +3032,3 @@ extern "C" int brl_ppo_stats(int device, const float *partials, int64_t batch, c
   return BRL_OK;
 }
 
-extern "C" int brl_ppo_stats_at(int device, const float *partials, int64_t batch, const float *gram, float vf_coef,
-                                float ent_coef, float *out_rows, const int32_t *row_index, void *stream) {
-  NEED(partials && out_rows && row_index && batch > 0, "partials / out_rows / row_index / batch");
-  HIP_TRY(hipSetDevice(device));
-  hipLaunchKernelGGL(k_ppo_stats, dim3(1), dim3(512), 0, (hipStream_t)stream, partials, (int64_t)thread_grid(batch, 4), batch,
-                     gram, vf_coef, ent_coef, out_rows, row_index);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
-}

@@ -442,7 +442,11 @@ class FusedMinibatch:
             elif self.allreduce_mode == "flat":
                 pool = torch.cuda.graph_pool_handle()
                 self.segs = []
-                for seg in (self._grads, self._opt):
+                # three graphs: [gradients] | [clip + Adam of step i, then the gradients of step i + 1] | [clip + Adam]: a run of n
+                # steps is first, (all-reduce, middle) x (n - 1), all-reduce, last — ONE replay and one collective per step
+                # (a replay costs ~20 us of host -> device latency; as gradient graph + Adam graph the step took 0.282 ms, see
+                # bench.py's config4_rehearsal)
+                for seg in (self._grads, lambda: (self._opt(), self._grads()), self._opt):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, pool=pool, **gkw), torch.no_grad():
                         seg()
@@ -723,10 +727,14 @@ class FusedMinibatch:
         ar = self._collective if self._collective is not None else \
             (lambda t, async_op: dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op))
         if self.allreduce_mode == "flat":
-            for _ in range(n):
-                self.segs[0].replay()
+            if n <= 0:
+                return
+            self.segs[0].replay()
+            for _ in range(n - 1):
                 ar(self.G, False)                                     # brl_adam_clip divides by world (grad_scale)
                 self.segs[1].replay()
+            ar(self.G, False)
+            self.segs[2].replay()
             return
         for _ in range(n):
             works = []

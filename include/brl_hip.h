@@ -47,6 +47,9 @@ extern "C" {
 typedef struct brl_handle brl_handle;
 
 const char *brl_last_error(void);
+/* The version of the EXPORTED SET: the number of the build round in which a symbol was last added or removed (4 now).  A symbol's
+ * signature and meaning never change once exported — a changed form gets a new name and the old one moves to the "superseded
+ * forms" section at the end of this header until nothing uses it, then it is dropped and the version is bumped. */
 int brl_version(void);
 
 /* BridgeBidding(dds_results_table_path)  — ppo.py:303, pgx.bridge_bidding.BridgeBidding.
@@ -355,64 +358,15 @@ int brl_ppo_stats(int device, const float *partials, int64_t batch, const float 
 /* ---- one PPO minibatch step without the small launches (src/update.py:74-242; brl_amd/update.py::FusedMinibatch strings
  * these together with the 14 GEMMs of the 4 x 1024 MLP and captures the step in one hipGraph) ---------------------------- */
 
-/* brl_ppo_loss on the MERGED head output: heads float [batch,39] = 38 logits then the value (one GEMM for both heads);
- * dheads float [batch,39] receives d(total)/d(heads).  Everything else as brl_ppo_loss. */
-int brl_ppo_loss_heads(int device, const float *heads, const uint8_t *mask, const int32_t *action, const float *old_value,
-                       const float *old_log_prob, const float *gae, const float *targets, int64_t batch, float clip_eps,
-                       float vf_coef, float ent_coef, int masked, int value_clipping, float *dheads, float *partials,
-                       float *illegal_probs, void *stream);
 
-/* `shuffled = take(batch, permutation)` + the slice of minibatch *mb_index (src/update.py:193-206) in one launch: row
- * perm[*mb_index * mbs + b] of the flattened [T*N] trajectory `flat` (and of adv / targets) -> the static minibatch
- * buffers; x0 float [mbs,480] = obs.astype(float32) (src/update.py:95).  mb_index is DEVICE memory (brl_adam_clip advances
- * it), so a captured graph walks through an epoch by itself. */
-int brl_mb_gather(int device, const brl_transition *flat, const float *adv, const float *targets, const int64_t *perm,
-                  const int32_t *mb_index, int64_t mbs, float *x0, uint8_t *mask, int32_t *action, float *old_value,
-                  float *old_log_prob, float *gae_out, float *targets_out, void *stream);
 
-/* Backward of `h = relu(z)` plus the bias gradient of that layer: dh [rows,ld] *= (h > 0) in place and the column sums
- * of every row tile (16 rows when cols and ld are multiples of 4, else 64) into scratch (float [ceil(rows / 16) * cols]
- * is always enough); db != NULL: a second launch adds the tiles in index
- * order, db[c] = sum_r dh[r,c] (deterministic).  h == NULL: column sums only (the head's bias gradient).
- * db == NULL: tiles only — brl_bias_finalize then finishes several layers with one launch. */
-int brl_relu_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, float *db,
-                        float *scratch, void *stream);
 
-/* db[i][c] = sum over the tiles of scratch[i] (as written by brl_relu_bwd_colsum for `rows` dense rows, ld == cols[i])
- * for nseg <= 12 layers. */
-int brl_bias_finalize(int device, int nseg, const float *const *scratch, const int64_t *cols, float *const *db, int64_t rows,
-                      void *stream);
 
-/* brl_ppo_stats writing row *row_index (device memory) of out_rows float [steps,8]: the loss log of a whole update. */
-int brl_ppo_stats_at(int device, const float *partials, int64_t batch, const float *gram, float vf_coef, float ent_coef,
-                     float *out_rows, const int32_t *row_index, void *stream);
 
-/* optax.chain(clip_by_global_norm(max_norm), adam(lr, eps)) (ppo.py:195-211) on flat fp32 buffers of n elements, two
- * launches (n a multiple of 4: pad the buffers with zeros): *step (device float) += 1; the gradient is grad_scale * g
- * (1 / world_size after a SUM all-reduce: the ranks' mean, ppo.py's pmean; 1 otherwise), scaled by
- * min(1, max_norm / (|gradient| + 1e-6)) (max_norm <= 0: no clipping); m, v, p updated with torch.optim.Adam's arithmetic.
- * lr_dev (may be NULL): the learning rate in device memory, used instead of `lr` (a captured launch then follows
- * ppo.py:186-192's linear schedule).  scratch: float [1024].  mb_index (may be NULL): advanced by one.
- * norm_out (may be NULL): |g| before clipping. */
-int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
-                  const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale, float *scratch,
-                  int32_t *mb_index, float *norm_out, void *stream);
 
 /* ---- the 39-column head (38 logits + value, src/models.py:30-33) of one PPO minibatch step as three launches instead of four
  * library GEMMs with N or K = 39 and five small kernels (brl_amd/csrc/ppo_heads.hpp) ------------------------------------- */
 
-/* heads = h head_w^T + head_b (h float [batch, ldh >= hidden], the last hidden layer's output; head_w float [39, hidden] = actor
- * rows then the critic row; head_b float [39]; hidden % 16 == 0), then `_loss_fn` (src/update.py:90-167) exactly as
- * brl_ppo_loss_heads on that matrix: dheads float [batch,39] = d(total)/d(heads); partials float [ceil(batch / 4) * 8] for
- * brl_ppo_stats_gram; gram_partials (may be NULL) float [ceil(batch / 4) * 1444]: per 4-sample group, P^T P of its
- * illegal-action probabilities (src/update.py:136-141).  reward_scaling != 0: the advantages are normalised over the
- * minibatch first, (gae - mean) / (std + 1e-8) with jnp's ddof = 0 (src/update.py:31-44,118).  heads_out (may be NULL):
- * float [batch,39]. */
-int brl_ppo_heads_loss(int device, const float *h, int64_t ldh, const float *head_w, const float *head_b, int64_t hidden,
-                       const uint8_t *mask, const int32_t *action, const float *old_value, const float *old_log_prob,
-                       const float *gae, const float *targets, int64_t batch, float clip_eps, float vf_coef, float ent_coef,
-                       int masked, int value_clipping, int reward_scaling, float *heads_out, float *dheads, float *partials,
-                       float *gram_partials, void *stream);
 /* The same as TWO launches: the heads product split over K across workgroups (ksplit ranges, 1..8; 4 at hidden = 1024) into
  * head_parts float [ksplit, batch, 39] (scratch), then the loss on bias + the parts added in order.  One workgroup of the
  * one-launch form pulls all of W_h through its CU before it can start (9.3 k of its 24.4 k cycles); here a workgroup reads a
@@ -438,7 +392,7 @@ int brl_ppo_heads_bwd(int device, const float *dheads, const float *h, int64_t l
                       const float *loss_partials, const float *gram_partials, int64_t ngroups, const int32_t *row_index,
                       float *stat_sums, float *gram_sums, void *stream);
 
-/* brl_ppo_stats_at from brl_ppo_heads_loss's outputs: partials float [npartials, 8], gram_partials float [ngram, 1444] (summed
+/* The log row of one step from brl_ppo_heads_loss_split's outputs (written at row *row_index when given): partials float [npartials, 8], gram_partials float [ngram, 1444] (summed
  * in order).  The illegal-action norm comes from 4 squarings of G / trace by the whole block and 16 power-iteration steps with
  * that matrix (G^256 v, as brl_ppo_stats).  total_loss includes illegal_coef * norm / 2.  row_index may be NULL (row 0).  vec_out (may be NULL): float [40] = the top right
  * singular vector v1 [38], sigma_1, 0 — what the gradient of the norm needs (d sigma_1 / dP = u1 v1^T). */
@@ -564,6 +518,67 @@ int brl_mlp_gemm_adam(int device, const float *a, int64_t lda, const float *b, i
 int brl_adam_apply_range(int device, float *p, const float *g, float *m, float *v, int64_t lo, int64_t hi, const float *scratch,
                          int npartials, const float *step, float lr, const float *lr_dev, float beta1, float beta2, float eps,
                          float max_norm, float grad_scale, int32_t *pending, int clear_pending, void *stream);
+
+/* ==================================================================================================================
+ * SUPERSEDED FORMS — still exported because tests use them as the reference form of their successors and the A/B scripts
+ * under scripts/ time them; the default brl_amd code path calls none of them.  Successors: brl_ppo_loss_heads ->
+ * brl_ppo_heads_loss_split (heads formed inside); brl_mb_gather -> brl_mb_gather_bind / _dev (device-resident arguments);
+ * brl_relu_bwd_colsum -> brl_act_bwd_colsum (either activation) -> brl_mlp_gemm's GATE_COLSUM epilogue; brl_bias_finalize ->
+ * brl_bias_finalize_ex -> the finalize blocks of brl_adam_clip_fin_gather; brl_adam_clip -> brl_adam_clip_gather /
+ * _fin_gather; brl_ppo_heads_loss -> brl_ppo_heads_loss_split.  (brl_ppo_stats_at was dropped in version 4: no caller left.)
+ * ================================================================================================================== */
+
+/* brl_ppo_loss on the MERGED head output: heads float [batch,39] = 38 logits then the value (one GEMM for both heads);
+ * dheads float [batch,39] receives d(total)/d(heads).  Everything else as brl_ppo_loss. */
+int brl_ppo_loss_heads(int device, const float *heads, const uint8_t *mask, const int32_t *action, const float *old_value,
+                       const float *old_log_prob, const float *gae, const float *targets, int64_t batch, float clip_eps,
+                       float vf_coef, float ent_coef, int masked, int value_clipping, float *dheads, float *partials,
+                       float *illegal_probs, void *stream);
+
+/* `shuffled = take(batch, permutation)` + the slice of minibatch *mb_index (src/update.py:193-206) in one launch: row
+ * perm[*mb_index * mbs + b] of the flattened [T*N] trajectory `flat` (and of adv / targets) -> the static minibatch
+ * buffers; x0 float [mbs,480] = obs.astype(float32) (src/update.py:95).  mb_index is DEVICE memory (brl_adam_clip advances
+ * it), so a captured graph walks through an epoch by itself. */
+int brl_mb_gather(int device, const brl_transition *flat, const float *adv, const float *targets, const int64_t *perm,
+                  const int32_t *mb_index, int64_t mbs, float *x0, uint8_t *mask, int32_t *action, float *old_value,
+                  float *old_log_prob, float *gae_out, float *targets_out, void *stream);
+
+/* Backward of `h = relu(z)` plus the bias gradient of that layer: dh [rows,ld] *= (h > 0) in place and the column sums
+ * of every row tile (16 rows when cols and ld are multiples of 4, else 64) into scratch (float [ceil(rows / 16) * cols]
+ * is always enough); db != NULL: a second launch adds the tiles in index
+ * order, db[c] = sum_r dh[r,c] (deterministic).  h == NULL: column sums only (the head's bias gradient).
+ * db == NULL: tiles only — brl_bias_finalize then finishes several layers with one launch. */
+int brl_relu_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, float *db,
+                        float *scratch, void *stream);
+
+/* db[i][c] = sum over the tiles of scratch[i] (as written by brl_relu_bwd_colsum for `rows` dense rows, ld == cols[i])
+ * for nseg <= 12 layers. */
+int brl_bias_finalize(int device, int nseg, const float *const *scratch, const int64_t *cols, float *const *db, int64_t rows,
+                      void *stream);
+
+/* optax.chain(clip_by_global_norm(max_norm), adam(lr, eps)) (ppo.py:195-211) on flat fp32 buffers of n elements, two
+ * launches (n a multiple of 4: pad the buffers with zeros): *step (device float) += 1; the gradient is grad_scale * g
+ * (1 / world_size after a SUM all-reduce: the ranks' mean, ppo.py's pmean; 1 otherwise), scaled by
+ * min(1, max_norm / (|gradient| + 1e-6)) (max_norm <= 0: no clipping); m, v, p updated with torch.optim.Adam's arithmetic.
+ * lr_dev (may be NULL): the learning rate in device memory, used instead of `lr` (a captured launch then follows
+ * ppo.py:186-192's linear schedule).  scratch: float [1024].  mb_index (may be NULL): advanced by one.
+ * norm_out (may be NULL): |g| before clipping. */
+int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
+                  const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale, float *scratch,
+                  int32_t *mb_index, float *norm_out, void *stream);
+
+/* heads = h head_w^T + head_b (h float [batch, ldh >= hidden], the last hidden layer's output; head_w float [39, hidden] = actor
+ * rows then the critic row; head_b float [39]; hidden % 16 == 0), then `_loss_fn` (src/update.py:90-167) exactly as
+ * brl_ppo_loss_heads on that matrix: dheads float [batch,39] = d(total)/d(heads); partials float [ceil(batch / 4) * 8] for
+ * brl_ppo_stats_gram; gram_partials (may be NULL) float [ceil(batch / 4) * 1444]: per 4-sample group, P^T P of its
+ * illegal-action probabilities (src/update.py:136-141).  reward_scaling != 0: the advantages are normalised over the
+ * minibatch first, (gae - mean) / (std + 1e-8) with jnp's ddof = 0 (src/update.py:31-44,118).  heads_out (may be NULL):
+ * float [batch,39]. */
+int brl_ppo_heads_loss(int device, const float *h, int64_t ldh, const float *head_w, const float *head_b, int64_t hidden,
+                       const uint8_t *mask, const int32_t *action, const float *old_value, const float *old_log_prob,
+                       const float *gae, const float *targets, int64_t batch, float clip_eps, float vf_coef, float ent_coef,
+                       int masked, int value_clipping, int reward_scaling, float *heads_out, float *dheads, float *partials,
+                       float *gram_partials, void *stream);
 
 #ifdef __cplusplus
 }

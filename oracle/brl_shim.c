@@ -444,11 +444,6 @@ int brl_bias_finalize(int device, int nseg, const float *const *scr, const int64
   (void)device; (void)nseg; (void)scr; (void)cols; (void)db; (void)rows; (void)s;
   NOT_HERE("brl_bias_finalize");
 }
-int brl_ppo_stats_at(int device, const float *pt, int64_t b, const float *gram, float vc, float ec, float *out, const int32_t *ri,
-                     void *s) {
-  (void)device; (void)pt; (void)b; (void)gram; (void)vc; (void)ec; (void)out; (void)ri; (void)s;
-  NOT_HERE("brl_ppo_stats_at");
-}
 int brl_policy_step_ex(brl_handle *h, const uint64_t *si, uint64_t *so, int64_t n, const float *lg, int64_t ls, int mode,
                        const uint32_t *db, uint32_t dof, int ar, int32_t *a, float *lp, uint8_t *obs, uint8_t *m, float *ra,
                        uint8_t *ta, int32_t *cp, const brl_macro_ext *ext, void *s) {

@@ -1688,7 +1688,7 @@ def _fused_rank(rank, world, port, out_dir, backend="gloo", mode="flat"):
     cfg = dict(CFG, minibatch_size=256, update_epochs=1, grad_allreduce=mode)
     rs, (total, _) = make_update_step(cfg, fp)((net, None, None, None, 0, 5), tb, adv.cuda(), tgt.cuda())
     assert isinstance(rs[1].get("graphed"), FusedMinibatch) and rs[1]["graphed"].world == world, rs[1].get("graph_error")
-    assert rs[1]["graphed"].allreduce_mode == mode and len(rs[1]["graphed"].segs) == (2 if mode == "flat" else 7)
+    assert rs[1]["graphed"].allreduce_mode == mode and len(rs[1]["graphed"].segs) == (3 if mode == "flat" else 7)
     torch.save((torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu(), total.cpu()),
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
