@@ -2,6 +2,7 @@
 // (csrc/mlp_gemm.hpp) behind one C-ABI entry point, brl_mlp_gemm (include/brl_hip.h).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "abi_common.hpp"
 #include "adam_role.hpp"
@@ -14,18 +15,34 @@
 __global__ __launch_bounds__(mg::THREADS) void k_gemm64_fwd_adam(mg::Args G, AdamRange R, int tiles, int riders) {
   __shared__ __attribute__((aligned(16))) float lds[mg::LDS_FLOATS + 128];
   const int b = (int)blockIdx.x;
-  if (b < tiles) mg::gemm_tile<true, true, mg::EPI_BIAS_ACT>(G, lds, b, tiles);
+  if (b < tiles) mg::gemm_tile<true, true, mg::EPI_BIAS_ACT, 2>(G, lds, b, tiles);
   else adam_range_block(R, b - tiles, riders, lds);
 }
 
 // dh = (dz W) * act'(h) of the layer below the top (on the backward chain) with the head's weight-gradient role (NOT on the chain:
 // csrc/heads_dw_role.hpp) as extra workgroups of the same launch: blocks [0, tiles) are GEMM tiles — one per CU at the step's
 // shape — the rest sit beside them as a second workgroup per CU.
+template <int NB>
 __global__ __launch_bounds__(mg::THREADS) void k_gemm64_dh_heads_dw(mg::Args G, HeadsBwdArgs A, int tiles) {
-  __shared__ __attribute__((aligned(16))) float lds[mg::LDS_FLOATS + 128];
+  __shared__ __attribute__((aligned(16))) float lds[mg::lds_floats<NB>()];
   const int b = (int)blockIdx.x;
-  if (b < tiles) mg::gemm_tile<true, false, mg::EPI_GATE_COLSUM>(G, lds, b, tiles);
+  if (b < tiles) mg::gemm_tile<true, false, mg::EPI_GATE_COLSUM, NB>(G, lds, b, tiles);
   else heads_bwd_dw_block(A, b - tiles);
+}
+
+// Tile width of a launch: 64 x 64 tiles (one workgroup per CU at 1024 x 1024) or 64 x 32 (two per CU, and twice the tiles for
+// the step's narrow products: dW_0 is 1024 x 480 = 128 tiles of 64 x 64 on a 256-CU chip).  BRL_GEMM_TILE_N = 32 / 64 forces one
+// (A/B runs); default: 64 x 32 up to one 64 x 64 tile per CU.
+static int tile_nb(int64_t m, int64_t n) {
+  static const int forced = [] {
+    const char *e = getenv("BRL_GEMM_TILE_N");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 32) return 1;
+  if (forced == 64) return 2;
+  // up to one 64 x 64 tile per CU (the step's 1024 x 1024 products): two narrower workgroups per CU run the step 2-3 us faster
+  // than one wide one (operands cold in L2: one's load stalls sit under the other's MFMAs; profiles/r04/r04_experiments.txt §2b)
+  return (((m + 63) / 64) * ((n + 63) / 64) <= 256) ? 1 : 2;
 }
 
 extern "C" int brl_mlp_gemm(int device, int layout, int epilogue, const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
@@ -51,9 +68,14 @@ extern "C" int brl_mlp_gemm(int device, int layout, int epilogue, const float *a
   G.A = a; G.lda = lda; G.B = b; G.ldb = ldb; G.C = c; G.ldc = ldc;
   G.M = (int)m; G.N = (int)n; G.K = (int)k; G.act = act;
   G.bias = bias; G.gate = gate; G.ldg = ldg; G.colsum = colsum; G.sqsum = sqsum;
-  const unsigned tiles = (unsigned)(((m + 63) / 64) * ((n + 63) / 64));
+  const int nb = tile_nb(m, n);
+  const unsigned tiles = (unsigned)(((m + 63) / 64) * ((n + 32 * nb - 1) / (32 * nb)));
   hipStream_t s = (hipStream_t)stream;
-#define MG_LAUNCH(AK, BK_, E) hipLaunchKernelGGL((mg::k_gemm64<AK, BK_, E>), dim3(tiles), dim3(mg::THREADS), 0, s, G)
+#define MG_LAUNCH(AK, BK_, E)                                                                                   \
+  do {                                                                                                          \
+    if (nb == 2) hipLaunchKernelGGL((mg::k_gemm64n<AK, BK_, E, 2>), dim3(tiles), dim3(mg::THREADS), 0, s, G);    \
+    else hipLaunchKernelGGL((mg::k_gemm64n<AK, BK_, E, 1>), dim3(tiles), dim3(mg::THREADS), 0, s, G);            \
+  } while (0)
   if (layout == BRL_GEMM_NT) {
     if (epilogue == BRL_GEMM_EPI_BIAS_ACT) MG_LAUNCH(true, true, mg::EPI_BIAS_ACT);
     else MG_LAUNCH(true, true, mg::EPI_NONE);
@@ -97,9 +119,11 @@ extern "C" int brl_mlp_gemm_dh_heads_dw(int device, const float *dz, int64_t ldd
   NEED(!sums || (loss_partials && gram_partials && ngroups > 0 && row_index && stat_sums), "statistics sums: partials / ngroups / row_index / stat_sums");
   A.loss_partials = loss_partials; A.gram_partials = gram_partials; A.ngroups = (int)ngroups; A.row_index = row_index;
   A.stat_sums = stat_sums; A.gram_sums = gram_sums;
-  const int tiles = (int)(((m + 63) / 64) * ((n + 63) / 64));
+  const int nb = tile_nb(m, n);
+  const int tiles = (int)(((m + 63) / 64) * ((n + 32 * nb - 1) / (32 * nb)));
   const unsigned blocks = (unsigned)(tiles + A.blocks_a + (sums ? HB_GRAM_BLOCKS : 0));
-  hipLaunchKernelGGL(k_gemm64_dh_heads_dw, dim3(blocks), dim3(mg::THREADS), 0, (hipStream_t)stream, G, A, tiles);
+  if (nb == 2) hipLaunchKernelGGL(k_gemm64_dh_heads_dw<2>, dim3(blocks), dim3(mg::THREADS), 0, (hipStream_t)stream, G, A, tiles);
+  else hipLaunchKernelGGL(k_gemm64_dh_heads_dw<1>, dim3(blocks), dim3(mg::THREADS), 0, (hipStream_t)stream, G, A, tiles);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

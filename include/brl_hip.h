@@ -460,7 +460,8 @@ int brl_adam_clip_fin_gather(int device, float *p, float *g, float *m, float *v,
 
 /* ---- round 4: the step's fp32 GEMMs with the elementwise work of src/update.py:74-242 in their epilogues -------------------
  * One fp32 product C[m,n] (row-major, ldc) on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, a k-ordered fma chain per
- * output), 64 x 64 output tiles (csrc/mlp_gemm.hpp).  Layouts (what is contiguous in memory):
+ * output), 64 x 64 or 64 x 32 output tiles (csrc/mlp_gemm.hpp; colsum / sqsum partials are per 64 ROWS either way; sqsum holds
+ * one word per tile: size it for 64 x 32 tiles, ceil(m / 64) * ceil(n / 32)).  Layouts (what is contiguous in memory):
  *   BRL_GEMM_NT  c = a b^T         a [m,k] (lda), b [n,k] (ldb)          the forward pass: x W^T        (src/models.py:23-33)
  *   BRL_GEMM_NN  c = a b           a [m,k] (lda), b [k,n] (ldb)          dh = dz W                       (autograd of the same)
  *   BRL_GEMM_TN  c = a^T b         a [k,m] (lda), b [k,n] (ldb)          dW = dz^T h

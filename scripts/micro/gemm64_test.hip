@@ -22,9 +22,11 @@ static float frand() { rs = rs * 1664525u + 1013904223u; return ((rs >> 8) & 0xF
 
 struct Case { const char *name; bool akc, bkc; int M, N, K; int epi; int act; };
 
+static int g_nb = 2;   // 16-column B blocks per wave: 2 = 64 x 64 tiles, 1 = 64 x 32 tiles (argv[2])
 static void launch(const Case &c, const mg::Args &G, hipStream_t s) {
-  const int tiles = ((G.M + 63) / 64) * ((G.N + 63) / 64);
-#define L(a, b, e) hipLaunchKernelGGL((mg::k_gemm64<a, b, e>), dim3(tiles), dim3(mg::THREADS), 0, s, G)
+  const int tiles = ((G.M + 63) / 64) * ((G.N + 32 * g_nb - 1) / (32 * g_nb));
+#define L(a, b, e) do { if (g_nb == 2) hipLaunchKernelGGL((mg::k_gemm64n<a, b, e, 2>), dim3(tiles), dim3(mg::THREADS), 0, s, G); \
+                        else hipLaunchKernelGGL((mg::k_gemm64n<a, b, e, 1>), dim3(tiles), dim3(mg::THREADS), 0, s, G); } while (0)
   if (c.akc && c.bkc) { if (c.epi == mg::EPI_BIAS_ACT) L(true, true, mg::EPI_BIAS_ACT); else L(true, true, mg::EPI_NONE); }
   else if (c.akc && !c.bkc) { if (c.epi == mg::EPI_GATE_COLSUM) L(true, false, mg::EPI_GATE_COLSUM); else L(true, false, mg::EPI_NONE); }
   else if (!c.akc && !c.bkc) { if (c.epi == mg::EPI_SQSUM) L(false, false, mg::EPI_SQSUM); else L(false, false, mg::EPI_NONE); }
@@ -43,6 +45,8 @@ static void launch_lib(rocblas_handle h, const Case &c, const float *A, const fl
 
 int main(int argc, char **argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 5;
+  g_nb = argc > 2 ? atoi(argv[2]) : 2;
+  printf("tiles 64 x %d\n", 32 * g_nb);
   const Case cases[] = {
       {"fwd  NT 1024x1024x1024 +bias relu", true, true, 1024, 1024, 1024, mg::EPI_BIAS_ACT, 0},
       {"fwd0 NT 1024x1024x480  +bias relu", true, true, 1024, 1024, 480, mg::EPI_BIAS_ACT, 0},
@@ -76,7 +80,7 @@ int main(int argc, char **argv) {
     auto a_at = [&](int m, int k) { return c.akc ? A[(size_t)m * K + k] : A[(size_t)k * M + m]; };
     auto b_at = [&](int n, int k) { return c.bkc ? B[(size_t)n * K + k] : B[(size_t)k * N + n]; };
     float *dA, *dB, *dC, *dC2, *dbias, *dgate, *dcs, *dsq;
-    const int csr = (M + 63) / 64, ntile = csr * ((N + 63) / 64);
+    const int csr = (M + 63) / 64, ntile = csr * ((N + 32 * g_nb - 1) / (32 * g_nb));
     CK(hipMalloc(&dA, A.size() * 4)); CK(hipMalloc(&dB, B.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4)); CK(hipMalloc(&dC2, (size_t)M * N * 4));
     CK(hipMalloc(&dbias, N * 4)); CK(hipMalloc(&dgate, (size_t)M * N * 4)); CK(hipMalloc(&dcs, (size_t)csr * N * 4)); CK(hipMalloc(&dsq, ntile * 4));
     CK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice));

@@ -2021,7 +2021,7 @@ def test_mlp_gemm_matches_float64(layout, epi, M, N, K, act):
     C = torch.full((M, N), float("nan"), device="cuda")
     tm, tn = (M + 63) // 64, (N + 63) // 64
     colsum = torch.full((tm, N), float("nan"), device="cuda")
-    sqsum = torch.full((tm * tn,), float("nan"), device="cuda")
+    sqsum = torch.zeros((tm * ((N + 31) // 32),), device="cuda")   # one word per tile: sized for 64 x 32 tiles (the library picks the width)
     s = torch.cuda.current_stream().cuda_stream
     _capi.check(L.brl_mlp_gemm(0, layout, epi, A.data_ptr(), A.stride(0), Bm.data_ptr(), Bm.stride(0), C.data_ptr(), N, M, N, K, act,
                                bias.data_ptr(), gate.data_ptr(), N, colsum.data_ptr(), sqsum.data_ptr(), s))
