@@ -60,9 +60,7 @@ __device__ __forceinline__ void adam_range_block(const AdamRange &A, const int b
   const int64_t n4 = A.hi4 - A.lo4;
   const int64_t chunk = (n4 + nb - 1) / nb;
   const int64_t lo = A.lo4 + (int64_t)b * chunk, hi = (lo + chunk < A.hi4) ? lo + chunk : A.hi4;
-  for (int64_t i = lo + tid; i < hi; i += 256) {
-    const float4 g4 = reinterpret_cast<const float4 *>(A.g)[i];
-    float4 m4 = reinterpret_cast<float4 *>(A.m)[i], v4 = reinterpret_cast<float4 *>(A.v)[i], p4 = reinterpret_cast<float4 *>(A.p)[i];
+  auto upd = [&](float4 &p4, const float4 g4, float4 &m4, float4 &v4) __attribute__((always_inline)) {
     const float gs[4] = {g4.x * scale, g4.y * scale, g4.z * scale, g4.w * scale};
     float ms[4] = {m4.x, m4.y, m4.z, m4.w}, vs[4] = {v4.x, v4.y, v4.z, v4.w}, ps[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
@@ -71,8 +69,28 @@ __device__ __forceinline__ void adam_range_block(const AdamRange &A, const int b
       vs[k] = vs[k] * b2 + gs[k] * gs[k] * (1.0f - b2);          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
       ps[k] -= step_size * (ms[k] / (sqrtf(vs[k]) / bc2_sqrt + eps));
     }
-    reinterpret_cast<float4 *>(A.m)[i] = make_float4(ms[0], ms[1], ms[2], ms[3]);
-    reinterpret_cast<float4 *>(A.v)[i] = make_float4(vs[0], vs[1], vs[2], vs[3]);
-    reinterpret_cast<float4 *>(A.p)[i] = make_float4(ps[0], ps[1], ps[2], ps[3]);
+    m4 = make_float4(ms[0], ms[1], ms[2], ms[3]);
+    v4 = make_float4(vs[0], vs[1], vs[2], vs[3]);
+    p4 = make_float4(ps[0], ps[1], ps[2], ps[3]);
+  };
+  // two float4s of every array per trip: EIGHT 16-byte loads in flight per thread before anything waits (the sweep is bound by
+  // how many bytes a CU keeps in flight, not by arithmetic)
+  int64_t i = lo + tid;
+  for (; i + 256 < hi; i += 512) {
+    const int64_t j = i + 256;
+    const float4 ga = reinterpret_cast<const float4 *>(A.g)[i], gb = reinterpret_cast<const float4 *>(A.g)[j];
+    float4 ma = reinterpret_cast<float4 *>(A.m)[i], mb = reinterpret_cast<float4 *>(A.m)[j];
+    float4 va = reinterpret_cast<float4 *>(A.v)[i], vb = reinterpret_cast<float4 *>(A.v)[j];
+    float4 pa = reinterpret_cast<float4 *>(A.p)[i], pb = reinterpret_cast<float4 *>(A.p)[j];
+    upd(pa, ga, ma, va);
+    upd(pb, gb, mb, vb);
+    reinterpret_cast<float4 *>(A.m)[i] = ma; reinterpret_cast<float4 *>(A.v)[i] = va; reinterpret_cast<float4 *>(A.p)[i] = pa;
+    reinterpret_cast<float4 *>(A.m)[j] = mb; reinterpret_cast<float4 *>(A.v)[j] = vb; reinterpret_cast<float4 *>(A.p)[j] = pb;
+  }
+  for (; i < hi; i += 256) {
+    const float4 g4 = reinterpret_cast<const float4 *>(A.g)[i];
+    float4 m4 = reinterpret_cast<float4 *>(A.m)[i], v4 = reinterpret_cast<float4 *>(A.v)[i], p4 = reinterpret_cast<float4 *>(A.p)[i];
+    upd(p4, g4, m4, v4);
+    reinterpret_cast<float4 *>(A.m)[i] = m4; reinterpret_cast<float4 *>(A.v)[i] = v4; reinterpret_cast<float4 *>(A.p)[i] = p4;
   }
 }
