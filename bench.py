@@ -655,6 +655,12 @@ def bench_secondary(torch, dev):
     t_dup, _ = timed(lambda: dup_eval(team1, opp, 7), 3)
     phases["evaluators"] = {"ms": (t_simple + 3 * t_dup) * 1e3, "simple_evaluate_ms": t_simple * 1e3,
                             "simple_duplicate_evaluate_ms": t_dup * 1e3, "num_eval_envs": n_eval, "dtype": "fp32",
+                            "ms_as_brl_amd_train_plays_them": (t_simple + t_dup) * 1e3,
+                            "as_played": "brl_amd.train plays each distinct (parameter version, opponent) pair once: imp_opp of "
+                                         "iteration i + 1 IS imp_opp_after of iteration i (same networks, boards, arg-max play), "
+                                         "imp_opp_before IS imp_opp unless the pool switched the opponent: 1 + 1 evaluations per "
+                                         "iteration in the steady state, 1 + 2 when the opponent changes; `ms` counts the "
+                                         "reference's 1 + 3",
                             "what": "per iteration (ppo.py:366-381,461-484, self_play): jit_simple_evaluate + 3 x "
                                     "jit_simple_duplicate_evaluate; the full duplicate evaluation with statistics runs every "
                                     "num_eval_step iterations only and is not included"}

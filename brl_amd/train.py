@@ -264,6 +264,21 @@ def train(config, log=print):
     steps = 0
     history = []
     i = -1
+    # ppo.py plays jit_simple_duplicate_evaluate(params, opp_params, eval_rng) three times per iteration (:376 imp_opp, :461
+    # imp_opp_before, :480 imp_opp_after) with ONE eval_rng for the whole run (:251).  The evaluation is a deterministic function
+    # of (params, opp_params, eval_rng) — arg-max play on the same boards, integer IMPs — so two of those calls repeat an earlier
+    # one whenever neither network changed in between: imp_opp of iteration i + 1 is imp_opp_after of iteration i, and
+    # imp_opp_before is imp_opp where the pool left the opponent alone.  Each distinct (parameter version, opponent) pair is
+    # played once (~12 ms per evaluation at num_eval_envs = 10000; the logged numbers are the same).
+    memo = {"version": None, "opp": None, "imp": None}
+
+    def duplicate_imp(params, opp, version):
+        if memo["version"] == version and memo["opp"] is opp:   # (the memo keeps `opp` alive: its identity cannot be reused)
+            return memo["imp"]
+        imp = float(simple_duplicate_evaluate(params, opp, eval_rng)[0][0])
+        memo.update(version=version, opp=opp, imp=imp)
+        return imp
+
     for i in range(config["num_updates"]):
         params = runner_state[0]
         if i != 0 and i % config["save_model_interval"] == 0 and config["save_model"] and rank == 0:  # ppo.py:351-362
@@ -279,7 +294,7 @@ def train(config, log=print):
                 rec.update(make_evaluate_log(log_info))
         opp_name = "latest"
         if config["self_play"]:                                                                      # ppo.py:376-460
-            (imp_opp, _, _), _, _ = simple_duplicate_evaluate(params, opp_params, eval_rng)
+            imp_opp = duplicate_imp(params, opp_params, i)
             params_list = ckpt.list_checkpoints(pool_dir)[-int(config["num_model_zoo"]):]
 
             def league_imps():
@@ -303,7 +318,7 @@ def train(config, log=print):
                 opp_params = snapshot_latest(params)
             else:
                 opp_name = "unchanged"
-        imp_before = float(simple_duplicate_evaluate(params, opp_params, eval_rng)[0][0]) if do_eval else float("nan")  # :461
+        imp_before = duplicate_imp(params, opp_params, i) if do_eval else float("nan")                # ppo.py:461
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         runner_state, traj = roll_out(runner_state, opp_params)                                       # ppo.py:467
@@ -312,7 +327,7 @@ def train(config, log=print):
         torch.cuda.synchronize(); t2 = time.perf_counter()
         runner_state, loss_info = update_step(runner_state, traj, adv, tgt)                           # ppo.py:473
         torch.cuda.synchronize(); t3 = time.perf_counter()
-        imp_after = float(simple_duplicate_evaluate(runner_state[0], opp_params, eval_rng)[0][0]) if do_eval else float("nan")  # :480
+        imp_after = duplicate_imp(runner_state[0], opp_params, i + 1) if do_eval else float("nan")    # ppo.py:480
         steps += config["num_envs"] * config["num_steps"] * world                                     # ppo.py:489
         total_loss, (value_loss, loss_actor, entropy, approx_kl, clipfracs, illegal_action_loss) = loss_info
         board_num = int(sum_over_ranks(float(runner_state[4].item()), dev))
