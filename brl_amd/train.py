@@ -270,13 +270,16 @@ def train(config, log=print):
     # one whenever neither network changed in between: imp_opp of iteration i + 1 is imp_opp_after of iteration i, and
     # imp_opp_before is imp_opp where the pool left the opponent alone.  Each distinct (parameter version, opponent) pair is
     # played once (~12 ms per evaluation at num_eval_envs = 10000; the logged numbers are the same).
-    memo = {"version": None, "opp": None, "imp": None}
+    # (`opp_version` counts the loop's assignments to opp_params: the "latest" opponent is a persistent module rewritten in place)
+    memo = {"key": None, "imp": None}
+    opp_version = 0
 
     def duplicate_imp(params, opp, version):
-        if memo["version"] == version and memo["opp"] is opp:   # (the memo keeps `opp` alive: its identity cannot be reused)
+        key = (version, opp_version)
+        if memo["key"] == key:
             return memo["imp"]
         imp = float(simple_duplicate_evaluate(params, opp, eval_rng)[0][0])
-        memo.update(version=version, opp=opp, imp=imp)
+        memo.update(key=key, imp=imp)
         return imp
 
     for i in range(config["num_updates"]):
@@ -314,8 +317,10 @@ def train(config, log=print):
             if code >= 0:
                 opp_name = params_list[code]
                 opp_params = load_opponent(os.path.join(pool_dir, opp_name), config["actor_activation"], config["actor_model_type"])
+                opp_version += 1
             elif code == -1:
                 opp_params = snapshot_latest(params)
+                opp_version += 1
             else:
                 opp_name = "unchanged"
         imp_before = duplicate_imp(params, opp_params, i) if do_eval else float("nan")                # ppo.py:461
