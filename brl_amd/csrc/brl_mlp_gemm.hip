@@ -30,6 +30,28 @@ __global__ __launch_bounds__(mg::THREADS) void k_gemm64_dh_heads_dw(mg::Args G, 
   else heads_bwd_dw_block(A, b - tiles);
 }
 
+// The two backward products of one hidden layer — both fed by dz_l and h_{l-1} — in ONE launch: blocks [0, th) are tiles of
+// dz_{l-1} = (dz_l W_l) * act'(h_{l-1}) (+ the bias gradient's tile sums), blocks [th, th + tw) tiles of dW_l = dz_l^T h_{l-1}
+// (+ its tile square sums), the rest (optional) the head's weight-gradient role.  Two or more workgroups per CU: one tile's
+// prologue, barrier waits and epilogue sit under another's MFMAs — 2 x 1024^3 in ~33 us where the two launches took 21 + 16.
+template <int NB>
+__global__ __launch_bounds__(mg::THREADS) void k_gemm64_bwd_pair(mg::Args GH, mg::Args GW, HeadsBwdArgs A, int th, int tw) {
+  __shared__ __attribute__((aligned(16))) float lds[mg::lds_floats<NB>()];
+  const int b = (int)blockIdx.x;
+  // (the two kinds alternate in groups of 8 blocks while both last — every CU gets some of each, and a tile index keeps its
+  //  residue mod 8 = its XCD, which gemm_tile's tile mapping relies on for L2 locality; speed only)
+  const int mn = (th < tw ? th : tw) & ~7, both = 2 * mn;
+  int kind, idx;
+  if (b < both) { kind = (b >> 3) & 1; idx = ((b >> 4) << 3) + (b & 7); }
+  else if (b < th + tw) {
+    const int r = b - both;                    // what is left of each kind, the gate product first
+    if (r < th - mn) { kind = 0; idx = mn + r; } else { kind = 1; idx = mn + r - (th - mn); }
+  } else { kind = 2; idx = b - th - tw; }
+  if (kind == 0) mg::gemm_tile<true, false, mg::EPI_GATE_COLSUM, NB>(GH, lds, idx, th);
+  else if (kind == 1) mg::gemm_tile<false, false, mg::EPI_SQSUM, NB>(GW, lds, idx, tw);
+  else heads_bwd_dw_block(A, idx);
+}
+
 // Tile width of a launch: 64 x 64 tiles (one workgroup per CU at 1024 x 1024) or 64 x 32 (two per CU, and twice the tiles for
 // the step's narrow products: dW_0 is 1024 x 480 = 128 tiles of 64 x 64 on a 256-CU chip).  BRL_GEMM_TILE_N = 32 / 64 forces one
 // (A/B runs); default: 64 x 32 up to one 64 x 64 tile per CU.
@@ -153,6 +175,55 @@ extern "C" int brl_mlp_gemm_adam(int device, const float *a, int64_t lda, const 
   const int64_t n4 = (hi - lo) / 4;
   const int riders = (int)((n4 + 1023) / 1024);   // four float4s per thread: 256 riders for a 1024 x 1024 layer
   hipLaunchKernelGGL(k_gemm64_fwd_adam, dim3((unsigned)(tiles + riders)), dim3(mg::THREADS), 0, (hipStream_t)stream, G, R, tiles, riders);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_mlp_gemm_bwd_pair(int device, const float *dz, int64_t lddz, const float *w, int64_t ldw, const float *h_prev,
+                                     int64_t ldh, float *dz_out, int64_t ldo, float *dw_out, int64_t lddw, int64_t batch, int64_t n_out,
+                                     int64_t n_in, int act, float *colsum, float *sqsum, const float *dheads, const float *h_top,
+                                     int64_t ldht, int64_t hidden, int nsplit, float *dwh_partials, float *dbh_partials,
+                                     const float *loss_partials, const float *gram_partials, int64_t ngroups, const int32_t *row_index,
+                                     float *stat_sums, float *gram_sums, void *stream) {
+  NEED(dz && w && h_prev && dz_out && dw_out && batch > 0 && n_out > 0 && n_in > 0, "dz / w / h_prev / dz_out / dw_out / sizes");
+  NEED(batch < (1 << 24) && n_out < (1 << 24) && n_in < (1 << 24), "sizes below 2^24");
+  NEED(batch % 4 == 0 && n_out % 4 == 0 && n_in % 4 == 0 && lddz % 4 == 0 && ldw % 4 == 0 && ldh % 4 == 0 && ldo % 4 == 0 && lddw % 4 == 0,
+       "sizes and leading dimensions multiples of 4");
+  NEED(lddz >= n_out && ldw >= n_in && ldh >= n_in && ldo >= n_in && lddw >= n_in, "leading dimensions");
+  NEED(batch * lddz < (1ll << 29) && n_out * ldw < (1ll << 29) && batch * ldh < (1ll << 29), "operands below 2 GB");
+  NEED(act == 0 || act == 1, "act (0 ReLU, 1 tanh)");
+  const bool ride = dheads != nullptr;
+  NEED(!ride || (h_top && dwh_partials && dbh_partials && hidden > 0 && hidden % 256 == 0 && ldht >= hidden && ldht % 4 == 0 &&
+                 nsplit >= 1 && (batch + nsplit - 1) / nsplit <= 64), "the head's weight-gradient role: arrays / hidden / nsplit");
+  HIP_TRY(hipSetDevice(device));
+  // dz_{l-1} [batch, n_in] = dz [batch, n_out] w [n_out, n_in], gated by h_prev [batch, n_in]
+  mg::Args GH{};
+  GH.A = dz; GH.lda = lddz; GH.B = w; GH.ldb = ldw; GH.C = dz_out; GH.ldc = ldo; GH.M = (int)batch; GH.N = (int)n_in; GH.K = (int)n_out;
+  GH.act = act; GH.gate = h_prev; GH.ldg = ldh; GH.colsum = colsum;
+  // dW [n_out, n_in] = dz^T h_prev
+  mg::Args GW{};
+  GW.A = dz; GW.lda = lddz; GW.B = h_prev; GW.ldb = ldh; GW.C = dw_out; GW.ldc = lddw; GW.M = (int)n_out; GW.N = (int)n_in; GW.K = (int)batch;
+  GW.act = act; GW.sqsum = sqsum;
+  HeadsBwdArgs A{};
+  int extra = 0;
+  if (ride) {
+    A.dheads = dheads; A.h = h_top; A.ldh = ldht; A.B = batch; A.H = (int)hidden; A.act = act; A.nsplit = nsplit;
+    A.rows_per_split = (int)((batch + nsplit - 1) / nsplit);
+    A.dWh_partials = dwh_partials; A.dbh_partials = dbh_partials;
+    A.blocks_a = (int)(hidden / HB_JT) * nsplit;
+    const bool sums = gram_sums != nullptr;
+    NEED(!sums || (loss_partials && gram_partials && ngroups > 0 && row_index && stat_sums), "statistics sums: partials / ngroups / row_index / stat_sums");
+    A.loss_partials = loss_partials; A.gram_partials = gram_partials; A.ngroups = (int)ngroups; A.row_index = row_index;
+    A.stat_sums = stat_sums; A.gram_sums = gram_sums;
+    extra = A.blocks_a + (sums ? HB_GRAM_BLOCKS : 0);
+  }
+  static const int forced = [] { const char *e = getenv("BRL_GEMM_PAIR_TILE_N"); return e ? atoi(e) : 0; }();
+  const int nb = forced == 32 ? 1 : 2;   // (two 64 x 64 tiles per CU at the step's shape)
+  const int th = (int)(((batch + 63) / 64) * ((n_in + 32 * nb - 1) / (32 * nb)));
+  const int tw = (int)(((n_out + 63) / 64) * ((n_in + 32 * nb - 1) / (32 * nb)));
+  const unsigned blocks = (unsigned)(th + tw + extra);
+  if (nb == 2) hipLaunchKernelGGL(k_gemm64_bwd_pair<2>, dim3(blocks), dim3(mg::THREADS), 0, (hipStream_t)stream, GH, GW, A, th, tw);
+  else hipLaunchKernelGGL(k_gemm64_bwd_pair<1>, dim3(blocks), dim3(mg::THREADS), 0, (hipStream_t)stream, GH, GW, A, th, tw);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

@@ -371,6 +371,10 @@ class FusedMinibatch:
             self.defer = (views[body[2].weight].start, bias0)
             self.ride = {l: (views[body[l + 1].weight].start,
                              views[body[l + 2].weight].start if l + 2 < nl else bias0) for l in range(1, nl - 1)}
+        # both backward products of a hidden layer in ONE launch (brl_mlp_gemm_bwd_pair): config["bwd_pair"].  Built, checked,
+        # NOT the default: the pair takes 37.7-38.2 us in the step, no less than its two launches (own dh 21.3 + a third of the
+        # batched library product 15.8): 0.2312 vs 0.2295 ms per step (profiles/r04/r04_experiments.txt §6)
+        self.bwd_pair = self.own_gemm and bool(config.get("bwd_pair", False))
         groups64 = (B + 63) // 64                      # 64-row tiles of brl_mlp_gemm's column sums
         self.tile_rows = [64 if (self.own_gemm and l < nl - 1) else 16 for l in range(nl)]
         self.tile_sums = [f(groups * H) for _ in body]   # per-layer partial column sums (bias gradients)
@@ -593,6 +597,21 @@ class FusedMinibatch:
         s = torch.cuda.current_stream().cuda_stream
         di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         nl = len(self.W)
+        if self.bwd_pair:
+            # per hidden layer ONE launch: dz_{l-1} (activation derivative + bias tile sums inside) AND dW_l = dz_l^T h_{l-1}; the
+            # first also hosts the head's dW role.  Then dW_0 (K = 480 columns) with the library.
+            for l in range(nl - 1, 0, -1):
+                first = l == nl - 1 and self.dw_deferred
+                top = self.h[nl - 1]
+                chk(L.brl_mlp_gemm_bwd_pair(
+                    di, self.dzs[l].data_ptr(), self.H, self.W[l].data_ptr(), self.W[l].stride(0), self.h[l - 1].data_ptr(), self.H,
+                    self.dzs[l - 1].data_ptr(), self.H, self.GW[l].data_ptr(), self.GW[l].stride(0), B, self.W[l].shape[0],
+                    self.W[l].shape[1], self.act, self.tile_sums[l - 1].data_ptr(), None,
+                    self.dheads.data_ptr() if first else None, top.data_ptr(), top.stride(0), self.H, self.nsplit,
+                    self.dwh_partials.data_ptr(), self.dbh_partials.data_ptr(), self.partials.data_ptr(), self.gram_partials.data_ptr(),
+                    self.lgroups, self.mb_index.data_ptr(), self.stat_sums.data_ptr(), self.gram_sums.data_ptr(), s))
+            torch.mm(self.dzs[0].t(), self.x0, out=self.GW[0])
+            return
         for l in range(nl - 1, 0, -1):
             if self.own_gemm and l == nl - 1 and self.dw_deferred:   # + the head's dW_h / db_h partials and the step's statistics sums
                 top = self.h[nl - 1]

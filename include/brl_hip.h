@@ -496,6 +496,18 @@ int brl_mlp_gemm_dh_heads_dw(int device, const float *dz, int64_t lddz, const fl
                              float *dw_partials, float *db_partials, const float *loss_partials, const float *gram_partials,
                              int64_t ngroups, const int32_t *row_index, float *stat_sums, float *gram_sums, void *stream);
 
+/* The two backward products of one hidden layer in ONE launch (both read dz [batch, n_out] and h_prev [batch, n_in] = the output of
+ * the layer below): dz_out [batch, n_in] = (dz w) * act'(h_prev) with w [n_out, n_in] (+ colsum [ceil(batch / 64), n_in], may be
+ * NULL), and dw_out [n_out, n_in] = dz^T h_prev (+ sqsum [ceil(n_out / 64) * ceil(n_in / 32)], may be NULL).  dheads != NULL: the
+ * weight-gradient role of brl_ppo_heads_bwd rides too (arguments as brl_act_bwd_colsum_heads_dw).  Replaces torch.mm +
+ * brl_act_bwd_colsum and one third of FusedMinibatch's batched weight-gradient product (src/update.py:86-178 under jax.grad). */
+int brl_mlp_gemm_bwd_pair(int device, const float *dz, int64_t lddz, const float *w, int64_t ldw, const float *h_prev, int64_t ldh,
+                          float *dz_out, int64_t ldo, float *dw_out, int64_t lddw, int64_t batch, int64_t n_out, int64_t n_in, int act,
+                          float *colsum, float *sqsum, const float *dheads, const float *h_top, int64_t ldht, int64_t hidden,
+                          int nsplit, float *dwh_partials, float *dbh_partials, const float *loss_partials,
+                          const float *gram_partials, int64_t ngroups, const int32_t *row_index, float *stat_sums, float *gram_sums,
+                          void *stream);
+
 /* ---- the Adam sweep off the step's dependency chain (round 4) ----------------------------------------------------------------
  * brl_adam_clip_fin_gather whose apply launch leaves out the floats [defer_lo, defer_hi) of the flat buffers (multiples of 4) and
  * sets *pending = 1: that part of the sweep is owed.  It is paid, layer by layer, by extra workgroups of the NEXT step's forward

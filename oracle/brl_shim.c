@@ -348,6 +348,26 @@ int brl_mlp_gemm_dh_heads_dw(int device, const float *dz, int64_t lddz, const fl
   (void)loss_partials; (void)gram_partials; (void)ngroups; (void)row_index; (void)stat_sums; (void)gram_sums; (void)s;
   NOT_HERE("brl_mlp_gemm_dh_heads_dw");
 }
+int brl_mlp_gemm_bwd_pair(int device, const float *dz, int64_t lddz, const float *w, int64_t ldw, const float *h_prev, int64_t ldh,
+                          float *dz_out, int64_t ldo, float *dw_out, int64_t lddw, int64_t batch, int64_t n_out, int64_t n_in, int act,
+                          float *colsum, float *sqsum, const float *dheads, const float *h_top, int64_t ldht, int64_t hidden,
+                          int nsplit, float *dwh_partials, float *dbh_partials, const float *loss_partials,
+                          const float *gram_partials, int64_t ngroups, const int32_t *row_index, float *stat_sums, float *gram_sums,
+                          void *s) {
+  (void)h_top; (void)ldht; (void)hidden; (void)nsplit; (void)dwh_partials; (void)dbh_partials; (void)loss_partials; (void)gram_partials;
+  (void)ngroups; (void)row_index; (void)stat_sums; (void)gram_sums;
+  if (dheads) NOT_HERE("brl_mlp_gemm_bwd_pair with the head's role");
+  /* the two products by their definitions (brl_mlp_gemm above) */
+  int rc = brl_mlp_gemm(device, 1, 2, dz, lddz, w, ldw, dz_out, ldo, batch, n_in, n_out, act, NULL, h_prev, ldh, colsum, NULL, s);
+  if (rc) return rc;
+  float *sq = sqsum;
+  float dummy[1];
+  (void)dummy;
+  if (sq) {   /* the shim's square sums are per 64 x 64 tile; the library's per tile of ITS width: only their total is comparable */
+    return brl_mlp_gemm(device, 2, 3, dz, lddz, h_prev, ldh, dw_out, lddw, n_out, n_in, batch, act, NULL, NULL, 0, NULL, sq, s);
+  }
+  return brl_mlp_gemm(device, 2, 0, dz, lddz, h_prev, ldh, dw_out, lddw, n_out, n_in, batch, act, NULL, NULL, 0, NULL, NULL, s);
+}
 int brl_adam_clip_fin_gather_defer(int device, float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
                                    const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float *scratch,
                                    int64_t scratch_len, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs,

@@ -2048,6 +2048,34 @@ def test_mlp_gemm_matches_float64(layout, epi, M, N, K, act):
     assert torch.equal(C, C2)
 
 
+@pytest.mark.parametrize("B,Ho,Hi,act", [(1024, 1024, 1024, 0), (1000, 256, 512, 1), (64, 128, 64, 0)])
+def test_mlp_gemm_backward_pair_matches_float64(B, Ho, Hi, act):
+    """brl_mlp_gemm_bwd_pair: dz_{l-1} = (dz_l W_l) * act'(h_{l-1}) with the bias gradient's 64-row tile sums AND dW_l = dz_l^T h_{l-1}
+    with its tile square sums from ONE launch (src/update.py:86-178 under jax.grad), against float64 products of the same operands."""
+    from brl_amd import _capi
+    L = _capi.lib()
+    g = torch.Generator(device="cuda").manual_seed(B + Ho + Hi)
+    r = lambda *sh: (torch.rand(sh, device="cuda", generator=g) * 2 - 1)  # noqa: E731
+    dz, W, hp = r(B, Ho), r(Ho, Hi), r(B, Hi)
+    dz_out, dW = torch.full((B, Hi), float("nan"), device="cuda"), torch.full((Ho, Hi), float("nan"), device="cuda")
+    tb = (B + 63) // 64
+    colsum = torch.zeros((tb, Hi), device="cuda")
+    sqsum = torch.zeros((((Ho + 63) // 64) * ((Hi + 31) // 32),), device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    _capi.check(L.brl_mlp_gemm_bwd_pair(0, dz.data_ptr(), Ho, W.data_ptr(), Hi, hp.data_ptr(), Hi, dz_out.data_ptr(), Hi, dW.data_ptr(), Hi,
+                                        B, Ho, Hi, act, colsum.data_ptr(), sqsum.data_ptr(), None, None, 0, 0, 0, None, None, None, None,
+                                        0, None, None, None, s))
+    torch.cuda.synchronize()
+    gate = (hp > 0).double() if act == 0 else (1 - hp.double() ** 2)
+    ref_dz = (dz.double() @ W.double()) * gate
+    ref_dW = dz.double().t() @ hp.double()
+    assert float((dz_out.double() - ref_dz).abs().max()) < 2e-4 * max(1.0, float(ref_dz.abs().max())) * (Ho / 1024 + 1) ** 0.5
+    assert float((dW.double() - ref_dW).abs().max()) < 2e-4 * max(1.0, float(ref_dW.abs().max())) * (B / 1024 + 1) ** 0.5
+    want = torch.stack([dz_out[64 * t:64 * t + 64].double().sum(0) for t in range(tb)])
+    assert float((colsum.double() - want).abs().max()) < 1e-3
+    assert abs(float(sqsum.double().sum()) - float((dW.double() ** 2).sum())) <= 1e-5 * max(1.0, float((dW.double() ** 2).sum()))
+
+
 def test_mlp_gemm_rejects_what_it_cannot_do():
     from brl_amd import _capi
     L = _capi.lib()
