@@ -12,10 +12,11 @@
 // A forward layer of step i + 1 (bias + activation in the epilogue) with the part of step i's Adam sweep that updates the NEXT
 // layer's weights as extra workgroups of the same launch (csrc/adam_role.hpp): blocks [0, tiles) are GEMM tiles — one per CU at
 // the step's shape — the rest sit beside them as a second workgroup per CU, HBM-bound beside MFMA-bound.
+template <int NB>
 __global__ __launch_bounds__(mg::THREADS) void k_gemm64_fwd_adam(mg::Args G, AdamRange R, int tiles, int riders) {
-  __shared__ __attribute__((aligned(16))) float lds[mg::LDS_FLOATS + 128];
+  __shared__ __attribute__((aligned(16))) float lds[mg::lds_floats<NB>()];
   const int b = (int)blockIdx.x;
-  if (b < tiles) mg::gemm_tile<true, true, mg::EPI_BIAS_ACT, 2>(G, lds, b, tiles);
+  if (b < tiles) mg::gemm_tile<true, true, mg::EPI_BIAS_ACT, NB>(G, lds, b, tiles);
   else adam_range_block(R, b - tiles, riders, lds);
 }
 
@@ -171,10 +172,12 @@ extern "C" int brl_mlp_gemm_adam(int device, const float *a, int64_t lda, const 
   AdamRange R{};
   R.p = p; R.g = g; R.m = mom; R.v = var; R.lo4 = lo >> 2; R.hi4 = hi >> 2; R.partials = scratch; R.npartials = npartials; R.step = step;
   R.lr_dev = lr_dev; R.lr = lr; R.b1 = beta1; R.b2 = beta2; R.eps = eps; R.max_norm = max_norm; R.gscale = grad_scale; R.pending = pending;
-  const int tiles = (int)(((m + 63) / 64) * ((n + 63) / 64));
+  const int nb = tile_nb(m, n);
+  const int tiles = (int)(((m + 63) / 64) * ((n + 32 * nb - 1) / (32 * nb)));
   const int64_t n4 = (hi - lo) / 4;
   const int riders = (int)((n4 + 1023) / 1024);   // four float4s per thread: 256 riders for a 1024 x 1024 layer
-  hipLaunchKernelGGL(k_gemm64_fwd_adam, dim3((unsigned)(tiles + riders)), dim3(mg::THREADS), 0, (hipStream_t)stream, G, R, tiles, riders);
+  if (nb == 2) hipLaunchKernelGGL(k_gemm64_fwd_adam<2>, dim3((unsigned)(tiles + riders)), dim3(mg::THREADS), 0, (hipStream_t)stream, G, R, tiles, riders);
+  else hipLaunchKernelGGL(k_gemm64_fwd_adam<1>, dim3((unsigned)(tiles + riders)), dim3(mg::THREADS), 0, (hipStream_t)stream, G, R, tiles, riders);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }
