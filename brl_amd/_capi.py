@@ -132,6 +132,9 @@ def lib() -> C.CDLL:
         "brl_adam_apply_range": [i32, _vp, _vp, _vp, _vp, i64, i64, _vp, i32, _vp, f32, _vp, f32, f32, f32, f32, f32, _vp, i32, _vp],
         "brl_mlp_gemm_bwd_pair": [i32, _vp, i64, _vp, i64, _vp, i64, _vp, i64, _vp, i64, i64, i64, i64, i32, _vp, _vp, _vp, _vp, i64, i64, i32,
                                   _vp, _vp, _vp, _vp, i64, _vp, _vp, _vp, _vp],
+        "brl_mlp_gemm_fwd_heads": [i32, _vp, i64, _vp, i64, _vp, i64, i64, i64, i64, i32, _vp, _vp, i64, _vp, i32, _vp],
+        "brl_ppo_heads_loss_parts": [i32, _vp, _vp, i32, _vp, _vp, _vp, _vp, _vp, _vp, i64, f32, f32, f32, i32, i32, i32, _vp, _vp, _vp,
+                                     _vp, _vp],
         "brl_mlp_gemm_dh_heads_dw": [i32, _vp, i64, _vp, i64, _vp, i64, i64, i64, i64, i32, _vp, i64, _vp, _vp, _vp, i64, i64, i64, i32,
                                      _vp, _vp, _vp, _vp, i64, _vp, _vp, _vp, _vp],
     }
@@ -150,7 +153,8 @@ EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_de
            "brl_relu_bwd_colsum", "brl_adam_clip", "brl_bias_finalize", "brl_policy_step_ex",
            "brl_eval_step_team", "brl_rollout_random_gae", "brl_ppo_heads_loss", "brl_ppo_heads_loss_split", "brl_ppo_heads_bwd", "brl_ppo_stats_gram",
            "brl_act_bwd_colsum", "brl_act_bwd_colsum_heads_dw", "brl_bias_finalize_ex", "brl_ppo_stats_rows", "brl_mb_gather_bind", "brl_mb_gather_dev", "brl_ppo_illegal_grad", "brl_adam_clip_gather", "brl_adam_clip_fin_gather", "brl_mlp_gemm", "brl_mlp_gemm_dh_heads_dw", "brl_adam_clip_fin_gather_defer", "brl_mlp_gemm_adam",
-           "brl_adam_apply_range", "brl_mlp_gemm_bwd_pair"]
+           "brl_adam_apply_range", "brl_mlp_gemm_bwd_pair", "brl_mlp_gemm_fwd_heads",
+           "brl_ppo_heads_loss_parts"]
 
 
 def check(rc: int) -> None:

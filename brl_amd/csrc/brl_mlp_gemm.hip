@@ -230,3 +230,28 @@ extern "C" int brl_mlp_gemm_bwd_pair(int device, const float *dz, int64_t lddz, 
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }
+
+// The LAST hidden layer of the forward pass with its share of `actor(x), critic(x)` (src/models.py:30-33) in the epilogue: 64 x 64
+// tiles, one partial head product [m, 39] per column tile — k_heads_loss adds bias + the parts in order, k_heads_product's launch
+// (5 us, on the step's dependency chain) disappears.
+extern "C" int brl_mlp_gemm_fwd_heads(int device, const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc,
+                                      int64_t m, int64_t n, int64_t k, int act, const float *bias, const float *head_w, int64_t ldhw,
+                                      float *head_parts, int nparts, void *stream) {
+  NEED(a && b && c && bias && head_w && head_parts && m > 0 && n > 0 && k > 0, "a / b / c / bias / head_w / head_parts / m / n / k");
+  NEED(m < (1 << 24) && n < (1 << 24) && k < (1 << 24), "m / n / k below 2^24");
+  NEED(n % 4 == 0 && k % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && ldhw % 4 == 0 && lda >= k && ldb >= k && ldc >= n && ldhw >= n,
+       "n, k and the leading dimensions multiples of 4");
+  NEED(m * lda < (1ll << 29) && n * ldb < (1ll << 29), "operands below 2 GB");
+  NEED(act == 0 || act == 1, "act (0 ReLU, 1 tanh)");
+  NEED(nparts == (int)((n + 63) / 64) || nparts == (int)((n + 31) / 32), "nparts = ceil(n / 64) or ceil(n / 32): one part per column tile");
+  const int nb = nparts == (int)((n + 63) / 64) ? 2 : 1;   // (the caller picks the tile width through the number of parts)
+  HIP_TRY(hipSetDevice(device));
+  mg::Args G{};
+  G.A = a; G.lda = lda; G.B = b; G.ldb = ldb; G.C = c; G.ldc = ldc; G.M = (int)m; G.N = (int)n; G.K = (int)k; G.act = act; G.bias = bias;
+  G.wh = head_w; G.ldwh = ldhw; G.hparts = head_parts;
+  const unsigned tiles = (unsigned)(((m + 63) / 64) * nparts);
+  if (nb == 2) hipLaunchKernelGGL((mg::k_gemm64n<true, true, mg::EPI_BIAS_ACT_HEADS, 2>), dim3(tiles), dim3(mg::THREADS), 0, (hipStream_t)stream, G);
+  else hipLaunchKernelGGL((mg::k_gemm64n<true, true, mg::EPI_BIAS_ACT_HEADS, 1>), dim3(tiles), dim3(mg::THREADS), 0, (hipStream_t)stream, G);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}

@@ -449,6 +449,29 @@ extern "C" int brl_ppo_heads_loss_split(int device, const float *h, int64_t ldh,
   return BRL_OK;
 }
 
+// brl_ppo_heads_loss_split's second launch alone: the partial products come from elsewhere (brl_mlp_gemm_fwd_heads: the last
+// hidden layer's forward launch leaves one per 64-column tile)
+extern "C" int brl_ppo_heads_loss_parts(int device, const float *head_b, const float *head_parts, int nparts, const uint8_t *mask,
+                                        const int32_t *action, const float *old_value, const float *old_log_prob, const float *gae,
+                                        const float *targets, int64_t batch, float clip_eps, float vf_coef, float ent_coef, int masked,
+                                        int value_clipping, int reward_scaling, float *heads_out, float *dheads, float *partials,
+                                        float *gram_partials, void *stream) {
+  NEED(batch > 0 && head_b && head_parts && mask && action && old_value && old_log_prob && gae && targets, "NULL input array / batch");
+  NEED(dheads && partials, "NULL output array");
+  NEED(nparts >= 1 && nparts <= HD_MAX_PARTS, "nparts (1..32)");
+  HIP_TRY(hipSetDevice(device));
+  constexpr int64_t HS = BRL_NUM_ACTIONS + 1;
+  HeadsLossArgs A{};
+  A.h = nullptr; A.ldh = 0; A.Wh = nullptr; A.bh = head_b; A.H = 0;
+  A.P = PpoArgs{nullptr, HS, nullptr, mask, action, old_value, old_log_prob, gae, targets, batch, clip_eps, vf_coef,
+                ent_coef, masked, value_clipping, dheads, dheads + BRL_NUM_ACTIONS, partials, nullptr, HS, HS, HS};
+  A.heads_out = heads_out; A.gram_partials = gram_partials; A.reward_scaling = reward_scaling;
+  A.parts = head_parts; A.nparts = nparts; A.part_stride = batch * HS;
+  hipLaunchKernelGGL(k_heads_loss, dim3((unsigned)((batch + HD_ROWS - 1) / HD_ROWS)), dim3(HD_WAVES * 64), 0, (hipStream_t)stream, A);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
 extern "C" int brl_ppo_heads_bwd(int device, const float *dheads, const float *h, int64_t ldh, const float *head_w, int64_t batch,
                                  int64_t hidden, int act, int nsplit, float *dw_partials, float *db_partials, float *dh,
                                  float *tile_sums, const float *loss_partials, const float *gram_partials, int64_t ngroups,

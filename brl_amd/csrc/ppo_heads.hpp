@@ -15,6 +15,7 @@
 
 constexpr int HD_ROWS = 4;     // samples per workgroup of k_heads_loss (of the 16 rows of an MFMA tile; see the kernel)
 constexpr int HD_WAVES = 8;    // waves per workgroup = K splits; waves 0..3 finish one sample each
+constexpr int HD_MAX_PARTS = 32;   // partial products k_heads_loss can add (k_heads_product: <= 8 K ranges; the forward GEMM's epilogue: one per 64-column tile)
 #include "heads_dw_role.hpp"   // HD_NOUT, HD_GRAM, HB_JT, hd_f32x4, HeadsBwdArgs, heads_bwd_dw_block
 
 
@@ -31,7 +32,7 @@ struct HeadsLossArgs {
   // parts != NULL: the heads product has been formed by k_heads_product as `nparts` partial sums over K ranges:
   // heads[b][n] = bh[n] + parts[0][b][n] + parts[1][b][n] + ..  (in that order); h / Wh are not read here
   const float *parts;   // [nparts][part_stride], row b at b * 39
-  int nparts;           // <= 8
+  int nparts;           // <= HD_MAX_PARTS
   int64_t part_stride;
 };
 
@@ -92,9 +93,9 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
   const PpoSampleIn my_in = ppo_sample_load(A.P, my_b, my_valid, lane);
   const float my_bias = (lane < HD_NOUT) ? A.bh[lane] : 0.0f;
   const bool split = A.parts != nullptr;   // (uniform) the product comes in as partial sums
-  float my_part[8];
+  float my_part[HD_MAX_PARTS];
 #pragma unroll
-  for (int p = 0; p < 8; p++)
+  for (int p = 0; p < HD_MAX_PARTS; p++)
     my_part[p] = (split && my_valid && lane < HD_NOUT && p < A.nparts) ? A.parts[(int64_t)p * A.part_stride + my_b * HD_NOUT + lane] : 0.0f;
 
   // ---- heads of 16 samples: D[sample][n] = sum_k h[sample][k] W_h[n][k]; wave w takes the 16-deep K groups w, w + 8, ..
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
       hv = my_bias;
       if (split) {
 #pragma unroll
-        for (int p = 0; p < 8; p++) hv += my_part[p];   // fixed order (absent parts are exact zeros)
+        for (int p = 0; p < HD_MAX_PARTS; p++) hv += my_part[p];   // fixed order (absent parts are exact zeros)
       } else {
 #pragma unroll
         for (int k = 0; k < HD_WAVES; k++) hv += red[k][nb][sl][c];   // fixed order

@@ -336,7 +336,16 @@ class FusedMinibatch:
         self.ill_coef = float(config.get("illegal_action_l2norm_coef", 0.0) or 0.0)
         self.heads = f(B, K) if self.ill_coef else None      # the gradient of the illegal-action norm re-reads the logits
         self.head_ksplit = max(1, min(4, H // 256))          # K ranges of the heads product (brl_ppo_heads_loss_split)
-        self.head_parts = f(self.head_ksplit, B, K)
+        # config["fuse_heads_fwd"]: the LAST hidden layer's forward launch (own kernel) leaves the heads' partial products, one
+        # per 64-column tile (brl_mlp_gemm_fwd_heads): no k_heads_product launch on the chain
+        # Built, checked, NOT the default: the fused launch takes 23.7-24.4 us in the step where the library's forward launch +
+        # k_heads_product take 19.9 + 5.1 (the epilogue — 24 MFMAs per wave, an LDS exchange between the two column halves, the
+        # part's stores — is not hidden behind anything): 0.2295-0.2307 vs 0.2300-0.2309 ms per step.
+        self.fuse_heads_fwd = (bool(config.get("fuse_heads_fwd", False)) and bool(config.get("own_gemm", True)) and self.single_chain
+                               and B % 4 == 0 and H % 4 == 0 and (H + 63) // 64 <= 32 and K == 39 and len(body) > 1)
+        # (64 x 32 tiles — two workgroups per CU, the faster form in the step — where that gives <= 32 parts)
+        self.head_nparts = ((H + 31) // 32 if (H + 31) // 32 <= 32 else (H + 63) // 64) if self.fuse_heads_fwd else 0
+        self.head_parts = f(max(self.head_ksplit, self.head_nparts), B, K)
         self.vec = f(40) if self.ill_coef else None          # v1 [38], sigma_1 of the step's illegal-action matrix
         self.H, self.K = H, K
         self.act = 0 if params.act is torch.relu else 1
@@ -527,6 +536,13 @@ class FusedMinibatch:
         cfg = self.cfg
         x = self.x0   # minibatch *mb_index of the bound trajectory: gathered by the previous step's Adam launch (or by the bind)
         for l, (W, b) in enumerate(zip(self.W, self.b)):          # forward: bias + activation
+            if self.fuse_heads_fwd and l == len(self.W) - 1:      # last hidden layer + the heads' partial products
+                chk(L.brl_mlp_gemm_fwd_heads(di, x.data_ptr(), x.stride(0), W.data_ptr(), W.stride(0), self.h[l].data_ptr(),
+                                             self.h[l].stride(0), B, W.shape[0], W.shape[1], self.act, b.data_ptr(),
+                                             self.Wh.data_ptr(), self.Wh.stride(0), self.head_parts.data_ptr(),
+                                             self.head_nparts, s))
+                x = self.h[l]
+                continue
             if self.adam_ride and l in self.ride:                 # + the owed Adam sweep of the next layer's weights
                 lo, hi = self.ride[l]
                 chk(L.brl_mlp_gemm_adam(di, x.data_ptr(), x.stride(0), W.data_ptr(), W.stride(0), self.h[l].data_ptr(),
@@ -545,8 +561,17 @@ class FusedMinibatch:
                 x = torch._addmm_activation(b, x, W.t(), use_gelu=False, out=self.h[l])
             else:
                 x = torch.addmm(b, x, W.t(), out=self.h[l]).tanh_()
-        # (two launches: the heads product split over K across workgroups, then the loss on bias + its parts)
-        chk(L.brl_ppo_heads_loss_split(di, x.data_ptr(), x.stride(0), self.Wh.data_ptr(), self.bh.data_ptr(), self.H,
+        if self.fuse_heads_fwd:   # (one launch: the loss on bias + the parts the last layer's launch left)
+            chk(L.brl_ppo_heads_loss_parts(di, self.bh.data_ptr(), self.head_parts.data_ptr(), self.head_nparts,
+                                           self.mask.data_ptr(), self.action.data_ptr(), self.old_v.data_ptr(), self.old_lp.data_ptr(),
+                                           self.adv.data_ptr(), self.tgt.data_ptr(), B, float(cfg["clip_eps"]), float(cfg["vf_coef"]),
+                                           float(cfg["ent_coef"]), int(bool(cfg.get("actor_illegal_action_mask", True))),
+                                           int(bool(cfg.get("value_clipping", True))), int(bool(cfg.get("reward_scaling", False))),
+                                           self.heads.data_ptr() if self.ill_coef else None, self.dheads.data_ptr(),
+                                           self.partials.data_ptr(), self.gram_partials.data_ptr(), s))
+        else:
+          # (two launches: the heads product split over K across workgroups, then the loss on bias + its parts)
+          chk(L.brl_ppo_heads_loss_split(di, x.data_ptr(), x.stride(0), self.Wh.data_ptr(), self.bh.data_ptr(), self.H,
                                        self.mask.data_ptr(), self.action.data_ptr(), self.old_v.data_ptr(), self.old_lp.data_ptr(),
                                        self.adv.data_ptr(), self.tgt.data_ptr(), B, float(cfg["clip_eps"]), float(cfg["vf_coef"]),
                                        float(cfg["ent_coef"]), int(bool(cfg.get("actor_illegal_action_mask", True))),

@@ -508,6 +508,20 @@ int brl_mlp_gemm_bwd_pair(int device, const float *dz, int64_t lddz, const float
                           const float *gram_partials, int64_t ngroups, const int32_t *row_index, float *stat_sums, float *gram_sums,
                           void *stream);
 
+/* The last hidden layer of the forward pass (brl_mlp_gemm NT + bias + activation, 64 x 64 tiles) with its share of the 39-column
+ * head product in the epilogue: head_parts [nparts][m, 39], nparts = ceil(n / 64) or ceil(n / 32) (= the tile width the launch
+ * uses), with sum over the parts = c head_w^T (head_w [39, ldhw] =
+ * actor rows then the critic row, src/models.py:30-33); brl_ppo_heads_loss_parts then is brl_ppo_heads_loss_split without its
+ * product launch: heads = head_b + parts[0] + parts[1] + ... in that order (nparts <= 32). */
+int brl_mlp_gemm_fwd_heads(int device, const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int64_t m,
+                           int64_t n, int64_t k, int act, const float *bias, const float *head_w, int64_t ldhw, float *head_parts,
+                           int nparts, void *stream);
+int brl_ppo_heads_loss_parts(int device, const float *head_b, const float *head_parts, int nparts, const uint8_t *mask,
+                             const int32_t *action, const float *old_value, const float *old_log_prob, const float *gae,
+                             const float *targets, int64_t batch, float clip_eps, float vf_coef, float ent_coef, int masked,
+                             int value_clipping, int reward_scaling, float *heads_out, float *dheads, float *partials,
+                             float *gram_partials, void *stream);
+
 /* ---- the Adam sweep off the step's dependency chain (round 4) ----------------------------------------------------------------
  * brl_adam_clip_fin_gather whose apply launch leaves out the floats [defer_lo, defer_hi) of the flat buffers (multiples of 4) and
  * sets *pending = 1: that part of the sweep is owed.  It is paid, layer by layer, by extra workgroups of the NEXT step's forward

@@ -368,6 +368,33 @@ int brl_mlp_gemm_bwd_pair(int device, const float *dz, int64_t lddz, const float
   }
   return brl_mlp_gemm(device, 2, 0, dz, lddz, h_prev, ldh, dw_out, lddw, n_out, n_in, batch, act, NULL, NULL, 0, NULL, NULL, s);
 }
+int brl_mlp_gemm_fwd_heads(int device, const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int64_t m,
+                           int64_t n, int64_t k, int act, const float *bias, const float *head_w, int64_t ldhw, float *head_parts,
+                           int nparts, void *s) {
+  /* the layer by its definition, then the per-tile partial head products of what it stored (float64 sums per 64-column tile) */
+  int rc = brl_mlp_gemm(device, 0, 1, a, lda, b, ldb, c, ldc, m, n, k, act, bias, NULL, 0, NULL, NULL, s);
+  if (rc) return rc;
+  const int tw = nparts == (int)((n + 63) / 64) ? 64 : 32;
+  if (!head_w || !head_parts || nparts != (int)((n + tw - 1) / tw)) return fail("bad argument: brl_mlp_gemm_fwd_heads (oracle shim)");
+  for (int t = 0; t < nparts; t++)
+    for (int64_t i = 0; i < m; i++)
+      for (int hd = 0; hd < 39; hd++) {
+        double acc = 0.0;
+        for (int64_t j = (int64_t)tw * t; j < (int64_t)tw * (t + 1) && j < n; j++) acc += (double)c[i * ldc + j] * head_w[hd * ldhw + j];
+        head_parts[((int64_t)t * m + i) * 39 + hd] = (float)acc;
+      }
+  return BRL_OK;
+}
+int brl_ppo_heads_loss_parts(int device, const float *head_b, const float *head_parts, int nparts, const uint8_t *mask,
+                             const int32_t *action, const float *old_value, const float *old_log_prob, const float *gae,
+                             const float *targets, int64_t batch, float clip_eps, float vf_coef, float ent_coef, int masked,
+                             int value_clipping, int reward_scaling, float *heads_out, float *dheads, float *partials,
+                             float *gram_partials, void *s) {
+  (void)device; (void)head_b; (void)head_parts; (void)nparts; (void)mask; (void)action; (void)old_value; (void)old_log_prob; (void)gae;
+  (void)targets; (void)batch; (void)clip_eps; (void)vf_coef; (void)ent_coef; (void)masked; (void)value_clipping; (void)reward_scaling;
+  (void)heads_out; (void)dheads; (void)partials; (void)gram_partials; (void)s;
+  NOT_HERE("brl_ppo_heads_loss_parts");
+}
 int brl_adam_clip_fin_gather_defer(int device, float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
                                    const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float *scratch,
                                    int64_t scratch_len, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs,

@@ -2076,6 +2076,45 @@ def test_mlp_gemm_backward_pair_matches_float64(B, Ho, Hi, act):
     assert abs(float(sqsum.double().sum()) - float((dW.double() ** 2).sum())) <= 1e-5 * max(1.0, float((dW.double() ** 2).sum()))
 
 
+@pytest.mark.parametrize("B,H,K,act,tw", [(1024, 1024, 1024, 0, 32), (1024, 1024, 1024, 0, 64), (1000, 256, 512, 1, 32), (48, 512, 480, 0, 64)])
+def test_mlp_gemm_forward_with_heads_matches_float64(B, H, K, act, tw):
+    """brl_mlp_gemm_fwd_heads: the last hidden layer (bias + activation) AND, per 64-column tile, its share of the 39-column head
+    product (src/models.py:30-33) from one launch; the sum of the parts against a float64 product of the STORED layer output, and
+    brl_ppo_heads_loss_parts' heads (bias + parts in order) against the same."""
+    from brl_amd import _capi
+    L = _capi.lib()
+    g = torch.Generator(device="cuda").manual_seed(B + H + K)
+    r = lambda *sh: (torch.rand(sh, device="cuda", generator=g) * 2 - 1)  # noqa: E731
+    x, W, b, Wh, bh = r(B, K), r(H, K) * 0.1, r(H), r(39, H) * 0.1, r(39)
+    y = torch.full((B, H), float("nan"), device="cuda")
+    nparts = (H + tw - 1) // tw     # (the number of parts selects the tile width)
+    parts = torch.full((nparts, B, 39), float("nan"), device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    _capi.check(L.brl_mlp_gemm_fwd_heads(0, x.data_ptr(), K, W.data_ptr(), K, y.data_ptr(), H, B, H, K, act, b.data_ptr(), Wh.data_ptr(), H,
+                                         parts.data_ptr(), nparts, s))
+    torch.cuda.synchronize()
+    ref = x.double() @ W.double().t() + b.double()
+    ref = ref.clamp_min(0) if act == 0 else ref.tanh()
+    assert float((y.double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
+    want = y.double() @ Wh.double().t()                         # on what was STORED
+    assert not torch.isnan(parts).any()
+    assert float((parts.double().sum(0) - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
+    for t in range(nparts):                                     # every part is its own tile's share
+        wt = y[:, tw * t:tw * t + tw].double() @ Wh[:, tw * t:tw * t + tw].double().t()
+        assert float((parts[t].double() - wt).abs().max()) < 1e-4 * max(1.0, float(wt.abs().max()))
+    # the loss launch on those parts forms heads = bias + parts in order
+    mask = torch.ones((B, 38), dtype=torch.uint8, device="cuda")
+    z = lambda *sh: torch.zeros(sh, device="cuda")  # noqa: E731
+    action = torch.zeros(B, dtype=torch.int32, device="cuda")
+    heads, dheads, partials, gram = z(B, 39), z(B, 39), z((B + 3) // 4, 8), z((B + 3) // 4, 1444)
+    lp = torch.full((B,), -3.6, device="cuda")
+    _capi.check(L.brl_ppo_heads_loss_parts(0, bh.data_ptr(), parts.data_ptr(), nparts, mask.data_ptr(), action.data_ptr(), z(B).data_ptr(),
+                                           lp.data_ptr(), z(B).data_ptr(), z(B).data_ptr(), B, 0.2, 0.5, 0.001, 1, 1, 0, heads.data_ptr(),
+                                           dheads.data_ptr(), partials.data_ptr(), gram.data_ptr(), s))
+    torch.cuda.synchronize()
+    assert float((heads.double() - (want + bh.double())).abs().max()) < 2e-4 * max(1.0, float(want.abs().max()))
+
+
 def test_mlp_gemm_rejects_what_it_cannot_do():
     from brl_amd import _capi
     L = _capi.lib()
