@@ -6,7 +6,10 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 echo "== pytest -m gpu" | tee $OUT/summary.txt
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 | tee $OUT/pytest_gpu.txt
+# (the whole log is kept, and the test that was running: a crash of the process must say where)
+rm -f $OUT/pytest_trace.txt
+BRL_TEST_TRACE=$OUT/pytest_trace.txt timeout -k 10 1500 python -X faulthandler -m pytest tests -x -q -m gpu > $OUT/pytest_gpu_full.txt 2>&1
+tail -8 $OUT/pytest_gpu_full.txt | tee $OUT/pytest_gpu.txt
 echo "== smoke" | tee -a $OUT/summary.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.txt
 echo "== bench" | tee -a $OUT/summary.txt

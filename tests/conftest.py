@@ -15,6 +15,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_runtest_logstart(nodeid, location):
+    """BRL_TEST_TRACE=<file>: the test that is about to run, appended and flushed — a run that dies with the process (a GPU
+    memory fault aborts it from a runtime thread) still says where it was (scripts/gpu_round.sh sets it)."""
+    path = os.environ.get("BRL_TEST_TRACE")
+    if path:
+        with open(path, "a") as f:
+            f.write(nodeid + "\n")
+
+
 @pytest.fixture(scope="session")
 def dds():
     """1000 double-dummy deals derived from the reference's wb5/dataset_for_vs_wb5.json."""

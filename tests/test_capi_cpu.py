@@ -44,6 +44,39 @@ def test_binding_covers_every_declared_symbol(built_lib):
     assert L.brl_last_error() is not None
 
 
+def test_binding_argument_types_match_header(built_lib):
+    """Every argument of every declaration in include/brl_hip.h against the ctypes argtypes: beyond the sixth integer argument
+    the x86-64 ABI passes on the stack, where an `int` bound to an `int64_t` parameter reads 32 bits of garbage."""
+    from brl_amd import _capi
+    text = open(os.path.join(ROOT, "include", "brl_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    decls = re.findall(r"\b(?:int|const char \*|void)\s*(brl_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S)
+    assert sorted(n for n, _ in decls) == header_symbols()
+    scalar = {"int": 4, "int32_t": 4, "uint32_t": 4, "unsigned": 4, "int64_t": 8, "uint64_t": 8, "float": "f", "double": "d"}
+
+    def c_kind(arg):
+        if "*" in arg:
+            return "ptr"
+        words = arg.split()
+        return scalar[" ".join(words[:-1]) if len(words) > 1 else words[0]]
+
+    def py_kind(t):
+        if t in (ctypes.c_float,):
+            return "f"
+        if t in (ctypes.c_double,):
+            return "d"
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or issubclass(t, ctypes._Pointer):
+            return "ptr"
+        return ctypes.sizeof(t)
+
+    L = _capi.lib()
+    for name, args in decls:
+        want = [] if args.strip() in ("", "void") else [c_kind(a.strip()) for a in args.split(",")]
+        got = [py_kind(t) for t in (getattr(L, name).argtypes or [])]
+        assert want == got, f"{name}: header {want} != ctypes {got}"
+
+
 def test_struct_layouts_match_header():
     from brl_amd import _capi
     text = open(os.path.join(ROOT, "include", "brl_hip.h")).read()
