@@ -282,7 +282,8 @@ class _PolicyRollout:
         import torch.distributed as dist
         # (under a process group the NCCL watchdog thread touches the device while this thread captures)
         gkw = {"capture_error_mode": "thread_local"} if (dist.is_available() and dist.is_initialized()) else {}
-        with torch.no_grad():
+        from ._capture import quiet_gc
+        with torch.no_grad(), quiet_gc():   # (a graph freed by the collector mid-capture would abort the process: _capture.py)
             for t0 in range(0, self.T, self.graph_steps):   # (a replay boundary costs ~8 us of idle GPU: several scan steps per graph)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, **gkw):

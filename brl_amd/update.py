@@ -14,6 +14,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+from ._capture import quiet_gc
 from .roll_out import Transition
 
 _NEG = torch.finfo(torch.float32).min
@@ -191,7 +192,7 @@ class GraphedMinibatch:
                     self._step()
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with quiet_gc(), torch.cuda.graph(graph):   # (_capture.py: no collector run while a stream captures)
                 self.out = self._step()
             self.graph = graph
         finally:
@@ -437,50 +438,51 @@ class FusedMinibatch:
             # under a process group the NCCL watchdog thread queries events while this thread captures: "global" capture mode
             # would turn that into a capture error
             gkw = {"capture_error_mode": "thread_local"} if (dist.is_available() and dist.is_initialized()) else {}
-            if self.world == 1:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, **gkw), torch.no_grad():
-                    self._step()
-                self.graph = graph
-                # ... and the same step K times in ONE graph: a replay boundary costs ~5 us (graph launch behind the last
-                # kernel), the step ~0.3 ms; mb_index lives in device memory, so the K copies walk K minibatches
-                self.multi = int(config.get("update_graph_steps", 8))
-                self.graph_multi = None
-                if self.multi > 1:
-                    gm = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gm, **gkw), torch.no_grad():
-                        for _ in range(self.multi):
-                            self._step()
-                    self.graph_multi = gm
-            elif self.allreduce_mode == "flat":
-                pool = torch.cuda.graph_pool_handle()
-                self.segs = []
-                # three graphs: [gradients] | [clip + Adam of step i, then the gradients of step i + 1] | [clip + Adam]: a run of n
-                # steps is first, (all-reduce, middle) x (n - 1), all-reduce, last — ONE replay and one collective per step
-                # (a replay costs ~20 us of host -> device latency; as gradient graph + Adam graph the step took 0.282 ms, see
-                # bench.py's config4_rehearsal)
-                for seg in (self._grads, lambda: (self._opt(), self._grads()), self._opt):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=pool, **gkw), torch.no_grad():
-                        seg()
-                    self.segs.append(g)
-                self.buckets = [self.G]
-                self.graph = self.segs[0]
-            else:
-                # one graph per all-reduce bucket: forward + loss + head backward | each hidden layer's backward | bias
-                # gradients | clip + Adam; the bucket's all-reduce is issued (async) behind its graph and overlaps with
-                # the graphs that follow (RCCL over xGMI: five collectives of <= 4.2 MB beside ~0.2 ms of backward GEMMs)
-                pool = torch.cuda.graph_pool_handle()
-                self.segs = []
-                for seg in [lambda: self._seg_head()] + [(lambda l=l: self._seg_layer(l)) for l in range(nl - 1, -1, -1)] \
-                        + [lambda: self._seg_fin(), lambda: self._opt()]:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=pool, **gkw), torch.no_grad():
-                        seg()
-                    self.segs.append(g)
-                # (the head's weight gradient is finished by _seg_fin, beside the bias gradients: contiguous in the flat buffer)
-                self.buckets = [None] + [self.GW[l] for l in range(nl - 1, -1, -1)] + [self.G[wa.start:ba.start + K]]
-                self.graph = self.segs[0]
+            with quiet_gc():   # (_capture.py: no collector run while a stream captures)
+                if self.world == 1:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, **gkw), torch.no_grad():
+                        self._step()
+                    self.graph = graph
+                    # ... and the same step K times in ONE graph: a replay boundary costs ~5 us (graph launch behind the last
+                    # kernel), the step ~0.3 ms; mb_index lives in device memory, so the K copies walk K minibatches
+                    self.multi = int(config.get("update_graph_steps", 8))
+                    self.graph_multi = None
+                    if self.multi > 1:
+                        gm = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gm, **gkw), torch.no_grad():
+                            for _ in range(self.multi):
+                                self._step()
+                        self.graph_multi = gm
+                elif self.allreduce_mode == "flat":
+                    pool = torch.cuda.graph_pool_handle()
+                    self.segs = []
+                    # three graphs: [gradients] | [clip + Adam of step i, then the gradients of step i + 1] | [clip + Adam]: a run of n
+                    # steps is first, (all-reduce, middle) x (n - 1), all-reduce, last — ONE replay and one collective per step
+                    # (a replay costs ~20 us of host -> device latency; as gradient graph + Adam graph the step took 0.282 ms, see
+                    # bench.py's config4_rehearsal)
+                    for seg in (self._grads, lambda: (self._opt(), self._grads()), self._opt):
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, pool=pool, **gkw), torch.no_grad():
+                            seg()
+                        self.segs.append(g)
+                    self.buckets = [self.G]
+                    self.graph = self.segs[0]
+                else:
+                    # one graph per all-reduce bucket: forward + loss + head backward | each hidden layer's backward | bias
+                    # gradients | clip + Adam; the bucket's all-reduce is issued (async) behind its graph and overlaps with
+                    # the graphs that follow (RCCL over xGMI: five collectives of <= 4.2 MB beside ~0.2 ms of backward GEMMs)
+                    pool = torch.cuda.graph_pool_handle()
+                    self.segs = []
+                    for seg in [lambda: self._seg_head()] + [(lambda l=l: self._seg_layer(l)) for l in range(nl - 1, -1, -1)] \
+                            + [lambda: self._seg_fin(), lambda: self._opt()]:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, pool=pool, **gkw), torch.no_grad():
+                            seg()
+                        self.segs.append(g)
+                    # (the head's weight gradient is finished by _seg_fin, beside the bias gradients: contiguous in the flat buffer)
+                    self.buckets = [None] + [self.GW[l] for l in range(nl - 1, -1, -1)] + [self.G[wa.start:ba.start + K]]
+                    self.graph = self.segs[0]
         finally:
             with torch.no_grad():
                 for t, q in zip((self.P, self.M, self.V, self.step, self.mb_index), saved):

@@ -822,6 +822,69 @@ def test_graphed_policy_rollout_matches_eager(env, dt):
                 p.add_(0.01 * torch.randn_like(p))
 
 
+def test_capture_with_a_dead_graph_cycle_and_an_eager_collector(env):
+    """A dead reference cycle that still owns a hipGraph must be gone BEFORE the rollout's / the update's capture begins, and the
+    cyclic collector must not run while a stream captures: the graph's destructor synchronises the device, which aborts the
+    process mid-capture (brl_amd/_capture.py).  Seen as `Fatal Python error: Aborted ... Garbage-collecting` in
+    test_ppo_iteration_at_config3_size[bf16], whose first parametrisation leaves such cycles behind."""
+    import gc
+    import weakref
+    import brl_amd
+    from brl_amd.models import make_forward_pass
+    from brl_amd.train import DEFAULTS
+    from brl_amd.update import FusedMinibatch, make_optimizer
+
+    class Holder:
+        pass
+
+    def dead_cycle():
+        h = Holder()
+        h.me, h.graph, h.x = h, torch.cuda.CUDAGraph(), torch.zeros(64, device="cuda")
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            h.x.add_(1.0)
+        torch.cuda.current_stream().wait_stream(s)
+        with torch.cuda.graph(h.graph):
+            h.x.add_(1.0)
+        h.graph.replay()
+        return weakref.ref(h)
+
+    fp = make_forward_pass("relu", "DeepMind")
+    actor, opp = fp.init(3, device="cuda"), fp.init(4, device="cuda")
+    n, T = 256, 4
+    cfg = {"num_steps": T, "reward_scale": 7600, "game_mode": "competitive", "actor_illegal_action_mask": True, "graph_rollout": True}
+    ucfg = dict(DEFAULTS, num_envs=n, num_steps=T, minibatch_size=256, update_epochs=1)
+    st = env.init(5, num_envs=n)
+    old = gc.get_threshold()
+    gc.collect()
+    gc.disable()
+    try:
+        # the collector is off: only the captures' own up-front collection can free the cycle
+        ref = dead_cycle()
+        assert ref() is not None
+        roll = brl_amd.make_roll_out(cfg, env, fp, fp)
+        rs, traj = roll((actor, None, st, st.observation, 0, 0), opp)
+        assert ref() is None and not gc.isenabled()
+        ref = dead_cycle()
+        fm = FusedMinibatch(ucfg, actor, make_optimizer(ucfg, actor)["opt"], 256, torch.device("cuda"))
+        assert ref() is None and not gc.isenabled() and fm.graph is not None
+        # ... and with a collector that runs at every container allocation
+        gc.set_threshold(1, 1, 1)
+        gc.enable()
+        roll2 = brl_amd.make_roll_out(cfg, env, fp, fp)
+        rs2, traj2 = roll2((actor, None, st, st.observation, 0, 0), opp)
+        fm2 = FusedMinibatch(ucfg, actor, make_optimizer(ucfg, actor)["opt"], 256, torch.device("cuda"))
+        assert gc.isenabled() and fm2.graph is not None
+    finally:
+        gc.set_threshold(*old)
+        gc.enable()
+    torch.cuda.synchronize()
+    for name in traj._fields:
+        assert torch.equal(getattr(traj, name), getattr(traj2, name)), name
+    assert int(traj.done.sum()) == int(rs[4].item()) == int(rs2[4].item())
+
+
 def test_full_size_properties(dds):
     """BASELINE.json size (N=8192, T=32): size-independent properties of the fused rollout."""
     import brl_amd
