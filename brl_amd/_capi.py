@@ -46,6 +46,12 @@ class EvalStatsPtrs(C.Structure):
     _fields_ = [(n, _vp) for n in _names]
 
 
+class MlpRef(C.Structure):
+    """brl_mlp_ref: a "DeepMind" network by reference (pointers into the module's own parameters)"""
+    _fields_ = [("nlayers", C.c_int32), ("act", C.c_int32), ("in_features", C.c_int64), ("hidden", C.c_int64),
+                ("w", _vp * 8), ("b", _vp * 8), ("actor_w", _vp), ("actor_b", _vp), ("critic_w", _vp), ("critic_b", _vp)]
+
+
 EVAL_COUNTS = 231  # BRL_EVAL_COUNTS
 
 
@@ -89,7 +95,7 @@ def lib() -> C.CDLL:
                                C.POINTER(MacroExt), _vp],
         "brl_obs_cast": [_vp, _vp, i64, _vp, i32, _vp],
         "brl_obs_cast_rows": [_vp, _vp, _vp, i64, _vp, i32, _vp],
-        "brl_live_index": [_vp, _vp, i64, _vp, _vp, _vp],
+        "brl_live_index": [_vp, _vp, i64, _vp, _vp, i64, _vp],
         "brl_linear_act_heads": [_vp, _vp, i64, _vp, i64, _vp, _vp, i64, i64, i32, i32, i32, i32, _vp, i64, i32, _vp, i64, i64, _vp],
         "brl_linear_act": [_vp, _vp, i64, _vp, i64, _vp, _vp, i64, i64, i32, i32, i32, i32, _vp],
         "brl_gae": [_vp, _vp, _vp, _vp, _vp, f32, f32, i32, i64, _vp, _vp, _vp],
@@ -135,6 +141,7 @@ def lib() -> C.CDLL:
         "brl_mlp_gemm_fwd_heads": [i32, _vp, i64, _vp, i64, _vp, i64, i64, i64, i64, i32, _vp, _vp, i64, _vp, i32, _vp],
         "brl_ppo_heads_loss_parts": [i32, _vp, _vp, i32, _vp, _vp, _vp, _vp, _vp, _vp, i64, f32, f32, f32, i32, i32, i32, _vp, _vp, _vp,
                                      _vp, _vp],
+        "brl_mlp_forward_rows": [i32, C.POINTER(MlpRef), _vp, _vp, i64, _vp, i64, _vp, i64, _vp],
         "brl_mlp_gemm_dh_heads_dw": [i32, _vp, i64, _vp, i64, _vp, i64, i64, i64, i64, i32, _vp, i64, _vp, _vp, _vp, i64, i64, i64, i32,
                                      _vp, _vp, _vp, _vp, i64, _vp, _vp, _vp, _vp],
     }
@@ -154,7 +161,7 @@ EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_de
            "brl_eval_step_team", "brl_rollout_random_gae", "brl_ppo_heads_loss", "brl_ppo_heads_loss_split", "brl_ppo_heads_bwd", "brl_ppo_stats_gram",
            "brl_act_bwd_colsum", "brl_act_bwd_colsum_heads_dw", "brl_bias_finalize_ex", "brl_ppo_stats_rows", "brl_mb_gather_bind", "brl_mb_gather_dev", "brl_ppo_illegal_grad", "brl_adam_clip_gather", "brl_adam_clip_fin_gather", "brl_mlp_gemm", "brl_mlp_gemm_dh_heads_dw", "brl_adam_clip_fin_gather_defer", "brl_mlp_gemm_adam",
            "brl_adam_apply_range", "brl_mlp_gemm_bwd_pair", "brl_mlp_gemm_fwd_heads",
-           "brl_ppo_heads_loss_parts"]
+           "brl_ppo_heads_loss_parts", "brl_mlp_forward_rows"]
 
 
 def check(rc: int) -> None:

@@ -2176,7 +2176,7 @@ extern "C" int brl_obs_cast_rows(brl_handle *h, const uint8_t *obs, const int64_
 // finished, and the indices of the others in ascending order at the front of `live` (the entries behind them are left as they
 // are: the caller initialises the list with 0..n-1 once, so they stay valid board indices).  One workgroup: a thread counts
 // its run of boards, the runs' offsets come from a scan in LDS — deterministic order, no atomics.
-__global__ __launch_bounds__(1024) void k_live_index(const uint8_t *terminated, int64_t n, int64_t *live, int64_t *finished) {
+__global__ __launch_bounds__(1024) void k_live_index(const uint8_t *terminated, int64_t n, int64_t *live, int64_t *finished, int64_t tag) {
   __shared__ int64_t part[1024];
   const int tid = (int)threadIdx.x;
   // (a thread's run of boards, rounded up to 8 so that the flags can be read 8 at a time: one load instead of a chain of byte loads)
@@ -2205,14 +2205,33 @@ __global__ __launch_bounds__(1024) void k_live_index(const uint8_t *terminated, 
   if (live != nullptr)
     for (int64_t i = a; i < b; i++)
       if (!terminated[i]) live[pos++] = i;
-  if (tid == 1023 && finished != nullptr) *finished = n - part[1023];
+  if (tid == 1023 && finished != nullptr) {
+    const int64_t count = n - part[1023];
+    // tag >= 0: the word is read by the HOST while the stream runs on (pinned memory, no event): tag and count arrive as one
+    // 64-bit store, released at system scope
+    if (tag >= 0) __hip_atomic_store(finished, (tag << 32) | count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    else *finished = count;
+  }
 }
 
-extern "C" int brl_live_index(brl_handle *h, const uint8_t *terminated, int64_t n, int64_t *live, int64_t *finished,
+extern "C" int brl_live_index(brl_handle *h, const uint8_t *terminated, int64_t n, int64_t *live, int64_t *finished, int64_t tag,
                               void *stream) {
   COMMON(h, n);
   NEED(terminated && (live || finished), "NULL terminated / outputs");
-  hipLaunchKernelGGL(k_live_index, dim3(1), dim3(1024), 0, (hipStream_t)stream, terminated, n, live, finished);
+  NEED(tag < ((int64_t)1 << 31) && n < ((int64_t)1 << 32), "tag below 2^31, n below 2^32");
+  if (finished != nullptr) {
+    // `finished` may be PINNED HOST memory: the launch then stores the count where the host reads it (behind an event) — no copy
+    // launch, no copy engine between two iterations of an evaluator.  Translated to the address the device uses.
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, finished) == hipSuccess && at.type == hipMemoryTypeHost) {
+      void *dp = nullptr;
+      HIP_TRY(hipHostGetDevicePointer(&dp, finished, 0));
+      finished = (int64_t *)dp;
+    } else {
+      (void)hipGetLastError();   // (an address the runtime does not know: left as it is)
+    }
+  }
+  hipLaunchKernelGGL(k_live_index, dim3(1), dim3(1024), 0, (hipStream_t)stream, terminated, n, live, finished, tag);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

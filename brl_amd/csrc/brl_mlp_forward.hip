@@ -1,0 +1,120 @@
+// brl_mlp_forward.hip — translation unit of libbrl_hip.so: the policy network's fp32 forward for selected rows with the library's
+// own kernels end to end, behind ONE C-ABI call (brl_mlp_forward_rows, include/brl_hip.h): observation bytes of the selected
+// boards -> float, the hidden layers through brl_mlp_gemm (bias + activation in the epilogue, nn.Linear's own weight layout), the
+// 38 + 1 heads with the scatter back to the boards' rows.  Written for the small-batch iterations of the evaluators
+// (src/evaluation.py:120-197: the last boards of a duplicate evaluation), which are bound by host launches, not by the GPU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "abi_common.hpp"
+
+namespace {
+
+constexpr int NHEADS = BRL_NUM_ACTIONS + 1;   // 38 logits + the value
+
+// x[r] = float(obs[rows[r]]): one 128-thread workgroup per row, 4 observation bytes -> one 16-byte store
+__global__ __launch_bounds__(128) void k_obs_rows_f32(const uint8_t *obs, const int64_t *rows, float *x) {
+  const int64_t r = blockIdx.x, src = rows ? rows[r] : r;
+  const int t = (int)threadIdx.x;
+  if (t < BRL_OBS_SIZE / 4) {
+    const uint32_t w = reinterpret_cast<const uint32_t *>(obs + src * BRL_OBS_SIZE)[t];
+    reinterpret_cast<float4 *>(x + r * BRL_OBS_SIZE)[t] =
+        make_float4((float)(w & 0xFFu), (float)((w >> 8) & 0xFFu), (float)((w >> 16) & 0xFFu), (float)(w >> 24));
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// The heads: out[rows[r]][hd] = h[r] . w_hd + b_hd for hd = 0..38 (38 actor rows, then the critic row).  A workgroup owns R rows of
+// h, held in registers (lane l: columns 4 l + 256 j .. + 3); wave w takes heads w, w + 4, ...: one coalesced pass over the head's
+// weights, R partial dot products per lane, a wave reduction each.  39 x hidden weights per workgroup come from L2.
+template <int R>
+__global__ __launch_bounds__(256) void k_heads_rows(const float *h, int64_t ldh, int hidden, const float *actor_w, const float *actor_b,
+                                                    const float *critic_w, const float *critic_b, const int64_t *rows, int64_t m,
+                                                    float *out, int64_t ldo) {
+  const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * R;
+  float4 hv[R][4];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int64_t row = (r0 + r < m) ? r0 + r : m - 1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int k = 4 * lane + 256 * j;
+      hv[r][j] = (k < hidden) ? *reinterpret_cast<const float4 *>(h + row * ldh + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  int64_t dst[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int64_t row = (r0 + r < m) ? r0 + r : m - 1;
+    dst[r] = (rows ? rows[row] : row) * ldo;
+  }
+  for (int hd = w; hd < NHEADS; hd += 4) {
+    const float *wr = (hd < BRL_NUM_ACTIONS) ? actor_w + (int64_t)hd * hidden : critic_w;
+    const float bias = (hd < BRL_NUM_ACTIONS) ? actor_b[hd] : critic_b[0];
+    float4 wv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int k = 4 * lane + 256 * j;
+      wv[j] = (k < hidden) ? *reinterpret_cast<const float4 *>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      float s = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        s = fmaf(hv[r][j].x, wv[j].x, s);
+        s = fmaf(hv[r][j].y, wv[j].y, s);
+        s = fmaf(hv[r][j].z, wv[j].z, s);
+        s = fmaf(hv[r][j].w, wv[j].w, s);
+      }
+      s = wave_sum(s);
+      if (lane == 0 && r0 + r < m) out[dst[r] + hd] = s + bias;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int brl_mlp_forward_rows(int device, const brl_mlp_ref *net, const uint8_t *obs, const int64_t *rows, int64_t m,
+                                    float *scratch, int64_t scratch_len, float *out, int64_t ldo, void *stream) {
+  NEED(net && obs && scratch && out && m > 0, "net / obs / scratch / out / m");
+  NEED(net->nlayers >= 1 && net->nlayers <= 8, "nlayers (1..8)");
+  NEED(net->in_features == BRL_OBS_SIZE, "in_features (480)");
+  NEED(net->hidden > 0 && net->hidden % 4 == 0 && net->hidden <= 1024, "hidden (a multiple of 4, <= 1024)");
+  NEED(net->act == 0 || net->act == 1, "act (0 ReLU, 1 tanh)");
+  NEED(net->actor_w && net->actor_b && net->critic_w && net->critic_b, "NULL head arrays");
+  for (int l = 0; l < net->nlayers; l++) NEED(net->w[l] && net->b[l], "NULL layer arrays");
+  NEED(ldo >= NHEADS, "ldo (>= 39)");
+  NEED(m < (1 << 24), "m below 2^24");
+  const int64_t H = net->hidden;
+  NEED(scratch_len >= m * (BRL_OBS_SIZE + 2 * H) && (((uintptr_t)scratch) & 15) == 0, "scratch: m * (480 + 2 * hidden) floats, 16-byte aligned");
+  NEED((((uintptr_t)net->actor_w | (uintptr_t)net->critic_w) & 15) == 0, "head weights not 16-byte aligned");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  float *x = scratch, *act[2] = {scratch + m * BRL_OBS_SIZE, scratch + m * BRL_OBS_SIZE + m * H};
+  hipLaunchKernelGGL(k_obs_rows_f32, dim3((unsigned)m), dim3(128), 0, s, obs, rows, x);
+  const float *cur = x;
+  int64_t k = BRL_OBS_SIZE;
+  for (int l = 0; l < net->nlayers; l++) {
+    float *dst = act[l & 1];
+    if (int rc = brl_mlp_gemm(device, BRL_GEMM_NT, BRL_GEMM_EPI_BIAS_ACT, cur, k, net->w[l], k, dst, H, m, H, k, net->act, net->b[l],
+                              nullptr, 0, nullptr, nullptr, stream))
+      return rc;
+    cur = dst;
+    k = H;
+  }
+  if (m >= 2048)
+    hipLaunchKernelGGL(k_heads_rows<8>, dim3((unsigned)((m + 7) / 8)), dim3(256), 0, s, cur, H, (int)H, net->actor_w, net->actor_b,
+                       net->critic_w, net->critic_b, rows, m, out, ldo);
+  else
+    hipLaunchKernelGGL(k_heads_rows<4>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, cur, H, (int)H, net->actor_w, net->actor_b,
+                       net->critic_w, net->critic_b, rows, m, out, ldo);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}

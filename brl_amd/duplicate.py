@@ -26,9 +26,17 @@ class Table_info(NamedTuple):  # src/duplicate.py:138-144
 
     @staticmethod
     def from_state(state: State) -> "Table_info":
-        """What src/evaluation.py:96-111 builds from a freshly initialised state."""
-        return Table_info(state.terminated.clone(), state.rewards.clone(), state._last_bid.clone(),
-                          state._last_bidder.clone(), state._call_x.clone(), state._call_xx.clone())
+        """What src/evaluation.py:96-111 builds from a freshly initialised state: its own tensors, filled by ONE
+        brl_get_fields launch (as six attribute reads + six clones an evaluator paid 24 launches for its two tables)."""
+        n, dev = state.num_envs, state.packed.device
+        f, out = _capi.Fields(), []
+        for name in ("terminated", "rewards", "_last_bid", "_last_bidder", "_call_x", "_call_xx"):
+            cname, dtype, shape = State._FIELDS[name]
+            t = torch.empty((n,) + shape, dtype=dtype, device=dev)
+            setattr(f, cname, ptr(t))
+            out.append(t)
+        check(_capi.lib().brl_get_fields(state.env._h, ptr(state.packed), n, C.byref(f), _stream()))
+        return Table_info(*out)
 
     def _ptrs(self) -> _capi.TableInfoPtrs:
         p = _capi.TableInfoPtrs()

@@ -65,6 +65,14 @@ class _Shard:
         return t
 
 
+# rows up to which an evaluator's forward goes through brl_mlp_forward_rows (above, the library GEMMs' larger tiles win on the GPU
+# and the host is not the bound); BRL_EVAL_OWN_ROWS=0 switches it off (A/B)
+_OWN_FORWARD_ROWS = int(os.environ.get("BRL_EVAL_OWN_ROWS", "1024"))
+
+
+_HOST_COUNT = os.environ.get("BRL_EVAL_HOST_COUNT", "1") != "0"   # (0: count to device memory + a copy launch, the earlier form: A/B)
+
+
 def masked_mode(logits: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     """``Categorical(logits + finfo.min * ~mask).mode()``: arg-max over the legal actions."""
     return torch.where(mask, logits, torch.full_like(logits, _NEG)).argmax(dim=-1).to(torch.int32)
@@ -77,7 +85,40 @@ class _Forward:
 
     def __init__(self, forward_pass, params):
         self.fp, self.params = forward_pass, params
-        self.snap = InferenceSnapshot.make(params)
+        self.snap = InferenceSnapshot.make(params, views=os.environ.get("BRL_SNAPSHOT_VIEWS", "1") != "0")
+        self.ref = self._by_reference(params)
+
+    @staticmethod
+    def _by_reference(m):
+        """brl_mlp_ref of a "DeepMind" fp32 network — pointers to the module's own parameters, for brl_mlp_forward_rows (the
+        evaluators' small-batch iterations: one host call per forward) — or None where that entry point does not apply"""
+        act = getattr(m, "act", None)
+        if not str(getattr(m, "model", "")).startswith("DeepMind") or act not in (torch.relu, torch.tanh):
+            return None
+        ts = [t for lin in m.body for t in (lin.weight, lin.bias)] + [m.actor.weight, m.actor.bias, m.critic.weight, m.critic.bias]
+        hidden = m.body[0].weight.shape[0]
+        if (len(m.body) > 8 or hidden % 4 or hidden > 1024 or m.body[0].weight.shape[1] != OBS_SIZE
+                or m.actor.weight.shape[0] != NUM_ACTIONS
+                or any((not t.is_cuda) or t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16 for t in ts)
+                or any(lin.weight.shape[0] != hidden for lin in m.body)):
+            return None
+        r = _capi.MlpRef()
+        r.nlayers, r.act, r.in_features, r.hidden = len(m.body), 0 if act is torch.relu else 1, OBS_SIZE, hidden
+        for i, lin in enumerate(m.body):
+            r.w[i], r.b[i] = lin.weight.data_ptr(), lin.bias.data_ptr()
+        r.actor_w, r.actor_b = m.actor.weight.data_ptr(), m.actor.bias.data_ptr()
+        r.critic_w, r.critic_b = m.critic.weight.data_ptr(), m.critic.bias.data_ptr()
+        return r
+
+    def rows(self, obs_bool, idx, m, out, env):
+        """logits (+ value) of the boards idx[0..m) written to their rows of ``out`` [n, >= 39]: ONE call into the library"""
+        hidden = int(self.ref.hidden)
+        need = m * (OBS_SIZE + 2 * hidden)
+        if getattr(self, "_scratch", None) is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.float32, device=out.device)
+        di = out.device.index if out.device.index is not None else torch.cuda.current_device()
+        check(_capi.lib().brl_mlp_forward_rows(di, C.byref(self.ref), ptr(obs_bool), ptr(idx), m, ptr(self._scratch),
+                                               self._scratch.numel(), out.data_ptr(), out.stride(0), _stream()))
 
     def __call__(self, obs_bool, obs_f32):
         if self.snap is not None:
@@ -104,31 +145,60 @@ class EvalStats:
 
 class _DoneWatch:
     """The loop condition ``~state.terminated.all()`` (src/evaluation.py:120-122) without stalling the GPU and without running
-    far past the end: after every iteration the number of finished boards is reduced on the device and copied to pinned host
-    memory behind an event; before iteration i is launched the host waits for the count of iteration i - DEPTH — the GPU is
-    still busy with iteration i - 1 meanwhile.  The loop stops at most DEPTH iterations after the last board finished (finished
-    boards take no-op calls, G9); a blocking read every 16 iterations idled the GPU for ~120 us per read and overshot by 8
-    iterations (of ~35) on average.
+    far past the end: after every iteration ONE launch (brl_live_index) counts the finished boards and stores the count, tagged
+    with the iteration, straight into pinned host memory; before iteration i is launched the host waits — polling that word —
+    for the count of iteration i - DEPTH, while the GPU is still busy with iteration i - 1.  The loop stops at most DEPTH
+    iterations after the last board finished (finished boards take no-op calls, G9).  History: a blocking read every 16
+    iterations idled the GPU for ~120 us per read and overshot by 8 iterations (of ~35); a copy to pinned memory + an event per
+    iteration cost the stream ~10 us per iteration (the copy launch and the bubble behind the event's barrier packet).
     ``compact``: the same launch also leaves the indices of the boards still playing (no host round trip), so that the
     forwards can run on those rows only — boards only ever finish, so the list of iteration i - DEPTH
     is a superset of the boards playing at iteration i."""
     DEPTH, RING = 2, 4
+    _epochs = 0
 
     def __init__(self, env, n, compact=False):
-        self.env, self.n = env, n
+        self._h, self.n = env._h, n   # (the handle, not the environment: the environment keeps its watches — no reference cycle,
+                                      #  both die by reference count, never at the collector's or the interpreter's whim)
         self.host = torch.zeros(self.RING, dtype=torch.int64).pin_memory()
+        self.words = self.host.numpy()   # (the same memory: a plain load per poll)
         self.dev = torch.zeros(self.RING, dtype=torch.int64, device=env.device)
         self.events = [torch.cuda.Event() for _ in range(self.RING)]
         self.idx = None
+        self.busy = False
+        self.epoch = 0
         if compact:   # (entries behind the live boards stay valid board indices: initialised with 0..n-1)
             self.idx = [torch.arange(n, dtype=torch.int64, device=env.device) for _ in range(self.RING)]
 
+    @staticmethod
+    def take(env, n, compact):
+        """a watch of this environment that no loop is using — kept between evaluations (pinned memory, events and index lists
+        cost ~10 launches to set up; the lists only ever hold valid board indices and a count is accepted only with the tag of
+        the current loop, so nothing needs resetting); ``release`` hands it back"""
+        cache = env.__dict__.setdefault("_done_watches", {})
+        w = cache.get((n, compact))
+        if w is None or w.busy:
+            w = _DoneWatch(env, n, compact)
+            cache.setdefault((n, compact), w)
+        w.busy = True
+        _DoneWatch._epochs += 1
+        w.epoch = _DoneWatch._epochs & 0x7FFF   # (a loop's tags: epoch << 16 | iteration + 1 — never those of an earlier loop)
+        return w
+
+    def release(self):
+        self.busy = False
+
+    def _tag(self, i: int) -> int:
+        return (self.epoch << 16) | ((i + 1) & 0xFFFF)
+
     def post(self, i: int, terminated: torch.Tensor):
-        """after iteration i's launches: publish how many boards are finished (and which are not) — ONE launch
-        (brl_live_index) + the copy to pinned memory"""
+        """after iteration i's launches: publish how many boards are finished (and which are not) — ONE launch"""
         k = i % self.RING
-        check(_capi.lib().brl_live_index(self.env._h, ptr(terminated), self.n, ptr(self.idx[k]) if self.idx is not None else None,
-                                         ptr(self.dev[k:k + 1]), _stream()))
+        live = ptr(self.idx[k]) if self.idx is not None else None
+        if _HOST_COUNT:   # the launch stores tag | count in the pinned word itself (include/brl_hip.h: brl_live_index)
+            check(_capi.lib().brl_live_index(self._h, ptr(terminated), self.n, live, self.host.data_ptr() + 8 * k, self._tag(i), _stream()))
+            return
+        check(_capi.lib().brl_live_index(self._h, ptr(terminated), self.n, live, ptr(self.dev[k:k + 1]), -1, _stream()))
         self.host[k:k + 1].copy_(self.dev[k:k + 1], non_blocking=True)
         self.events[k].record()
 
@@ -138,6 +208,18 @@ class _DoneWatch:
         if j < 0:
             return None
         k = j % self.RING
+        if _HOST_COUNT:
+            import time
+            want, words, t0, spins = self._tag(j), self.words, None, 0
+            while True:
+                v = int(words[k])
+                if (v >> 32) == want:
+                    return v & 0xFFFFFFFF, (self.idx[k] if self.idx is not None else None)
+                spins += 1
+                if spins & 0x3FFF == 0:   # (a launch that never completes must not hang the host for ever)
+                    t0 = t0 or time.perf_counter()
+                    if time.perf_counter() - t0 > 60.0:
+                        raise RuntimeError("brl_amd.evaluation: the finished-board count of an iteration never arrived (GPU fault?)")
         self.events[k].synchronize()
         return int(self.host[k]), (self.idx[k] if self.idx is not None else None)
 
@@ -178,6 +260,11 @@ class _ActiveRows:
         if self.idx is None or self.full is None:
             self.full = fwd(obs, obs.to(torch.float32))
             return self.full
+        if self.m <= _OWN_FORWARD_ROWS and getattr(fwd, "ref", None) is not None:
+            # few boards left: the iteration is bound by host launches — gather + cast, the layers, the heads and the scatter
+            # back in one call (brl_mlp_forward_rows; rows of finished boards keep their last logits: never used)
+            fwd.rows(obs, self.idx, self.m, self.full, env)
+            return self.full
         x = torch.empty((self.m, OBS_SIZE), dtype=torch.float32, device=obs.device)
         check(_capi.lib().brl_obs_cast_rows(env._h, ptr(obs), ptr(self.idx), self.m, ptr(x), 0, _stream()))   # gather + astype
         self.full.index_copy_(0, self.idx, fwd(None, x))   # (rows of finished boards keep their last logits: never used)
@@ -205,11 +292,12 @@ def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward,
     # reference's lock-step loop.)
     alternate = (fwd2 is not fwd1) and record_actions is None and record_logits is None
     compact = record_actions is None and record_logits is None and os.environ.get("BRL_EVAL_COMPACT", "1") != "0"
-    watch = _DoneWatch(env, n, compact)
+    watch = _DoneWatch.take(env, n, compact)
     rows = [_ActiveRows(n), _ActiveRows(n)]   # (one logits buffer per team: their forwards alternate)
     while True:
         polled = watch.poll(count)
         if polled is not None and polled[0] >= n:
+            watch.release()   # (an exception above leaves it marked busy: the next loop simply builds its own)
             break
         nobs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=dev)
         if alternate:
@@ -436,7 +524,7 @@ def make_simple_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_
             state = sh.init(eval_env, rng)
             R = torch.zeros(sh.n, dtype=torch.float32, device=eval_env.device)
             it = 0
-            watch = _DoneWatch(eval_env, sh.n)
+            watch = _DoneWatch.take(eval_env, sh.n, False)
             while not watch.finished(it):
                 actor = state.current_player.to(torch.int64)
                 logits, _ = actor_forward_pass.apply(actor_params, state.observation.to(torch.float32))
@@ -448,6 +536,7 @@ def make_simple_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_
                 R += state.rewards.gather(1, actor[:, None])[:, 0]   # src/evaluation.py:60
                 watch.post(it, state.terminated)
                 it += 1
+            watch.release()
         if sh.active:   # (scores are integers: the float64 sum over the ranks is exact)
             return (sh.allsum(R.to(torch.float64).sum().reshape(1))[0] / float(num_eval_envs)).to(torch.float32)
         return R.mean()

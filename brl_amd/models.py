@@ -73,7 +73,7 @@ class InferenceSnapshot:
     updates (``refresh`` re-reads them in place).  ``make`` returns None for architectures it does not cover (callers fall
     back to ``module(x)``)."""
 
-    def __init__(self, module: "ActorCritic", dtype=None, env=None, own_cast=True):
+    def __init__(self, module: "ActorCritic", dtype=None, env=None, own_cast=True, views=False):
         # env: a BridgeBidding whose library runs the 16-bit hidden layers (brl_linear_act) and — own_cast — converts the 0/1
         # observation bytes to `dtype` (brl_obs_cast: 3 us instead of 15 us of GPU time per forward, but a slower launch than
         # torch's .to(): only worth it in hipGraph replays)
@@ -81,13 +81,23 @@ class InferenceSnapshot:
         self.own_cast = bool(own_cast)
         self.dtype = dtype or torch.float32
         dt = self.dtype
-        self.body = [(lin.weight.detach().to(dt).t().contiguous(), lin.bias.detach().to(dt)) for lin in module.body]
-        self.head_w = torch.cat([module.actor.weight, module.critic.weight], 0).detach().to(dt).t().contiguous()
-        self.head_b = torch.cat([module.actor.bias, module.critic.bias], 0).detach().to(dt)
+        # views (fp32 only): the hidden layers multiply with the module's own weights through transposed VIEWS — nothing is
+        # copied (an evaluator builds its snapshots per call: nine launches per network otherwise) and nothing needs a refresh
+        self.views = bool(views) and dt == torch.float32 and all(lin.weight.dtype == torch.float32 for lin in module.body)
+        if self.views:
+            self.body = [(lin.weight.detach().t(), lin.bias.detach()) for lin in module.body]
+        else:
+            self.body = [(lin.weight.detach().to(dt).t().contiguous(), lin.bias.detach().to(dt)) for lin in module.body]
         self.n_actions = module.actor.weight.shape[0]
-        # for the step kernel that forms the heads itself (brl_macro_ext.head_h): [39, hidden] row-major in `dtype`, the bias
-        # as float holding the SAME (rounded) values the GEMM path adds
-        self.head_wt = self.head_w.t().contiguous()
+        self.head_b = torch.cat([module.actor.bias, module.critic.bias], 0).detach().to(dt)
+        # head_wt — for the step kernel that forms the heads itself (brl_macro_ext.head_h): [39, hidden] row-major in `dtype`;
+        # head_bf: the bias as float holding the SAME (rounded) values the GEMM path adds
+        if self.views:   # (two launches: the merged rows ARE head_wt, head_w is their transposed view)
+            self.head_wt = torch.cat([module.actor.weight, module.critic.weight], 0).detach()
+            self.head_w = self.head_wt.t()
+        else:
+            self.head_w = torch.cat([module.actor.weight, module.critic.weight], 0).detach().to(dt).t().contiguous()
+            self.head_wt = self.head_w.t().contiguous()
         self.head_bf = self.head_b.float().contiguous()
         # 16-bit inference with a library handle: the hidden layers run on the library's own kernel (brl_linear_act,
         # csrc/mlp_infer.hpp) — nn.Linear's [out, in] layout in `dtype`, the bias as float holding the rounded values
@@ -101,15 +111,19 @@ class InferenceSnapshot:
         """Re-read the weights of `module` INTO the existing tensors (their addresses are baked into captured graphs)."""
         if self.body_nk is not None:
             return self._refresh16(module)
-        for (w, b), lin in zip(self.body, module.body):
-            w.copy_(lin.weight.detach().t())
-            b.copy_(lin.bias.detach())
+        if self.views:   # (the hidden layers alias the module's parameters: only the merged heads are copies)
+            self.body = [(lin.weight.detach().t(), lin.bias.detach()) for lin in module.body]
+        else:
+            for (w, b), lin in zip(self.body, module.body):
+                w.copy_(lin.weight.detach().t())
+                b.copy_(lin.bias.detach())
         k = self.n_actions
         self.head_w[:, :k].copy_(module.actor.weight.detach().t())
         self.head_w[:, k:].copy_(module.critic.weight.detach().t())
         self.head_b[:k].copy_(module.actor.bias.detach())
         self.head_b[k:].copy_(module.critic.bias.detach())
-        self.head_wt.copy_(self.head_w.t())
+        if not self.views:
+            self.head_wt.copy_(self.head_w.t())
         self.head_bf.copy_(self.head_b)
 
     def _refresh16(self, module):
@@ -137,10 +151,10 @@ class InferenceSnapshot:
         self._body_stale = True   # self.body's weights ([in, out]) no longer match: rebuilt on demand (_body)
 
     @staticmethod
-    def make(module, dtype=None, env=None, own_cast=True):
+    def make(module, dtype=None, env=None, own_cast=True, views=False):
         if not str(getattr(module, "model", "")).startswith("DeepMind") or module.act is not torch.relu:
             return None
-        return InferenceSnapshot(module, dtype, env, own_cast)
+        return InferenceSnapshot(module, dtype, env, own_cast, views)
 
     _FMT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 

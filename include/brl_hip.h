@@ -238,8 +238,13 @@ int brl_obs_cast(brl_handle *h, const uint8_t *obs, int64_t n, void *out, int fm
 int brl_obs_cast_rows(brl_handle *h, const uint8_t *obs, const int64_t *rows, int64_t m, void *out, int fmt, void *stream);
 /* The evaluators' loop condition `~state.terminated.all()` (src/evaluation.py:120-122, 153-178) as data, without a host round
  * trip: *finished = number of boards with terminated != 0; live[0 .. n - *finished) = the indices of the others, ascending
- * (entries behind them are left untouched).  Either output may be NULL. */
-int brl_live_index(brl_handle *h, const uint8_t *terminated, int64_t n, int64_t *live, int64_t *finished, void *stream);
+ * (entries behind them are left untouched).  Either output may be NULL.  `finished` may be pinned host memory (hipHostMalloc /
+ * a pinned torch tensor): the count is then stored where the host reads it — no copy launch in between.  tag >= 0 (< 2^31):
+ * *finished = (tag << 32) | count as ONE 64-bit store released at system scope: the host can poll the word while the stream
+ * runs on (a fresh tag says which launch wrote it) instead of waiting for an event behind the launch — an event between two
+ * iterations of an evaluator costs the stream ~6 us.  tag < 0: the plain count. */
+int brl_live_index(brl_handle *h, const uint8_t *terminated, int64_t n, int64_t *live, int64_t *finished, int64_t tag,
+                   void *stream);
 
 /* One hidden layer of the policy network in 16-bit inference precision — `hk.Linear(1024)` + `jax.nn.relu`,
  * src/models.py:23-33, as called per env.step by src/roll_out.py:73-84 / src/evaluation.py:52-60:
@@ -545,6 +550,29 @@ int brl_mlp_gemm_adam(int device, const float *a, int64_t lda, const float *b, i
 int brl_adam_apply_range(int device, float *p, const float *g, float *m, float *v, int64_t lo, int64_t hi, const float *scratch,
                          int npartials, const float *step, float lr, const float *lr_dev, float beta1, float beta2, float eps,
                          float max_norm, float grad_scale, int32_t *pending, int clear_pending, void *stream);
+
+/* ---- the policy network's fp32 forward for the boards an evaluator still plays, own kernels end to end (round 4) ------------
+ * `actor(x), critic(x)` of src/models.py:23-33 ("DeepMind": nlayers x [hk.Linear(hidden) + activation], then the two heads) as
+ * called per env.step by src/evaluation.py:52-60,146-151, for m selected rows: x[r] = float(obs[rows[r]]) (obs uint8 [.,480],
+ * 0/1; rows NULL: row r itself), nlayers launches of brl_mlp_gemm's kernel (BRL_GEMM_NT + BRL_GEMM_EPI_BIAS_ACT; the weights
+ * in nn.Linear's own [out, in] layout — nothing is transposed, copied or cached), one launch for the 38 + 1 heads that writes
+ * row r's logits and value to out[rows[r] * ldo + 0..38] (the scatter back included).  One host call instead of the ~8 launches
+ * through torch of the library path: an evaluator's small-batch iterations are bound by host launches.
+ * scratch: m * (480 + 2 * hidden) floats, 16-byte aligned.  in_features must be 480, hidden % 4 == 0 and <= 1024. */
+typedef struct brl_mlp_ref {
+  int32_t nlayers;          /* hidden layers, 1..8 */
+  int32_t act;              /* 0 = ReLU, 1 = tanh (src/models.py:16) */
+  int64_t in_features;      /* 480 */
+  int64_t hidden;
+  const float *w[8];        /* w[l]: [hidden, in_l] row-major, in_0 = in_features, in_l = hidden */
+  const float *b[8];        /* b[l]: [hidden] */
+  const float *actor_w;     /* [38, hidden] */
+  const float *actor_b;     /* [38] */
+  const float *critic_w;    /* [1, hidden] */
+  const float *critic_b;    /* [1] */
+} brl_mlp_ref;
+int brl_mlp_forward_rows(int device, const brl_mlp_ref *net, const uint8_t *obs, const int64_t *rows, int64_t m, float *scratch,
+                         int64_t scratch_len, float *out, int64_t ldo, void *stream);
 
 /* ==================================================================================================================
  * SUPERSEDED FORMS — still exported because tests use them as the reference form of their successors and the A/B scripts

@@ -301,9 +301,17 @@ int brl_obs_cast_rows(brl_handle *h, const uint8_t *obs, const int64_t *rows, in
   (void)h; (void)obs; (void)rows; (void)m; (void)out; (void)fmt; (void)s;
   NOT_HERE("brl_obs_cast_rows");
 }
-int brl_live_index(brl_handle *h, const uint8_t *terminated, int64_t n, int64_t *live, int64_t *finished, void *s) {
-  (void)h; (void)terminated; (void)n; (void)live; (void)finished; (void)s;
-  NOT_HERE("brl_live_index");
+int brl_live_index(brl_handle *h, const uint8_t *terminated, int64_t n, int64_t *live, int64_t *finished, int64_t tag, void *s) {
+  (void)h; (void)s;
+  if (!terminated || (!live && !finished) || n <= 0) {
+    snprintf(g_err, sizeof(g_err), "bad argument: brl_live_index (oracle shim)");
+    return BRL_E_ARG;
+  }
+  int64_t k = 0;
+  for (int64_t i = 0; i < n; i++)
+    if (!terminated[i]) { if (live) live[k] = i; k++; }
+  if (finished) *finished = tag >= 0 ? ((tag << 32) | (n - k)) : (n - k);
+  return BRL_OK;
 }
 /* brl_mlp_gemm on the host: the plain definition (include/brl_hip.h), float64 accumulation — the checker of the MFMA kernel's
  * fp32 fma chains for small shapes (tests compare at 2e-4 * max|ref|); same argument rules as the library. */
@@ -335,6 +343,42 @@ int brl_mlp_gemm(int device, int layout, int epilogue, const float *a, int64_t l
       c[i * ldc + j] = v;
       if (epilogue == 2 && colsum) colsum[(i / 64) * n + j] += v;
       if (epilogue == 3) sqsum[(i / 64) * tn + j / 64] += v * v;
+    }
+  return BRL_OK;
+}
+/* the policy network's forward for selected rows, float64 accumulation (the checker of brl_mlp_forward_rows: src/models.py:23-33) */
+int brl_mlp_forward_rows(int device, const brl_mlp_ref *net, const uint8_t *obs, const int64_t *rows, int64_t m, float *scratch,
+                         int64_t scratch_len, float *out, int64_t ldo, void *s) {
+  (void)device; (void)s;
+  if (!net || !obs || !scratch || !out || m <= 0 || net->nlayers < 1 || net->nlayers > 8 || net->in_features != BRL_OBS_SIZE ||
+      net->hidden <= 0 || net->hidden % 4 || net->hidden > 1024 || (net->act != 0 && net->act != 1) || ldo < BRL_NUM_ACTIONS + 1 ||
+      scratch_len < m * (BRL_OBS_SIZE + 2 * net->hidden)) {
+    snprintf(g_err, sizeof(g_err), "bad argument: brl_mlp_forward_rows (oracle shim)");
+    return BRL_E_ARG;
+  }
+  const int64_t H = net->hidden;
+  float *x = scratch, *buf[2] = {scratch + m * BRL_OBS_SIZE, scratch + m * BRL_OBS_SIZE + m * H};
+  for (int64_t r = 0; r < m; r++)
+    for (int q = 0; q < BRL_OBS_SIZE; q++) x[r * BRL_OBS_SIZE + q] = (float)obs[(rows ? rows[r] : r) * BRL_OBS_SIZE + q];
+  const float *cur = x;
+  int64_t k = BRL_OBS_SIZE;
+  for (int l = 0; l < net->nlayers; l++) {
+    float *dst = buf[l & 1];
+    for (int64_t r = 0; r < m; r++)
+      for (int64_t j = 0; j < H; j++) {
+        double acc = net->b[l][j];
+        for (int64_t q = 0; q < k; q++) acc += (double)cur[r * k + q] * (double)net->w[l][j * k + q];
+        dst[r * H + j] = (float)(net->act == 0 ? (acc > 0 ? acc : 0) : tanh(acc));
+      }
+    cur = dst;
+    k = H;
+  }
+  for (int64_t r = 0; r < m; r++)
+    for (int hd = 0; hd < BRL_NUM_ACTIONS + 1; hd++) {
+      const float *w = hd < BRL_NUM_ACTIONS ? net->actor_w + (int64_t)hd * H : net->critic_w;
+      double acc = hd < BRL_NUM_ACTIONS ? net->actor_b[hd] : net->critic_b[0];
+      for (int64_t q = 0; q < H; q++) acc += (double)cur[r * H + q] * (double)w[q];
+      out[(rows ? rows[r] : r) * ldo + hd] = (float)acc;
     }
   return BRL_OK;
 }

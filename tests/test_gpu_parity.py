@@ -751,12 +751,24 @@ def test_live_index_and_row_cast(env):
             term = torch.rand(n, device=dev, generator=g) < p
             live = torch.full((n,), -7, dtype=torch.int64, device=dev)
             fin = torch.zeros(1, dtype=torch.int64, device=dev)
-            _capi.check(L.brl_live_index(env._h, term.data_ptr(), n, live.data_ptr(), fin.data_ptr(), _stream()))
+            _capi.check(L.brl_live_index(env._h, term.data_ptr(), n, live.data_ptr(), fin.data_ptr(), -1, _stream()))
             want = (~term).nonzero().squeeze(1)
             assert int(fin) == int(term.sum())
             assert torch.equal(live[:want.numel()], want) and bool((live[want.numel():] == -7).all())
-            _capi.check(L.brl_live_index(env._h, term.data_ptr(), n, None, fin.data_ptr(), _stream()))   # count only
+            _capi.check(L.brl_live_index(env._h, term.data_ptr(), n, None, fin.data_ptr(), -1, _stream()))   # count only
             assert int(fin) == int(term.sum())
+    # the count straight into pinned host memory, tagged: the host polls the word (no event, no copy)
+    import time
+    word = torch.zeros(1, dtype=torch.int64).pin_memory()
+    view = word.numpy()
+    for tag, n in ((1, 777), (2, 8192), (0x7FFFFFFF, 10000)):
+        term = torch.rand(n, device=dev, generator=g) < 0.4
+        _capi.check(L.brl_live_index(env._h, term.data_ptr(), n, None, word.data_ptr(), tag, _stream()))
+        t0 = time.perf_counter()
+        while int(view[0]) >> 32 != tag:
+            assert time.perf_counter() - t0 < 20.0, "the tagged count never arrived"
+        assert int(view[0]) & 0xFFFFFFFF == int(term.sum())
+    torch.cuda.synchronize()
     st = env.init(5, num_envs=3000)
     obs = st.observation
     rows = torch.randint(0, 3000, (777,), device=dev, generator=g)
@@ -2188,6 +2200,78 @@ def test_mlp_gemm_rejects_what_it_cannot_do():
         assert L.brl_mlp_gemm(0, lay, epi, x.data_ptr(), 64, x.data_ptr(), 64, x.data_ptr(), 64, m, n, k, 0, x.data_ptr(), None, 0, None,
                               None, s) == -1
         assert b"bad argument" in L.brl_last_error()
+
+
+@pytest.mark.parametrize("activation,model,n,m", [("relu", "DeepMind", 1500, 256), ("relu", "DeepMind", 700, 513),
+                                                  ("tanh", "DeepMind", 300, 37), ("relu", "DeepMind_6", 1100, 1024)])
+def test_mlp_forward_rows_matches_float64(activation, model, n, m):
+    """brl_mlp_forward_rows (the evaluators' small-batch forward: cast + layers + heads + scatter in one call) against the
+    module in float64 on the host, and against the oracle shim's restatement of the same entry point; rows that are not
+    selected keep what they held (src/models.py:23-33)."""
+    import ctypes as C
+    from brl_amd import _capi
+    from brl_amd.evaluation import _Forward
+    from brl_amd.models import make_forward_pass
+    fp = make_forward_pass(activation, model)
+    net = fp.init(7, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(n + m)
+    obs = torch.rand(n, 480, device="cuda", generator=g) < 0.1
+    rows = torch.randperm(n, device="cuda", generator=g)[:m].contiguous() if m <= n else None
+    out = torch.full((n, 40), 123.0, device="cuda")
+    fwd = _Forward(fp, net)
+    assert fwd.ref is not None
+    fwd.rows(obs, rows, m, out, None)
+    torch.cuda.synchronize()
+    net64 = fp.init(7).double()
+    with torch.no_grad():
+        logits, value = net64(obs[rows].cpu().double())
+    got = out[rows].cpu().double()
+    scale = max(1.0, float(logits.abs().max()))
+    assert float((got[:, :38] - logits).abs().max()) < 2e-4 * scale
+    assert float((got[:, 38] - value).abs().max()) < 2e-4 * scale
+    untouched = torch.ones(n, dtype=torch.bool)
+    untouched[rows.cpu()] = False
+    assert bool((out.cpu()[untouched] == 123.0).all()) and bool((out[:, 39] == 123.0).all())
+    # ... and the oracle shim's restatement of the entry point on the host (same struct, host pointers)
+    import os
+    import oracle as oracle_pkg
+    oracle_pkg.build()
+    shim = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "liboracle_brl.so"))
+    cpu = fp.init(7)
+    r = _capi.MlpRef()
+    r.nlayers, r.act, r.in_features, r.hidden = len(cpu.body), 0 if activation == "relu" else 1, 480, 1024
+    for i, lin in enumerate(cpu.body):
+        r.w[i], r.b[i] = lin.weight.data_ptr(), lin.bias.data_ptr()
+    r.actor_w, r.actor_b, r.critic_w, r.critic_b = (cpu.actor.weight.data_ptr(), cpu.actor.bias.data_ptr(),
+                                                    cpu.critic.weight.data_ptr(), cpu.critic.bias.data_ptr())
+    k = min(m, 24)   # (a few rows: the shim is a plain triple loop)
+    obs_h, rows_h = obs.cpu().to(torch.uint8).contiguous(), rows[:k].cpu().contiguous()
+    scratch, out_h = torch.empty(k * (480 + 2048)), torch.full((n, 40), 123.0)
+    shim.brl_mlp_forward_rows.argtypes = [C.c_int, C.POINTER(_capi.MlpRef)] + [C.c_void_p] * 2 + [C.c_int64, C.c_void_p, C.c_int64,
+                                                                                               C.c_void_p, C.c_int64, C.c_void_p]
+    assert shim.brl_mlp_forward_rows(0, C.byref(r), obs_h.data_ptr(), rows_h.data_ptr(), k, scratch.data_ptr(), scratch.numel(),
+                                     out_h.data_ptr(), 40, None) == 0
+    assert float((out_h[rows_h][:, :39].double() - got[:k, :39]).abs().max()) < 2e-4 * scale
+
+
+def test_mlp_forward_rows_rejects_what_it_cannot_do():
+    import ctypes as C
+    from brl_amd import _capi
+    L = _capi.lib()
+    x = torch.zeros(1 << 16, device="cuda")   # (every array of the valid call lies inside it: w[0] is 64 x 480 floats)
+    r = _capi.MlpRef()
+    r.nlayers, r.act, r.in_features, r.hidden = 1, 0, 480, 64
+    r.w[0] = r.b[0] = r.actor_w = r.actor_b = r.critic_w = r.critic_b = x.data_ptr()
+    s = torch.cuda.current_stream().cuda_stream
+    args = lambda: (0, C.byref(r), x.data_ptr(), None, 1, x.data_ptr(), x.numel(), x.data_ptr(), 40, s)   # noqa: E731
+    assert L.brl_mlp_forward_rows(*args()) == 0
+    for field, bad in (("nlayers", 9), ("in_features", 481), ("hidden", 1028), ("hidden", 62), ("act", 2)):
+        keep = getattr(r, field)
+        setattr(r, field, bad)
+        assert L.brl_mlp_forward_rows(*args()) == -1 and b"bad argument" in L.brl_last_error(), field
+        setattr(r, field, keep)
+    assert L.brl_mlp_forward_rows(0, C.byref(r), x.data_ptr(), None, 1, x.data_ptr(), 100, x.data_ptr(), 40, s) == -1   # scratch too small
+    torch.cuda.synchronize()
 
 
 def test_longest_auction_319_calls(env, oracle, dds):
