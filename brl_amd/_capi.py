@@ -105,7 +105,7 @@ def lib() -> C.CDLL:
         "brl_eval_step": [_vp, _vp, _vp, i64, _vp, i64, _vp, i64, C.POINTER(TableInfoPtrs), C.POINTER(TableInfoPtrs),
                           C.POINTER(EvalStatsPtrs), i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
         "brl_eval_step_team": [_vp, _vp, _vp, i64, _vp, i64, i32, C.POINTER(TableInfoPtrs), C.POINTER(TableInfoPtrs),
-                               C.POINTER(EvalStatsPtrs), i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+                               C.POINTER(EvalStatsPtrs), i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
         "brl_eval_reduce": [_vp, i64, C.POINTER(TableInfoPtrs), C.POINTER(TableInfoPtrs), _vp, _vp, _vp, _vp],
         "brl_ppo_loss": [i32, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, i64, f32, f32, f32, i32, i32, _vp, _vp, _vp, _vp, _vp],
         "brl_ppo_stats": [i32, _vp, i64, _vp, f32, f32, _vp, _vp],

@@ -19,7 +19,14 @@ from . import _capi
 from ._capi import NUM_ACTIONS, OBS_SIZE, STATE_WORDS, check, ptr
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """the current HIP stream's handle (what every C-ABI call takes).  torch.cuda.current_stream() costs ~9 us per call (device
+    lookups, a Stream object): ~30 us of an evaluator's 75 us host iteration; the raw accessor is the same handle in ~0.3 us."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -1473,6 +1473,7 @@ struct EvalArgs {
   StepOut o;
   int acting_team;        // -1: every board acts (the reference's loop); 0 / 1: only the boards whose turn it is for THAT team
                           // act, the others wait (finished boards always take their no-op step) — brl_eval_step_team
+  float *obs_f32;         // optional [n,480]: the new observation as the next forward's input (`.astype(jnp.float32)`) too
 };
 
 template <int K>
@@ -1562,6 +1563,18 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_eval_step(EvalArgs A) {
     }
   }
   wave_step_outputs<K>(w, t, A.n, A.o);
+  if (A.obs_f32 != nullptr) {  // (as k_policy_step's obs_cast: the cast launch in front of a full-batch forward disappears)
+    const int oseat = cur_seat(t);
+    const uint32_t pack = (uint32_t)oseat | (vul_nibble(t, oseat) << 2);
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      if (w.table0 + j < A.n) {
+        const uint32_t p = __builtin_amdgcn_readlane(pack, j);
+        emit_obs_row_cast(w.wimg + j * TABLE_BYTES, (int)(p & 3u), p >> 2,
+                          reinterpret_cast<uint8_t *>(A.obs_f32) + (w.table0 + j) * BRL_OBS_SIZE * 4, 0, w.c);
+      }
+    }
+  }
   wave_end<K>(w, t, A.state_out, A.n);
 }
 
@@ -2387,11 +2400,12 @@ extern "C" int brl_eval_step_team(brl_handle *h, const uint64_t *state_in, uint6
                                   int64_t stride, int acting_team, const brl_table_info *table_a,
                                   const brl_table_info *table_b, const brl_eval_stats *stats, int bid_set, float *cum_return,
                                   float *rewards_sum, int32_t *action_out, uint8_t *obs, uint8_t *mask, float *rewards,
-                                  uint8_t *terminated, int32_t *current_player, void *stream) {
+                                  uint8_t *terminated, int32_t *current_player, float *obs_f32, void *stream) {
   COMMON(h, n);
   NEED(state_in && state_out && logits, "NULL state / logits");
   NEED(stride >= BRL_NUM_ACTIONS, "logits stride");
   NEED(acting_team == 0 || acting_team == 1, "acting_team");
+  NEED((((uintptr_t)obs_f32) & 15) == 0, "obs_f32 not 16-byte aligned");
   NEED((table_a == nullptr) == (table_b == nullptr), "table_a and table_b go together");
   if (table_a) NEED(table_info_ok(table_a) && table_info_ok(table_b), "table_a / table_b has NULL members");
   EvalArgs A{};
@@ -2403,6 +2417,7 @@ extern "C" int brl_eval_step_team(brl_handle *h, const uint64_t *state_in, uint6
   A.bid_set = bid_set; A.cum_return = cum_return; A.rewards_sum = rewards_sum; A.action_out = action_out;
   A.o = StepOut{obs, mask, rewards, terminated, current_player};
   A.acting_team = acting_team;
+  A.obs_f32 = obs_f32;
   return eval_step_impl(h, A, stream);
 }
 

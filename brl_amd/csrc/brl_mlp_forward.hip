@@ -23,24 +23,32 @@ __global__ __launch_bounds__(128) void k_obs_rows_f32(const uint8_t *obs, const 
   }
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
-// The heads: out[rows[r]][hd] = h[r] . w_hd + b_hd for hd = 0..38 (38 actor rows, then the critic row).  A workgroup owns R rows of
-// h, held in registers (lane l: columns 4 l + 256 j .. + 3); wave w takes heads w, w + 4, ...: one coalesced pass over the head's
-// weights, R partial dot products per lane, a wave reduction each.  39 x hidden weights per workgroup come from L2.
-template <int R>
+// The heads: out[rows[r]][hd] = h[r] . w_hd + b_hd for hd = 0..38 (38 actor rows, then the critic row).  Workgroup (x, y) owns 4
+// rows of h (in registers: lane l holds columns 4 l + 256 j .. + 3) and the 13 heads 13 y .. 13 y + 12; wave w takes its heads
+// w, w + 4, w + 8 (, w + 12): ALL of their weights are requested before anything is used (the kernel is a chain of L2 round trips,
+// not arithmetic), 16 partial dot products per lane, reduced across the wave by a halving butterfly (16 + 8 + 4 + 2 + 2 shuffles
+// instead of 16 x 6).
+constexpr int HR = 4, HG = 13, HPW = 4;   // rows per workgroup, heads per workgroup, heads per wave (at most)
 __global__ __launch_bounds__(256) void k_heads_rows(const float *h, int64_t ldh, int hidden, const float *actor_w, const float *actor_b,
                                                     const float *critic_w, const float *critic_b, const int64_t *rows, int64_t m,
                                                     float *out, int64_t ldo) {
   const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t r0 = (int64_t)blockIdx.x * R;
-  float4 hv[R][4];
+  const int64_t r0 = (int64_t)blockIdx.x * HR;
+  const int h0 = (int)blockIdx.y * HG;
+  float4 wv[HPW][4], hv[HR][4];
 #pragma unroll
-  for (int r = 0; r < R; r++) {
+  for (int i = 0; i < HPW; i++) {
+    const int l = w + 4 * i, hd = h0 + l;
+    const bool ok = l < HG && hd < NHEADS;
+    const float *wr = (hd < BRL_NUM_ACTIONS) ? actor_w + (int64_t)(ok ? hd : 0) * hidden : critic_w;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int k = 4 * lane + 256 * j;
+      wv[i][j] = (ok && k < hidden) ? *reinterpret_cast<const float4 *>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < HR; r++) {
     const int64_t row = (r0 + r < m) ? r0 + r : m - 1;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -48,39 +56,50 @@ __global__ __launch_bounds__(256) void k_heads_rows(const float *h, int64_t ldh,
       hv[r][j] = (k < hidden) ? *reinterpret_cast<const float4 *>(h + row * ldh + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  int64_t dst[R];
+  float v[HPW * HR];   // [head i][row r]
 #pragma unroll
-  for (int r = 0; r < R; r++) {
-    const int64_t row = (r0 + r < m) ? r0 + r : m - 1;
-    dst[r] = (rows ? rows[row] : row) * ldo;
-  }
-  for (int hd = w; hd < NHEADS; hd += 4) {
-    const float *wr = (hd < BRL_NUM_ACTIONS) ? actor_w + (int64_t)hd * hidden : critic_w;
-    const float bias = (hd < BRL_NUM_ACTIONS) ? actor_b[hd] : critic_b[0];
-    float4 wv[4];
+  for (int i = 0; i < HPW; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int k = 4 * lane + 256 * j;
-      wv[j] = (k < hidden) ? *reinterpret_cast<const float4 *>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) {
+    for (int r = 0; r < HR; r++) {
       float s = 0.0f;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        s = fmaf(hv[r][j].x, wv[j].x, s);
-        s = fmaf(hv[r][j].y, wv[j].y, s);
-        s = fmaf(hv[r][j].z, wv[j].z, s);
-        s = fmaf(hv[r][j].w, wv[j].w, s);
+        s = fmaf(hv[r][j].x, wv[i][j].x, s);
+        s = fmaf(hv[r][j].y, wv[i][j].y, s);
+        s = fmaf(hv[r][j].z, wv[i][j].z, s);
+        s = fmaf(hv[r][j].w, wv[i][j].w, s);
       }
-      s = wave_sum(s);
-      if (lane == 0 && r0 + r < m) out[dst[r] + hd] = s + bias;
+      v[i * HR + r] = s;
+    }
+  // halving butterfly: after the step with lane bit `off`, a lane keeps the half of the values its bit selects; four steps leave one
+  // value per lane (index = lane bits 5..2), two more add what lanes differing in bits 1..0 hold — a fixed order
+#pragma unroll
+  for (int step = 0; step < 4; step++) {
+    const int off = 32 >> step, half = (HPW * HR / 2) >> step;
+    const bool hi = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < half; i++) {
+      const float send = hi ? v[i] : v[i + half], keep = hi ? v[i + half] : v[i];
+      v[i] = keep + __shfl_xor(send, off, 64);
+    }
+  }
+  float s = v[0];
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 1, 64);
+  if ((lane & 3) == 0) {
+    const int idx = lane >> 2, i = idx / HR, r = idx % HR, l = w + 4 * i, hd = h0 + l;
+    if (l < HG && hd < NHEADS && r0 + r < m) {
+      const int64_t row = r0 + r;
+      out[(rows ? rows[row] : row) * ldo + hd] = s + ((hd < BRL_NUM_ACTIONS) ? actor_b[hd] : critic_b[0]);
     }
   }
 }
 
 }  // namespace
 
+// (K divided over several workgroups per tile — tiles x slices = 512 workgroups, the last slice to arrive adding the partial tiles
+//  in index order — was built and measured for the layers of m <= 512 rows: 11.3 us per layer against 12.5 at m = 256, slower at
+//  m = 512: a layer this small is a chain of ~5 dependent memory round trips either way; profiles/r04/r04_experiments.txt section 11.)
 extern "C" int brl_mlp_forward_rows(int device, const brl_mlp_ref *net, const uint8_t *obs, const int64_t *rows, int64_t m,
                                     float *scratch, int64_t scratch_len, float *out, int64_t ldo, void *stream) {
   NEED(net && obs && scratch && out && m > 0, "net / obs / scratch / out / m");
@@ -103,18 +122,14 @@ extern "C" int brl_mlp_forward_rows(int device, const brl_mlp_ref *net, const ui
   int64_t k = BRL_OBS_SIZE;
   for (int l = 0; l < net->nlayers; l++) {
     float *dst = act[l & 1];
-    if (int rc = brl_mlp_gemm(device, BRL_GEMM_NT, BRL_GEMM_EPI_BIAS_ACT, cur, k, net->w[l], k, dst, H, m, H, k, net->act, net->b[l],
-                              nullptr, 0, nullptr, nullptr, stream))
-      return rc;
+    const int rc = brl_mlp_gemm(device, BRL_GEMM_NT, BRL_GEMM_EPI_BIAS_ACT, cur, k, net->w[l], k, dst, H, m, H, k, net->act, net->b[l],
+                                nullptr, 0, nullptr, nullptr, stream);
+    if (rc) return rc;
     cur = dst;
     k = H;
   }
-  if (m >= 2048)
-    hipLaunchKernelGGL(k_heads_rows<8>, dim3((unsigned)((m + 7) / 8)), dim3(256), 0, s, cur, H, (int)H, net->actor_w, net->actor_b,
-                       net->critic_w, net->critic_b, rows, m, out, ldo);
-  else
-    hipLaunchKernelGGL(k_heads_rows<4>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, cur, H, (int)H, net->actor_w, net->actor_b,
-                       net->critic_w, net->critic_b, rows, m, out, ldo);
+  hipLaunchKernelGGL(k_heads_rows, dim3((unsigned)((m + HR - 1) / HR), (NHEADS + HG - 1) / HG), dim3(256), 0, s, cur, H, (int)H,
+                     net->actor_w, net->actor_b, net->critic_w, net->critic_b, rows, m, out, ldo);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

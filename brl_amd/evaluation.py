@@ -70,6 +70,7 @@ class _Shard:
 _OWN_FORWARD_ROWS = int(os.environ.get("BRL_EVAL_OWN_ROWS", "1024"))
 
 
+_STEP_CASTS = os.environ.get("BRL_EVAL_STEP_CASTS", "1") != "0"   # (0: a cast launch in front of every full-batch forward: A/B)
 _HOST_COUNT = os.environ.get("BRL_EVAL_HOST_COUNT", "1") != "0"   # (0: count to device memory + a copy launch, the earlier form: A/B)
 
 
@@ -254,11 +255,12 @@ class _ActiveRows:
         if m < self.m:
             self.m, self.idx = m, polled[1][:m]
 
-    def forward(self, fwd, obs, env):
+    def forward(self, fwd, obs, env, x=None):
+        """``x``: the observation as float32 when the launch that produced it wrote that too (brl_eval_step_team.obs_f32)"""
         if getattr(fwd, "constant", False):   # (the same logits whatever the observation: nothing to compute)
             return fwd(obs, None)
         if self.idx is None or self.full is None:
-            self.full = fwd(obs, obs.to(torch.float32))
+            self.full = fwd(obs, x if x is not None else obs.to(torch.float32))
             return self.full
         if self.m <= _OWN_FORWARD_ROWS and getattr(fwd, "ref", None) is not None:
             # few boards left: the iteration is bound by host launches — gather + cast, the layers, the heads and the scatter
@@ -294,6 +296,7 @@ def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward,
     compact = record_actions is None and record_logits is None and os.environ.get("BRL_EVAL_COMPACT", "1") != "0"
     watch = _DoneWatch.take(env, n, compact)
     rows = [_ActiveRows(n), _ActiveRows(n)]   # (one logits buffer per team: their forwards alternate)
+    obs_f32 = None
     while True:
         polled = watch.poll(count)
         if polled is not None and polled[0] >= n:
@@ -303,12 +306,16 @@ def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward,
         if alternate:
             team = count & 1
             rows[team].update(polled)
-            lg = rows[team].forward(fwd2 if team else fwd1, obs, env)
+            lg = rows[team].forward(fwd2 if team else fwd1, obs, env, obs_f32)
+            # the next iteration's forward still takes every board: this launch writes its float32 input as well
+            nxt = rows[team ^ 1]
+            obs_f32 = torch.empty((n, OBS_SIZE), dtype=torch.float32, device=dev) \
+                if (_STEP_CASTS and nxt.idx is None and not getattr(fwd1 if team else fwd2, "constant", False)) else None
             check(_capi.lib().brl_eval_step_team(
                 env._h, ptr(packed), ptr(packed), n, lg.data_ptr(), lg.stride(0), team,
                 C.byref(pa) if pa is not None else None, C.byref(pb) if pb is not None else None,
                 C.byref(ps) if ps is not None else None, int(bid_set),
-                ptr(cum_return), ptr(rewards_sum), ptr(action), ptr(nobs), None, None, ptr(term), None, _stream()))
+                ptr(cum_return), ptr(rewards_sum), ptr(action), ptr(nobs), None, None, ptr(term), None, ptr(obs_f32), _stream()))
             obs = nobs
             watch.post(count, term)
             count += 1

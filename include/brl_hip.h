@@ -317,12 +317,14 @@ int brl_eval_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, 
  * accumulators untouched, action_out = -1), finished boards take their no-op step as always.  Alternating the team from
  * launch to launch plays every board exactly as brl_eval_step does (the calls are deterministic arg-maxes) with ONE forward
  * per iteration instead of the two the reference evaluates and selects from (src/evaluation.py:146-151): a board's teams
- * alternate call by call, so it waits at most one launch at its start and one at the table switch. */
+ * alternate call by call, so it waits at most one launch at its start and one at the table switch.
+ * obs_f32 (optional, [n,480], 16-byte aligned): the new observation ALSO as float — the next forward's input
+ * (`observation.astype(jnp.float32)`, src/evaluation.py:52), so that no cast launch sits in front of a full-batch forward. */
 int brl_eval_step_team(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n, const float *logits,
                        int64_t stride, int acting_team, const brl_table_info *table_a, const brl_table_info *table_b,
                        const brl_eval_stats *stats, int bid_set, float *cum_return, float *rewards_sum, int32_t *action_out,
                        uint8_t *obs, uint8_t *mask, float *rewards, uint8_t *terminated, int32_t *current_player,
-                       void *stream);
+                       float *obs_f32, void *stream);
 
 /* End-of-run histograms behind make_evaluate's log_info — src/evaluation.py:841-1031 (make_terminated_log,
  * make_contract_log) — as exact integer counts.  out: device int64 [BRL_EVAL_COUNTS], zeroed by the call:

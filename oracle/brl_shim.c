@@ -543,8 +543,8 @@ int brl_policy_step_ex(brl_handle *h, const uint64_t *si, uint64_t *so, int64_t 
 }
 int brl_eval_step_team(brl_handle *h, const uint64_t *si, uint64_t *so, int64_t n, const float *lg, int64_t st, int team,
                        const brl_table_info *ta, const brl_table_info *tb, const brl_eval_stats *es, int bs, float *cr, float *rs,
-                       int32_t *ao, uint8_t *obs, uint8_t *m, float *rw, uint8_t *tm, int32_t *cp, void *s) {
-  (void)h; (void)si; (void)so; (void)n; (void)lg; (void)st; (void)team; (void)ta; (void)tb; (void)es; (void)bs; (void)cr; (void)rs; (void)ao; (void)obs; (void)m; (void)rw; (void)tm; (void)cp; (void)s;
+                       int32_t *ao, uint8_t *obs, uint8_t *m, float *rw, uint8_t *tm, int32_t *cp, float *of, void *s) {
+  (void)h; (void)si; (void)so; (void)n; (void)lg; (void)st; (void)team; (void)ta; (void)tb; (void)es; (void)bs; (void)cr; (void)rs; (void)ao; (void)obs; (void)m; (void)rw; (void)tm; (void)cp; (void)of; (void)s;
   NOT_HERE("brl_eval_step_team");
 }
 int brl_rollout_random_gae(brl_handle *h, uint64_t *state, int64_t n, int T, uint32_t draw_base, float reward_scale,

@@ -32,8 +32,8 @@ def main():
     log = []
     orig = ev._ActiveRows.forward
 
-    def probe(self, fwd, obs, env_):
-        r = orig(self, fwd, obs, env_)
+    def probe(self, fwd, obs, env_, x=None):
+        r = orig(self, fwd, obs, env_, x)
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         log.append((self.m if self.idx is not None else self.n, e, time.perf_counter()))

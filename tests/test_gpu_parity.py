@@ -778,6 +778,26 @@ def test_live_index_and_row_cast(env):
         assert torch.equal(out, obs[rows].to(dt))
 
 
+def test_eval_step_team_writes_the_float_observation_too(env):
+    """brl_eval_step_team.obs_f32: the new observation as the next forward's float32 input, by the launch that steps the boards —
+    equal to `observation.astype(float32)` (src/evaluation.py:52) for acting, waiting and finished boards alike."""
+    from brl_amd import _capi
+    from brl_amd.bridge_bidding import _stream
+    L, dev, n = _capi.lib(), env.device, 3000
+    st = env.init(9, num_envs=n)
+    packed = st.packed.clone()
+    g = torch.Generator(device=dev).manual_seed(1)
+    for it in range(12):
+        logits = torch.randn(n, 39, device=dev, generator=g)
+        obs = torch.empty((n, 480), dtype=torch.bool, device=dev)
+        x = torch.full((n, 480), -1.0, device=dev)
+        term = torch.empty(n, dtype=torch.bool, device=dev)
+        _capi.check(L.brl_eval_step_team(env._h, packed.data_ptr(), packed.data_ptr(), n, logits.data_ptr(), 39, it & 1, None, None, None, 0,
+                                         None, None, None, obs.data_ptr(), None, None, term.data_ptr(), None, x.data_ptr(), _stream()))
+        assert torch.equal(x, obs.to(torch.float32)), it
+    assert bool(term.any())   # (some boards are finished by now: their rows were checked too)
+
+
 def test_evaluators_on_live_rows_equal_full_batches(env, monkeypatch):
     """The evaluators forward only the boards still playing (brl_amd/evaluation.py::_ActiveRows): every returned number equals
     the run that forwards all boards every iteration."""
