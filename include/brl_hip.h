@@ -47,9 +47,11 @@ extern "C" {
 typedef struct brl_handle brl_handle;
 
 const char *brl_last_error(void);
-/* The version of the EXPORTED SET: the number of the build round in which a symbol was last added or removed (4 now).  A symbol's
- * signature and meaning never change once exported — a changed form gets a new name and the old one moves to the "superseded
- * forms" section at the end of this header until nothing uses it, then it is dropped and the version is bumped. */
+/* The version of the EXPORTED SET: the number of the build round in which a symbol was last added, removed or changed (4 now).
+ * Under ONE version a symbol's signature and meaning never change; a changed form normally gets a new name and the old one moves
+ * to the "superseded forms" section at the end of this header until nothing uses it.  Version 4 against version 3: added the
+ * brl_mlp_gemm family, brl_mlp_forward_rows, brl_adam_clip_fin_gather_defer, brl_adam_apply_range, brl_ppo_heads_loss_parts;
+ * removed brl_ppo_stats_at; brl_live_index gained `tag`, brl_eval_step_team gained `obs_f32` (both before `stream`). */
 int brl_version(void);
 
 /* BridgeBidding(dds_results_table_path)  — ppo.py:303, pgx.bridge_bidding.BridgeBidding.
