@@ -274,7 +274,7 @@ class _ActiveRows:
 
 
 def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward, tables, stats, bid_set, cum_return,
-               rewards_sum, sync_every, record_actions=None, record_logits=None):
+               rewards_sum, sync_every, record_actions=None, record_logits=None, by_turn=False):
     """Runs ``brl_eval_step`` until every board is finished; ``state.packed`` is advanced in place.  (``sync_every`` — how often
     the loop condition used to be read back — is kept in the signatures and ignored: see ``_DoneWatch``.)"""
     n, dev = state.num_envs, env.device
@@ -303,6 +303,22 @@ def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward,
             watch.release()   # (an exception above leaves it marked busy: the next loop simply builds its own)
             break
         nobs = torch.empty((n, OBS_SIZE), dtype=torch.bool, device=dev)
+        if by_turn:
+            # the networks take turns by CALL, not by team: call i of every board is made by fwd1 (i even: the player who opened
+            # and their partner) or fwd2 (i odd) — the macro-step of src/utils.py:133-202 one call at a time, every board in step;
+            # ONE forward per call, on the boards still playing
+            k = count & 1
+            rows[k].update(polled)
+            lg = rows[k].forward(fwd2 if k else fwd1, obs, env)
+            check(_capi.lib().brl_eval_step(
+                env._h, ptr(packed), ptr(packed), n, lg.data_ptr(), lg.stride(0), lg.data_ptr(), lg.stride(0),
+                C.byref(pa) if pa is not None else None, C.byref(pb) if pb is not None else None,
+                C.byref(ps) if ps is not None else None, int(bid_set),
+                ptr(cum_return), ptr(rewards_sum), ptr(action), ptr(nobs), None, None, ptr(term), None, _stream()))
+            obs = nobs
+            watch.post(count, term)
+            count += 1
+            continue
         if alternate:
             team = count & 1
             rows[team].update(polled)
@@ -520,7 +536,26 @@ def make_simple_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_
     actor_forward_pass = make_forward_pass(team1_activation, team1_model_type)
     opp_forward_pass = make_forward_pass(team2_activation, team2_model_type)
 
+    def by_turn(actor_params, rng):
+        """the same evaluation one CALL per iteration (``_eval_loop(by_turn=True)``): the forwards run on the boards still playing
+        only (bias + activation in the GEMM epilogue, the last boards through brl_mlp_forward_rows), the loop stops two calls
+        after the last board, not up to five.  A board's return is what its opening player collected: rewards are zero except on
+        the call that ends the auction, so the sum over macro-steps of src/evaluation.py:60 is that one entry."""
+        sh = _Shard(num_eval_envs, shard)
+        with torch.no_grad():
+            state = sh.init(eval_env, rng)
+            opener = state.current_player.to(torch.int64)
+            rsum = torch.zeros((sh.n, 4), dtype=torch.float32, device=eval_env.device)
+            _eval_loop(eval_env, state, _Forward(actor_forward_pass, actor_params), _Forward(opp_forward_pass, team2_params),
+                       None, None, 0, None, rsum, sync_every, by_turn=True)
+            R = rsum.gather(1, opener[:, None])[:, 0]
+        if sh.active:   # (scores are integers: the float64 sum over the ranks is exact)
+            return (sh.allsum(R.to(torch.float64).sum().reshape(1))[0] / float(num_eval_envs)).to(torch.float32)
+        return R.mean()
+
     def simple_evaluate(actor_params, rng):
+        if record_actions is None and os.environ.get("BRL_SIMPLE_EVAL_BY_TURN", "1") != "0":
+            return by_turn(actor_params, rng)
         step_fn = single_play_step_two_policy_commpetitive_deterministic(
             step_fn=eval_env.step, actor_forward_pass=actor_forward_pass, actor_params=actor_params,
             opp_forward_pass=opp_forward_pass, opp_params=team2_params)
