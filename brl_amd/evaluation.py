@@ -261,6 +261,11 @@ class _ActiveRows:
             return fwd(obs, None)
         if self.idx is None or self.full is None:
             self.full = fwd(obs, x if x is not None else obs.to(torch.float32))
+            if getattr(fwd, "ref", None) is not None and self.full.stride(0) <= NUM_ACTIONS:
+                # (the module's own [n, 38] logits: brl_mlp_forward_rows writes 38 + 1 numbers per row later on)
+                wide = torch.empty((self.full.shape[0], NUM_ACTIONS + 2), dtype=torch.float32, device=self.full.device)
+                wide[:, :NUM_ACTIONS] = self.full
+                self.full = wide
             return self.full
         if self.m <= _OWN_FORWARD_ROWS and getattr(fwd, "ref", None) is not None:
             # few boards left: the iteration is bound by host launches — gather + cast, the layers, the heads and the scatter
@@ -269,7 +274,8 @@ class _ActiveRows:
             return self.full
         x = torch.empty((self.m, OBS_SIZE), dtype=torch.float32, device=obs.device)
         check(_capi.lib().brl_obs_cast_rows(env._h, ptr(obs), ptr(self.idx), self.m, ptr(x), 0, _stream()))   # gather + astype
-        self.full.index_copy_(0, self.idx, fwd(None, x))   # (rows of finished boards keep their last logits: never used)
+        out = fwd(None, x)
+        self.full[:, :out.shape[1]].index_copy_(0, self.idx, out)   # (rows of finished boards keep their last logits: never used)
         return self.full
 
 

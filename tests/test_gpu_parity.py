@@ -1340,6 +1340,22 @@ def test_simple_evaluate_replays_through_oracle(env, oracle, n):
     assert done_at is not None and len(rec) - 1 - done_at <= 2
 
 
+@pytest.mark.parametrize("actor_kind,opp_kind", [(("tanh", "DeepMind"), ("relu", "FAIR")), (("relu", "FAIR"), ("relu", "DeepMind_6"))])
+def test_simple_evaluate_by_turn_equals_the_macro_step_loop(env, monkeypatch, actor_kind, opp_kind):
+    """make_simple_evaluate one call per iteration on the boards still playing (the default) against the mirror of the reference's
+    macro-step loop (src/evaluation.py:36-63), for the networks the fused snapshots do not cover (tanh: brl_mlp_forward_rows + the
+    module; FAIR: the module itself) — the same return, exactly (scores are integers; the calls are arg-maxes)."""
+    from brl_amd.evaluation import make_simple_evaluate
+    from brl_amd.models import make_forward_pass
+    a = make_forward_pass(*actor_kind).init(1, device="cuda")
+    o = make_forward_pass(*opp_kind).init(2, device="cuda")
+    ev = make_simple_evaluate(env, actor_kind[0], actor_kind[1], opp_kind[0], opp_kind[1], o, 1536)
+    fast = float(ev(a, 21))
+    monkeypatch.setenv("BRL_SIMPLE_EVAL_BY_TURN", "0")
+    slow = float(ev(a, 21))
+    assert fast == slow and abs(fast) <= 7600.0
+
+
 def test_ppo_loop_runs_end_to_end(env, tmp_path):
     """BASELINE config 4 at toy size — the ppo.py:348-570 loop: evaluations, FSP pool behind the threshold gate,
     roll_out -> calc_gae -> update_step, the reference's log keys, LUT rotation after hash_size boards (G14),
