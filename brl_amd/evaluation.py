@@ -96,11 +96,13 @@ class _Forward:
         act = getattr(m, "act", None)
         if not str(getattr(m, "model", "")).startswith("DeepMind") or act not in (torch.relu, torch.tanh):
             return None
-        ts = [t for lin in m.body for t in (lin.weight, lin.bias)] + [m.actor.weight, m.actor.bias, m.critic.weight, m.critic.bias]
+        vec = [t for lin in m.body for t in (lin.weight, lin.bias)] + [m.actor.weight, m.critic.weight]   # read 16 bytes at a time
+        ts = vec + [m.actor.bias, m.critic.bias]   # (read one by one: inside FusedMinibatch's flat buffer critic.bias sits 8 bytes off)
         hidden = m.body[0].weight.shape[0]
         if (len(m.body) > 8 or hidden % 4 or hidden > 1024 or m.body[0].weight.shape[1] != OBS_SIZE
                 or m.actor.weight.shape[0] != NUM_ACTIONS
-                or any((not t.is_cuda) or t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16 for t in ts)
+                or any((not t.is_cuda) or t.dtype != torch.float32 or not t.is_contiguous() for t in ts)
+                or any(t.data_ptr() % 16 for t in vec)
                 or any(lin.weight.shape[0] != hidden for lin in m.body)):
             return None
         r = _capi.MlpRef()

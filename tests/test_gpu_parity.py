@@ -2290,6 +2290,38 @@ def test_mlp_forward_rows_matches_float64(activation, model, n, m):
     assert float((out_h[rows_h][:, :39].double() - got[:k, :39]).abs().max()) < 2e-4 * scale
 
 
+def test_mlp_forward_rows_takes_parameters_inside_the_fused_update_buffers():
+    """The learner's parameters are views of FusedMinibatch's flat buffers (critic.bias sits 8 bytes off a 16-byte boundary there):
+    the evaluators' one-call forward must still apply to them, and read the live values."""
+    import copy
+    from brl_amd.evaluation import _Forward
+    from brl_amd.models import make_forward_pass
+    from brl_amd.train import DEFAULTS
+    from brl_amd.update import FusedMinibatch, make_optimizer
+    fp = make_forward_pass("relu", "DeepMind")
+    net = fp.init(11, device="cuda")
+    cfg = dict(DEFAULTS, num_envs=256, num_steps=4, minibatch_size=256, update_epochs=1)
+    fm = FusedMinibatch(cfg, net, make_optimizer(cfg, net)["opt"], 256, torch.device("cuda"))
+    assert net.critic.bias.data_ptr() == fm.P[fm.views[net.critic.bias]].data_ptr() and net.critic.bias.data_ptr() % 16 != 0
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.01 * torch.randn_like(p))   # (in place: the views stay views)
+    fwd = _Forward(fp, net)
+    assert fwd.ref is not None
+    n, m = 900, 300
+    g = torch.Generator(device="cuda").manual_seed(5)
+    obs = torch.rand(n, 480, device="cuda", generator=g) < 0.1
+    rows = torch.randperm(n, device="cuda", generator=g)[:m].contiguous()
+    out = torch.zeros((n, 39), device="cuda")
+    fwd.rows(obs, rows, m, out, None)
+    net64 = copy.deepcopy(net).cpu().double()
+    with torch.no_grad():
+        logits, value = net64(obs[rows].cpu().double())
+    got = out[rows].cpu().double()
+    scale = max(1.0, float(logits.abs().max()))
+    assert float((got[:, :38] - logits).abs().max()) < 2e-4 * scale and float((got[:, 38] - value).abs().max()) < 2e-4 * scale
+
+
 def test_mlp_forward_rows_rejects_what_it_cannot_do():
     import ctypes as C
     from brl_amd import _capi
