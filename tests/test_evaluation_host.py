@@ -40,3 +40,20 @@ def test_batch_size_never_grows_and_ignores_missing_lists():
     assert rows.m == 1536
     rows.update((100, idx))            # an older, larger count arriving late must not grow the batch again
     assert rows.m == 1536
+
+
+def test_done_watch_tags_identify_loop_and_iteration():
+    """The finished-board count reaches the host as (tag << 32) | count in pinned memory (brl_live_index); a tag names the loop
+    (epoch) and the iteration, fits the kernel's 31 bits, and no two iterations the host could confuse share one: the ring has 4
+    slots, a slot is rewritten every 4 iterations, and a new loop on the same watch takes a new epoch."""
+    from brl_amd.evaluation import _DoneWatch
+    w = object.__new__(_DoneWatch)
+    seen = set()
+    for epoch in (1, 2, 0x7FFF):
+        w.epoch = epoch
+        tags = [w._tag(i) for i in range(0, 5000)]
+        assert all(0 < t < (1 << 31) for t in tags)
+        assert len(set(tags)) == len(tags)                      # within a loop: distinct for 65535 iterations
+        assert not (seen & set(tags))                           # across loops: disjoint
+        seen |= set(tags)
+    assert _DoneWatch.DEPTH < _DoneWatch.RING                   # the slot polled for iteration i - DEPTH is not the one being written
