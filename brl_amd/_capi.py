@@ -112,7 +112,6 @@ def lib() -> C.CDLL:
         "brl_ppo_loss_heads": [i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, i64, f32, f32, f32, i32, i32, _vp, _vp, _vp, _vp],
         "brl_mb_gather": [i32, C.POINTER(TransitionPtrs), _vp, _vp, _vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
         "brl_relu_bwd_colsum": [i32, _vp, _vp, i64, i64, i64, _vp, _vp, _vp],
-        "brl_bias_finalize": [i32, i32, _vp, _vp, _vp, i64, _vp],
         "brl_adam_clip": [i32, _vp, _vp, _vp, _vp, i64, _vp, f32, _vp, f32, f32, f32, f32, f32, _vp, _vp, _vp, _vp],
         "brl_ppo_heads_loss": [i32, _vp, i64, _vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, i64, f32, f32, f32, i32, i32, i32,
                                _vp, _vp, _vp, _vp, _vp],
@@ -157,7 +156,7 @@ EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_de
            "brl_init_random", "brl_init_from_deals", "brl_step", "brl_observe", "brl_get_fields",
            "brl_rollout_random", "brl_policy_step", "brl_policy_step_at", "brl_obs_cast", "brl_obs_cast_rows", "brl_live_index", "brl_linear_act", "brl_linear_act_heads", "brl_gae", "brl_imp_reward", "brl_duplicate_step",
            "brl_eval_step", "brl_eval_reduce", "brl_ppo_loss", "brl_ppo_stats", "brl_ppo_loss_heads", "brl_mb_gather",
-           "brl_relu_bwd_colsum", "brl_adam_clip", "brl_bias_finalize", "brl_policy_step_ex",
+           "brl_relu_bwd_colsum", "brl_adam_clip", "brl_policy_step_ex",
            "brl_eval_step_team", "brl_rollout_random_gae", "brl_ppo_heads_loss", "brl_ppo_heads_loss_split", "brl_ppo_heads_bwd", "brl_ppo_stats_gram",
            "brl_act_bwd_colsum", "brl_act_bwd_colsum_heads_dw", "brl_bias_finalize_ex", "brl_ppo_stats_rows", "brl_mb_gather_bind", "brl_mb_gather_dev", "brl_ppo_illegal_grad", "brl_adam_clip_gather", "brl_adam_clip_fin_gather", "brl_mlp_gemm", "brl_mlp_gemm_dh_heads_dw", "brl_adam_clip_fin_gather_defer", "brl_mlp_gemm_adam",
            "brl_adam_apply_range", "brl_mlp_gemm_bwd_pair", "brl_mlp_gemm_fwd_heads",

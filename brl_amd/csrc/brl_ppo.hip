@@ -326,25 +326,6 @@ extern "C" int brl_relu_bwd_colsum(int device, float *dh, const float *h, int64_
   return BRL_OK;
 }
 
-extern "C" int brl_bias_finalize(int device, int nseg, const float *const *scratch, const int64_t *cols, float *const *db,
-                                 int64_t rows, void *stream) {
-  NEED(nseg >= 1 && nseg <= BIAS_MAX_SEGS && scratch && cols && db && rows > 0, "nseg / scratch / cols / db / rows");
-  HIP_TRY(hipSetDevice(device));
-  BiasSegs S{};
-  S.n = nseg;
-  int64_t maxc = 0;
-  for (int i = 0; i < nseg; i++) {
-    NEED(scratch[i] && db[i] && cols[i] > 0, "segment");
-    const int64_t tr = relu_tile_rows(cols[i], cols[i]);  // (dense rows: ld == cols, as brl_relu_bwd_colsum was called)
-    S.tiles[i] = (rows + tr - 1) / tr;
-    S.partials[i] = scratch[i]; S.cols[i] = cols[i]; S.db[i] = db[i];
-    maxc = cols[i] > maxc ? cols[i] : maxc;
-  }
-  hipLaunchKernelGGL(k_bias_finalize, dim3((unsigned)((maxc + 63) / 64), (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, S);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
-}
-
 extern "C" int brl_act_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, int act,
                                   float *scratch, void *stream) {
   NEED(dh && h && scratch && rows > 0 && cols > 0 && ld >= cols, "dh / h / scratch / rows / cols / ld");

@@ -51,7 +51,7 @@ const char *brl_last_error(void);
  * Under ONE version a symbol's signature and meaning never change; a changed form normally gets a new name and the old one moves
  * to the "superseded forms" section at the end of this header until nothing uses it.  Version 4 against version 3: added the
  * brl_mlp_gemm family, brl_mlp_forward_rows, brl_adam_clip_fin_gather_defer, brl_adam_apply_range, brl_ppo_heads_loss_parts;
- * removed brl_ppo_stats_at; brl_live_index gained `tag`, brl_eval_step_team gained `obs_f32` (both before `stream`). */
+ * removed brl_ppo_stats_at and brl_bias_finalize; brl_live_index gained `tag`, brl_eval_step_team gained `obs_f32` (both before `stream`). */
 int brl_version(void);
 
 /* BridgeBidding(dds_results_table_path)  — ppo.py:303, pgx.bridge_bidding.BridgeBidding.
@@ -443,7 +443,7 @@ int brl_act_bwd_colsum_heads_dw(int device, float *dz, const float *hh, int64_t 
                                 const float *gram_partials, int64_t ngroups, const int32_t *row_index, float *stat_sums,
                                 float *gram_sums, void *stream);
 
-/* brl_bias_finalize with the tile count of every segment given: out[i][c] = sum_{t < tiles[i]} partials[i][t * cols[i] + c],
+/* The sums of several layers' tile partials in one launch: out[i][c] = sum_{t < tiles[i]} partials[i][t * cols[i] + c],
  * in order, for nseg <= 12 segments (bias gradients of the layers, and the head's weight / bias gradients from
  * brl_ppo_heads_bwd's batch splits). */
 int brl_bias_finalize_ex(int device, int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles,
@@ -582,9 +582,9 @@ int brl_mlp_forward_rows(int device, const brl_mlp_ref *net, const uint8_t *obs,
  * SUPERSEDED FORMS — still exported because tests use them as the reference form of their successors and the A/B scripts
  * under scripts/ time them; the default brl_amd code path calls none of them.  Successors: brl_ppo_loss_heads ->
  * brl_ppo_heads_loss_split (heads formed inside); brl_mb_gather -> brl_mb_gather_bind / _dev (device-resident arguments);
- * brl_relu_bwd_colsum -> brl_act_bwd_colsum (either activation) -> brl_mlp_gemm's GATE_COLSUM epilogue; brl_bias_finalize ->
+ * brl_relu_bwd_colsum -> brl_act_bwd_colsum (either activation) -> brl_mlp_gemm's GATE_COLSUM epilogue;
  * brl_bias_finalize_ex -> the finalize blocks of brl_adam_clip_fin_gather; brl_adam_clip -> brl_adam_clip_gather /
- * _fin_gather; brl_ppo_heads_loss -> brl_ppo_heads_loss_split.  (brl_ppo_stats_at was dropped in version 4: no caller left.)
+ * _fin_gather; brl_ppo_heads_loss -> brl_ppo_heads_loss_split.  (brl_ppo_stats_at and brl_bias_finalize were dropped in version 4: no caller left.)
  * ================================================================================================================== */
 
 /* brl_ppo_loss on the MERGED head output: heads float [batch,39] = 38 logits then the value (one GEMM for both heads);
@@ -606,14 +606,9 @@ int brl_mb_gather(int device, const brl_transition *flat, const float *adv, cons
  * of every row tile (16 rows when cols and ld are multiples of 4, else 64) into scratch (float [ceil(rows / 16) * cols]
  * is always enough); db != NULL: a second launch adds the tiles in index
  * order, db[c] = sum_r dh[r,c] (deterministic).  h == NULL: column sums only (the head's bias gradient).
- * db == NULL: tiles only — brl_bias_finalize then finishes several layers with one launch. */
+ * db == NULL: tiles only — brl_bias_finalize_ex then finishes several layers with one launch. */
 int brl_relu_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, float *db,
                         float *scratch, void *stream);
-
-/* db[i][c] = sum over the tiles of scratch[i] (as written by brl_relu_bwd_colsum for `rows` dense rows, ld == cols[i])
- * for nseg <= 12 layers. */
-int brl_bias_finalize(int device, int nseg, const float *const *scratch, const int64_t *cols, float *const *db, int64_t rows,
-                      void *stream);
 
 /* optax.chain(clip_by_global_norm(max_norm), adam(lr, eps)) (ppo.py:195-211) on flat fp32 buffers of n elements, two
  * launches (n a multiple of 4: pad the buffers with zeros): *step (device float) += 1; the gradient is grad_scale * g

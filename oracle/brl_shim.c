@@ -531,10 +531,6 @@ int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int6
   (void)gs; (void)lrd; (void)device; (void)p; (void)g; (void)m; (void)v; (void)n; (void)step; (void)lr; (void)b1; (void)b2; (void)eps; (void)mn; (void)scratch; (void)mbi; (void)no; (void)s;
   NOT_HERE("brl_adam_clip");
 }
-int brl_bias_finalize(int device, int nseg, const float *const *scr, const int64_t *cols, float *const *db, int64_t rows, void *s) {
-  (void)device; (void)nseg; (void)scr; (void)cols; (void)db; (void)rows; (void)s;
-  NOT_HERE("brl_bias_finalize");
-}
 int brl_policy_step_ex(brl_handle *h, const uint64_t *si, uint64_t *so, int64_t n, const float *lg, int64_t ls, int mode,
                        const uint32_t *db, uint32_t dof, int ar, int32_t *a, float *lp, uint8_t *obs, uint8_t *m, float *ra,
                        uint8_t *ta, int32_t *cp, const brl_macro_ext *ext, void *s) {

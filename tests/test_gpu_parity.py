@@ -1911,7 +1911,7 @@ def test_fused_update_follows_a_reloaded_optimizer_state():
 
 
 def test_fused_update_helpers_match_torch():
-    """brl_mb_gather, brl_relu_bwd_colsum (+ brl_bias_finalize) and brl_adam_clip against their torch counterparts."""
+    """brl_mb_gather, brl_relu_bwd_colsum and brl_adam_clip against their torch counterparts."""
     import ctypes as C
     from brl_amd import _capi
     L, dev = _capi.lib(), torch.device("cuda", 0)
