@@ -505,6 +505,35 @@ int brl_mlp_gemm_dh_heads_dw(int device, const float *dz, int64_t lddz, const fl
                              float *dw_partials, float *db_partials, const float *loss_partials, const float *gram_partials,
                              int64_t ngroups, const int32_t *row_index, float *stat_sums, float *gram_sums, void *stream);
 
+/* ---- the policy network's fp32 forward for the boards an evaluator still plays, own kernels end to end (round 4) ------------
+ * `actor(x), critic(x)` of src/models.py:23-33 ("DeepMind": nlayers x [hk.Linear(hidden) + activation], then the two heads) as
+ * called per env.step by src/evaluation.py:52-60,146-151, for m selected rows: x[r] = float(obs[rows[r]]) (obs uint8 [.,480],
+ * 0/1; rows NULL: row r itself), nlayers launches of brl_mlp_gemm's kernel (BRL_GEMM_NT + BRL_GEMM_EPI_BIAS_ACT; the weights
+ * in nn.Linear's own [out, in] layout — nothing is transposed, copied or cached), one launch for the 38 + 1 heads that writes
+ * row r's logits and value to out[rows[r] * ldo + 0..38] (the scatter back included).  One host call instead of the ~8 launches
+ * through torch of the library path: an evaluator's small-batch iterations are bound by host launches (DESIGN section 4.2).
+ * scratch: m * (480 + 2 * hidden) floats, 16-byte aligned.  in_features must be 480, hidden % 4 == 0 and <= 1024. */
+typedef struct brl_mlp_ref {
+  int32_t nlayers;          /* hidden layers, 1..8 */
+  int32_t act;              /* 0 = ReLU, 1 = tanh (src/models.py:16) */
+  int64_t in_features;      /* 480 */
+  int64_t hidden;
+  const float *w[8];        /* w[l]: [hidden, in_l] row-major, in_0 = in_features, in_l = hidden */
+  const float *b[8];        /* b[l]: [hidden] */
+  const float *actor_w;     /* [38, hidden] */
+  const float *actor_b;     /* [38] */
+  const float *critic_w;    /* [1, hidden] */
+  const float *critic_b;    /* [1] */
+} brl_mlp_ref;
+int brl_mlp_forward_rows(int device, const brl_mlp_ref *net, const uint8_t *obs, const int64_t *rows, int64_t m, float *scratch,
+                         int64_t scratch_len, float *out, int64_t ldo, void *stream);
+
+/* ==================================================================================================================
+ * OPT-IN VARIANTS — fusions of the PPO minibatch step that were built, checked bit for bit against the default path (tests) and
+ * measured NO FASTER inside the step (profiles/r04/r04_experiments.txt): the default brl_amd code path
+ * calls none of them; FusedMinibatch takes them under config["bwd_pair"], ["fuse_heads_fwd"], ["adam_ride"].
+ * ================================================================================================================== */
+
 /* The two backward products of one hidden layer in ONE launch (both read dz [batch, n_out] and h_prev [batch, n_in] = the output of
  * the layer below): dz_out [batch, n_in] = (dz w) * act'(h_prev) with w [n_out, n_in] (+ colsum [ceil(batch / 64), n_in], may be
  * NULL), and dw_out [n_out, n_in] = dz^T h_prev (+ sqsum [ceil(n_out / 64) * ceil(n_in / 32)], may be NULL).  dheads != NULL: the
@@ -554,29 +583,6 @@ int brl_mlp_gemm_adam(int device, const float *a, int64_t lda, const float *b, i
 int brl_adam_apply_range(int device, float *p, const float *g, float *m, float *v, int64_t lo, int64_t hi, const float *scratch,
                          int npartials, const float *step, float lr, const float *lr_dev, float beta1, float beta2, float eps,
                          float max_norm, float grad_scale, int32_t *pending, int clear_pending, void *stream);
-
-/* ---- the policy network's fp32 forward for the boards an evaluator still plays, own kernels end to end (round 4) ------------
- * `actor(x), critic(x)` of src/models.py:23-33 ("DeepMind": nlayers x [hk.Linear(hidden) + activation], then the two heads) as
- * called per env.step by src/evaluation.py:52-60,146-151, for m selected rows: x[r] = float(obs[rows[r]]) (obs uint8 [.,480],
- * 0/1; rows NULL: row r itself), nlayers launches of brl_mlp_gemm's kernel (BRL_GEMM_NT + BRL_GEMM_EPI_BIAS_ACT; the weights
- * in nn.Linear's own [out, in] layout — nothing is transposed, copied or cached), one launch for the 38 + 1 heads that writes
- * row r's logits and value to out[rows[r] * ldo + 0..38] (the scatter back included).  One host call instead of the ~8 launches
- * through torch of the library path: an evaluator's small-batch iterations are bound by host launches (DESIGN section 4.2).
- * scratch: m * (480 + 2 * hidden) floats, 16-byte aligned.  in_features must be 480, hidden % 4 == 0 and <= 1024. */
-typedef struct brl_mlp_ref {
-  int32_t nlayers;          /* hidden layers, 1..8 */
-  int32_t act;              /* 0 = ReLU, 1 = tanh (src/models.py:16) */
-  int64_t in_features;      /* 480 */
-  int64_t hidden;
-  const float *w[8];        /* w[l]: [hidden, in_l] row-major, in_0 = in_features, in_l = hidden */
-  const float *b[8];        /* b[l]: [hidden] */
-  const float *actor_w;     /* [38, hidden] */
-  const float *actor_b;     /* [38] */
-  const float *critic_w;    /* [1, hidden] */
-  const float *critic_b;    /* [1] */
-} brl_mlp_ref;
-int brl_mlp_forward_rows(int device, const brl_mlp_ref *net, const uint8_t *obs, const int64_t *rows, int64_t m, float *scratch,
-                         int64_t scratch_len, float *out, int64_t ldo, void *stream);
 
 /* ==================================================================================================================
  * SUPERSEDED FORMS — still exported because tests use them as the reference form of their successors and the A/B scripts
