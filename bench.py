@@ -653,8 +653,14 @@ def bench_secondary(torch, dev):
     dup_eval = make_simple_duplicate_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", n_eval)
     t_simple, _ = timed(lambda: simple(team1, 7), 3)
     t_dup, _ = timed(lambda: dup_eval(team1, opp, 7), 3)
+    # ... and the duplicate evaluation WITH bidding statistics that ppo.py runs every num_eval_step iterations (ppo.py:383-392,
+    # src/evaluation.py:207-1032), its 23-entry log_info turned into the eval/... dict on the host: reported, not part of `ms`
+    from brl_amd.evaluation import make_evaluate, make_evaluate_log
+    full_eval = make_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", opp, n_eval, duplicate=True)
+    t_full, _ = timed(lambda: make_evaluate_log(full_eval(team1, 7)[0]), 3)
     phases["evaluators"] = {"ms": (t_simple + 3 * t_dup) * 1e3, "simple_evaluate_ms": t_simple * 1e3,
-                            "simple_duplicate_evaluate_ms": t_dup * 1e3, "num_eval_envs": n_eval, "dtype": "fp32",
+                            "simple_duplicate_evaluate_ms": t_dup * 1e3, "duplicate_evaluate_with_statistics_ms": t_full * 1e3,
+                            "num_eval_envs": n_eval, "dtype": "fp32",
                             "ms_as_brl_amd_train_plays_them": (t_simple + t_dup) * 1e3,
                             "as_played": "brl_amd.train plays each distinct (parameter version, opponent) pair once: imp_opp of "
                                          "iteration i + 1 IS imp_opp_after of iteration i (same networks, boards, arg-max play), "
