@@ -324,6 +324,8 @@ def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward,
                 C.byref(ps) if ps is not None else None, int(bid_set),
                 ptr(cum_return), ptr(rewards_sum), ptr(action), ptr(nobs), None, None, ptr(term), None, _stream()))
             obs = nobs
+            if record_actions is not None:
+                record_actions.append(action.clone())
             watch.post(count, term)
             count += 1
             continue
@@ -536,11 +538,13 @@ def make_evaluate_log(log_info):
 
 def make_simple_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_type, team2_activation,
                          team2_model_type, team2_params, num_eval_envs, sync_every: int = 8, shard=None,
-                         record_actions=None):
+                         record_actions=None, record_calls=None):
     """src/evaluation.py:11-66: actor (greedy) vs a fixed opponent (greedy) on single tables, no
     auto-reset; returns the mean total reward of the acting player.  ``team2_params`` replaces the
     reference's pickle path (model files are torch modules here).  ``record_actions``: optional list that receives,
-    per loop iteration, the four calls of the macro-step as [4, n] (tests replay them through the oracle)."""
+    per loop iteration, the four calls of the macro-step as [4, n] (tests replay them through the oracle; the mirror of the
+    reference's macro-step loop runs).  ``record_calls``: optional list that receives one [n] tensor per CALL of the by-turn loop
+    (the default loop, forwarding every board: the oracle replay of that loop)."""
     actor_forward_pass = make_forward_pass(team1_activation, team1_model_type)
     opp_forward_pass = make_forward_pass(team2_activation, team2_model_type)
 
@@ -555,7 +559,7 @@ def make_simple_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_
             opener = state.current_player.to(torch.int64)
             rsum = torch.zeros((sh.n, 4), dtype=torch.float32, device=eval_env.device)
             _eval_loop(eval_env, state, _Forward(actor_forward_pass, actor_params), _Forward(opp_forward_pass, team2_params),
-                       None, None, 0, None, rsum, sync_every, by_turn=True)
+                       None, None, 0, None, rsum, sync_every, record_actions=record_calls, by_turn=True)
             R = rsum.gather(1, opener[:, None])[:, 0]
         if sh.active:   # (scores are integers: the float64 sum over the ranks is exact)
             return (sh.allsum(R.to(torch.float64).sum().reshape(1))[0] / float(num_eval_envs)).to(torch.float32)

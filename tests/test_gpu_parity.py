@@ -1340,6 +1340,37 @@ def test_simple_evaluate_replays_through_oracle(env, oracle, n):
     assert done_at is not None and len(rec) - 1 - done_at <= 2
 
 
+@pytest.mark.parametrize("n", [512, 10000])
+def test_simple_evaluate_by_turn_replays_through_oracle(env, oracle, n):
+    """The default loop of make_simple_evaluate — one call per iteration, the actor's network on even calls, the opponent's on odd
+    ones — replayed through the oracle's step from the recorded calls: every call legal while the board is live, finished boards
+    untouched (G9), a board's return = what the player who opened collected (src/evaluation.py:53-60 summed over the macro-steps)."""
+    from brl_amd.evaluation import make_simple_evaluate
+    from brl_amd.models import make_forward_pass
+    fp = make_forward_pass("relu", "DeepMind")
+    a, o = fp.init(1, device="cuda"), fp.init(2, device="cuda")
+    calls = []
+    got = float(make_simple_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", o, n, record_calls=calls)(a, 11))
+    torch.cuda.synchronize()
+    assert got == float(make_simple_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", o, n)(a, 11))   # live-row forwards: same number
+    ref = oracle.init_random(n, seed=11)
+    opener = ref["current_player"].copy()
+    rows = np.arange(n)
+    R = np.zeros(n, np.float64)
+    done_at = None
+    for i, c in enumerate(calls):
+        c = to_np(c)
+        live = ref["terminated"] == 0
+        assert (ref["legal_action_mask"][rows, c][live] == 1).all(), f"call {i}: a greedy call is illegal"
+        oracle.step(ref, c)
+        R += ref["rewards"][rows, opener]
+        if done_at is None and ref["terminated"].all():
+            done_at = i
+    assert done_at is not None and len(calls) - 1 - done_at <= 2      # the loop stops at most two calls after the last board
+    assert np.abs(R).max() <= 7600 and (R != 0).any() and np.array_equal(R, np.round(R))
+    assert abs(got - R.mean()) <= 1e-6 * max(1.0, np.abs(R).mean()) * 8
+
+
 @pytest.mark.parametrize("actor_kind,opp_kind", [(("tanh", "DeepMind"), ("relu", "FAIR")), (("relu", "FAIR"), ("relu", "DeepMind_6"))])
 def test_simple_evaluate_by_turn_equals_the_macro_step_loop(env, monkeypatch, actor_kind, opp_kind):
     """make_simple_evaluate one call per iteration on the boards still playing (the default) against the mirror of the reference's
