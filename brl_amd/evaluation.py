@@ -282,7 +282,7 @@ class _ActiveRows:
 
 
 def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward, tables, stats, bid_set, cum_return,
-               rewards_sum, sync_every, record_actions=None, record_logits=None, by_turn=False):
+               rewards_sum, sync_every, record_actions=None, record_logits=None, by_turn=False, record_calls=None):
     """Runs ``brl_eval_step`` until every board is finished; ``state.packed`` is advanced in place.  (``sync_every`` — how often
     the loop condition used to be read back — is kept in the signatures and ignored: see ``_DoneWatch``.)"""
     n, dev = state.num_envs, env.device
@@ -342,6 +342,8 @@ def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward,
                 C.byref(pa) if pa is not None else None, C.byref(pb) if pb is not None else None,
                 C.byref(ps) if ps is not None else None, int(bid_set),
                 ptr(cum_return), ptr(rewards_sum), ptr(action), ptr(nobs), None, None, ptr(term), None, ptr(obs_f32), _stream()))
+            if record_calls is not None:   # (the calls of THIS loop — -1: the board waited for its team's iteration — for oracle replays)
+                record_calls.append(action.clone())
             obs = nobs
             watch.post(count, term)
             count += 1
@@ -372,9 +374,11 @@ def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward,
 
 
 def make_simple_duplicate_evaluate(eval_env: BridgeBidding, team1_activation, team1_model_type, team2_activation,
-                                   team2_model_type, num_eval_envs, sync_every: int = 16, record_actions=None, shard=None):
+                                   team2_model_type, num_eval_envs, sync_every: int = 16, record_actions=None, shard=None,
+                                   record_calls=None):
     """src/evaluation.py:69-204.  ``record_actions``: optional list that receives each iteration's action tensor
-    (tests replay them through the oracle).  ``shard`` (see _Shard): the boards are split over the ranks, (mean IMP,
+    (tests replay them through the oracle; the reference's lock-step loop runs).  ``record_calls``: the same for the DEFAULT
+    loop (teams alternate, forwards on the boards still playing): one [n] tensor per iteration, -1 where a board waited.  ``shard`` (see _Shard): the boards are split over the ranks, (mean IMP,
     standard error, win rate) are those of all ``num_eval_envs`` boards on every rank; the Table_info are this rank's."""
     team1_forward_pass = make_forward_pass(team1_activation, team1_model_type)
     team2_forward_pass = make_forward_pass(team2_activation, team2_model_type)
@@ -389,7 +393,7 @@ def make_simple_duplicate_evaluate(eval_env: BridgeBidding, team1_activation, te
             fwd1 = _Forward(team1_forward_pass, team1_params)
             fwd2 = fwd1 if team2_params is team1_params else _Forward(team2_forward_pass, team2_params)
             _eval_loop(eval_env, state, fwd1, fwd2, (table_a_info, table_b_info), None, 0, cum_return, None,
-                       sync_every, record_actions)                   # :120-197; cum_return += rewards[:, 0] (G8)
+                       sync_every, record_actions, record_calls=record_calls)   # :120-197; cum_return += rewards[:, 0] (G8)
             n = float(num_eval_envs)
             if sh.active:   # sums over every rank's boards (IMPs are integers: exact in float64)
                 x = cum_return.to(torch.float64)

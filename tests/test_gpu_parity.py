@@ -1117,6 +1117,48 @@ def test_simple_duplicate_evaluate_replays_through_oracle(env, oracle, n):
     assert float(mean0) == 0.0 and float(win0) == 0.0
 
 
+@pytest.mark.parametrize("n", [640, 8192])   # 8192 = BASELINE.json configs[2]
+def test_simple_duplicate_evaluate_default_loop_replays_through_oracle(env, oracle, n):
+    """The loop configs[2] actually runs — the teams alternate (a board whose player to act is on the other team waits: action -1),
+    forwards on the boards still playing, the last boards through brl_mlp_forward_rows — replayed through the oracle's
+    duplicate_step from its own recorded calls: waiting boards keep their state, every call of a live board is legal, the
+    snapshots of both tables, the IMPs and the three returned numbers match (src/evaluation.py:120-202, G8, G12)."""
+    from brl_amd.evaluation import make_simple_duplicate_evaluate
+    from brl_amd.models import make_forward_pass
+    from oracle import Oracle
+    fp = make_forward_pass("relu", "DeepMind")
+    t1, t2 = fp.init(3, device="cuda"), fp.init(4, device="cuda")
+    calls = []
+    ev = make_simple_duplicate_evaluate(env, "relu", "DeepMind", "relu", "DeepMind", n, record_calls=calls)
+    (mean, se, win), A, B = ev(t1, t2, 99)
+    torch.cuda.synchronize()
+    ref = oracle.init_random(n, seed=99)
+    oA, oB = Oracle.table_info_from(ref), Oracle.table_info_from(ref)
+    cum = np.zeros(n, np.float32)
+    rows = np.arange(n)
+    waited = 0
+    for i, a in enumerate(calls):
+        act = to_np(a)
+        idle = act < 0
+        live = (ref["terminated"] == 0) & ~idle
+        team = (ref["current_player"] >> 1)
+        assert (team[live] == (i & 1)).all() and (team[idle & (ref["terminated"] == 0)] != (i & 1)).all()   # who acted, who waited
+        assert (ref["legal_action_mask"][rows, np.where(idle, 0, act)][live] == 1).all()
+        keep = (ref[idle].copy(), oA[idle].copy(), oB[idle].copy())
+        oracle.duplicate_step(ref, np.where(idle, 0, act).astype(np.int32), oA, oB)
+        ref[idle], oA[idle], oB[idle] = keep
+        cum[~idle] += ref["rewards"][~idle, 0]
+        waited += int(idle.sum())
+    assert ref["terminated"].all() and oA["terminated"].all() and oB["terminated"].all()
+    assert 0 < waited <= 2 * n + n // 2     # a board waits at most one iteration at its start and one at the table switch
+    for T, oT in ((A, oA), (B, oB)):
+        for f in ("terminated", "rewards", "last_bid", "last_bidder", "call_x", "call_xx"):
+            assert np.array_equal(to_np(getattr(T, f)).astype(np.float64), oT[f].astype(np.float64)), f
+    assert abs(float(mean) - cum.mean()) < 1e-5
+    assert abs(float(se) - cum.std(ddof=1) / np.sqrt(n)) < 1e-5
+    assert abs(float(win) - (cum > 0).mean()) < 1e-6
+
+
 def _replay_evaluate(oracle, rec_actions, rec_logits, seed, n, duplicate):
     """Replays make_evaluate's loop through the oracle with the recorded greedy actions / logits and restates its
     statistics with oracle/eval_stats.py (numpy, after src/evaluation.py:583-1031)."""
