@@ -63,6 +63,11 @@ def synthetic_lut(n: int, seed: int = 0):
     return keys, values
 
 
+# fp32 GEMM FLOPs one sample costs in the PPO update AS EXECUTED (DeepMind MLP 480 -> 4 x 1024 -> 38 + 1): forward 2 x 3 677 184,
+# weight gradients the same again, input gradients for everything but layer 0 (480 x 1024): 21.08 MFLOP, not 3 x forward = 22.06
+UPDATE_FLOP_PER_SAMPLE = 2 * (3 * 3_677_184 - 480 * 1024)
+
+
 def cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -629,11 +634,21 @@ def bench_secondary(torch, dev):
         return info
     t_upd, _ = timed(do_update, 3)
     nmb = cfg32["update_epochs"] * cfg32["num_minibatches"]
-    uflop = 3 * rows * fwd_flop * cfg32["update_epochs"]
+    # what the step's launches EXECUTE (r04u_step_pmc.txt: sum of MfmaFlopsF32 = 21.6 GFLOP at minibatch 1024): forward + a weight
+    # gradient for every layer + an input gradient for every layer but the first (nobody needs d(loss)/d(obs)); the customary
+    # "3 x forward" (22.6 GFLOP) counts a product that is never formed and is kept only as `nominal_3x_forward`
+    step_flop = UPDATE_FLOP_PER_SAMPLE * cfg32["minibatch_size"]
+    uflop = UPDATE_FLOP_PER_SAMPLE * rows * cfg32["update_epochs"]
+    nominal = 3 * rows * fwd_flop * cfg32["update_epochs"]
     graphed = ubox["rs"][1].get("graphed")
     phases["update"] = {"ms": t_upd * 1e3, "minibatch_steps": nmb, "ms_per_minibatch": t_upd / nmb * 1e3,
-                        "gemm_tflops": uflop / t_upd / 1e12, "mfma_peak_tflops": 157.3,
-                        "mfma_frac": uflop / t_upd / 1e12 / 157.3, "dtype": "fp32",
+                        "gemm_flop_per_step": step_flop, "gemm_tflops": uflop / t_upd / 1e12, "mfma_peak_tflops": 157.3,
+                        "mfma_frac": uflop / t_upd / 1e12 / 157.3,
+                        "nominal_3x_forward": {"gemm_flop_per_step": 3 * fwd_flop * cfg32["minibatch_size"],
+                                               "gemm_tflops": nominal / t_upd / 1e12, "mfma_frac": nominal / t_upd / 1e12 / 157.3,
+                                               "note": "counts layer 0's input gradient, which no launch forms: not a rate the "
+                                                       "kernels ran at (rounds 1-4 reported this figure)"},
+                        "dtype": "fp32",
                         "path": type(graphed).__name__ if graphed else "eager: " + str(ubox["rs"][1].get("graph_error")),
                         "what": "10 epochs x 256 minibatches of 1024 samples: forward + backward + global-norm clip + Adam"}
     # ---- configs[4] rehearsal on ONE GPU: the compute side of a rank's minibatch step under a process group (world = 2
@@ -784,7 +799,7 @@ def bench_ppo(args, torch, dev, rank, world, barrier, max_over_ranks):
     rows = NUM_ENVS * NUM_STEPS
     fwd_flop = 2 * 3_677_184                      # 7.354 MFLOP per forward per sample
     roll_flop = 4 * rows * fwd_flop + NUM_ENVS * fwd_flop
-    upd_flop = 3 * rows * fwd_flop * cfg["update_epochs"]
+    upd_flop = UPDATE_FLOP_PER_SAMPLE * rows * cfg["update_epochs"]   # executed: no input gradient for layer 0 (see bench_secondary)
     return {
         "metric": "ppo.py iteration macro-steps/sec at num_envs=8192, num_steps=32, minibatch 1024, 10 epochs (secondary, configs[3])",
         "value": world * rows * iters / elapsed, "unit": "macro-steps/s", "n_gpus": world, "steps": iters, "warmup": 1,
@@ -798,7 +813,9 @@ def bench_ppo(args, torch, dev, rank, world, barrier, max_over_ranks):
                     "gemm_tflops": roll_flop / med["rollout"] / 1e12,
                     "mfma_peak_tflops": 2500.0 if cfg["inference_dtype"] in ("bf16", "fp16") else 157.3},
         "update": {"gemm_tflops": upd_flop / med["update"] / 1e12, "mfma_peak_tflops": 157.3,
-                   "note": "fp32 GEMMs (fwd + 2x bwd), 2560 minibatch steps of 1024 samples, hipGraph-replayed"},
+                   "gemm_flop_per_step": UPDATE_FLOP_PER_SAMPLE * 1024,
+                   "note": "fp32 GEMMs as executed (forward, dW for every layer, dX for every layer but the first), 2560 minibatch "
+                           "steps of 1024 samples, hipGraph-replayed"},
     }
 
 

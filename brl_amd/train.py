@@ -148,7 +148,9 @@ def _weight_delta(a: torch.nn.Module, b) -> float:
         return float(torch.stack([(x - y).abs().max() for x, y in zip(pa, pb)]).max())
 
 
-def train(config, log=print):
+def train(config, log=print, on_rollout=None):
+    """``on_rollout(i, runner_state, traj_batch, roll_out)``: optional observer called right after iteration i's roll_out (tests
+    replay a rank's shard through the oracle from it; the buffers are the loop's own — copy what you keep)."""
     import torch.distributed as dist
 
     import brl_amd
@@ -328,6 +330,8 @@ def train(config, log=print):
         t0 = time.perf_counter()
         runner_state, traj = roll_out(runner_state, opp_params)                                       # ppo.py:467
         torch.cuda.synchronize(); t1 = time.perf_counter()
+        if on_rollout is not None:
+            on_rollout(i, runner_state, traj, roll_out)
         adv, tgt = calc_gae(runner_state, traj)                                                       # ppo.py:471
         torch.cuda.synchronize(); t2 = time.perf_counter()
         runner_state, loss_info = update_step(runner_state, traj, adv, tgt)                           # ppo.py:473

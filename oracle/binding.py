@@ -55,22 +55,35 @@ TABLE_INFO_DTYPE = np.dtype(
 )
 
 
+def build_dir() -> str:
+    """oracle/_build, or oracle/_build_asan under BRL_ORACLE_BUILD=asan (the `make asan` objects: AddressSanitizer + UBSan,
+    loaded into a python started with LD_PRELOAD=libasan.so:libubsan.so — scripts/cpu_sanitize.sh)"""
+    return os.path.join(_HERE, "_build_asan" if os.environ.get("BRL_ORACLE_BUILD") == "asan" else "_build")
+
+
 def lib_path() -> str:
-    return os.path.join(_HERE, "_build", "liboracle.so")
+    return os.path.join(build_dir(), "liboracle.so")
+
+
+def shim_path() -> str:
+    """the oracle behind the C symbols of include/brl_hip.h (oracle/brl_shim.c)"""
+    return os.path.join(build_dir(), "liboracle_brl.so")
 
 
 def build(force: bool = False) -> str:
     """Compile the C oracle with gcc (a few hundred ms)."""
     src = os.path.join(_HERE, "bridge_oracle.c")
     out = lib_path()
-    shim = os.path.join(_HERE, "_build", "liboracle_brl.so")
+    shim = shim_path()
+    asan = os.environ.get("BRL_ORACLE_BUILD") == "asan"
     deps = [src, os.path.join(_HERE, "brl_shim.c"), os.path.join(_HERE, "Makefile"),
             os.path.join(os.path.dirname(_HERE), "include", "brl_hip.h")]
     # (checked here, without starting a process: a test session calls this once per Oracle(), often with the GPU runtime up)
     stale = force or not (os.path.exists(out) and os.path.exists(shim)) or \
         min(os.path.getmtime(out), os.path.getmtime(shim)) < max(os.path.getmtime(d) for d in deps)
     if stale:
-        subprocess.check_call(["make", "-C", _HERE, "--no-print-directory", "-s"] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-C", _HERE, "--no-print-directory", "-s"] + (["asan"] if asan else [])
+                              + (["-B"] if force else []))
     return out
 
 

@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def shim():
     import oracle
     oracle.build()
-    return ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "liboracle_brl.so"))
+    from oracle.binding import shim_path
+    return ctypes.CDLL(shim_path())
 
 
 def test_shim_exports_every_symbol_of_the_header(shim):

@@ -1492,7 +1492,15 @@ def _train_rank(rank, world, port, out_dir, backend="gloo"):
                lut_len=2000, synthetic_lut_files=2, hash_size=100_000, num_eval_envs=128, num_prioritized_envs=64,
                num_eval_step=2, lr=1e-4, ratio_model_zoo=1.0, log_path=out_dir, exp_name="t",   # ONE pool directory: rank 0 saves
                graph_rollout=True)
-    rs, hist = train(cfg, log=lambda *_: None)
+    def keep_first_rollout(i, runner_state, traj, roll_out):
+        """iteration 0's Transition + sub-step actions + final packed state of THIS rank's shard, for the parent's oracle replay"""
+        if i == 0:
+            torch.cuda.synchronize()
+            torch.save({"traj": tuple(x.cpu() for x in traj), "sub_actions": roll_out.sub_actions.cpu(),
+                        "packed": runner_state[2].packed.cpu(), "terminated_count": int(runner_state[4].item()),
+                        "env_offset": runner_state[2].env.env_offset}, os.path.join(out_dir, f"rollout{rank}.pt"))
+
+    rs, hist = train(cfg, log=lambda *_: None, on_rollout=keep_first_rollout)
     flat = torch.cat([p.detach().reshape(-1) for p in rs[0].parameters()]).cpu()
     torch.save((flat, [h["train/total_loss"] for h in hist], type(rs[1].get("graphed")).__name__,
                 getattr(rs[1].get("graphed"), "world", None), torch.cuda.current_device()), os.path.join(out_dir, f"rank{rank}.pt"))
@@ -1501,10 +1509,35 @@ def _train_rank(rank, world, port, out_dir, backend="gloo"):
     dist.destroy_process_group()
 
 
+def _replay_rank_rollout(tmp_path, rank, num_envs=256):
+    """a rank's first rollout of `_train_rank` (its own shard: env_offset = rank * num_envs) replayed through the oracle: the
+    Transition's obs / mask / done / reward, the final packed state and the board count, bit for bit"""
+    import brl_amd
+    from bench import synthetic_lut as bench_lut
+    from brl_amd.bridge_bidding import State
+    from oracle import Oracle
+    d = torch.load(tmp_path / f"rollout{rank}.pt")
+    assert d["env_offset"] == rank * num_envs
+    keys, values = bench_lut(2000, 0)                      # train(): luts[rotation.current], file 0 of the synthetic tables
+    orc = Oracle(keys, values)
+    ref = orc.init_random(num_envs, seed=0, env_offset=rank * num_envs)   # DEFAULTS["seed"] = 0
+    traj = brl_amd.Transition(*d["traj"])
+    want = replay_policy_rollout(orc, ref, traj, d["sub_actions"], 0, env_offset=rank * num_envs)
+    for name in ("obs", "legal_action_mask", "done", "reward"):
+        assert np.array_equal(to_np(getattr(traj, name)), want[name]), f"rank {rank}: {name}"
+    act = to_np(traj.action)
+    assert np.take_along_axis(want["legal_action_mask"], act[..., None].astype(np.int64), 2).all()
+    assert d["terminated_count"] == want["terminated_count"] > 0
+    env = brl_amd.BridgeBidding(lut=(keys, values))
+    assert_state_equal(State(env, d["packed"].to(env.device)), ref, where=f"rank {rank}: packed state after its first rollout")
+    return to_np(traj.obs)
+
+
 def test_ppo_loop_two_ranks(tmp_path):
-    """BASELINE config 5 at toy size: the ppo.py loop on two ranks (own env shard each via env_offset, gradient all-reduce
-    inside FusedMinibatch's bucketed graphs, the pool's opponent index broadcast from rank 0; gloo on this one-GPU box,
-    RCCL on a node): both ranks end with IDENTICAL parameters although their shards differ."""
+    """BASELINE config 5 at toy size: the ppo.py loop on two ranks (own env shard each via env_offset, ONE all-reduce of the flat
+    gradient between FusedMinibatch's graphs — the default "flat" form —, the pool's opponent index broadcast from rank 0; gloo on
+    this one-GPU box, RCCL on a node): both ranks end with IDENTICAL parameters although their shards differ — and each rank's
+    first rollout IS its shard: replayed through the oracle at env_offset = rank * num_envs."""
     import socket
     import torch.multiprocessing as mp
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
@@ -1514,11 +1547,13 @@ def test_ppo_loop_two_ranks(tmp_path):
     assert len(r0[1]) == 3 and all(np.isfinite(x) for x in r0[1] + r1[1])
     assert r0[1] != r1[1]                      # different shards: different losses ...
     assert torch.equal(r0[0], r1[0])           # ... same parameters (all-reduced gradients)
+    obs0, obs1 = _replay_rank_rollout(tmp_path, 0), _replay_rank_rollout(tmp_path, 1)
+    assert not np.array_equal(obs0, obs1)
 
 
 def test_ppo_loop_two_ranks_rccl(tmp_path):
-    """The same loop over RCCL ("nccl"), one GPU per rank — BASELINE configs[4]'s collective path (bucketed gradient
-    all-reduces behind FusedMinibatch's graph segments, opponent-index broadcast, summed counters) on real xGMI links.
+    """The same loop over RCCL ("nccl"), one GPU per rank — BASELINE configs[4]'s collective path (the flat gradient's
+    all-reduce between FusedMinibatch's graphs, opponent-index broadcast, summed counters) on real xGMI links.
     SKIPPED with a reason on a box with fewer than 2 GPUs."""
     _two_gpus_or_skip()
     import socket
@@ -1528,7 +1563,8 @@ def test_ppo_loop_two_ranks_rccl(tmp_path):
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert r0[2] == "FusedMinibatch" and r0[3] == 2 and (r0[4], r1[4]) == (0, 1)   # one device per rank
     assert len(r0[1]) == 3 and all(np.isfinite(x) for x in r0[1] + r1[1]) and r0[1] != r1[1]
-    assert torch.equal(r0[0], r1[0])
+    assert torch.equal(r0[0], r1[0])           # post-run cross-rank parameter equality (a mis-captured collective would break it)
+    _replay_rank_rollout(tmp_path, 1)
 
 
 @pytest.mark.parametrize("infer", [None, "bf16"])   # None = the reference's fp32 forwards (the default), bf16 = the opt-in path
@@ -2345,7 +2381,8 @@ def test_mlp_forward_rows_matches_float64(activation, model, n, m):
     import os
     import oracle as oracle_pkg
     oracle_pkg.build()
-    shim = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "liboracle_brl.so"))
+    from oracle.binding import shim_path
+    shim = C.CDLL(shim_path())
     cpu = fp.init(7)
     r = _capi.MlpRef()
     r.nlayers, r.act, r.in_features, r.hidden = len(cpu.body), 0 if activation == "relu" else 1, 480, 1024
