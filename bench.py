@@ -651,9 +651,9 @@ def bench_secondary(torch, dev):
                         "dtype": "fp32",
                         "path": type(graphed).__name__ if graphed else "eager: " + str(ubox["rs"][1].get("graph_error")),
                         "what": "10 epochs x 256 minibatches of 1024 samples: forward + backward + global-norm clip + Adam"}
-    # ---- configs[4] rehearsal on ONE GPU: the compute side of a rank's minibatch step under a process group (world = 2
-    # semantics: graph segments, sums of partials as their own launch, grad_scale), the all-reduce replaced by a no-op with
-    # the same stream ordering (side stream waits for the segment, the Adam graph waits for the side stream)
+    # ---- configs[4] rehearsal on ONE GPU: the compute side of a rank's minibatch step under a process group (world = 8
+    # geometry: buckets, slices, the norm's partials, grad_scale), every collective replaced by a no-op with the same stream
+    # ordering inside the step's graph
     try:
         out["config4_rehearsal"] = rehearse_multirank(torch, dev, cfg32, fp, traj32, adv, tgt, phases["update"]["ms_per_minibatch"])
     except Exception as e:
@@ -698,34 +698,57 @@ def bench_secondary(torch, dev):
 
 
 def rehearse_multirank(torch, dev, cfg, fp, traj, adv, tgt, single_ms):
-    """ms per minibatch step of FusedMinibatch as a rank of a multi-GPU job runs it, measured on one GPU: both all-reduce
-    modes of config["grad_allreduce"], 256 steps (one epoch of 8192 x 32 at minibatch 1024), collectives = no-ops that keep
-    the event edges of an asynchronous RCCL collective (what crosses xGMI is NOT in this number — DESIGN §7 adds it)."""
+    """ms per minibatch step of FusedMinibatch as ONE RANK OF EIGHT runs it (configs[4]'s geometry: five buckets x eight slices),
+    measured on one GPU: both forms of config["grad_allreduce"], 256 steps (one epoch of 8192 x 32 at minibatch 1024), every
+    collective a no-op that keeps the stream edges of an asynchronous RCCL collective and sits INSIDE the eight-step hipGraph like
+    the real ones (RCCL's collectives record into a graph: profiles/r05/r05a_rccl_capture_probe.txt).  What crosses xGMI is NOT in
+    this number — DESIGN §7 adds it; the parameters it leaves are not a real update (nothing is reduced or gathered)."""
     from brl_amd.roll_out import Transition
     from brl_amd.update import FusedMinibatch, make_optimizer
     rows = NUM_ENVS * NUM_STEPS
     flat = Transition(*[x.reshape((rows,) + x.shape[2:]) for x in traj])
     adv_f, tgt_f = adv.reshape(rows), tgt.reshape(rows)
     side = torch.cuda.Stream()
+    world, rank = 8, 3
 
     class _Work:
         def wait(self):
             torch.cuda.current_stream().wait_stream(side)
 
-    def noop_allreduce(t, async_op):
-        cur = torch.cuda.current_stream()
-        side.wait_stream(cur)          # the collective starts behind the segment that produced its bucket
-        if async_op:
-            return _Work()
-        cur.wait_stream(side)          # a blocking collective: the next graph waits for it
+    class NoopCollectives:
+        capturable = True
 
-    res = {"what": "one rank's minibatch step under world = 2 semantics on one GPU, all-reduce = no-op with the same stream "
-                   "ordering; 256 steps, median of 3; ring traffic per step and rank at world 8: 2 * 7/8 * 14.7 MB = 25.8 MB",
+        def __init__(self):
+            self.rank, self.world, self.calls = rank, world, 0
+
+        def _edge(self, async_op):
+            self.calls += 1
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)          # the collective starts behind the kernels that produced its bucket
+            if async_op:
+                return _Work()
+            cur.wait_stream(side)          # a blocking collective: what follows waits for it
+            return None
+
+        def all_reduce(self, t, async_op):
+            return self._edge(async_op)
+
+        def reduce_scatter(self, out, inp, async_op):
+            return self._edge(async_op)
+
+        def all_gather(self, out, inp, async_op):
+            return self._edge(async_op)
+
+    res = {"what": "one rank's minibatch step with world = 8 geometry on one GPU, collectives = no-ops with an asynchronous "
+                   "collective's stream edges, captured inside the eight-step hipGraph; 256 steps, median of 3; ring traffic per "
+                   "step and rank at world 8: 2 * 7/8 * 14.7 MB = 25.8 MB in both forms",
            "single_rank_ms_per_minibatch": single_ms}
-    for mode in ("flat", "bucketed"):
+    for mode in ("sharded", "flat"):
         net = fp.init(0, device=dev)
         opt = make_optimizer(cfg, net)["opt"]
-        fm = FusedMinibatch(dict(cfg, grad_allreduce=mode), net, opt, 1024, dev, world=2, collective=noop_allreduce)
+        co = NoopCollectives()
+        fm = FusedMinibatch(dict(cfg, grad_allreduce=mode), net, opt, 1024, dev, world=world, collective=co)
+        per_step = sum(1 for item in fm.program if item[0] == "c")
         ts = []
         for rep in range(4):
             perms = [torch.randperm(rows, device=dev)]
@@ -737,8 +760,9 @@ def rehearse_multirank(torch, dev, cfg, fp, traj, adv, tgt, single_ms):
             ts.append(time.perf_counter() - t0)
             fm.end_update()
         t = float(np.median(ts[1:]))
-        res[mode] = {"ms_per_minibatch": t / (rows // 1024) * 1e3, "graph_replays_per_step": 1 if mode == "flat" else len(fm.segs),
-                     "collectives_per_step": 1 if mode == "flat" else len([b for b in fm.buckets if b is not None]),
+        res[mode] = {"ms_per_minibatch": t / (rows // 1024) * 1e3, "graph_replays_per_step": 1.0 / fm.multi if fm.in_graph else None,
+                     "collectives_per_step": per_step, "collectives_inside_the_graph": bool(fm.in_graph),
+                     "adam_sweep_fraction": 1.0 / world if mode == "sharded" else 1.0,
                      "overhead_vs_single_rank_ms": t / (rows // 1024) * 1e3 - single_ms}
         del fm, net, opt
     return res

@@ -52,6 +52,12 @@ class MlpRef(C.Structure):
                 ("w", _vp * 8), ("b", _vp * 8), ("actor_w", _vp), ("actor_b", _vp), ("critic_w", _vp), ("critic_b", _vp)]
 
 
+class ShardGeom(C.Structure):
+    """brl_shard_geom: the bucketed flat buffers of the multi-rank PPO step (offsets / slice lengths in floats)"""
+    _fields_ = [("nbuckets", C.c_int32), ("world", C.c_int32), ("nsub", C.c_int32), ("reserved", C.c_int32),
+                ("off", C.c_int64 * 12), ("len", C.c_int64 * 12)]
+
+
 EVAL_COUNTS = 231  # BRL_EVAL_COUNTS
 
 
@@ -109,17 +115,10 @@ def lib() -> C.CDLL:
         "brl_eval_reduce": [_vp, i64, C.POINTER(TableInfoPtrs), C.POINTER(TableInfoPtrs), _vp, _vp, _vp, _vp],
         "brl_ppo_loss": [i32, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, i64, f32, f32, f32, i32, i32, _vp, _vp, _vp, _vp, _vp],
         "brl_ppo_stats": [i32, _vp, i64, _vp, f32, f32, _vp, _vp],
-        "brl_ppo_loss_heads": [i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, i64, f32, f32, f32, i32, i32, _vp, _vp, _vp, _vp],
-        "brl_mb_gather": [i32, C.POINTER(TransitionPtrs), _vp, _vp, _vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-        "brl_relu_bwd_colsum": [i32, _vp, _vp, i64, i64, i64, _vp, _vp, _vp],
-        "brl_adam_clip": [i32, _vp, _vp, _vp, _vp, i64, _vp, f32, _vp, f32, f32, f32, f32, f32, _vp, _vp, _vp, _vp],
-        "brl_ppo_heads_loss": [i32, _vp, i64, _vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, i64, f32, f32, f32, i32, i32, i32,
-                               _vp, _vp, _vp, _vp, _vp],
         "brl_ppo_heads_loss_split": [i32, _vp, i64, _vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, i64, f32, f32, f32, i32, i32, i32, _vp, _vp, _vp, _vp, _vp, i32, _vp],
         "brl_ppo_heads_bwd": [i32, _vp, _vp, i64, _vp, i64, i64, i32, i32, _vp, _vp, _vp, _vp, _vp, _vp, i64, _vp, _vp, _vp, _vp],
         "brl_ppo_stats_rows": [i32, _vp, _vp, i64, i64, f32, f32, f32, _vp, _vp],
         "brl_mb_gather_bind": [i32, C.POINTER(TransitionPtrs), _vp, _vp, _vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, i64, _vp, _vp],
-        "brl_adam_clip_gather": [i32, _vp, _vp, _vp, _vp, i64, _vp, f32, _vp, f32, f32, f32, f32, f32, _vp, _vp, _vp, _vp, i64, _vp],
         "brl_adam_clip_fin_gather": [i32, _vp, _vp, _vp, _vp, i64, _vp, f32, _vp, f32, f32, f32, f32, _vp, i64, _vp, _vp, _vp, i64,
                                      i32, _vp, _vp, _vp, _vp, _vp],
         "brl_mb_gather_dev": [i32, _vp, i64, _vp],
@@ -130,17 +129,10 @@ def lib() -> C.CDLL:
                                         _vp, _vp, _vp, _vp],
         "brl_bias_finalize_ex": [i32, i32, _vp, _vp, _vp, _vp, _vp],
         "brl_mlp_gemm": [i32, i32, i32, _vp, i64, _vp, i64, _vp, i64, i64, i64, i64, i32, _vp, _vp, i64, _vp, _vp, _vp],
-        "brl_adam_clip_fin_gather_defer": [i32, _vp, _vp, _vp, _vp, i64, _vp, f32, _vp, f32, f32, f32, f32, _vp, i64, _vp, _vp, _vp, i64,
-                                           i32, _vp, _vp, _vp, _vp, i64, i64, _vp, _vp],
-        "brl_mlp_gemm_adam": [i32, _vp, i64, _vp, i64, _vp, i64, i64, i64, i64, i32, _vp, _vp, _vp, _vp, _vp, i64, i64, _vp, i32, _vp, f32,
-                              _vp, f32, f32, f32, f32, f32, _vp, _vp],
-        "brl_adam_apply_range": [i32, _vp, _vp, _vp, _vp, i64, i64, _vp, i32, _vp, f32, _vp, f32, f32, f32, f32, f32, _vp, i32, _vp],
-        "brl_mlp_gemm_bwd_pair": [i32, _vp, i64, _vp, i64, _vp, i64, _vp, i64, _vp, i64, i64, i64, i64, i32, _vp, _vp, _vp, _vp, i64, i64, i32,
-                                  _vp, _vp, _vp, _vp, i64, _vp, _vp, _vp, _vp],
-        "brl_mlp_gemm_fwd_heads": [i32, _vp, i64, _vp, i64, _vp, i64, i64, i64, i64, i32, _vp, _vp, i64, _vp, i32, _vp],
-        "brl_ppo_heads_loss_parts": [i32, _vp, _vp, i32, _vp, _vp, _vp, _vp, _vp, _vp, i64, f32, f32, f32, i32, i32, i32, _vp, _vp, _vp,
-                                     _vp, _vp],
         "brl_mlp_forward_rows": [i32, C.POINTER(MlpRef), _vp, _vp, i64, _vp, i64, _vp, i64, _vp],
+        "brl_adam_shard_norm": [i32, _vp, C.POINTER(ShardGeom), i32, i32, f32, _vp, _vp, _vp, _vp],
+        "brl_adam_shard_apply": [i32, _vp, _vp, _vp, _vp, C.POINTER(ShardGeom), i32, i32, _vp, _vp, f32, _vp, f32, f32, f32, f32, f32, _vp,
+                                 _vp, i64, _vp],
         "brl_mlp_gemm_dh_heads_dw": [i32, _vp, i64, _vp, i64, _vp, i64, i64, i64, i64, i32, _vp, i64, _vp, _vp, _vp, i64, i64, i64, i32,
                                      _vp, _vp, _vp, _vp, i64, _vp, _vp, _vp, _vp],
     }
@@ -155,12 +147,9 @@ def lib() -> C.CDLL:
 EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_destroy", "brl_set_rng",
            "brl_init_random", "brl_init_from_deals", "brl_step", "brl_observe", "brl_get_fields",
            "brl_rollout_random", "brl_policy_step", "brl_policy_step_at", "brl_obs_cast", "brl_obs_cast_rows", "brl_live_index", "brl_linear_act", "brl_linear_act_heads", "brl_gae", "brl_imp_reward", "brl_duplicate_step",
-           "brl_eval_step", "brl_eval_reduce", "brl_ppo_loss", "brl_ppo_stats", "brl_ppo_loss_heads", "brl_mb_gather",
-           "brl_relu_bwd_colsum", "brl_adam_clip", "brl_policy_step_ex",
-           "brl_eval_step_team", "brl_rollout_random_gae", "brl_ppo_heads_loss", "brl_ppo_heads_loss_split", "brl_ppo_heads_bwd", "brl_ppo_stats_gram",
-           "brl_act_bwd_colsum", "brl_act_bwd_colsum_heads_dw", "brl_bias_finalize_ex", "brl_ppo_stats_rows", "brl_mb_gather_bind", "brl_mb_gather_dev", "brl_ppo_illegal_grad", "brl_adam_clip_gather", "brl_adam_clip_fin_gather", "brl_mlp_gemm", "brl_mlp_gemm_dh_heads_dw", "brl_adam_clip_fin_gather_defer", "brl_mlp_gemm_adam",
-           "brl_adam_apply_range", "brl_mlp_gemm_bwd_pair", "brl_mlp_gemm_fwd_heads",
-           "brl_ppo_heads_loss_parts", "brl_mlp_forward_rows"]
+           "brl_eval_step", "brl_eval_reduce", "brl_ppo_loss", "brl_ppo_stats", "brl_policy_step_ex",
+           "brl_eval_step_team", "brl_rollout_random_gae", "brl_ppo_heads_loss_split", "brl_adam_shard_norm", "brl_adam_shard_apply", "brl_ppo_heads_bwd", "brl_ppo_stats_gram",
+           "brl_act_bwd_colsum", "brl_act_bwd_colsum_heads_dw", "brl_bias_finalize_ex", "brl_ppo_stats_rows", "brl_mb_gather_bind", "brl_mb_gather_dev", "brl_ppo_illegal_grad", "brl_adam_clip_fin_gather", "brl_mlp_gemm", "brl_mlp_gemm_dh_heads_dw", "brl_mlp_forward_rows"]
 
 
 def check(rc: int) -> None:

@@ -20,3 +20,14 @@ def quiet_gc():
     finally:
         if was_enabled:
             gc.enable()
+
+
+def graph_kwargs() -> dict:
+    """``torch.cuda.graph`` keyword arguments for a capture of this package: ``capture_error_mode="thread_local"`` ONLY while an
+    NCCL / RCCL process group lives — its watchdog thread queries events beside the capturing thread, which the default
+    ("global") mode reports as a capture error.  Every other capture (no process group, gloo) keeps the default, where an unsafe
+    call from ANY thread fails the capture instead of going unnoticed."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        return {"capture_error_mode": "thread_local"}
+    return {}

@@ -1,9 +1,7 @@
 // adam_role.hpp — clip_by_global_norm + Adam on a RANGE of the flat fp32 buffers (ppo.py:195-211: optax.chain(clip_by_global_norm,
-// adam); torch.optim.Adam's arithmetic), as a device function a kernel can give to its surplus workgroups.  The sweep is
-// HBM-bound (7 floats moved per parameter) and, once the step's norm partials exist, depends on nothing else: the part of it that
-// the NEXT step's forward pass does not need at once leaves the step's dependency chain and rides, layer by layer, in the forward
-// GEMM launches of the next step (csrc/brl_mlp_gemm.hip: the layer whose weights a launch updates is the layer the NEXT launch
-// multiplies with).  Every block re-adds the norm partials in the same fixed order: deterministic, no cross-block hand-off.
+// adam); torch.optim.Adam's arithmetic) as a device function: the whole buffer (single rank, k_adam_apply) or one slice of one
+// bucket (k_shard_apply).  The sweep is HBM-bound (7 floats moved per parameter).  Every block re-adds the norm partials in the
+// same fixed order: deterministic, no cross-block hand-off.
 #pragma once
 #include <stdint.h>
 
@@ -17,7 +15,6 @@ struct AdamRange {
   const float *step;           // Adam's step count t (already advanced by the norm launch)
   const float *lr_dev;         // device-resident learning rate, or NULL: lr
   float lr, b1, b2, eps, max_norm, gscale;
-  const int32_t *pending;      // NULL, or: the range is swept only where *pending != 0 (no deferred step before an update's first)
   float *norm_out;             // NULL, or: block 0 stores the gradient norm
 };
 
@@ -29,7 +26,6 @@ __device__ __forceinline__ float adam_wave_sum(float v) {   // (sum over the 64 
 
 // block `b` of `nb` blocks of 256 threads sweeps its share of the range.  red: 8 floats of LDS.
 __device__ __forceinline__ void adam_range_block(const AdamRange &A, const int b, const int nb, float *red) {
-  if (A.pending != nullptr && *A.pending == 0) return;
   const int tid = (int)threadIdx.x;
   {
     float s = 0.0f;

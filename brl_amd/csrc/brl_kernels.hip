@@ -1760,7 +1760,7 @@ static int fail(int code, const char *fmt, const char *detail) { return brl_fail
 #include "abi_common.hpp"   // HIP_TRY, NEED
 
 extern "C" const char *brl_last_error(void) { return g_err; }
-extern "C" int brl_version(void) { return 4; }   // include/brl_hip.h: the round the exported set last changed in
+extern "C" int brl_version(void) { return 5; }   // include/brl_hip.h: the round the exported set last changed in
 
 static inline Rng rng_of(const brl_handle *h) { return Rng{(uint32_t)h->seed, (uint32_t)(h->seed >> 32)}; }
 static inline LutRef lut_of(const brl_handle *h) { return LutRef{h->lut_keys, h->lut_values, (uint32_t)h->lut_len, h->lut_hands}; }

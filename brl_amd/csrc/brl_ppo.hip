@@ -228,7 +228,7 @@ __global__ __launch_bounds__(512) void k_ppo_stats(const float *partials, int64_
   }
 }
 
-#include "ppo_update.hpp"  // k_mb_gather, k_relu_bwd_colsum, k_adam_norm / k_adam_apply
+#include "ppo_update.hpp"  // k_mb_gather_dev, k_relu_bwd_tiles4, k_bias_finalize, k_adam_norm_fin / k_adam_apply, k_shard_norm / k_shard_apply
 #include "ppo_heads.hpp"   // k_heads_loss, k_heads_bwd, k_ppo_stats2: the 39-column head products and what hangs on them
 
 // =====================================================================================
@@ -247,36 +247,6 @@ extern "C" int brl_ppo_loss(int device, const float *logits, int64_t logits_stri
   PpoArgs A{logits, logits_stride, value, mask, action, old_value, old_log_prob, gae, targets, batch, clip_eps, vf_coef,
             ent_coef, masked, value_clipping, dlogits, dvalue, partials, illegal_probs, 1, BRL_NUM_ACTIONS, 1};
   hipLaunchKernelGGL(k_ppo_loss, dim3(thread_grid(batch, 4)), dim3(256), 0, (hipStream_t)stream, A);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
-}
-
-extern "C" int brl_ppo_loss_heads(int device, const float *heads, const uint8_t *mask, const int32_t *action,
-                                  const float *old_value, const float *old_log_prob, const float *gae, const float *targets,
-                                  int64_t batch, float clip_eps, float vf_coef, float ent_coef, int masked, int value_clipping,
-                                  float *dheads, float *partials, float *illegal_probs, void *stream) {
-  NEED(batch > 0, "batch");
-  NEED(heads && mask && action && old_value && old_log_prob && gae && targets, "NULL input array");
-  NEED(dheads && partials, "NULL output array");
-  HIP_TRY(hipSetDevice(device));
-  constexpr int64_t HS = BRL_NUM_ACTIONS + 1;  // [batch, 39]: 38 logits, then the value
-  PpoArgs A{heads, HS, heads + BRL_NUM_ACTIONS, mask, action, old_value, old_log_prob, gae, targets, batch, clip_eps, vf_coef,
-            ent_coef, masked, value_clipping, dheads, dheads + BRL_NUM_ACTIONS, partials, illegal_probs, HS, HS, HS};
-  hipLaunchKernelGGL(k_ppo_loss, dim3(thread_grid(batch, 4)), dim3(256), 0, (hipStream_t)stream, A);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
-}
-
-extern "C" int brl_mb_gather(int device, const brl_transition *flat, const float *adv, const float *targets, const int64_t *perm,
-                             const int32_t *mb_index, int64_t mbs, float *x0, uint8_t *mask, int32_t *action, float *old_value,
-                             float *old_log_prob, float *gae_out, float *targets_out, void *stream) {
-  NEED(flat && flat->obs && flat->legal_action_mask && flat->action && flat->value && flat->log_prob, "trajectory");
-  NEED(adv && targets && perm && mb_index && mbs > 0, "adv / targets / perm / mb_index / mbs");
-  NEED(x0 && mask && action && old_value && old_log_prob && gae_out && targets_out, "NULL output array");
-  HIP_TRY(hipSetDevice(device));
-  GatherArgs A{flat->obs, flat->legal_action_mask, flat->action, flat->value, flat->log_prob, adv, targets, perm, mb_index, mbs,
-               x0, mask, action, old_value, old_log_prob, gae_out, targets_out, (int64_t)1 << 62};
-  hipLaunchKernelGGL(k_mb_gather, dim3((unsigned)mbs), dim3(128), 0, (hipStream_t)stream, A);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }
@@ -302,26 +272,6 @@ extern "C" int brl_mb_gather_dev(int device, const void *args_dev, int64_t mbs, 
   NEED(args_dev && mbs > 0, "args_dev / mbs");
   HIP_TRY(hipSetDevice(device));
   hipLaunchKernelGGL(k_mb_gather_dev, dim3((unsigned)mbs), dim3(128), 0, (hipStream_t)stream, (const GatherArgs *)args_dev);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
-}
-
-extern "C" int brl_relu_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, float *db,
-                                   float *scratch, void *stream) {
-  NEED(dh && scratch && rows > 0 && cols > 0 && ld >= cols, "dh / scratch / rows / cols / ld");
-  HIP_TRY(hipSetDevice(device));
-  const int64_t tr = relu_tile_rows(cols, ld), tiles = (rows + tr - 1) / tr;
-  if (tr == 16)
-    hipLaunchKernelGGL(k_relu_bwd_tiles4, dim3((unsigned)((cols + 255) / 256), (unsigned)tiles), dim3(256), 0, (hipStream_t)stream,
-                       dh, h, rows, cols, ld, scratch);
-  else
-    hipLaunchKernelGGL(k_relu_bwd_tiles, dim3((unsigned)((cols + 63) / 64), (unsigned)tiles), dim3(256), 0, (hipStream_t)stream, dh,
-                       h, rows, cols, ld, scratch);
-  if (db != nullptr) {
-    BiasSegs S{};
-    S.n = 1; S.tiles[0] = tiles; S.partials[0] = scratch; S.cols[0] = cols; S.db[0] = db;
-    hipLaunchKernelGGL(k_bias_finalize, dim3((unsigned)((cols + 63) / 64), 1), dim3(256), 0, (hipStream_t)stream, S);
-  }
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }
@@ -384,26 +334,6 @@ extern "C" int brl_bias_finalize_ex(int device, int nseg, const float *const *pa
   return BRL_OK;
 }
 
-extern "C" int brl_ppo_heads_loss(int device, const float *h, int64_t ldh, const float *head_w, const float *head_b, int64_t hidden,
-                                  const uint8_t *mask, const int32_t *action, const float *old_value, const float *old_log_prob,
-                                  const float *gae, const float *targets, int64_t batch, float clip_eps, float vf_coef,
-                                  float ent_coef, int masked, int value_clipping, int reward_scaling, float *heads_out,
-                                  float *dheads, float *partials, float *gram_partials, void *stream) {
-  NEED(batch > 0 && hidden > 0 && hidden % 16 == 0 && ldh >= hidden && ldh % 4 == 0, "batch / hidden (a multiple of 16) / ldh");
-  NEED(h && head_w && head_b && mask && action && old_value && old_log_prob && gae && targets, "NULL input array");
-  NEED(dheads && partials, "NULL output array");
-  HIP_TRY(hipSetDevice(device));
-  constexpr int64_t HS = BRL_NUM_ACTIONS + 1;
-  HeadsLossArgs A{};
-  A.h = h; A.ldh = ldh; A.Wh = head_w; A.bh = head_b; A.H = (int)hidden;
-  A.P = PpoArgs{nullptr, HS, nullptr, mask, action, old_value, old_log_prob, gae, targets, batch, clip_eps, vf_coef,
-                ent_coef, masked, value_clipping, dheads, dheads + BRL_NUM_ACTIONS, partials, nullptr, HS, HS, HS};
-  A.heads_out = heads_out; A.gram_partials = gram_partials; A.reward_scaling = reward_scaling;
-  hipLaunchKernelGGL(k_heads_loss, dim3((unsigned)((batch + HD_ROWS - 1) / HD_ROWS)), dim3(HD_WAVES * 64), 0, (hipStream_t)stream, A);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
-}
-
 extern "C" int brl_ppo_heads_loss_split(int device, const float *h, int64_t ldh, const float *head_w, const float *head_b,
                                         int64_t hidden, const uint8_t *mask, const int32_t *action, const float *old_value,
                                         const float *old_log_prob, const float *gae, const float *targets, int64_t batch,
@@ -425,29 +355,6 @@ extern "C" int brl_ppo_heads_loss_split(int device, const float *h, int64_t ldh,
                 ent_coef, masked, value_clipping, dheads, dheads + BRL_NUM_ACTIONS, partials, nullptr, HS, HS, HS};
   A.heads_out = heads_out; A.gram_partials = gram_partials; A.reward_scaling = reward_scaling;
   A.parts = head_parts; A.nparts = ksplit; A.part_stride = batch * HS;
-  hipLaunchKernelGGL(k_heads_loss, dim3((unsigned)((batch + HD_ROWS - 1) / HD_ROWS)), dim3(HD_WAVES * 64), 0, (hipStream_t)stream, A);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
-}
-
-// brl_ppo_heads_loss_split's second launch alone: the partial products come from elsewhere (brl_mlp_gemm_fwd_heads: the last
-// hidden layer's forward launch leaves one per 64-column tile)
-extern "C" int brl_ppo_heads_loss_parts(int device, const float *head_b, const float *head_parts, int nparts, const uint8_t *mask,
-                                        const int32_t *action, const float *old_value, const float *old_log_prob, const float *gae,
-                                        const float *targets, int64_t batch, float clip_eps, float vf_coef, float ent_coef, int masked,
-                                        int value_clipping, int reward_scaling, float *heads_out, float *dheads, float *partials,
-                                        float *gram_partials, void *stream) {
-  NEED(batch > 0 && head_b && head_parts && mask && action && old_value && old_log_prob && gae && targets, "NULL input array / batch");
-  NEED(dheads && partials, "NULL output array");
-  NEED(nparts >= 1 && nparts <= HD_MAX_PARTS, "nparts (1..32)");
-  HIP_TRY(hipSetDevice(device));
-  constexpr int64_t HS = BRL_NUM_ACTIONS + 1;
-  HeadsLossArgs A{};
-  A.h = nullptr; A.ldh = 0; A.Wh = nullptr; A.bh = head_b; A.H = 0;
-  A.P = PpoArgs{nullptr, HS, nullptr, mask, action, old_value, old_log_prob, gae, targets, batch, clip_eps, vf_coef,
-                ent_coef, masked, value_clipping, dheads, dheads + BRL_NUM_ACTIONS, partials, nullptr, HS, HS, HS};
-  A.heads_out = heads_out; A.gram_partials = gram_partials; A.reward_scaling = reward_scaling;
-  A.parts = head_parts; A.nparts = nparts; A.part_stride = batch * HS;
   hipLaunchKernelGGL(k_heads_loss, dim3((unsigned)((batch + HD_ROWS - 1) / HD_ROWS)), dim3(HD_WAVES * 64), 0, (hipStream_t)stream, A);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
@@ -513,103 +420,16 @@ extern "C" int brl_ppo_stats_rows(int device, const float *stat_sums, const floa
   return BRL_OK;
 }
 
-static AdamRange adam_range(float *p, const float *g, float *m, float *v, int64_t lo, int64_t hi, const float *scratch, int npartials,
-                            const float *step, float lr, const float *lr_dev, float beta1, float beta2, float eps, float max_norm,
-                            float grad_scale, const int32_t *pending, float *norm_out) {
-  AdamRange R{};
-  R.p = p; R.g = g; R.m = m; R.v = v; R.lo4 = lo >> 2; R.hi4 = hi >> 2; R.partials = scratch; R.npartials = npartials; R.step = step;
-  R.lr_dev = lr_dev; R.lr = lr; R.b1 = beta1; R.b2 = beta2; R.eps = eps; R.max_norm = max_norm; R.gscale = grad_scale;
-  R.pending = pending; R.norm_out = norm_out;
-  return R;
-}
-
-// [defer_lo, defer_hi) (floats, multiples of 4; empty: nothing deferred): the part of the sweep this call leaves to
-// brl_mlp_gemm_adam / brl_adam_apply_range; *pending is then set to 1 by the apply launch
-static int adam_clip_impl(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
-                          const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale,
-                          float *scratch, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t gather_rows, void *stream,
-                          const BiasSegs *fin = nullptr, int64_t tail_lo = 0, const FinBlocks *fb = nullptr, int64_t defer_lo = 0,
-                          int64_t defer_hi = 0, int32_t *pending = nullptr) {
-  NEED(p && g && m && v && step && scratch && n > 0 && n % 4 == 0, "p / g / m / v / step / scratch / n (a multiple of 4)");
-  NEED(!gather_args || (mb_index && gather_rows > 0), "gather_args needs mb_index and the minibatch size");
-  NEED(defer_lo % 4 == 0 && defer_hi % 4 == 0 && defer_lo >= 0 && defer_lo <= defer_hi && defer_hi <= n, "deferred range");
-  NEED(defer_lo == defer_hi || pending, "a deferred range needs the pending flag");
-  HIP_TRY(hipSetDevice(device));
-  int npartials = ADAM_BLOCKS;
-  if (fin != nullptr) {   // the finalize launch rides along: see k_adam_norm_fin
-    npartials += fb->off[fin->n];
-    hipLaunchKernelGGL(k_adam_norm_fin, dim3((unsigned)npartials), dim3(ADAM_THREADS), 0, (hipStream_t)stream, g, n, grad_scale, scratch,
-                       step, mb_index, *fin, tail_lo, *fb);
-  } else {
-    hipLaunchKernelGGL(k_adam_norm, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, g, n, grad_scale, scratch, step, mb_index);
-  }
-  const unsigned extra = gather_args ? (unsigned)((gather_rows + 1) / 2) : 0u;
-  // the sweep's blocks are sized like the undivided launch's (n / 4 / ADAM_BLOCKS float4s each), per range
-  const int64_t per = (n / 4 + ADAM_BLOCKS - 1) / ADAM_BLOCKS;
-  const int64_t len1 = (defer_lo == defer_hi) ? n : defer_lo, len2 = (defer_lo == defer_hi) ? 0 : n - defer_hi;
-  const int nb1 = (int)((len1 / 4 + per - 1) / per), nb2 = (int)((len2 / 4 + per - 1) / per);
-  const AdamRange R1 = adam_range(p, g, m, v, 0, len1, scratch, npartials, step, lr, lr_dev, beta1, beta2, eps, max_norm, grad_scale, nullptr, norm_out);
-  const AdamRange R2 = adam_range(p, g, m, v, defer_hi, n, scratch, npartials, step, lr, lr_dev, beta1, beta2, eps, max_norm, grad_scale, nullptr, nullptr);
-  hipLaunchKernelGGL(k_adam_apply, dim3((unsigned)(nb1 + nb2) + extra), dim3(ADAM_THREADS), 0, (hipStream_t)stream, R1, R2, nb1, nb2,
-                     (const GatherArgs *)gather_args, (defer_lo == defer_hi) ? (int32_t *)nullptr : pending);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
-}
-
-extern "C" int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
-                             const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale,
-                             float *scratch, int32_t *mb_index, float *norm_out, void *stream) {
-  return adam_clip_impl(device, p, g, m, v, n, step, lr, lr_dev, beta1, beta2, eps, max_norm, grad_scale, scratch, mb_index, norm_out,
-                        nullptr, 0, stream);
-}
-
-extern "C" int brl_adam_clip_gather(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
-                                    const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale,
-                                    float *scratch, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs,
-                                    void *stream) {
-  NEED(gather_args != nullptr, "gather_args");
-  return adam_clip_impl(device, p, g, m, v, n, step, lr, lr_dev, beta1, beta2, eps, max_norm, grad_scale, scratch, mb_index, norm_out,
-                        gather_args, mbs, stream);
-}
-
+// clip_by_global_norm + Adam of the whole flat buffers, single rank: the norm launch (which also finishes the sums of partials,
+// see k_adam_norm_fin) and the sweep (+ the NEXT minibatch's gather as extra workgroups)
 extern "C" int brl_adam_clip_fin_gather(int device, float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
                                         const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float *scratch,
                                         int64_t scratch_len, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs,
                                         int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles,
                                         float *const *out, void *stream) {
   NEED(nseg >= 1 && nseg <= BIAS_MAX_SEGS && partials && cols && tiles && out, "nseg / partials / cols / tiles / out");
-  NEED(g != nullptr && n > 0, "g / n");
-  BiasSegs S{};
-  S.n = nseg;
-  int64_t maxc = 0, covered = 0;
-  const float *lo = g + n;
-  for (int i = 0; i < nseg; i++) {
-    NEED(partials[i] && out[i] && cols[i] > 0 && tiles[i] > 0, "segment");
-    NEED(out[i] >= g && out[i] + cols[i] <= g + n, "segment outputs must lie inside the gradient buffer");
-    S.tiles[i] = tiles[i]; S.partials[i] = partials[i]; S.cols[i] = cols[i]; S.db[i] = out[i];
-    maxc = cols[i] > maxc ? cols[i] : maxc;
-    covered += cols[i];
-    lo = (out[i] < lo) ? out[i] : lo;
-  }
-  const int64_t tail_lo = lo - g;
-  // the segments must be exactly the tail of the buffer (up to its zero padding): everything in front is square-summed as it is
-  NEED(tail_lo % 4 == 0 && covered <= n - tail_lo && n - tail_lo - covered < 4, "the finalised segments must tile the end of the gradient buffer");
-  FinBlocks FB{};
-  for (int i = 0; i < nseg; i++) FB.off[i + 1] = FB.off[i] + (int)((cols[i] + 63) / 64);
-  (void)maxc;
-  NEED(scratch_len >= ADAM_BLOCKS + (int64_t)FB.off[nseg], "scratch too small for the finalize blocks' partials");
-  return adam_clip_impl(device, p, g, m, v, n, step, lr, lr_dev, beta1, beta2, eps, max_norm, 1.0f, scratch, mb_index, norm_out,
-                        gather_args, mbs, stream, &S, tail_lo, &FB);
-}
-
-extern "C" int brl_adam_clip_fin_gather_defer(int device, float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
-                                              const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float *scratch,
-                                              int64_t scratch_len, int32_t *mb_index, float *norm_out, const void *gather_args,
-                                              int64_t mbs, int nseg, const float *const *partials, const int64_t *cols,
-                                              const int64_t *tiles, float *const *out, int64_t defer_lo, int64_t defer_hi,
-                                              int32_t *pending, void *stream) {
-  NEED(nseg >= 1 && nseg <= BIAS_MAX_SEGS && partials && cols && tiles && out, "nseg / partials / cols / tiles / out");
-  NEED(g != nullptr && n > 0, "g / n");
+  NEED(p && g && m && v && step && scratch && n > 0 && n % 4 == 0, "p / g / m / v / step / scratch / n (a multiple of 4)");
+  NEED(!gather_args || (mb_index && mbs > 0), "gather_args needs mb_index and the minibatch size");
   BiasSegs S{};
   S.n = nseg;
   int64_t covered = 0;
@@ -622,26 +442,68 @@ extern "C" int brl_adam_clip_fin_gather_defer(int device, float *p, float *g, fl
     lo = (out[i] < lo) ? out[i] : lo;
   }
   const int64_t tail_lo = lo - g;
+  // the segments must be exactly the tail of the buffer (up to its zero padding): everything in front is square-summed as it is
   NEED(tail_lo % 4 == 0 && covered <= n - tail_lo && n - tail_lo - covered < 4, "the finalised segments must tile the end of the gradient buffer");
   FinBlocks FB{};
   for (int i = 0; i < nseg; i++) FB.off[i + 1] = FB.off[i] + (int)((cols[i] + 63) / 64);
   NEED(scratch_len >= ADAM_BLOCKS + (int64_t)FB.off[nseg], "scratch too small for the finalize blocks' partials");
-  return adam_clip_impl(device, p, g, m, v, n, step, lr, lr_dev, beta1, beta2, eps, max_norm, 1.0f, scratch, mb_index, norm_out,
-                        gather_args, mbs, stream, &S, tail_lo, &FB, defer_lo, defer_hi, pending);
+  HIP_TRY(hipSetDevice(device));
+  const int npartials = ADAM_BLOCKS + FB.off[nseg];
+  hipLaunchKernelGGL(k_adam_norm_fin, dim3((unsigned)npartials), dim3(ADAM_THREADS), 0, (hipStream_t)stream, g, n, 1.0f, scratch, step,
+                     mb_index, S, tail_lo, FB);
+  const unsigned extra = gather_args ? (unsigned)((mbs + 1) / 2) : 0u;
+  AdamRange R{};
+  R.p = p; R.g = g; R.m = m; R.v = v; R.lo4 = 0; R.hi4 = n >> 2; R.partials = scratch; R.npartials = npartials; R.step = step;
+  R.lr_dev = lr_dev; R.lr = lr; R.b1 = beta1; R.b2 = beta2; R.eps = eps; R.max_norm = max_norm; R.gscale = 1.0f; R.norm_out = norm_out;
+  hipLaunchKernelGGL(k_adam_apply, dim3((unsigned)ADAM_BLOCKS + extra), dim3(ADAM_THREADS), 0, (hipStream_t)stream, R, ADAM_BLOCKS,
+                     (const GatherArgs *)gather_args);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
 }
 
-extern "C" int brl_adam_apply_range(int device, float *p, const float *g, float *m, float *v, int64_t lo, int64_t hi, const float *scratch,
-                                    int npartials, const float *step, float lr, const float *lr_dev, float beta1, float beta2, float eps,
-                                    float max_norm, float grad_scale, int32_t *pending, int clear_pending, void *stream) {
-  NEED(p && g && m && v && scratch && step && npartials > 0, "p / g / m / v / scratch / step / npartials");
-  NEED(lo % 4 == 0 && hi % 4 == 0 && lo >= 0 && lo < hi, "range (multiples of 4)");
-  NEED(!clear_pending || pending, "clear_pending needs the flag");
+// ---- the multi-rank step's clip + Adam: on the rank slices of a bucketed flat buffer (ppo_update.hpp: ShardGeom) ------------
+static int shard_geom(const brl_shard_geom *geom, int rank_lo, int rank_hi, ShardGeom *out) {
+  NEED(geom && geom->nbuckets >= 1 && geom->nbuckets <= SHARD_MAX_BUCKETS && geom->world >= 1 && geom->nsub >= 1, "geometry");
+  NEED(rank_lo >= 0 && rank_lo < rank_hi && rank_hi <= geom->world, "rank range");
+  ShardGeom G{};
+  G.nb = geom->nbuckets; G.world = geom->world; G.J = geom->nsub;
+  for (int b = 0; b < G.nb; b++) {
+    NEED(geom->off[b] >= 0 && geom->off[b] % 4 == 0 && geom->len[b] > 0 && geom->len[b] % 4 == 0, "bucket offsets / slice lengths multiples of 4 floats");
+    G.off4[b] = geom->off[b] >> 2; G.len4[b] = geom->len[b] >> 2;
+    G.blk[b + 1] = G.blk[b] + (int)((G.len4[b] + SHARD_PER4 - 1) / SHARD_PER4);
+  }
+  *out = G;
+  return BRL_OK;
+}
+
+extern "C" int brl_adam_shard_norm(int device, const float *g, const brl_shard_geom *geom, int rank_lo, int rank_hi, float grad_scale,
+                                   float *partials, float *step, int32_t *mb_index, void *stream) {
+  NEED(g && partials && step, "g / partials / step");
+  ShardGeom G;
+  if (int rc = shard_geom(geom, rank_lo, rank_hi, &G)) return rc;
   HIP_TRY(hipSetDevice(device));
-  const AdamRange R = adam_range(p, g, m, v, lo, hi, scratch, npartials, step, lr, lr_dev, beta1, beta2, eps, max_norm, grad_scale, pending, nullptr);
-  const int64_t n4 = (hi - lo) / 4;
-  const unsigned nb = (unsigned)((n4 + 1023) / 1024);   // four float4s per thread
-  hipLaunchKernelGGL(k_adam_range, dim3(nb), dim3(ADAM_THREADS), 0, (hipStream_t)stream, R);
-  if (clear_pending) hipLaunchKernelGGL(k_clear_flag, dim3(1), dim3(1), 0, (hipStream_t)stream, pending);
+  hipLaunchKernelGGL(k_shard_norm, dim3((unsigned)((rank_hi - rank_lo) * G.nb * G.J)), dim3(ADAM_THREADS), 0, (hipStream_t)stream, g, G,
+                     rank_lo, grad_scale, partials, step, mb_index);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_adam_shard_apply(int device, float *p, const float *g, float *m, float *v, const brl_shard_geom *geom, int rank_lo,
+                                    int rank_hi, const float *partials, const float *step, float lr, const float *lr_dev, float beta1,
+                                    float beta2, float eps, float max_norm, float grad_scale, float *norm_out, const void *gather_args,
+                                    int64_t mbs, void *stream) {
+  NEED(p && g && m && v && partials && step, "p / g / m / v / partials / step");
+  NEED(!gather_args || mbs > 0, "gather_args needs the minibatch size");
+  ShardGeom G;
+  if (int rc = shard_geom(geom, rank_lo, rank_hi, &G)) return rc;
+  HIP_TRY(hipSetDevice(device));
+  AdamRange R{};
+  R.p = p; R.g = g; R.m = m; R.v = v; R.partials = partials; R.npartials = G.world * G.nb * G.J; R.step = step;
+  R.lr_dev = lr_dev; R.lr = lr; R.b1 = beta1; R.b2 = beta2; R.eps = eps; R.max_norm = max_norm; R.gscale = grad_scale; R.norm_out = norm_out;
+  const int sweep = (rank_hi - rank_lo) * G.blk[G.nb];
+  const unsigned extra = gather_args ? (unsigned)((mbs + 1) / 2) : 0u;
+  hipLaunchKernelGGL(k_shard_apply, dim3((unsigned)sweep + extra), dim3(ADAM_THREADS), 0, (hipStream_t)stream, R, G, rank_lo, sweep,
+                     (const GatherArgs *)gather_args);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

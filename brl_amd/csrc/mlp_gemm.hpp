@@ -25,12 +25,11 @@
 namespace mg {
 
 constexpr int BM = 64, BN = 64, BK = 32, THREADS = 256;
-constexpr int NHEADS = 39;   // 38 logits + the value (include/brl_hip.h: BRL_NUM_ACTIONS + 1)
 constexpr int LDS_FLOATS = 2 * (2 * 64 * BK);      // the 64 x 64 form: two stages of an A and a B tile = 32 KB (+ 128 reduction words)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { EPI_NONE = 0, EPI_BIAS_ACT = 1, EPI_GATE_COLSUM = 2, EPI_SQSUM = 3, EPI_BIAS_ACT_HEADS = 4 };
+enum { EPI_NONE = 0, EPI_BIAS_ACT = 1, EPI_GATE_COLSUM = 2, EPI_SQSUM = 3 };
 
 struct Args {
   const float *A;   // KC: A[m * lda + k]   MC: A[k * lda + m]
@@ -46,11 +45,6 @@ struct Args {
   int64_t ldg;
   float *colsum;       // EPI_GATE_COLSUM: [ceil(M / 64)][N] column sums of the STORED values per 64-row tile, or NULL
   float *sqsum;        // EPI_SQSUM: [tiles] sum of squares of the stored tile (tile index = tm * tiles_n + tn)
-  // EPI_BIAS_ACT_HEADS: EPI_BIAS_ACT + this tile's share of the 39-column head product on what it stores:
-  // hparts[tn][m][hd] = sum over the tile's columns n of C[m][n] * wh[hd][n]   (the loss launch adds bias + the tiles_n parts in order)
-  const float *wh;     // [NHEADS][ldwh]: actor rows, then the critic row (src/models.py:30-33)
-  int64_t ldwh;
-  float *hparts;       // [tiles_n][M][NHEADS]
 #ifdef MG_TIMING
   unsigned long long *dbg;   // timing build: per workgroup 8 words (shader cycles at 4 points, 100 MHz ticks at 4 points)
 #endif
@@ -249,18 +243,11 @@ __device__ __forceinline__ void gemm_tile(const Args &G, float *lds, int bid, in
   // the epilogue's operands (bias / the layer's forward output for the activation derivative) are requested HERE, behind the
   // first two chunks: they land during the first phases, the epilogue finds them in registers (loads cannot sink below the
   // loop: its barriers are compiler memory barriers).  Rows / columns outside the matrix read a clamped address.
-  f32x4 ebias[NB], egate[2][NB], ewh[3][NB];
+  f32x4 ebias[NB], egate[2][NB];
 #pragma unroll
   for (int bj = 0; bj < NB; bj++) {
     const int n = n0 + 16 * NB * wn + 16 * bj + 4 * g, nc = n < G.N ? n : 0;
-    if (EPI == EPI_BIAS_ACT || EPI == EPI_BIAS_ACT_HEADS) ebias[bj] = *reinterpret_cast<const f32x4 *>(G.bias + nc);
-    if (EPI == EPI_BIAS_ACT_HEADS) {   // head weights of this lane's columns: head 16 hb + c16 (the MFMA's row index), columns n .. n + 3
-#pragma unroll
-      for (int hb = 0; hb < 3; hb++) {
-        const int hd = 16 * hb + c16;
-        ewh[hb][bj] = (hd < NHEADS && n < G.N) ? *reinterpret_cast<const f32x4 *>(G.wh + (int64_t)hd * G.ldwh + nc) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      }
-    }
+    if (EPI == EPI_BIAS_ACT) ebias[bj] = *reinterpret_cast<const f32x4 *>(G.bias + nc);
 #pragma unroll
     for (int bi = 0; bi < 2; bi++) {
       const int m = m0 + 32 * wm + 16 * bi + c16, mc = m < G.M ? m : G.M - 1;
@@ -369,11 +356,6 @@ __device__ __forceinline__ void gemm_tile(const Args &G, float *lds, int bid, in
   // ---- epilogue: lane (c, g) holds, per (bi, bj), C[m = m0 + 32 wm + 16 bi + c][n = n0 + 16 NB wn + 16 bj + 4 g + 0..3]
   float csum[NB][4];
   float sq = 0.0f;
-  f32x4 hacc[2][3];   // EPI_BIAS_ACT_HEADS: register r of lane (c, g) = part[row 16 bi + c][head 16 hb + 4 g + r] of the wave's columns
-#pragma unroll
-  for (int bi = 0; bi < 2; bi++)
-#pragma unroll
-    for (int hb = 0; hb < 3; hb++) hacc[bi][hb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int bj = 0; bj < NB; bj++)
 #pragma unroll
@@ -387,7 +369,7 @@ __device__ __forceinline__ void gemm_tile(const Args &G, float *lds, int bid, in
       const int n = n0 + 16 * NB * wn + 16 * bj + 4 * g;
       const bool ok = m < G.M && n < G.N;   // (N is a multiple of 4: the lane's four columns are inside or outside together)
       f32x4 v = acc[bi][bj];
-      if (EPI == EPI_BIAS_ACT || EPI == EPI_BIAS_ACT_HEADS) {
+      if (EPI == EPI_BIAS_ACT) {
         const f32x4 bb = ebias[bj];
         if (relu) {
 #pragma unroll
@@ -414,66 +396,6 @@ __device__ __forceinline__ void gemm_tile(const Args &G, float *lds, int bid, in
         for (int i = 0; i < 4; i++) sq += ok ? v[i] * v[i] : 0.0f;
       }
       if (ok) *reinterpret_cast<f32x4 *>(G.C + (int64_t)m * G.ldc + n) = v;
-      if (EPI == EPI_BIAS_ACT_HEADS) {
-        // the heads' share of this block: D[hd][m] += sum_i wh[hd][n + i] * v[m][n + i] — the lane's four stored values ARE the
-        // instruction's B operand (row k = the lane's K group g <-> column 4 g + i in step i, column j = m = c16), the head
-        // weights its A operand; rows / columns outside the matrix contribute zeros (their weights were loaded as zeros)
-        // (three accumulators in rotation; s_nop: hipcc pads nothing inside asm, the operand was written by a VALU instruction)
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const float vi = ok ? v[i] : 0.0f;
-#pragma unroll
-          for (int hb = 0; hb < 3; hb++)
-            asm volatile("s_nop 3\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(hacc[bi][hb]) : "v"(ewh[hb][bj][i]), "v"(vi));
-        }
-      }
-    }
-  }
-  if (EPI == EPI_BIAS_ACT_HEADS) {
-    // The two waves of a row half (wn = 0, 1) hold the shares of their own columns: wn = 1 leaves its own in LDS (the stages are
-    // free once every wave is past the K loop), wn = 0 adds them — a fixed order — into the tile's part image [64 rows][40], and
-    // all threads store whole rows of it (156 contiguous bytes; as 24 scattered 4-byte stores per lane the epilogue took 1 us more).
-#pragma unroll
-    for (int bi = 0; bi < 2; bi++)
-#pragma unroll
-      for (int hb = 0; hb < 3; hb++) asm volatile("s_nop 15" : "+v"(hacc[bi][hb]));   // (hipcc pads nothing behind inline asm)
-    __syncthreads();
-    float *hx = lds + wm * (6 * 256);   // [bi][hb][4][64 lanes] per row half
-    float *img = lds + 2 * (6 * 256);   // [64][40]
-    if (wn == 1) {
-#pragma unroll
-      for (int bi = 0; bi < 2; bi++)
-#pragma unroll
-        for (int hb = 0; hb < 3; hb++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) hx[((bi * 3 + hb) * 4 + r) * 64 + lane] = hacc[bi][hb][r];
-    }
-    __syncthreads();
-    if (wn == 0) {
-#pragma unroll
-      for (int bi = 0; bi < 2; bi++)
-#pragma unroll
-        for (int hb = 0; hb < 3; hb++) {
-          f32x4 t;
-#pragma unroll
-          for (int r = 0; r < 4; r++) t[r] = hacc[bi][hb][r] + hx[((bi * 3 + hb) * 4 + r) * 64 + lane];
-          // heads 16 hb + 4 g .. + 3 of row 32 wm + 16 bi + c16 (columns 39..47 of the padded block fall outside the 40-float row:
-          // only hb = 2, g >= 2 — those lanes skip)
-          if (16 * hb + 4 * g < 40) *reinterpret_cast<f32x4 *>(img + (32 * wm + 16 * bi + c16) * 40 + 16 * hb + 4 * g) = t;
-        }
-    }
-    __syncthreads();
-    // 64 rows x 39 floats: thread -> (row = tid >> 2, a quarter of the row's heads)
-    {
-      const int rr = tid >> 2, q = tid & 3;
-      if (m0 + rr < G.M) {
-        float *dst = G.hparts + ((int64_t)tn * G.M + m0 + rr) * NHEADS;
-#pragma unroll
-        for (int u = 0; u < 10; u++) {
-          const int hd = q * 10 + u;
-          if (hd < NHEADS) dst[hd] = img[rr * 40 + hd];
-        }
-      }
     }
   }
   float *red = lds + 2 * STAGE;   // 128 floats behind the stages: no wave can still be reading them

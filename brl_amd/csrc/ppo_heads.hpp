@@ -2,9 +2,11 @@
 // step (src/update.py:90-167).  Its three products are ~80 MFLOP each — nothing for the matrix cores of a 256-CU chip — yet
 // as library GEMMs (N = 39 or K = 39) they cost 9.5-13 us apiece plus the launches around them (loss 5 us, Gram matrix 5.6 us,
 // head column sums 5.3 us, top layer's ReLU backward 6.2 us: profiles/r02/r02w_policy_path_kernel_stats.txt).  Here:
-//   k_heads_loss  heads = h W_h^T + b_h (16 samples per workgroup, the K = 1024 sum split over 8 waves of v_mfma_f32_16x16x4_f32,
-//                 partial sums meet in LDS) -> `_loss_fn` of those samples (ppo_loss_sample: one wave per sample) -> d(loss)/d(heads),
-//                 the statistics partials and the workgroup's 38 x 38 Gram-matrix partial of the illegal-action probabilities;
+//   k_heads_product  h W_h^T (16 samples per workgroup, the K = 1024 sum split over workgroups AND over their 8 waves of
+//                 v_mfma_f32_16x16x4_f32; partial sums per K range);
+//   k_heads_loss  heads = b_h + the parts -> `_loss_fn` of 4 samples per workgroup (ppo_loss_sample: one wave per sample) ->
+//                 d(loss)/d(heads), the statistics partials and the workgroup's 38 x 38 Gram-matrix partial of the illegal-action
+//                 probabilities;
 //   k_heads_bwd   role A: dW_h = d(heads)^T h and db_h = column sums of d(heads), per batch split (deterministic partials,
 //                 summed by k_bias_finalize);  role B: dh = d(heads) W_h, times the top layer's activation derivative, with
 //                 that layer's bias-gradient column sums per 16-row tile;
@@ -15,7 +17,7 @@
 
 constexpr int HD_ROWS = 4;     // samples per workgroup of k_heads_loss (of the 16 rows of an MFMA tile; see the kernel)
 constexpr int HD_WAVES = 8;    // waves per workgroup = K splits; waves 0..3 finish one sample each
-constexpr int HD_MAX_PARTS = 32;   // partial products k_heads_loss can add (k_heads_product: <= 8 K ranges; the forward GEMM's epilogue: one per 64-column tile)
+constexpr int HD_MAX_PARTS = 8;    // partial products k_heads_loss adds (k_heads_product: <= 8 K ranges)
 #include "heads_dw_role.hpp"   // HD_NOUT, HD_GRAM, HB_JT, hd_f32x4, HeadsBwdArgs, heads_bwd_dw_block
 
 
@@ -29,7 +31,7 @@ struct HeadsLossArgs {
   float *heads_out;     // [B, 39] or NULL
   float *gram_partials; // [ceil(B / 4)][1444] or NULL
   int reward_scaling;   // src/update.py:31-44: advantages normalised over the minibatch (jnp std: ddof = 0)
-  // parts != NULL: the heads product has been formed by k_heads_product as `nparts` partial sums over K ranges:
+  // the heads product, formed by k_heads_product as `nparts` partial sums over K ranges:
   // heads[b][n] = bh[n] + parts[0][b][n] + parts[1][b][n] + ..  (in that order); h / Wh are not read here
   const float *parts;   // [nparts][part_stride], row b at b * 39
   int nparts;           // <= HD_MAX_PARTS
@@ -46,7 +48,6 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
   const unsigned long long hd_t0 = __builtin_amdgcn_s_memtime();
   float hd_st[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #endif
-  __shared__ float red[HD_WAVES][3][4][16];            // K-split partial sums of tile rows 0..3 (6 KB)
   __shared__ float illp_s[HD_ROWS][BRL_NUM_ACTIONS + 2];
   __shared__ float part_s[HD_ROWS][8];
   __shared__ float rs_red[HD_WAVES], rs_stat[2];
@@ -87,78 +88,15 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
     adv_inv = rs_stat[1];
   }
 
-  // everything the loss of this wave's sample reads from global memory, issued NOW (consumed behind the barrier below)
+  // everything the loss of this wave's sample reads from global memory, issued at once
   const int64_t my_b = row0 + ((w < HD_ROWS) ? w : 0);
   const bool my_valid = w < HD_ROWS && my_b < B;
   const PpoSampleIn my_in = ppo_sample_load(A.P, my_b, my_valid, lane);
   const float my_bias = (lane < HD_NOUT) ? A.bh[lane] : 0.0f;
-  const bool split = A.parts != nullptr;   // (uniform) the product comes in as partial sums
-  float my_part[HD_MAX_PARTS];
+  float my_part[HD_MAX_PARTS];   // the heads product comes in as partial sums over K ranges (k_heads_product)
 #pragma unroll
   for (int p = 0; p < HD_MAX_PARTS; p++)
-    my_part[p] = (split && my_valid && lane < HD_NOUT && p < A.nparts) ? A.parts[(int64_t)p * A.part_stride + my_b * HD_NOUT + lane] : 0.0f;
-
-  // ---- heads of 16 samples: D[sample][n] = sum_k h[sample][k] W_h[n][k]; wave w takes the 16-deep K groups w, w + 8, ..
-  // lane (r, kq): A row = sample r, B column = head n = 16 nb + r, K = 16 g + 4 kq + s in MFMA step s (the K order inside a
-  // group is permuted the same way for both operands)
-  // Only FOUR of the tile's 16 rows are real samples (the others repeat them): the heads product is ~80 MFLOP — nothing —, but the
-  // loss behind it is ~900 VALU instructions per sample, and with 16 samples per workgroup only 64 CUs would share them, four
-  // waves deep on every SIMD (measured: 14 k cycles of 25 k).  256 workgroups x 4 samples: one loss wave per SIMD, every CU busy.
-  if (!split) {
-  const int r = lane & 15, kq = lane >> 4;
-  const int64_t arow = (row0 + (r & (HD_ROWS - 1)) < B) ? row0 + (r & (HD_ROWS - 1)) : B - 1;
-  const float *ap = A.h + arow * A.ldh + 4 * kq;
-  const float *bp[3];
-  bool bok[3];
-#pragma unroll
-  for (int nb = 0; nb < 3; nb++) {
-    const int n = 16 * nb + r;
-    bok[nb] = n < HD_NOUT;
-    bp[nb] = A.Wh + (int64_t)(bok[nb] ? n : 0) * A.H + 4 * kq;
-  }
-  hd_f32x4 acc[3];
-#pragma unroll
-  for (int nb = 0; nb < 3; nb++) acc[nb] = hd_f32x4{0.f, 0.f, 0.f, 0.f};
-  const int ngroups = A.H / 16;
-  // (latency-bound: 64 workgroups, every operand read once — so ALL of a wave's loads are in flight before the first MFMA:
-  //  8 groups per pass = 8 + 24 16-byte loads per lane = the whole K range of the wave at H = 1024)
-  constexpr int GP = 8;
-  for (int g0 = w; g0 < ngroups; g0 += GP * HD_WAVES) {
-    hd_f32x4 av[GP], bv[GP][3];
-#pragma unroll
-    for (int u = 0; u < GP; u++) {
-      const int g = g0 + u * HD_WAVES;
-      const int gc = (g < ngroups) ? g : g0;
-      av[u] = *reinterpret_cast<const hd_f32x4 *>(ap + 16 * gc);
-#pragma unroll
-      for (int nb = 0; nb < 3; nb++) bv[u][nb] = *reinterpret_cast<const hd_f32x4 *>(bp[nb] + 16 * gc);
-    }
-#ifdef HD_TIMING
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    HD_STAMP(1);   // operands have arrived
-#endif
-#pragma unroll
-    for (int u = 0; u < GP; u++) {
-      if (g0 + u * HD_WAVES >= ngroups) break;
-#pragma unroll
-      for (int nb = 0; nb < 3; nb++) {
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][s], bok[nb] ? bv[u][nb][s] : 0.0f, acc[nb], 0, 0, 0);
-      }
-    }
-  }
-  HD_STAMP(0);   // loads + MFMAs done
-  // accumulator register q of lane (c, rq): D[sample 4 rq + q][head 16 nb + c]
-  static_assert(HD_ROWS == 4, "tile rows 0..3 = registers 0..3 of lanes 0..15");
-  if (lane < 16) {
-#pragma unroll
-    for (int nb = 0; nb < 3; nb++)
-#pragma unroll
-      for (int q = 0; q < 4; q++) red[w][nb][q][lane] = acc[nb][q];
-  }
-  }
-  __syncthreads();
+    my_part[p] = (my_valid && lane < HD_NOUT && p < A.nparts) ? A.parts[(int64_t)p * A.part_stride + my_b * HD_NOUT + lane] : 0.0f;
 
   // ---- `_loss_fn` (src/update.py:90-167): wave w < 4 takes sample w; lane a = head a
   if (w < HD_ROWS) {
@@ -167,15 +105,9 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
     const bool valid = my_valid;
     float hv = 0.0f;
     if (lane < HD_NOUT) {
-      const int nb = lane >> 4, c = lane & 15;
       hv = my_bias;
-      if (split) {
 #pragma unroll
-        for (int p = 0; p < HD_MAX_PARTS; p++) hv += my_part[p];   // fixed order (absent parts are exact zeros)
-      } else {
-#pragma unroll
-        for (int k = 0; k < HD_WAVES; k++) hv += red[k][nb][sl][c];   // fixed order
-      }
+      for (int p = 0; p < HD_MAX_PARTS; p++) hv += my_part[p];   // fixed order (absent parts are exact zeros)
       if (valid && A.heads_out) A.heads_out[b * HD_NOUT + lane] = hv;
     }
     const float v = __shfl(hv, BRL_NUM_ACTIONS, 64);

@@ -1,7 +1,7 @@
 // ppo_update.hpp — the non-GEMM half of one PPO minibatch step (src/update.py:74-242) as a handful of launches:
-// minibatch gather, ReLU backward + bias gradient, global-norm clip + Adam on flat buffers.  The GEMMs (5 forward, 9
-// backward) stay with hipBLASLt / rocBLAS through torch; brl_amd/update.py::FusedMinibatch strings them together and
-// captures the whole step in one hipGraph.  Included by brl_kernels.hip (C-ABI at the end of this file).
+// minibatch gather, activation backward + bias gradient, global-norm clip + Adam on flat buffers (whole, or the rank's slices
+// under a process group).  brl_amd/update.py::FusedMinibatch strings them together with the GEMMs and captures the step in a
+// hipGraph.  Included by brl_ppo.hip (C-ABI there).
 #pragma once
 
 // ---- minibatch gather: row perm[mb * B + b] of the flattened [T*N] trajectory -> static minibatch buffers, observation
@@ -24,9 +24,7 @@ struct GatherArgs {
 
 __device__ __forceinline__ void mb_gather_row(const GatherArgs &A, int64_t b, int t);
 
-__global__ __launch_bounds__(128) void k_mb_gather(GatherArgs A) { mb_gather_row(A, blockIdx.x, (int)threadIdx.x); }
-
-// the same launch with its arguments in DEVICE memory (written by k_mb_gather_bind once per update): the captured minibatch
+// the launch reads its arguments from DEVICE memory (written by k_mb_gather_bind once per update): the captured minibatch
 // step starts with its own gather and stays valid when the next update brings another trajectory / permutation
 __global__ __launch_bounds__(128) void k_mb_gather_dev(const GatherArgs *Ad) {
   const GatherArgs A = *Ad;
@@ -58,48 +56,9 @@ __device__ __forceinline__ void mb_gather_row(const GatherArgs &A, int64_t b, in
   }
 }
 
-// ---- ReLU backward + bias gradient of one hidden layer, two launches: k_relu_bwd_tiles: dz = dh * (h > 0) in place and
-// the column sums of every 64-row tile (h == NULL: no ReLU — the head: column sums of d(out)); k_bias_finalize: db[c] = sum
-// over the row tiles in index order (deterministic; no atomics, no cross-block hand-off inside a launch).
-__global__ __launch_bounds__(256) void k_relu_bwd_tiles(float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld,
-                                                         float *partials) {
-  __shared__ float part[4][64];
-  const int c = (int)(threadIdx.x & 63u), rg = (int)(threadIdx.x >> 6);
-  const int64_t col = (int64_t)blockIdx.x * 64 + c, r0 = (int64_t)blockIdx.y * 64 + rg;
-  float d[16], hv[16];
-  const bool cv = col < cols;
-  // (unconditional loads from clamped addresses, the h == NULL case decided once: a guard per element makes the compiler
-  //  branch around every load and wait for each — 32 memory round trips instead of one)
-  const int64_t cc = cv ? col : cols - 1;
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int64_t r = r0 + 4 * k, rc = (r < rows) ? r : rows - 1;
-    d[k] = dh[rc * ld + cc];
-  }
-  if (h != nullptr) {
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const int64_t r = r0 + 4 * k, rc = (r < rows) ? r : rows - 1;
-      hv[k] = h[rc * ld + cc];
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 16; k++) hv[k] = 1.0f;
-  }
-  float s = 0.0f;
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int64_t r = r0 + 4 * k;
-    const float z = (cv && r < rows && hv[k] > 0.0f) ? d[k] : 0.0f;
-    if (h != nullptr && cv && r < rows) dh[r * ld + col] = z;
-    s += z;
-  }
-  part[rg][c] = s;
-  __syncthreads();
-  if (rg == 0 && cv) partials[(int64_t)blockIdx.y * cols + col] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
-}
-
-// the same for cols % 4 == 0 (the hidden layers): float4 accesses, 16-row tiles, a block covers 256 columns
+// ---- activation backward + bias gradient of one hidden layer (where the own GEMM's epilogue does not do it): dz = dh * act'(h)
+// in place and the column sums of every 16-row tile; k_bias_finalize: db[c] = sum over the row tiles in index order (deterministic;
+// no atomics, no cross-block hand-off inside a launch).  cols % 4 == 0: float4 accesses, a block covers 256 columns.
 // act: 0 = ReLU (dz = dh where h > 0), 1 = tanh (dz = dh * (1 - h^2): src/models.py:16 `activation == "tanh"`)
 __device__ __forceinline__ void relu_bwd_tiles4_block(float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld,
                                                       float *partials, int act, const int bx, const int by) {
@@ -108,9 +67,11 @@ __device__ __forceinline__ void relu_bwd_tiles4_block(float *dh, const float *h,
   const int64_t col = ((int64_t)bx * 64 + cg) * 4, r0 = (int64_t)by * 16 + rg;
   const bool cv = col < cols;
   float4 d[4], hv[4];
-  const int64_t cc = cv ? col : cols - 4;  // (cols % 4 == 0: see relu_tile_rows)
+  const int64_t cc = cv ? col : cols - 4;  // (cols % 4 == 0)
+  // (unconditional loads from clamped addresses, the h == NULL case decided once: a guard per element makes the compiler
+  //  branch around every load and wait for each — 8 memory round trips instead of one)
 #pragma unroll
-  for (int k = 0; k < 4; k++) {  // unconditional loads from clamped addresses (see k_relu_bwd_tiles)
+  for (int k = 0; k < 4; k++) {
     const int64_t r = r0 + 4 * k, rc = (r < rows) ? r : rows - 1;
     d[k] = *reinterpret_cast<const float4 *>(dh + rc * ld + cc);
   }
@@ -152,7 +113,6 @@ __global__ __launch_bounds__(256) void k_relu_bwd_tiles4(float *dh, const float 
 }
 
 constexpr int BIAS_MAX_SEGS = 12;  // DeepMind_8: 8 hidden layers + the head
-__host__ __device__ inline int64_t relu_tile_rows(int64_t cols, int64_t ld) { return (cols % 4 == 0 && ld % 4 == 0) ? 16 : 64; }
 struct BiasSegs {  // up to 12 layers finalised by one launch (blockIdx.y = layer)
   int n;
   int64_t tiles[BIAS_MAX_SEGS];
@@ -200,33 +160,9 @@ __global__ __launch_bounds__(256) void k_bias_finalize(BiasSegs S) {
 // torch.optim.Adam does (bias corrections 1 - beta^t, denominator sqrt(v) / sqrt(bc2) + eps).
 constexpr int ADAM_BLOCKS = 1024, ADAM_THREADS = 256;  // n is a multiple of 4 (the caller pads its flat buffers)
 
-__global__ __launch_bounds__(ADAM_THREADS) void k_adam_norm(const float *g, int64_t n, float gscale, float *partials, float *step,
-                                                            int32_t *mb_index) {
-  __shared__ float red[ADAM_THREADS / 64];
-  const int64_t n4 = n >> 2;
-  const int64_t chunk = (n4 + ADAM_BLOCKS - 1) / ADAM_BLOCKS;
-  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n4) ? lo + chunk : n4;
-  float s = 0.0f;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += ADAM_THREADS) {
-    float4 x = reinterpret_cast<const float4 *>(g)[i];
-    x.x *= gscale; x.y *= gscale; x.z *= gscale; x.w *= gscale;  // (the all-reduced SUM of the ranks' gradients -> their mean)
-    s += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
-  }
-  s = wave_sum_f(s);
-  if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-    if (blockIdx.x == 0) {
-      *step += 1.0f;  // read by k_adam_apply (next launch)
-      if (mb_index) *mb_index += 1;  // ... and the minibatch counter: k_adam_apply's extra blocks gather the NEXT minibatch with it
-    }
-  }
-}
-
-// k_adam_norm + k_bias_finalize in ONE launch (single rank: nothing sits between them).  The flat gradient buffer ends with the
+// The norm launch + k_bias_finalize in ONE launch (single rank: nothing sits between them).  The flat gradient buffer ends with the
 // ranges k_bias_finalize produces (the head's weight gradient and every bias gradient, floats [tail_lo, n)): blocks
-// [0, ADAM_BLOCKS) square-sum g[0, tail_lo) as k_adam_norm does; block ADAM_BLOCKS + FB.off[seg] + bx finishes 64 columns of
+// [0, ADAM_BLOCKS) square-sum their chunk of g[0, tail_lo) (block 0 also advances the step / minibatch counters); block ADAM_BLOCKS + FB.off[seg] + bx finishes 64 columns of
 // segment `seg` (the sums k_bias_finalize forms, in its order), stores them AND adds their squares to its own partial — one
 // small launch (~5 us of latency chain) less per step.
 struct FinBlocks { int off[BIAS_MAX_SEGS + 1]; };   // segment `seg` owns the finalize blocks [off[seg], off[seg + 1]): 64 columns each
@@ -270,30 +206,81 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_norm_fin(const float *g, 
 
 #include "adam_role.hpp"   // AdamRange, adam_range_block: the sweep itself (shared with the GEMM translation unit, where parts of it ride)
 
-// blocks [0, nb1): range R1; [nb1, nb1 + nb2): range R2 (nb2 may be 0: one range); the rest (gather != NULL): the NEXT minibatch's
-// rows -> the static minibatch buffers, beside the parameter update.  Nothing of this step reads those buffers any more (stream
-// order), k_adam_norm has already advanced mb_index, and the 1024 random 535-byte rows are pure latency — 5.6 us as a launch of its
-// own in front of the forward pass.  set_pending (optional): the part of the sweep this launch leaves out is owed (adam_role.hpp).
-__global__ __launch_bounds__(ADAM_THREADS) void k_adam_apply(AdamRange R1, AdamRange R2, int nb1, int nb2, const GatherArgs *gather,
-                                                             int32_t *set_pending) {
+// blocks [0, nb): the sweep of range R; the rest (gather != NULL): the NEXT minibatch's rows -> the static minibatch buffers,
+// beside the parameter update.  Nothing of this step reads those buffers any more (stream order), the norm launch has already
+// advanced mb_index, and the 1024 random 535-byte rows are pure latency — 5.6 us as a launch of its own in front of the forward pass.
+__global__ __launch_bounds__(ADAM_THREADS) void k_adam_apply(AdamRange R, int nb, const GatherArgs *gather) {
   __shared__ float red[8];
   const int b = (int)blockIdx.x;
-  if (b >= nb1 + nb2) {
+  if (b >= nb) {
     const GatherArgs A = *gather;
     if ((int64_t)(*A.mb_index) >= A.nsteps) return;   // (the update's last step: nothing follows)
-    const int64_t row = ((int64_t)b - nb1 - nb2) * 2 + (threadIdx.x >> 7);
+    const int64_t row = ((int64_t)b - nb) * 2 + (threadIdx.x >> 7);
     if (row < A.B) mb_gather_row(A, row, (int)(threadIdx.x & 127u));
     return;
   }
-  if (b == 0 && threadIdx.x == 0 && set_pending) *set_pending = 1;
-  if (b < nb1) adam_range_block(R1, b, nb1, red);
-  else adam_range_block(R2, b - nb1, nb2, red);
+  adam_range_block(R, b, nb, red);
 }
 
-// a deferred range as a launch of its own (the end of an update: no forward pass follows that could carry it), and the
-// one-thread launch behind it that clears the flag
-__global__ __launch_bounds__(ADAM_THREADS) void k_adam_range(AdamRange R) {
-  __shared__ float red[8];
-  adam_range_block(R, (int)blockIdx.x, (int)gridDim.x, red);
+// ---- the multi-rank step: the flat buffers are cut into BUCKETS (one per all-reduce / reduce-scatter), every
+// bucket into `world` equal SLICES (slice r = what rank r owns after a reduce-scatter): bucket b = float4s [off4[b], off4[b] +
+// world * len4[b]).  The norm's partial sums are laid out per (rank, bucket, sub-block) — index (r * nb + b) * J + j — so that
+//   * a rank that holds only ITS reduced slices (reduce-scatter) computes its nb * J partials and an all-gather of 4 KB completes
+//     the array, and
+//   * a rank that holds the whole reduced gradient (all-reduce) computes all of them,
+// and both end with the SAME array, summed by every sweep block in the same fixed order: the two forms of the step give
+// bit-identical parameters.
+constexpr int SHARD_MAX_BUCKETS = 12;
+constexpr int64_t SHARD_PER4 = 1024;   // float4s per sweep block (four per thread)
+struct ShardGeom {
+  int nb, world, J;
+  int64_t off4[SHARD_MAX_BUCKETS], len4[SHARD_MAX_BUCKETS];
+  int blk[SHARD_MAX_BUCKETS + 1];      // sweep blocks of one rank's slices, prefix sums over the buckets
+};
+
+// block ((r - rank_lo) * nb + b) * J + j: the squares of sub-block j of rank r's slice of bucket b; block 0 advances the counters
+__global__ __launch_bounds__(ADAM_THREADS) void k_shard_norm(const float *g, ShardGeom G, int rank_lo, float gscale, float *partials,
+                                                             float *step, int32_t *mb_index) {
+  __shared__ float red[ADAM_THREADS / 64];
+  const int e = (int)blockIdx.x, j = e % G.J, rb = e / G.J, b = rb % G.nb, r = rank_lo + rb / G.nb;
+  const int64_t len = G.len4[b], chunk = (len + G.J - 1) / G.J;
+  const int64_t base = G.off4[b] + (int64_t)r * len;
+  const int64_t lo = base + (int64_t)j * chunk, hi = (lo + chunk < base + len) ? lo + chunk : base + len;
+  float s = 0.0f;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += ADAM_THREADS) {
+    float4 x = reinterpret_cast<const float4 *>(g)[i];
+    x.x *= gscale; x.y *= gscale; x.z *= gscale; x.w *= gscale;  // (the SUM of the ranks' gradients -> their mean)
+    s += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+  }
+  s = wave_sum_f(s);
+  if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[((int64_t)r * G.nb + b) * G.J + j] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (e == 0) {
+      *step += 1.0f;                  // read by k_shard_apply (a later launch)
+      if (mb_index) *mb_index += 1;   // ... and the minibatch counter: the sweep's extra blocks gather the NEXT minibatch with it
+    }
+  }
 }
-__global__ void k_clear_flag(int32_t *flag) { *flag = 0; }
+
+// blocks [0, sweep): clip + Adam on the slices of ranks [rank_lo, ..) — G.blk[nb] blocks per rank, bucket by bucket; the rest: the
+// next minibatch's gather (as k_adam_apply)
+__global__ __launch_bounds__(ADAM_THREADS) void k_shard_apply(AdamRange R, ShardGeom G, int rank_lo, int sweep, const GatherArgs *gather) {
+  __shared__ float red[8];
+  const int e = (int)blockIdx.x;
+  if (e >= sweep) {
+    const GatherArgs A = *gather;
+    if ((int64_t)(*A.mb_index) >= A.nsteps) return;
+    const int64_t row = ((int64_t)e - sweep) * 2 + (threadIdx.x >> 7);
+    if (row < A.B) mb_gather_row(A, row, (int)(threadIdx.x & 127u));
+    return;
+  }
+  const int per_rank = G.blk[G.nb], r = rank_lo + e / per_rank, q = e % per_rank;
+  int b = 0;
+  while (b + 1 < G.nb && q >= G.blk[b + 1]) b++;
+  R.lo4 = G.off4[b] + (int64_t)r * G.len4[b];
+  R.hi4 = R.lo4 + G.len4[b];
+  if (e != 0) R.norm_out = nullptr;   // (adam_range_block stores the norm from ITS block 0: only the launch's first block may)
+  adam_range_block(R, q - G.blk[b], G.blk[b + 1] - G.blk[b], red);
+}

@@ -1,0 +1,588 @@
+"""``FusedMinibatch`` — the PPO minibatch step of ``src/update.py:74-242`` as a hipGraph-captured PROGRAM of HIP launches, library
+GEMMs and (under a process group) RCCL collectives.  ``brl_amd.update.make_update_step`` drives it; DESIGN.md §4.3 / §7 describe
+the step and its multi-rank forms."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from ._capture import quiet_gc
+from .roll_out import Transition
+
+
+class _DistCollectives:
+    """The three collectives of the multi-rank step on torch.distributed (backend "nccl" = RCCL over xGMI on MI355X; gloo in the
+    CPU / one-GPU rehearsals).  ``capturable``: RCCL's collectives record into a hipGraph (probed: scripts/rccl_capture_probe.py),
+    gloo's copy through the host and cannot.  ``bench.py`` passes an object of the same shape whose collectives are no-ops with a
+    collective's stream edges (its one-GPU rehearsal of the step)."""
+
+    def __init__(self):
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.capturable = dist.get_backend() == "nccl"
+
+    def all_reduce(self, t, async_op):
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+
+    def reduce_scatter(self, out, inp, async_op):      # out = this rank's slice OF inp (in place)
+        return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, async_op=async_op)
+
+    def all_gather(self, out, inp, async_op):          # inp = this rank's slice OF out (in place)
+        return dist.all_gather_into_tensor(out, inp, async_op=async_op)
+
+
+class FusedMinibatch:
+    """One PPO minibatch step of a "DeepMind" MLP (src/update.py:74-242) with the forward layers and the batched weight gradient
+    left to the library and everything else hand-written HIP: the minibatch gather (``brl_mb_gather_dev``:
+    device-resident arguments), the 39-column head + ``_loss_fn`` + its gradients (``brl_ppo_heads_loss_split``), the head's
+    backward (``brl_ppo_heads_bwd``), dz_{l-1} = (dz_l W_l) act'(h_{l-1}) with the bias gradient's tile sums in the epilogue
+    (``brl_mlp_gemm``), global-norm clipping + Adam on flat parameter / gradient / moment buffers; the backward pass is written
+    out (no autograd); EIGHT steps are one hipGraph; the logged statistics are formed once per update from per-step sums
+    (``brl_ppo_stats_rows``).
+
+    The step is a PROGRAM — a list of kernel groups ("k"), collectives ("c") and waits ("w") — built once and executed by one of
+    two strategies: captured whole, collectives included, ``update_graph_steps`` times per hipGraph (single rank, and RCCL, whose
+    collectives record into a graph); or, for a backend that cannot be captured (gloo), one graph per kernel group with the
+    collectives issued eagerly between the replays.  Under a process group (``world > 1``, ``config["grad_allreduce"]``):
+
+      "sharded" (default)  reduce-scatter of the gradient bucket by bucket (one bucket per hidden layer, issued as soon as its
+          weight gradient exists, overlapping the rest of the backward pass; the last bucket = layer 0 + head + biases), the
+          norm's partial sums of the rank's own slices + a 4 KB all-gather, clip + Adam on the rank's 1/world slices only, then
+          the all-gather of the updated parameters bucket by bucket in forward order — the next step's layer l waits for ITS
+          bucket only.  Same ring bytes as an all-reduce; the Adam sweep shrinks by 1/world; the moments are valid on the rank's
+          slices only (``gather_optimizer_state`` completes them for a checkpoint).
+      "flat"  the same launches, ONE all-reduce of the flat gradient behind them, clip + Adam replicated on every rank.  Nothing
+          overlaps the collective: the simple form, kept as the fallback and as the check of the sharded one.
+
+    Both forms give bit-identical parameters (the norm's partials have one layout: csrc/ppo_update.hpp ShardGeom).
+
+    The module's parameters and the optimizer's moments become VIEWS of the flat buffers, so ``params``, ``state_dict``
+    checkpoints and the eager path keep working on the same memory.  Mirrors torch.optim.Adam's arithmetic and
+    ``clip_grad_norm_``; checked against the float64 numpy restatement and the eager path (tests/test_gpu_parity.py)."""
+
+    @staticmethod
+    def supports(config, params) -> bool:
+        # the DeepMind MLPs (4 / 6 / 8 x 1024) with either activation (src/models.py:16), reward_scaling and a non-zero
+        # illegal_action_l2norm_coef included; the FAIR net takes the autograd path
+        return (bool(config.get("fused_update", True)) and str(getattr(params, "model", "")).startswith("DeepMind")
+                and getattr(params, "act", None) in (torch.relu, torch.tanh)
+                and params.body[0].weight.shape[0] % 256 == 0
+                and next(params.parameters()).is_cuda and next(params.parameters()).dtype == torch.float32)
+
+    def __init__(self, config, params, opt, mbs: int, device, world: int = 1, log_capacity: int = 0, collective=None):
+        from . import _capi
+        import ctypes as C
+        self.cfg, self.params, self.opt, self.mbs, self.dev = config, params, opt, int(mbs), device
+        self.lib, self.capi = _capi.lib(), _capi
+        self.world = int(world)
+        multi = self.world > 1 or bool(config.get("force_collectives", False))   # (force_collectives: the multi-rank program at world 1 — tests / bench)
+        self.allreduce_mode = str(config.get("grad_allreduce", "sharded")) if multi else "none"
+        if self.allreduce_mode not in ("none", "flat", "sharded"):
+            raise ValueError("config['grad_allreduce'] must be 'sharded' or 'flat'")
+        self.coll = collective if collective is not None else (_DistCollectives() if multi else None)
+        self.rank = int(getattr(self.coll, "rank", 0)) if multi else 0
+        if config.get("tuned_gemm", True):   # committed TunableOp solutions for the step's GEMM shapes (brl_amd/tuned): lookups only
+            from . import tuned
+            tuned.enable()
+        f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)  # noqa: E731
+        body = list(params.body)
+        nl = len(body)
+        H = body[0].weight.shape[0]
+        K = params.actor.weight.shape[0] + 1
+        B = self.mbs
+        self.H, self.K, self.nl = H, K, nl
+        # ---- flat layout: W_1 .. W_{nl-1} (consecutive [H, H] blocks: one batched weight-gradient product, one collective bucket
+        # each), then the TAIL = W_0 | actor.weight | critic.weight (one [39, H] matrix) | the biases (hidden layers, actor |
+        # critic): the tail is what the backward pass finishes last — one bucket —, and its last part (head + biases) is what the
+        # sums of partials produce (brl_adam_clip_fin_gather wants those at the END of the buffer)
+        plist = [lin.weight for lin in body[1:]] + [body[0].weight, params.actor.weight, params.critic.weight] \
+            + [lin.bias for lin in body] + [params.actor.bias, params.critic.bias]
+        assert len(plist) == len(list(params.parameters()))
+        sizes = [q.numel() for q in plist]
+        hid = (nl - 1) * H * H
+        tail = sum(sizes) - hid
+        # buckets of the multi-rank step: every hidden layer + the tail, each cut into `world` slices of whole float4s
+        self.sharded_geom = multi and (H * H) % (4 * self.world) == 0
+        if self.allreduce_mode == "sharded" and not self.sharded_geom:
+            raise ValueError(f"grad_allreduce='sharded' needs hidden^2 divisible by 4 * world (hidden {H}, world {self.world}): use 'flat'")
+        quantum = 4 * self.world if multi else 4
+        tail_pad = (tail + quantum - 1) // quantum * quantum
+        self.n = n = hid + tail_pad             # zero padding at the end
+        if multi:
+            if self.sharded_geom:
+                offs = [l * H * H for l in range(nl - 1)] + [hid]
+                lens = [H * H // self.world] * (nl - 1) + [tail_pad // self.world]
+            else:                                # one bucket: the whole buffer
+                self.n = n = (sum(sizes) + quantum - 1) // quantum * quantum
+                offs, lens = [0], [n // self.world]
+            g = _capi.ShardGeom()
+            g.nbuckets, g.world = len(offs), self.world
+            g.nsub = max(1, 1024 // (self.world * len(offs)))
+            for b, (o, ln) in enumerate(zip(offs, lens)):
+                g.off[b], g.len[b] = o, ln
+            self.geom, self.bucket_off, self.bucket_len = g, offs, lens
+            self.norm_partials = f(self.world * g.nbuckets * g.nsub)
+        self.P, self.G, self.M, self.V = f(n), f(n), f(n), f(n)
+        self.step = torch.zeros((), dtype=torch.float32, device=device)
+        self.plist = plist
+        off = 0
+        views = {}
+        with torch.no_grad():
+            for q, k in zip(plist, sizes):
+                sl = slice(off, off + k)
+                self.P[sl].copy_(q.detach().reshape(-1))
+                st = opt.state.get(q, {})
+                if "exp_avg" in st:  # built after eager steps / from a loaded optimizer: continue from that state
+                    self.M[sl].copy_(st["exp_avg"].reshape(-1))
+                    self.V[sl].copy_(st["exp_avg_sq"].reshape(-1))
+                q.data = self.P[sl].view(q.shape)
+                q.grad = self.G[sl].view(q.shape)
+                st_step = st.get("step")
+                opt.state[q] = {"step": st_step.to(device=device, dtype=torch.float32).reshape(()) if torch.is_tensor(st_step)
+                                else torch.zeros((), dtype=torch.float32, device=device),
+                                "exp_avg": self.M[sl].view(q.shape), "exp_avg_sq": self.V[sl].view(q.shape)}
+                views[q] = sl
+                off += k
+        self.views = views
+        self.W = [lin.weight for lin in body]                      # [out, in] views of P
+        self.b = [lin.bias for lin in body]
+        self.GW = [self.G[views[lin.weight]].view(lin.weight.shape) for lin in body]
+        self.Gb = [self.G[views[lin.bias]] for lin in body]
+        wa = views[params.actor.weight]
+        self.Wh = self.P[wa.start:wa.start + K * H].view(K, H)     # actor rows, then the critic row
+        self.GWh = self.G[wa.start:wa.start + K * H].view(K, H)
+        ba = views[params.actor.bias]
+        self.bh = self.P[ba.start:ba.start + K]
+        self.Gbh = self.G[ba.start:ba.start + K]
+        # Activations and the gradients w.r.t. the pre-activations live in STACKED static buffers (out= costs the fused bias +
+        # ReLU GEMM nothing: scripts/fwd_probe.py): the hidden layers' weight gradients are ONE batched product
+        self.hs = f(nl, B, H)                       # h_l = act(h_{l-1} W_l^T + b_l)
+        self.dzs = f(nl, B, H)                      # d(loss) / d(pre-activation of layer l)
+        self.h = [self.hs[l] for l in range(nl)]
+        self.GW_hidden = self.G[:hid].view(nl - 1, H, H) if nl > 1 else None   # the gradients of W_1 .. W_{nl-1} as one tensor
+        self.x0 = f(B, 480)
+        self.mask = torch.zeros((B, 38), dtype=torch.uint8, device=device)
+        self.mask[:, 0] = 1  # a valid dummy batch for the warm-up iterations
+        self.action = torch.zeros(B, dtype=torch.int32, device=device)
+        self.old_v, self.old_lp, self.adv, self.tgt = f(B), f(B), f(B), f(B)
+        self.dheads = f(B, K)
+        self.ill_coef = float(config.get("illegal_action_l2norm_coef", 0.0) or 0.0)
+        self.heads = f(B, K) if self.ill_coef else None      # the gradient of the illegal-action norm re-reads the logits
+        self.head_ksplit = max(1, min(4, H // 256))          # K ranges of the heads product (brl_ppo_heads_loss_split)
+        self.head_parts = f(self.head_ksplit, B, K)
+        self.vec = f(40) if self.ill_coef else None          # v1 [38], sigma_1 of the step's illegal-action matrix
+        self.act = 0 if params.act is torch.relu else 1
+        groups = (B + 15) // 16                        # 16-row tiles of the bias-gradient column sums
+        self.lgroups = (B + 3) // 4                    # 4-sample groups of the loss launch (statistics / Gram partials)
+        self.partials = f(self.lgroups, 8)
+        self.gram_partials = f(self.lgroups, 38 * 38)
+        self.out = f(8)
+        self.scratch = f(8192)   # single rank: norm partials (1024 blocks + the finalize blocks that ride in the norm launch)
+        self.nsplit = (B + 63) // 64                   # batch splits of the head's weight / bias gradient (brl_ppo_heads_bwd)
+        self.dwh_partials = f(self.nsplit, K * H)
+        self.dbh_partials = f(self.nsplit, K)
+        # the step's 1024^3-class products on this library's own fp32 MFMA kernel (brl_mlp_gemm, csrc/mlp_gemm.hpp) where its
+        # fused epilogue removes a launch: dh = dz W with the activation derivative and the bias-gradient tile sums inside
+        # (replaces torch.mm + brl_act_bwd_colsum), and — sharded form — each layer's own weight gradient.  The forward layers
+        # (config["own_gemm_fwd"]: opt-in, 19.8-20.1 us per layer in the step against the tuned library kernel's 19.0-19.6) and
+        # the single-rank batched weight gradient stay with the library.
+        self.own_gemm = bool(config.get("own_gemm", True)) and B % 4 == 0 and H % 4 == 0 and nl > 1
+        self.own_fwd = self.own_gemm and bool(config.get("own_gemm_fwd", False))
+        # the head's weight-gradient role (not on the backward chain) rides with the first launch of the dz chain below the top
+        self.dw_deferred = nl > 1
+        groups64 = (B + 63) // 64                      # 64-row tiles of brl_mlp_gemm's column sums
+        self.tile_rows = [64 if (self.own_gemm and l < nl - 1) else 16 for l in range(nl)]
+        self.tile_sums = [f(groups * H) for _ in body]   # per-layer partial column sums (bias gradients)
+        # one launch finishes every sum of partials: the head's weight gradient, the hidden layers' bias gradients, the head's
+        # bias gradient — in the order they sit at the end of the flat buffer
+        nseg = nl + 2
+        self._seg_scratch = (C.c_void_p * nseg)(*([self.dwh_partials.data_ptr()] + [t.data_ptr() for t in self.tile_sums]
+                                                  + [self.dbh_partials.data_ptr()]))
+        self._seg_cols = (C.c_int64 * nseg)(*([K * H] + [H] * nl + [K]))
+        self._seg_tiles = (C.c_int64 * nseg)(*([self.nsplit] + [groups64 if r == 64 else groups for r in self.tile_rows] + [self.nsplit]))
+        self._seg_db = (C.c_void_p * nseg)(*([self.GWh.data_ptr()] + [g.data_ptr() for g in self.Gb] + [self.Gbh.data_ptr()]))
+        self._nseg = nseg
+        # The logged statistics (src/update.py:136-167) are NOT formed step by step: every step leaves its sums — 8 floats and
+        # the 38 x 38 Gram matrix of the illegal-action probabilities, reduced by spare workgroups of the head-backward
+        # launch — in row mb_index of these buffers, and ONE launch at the end of the update turns all rows into log rows
+        # (rows = minibatch steps of one update_step call; update_step rebuilds this object when an update needs more)
+        self._log_cap = max(int(config.get("update_log_capacity", 4096)), int(log_capacity))
+        self.log = f(self._log_cap, 8)
+        self.stat_sums = f(self._log_cap, 8)
+        self.gram_sums = f(self._log_cap, 38 * 38)
+        self.norm = f(1)
+        self.mb_index = torch.zeros(1, dtype=torch.int32, device=device)  # minibatch step within the current update
+        self.perm = None  # static int64 [epochs * T*N]: every epoch's permutation, filled by begin_update
+        # the step's own gather reads ITS arguments from device memory (brl_mb_gather_bind, once per update): the captured
+        # step needs no eager launch in front of it.  Until the first update: a dummy trajectory of mbs valid rows.
+        self.gargs = torch.zeros(256, dtype=torch.uint8, device=device)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)  # noqa: E731
+        dmask = z((B, 38), torch.bool)
+        dmask[:, 0] = True
+        self._dummy = (Transition(z((B,), torch.bool), z((B,), torch.int32), f(B), f(B), f(B), z((B, 480), torch.bool), dmask),
+                       f(B), f(B), (torch.arange(8 * B, device=device) % B).to(torch.int64))
+        self._bind_gather(*self._dummy)
+        d0 = opt.defaults
+        self.lr, (self.b1, self.b2), self.eps = float(d0["lr"]), d0["betas"], float(d0["eps"])
+        self.lr_dev = torch.full((1,), float(opt.param_groups[0]["lr"]), dtype=torch.float32, device=device)
+        self.max_norm = float(config["max_grad_norm"]) if config.get("global_gradient_clipping", True) else 0.0
+        self.program = self._build_program()
+        # collectives inside the graph where the backend records into one (RCCL), else eager between per-group graphs
+        want = config.get("collective_in_graph")
+        self.in_graph = (not multi) or (bool(getattr(self.coll, "capturable", False)) if want is None else bool(want))
+        self._works = {}
+        # warm-up and capture run real steps on the dummy batch: put parameters, moments and counters back afterwards
+        saved = [t.clone() for t in (self.P, self.M, self.V, self.step, self.mb_index)]
+        self.graph = self.graph_multi = self.segs = None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(3):      # (kernel groups only: the collectives of a warm-up would have to pair up across ranks)
+                    for item in self.program:
+                        if item[0] == "k":
+                            item[1]()
+            torch.cuda.current_stream().wait_stream(side)
+            from ._capture import graph_kwargs
+            gkw = graph_kwargs()
+            with quiet_gc():   # (_capture.py: no collector run while a stream captures)
+                if self.in_graph:
+                    self.graph = self._capture_steps(1, gkw)
+                    # ... and the same step K times in ONE graph: a replay boundary costs ~5 us (graph launch behind the last
+                    # kernel), the step ~0.23 ms; mb_index lives in device memory, so the K copies walk K minibatches
+                    self.multi = int(config.get("update_graph_steps", 8))
+                    if self.multi > 1:
+                        self.graph_multi = self._capture_steps(self.multi, gkw)
+                else:
+                    pool = torch.cuda.graph_pool_handle()
+                    self.segs = []          # the program with every run of kernel groups replaced by its graph
+                    run = []
+
+                    def close():
+                        if run:
+                            fns = list(run)
+                            g = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g, pool=pool, **gkw), torch.no_grad():
+                                for fn in fns:
+                                    fn()
+                            self.segs.append(("g", g))
+                            run.clear()
+                    for item in self.program:
+                        if item[0] == "k":
+                            run.append(item[1])
+                        elif item[0] == "c":
+                            close()
+                            self.segs.append(item)
+                    close()
+        finally:
+            with torch.no_grad():
+                for t, q in zip((self.P, self.M, self.V, self.step, self.mb_index), saved):
+                    t.copy_(q)
+
+    # ---- the step as a program ---------------------------------------------------------------------------------------
+    def _build_program(self):
+        """-> [("k", fn) | ("c", key, fn(async_op) -> work) | ("w", key)]: one minibatch step on the current stream"""
+        nl = self.nl
+        if self.allreduce_mode == "none":
+            return [("k", self._step_single)]
+        co, G, P = self.coll, self.G, self.P
+        if self.allreduce_mode == "flat":
+            return [("k", self._grads_chain),
+                    ("c", "ar", lambda a: co.all_reduce(G, a)), ("w", "ar"),          # SUM: the sweep scales by 1 / world
+                    ("k", lambda: (self._shard_norm(0, self.world), self._shard_apply(0, self.world)))]
+        # "sharded"
+        r = self.rank
+        bucket = lambda t, b: t[self.bucket_off[b]:self.bucket_off[b] + self.world * self.bucket_len[b]]   # noqa: E731
+        mine = lambda t, b: t[self.bucket_off[b] + r * self.bucket_len[b]:self.bucket_off[b] + (r + 1) * self.bucket_len[b]]  # noqa: E731
+        tail = nl - 1                                  # bucket index of W_0 | head | biases; bucket l - 1 = W_l
+        np_ = self.norm_partials
+        per = np_.numel() // self.world
+        prog = [("w", "ag%d" % tail), ("k", lambda: self._forward(0))]
+        for l in range(1, nl):                         # layer l multiplies with W_l: its all-gather (of the step before) must be in
+            prog += [("w", "ag%d" % (l - 1)), ("k", lambda l=l: self._forward(l))]
+        prog += [("k", self._heads)]
+        for l in range(nl - 1, 0, -1):                 # dW_l as soon as dz_l exists -> its bucket leaves; then dz_{l-1}
+            prog += [("k", lambda l=l: self._dw(l)),
+                     ("c", "rs%d" % (l - 1), lambda a, l=l: co.reduce_scatter(mine(G, l - 1), bucket(G, l - 1), a)),
+                     ("k", lambda l=l: self._dz(l))]
+        prog += [("k", lambda: (self._dw(0), self._seg_fin())),
+                 ("c", "rs%d" % tail, lambda a: co.reduce_scatter(mine(G, tail), bucket(G, tail), a))]
+        prog += [("w", "rs%d" % b) for b in range(nl)]
+        prog += [("k", lambda: self._shard_norm(r, r + 1)),
+                 ("c", "agn", lambda a: co.all_gather(np_, np_[r * per:(r + 1) * per], a)), ("w", "agn"),
+                 ("k", lambda: self._shard_apply(r, r + 1))]
+        for b in [tail] + list(range(nl - 1)):         # parameters back, in the order the next forward pass needs them
+            prog += [("c", "ag%d" % b, lambda a, b=b: co.all_gather(bucket(P, b), mine(P, b), a))]
+        return prog
+
+    def _capture_steps(self, k, gkw):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, **gkw), torch.no_grad():
+            for _ in range(k):
+                self._run_program(True)
+            self._drain()           # every forked stream joins before the capture ends
+        return g
+
+    def _run_program(self, async_op):
+        for item in self.program:
+            if item[0] == "k":
+                item[1]()
+            elif item[0] == "c":
+                w = item[2](async_op)
+                if w is not None:
+                    self._works[item[1]] = w
+            else:
+                w = self._works.pop(item[1], None)
+                if w is not None:
+                    w.wait()
+
+    def _drain(self):
+        for key in list(self._works):
+            self._works.pop(key).wait()
+
+    def _bind_gather(self, fl: Transition, adv, tgt, perm, first=True):
+        """binds the step's gather to a trajectory / permutation; ``first``: also gathers minibatch *mb_index now (every later
+        minibatch is gathered by the Adam launch of the step before it)"""
+        import ctypes as C
+        tp = self.capi.TransitionPtrs()
+        for name in self.capi.TransitionPtrs._names:
+            t = getattr(fl, name)
+            setattr(tp, name, (t.view(torch.uint8) if t.dtype == torch.bool else t).data_ptr())
+        self.capi.check(self.lib.brl_mb_gather_bind(self._di(), C.byref(tp), adv.data_ptr(), tgt.data_ptr(), perm.data_ptr(),
+                                                    self.mb_index.data_ptr(), self.mbs, self.x0.data_ptr(), self.mask.data_ptr(),
+                                                    self.action.data_ptr(), self.old_v.data_ptr(), self.old_lp.data_ptr(),
+                                                    self.adv.data_ptr(), self.tgt.data_ptr(), perm.numel() // self.mbs,
+                                                    self.gargs.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        if first:
+            self.capi.check(self.lib.brl_mb_gather_dev(self._di(), self.gargs.data_ptr(), self.mbs, torch.cuda.current_stream().cuda_stream))
+
+    def _di(self):
+        return self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+
+    # ---- kernel groups (each on the current stream) --------------------------------------------------------------------
+    def _step_single(self):
+        """single rank: forward, heads, the dz chain, the batched weight gradients, sums of partials inside the norm launch, clip +
+        Adam (+ the next gather)"""
+        for l in range(self.nl):
+            self._forward(l)
+        self._heads()
+        self._backward_chain()
+        self._fin_opt()
+
+    def _grads_chain(self):
+        """multi-rank "flat" form: everything that produces this rank's gradient, by the SAME launches as the sharded form (a weight
+        gradient per layer, not the single-rank batched product: the two forms then reduce bit-identical gradients), the sums of
+        partials as a launch of their own (they must exist before the all-reduce)"""
+        for l in range(self.nl):
+            self._forward(l)
+        self._heads()
+        for l in range(self.nl - 1, 0, -1):
+            self._dw(l)
+            self._dz(l)
+        self._dw(0)
+        self._seg_fin()
+
+    def _forward(self, l):
+        """h_l = act(h_{l-1} W_l^T + b_l); layer 0 reads the minibatch the previous step's Adam launch (or the bind) gathered"""
+        x = self.x0 if l == 0 else self.h[l - 1]
+        W, b = self.W[l], self.b[l]
+        if self.own_fwd and l > 0:                            # own kernel: bias + activation in its epilogue
+            self.capi.check(self.lib.brl_mlp_gemm(self._di(), 0, 1, x.data_ptr(), x.stride(0), W.data_ptr(), W.stride(0),
+                                                  self.h[l].data_ptr(), self.h[l].stride(0), self.mbs, W.shape[0], W.shape[1], self.act,
+                                                  b.data_ptr(), None, 0, None, None, torch.cuda.current_stream().cuda_stream))
+        elif self.act == 0:                                   # ReLU in the GEMM epilogue
+            torch._addmm_activation(b, x, W.t(), use_gelu=False, out=self.h[l])
+        else:
+            torch.addmm(b, x, W.t(), out=self.h[l]).tanh_()
+
+    def _heads(self):
+        """heads + `_loss_fn` + output gradients (two launches), backward of the merged head down to the top hidden layer's
+        pre-activation (one launch)"""
+        L, chk, B = self.lib, self.capi.check, self.mbs
+        s = torch.cuda.current_stream().cuda_stream
+        di, cfg = self._di(), self.cfg
+        x = self.h[self.nl - 1]
+        chk(L.brl_ppo_heads_loss_split(di, x.data_ptr(), x.stride(0), self.Wh.data_ptr(), self.bh.data_ptr(), self.H,
+                                       self.mask.data_ptr(), self.action.data_ptr(), self.old_v.data_ptr(), self.old_lp.data_ptr(),
+                                       self.adv.data_ptr(), self.tgt.data_ptr(), B, float(cfg["clip_eps"]), float(cfg["vf_coef"]),
+                                       float(cfg["ent_coef"]), int(bool(cfg.get("actor_illegal_action_mask", True))),
+                                       int(bool(cfg.get("value_clipping", True))), int(bool(cfg.get("reward_scaling", False))),
+                                       self.heads.data_ptr() if self.ill_coef else None,
+                                       self.dheads.data_ptr(), self.partials.data_ptr(), self.gram_partials.data_ptr(),
+                                       self.head_parts.data_ptr(), self.head_ksplit, s))
+        if self.ill_coef:
+            # src/update.py:146-152: + coef * sigma_1(P) / 2 — its gradient needs the step's top singular pair NOW (the logged
+            # statistics otherwise wait for the end of the update): one stats launch on the critical path of this configuration
+            chk(L.brl_ppo_stats_gram(di, self.partials.data_ptr(), self.lgroups, B, self.gram_partials.data_ptr(), self.lgroups,
+                                     float(cfg["vf_coef"]), float(cfg["ent_coef"]), self.ill_coef, self.out.data_ptr(), None,
+                                     self.vec.data_ptr(), s))
+            chk(L.brl_ppo_illegal_grad(di, self.heads.data_ptr(), self.mask.data_ptr(), self.vec.data_ptr(), self.ill_coef, B,
+                                       self.dheads.data_ptr(), s))
+        # backward of the head, written out: dz of the top hidden layer (activation derivative applied) and its bias-gradient tile
+        # sums; with one hidden layer only also dW_h / db_h partials per batch split (else they ride with the first dz launch)
+        top = self.nl - 1
+        chk(L.brl_ppo_heads_bwd(di, self.dheads.data_ptr(), x.data_ptr(), x.stride(0), self.Wh.data_ptr(), B, self.H, self.act,
+                                self.nsplit, None if self.dw_deferred else self.dwh_partials.data_ptr(),
+                                None if self.dw_deferred else self.dbh_partials.data_ptr(),
+                                self.dzs[top].data_ptr(), self.tile_sums[top].data_ptr(), self.partials.data_ptr(),
+                                self.gram_partials.data_ptr(), self.lgroups, self.mb_index.data_ptr(), self.stat_sums.data_ptr(),
+                                self.gram_sums.data_ptr(), s))
+
+    def _dz(self, l):
+        """dz_{l-1} = (dz_l W_l) * act'(h_{l-1}) + the tile sums of db_{l-1}; the first of the chain (l = nl - 1) also hosts the head's
+        dW_h / db_h partials and the step's statistics sums as extra workgroups"""
+        L, chk, B, H = self.lib, self.capi.check, self.mbs, self.H
+        s = torch.cuda.current_stream().cuda_stream
+        di = self._di()
+        first = l == self.nl - 1 and self.dw_deferred
+        top = self.h[self.nl - 1]
+        dz, out, W, gate, ts = self.dzs[l], self.dzs[l - 1], self.W[l], self.h[l - 1], self.tile_sums[l - 1]
+        heads_dw = (self.dheads.data_ptr(), top.data_ptr(), top.stride(0), B, H, self.nsplit, self.dwh_partials.data_ptr(),
+                    self.dbh_partials.data_ptr(), self.partials.data_ptr(), self.gram_partials.data_ptr(), self.lgroups,
+                    self.mb_index.data_ptr(), self.stat_sums.data_ptr(), self.gram_sums.data_ptr(), s)
+        if self.own_gemm:
+            if first:
+                chk(L.brl_mlp_gemm_dh_heads_dw(di, dz.data_ptr(), H, W.data_ptr(), W.stride(0), out.data_ptr(), H, B, W.shape[1], W.shape[0],
+                                               self.act, gate.data_ptr(), H, ts.data_ptr(), *heads_dw))
+            else:
+                chk(L.brl_mlp_gemm(di, 1, 2, dz.data_ptr(), H, W.data_ptr(), W.stride(0), out.data_ptr(), H, B, W.shape[1], W.shape[0],
+                                   self.act, None, gate.data_ptr(), H, ts.data_ptr(), None, s))
+            return
+        torch.mm(dz, W, out=out)
+        if first:
+            chk(L.brl_act_bwd_colsum_heads_dw(di, out.data_ptr(), gate.data_ptr(), B, H, H, self.act, ts.data_ptr(), *heads_dw))
+        else:
+            chk(L.brl_act_bwd_colsum(di, out.data_ptr(), gate.data_ptr(), B, H, H, self.act, ts.data_ptr(), s))
+
+    def _dw(self, l):
+        """dW_l = dz_l^T h_{l-1} as a product of its own (sharded form: the layer's bucket leaves as soon as it exists)"""
+        src = self.x0 if l == 0 else self.h[l - 1]
+        if self.own_gemm and l > 0:
+            dz, GW = self.dzs[l], self.GW[l]
+            self.capi.check(self.lib.brl_mlp_gemm(self._di(), 2, 0, dz.data_ptr(), dz.stride(0), src.data_ptr(), src.stride(0),
+                                                  GW.data_ptr(), GW.stride(0), GW.shape[0], GW.shape[1], self.mbs, self.act, None, None, 0,
+                                                  None, None, torch.cuda.current_stream().cuda_stream))
+        else:
+            torch.mm(self.dzs[l].t(), src, out=self.GW[l])
+
+    def _backward_chain(self):
+        """the dz chain first (dz_l for every layer), then the weight gradients — layers 1.. as ONE batched product (three 1024^3
+        products: 46-48 us instead of 3 x 19-21, scripts/bmm_probe.py), layer 0 (K = 480 columns) beside it"""
+        nl = self.nl
+        for l in range(nl - 1, 0, -1):
+            self._dz(l)
+        if nl > 1:
+            torch.bmm(self.dzs[1:].transpose(1, 2), self.hs[:nl - 1], out=self.GW_hidden)
+        torch.mm(self.dzs[0].t(), self.x0, out=self.GW[0])
+
+    def _seg_fin(self):
+        self.capi.check(self.lib.brl_bias_finalize_ex(self._di(), self._nseg, self._seg_scratch, self._seg_cols, self._seg_tiles,
+                                                      self._seg_db, torch.cuda.current_stream().cuda_stream))
+
+    def _fin_opt(self):
+        """single rank: every sum of partials is finished by extra workgroups of the norm launch (brl_adam_clip_fin_gather)"""
+        self.capi.check(self.lib.brl_adam_clip_fin_gather(
+            self._di(), self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), self.n, self.step.data_ptr(), self.lr,
+            self.lr_dev.data_ptr(), float(self.b1), float(self.b2), self.eps, self.max_norm, self.scratch.data_ptr(),
+            self.scratch.numel(), self.mb_index.data_ptr(), self.norm.data_ptr(), self.gargs.data_ptr(), self.mbs, self._nseg,
+            self._seg_scratch, self._seg_cols, self._seg_tiles, self._seg_db, torch.cuda.current_stream().cuda_stream))
+
+    def _shard_norm(self, lo, hi):
+        import ctypes as C
+        self.capi.check(self.lib.brl_adam_shard_norm(self._di(), self.G.data_ptr(), C.byref(self.geom), lo, hi, 1.0 / self.world,
+                                                     self.norm_partials.data_ptr(), self.step.data_ptr(), self.mb_index.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream))
+
+    def _shard_apply(self, lo, hi):
+        import ctypes as C
+        self.capi.check(self.lib.brl_adam_shard_apply(
+            self._di(), self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), C.byref(self.geom), lo, hi,
+            self.norm_partials.data_ptr(), self.step.data_ptr(), self.lr, self.lr_dev.data_ptr(), float(self.b1), float(self.b2),
+            self.eps, self.max_norm, 1.0 / self.world, self.norm.data_ptr(), self.gargs.data_ptr(), self.mbs,
+            torch.cuda.current_stream().cuda_stream))
+
+    # ---- one update_step call -----------------------------------------------------------------------------------
+    def begin_update(self, flat: Transition, adv_f, tgt_f, perms):
+        """flat: the [T*N, ...] views of the trajectory; adv_f / tgt_f: [T*N]; perms: one permutation of T*N per epoch.
+        Binds the step's gather to them (device-resident arguments) and resets the minibatch counter."""
+        steps = sum(p.numel() for p in perms) // self.mbs
+        if steps > self._log_cap:   # (checked before anything is touched; update_step never gets here: it rebuilds first)
+            raise RuntimeError("FusedMinibatch: more minibatch steps per update than its log holds (log_capacity)")
+        self._keep = (Transition(*[x.contiguous() for x in flat]), adv_f.contiguous(), tgt_f.contiguous())
+        fl, adv_c, tgt_c = self._keep
+        self._steps = steps
+        with torch.no_grad():
+            self._readopt()
+            allp = torch.cat(perms)
+            if self.perm is None or self.perm.numel() != allp.numel():
+                self.perm = torch.empty_like(allp)
+            self.perm.copy_(allp)
+            self.mb_index.zero_()
+            self.step.copy_(self.opt.state[self.plist[0]]["step"])  # the optimizer may have been stepped eagerly / loaded
+            self.lr_dev.fill_(float(self.opt.param_groups[0]["lr"]))  # constant within an update (ppo.py:186-192)
+            self._bind_gather(fl, adv_c, tgt_c, self.perm)
+
+    def _readopt(self):
+        """`opt.load_state_dict` (resume) or a foreign `p.data = ...` replaces tensors that were views of the flat buffers:
+        copy their contents in and point them back at the buffers (addresses are baked into the graph)."""
+        for q in self.plist:
+            sl = self.views[q]
+            if q.data.data_ptr() != self.P[sl].data_ptr():
+                self.P[sl].copy_(q.data.reshape(-1))
+                q.data = self.P[sl].view(q.shape)
+            st = self.opt.state.get(q)
+            if st is None or "exp_avg" not in st:
+                self.M[sl].zero_(); self.V[sl].zero_()
+                self.opt.state[q] = {"step": torch.zeros((), dtype=torch.float32, device=self.dev),
+                                     "exp_avg": self.M[sl].view(q.shape), "exp_avg_sq": self.V[sl].view(q.shape)}
+                continue
+            if st["exp_avg"].data_ptr() != self.M[sl].data_ptr():
+                self.M[sl].copy_(st["exp_avg"].reshape(-1))
+                self.V[sl].copy_(st["exp_avg_sq"].reshape(-1))
+                st["exp_avg"], st["exp_avg_sq"] = self.M[sl].view(q.shape), self.V[sl].view(q.shape)
+            if not torch.is_tensor(st["step"]) or st["step"].device != self.P.device:
+                st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=self.dev).reshape(())
+
+    def run_steps(self, n: int):
+        """the next n minibatch steps of the bound update"""
+        if self.in_graph:
+            k = self.multi if self.graph_multi is not None else 0
+            while k and n >= k:
+                self.graph_multi.replay()
+                n -= k
+            for _ in range(n):
+                self.graph.replay()
+            return
+        for _ in range(n):          # a backend that cannot be captured: graphs of kernel groups, eager blocking collectives between
+            for item in self.segs:
+                if item[0] == "g":
+                    item[1].replay()
+                else:
+                    w = item[2](False)
+                    if w is not None:
+                        w.wait()
+
+    def gather_optimizer_state(self):
+        """"sharded": Adam's moments are current on this rank's slices only — before the optimizer state is SAVED, every rank
+        calls this (a collective: two all-gathers per bucket) and ends with the complete moments, as in the replicated forms."""
+        if self.allreduce_mode != "sharded":
+            return
+        r = self.rank
+        for t in (self.M, self.V):
+            for o, ln in zip(self.bucket_off, self.bucket_len):
+                w = self.coll.all_gather(t[o:o + self.world * ln], t[o + r * ln:o + (r + 1) * ln], False)
+                if w is not None:
+                    w.wait()
+
+    def end_update(self):
+        """-> the [steps, 8] log of the update (total, value_loss, loss_actor, entropy, approx_kl, clipfrac, illegal-action
+        norm / 2, 0): ONE launch over the sums the steps left behind"""
+        with torch.no_grad():  # every parameter's step counter (torch keeps one per parameter)
+            for q in self.plist:
+                self.opt.state[q]["step"].copy_(self.step)
+            self.capi.check(self.lib.brl_ppo_stats_rows(self._di(), self.stat_sums.data_ptr(), self.gram_sums.data_ptr(), self._steps,
+                                                        self.mbs, float(self.cfg["vf_coef"]), float(self.cfg["ent_coef"]),
+                                                        self.ill_coef, self.log.data_ptr(),
+                                                        torch.cuda.current_stream().cuda_stream))
+            self._bind_gather(*self._dummy, first=False)   # (the trajectory may be freed by the caller now)
+        self._keep = None
+        return self.log[:self._steps]

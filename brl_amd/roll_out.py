@@ -279,10 +279,8 @@ class _PolicyRollout:
         torch.cuda.current_stream().wait_stream(side)
         pool = torch.cuda.graph_pool_handle()
         graphs = []
-        import torch.distributed as dist
-        # (under a process group the NCCL watchdog thread touches the device while this thread captures)
-        gkw = {"capture_error_mode": "thread_local"} if (dist.is_available() and dist.is_initialized()) else {}
-        from ._capture import quiet_gc
+        from ._capture import graph_kwargs, quiet_gc
+        gkw = graph_kwargs()   # (thread-local error mode only beside an RCCL watchdog thread: _capture.py)
         with torch.no_grad(), quiet_gc():   # (a graph freed by the collector mid-capture would abort the process: _capture.py)
             for t0 in range(0, self.T, self.graph_steps):   # (a replay boundary costs ~8 us of idle GPU: several scan steps per graph)
                 g = torch.cuda.CUDAGraph()

@@ -47,11 +47,14 @@ extern "C" {
 typedef struct brl_handle brl_handle;
 
 const char *brl_last_error(void);
-/* The version of the EXPORTED SET: the number of the build round in which a symbol was last added, removed or changed (4 now).
- * Under ONE version a symbol's signature and meaning never change; a changed form normally gets a new name and the old one moves
- * to the "superseded forms" section at the end of this header until nothing uses it.  Version 4 against version 3: added the
- * brl_mlp_gemm family, brl_mlp_forward_rows, brl_adam_clip_fin_gather_defer, brl_adam_apply_range, brl_ppo_heads_loss_parts;
- * removed brl_ppo_stats_at and brl_bias_finalize; brl_live_index gained `tag`, brl_eval_step_team gained `obs_f32` (both before `stream`). */
+/* The version of the EXPORTED SET: the number of the build round in which a symbol was last added, removed or changed (5 now).
+ * Under ONE version a symbol's signature and meaning never change.  Version 5 against version 4 — the boundary is the path, the
+ * experiment log (profiles/r04/r04_experiments.txt) keeps what was measured and dropped:
+ *   removed (fusions of the PPO step that measured no faster): brl_mlp_gemm_bwd_pair, brl_mlp_gemm_fwd_heads,
+ *     brl_ppo_heads_loss_parts, brl_adam_clip_fin_gather_defer, brl_mlp_gemm_adam, brl_adam_apply_range;
+ *   removed (superseded forms): brl_ppo_loss_heads, brl_mb_gather, brl_relu_bwd_colsum, brl_adam_clip, brl_ppo_heads_loss,
+ *     brl_adam_clip_gather (the multi-rank Adam: replaced by the two below);
+ *   added: brl_adam_shard_norm, brl_adam_shard_apply (clip + Adam on a rank's slices of the bucketed flat buffers). */
 int brl_version(void);
 
 /* BridgeBidding(dds_results_table_path)  — ppo.py:303, pgx.bridge_bidding.BridgeBidding.
@@ -365,21 +368,19 @@ int brl_ppo_stats(int device, const float *partials, int64_t batch, const float 
                   float *out, void *stream);
 
 /* ---- one PPO minibatch step without the small launches (src/update.py:74-242; brl_amd/update.py::FusedMinibatch strings
- * these together with the 14 GEMMs of the 4 x 1024 MLP and captures the step in one hipGraph) ---------------------------- */
+ * these together with the GEMMs of the 4 x 1024 MLP and captures the step in one hipGraph) ------------------------------------- */
 
+/* ---- the 39-column head (38 logits + value, src/models.py:30-33) of one PPO minibatch step as three entry points instead of
+ * four library GEMMs with N or K = 39 and five small kernels (brl_amd/csrc/ppo_heads.hpp) -------------------------------------- */
 
-
-
-
-
-
-/* ---- the 39-column head (38 logits + value, src/models.py:30-33) of one PPO minibatch step as three launches instead of four
- * library GEMMs with N or K = 39 and five small kernels (brl_amd/csrc/ppo_heads.hpp) ------------------------------------- */
-
-/* The same as TWO launches: the heads product split over K across workgroups (ksplit ranges, 1..8; 4 at hidden = 1024) into
- * head_parts float [ksplit, batch, 39] (scratch), then the loss on bias + the parts added in order.  One workgroup of the
- * one-launch form pulls all of W_h through its CU before it can start (9.3 k of its 24.4 k cycles); here a workgroup reads a
- * ksplit-th of it.  Same results up to the order of the fp32 sums over K. */
+/* heads = h head_w^T + head_b (h float [batch, ldh >= hidden], the last hidden layer's output; head_w float [39, hidden] = actor
+ * rows then the critic row; head_b float [39]; hidden % 16 == 0), then `_loss_fn` (src/update.py:90-167) exactly as brl_ppo_loss
+ * on that matrix (logits = columns 0..37, value = column 38).  TWO launches: the heads product split over K across workgroups
+ * (ksplit ranges, 1..8; 4 at hidden = 1024) into head_parts float [ksplit, batch, 39] (scratch), then the loss on head_b + the
+ * parts added in order.  Outputs: dheads float [batch,39] = d(total)/d(heads); partials float [ceil(batch / 4) * 8] for
+ * brl_ppo_stats_gram; gram_partials (may be NULL) float [ceil(batch / 4) * 1444]: per 4-sample group, P^T P of its
+ * illegal-action probabilities (src/update.py:136-141); heads_out (may be NULL) float [batch,39].  reward_scaling != 0: the
+ * advantages are normalised over the minibatch first, (gae - mean) / (std + 1e-8) with jnp's ddof = 0 (src/update.py:31-44,118). */
 int brl_ppo_heads_loss_split(int device, const float *h, int64_t ldh, const float *head_w, const float *head_b, int64_t hidden,
                        const uint8_t *mask, const int32_t *action, const float *old_value, const float *old_log_prob,
                        const float *gae, const float *targets, int64_t batch, float clip_eps, float vf_coef, float ent_coef,
@@ -391,8 +392,8 @@ int brl_ppo_heads_loss_split(int device, const float *h, int64_t ldh, const floa
  * per batch split of <= 64 rows (brl_bias_finalize_ex adds the splits in order: deterministic); dh float [batch, hidden] =
  * (d(heads) head_w) * act'(h) — act 0: ReLU (h > 0), 1: tanh (1 - h^2), src/models.py:16 —, i.e. the gradient w.r.t. the
  * last hidden layer's pre-activation, and tile_sums float [ceil(batch / 16), hidden]: its column sums per 16-row tile
- * (that layer's bias gradient, same layout as brl_relu_bwd_colsum's scratch).  hidden % 256 == 0.
- * gram_sums != NULL: the same launches also add up brl_ppo_heads_loss's loss_partials float [ngroups,8] and gram_partials float
+ * (that layer's bias gradient, same layout as brl_act_bwd_colsum's scratch).  hidden % 256 == 0.
+ * gram_sums != NULL: the same launches also add up brl_ppo_heads_loss_split's loss_partials float [ngroups,8] and gram_partials float
  * [ngroups,1444] (in group order) into row *row_index (device memory) of stat_sums float [rows,8] / gram_sums float [rows,1444]:
  * the statistics of a whole update are then formed by ONE brl_ppo_stats_rows at its end instead of a launch per step. */
 /* (dw_partials = db_partials = NULL: only the activation-gradient role is launched — see brl_act_bwd_colsum_heads_dw) */
@@ -410,7 +411,7 @@ int brl_ppo_stats_gram(int device, const float *partials, int64_t npartials, int
                        float *vec_out, void *stream);
 
 /* illegal_action_l2norm_coef != 0 (src/update.py:146-152): adds d(illegal_coef * sigma_1(P) / 2) / d(logits) to dheads float
- * [batch,39] in place — heads float [batch,39] as brl_ppo_heads_loss wrote them (heads_out), vec = brl_ppo_stats_gram's vec_out of
+ * [batch,39] in place — heads float [batch,39] as brl_ppo_heads_loss_split wrote them (heads_out), vec = brl_ppo_stats_gram's vec_out of
  * the same minibatch (the top right singular vector and sigma_1: d sigma_1 / dP = u1 v1^T with u1 = P v1 / sigma_1). */
 int brl_ppo_illegal_grad(int device, const float *heads, const uint8_t *mask, const float *vec, float illegal_coef, int64_t batch,
                          float *dheads, void *stream);
@@ -420,17 +421,21 @@ int brl_ppo_illegal_grad(int device, const float *heads, const uint8_t *mask, co
 int brl_ppo_stats_rows(int device, const float *stat_sums, const float *gram_sums, int64_t rows, int64_t batch, float vf_coef,
                        float ent_coef, float illegal_coef, float *out_rows, void *stream);
 
-/* brl_mb_gather with its arguments in DEVICE memory: brl_mb_gather_bind writes them into args_dev (256 bytes, stream-ordered:
- * a one-thread launch, no host copy) once per update; brl_mb_gather_dev(args_dev) is then a launch whose parameters never
- * change, so it can live inside the captured minibatch step and follow a new trajectory / permutation (src/update.py:193-206).
- * nsteps = the minibatches `perm` holds: brl_adam_clip_gather's gather of a minibatch >= nsteps is skipped. */
+/* `shuffled = take(batch, permutation)` + the slice of minibatch *mb_index (src/update.py:193-206): row perm[*mb_index * mbs + b]
+ * of the flattened [T*N] trajectory `flat` (and of adv / targets) -> the static minibatch buffers; x0 float [mbs,480] =
+ * obs.astype(float32) (src/update.py:95).  The launch reads its arguments from DEVICE memory: brl_mb_gather_bind writes them into
+ * args_dev (256 bytes, stream-ordered: a one-thread launch, no host copy) once per update; brl_mb_gather_dev(args_dev) is then a
+ * launch whose parameters never change, so it lives inside the captured minibatch step and follows a new trajectory /
+ * permutation.  mb_index is DEVICE memory (the Adam entry points advance it): a captured graph walks through an epoch by itself.
+ * nsteps = the minibatches `perm` holds: the Adam launch's gather of a minibatch >= nsteps is skipped. */
 int brl_mb_gather_bind(int device, const brl_transition *flat, const float *adv, const float *targets, const int64_t *perm,
                        const int32_t *mb_index, int64_t mbs, float *x0, uint8_t *mask, int32_t *action, float *old_value,
                        float *old_log_prob, float *gae_out, float *targets_out, int64_t nsteps, void *args_dev, void *stream);
 int brl_mb_gather_dev(int device, const void *args_dev, int64_t mbs, void *stream);
 
-/* brl_relu_bwd_colsum's tile pass for either activation: dh [rows,ld] *= act'(h) in place (act 0: ReLU, 1: tanh) and the
- * column sums of every 16-row tile into scratch float [ceil(rows / 16), cols]; cols and ld multiples of 4. */
+/* Backward of `h = act(z)` plus the bias gradient's partials of that layer (where brl_mlp_gemm's GATE_COLSUM epilogue does not do
+ * it): dh [rows,ld] *= act'(h) in place (act 0: ReLU, 1: tanh) and the column sums of every 16-row tile into scratch float
+ * [ceil(rows / 16), cols]; cols and ld multiples of 4. */
 int brl_act_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, int act, float *scratch,
                        void *stream);
 /* brl_act_bwd_colsum of ONE hidden layer with the weight-gradient role of brl_ppo_heads_bwd (dW_h / db_h partials + the step's
@@ -449,23 +454,49 @@ int brl_act_bwd_colsum_heads_dw(int device, float *dz, const float *hh, int64_t 
 int brl_bias_finalize_ex(int device, int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles,
                          float *const *out, void *stream);
 
-/* brl_adam_clip whose second launch ALSO gathers the NEXT minibatch (extra workgroups beside the parameter update: the rows
- * are pure latency, 5.6 us as a launch of their own): gather_args as written by brl_mb_gather_bind, mbs its minibatch size.
- * mb_index (required) is advanced by the FIRST launch, so the gather reads minibatch *mb_index of the bound permutation; the
- * first minibatch of an update is gathered by one brl_mb_gather_dev after the bind. */
-int brl_adam_clip_gather(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
-                         const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale, float *scratch,
-                         int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs, void *stream);
-/* brl_bias_finalize_ex + brl_adam_clip_gather as two launches instead of three (single rank: nothing sits between the finished
- * sums and the clip): the `nseg` segments (arguments as brl_bias_finalize_ex) must be exactly the END of the gradient buffer g
- * (the head's weight gradient + every bias gradient in FusedMinibatch's flat layout, up to the buffer's zero padding); the norm
- * launch square-sums everything in front of them as it stands and finishes + square-sums the segments itself.  scratch: at
- * least 1024 + sum over the segments of ceil(cols / 64) floats.  gather_args may be NULL (then mbs is ignored). */
+/* optax.chain(clip_by_global_norm(max_norm), adam(lr, eps)) (ppo.py:195-211) on FLAT fp32 buffers of n elements (n a multiple of
+ * 4: pad with zeros), single rank, two launches.  Launch 1: *step (device float) += 1, *mb_index += 1 (may be NULL), the `nseg`
+ * sums of partials (arguments as brl_bias_finalize_ex; they must be exactly the END of the gradient buffer g — the head's weight
+ * gradient + every bias gradient in FusedMinibatch's flat layout, up to the buffer's zero padding) and the partial square sums of
+ * the whole gradient.  Launch 2: the gradient scaled by min(1, max_norm / (|g| + 1e-6)) (max_norm <= 0: no clipping); m, v, p
+ * updated with torch.optim.Adam's arithmetic; extra workgroups gather the NEXT minibatch (gather_args as written by
+ * brl_mb_gather_bind, mbs its minibatch size; the first minibatch of an update is gathered by one brl_mb_gather_dev after the
+ * bind; gather_args may be NULL).  lr_dev (may be NULL): the learning rate in device memory, used instead of `lr` (a captured
+ * launch then follows ppo.py:186-192's linear schedule).  scratch: at least 1024 + sum over the segments of ceil(cols / 64)
+ * floats.  norm_out (may be NULL): |g| before clipping. */
 int brl_adam_clip_fin_gather(int device, float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
                              const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float *scratch,
                              int64_t scratch_len, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs,
                              int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles, float *const *out,
                              void *stream);
+
+/* The same under a process group (ppo.py has no counterpart: the reference is single-device; SURVEY section 8e: the gradient of
+ * the flat buffers crosses xGMI once per minibatch).  The flat buffers are cut into `nbuckets` BUCKETS — one per collective —
+ * and every bucket into `world` equal SLICES: bucket b = floats [off[b], off[b] + world * len[b]), slice r of it = what rank r
+ * holds after a reduce-scatter of the bucket (off, len multiples of 4).
+ *   brl_adam_shard_norm: partials[(r * nbuckets + b) * nsub + j] = the squares of sub-block j of slice (r, b) of grad_scale * g,
+ *     for r in [rank_lo, rank_hi); *step += 1, *mb_index += 1 (may be NULL).  A rank that owns only its reduced slices computes
+ *     its own row (rank_lo = rank, rank_hi = rank + 1) and an all-gather of world * nbuckets * nsub floats completes the array;
+ *     a rank that holds the whole all-reduced gradient computes all rows — the SAME array either way.
+ *   brl_adam_shard_apply: clip (norm = sqrt of the sum of ALL partials, added in a fixed order) + Adam on the slices of ranks
+ *     [rank_lo, rank_hi); g is addressed like p (the reduce-scatter is in place); grad_scale = 1 / world after a SUM reduction;
+ *     gather_args / mbs / lr_dev / norm_out as brl_adam_clip_fin_gather.
+ * Sharded form of a step: reduce-scatter per bucket, norm of the own slices, all-gather of the partials, apply on the own slices,
+ * all-gather of the parameters per bucket.  Replicated form: all-reduce, norm and apply with rank_lo = 0, rank_hi = world.
+ * Both give bit-identical parameters (given the same reduced gradient). */
+typedef struct brl_shard_geom {
+  int32_t nbuckets;   /* 1..12 */
+  int32_t world;
+  int32_t nsub;       /* norm sub-blocks per slice */
+  int32_t reserved;
+  int64_t off[12];    /* first float of bucket b */
+  int64_t len[12];    /* floats per SLICE of bucket b */
+} brl_shard_geom;
+int brl_adam_shard_norm(int device, const float *g, const brl_shard_geom *geom, int rank_lo, int rank_hi, float grad_scale,
+                        float *partials, float *step, int32_t *mb_index, void *stream);
+int brl_adam_shard_apply(int device, float *p, const float *g, float *m, float *v, const brl_shard_geom *geom, int rank_lo, int rank_hi,
+                         const float *partials, const float *step, float lr, const float *lr_dev, float beta1, float beta2, float eps,
+                         float max_norm, float grad_scale, float *norm_out, const void *gather_args, int64_t mbs, void *stream);
 
 /* ---- round 4: the step's fp32 GEMMs with the elementwise work of src/update.py:74-242 in their epilogues -------------------
  * One fp32 product C[m,n] (row-major, ldc) on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, a k-ordered fma chain per
@@ -527,118 +558,6 @@ typedef struct brl_mlp_ref {
 } brl_mlp_ref;
 int brl_mlp_forward_rows(int device, const brl_mlp_ref *net, const uint8_t *obs, const int64_t *rows, int64_t m, float *scratch,
                          int64_t scratch_len, float *out, int64_t ldo, void *stream);
-
-/* ==================================================================================================================
- * OPT-IN VARIANTS — fusions of the PPO minibatch step that were built, checked bit for bit against the default path (tests) and
- * measured NO FASTER inside the step (profiles/r04/r04_experiments.txt): the default brl_amd code path
- * calls none of them; FusedMinibatch takes them under config["bwd_pair"], ["fuse_heads_fwd"], ["adam_ride"].
- * ================================================================================================================== */
-
-/* The two backward products of one hidden layer in ONE launch (both read dz [batch, n_out] and h_prev [batch, n_in] = the output of
- * the layer below): dz_out [batch, n_in] = (dz w) * act'(h_prev) with w [n_out, n_in] (+ colsum [ceil(batch / 64), n_in], may be
- * NULL), and dw_out [n_out, n_in] = dz^T h_prev (+ sqsum [ceil(n_out / 64) * ceil(n_in / 32)], may be NULL).  dheads != NULL: the
- * weight-gradient role of brl_ppo_heads_bwd rides too (arguments as brl_act_bwd_colsum_heads_dw).  Replaces torch.mm +
- * brl_act_bwd_colsum and one third of FusedMinibatch's batched weight-gradient product (src/update.py:86-178 under jax.grad). */
-int brl_mlp_gemm_bwd_pair(int device, const float *dz, int64_t lddz, const float *w, int64_t ldw, const float *h_prev, int64_t ldh,
-                          float *dz_out, int64_t ldo, float *dw_out, int64_t lddw, int64_t batch, int64_t n_out, int64_t n_in, int act,
-                          float *colsum, float *sqsum, const float *dheads, const float *h_top, int64_t ldht, int64_t hidden,
-                          int nsplit, float *dwh_partials, float *dbh_partials, const float *loss_partials,
-                          const float *gram_partials, int64_t ngroups, const int32_t *row_index, float *stat_sums, float *gram_sums,
-                          void *stream);
-
-/* The last hidden layer of the forward pass (brl_mlp_gemm NT + bias + activation, 64 x 64 tiles) with its share of the 39-column
- * head product in the epilogue: head_parts [nparts][m, 39], nparts = ceil(n / 64) or ceil(n / 32) (= the tile width the launch
- * uses), with sum over the parts = c head_w^T (head_w [39, ldhw] =
- * actor rows then the critic row, src/models.py:30-33); brl_ppo_heads_loss_parts then is brl_ppo_heads_loss_split without its
- * product launch: heads = head_b + parts[0] + parts[1] + ... in that order (nparts <= 32). */
-int brl_mlp_gemm_fwd_heads(int device, const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int64_t m,
-                           int64_t n, int64_t k, int act, const float *bias, const float *head_w, int64_t ldhw, float *head_parts,
-                           int nparts, void *stream);
-int brl_ppo_heads_loss_parts(int device, const float *head_b, const float *head_parts, int nparts, const uint8_t *mask,
-                             const int32_t *action, const float *old_value, const float *old_log_prob, const float *gae,
-                             const float *targets, int64_t batch, float clip_eps, float vf_coef, float ent_coef, int masked,
-                             int value_clipping, int reward_scaling, float *heads_out, float *dheads, float *partials,
-                             float *gram_partials, void *stream);
-
-/* ---- the Adam sweep off the step's dependency chain (round 4) ----------------------------------------------------------------
- * brl_adam_clip_fin_gather whose apply launch leaves out the floats [defer_lo, defer_hi) of the flat buffers (multiples of 4) and
- * sets *pending = 1: that part of the sweep is owed.  It is paid, layer by layer, by extra workgroups of the NEXT step's forward
- * launches (brl_mlp_gemm_adam: the launch that multiplies with layer l's weights updates layer l + 1's) or, where no step follows,
- * by brl_adam_apply_range.  The norm partials in `scratch`, *step and the gradients of the range stay untouched until then (the
- * next step rewrites them only at its own end).  npartials of those calls = 1024 + sum over the segments of ceil(cols / 64). */
-int brl_adam_clip_fin_gather_defer(int device, float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
-                                   const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float *scratch,
-                                   int64_t scratch_len, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs,
-                                   int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles, float *const *out,
-                                   int64_t defer_lo, int64_t defer_hi, int32_t *pending, void *stream);
-/* brl_mlp_gemm(BRL_GEMM_NT, BRL_GEMM_EPI_BIAS_ACT, ...) — one forward layer — with clip + Adam on the floats [lo, hi) of the flat
- * buffers as extra workgroups of the same launch, applied only where *pending != 0.  The range must not contain the weights the
- * launch multiplies with. */
-int brl_mlp_gemm_adam(int device, const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int64_t m, int64_t n,
-                      int64_t k, int act, const float *bias, float *p, const float *g, float *mom, float *var, int64_t lo, int64_t hi,
-                      const float *scratch, int npartials, const float *step, float lr, const float *lr_dev, float beta1, float beta2,
-                      float eps, float max_norm, float grad_scale, const int32_t *pending, void *stream);
-/* The owed range as a launch of its own (pending may be NULL: unconditional); clear_pending: a one-thread launch behind it sets
- * *pending = 0. */
-int brl_adam_apply_range(int device, float *p, const float *g, float *m, float *v, int64_t lo, int64_t hi, const float *scratch,
-                         int npartials, const float *step, float lr, const float *lr_dev, float beta1, float beta2, float eps,
-                         float max_norm, float grad_scale, int32_t *pending, int clear_pending, void *stream);
-
-/* ==================================================================================================================
- * SUPERSEDED FORMS — still exported because tests use them as the reference form of their successors and the A/B scripts
- * under scripts/ time them; the default brl_amd code path calls none of them.  Successors: brl_ppo_loss_heads ->
- * brl_ppo_heads_loss_split (heads formed inside); brl_mb_gather -> brl_mb_gather_bind / _dev (device-resident arguments);
- * brl_relu_bwd_colsum -> brl_act_bwd_colsum (either activation) -> brl_mlp_gemm's GATE_COLSUM epilogue;
- * brl_bias_finalize_ex -> the finalize blocks of brl_adam_clip_fin_gather; brl_adam_clip -> brl_adam_clip_gather /
- * _fin_gather; brl_ppo_heads_loss -> brl_ppo_heads_loss_split.  (brl_ppo_stats_at and brl_bias_finalize were dropped in version 4: no caller left.)
- * ================================================================================================================== */
-
-/* brl_ppo_loss on the MERGED head output: heads float [batch,39] = 38 logits then the value (one GEMM for both heads);
- * dheads float [batch,39] receives d(total)/d(heads).  Everything else as brl_ppo_loss. */
-int brl_ppo_loss_heads(int device, const float *heads, const uint8_t *mask, const int32_t *action, const float *old_value,
-                       const float *old_log_prob, const float *gae, const float *targets, int64_t batch, float clip_eps,
-                       float vf_coef, float ent_coef, int masked, int value_clipping, float *dheads, float *partials,
-                       float *illegal_probs, void *stream);
-
-/* `shuffled = take(batch, permutation)` + the slice of minibatch *mb_index (src/update.py:193-206) in one launch: row
- * perm[*mb_index * mbs + b] of the flattened [T*N] trajectory `flat` (and of adv / targets) -> the static minibatch
- * buffers; x0 float [mbs,480] = obs.astype(float32) (src/update.py:95).  mb_index is DEVICE memory (brl_adam_clip advances
- * it), so a captured graph walks through an epoch by itself. */
-int brl_mb_gather(int device, const brl_transition *flat, const float *adv, const float *targets, const int64_t *perm,
-                  const int32_t *mb_index, int64_t mbs, float *x0, uint8_t *mask, int32_t *action, float *old_value,
-                  float *old_log_prob, float *gae_out, float *targets_out, void *stream);
-
-/* Backward of `h = relu(z)` plus the bias gradient of that layer: dh [rows,ld] *= (h > 0) in place and the column sums
- * of every row tile (16 rows when cols and ld are multiples of 4, else 64) into scratch (float [ceil(rows / 16) * cols]
- * is always enough); db != NULL: a second launch adds the tiles in index
- * order, db[c] = sum_r dh[r,c] (deterministic).  h == NULL: column sums only (the head's bias gradient).
- * db == NULL: tiles only — brl_bias_finalize_ex then finishes several layers with one launch. */
-int brl_relu_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, float *db,
-                        float *scratch, void *stream);
-
-/* optax.chain(clip_by_global_norm(max_norm), adam(lr, eps)) (ppo.py:195-211) on flat fp32 buffers of n elements, two
- * launches (n a multiple of 4: pad the buffers with zeros): *step (device float) += 1; the gradient is grad_scale * g
- * (1 / world_size after a SUM all-reduce: the ranks' mean, ppo.py's pmean; 1 otherwise), scaled by
- * min(1, max_norm / (|gradient| + 1e-6)) (max_norm <= 0: no clipping); m, v, p updated with torch.optim.Adam's arithmetic.
- * lr_dev (may be NULL): the learning rate in device memory, used instead of `lr` (a captured launch then follows
- * ppo.py:186-192's linear schedule).  scratch: float [1024].  mb_index (may be NULL): advanced by one.
- * norm_out (may be NULL): |g| before clipping. */
-int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
-                  const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float grad_scale, float *scratch,
-                  int32_t *mb_index, float *norm_out, void *stream);
-
-/* heads = h head_w^T + head_b (h float [batch, ldh >= hidden], the last hidden layer's output; head_w float [39, hidden] = actor
- * rows then the critic row; head_b float [39]; hidden % 16 == 0), then `_loss_fn` (src/update.py:90-167) exactly as
- * brl_ppo_loss_heads on that matrix: dheads float [batch,39] = d(total)/d(heads); partials float [ceil(batch / 4) * 8] for
- * brl_ppo_stats_gram; gram_partials (may be NULL) float [ceil(batch / 4) * 1444]: per 4-sample group, P^T P of its
- * illegal-action probabilities (src/update.py:136-141).  reward_scaling != 0: the advantages are normalised over the
- * minibatch first, (gae - mean) / (std + 1e-8) with jnp's ddof = 0 (src/update.py:31-44,118).  heads_out (may be NULL):
- * float [batch,39]. */
-int brl_ppo_heads_loss(int device, const float *h, int64_t ldh, const float *head_w, const float *head_b, int64_t hidden,
-                       const uint8_t *mask, const int32_t *action, const float *old_value, const float *old_log_prob,
-                       const float *gae, const float *targets, int64_t batch, float clip_eps, float vf_coef, float ent_coef,
-                       int masked, int value_clipping, int reward_scaling, float *heads_out, float *dheads, float *partials,
-                       float *gram_partials, void *stream);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ static int fail(const char *msg) {
   return BRL_E_ARG;
 }
 const char *brl_last_error(void) { return g_err; }
-int brl_version(void) { return 1; }
+int brl_version(void) { return 5; }   /* the exported set of include/brl_hip.h, version 5 */
 
 static int set_lut(brl_handle *h, const int32_t *keys, const int32_t *values, int64_t len) {
   free(h->keys);
@@ -392,78 +392,61 @@ int brl_mlp_gemm_dh_heads_dw(int device, const float *dz, int64_t lddz, const fl
   (void)loss_partials; (void)gram_partials; (void)ngroups; (void)row_index; (void)stat_sums; (void)gram_sums; (void)s;
   NOT_HERE("brl_mlp_gemm_dh_heads_dw");
 }
-int brl_mlp_gemm_bwd_pair(int device, const float *dz, int64_t lddz, const float *w, int64_t ldw, const float *h_prev, int64_t ldh,
-                          float *dz_out, int64_t ldo, float *dw_out, int64_t lddw, int64_t batch, int64_t n_out, int64_t n_in, int act,
-                          float *colsum, float *sqsum, const float *dheads, const float *h_top, int64_t ldht, int64_t hidden,
-                          int nsplit, float *dwh_partials, float *dbh_partials, const float *loss_partials,
-                          const float *gram_partials, int64_t ngroups, const int32_t *row_index, float *stat_sums, float *gram_sums,
-                          void *s) {
-  (void)h_top; (void)ldht; (void)hidden; (void)nsplit; (void)dwh_partials; (void)dbh_partials; (void)loss_partials; (void)gram_partials;
-  (void)ngroups; (void)row_index; (void)stat_sums; (void)gram_sums;
-  if (dheads) NOT_HERE("brl_mlp_gemm_bwd_pair with the head's role");
-  /* the two products by their definitions (brl_mlp_gemm above) */
-  int rc = brl_mlp_gemm(device, 1, 2, dz, lddz, w, ldw, dz_out, ldo, batch, n_in, n_out, act, NULL, h_prev, ldh, colsum, NULL, s);
-  if (rc) return rc;
-  float *sq = sqsum;
-  float dummy[1];
-  (void)dummy;
-  if (sq) {   /* the shim's square sums are per 64 x 64 tile; the library's per tile of ITS width: only their total is comparable */
-    return brl_mlp_gemm(device, 2, 3, dz, lddz, h_prev, ldh, dw_out, lddw, n_out, n_in, batch, act, NULL, NULL, 0, NULL, sq, s);
-  }
-  return brl_mlp_gemm(device, 2, 0, dz, lddz, h_prev, ldh, dw_out, lddw, n_out, n_in, batch, act, NULL, NULL, 0, NULL, NULL, s);
+/* clip + Adam on rank slices of the bucketed flat buffers (include/brl_hip.h: brl_shard_geom), host pointers.  The partial sums
+ * are per (rank, bucket, sub-block) exactly as the device kernels lay them out (float accumulation in index order inside a
+ * sub-block: not bit-equal to the device's tree order, the same to ~1e-6); the sweep is torch.optim.Adam's arithmetic in float. */
+static int shard_ok(const brl_shard_geom *G, int lo, int hi) {
+  if (!G || G->nbuckets < 1 || G->nbuckets > 12 || G->world < 1 || G->nsub < 1 || lo < 0 || lo >= hi || hi > G->world) return 0;
+  for (int b = 0; b < G->nbuckets; b++)
+    if (G->off[b] < 0 || G->off[b] % 4 || G->len[b] <= 0 || G->len[b] % 4) return 0;
+  return 1;
 }
-int brl_mlp_gemm_fwd_heads(int device, const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int64_t m,
-                           int64_t n, int64_t k, int act, const float *bias, const float *head_w, int64_t ldhw, float *head_parts,
-                           int nparts, void *s) {
-  /* the layer by its definition, then the per-tile partial head products of what it stored (float64 sums per 64-column tile) */
-  int rc = brl_mlp_gemm(device, 0, 1, a, lda, b, ldb, c, ldc, m, n, k, act, bias, NULL, 0, NULL, NULL, s);
-  if (rc) return rc;
-  const int tw = nparts == (int)((n + 63) / 64) ? 64 : 32;
-  if (!head_w || !head_parts || nparts != (int)((n + tw - 1) / tw)) return fail("bad argument: brl_mlp_gemm_fwd_heads (oracle shim)");
-  for (int t = 0; t < nparts; t++)
-    for (int64_t i = 0; i < m; i++)
-      for (int hd = 0; hd < 39; hd++) {
-        double acc = 0.0;
-        for (int64_t j = (int64_t)tw * t; j < (int64_t)tw * (t + 1) && j < n; j++) acc += (double)c[i * ldc + j] * head_w[hd * ldhw + j];
-        head_parts[((int64_t)t * m + i) * 39 + hd] = (float)acc;
+int brl_adam_shard_norm(int device, const float *g, const brl_shard_geom *G, int rank_lo, int rank_hi, float grad_scale, float *partials,
+                        float *step, int32_t *mb_index, void *s) {
+  (void)device; (void)s;
+  if (!g || !partials || !step || !shard_ok(G, rank_lo, rank_hi)) return fail("bad argument: brl_adam_shard_norm (oracle shim)");
+  for (int r = rank_lo; r < rank_hi; r++)
+    for (int b = 0; b < G->nbuckets; b++) {
+      const int64_t len4 = G->len[b] / 4, chunk4 = (len4 + G->nsub - 1) / G->nsub, base = G->off[b] + (int64_t)r * G->len[b];
+      for (int j = 0; j < G->nsub; j++) {
+        int64_t lo = (int64_t)j * chunk4 * 4, hi = lo + chunk4 * 4;
+        if (hi > G->len[b]) hi = G->len[b];
+        float acc = 0.0f;
+        for (int64_t i = lo; i < hi; i++) {
+          const float x = g[base + i] * grad_scale;
+          acc += x * x;
+        }
+        partials[((int64_t)r * G->nbuckets + b) * G->nsub + j] = acc;
       }
+    }
+  *step += 1.0f;
+  if (mb_index) *mb_index += 1;
   return BRL_OK;
 }
-int brl_ppo_heads_loss_parts(int device, const float *head_b, const float *head_parts, int nparts, const uint8_t *mask,
-                             const int32_t *action, const float *old_value, const float *old_log_prob, const float *gae,
-                             const float *targets, int64_t batch, float clip_eps, float vf_coef, float ent_coef, int masked,
-                             int value_clipping, int reward_scaling, float *heads_out, float *dheads, float *partials,
-                             float *gram_partials, void *s) {
-  (void)device; (void)head_b; (void)head_parts; (void)nparts; (void)mask; (void)action; (void)old_value; (void)old_log_prob; (void)gae;
-  (void)targets; (void)batch; (void)clip_eps; (void)vf_coef; (void)ent_coef; (void)masked; (void)value_clipping; (void)reward_scaling;
-  (void)heads_out; (void)dheads; (void)partials; (void)gram_partials; (void)s;
-  NOT_HERE("brl_ppo_heads_loss_parts");
-}
-int brl_adam_clip_fin_gather_defer(int device, float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
-                                   const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float *scratch,
-                                   int64_t scratch_len, int32_t *mb_index, float *norm_out, const void *gather_args, int64_t mbs,
-                                   int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles, float *const *out,
-                                   int64_t defer_lo, int64_t defer_hi, int32_t *pending, void *s) {
-  (void)device; (void)p; (void)g; (void)m; (void)v; (void)n; (void)step; (void)lr; (void)lr_dev; (void)beta1; (void)beta2; (void)eps;
-  (void)max_norm; (void)scratch; (void)scratch_len; (void)mb_index; (void)norm_out; (void)gather_args; (void)mbs; (void)nseg;
-  (void)partials; (void)cols; (void)tiles; (void)out; (void)defer_lo; (void)defer_hi; (void)pending; (void)s;
-  NOT_HERE("brl_adam_clip_fin_gather_defer");
-}
-int brl_mlp_gemm_adam(int device, const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int64_t m, int64_t n,
-                      int64_t k, int act, const float *bias, float *p, const float *g, float *mom, float *var, int64_t lo, int64_t hi,
-                      const float *scratch, int npartials, const float *step, float lr, const float *lr_dev, float beta1, float beta2,
-                      float eps, float max_norm, float grad_scale, const int32_t *pending, void *s) {
-  (void)device; (void)a; (void)lda; (void)b; (void)ldb; (void)c; (void)ldc; (void)m; (void)n; (void)k; (void)act; (void)bias; (void)p; (void)g;
-  (void)mom; (void)var; (void)lo; (void)hi; (void)scratch; (void)npartials; (void)step; (void)lr; (void)lr_dev; (void)beta1; (void)beta2;
-  (void)eps; (void)max_norm; (void)grad_scale; (void)pending; (void)s;
-  NOT_HERE("brl_mlp_gemm_adam");
-}
-int brl_adam_apply_range(int device, float *p, const float *g, float *m, float *v, int64_t lo, int64_t hi, const float *scratch,
-                         int npartials, const float *step, float lr, const float *lr_dev, float beta1, float beta2, float eps,
-                         float max_norm, float grad_scale, int32_t *pending, int clear_pending, void *s) {
-  (void)device; (void)p; (void)g; (void)m; (void)v; (void)lo; (void)hi; (void)scratch; (void)npartials; (void)step; (void)lr; (void)lr_dev;
-  (void)beta1; (void)beta2; (void)eps; (void)max_norm; (void)grad_scale; (void)pending; (void)clear_pending; (void)s;
-  NOT_HERE("brl_adam_apply_range");
+int brl_adam_shard_apply(int device, float *p, const float *g, float *m, float *v, const brl_shard_geom *G, int rank_lo, int rank_hi,
+                         const float *partials, const float *step, float lr, const float *lr_dev, float beta1, float beta2, float eps,
+                         float max_norm, float grad_scale, float *norm_out, const void *gather_args, int64_t mbs, void *s) {
+  (void)device; (void)s; (void)mbs;
+  if (!p || !g || !m || !v || !partials || !step || !shard_ok(G, rank_lo, rank_hi)) return fail("bad argument: brl_adam_shard_apply (oracle shim)");
+  if (gather_args) NOT_HERE("brl_adam_shard_apply with the minibatch gather");
+  float sum = 0.0f;
+  for (int64_t i = 0; i < (int64_t)G->world * G->nbuckets * G->nsub; i++) sum += partials[i];
+  const float norm = sqrtf(sum);
+  const float coef = max_norm > 0.0f ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+  if (norm_out) *norm_out = norm;
+  const float scale = coef * grad_scale, t = *step, rate = lr_dev ? *lr_dev : lr;
+  const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t), step_size = rate / bc1, bc2_sqrt = sqrtf(bc2);
+  for (int r = rank_lo; r < rank_hi; r++)
+    for (int b = 0; b < G->nbuckets; b++) {
+      const int64_t base = G->off[b] + (int64_t)r * G->len[b];
+      for (int64_t i = base; i < base + G->len[b]; i++) {
+        const float gs = g[i] * scale;
+        m[i] = m[i] + (gs - m[i]) * (1.0f - beta1);
+        v[i] = v[i] * beta2 + gs * gs * (1.0f - beta2);
+        p[i] -= step_size * (m[i] / (sqrtf(v[i]) / bc2_sqrt + eps));
+      }
+    }
+  return BRL_OK;
 }
 int brl_adam_clip_fin_gather(int device, float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
                              const float *lr_dev, float beta1, float beta2, float eps, float max_norm, float *scratch,
@@ -508,29 +491,6 @@ int brl_ppo_stats(int device, const float *pt, int64_t b, const float *gram, flo
 }
 /* the fused PPO minibatch step (GEMM-side helpers of brl_amd/update.py::FusedMinibatch): GPU library only; the float64
  * restatement the update tests compare with is tests/ppo_numpy.py */
-int brl_ppo_loss_heads(int device, const float *hd, const uint8_t *m, const int32_t *a, const float *ov, const float *olp,
-                       const float *g, const float *t, int64_t b, float ce, float vc, float ec, int mk, int vcl, float *dh,
-                       float *pt, float *ip, void *s) {
-  (void)device; (void)hd; (void)m; (void)a; (void)ov; (void)olp; (void)g; (void)t; (void)b; (void)ce; (void)vc; (void)ec; (void)mk; (void)vcl; (void)dh; (void)pt; (void)ip; (void)s;
-  NOT_HERE("brl_ppo_loss_heads");
-}
-int brl_mb_gather(int device, const brl_transition *flat, const float *adv, const float *tg, const int64_t *perm,
-                  const int32_t *mbi, int64_t mbs, float *x0, uint8_t *m, int32_t *a, float *ov, float *olp, float *go, float *to,
-                  void *s) {
-  (void)device; (void)flat; (void)adv; (void)tg; (void)perm; (void)mbi; (void)mbs; (void)x0; (void)m; (void)a; (void)ov; (void)olp; (void)go; (void)to; (void)s;
-  NOT_HERE("brl_mb_gather");
-}
-int brl_relu_bwd_colsum(int device, float *dh, const float *h, int64_t rows, int64_t cols, int64_t ld, float *db, float *scr,
-                        void *s) {
-  (void)device; (void)dh; (void)h; (void)rows; (void)cols; (void)ld; (void)db; (void)scr; (void)s;
-  NOT_HERE("brl_relu_bwd_colsum");
-}
-int brl_adam_clip(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr, const float *lrd,
-                  float b1, float b2,
-                  float eps, float mn, float gs, float *scratch, int32_t *mbi, float *no, void *s) {
-  (void)gs; (void)lrd; (void)device; (void)p; (void)g; (void)m; (void)v; (void)n; (void)step; (void)lr; (void)b1; (void)b2; (void)eps; (void)mn; (void)scratch; (void)mbi; (void)no; (void)s;
-  NOT_HERE("brl_adam_clip");
-}
 int brl_policy_step_ex(brl_handle *h, const uint64_t *si, uint64_t *so, int64_t n, const float *lg, int64_t ls, int mode,
                        const uint32_t *db, uint32_t dof, int ar, int32_t *a, float *lp, uint8_t *obs, uint8_t *m, float *ra,
                        uint8_t *ta, int32_t *cp, const brl_macro_ext *ext, void *s) {
@@ -551,12 +511,6 @@ int brl_rollout_random_gae(brl_handle *h, uint64_t *state, int64_t n, int T, uin
   return brl_gae(h, out->done, out->value, out->reward, last_val, gamma, gl, T, n, adv, tgt, s);
 }
 /* the head kernels of the fused PPO minibatch step (brl_amd/csrc/ppo_heads.hpp): GPU library only, like the entries above */
-int brl_ppo_heads_loss(int device, const float *h, int64_t ldh, const float *hw, const float *hb, int64_t hidden, const uint8_t *m,
-                       const int32_t *a, const float *ov, const float *olp, const float *g, const float *t, int64_t b, float ce,
-                       float vc, float ec, int mk, int vcl, int rs, float *ho, float *dh, float *pt, float *gp, void *s) {
-  (void)device; (void)h; (void)ldh; (void)hw; (void)hb; (void)hidden; (void)m; (void)a; (void)ov; (void)olp; (void)g; (void)t; (void)b; (void)ce; (void)vc; (void)ec; (void)mk; (void)vcl; (void)rs; (void)ho; (void)dh; (void)pt; (void)gp; (void)s;
-  NOT_HERE("brl_ppo_heads_loss");
-}
 int brl_ppo_heads_loss_split(int device, const float *h, int64_t ldh, const float *hw, const float *hb, int64_t hidden, const uint8_t *m,
                        const int32_t *a, const float *ov, const float *olp, const float *g, const float *t, int64_t b, float ce,
                        float vc, float ec, int mk, int vcl, int rs, float *ho, float *dh, float *pt, float *gp, float *hp, int ks, void *s) {
@@ -601,10 +555,4 @@ int brl_mb_gather_dev(int device, const void *ad, int64_t mbs, void *s) {
 int brl_ppo_illegal_grad(int device, const float *hd, const uint8_t *m, const float *vec, float ic, int64_t b, float *dh, void *s) {
   (void)device; (void)hd; (void)m; (void)vec; (void)ic; (void)b; (void)dh; (void)s;
   NOT_HERE("brl_ppo_illegal_grad");
-}
-int brl_adam_clip_gather(int device, float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr, const float *lrd,
-                         float b1, float b2, float eps, float mn, float gs, float *scratch, int32_t *mbi, float *no, const void *ga,
-                         int64_t mbs, void *s) {
-  (void)gs; (void)lrd; (void)device; (void)p; (void)g; (void)m; (void)v; (void)n; (void)step; (void)lr; (void)b1; (void)b2; (void)eps; (void)mn; (void)scratch; (void)mbi; (void)no; (void)ga; (void)mbs; (void)s;
-  NOT_HERE("brl_adam_clip_gather");
 }

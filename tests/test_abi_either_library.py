@@ -64,3 +64,59 @@ def test_product_library_matches_the_oracle_on_the_same_abi_scenario(shim, dds):
         if w.dtype in (np.uint32, np.uint64):
             g = g.view(w.dtype) if g.dtype != w.dtype else g
         assert g.shape == w.shape and np.array_equal(g, w), k
+
+
+def test_shard_adam_on_the_shim_sharded_equals_replicated_equals_torch(shim):
+    """brl_adam_shard_norm / brl_adam_shard_apply (the multi-rank step's clip + Adam, include/brl_hip.h) through the CPU shim, host
+    pointers: three ranks' sharded sweeps (own partials, "all-gather" = one shared array, own slices) == one replicated sweep ==
+    torch.optim.Adam + clip_grad_norm_; the counters advance once per step."""
+    import torch
+    from brl_amd._capi import ShardGeom
+    f32, vp, i32, i64 = ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    shim.brl_adam_shard_norm.argtypes = [i32, vp, ctypes.POINTER(ShardGeom), i32, i32, f32, vp, vp, vp, vp]
+    shim.brl_adam_shard_apply.argtypes = [i32, vp, vp, vp, vp, ctypes.POINTER(ShardGeom), i32, i32, vp, vp, f32, vp, f32, f32, f32, f32, f32, vp,
+                                          vp, i64, vp]
+    W, lens = 3, [64, 20, 8]                         # three buckets, slices of 64 / 20 / 8 floats
+    geom = ShardGeom()
+    geom.nbuckets, geom.world, geom.nsub = 3, W, 2
+    off = 0
+    for b, ln in enumerate(lens):
+        geom.off[b], geom.len[b] = off, ln
+        off += W * ln
+    n = off
+    rng = np.random.default_rng(0)
+    p0 = rng.standard_normal(n).astype(np.float32)
+    grads = [(rng.standard_normal(n) * (1e-3 if it == 1 else 1.0)).astype(np.float32) for it in range(3)]
+    ptr = lambda a: a.ctypes.data_as(vp)   # noqa: E731
+
+    def run(sharded):
+        p, m, v = p0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        step, idx, norm = np.zeros(1, np.float32), np.zeros(1, np.int32), np.zeros(1, np.float32)
+        for g in grads:
+            gs = (g * W).astype(np.float32)
+            part = np.full(W * 3 * 2, np.nan, np.float32)
+            for lo, hi in ([(r, r + 1) for r in range(W)] if sharded else [(0, W)]):
+                st = step.copy() if sharded else step            # (every rank has its own counter; they agree)
+                assert shim.brl_adam_shard_norm(0, ptr(gs), ctypes.byref(geom), lo, hi, f32(1.0 / W), ptr(part), ptr(st),
+                                                ptr(idx) if lo == 0 else None, None) == 0
+            if sharded:
+                step[:] = st
+            assert not np.isnan(part).any()
+            for lo, hi in ([(r, r + 1) for r in range(W)] if sharded else [(0, W)]):
+                assert shim.brl_adam_shard_apply(0, ptr(p), ptr(gs), ptr(m), ptr(v), ctypes.byref(geom), lo, hi, ptr(part), ptr(step),
+                                                 f32(1e-3), None, f32(0.9), f32(0.999), f32(1e-5), f32(0.5), f32(1.0 / W), ptr(norm),
+                                                 None, 0, None) == 0
+        assert step[0] == 3.0 and idx[0] == 3
+        return p, m, v, float(norm[0])
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    ref = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([ref], lr=1e-3, eps=1e-5)
+    for g in grads:
+        ref.grad = torch.from_numpy(g.copy())
+        want_norm = float(torch.nn.utils.clip_grad_norm_([ref], 0.5))
+        opt.step()
+    assert abs(a[3] - want_norm) < 1e-5 * want_norm
+    assert np.allclose(a[0], ref.detach().numpy(), atol=2e-6)
+    assert shim.brl_adam_shard_norm(0, ptr(p0), ctypes.byref(geom), 2, 2, f32(1.0), ptr(p0), ptr(p0), None, None) == -1   # empty rank range

@@ -1887,7 +1887,7 @@ def test_graphed_update_built_after_eager_steps_keeps_adam_state(fused):
         assert torch.allclose(outs[0], outs[1], atol=1e-5, rtol=1e-4)
 
 
-def _fused_rank(rank, world, port, out_dir, backend="gloo", mode="flat"):
+def _fused_rank(rank, world, port, out_dir, backend="gloo", mode="sharded", in_graph=None):
     import sys
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -1905,60 +1905,147 @@ def _fused_rank(rank, world, port, out_dir, backend="gloo", mode="flat"):
     net = fp.init(11, device="cuda")
     tb, adv, tgt = fake_batch(4, 256, seed=3)                       # the SAME shard on both ranks: mean gradient == own gradient
     tb = type(tb)(*[x.cuda() for x in tb])
-    cfg = dict(CFG, minibatch_size=256, update_epochs=1, grad_allreduce=mode)
+    cfg = dict(CFG, minibatch_size=256, update_epochs=2, grad_allreduce=mode, force_collectives=True, collective_in_graph=in_graph)
     rs, (total, _) = make_update_step(cfg, fp)((net, None, None, None, 0, 5), tb, adv.cuda(), tgt.cuda())
-    assert isinstance(rs[1].get("graphed"), FusedMinibatch) and rs[1]["graphed"].world == world, rs[1].get("graph_error")
-    assert rs[1]["graphed"].allreduce_mode == mode and len(rs[1]["graphed"].segs) == (3 if mode == "flat" else 7)
-    torch.save((torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu(), total.cpu()),
-               os.path.join(out_dir, f"rank{rank}.pt"))
+    fm = rs[1].get("graphed")
+    assert isinstance(fm, FusedMinibatch) and fm.world == world, rs[1].get("graph_error")
+    assert fm.allreduce_mode == mode and fm.in_graph == (backend == "nccl" if in_graph is None else in_graph)
+    if not fm.in_graph:   # graphs of kernel groups between eager collectives: flat 1, sharded (hidden layers + 1) + 1 + (hidden layers + 1)
+        assert len([x for x in fm.segs if x[0] == "c"]) == (1 if mode == "flat" else 2 * len(net.body) + 1)
+    fm.gather_optimizer_state()     # (sharded: the moments of the other ranks' slices)
+    flat = lambda ts: torch.cat([t.detach().reshape(-1) for t in ts]).cpu()   # noqa: E731
+    st = rs[1]["opt"].state
+    torch.save((flat(net.parameters()), total.cpu(), flat([st[q]["exp_avg"] for q in net.parameters()]),
+                flat([st[q]["exp_avg_sq"] for q in net.parameters()])), os.path.join(out_dir, f"{mode}{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["flat", "bucketed"])
-def test_fused_update_with_gradient_allreduce_two_ranks(tmp_path, mode):
-    """FusedMinibatch under a process group — "flat" (the default: gradient graph | ONE all-reduce | clip+Adam graph with
-    grad_scale 1/world) and "bucketed" (one graph per all-reduce bucket, collectives issued asynchronously): two ranks on the
-    same shard end with the parameters of the single-process step (gloo here; RCCL on a node)."""
-    import socket
-    import torch.multiprocessing as mp
+def _single_process_reference():
     from brl_amd.models import make_forward_pass
     from brl_amd.update import make_update_step
     from tests.test_update_cpu import CFG, fake_batch
-    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-    mp.start_processes(_fused_rank, args=(2, port, str(tmp_path), "gloo", mode), nprocs=2, join=True, start_method="spawn")
-    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
-    assert torch.equal(r0[0], r1[0])
     fp = make_forward_pass("relu", "DeepMind")
     net = fp.init(11, device="cuda")
     tb, adv, tgt = fake_batch(4, 256, seed=3)
     tb = type(tb)(*[x.cuda() for x in tb])
-    _, (total, _) = make_update_step(dict(CFG, minibatch_size=256, update_epochs=1), fp)((net, None, None, None, 0, 5), tb, adv.cuda(), tgt.cuda())
-    single = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()
-    assert torch.allclose(total.cpu(), r0[1], atol=1e-6) and torch.allclose(single, r0[0], atol=1e-6, rtol=1e-5)
+    rs, (total, _) = make_update_step(dict(CFG, minibatch_size=256, update_epochs=2), fp)((net, None, None, None, 0, 5), tb, adv.cuda(), tgt.cuda())
+    st = rs[1]["opt"].state
+    flat = lambda ts: torch.cat([t.detach().reshape(-1) for t in ts]).cpu()   # noqa: E731
+    return flat(net.parameters()), total.cpu(), flat([st[q]["exp_avg"] for q in net.parameters()])
 
 
-@pytest.mark.parametrize("mode", ["flat", "bucketed"])
-def test_fused_update_with_gradient_allreduce_two_ranks_rccl(tmp_path, mode):
-    """The same over RCCL ("nccl"), one GPU per rank: the all-reduces really cross xGMI ("bucketed": issued behind their graph
-    segments, overlapping the rest of the backward pass).  SKIPPED with a reason below 2 GPUs."""
+def _check_two_rank_step(tmp_path, backend, world=2, in_graph=None):
+    """both forms of the multi-rank step: every rank ends with the same parameters, "sharded" == "flat" BIT FOR BIT (parameters
+    and — after gather_optimizer_state — both Adam moments), and both equal the single-process step up to the fp32 order of the
+    norm's partial sums"""
+    import socket
+    import torch.multiprocessing as mp
+    res = {}
+    for mode in ("flat", "sharded"):
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        mp.start_processes(_fused_rank, args=(world, port, str(tmp_path), backend, mode, in_graph), nprocs=world, join=True,
+                           start_method="spawn")
+        res[mode] = [torch.load(tmp_path / f"{mode}{r}.pt") for r in range(world)]
+        for r in range(1, world):
+            for a, b in zip(res[mode][0], res[mode][r]):
+                assert torch.equal(a, b), f"{mode}: rank {r} differs from rank 0"
+    for a, b in zip(res["flat"][0], res["sharded"][0]):
+        assert torch.equal(a, b)                       # parameters, losses, exp_avg, exp_avg_sq
+    single, total, m1 = _single_process_reference()
+    got = res["sharded"][0]
+    assert torch.allclose(total, got[1], atol=1e-6) and torch.allclose(single, got[0], atol=1e-6, rtol=1e-5)
+    assert torch.allclose(m1, got[2], atol=1e-6, rtol=1e-4)
+
+
+def test_fused_update_with_gradient_collectives_two_ranks(tmp_path):
+    """FusedMinibatch under a process group — "sharded" (the default: reduce-scatter per layer bucket behind the backward pass,
+    clip + Adam on the rank's slices, all-gather of the parameters) and "flat" (ONE all-reduce, replicated clip + Adam): two gloo
+    ranks on this box's GPU (graphs of kernel groups between eager collectives; RCCL captures them into the step's graph)."""
+    _check_two_rank_step(tmp_path, "gloo")
+
+
+def test_fused_update_with_gradient_collectives_two_ranks_rccl(tmp_path):
+    """The same over RCCL ("nccl"), one GPU per rank: the collectives are nodes of the eight-step hipGraph and really cross xGMI
+    ("sharded": the reduce-scatters overlap the backward pass, the all-gathers the next forward pass).  SKIPPED below 2 GPUs."""
     _two_gpus_or_skip()
-    import socket
-    import torch.multiprocessing as mp
-    from brl_amd.models import make_forward_pass
-    from brl_amd.update import make_update_step
-    from tests.test_update_cpu import CFG, fake_batch
-    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-    mp.start_processes(_fused_rank, args=(2, port, str(tmp_path), "nccl", mode), nprocs=2, join=True, start_method="spawn")
-    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
-    assert torch.equal(r0[0], r1[0])
-    fp = make_forward_pass("relu", "DeepMind")
-    net = fp.init(11, device="cuda")
-    tb, adv, tgt = fake_batch(4, 256, seed=3)
-    tb = type(tb)(*[x.cuda() for x in tb])
-    _, (total, _) = make_update_step(dict(CFG, minibatch_size=256, update_epochs=1), fp)((net, None, None, None, 0, 5), tb, adv.cuda(), tgt.cuda())
-    single = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()
-    assert torch.allclose(total.cpu(), r0[1], atol=1e-6) and torch.allclose(single, r0[0], atol=1e-6, rtol=1e-5)
+    _check_two_rank_step(tmp_path, "nccl")
+
+
+def test_fused_update_collectives_inside_the_graph_rccl_world_1(tmp_path):
+    """The multi-rank program with REAL RCCL collectives captured inside the step's hipGraph, on the one GPU of this box
+    (init_process_group("nccl", world_size=1), force_collectives): reduce_scatter_tensor / all_gather_into_tensor / all_reduce nodes
+    record and replay (profiles/r05/r05a_rccl_capture_probe.txt), "sharded" == "flat" bit for bit, both == the single-rank step up to
+    the order of the norm's partial sums.  What a node run adds is peers, not code."""
+    _check_two_rank_step(tmp_path, "nccl", world=1)
+
+
+def test_fused_update_sharded_geometry_of_eight_ranks_on_one_gpu(tmp_path):
+    """configs[4]'s geometry (world = 8: five buckets x eight slices, 1024 norm partials) executed by ONE process that plays the
+    eight ranks in turn through the C-ABI: reduce-scatter / all-gather done by hand on host-visible copies.  The eight sharded
+    sweeps together == one replicated sweep (rank_lo = 0, rank_hi = 8) bit for bit == torch.optim.Adam + clip_grad_norm_ to fp32
+    rounding."""
+    import ctypes as C
+    from brl_amd import _capi
+    L, dev = _capi.lib(), torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(8)
+    W, H, nl = 8, 1024, 4
+    hid = (nl - 1) * H * H
+    tail = 480 * H + 39 * H + nl * H + 39
+    tail_pad = (tail + 4 * W - 1) // (4 * W) * (4 * W)
+    n = hid + tail_pad
+    geom = _capi.ShardGeom()
+    geom.nbuckets, geom.world, geom.nsub = nl, W, 1024 // (W * nl)
+    for b in range(nl - 1):
+        geom.off[b], geom.len[b] = b * H * H, H * H // W
+    geom.off[nl - 1], geom.len[nl - 1] = hid, tail_pad // W
+    npart = W * nl * geom.nsub
+    p0 = torch.randn(n, device=dev, generator=g) * 0.05
+    grads = [torch.randn(n, device=dev, generator=g) * (2e-4 if it == 1 else 1e-2) for it in range(3)]   # one step below the clip threshold
+    for t in [p0] + grads:
+        t[hid + tail:] = 0                                   # the buffers' zero padding
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, eps=1e-5)
+
+    def run(sharded):
+        p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        step, norm = torch.zeros((), device=dev), torch.zeros(1, device=dev)
+        idx = torch.zeros(1, dtype=torch.int32, device=dev)
+        norms = []
+        for grad in grads:
+            gsum = grad * W                                     # what a SUM reduction of eight equal gradients leaves
+            part = torch.full((npart,), float("nan"), device=dev)
+            if sharded:
+                step0 = step.clone()
+                for r in range(W):                              # every rank: partials of its own slices (its own step counter)
+                    step.copy_(step0)
+                    _capi.check(L.brl_adam_shard_norm(0, gsum.data_ptr(), C.byref(geom), r, r + 1, 1.0 / W, part.data_ptr(), step.data_ptr(),
+                                                      idx.data_ptr() if r == 0 else None, s))
+                for r in range(W):                              # (the all-gather of the partials has happened: one shared array)
+                    _capi.check(L.brl_adam_shard_apply(0, p.data_ptr(), gsum.data_ptr(), m.data_ptr(), v.data_ptr(), C.byref(geom), r, r + 1,
+                                                       part.data_ptr(), step.data_ptr(), 1e-3, None, 0.9, 0.999, 1e-5, 0.5, 1.0 / W,
+                                                       norm.data_ptr(), None, 0, s))
+            else:
+                _capi.check(L.brl_adam_shard_norm(0, gsum.data_ptr(), C.byref(geom), 0, W, 1.0 / W, part.data_ptr(), step.data_ptr(),
+                                                  idx.data_ptr(), s))
+                _capi.check(L.brl_adam_shard_apply(0, p.data_ptr(), gsum.data_ptr(), m.data_ptr(), v.data_ptr(), C.byref(geom), 0, W,
+                                                   part.data_ptr(), step.data_ptr(), 1e-3, None, 0.9, 0.999, 1e-5, 0.5, 1.0 / W,
+                                                   norm.data_ptr(), None, 0, s))
+            assert not torch.isnan(part).any()
+            norms.append(float(norm[0]))
+        assert float(step) == 3.0 and int(idx) == 3
+        return p, m, v, norms
+    a, b = run(True), run(False)
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+    assert a[3] == b[3]
+    for it, grad in enumerate(grads):
+        ref.grad = grad.clone()
+        want_norm = float(torch.nn.utils.clip_grad_norm_([ref], 0.5))
+        opt.step()
+        assert abs(a[3][it] - want_norm) < 1e-5 * want_norm
+    assert torch.allclose(a[0], ref.detach(), atol=2e-6), float((a[0] - ref.detach()).abs().max())
 
 
 @pytest.mark.parametrize("variant", ["DeepMind_6", "anneal_lr", "tanh", "reward_scaling", "illegal_coef"])
@@ -2020,44 +2107,52 @@ def test_fused_update_follows_a_reloaded_optimizer_state():
 
 
 def test_fused_update_helpers_match_torch():
-    """brl_mb_gather, brl_relu_bwd_colsum and brl_adam_clip against their torch counterparts."""
+    """brl_act_bwd_colsum + brl_bias_finalize_ex, brl_adam_clip_fin_gather and brl_mb_gather_bind / _dev against their torch counterparts."""
     import ctypes as C
     from brl_amd import _capi
     L, dev = _capi.lib(), torch.device("cuda", 0)
     s = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device="cuda").manual_seed(1)
-    # ReLU backward + bias gradient, ragged sizes
-    for rows, cols in ((1024, 1024), (300, 39), (64, 100), (250, 1024), (7, 8)):
+    # activation backward + bias gradient, ragged row counts
+    for rows, cols, act in ((1024, 1024, 0), (300, 40, 1), (64, 100, 0), (250, 1024, 1), (7, 8, 0)):
         dh = torch.randn(rows, cols, device=dev, generator=g)
-        h = torch.randn(rows, cols, device=dev, generator=g)
-        want_dz = dh * (h > 0)
+        h = torch.randn(rows, cols, device=dev, generator=g).clamp_(-0.99, 0.99)
+        want_dz = dh * (h > 0) if act == 0 else dh * (1 - h * h)
         db = torch.empty(cols, device=dev)
-        scratch = torch.empty(((rows + 15) // 16) * cols, device=dev)
+        tiles = (rows + 15) // 16
+        scratch = torch.empty(tiles * cols, device=dev)
         got = dh.clone()
-        _capi.check(L.brl_relu_bwd_colsum(0, got.data_ptr(), h.data_ptr(), rows, cols, cols, db.data_ptr(), scratch.data_ptr(), s))
-        assert torch.equal(got, want_dz) and torch.allclose(db, want_dz.sum(0), atol=1e-3, rtol=1e-5)
-        got2 = dh.clone()
-        _capi.check(L.brl_relu_bwd_colsum(0, got2.data_ptr(), None, rows, cols, cols, db.data_ptr(), scratch.data_ptr(), s))
-        assert torch.equal(got2, dh) and torch.allclose(db, dh.sum(0), atol=1e-3, rtol=1e-5)
-    # clip + Adam, three steps, against torch.optim.Adam + clip_grad_norm_
-    n = 4096 + 8
+        _capi.check(L.brl_act_bwd_colsum(0, got.data_ptr(), h.data_ptr(), rows, cols, cols, act, scratch.data_ptr(), s))
+        _capi.check(L.brl_bias_finalize_ex(0, 1, (C.c_void_p * 1)(scratch.data_ptr()), (C.c_int64 * 1)(cols), (C.c_int64 * 1)(tiles),
+                                           (C.c_void_p * 1)(db.data_ptr()), s))
+        assert torch.allclose(got, want_dz, rtol=1e-6, atol=0) and torch.allclose(db, want_dz.sum(0), atol=1e-3, rtol=1e-5)
+        assert act == 1 or torch.equal(got, want_dz)
+    # clip + Adam (single rank: the sums of partials ride in the norm launch), three steps, against torch.optim.Adam + clip_grad_norm_
+    n, tail, tiles = 4096 + 8, 8, 3                      # the last 8 gradients come as 3 tiles of partial sums
     p0 = torch.randn(n, device=dev, generator=g)
     ref = torch.nn.Parameter(p0.clone())
     opt = torch.optim.Adam([ref], lr=1e-3, eps=1e-5)
     p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
-    step, scratch, idx, norm = torch.zeros((), device=dev), torch.empty(1024, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), torch.empty(1, device=dev)
+    step, scratch, idx, norm = torch.zeros((), device=dev), torch.empty(2048, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), torch.empty(1, device=dev)
     lr_dev = torch.full((1,), 1e-3, device=dev)   # the third step reads the learning rate from device memory
     for it in range(3):
         grad = torch.randn(n, device=dev, generator=g) * (0.001 if it == 1 else 1.0)   # one step below the clip threshold
-        ref.grad = grad.clone()
+        parts = torch.randn(tiles, tail, device=dev, generator=g) * (0.001 if it == 1 else 1.0)
+        full = grad.clone()
+        full[n - tail:] = parts.sum(0)
+        ref.grad = full.clone()
         want_norm = torch.nn.utils.clip_grad_norm_([ref], 0.5)
         opt.step()
-        _capi.check(L.brl_adam_clip(0, p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, step.data_ptr(), 1e-3,
-                                    lr_dev.data_ptr() if it == 2 else None, 0.9, 0.999, 1e-5, 0.5, 1.0, scratch.data_ptr(), idx.data_ptr(), norm.data_ptr(), s))
+        grad[n - tail:] = float("nan")                   # (written by the norm launch's finalize blocks)
+        _capi.check(L.brl_adam_clip_fin_gather(0, p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, step.data_ptr(), 1e-3,
+                                               lr_dev.data_ptr() if it == 2 else None, 0.9, 0.999, 1e-5, 0.5, scratch.data_ptr(), scratch.numel(),
+                                               idx.data_ptr(), norm.data_ptr(), None, 0, 1, (C.c_void_p * 1)(parts.data_ptr()),
+                                               (C.c_int64 * 1)(tail), (C.c_int64 * 1)(tiles), (C.c_void_p * 1)(grad[n - tail:].data_ptr()), s))
+        assert torch.allclose(grad[n - tail:], full[n - tail:], atol=1e-6)
         assert torch.allclose(norm[0], want_norm, rtol=1e-5)
         assert torch.allclose(p, ref.detach(), atol=2e-6), float((p - ref.detach()).abs().max())
     assert int(idx.item()) == 3 and float(step.item()) == 3.0
-    # minibatch gather
+    # minibatch gather: arguments bound in device memory (what the captured minibatch step launches)
     from tests.test_update_cpu import fake_batch
     tb, adv, tgt = fake_batch(4, 64, seed=5)
     flat = type(tb)(*[x.reshape((256,) + x.shape[2:]).cuda() for x in tb])
@@ -2071,16 +2166,7 @@ def test_fused_update_helpers_match_torch():
     x0, mask, act = torch.empty(B, 480, device=dev), torch.empty(B, 38, dtype=torch.uint8, device=dev), torch.empty(B, dtype=torch.int32, device=dev)
     ov, olp, ga, tg = (torch.empty(B, device=dev) for _ in range(4))
     mbi = torch.full((1,), 2, dtype=torch.int32, device=dev)
-    _capi.check(L.brl_mb_gather(0, C.byref(tp), adv.data_ptr(), tgt.data_ptr(), perm.data_ptr(), mbi.data_ptr(), B, x0.data_ptr(),
-                                mask.data_ptr(), act.data_ptr(), ov.data_ptr(), olp.data_ptr(), ga.data_ptr(), tg.data_ptr(), s))
-    rows = perm[2 * B:3 * B]
-    assert torch.equal(x0, flat.obs[rows].float()) and torch.equal(mask.bool(), flat.legal_action_mask[rows])
-    assert torch.equal(act, flat.action[rows]) and torch.equal(ov, flat.value[rows]) and torch.equal(olp, flat.log_prob[rows])
-    assert torch.equal(ga, adv[rows]) and torch.equal(tg, tgt[rows])
-    # the same gather with its arguments bound in device memory (what the captured minibatch step launches)
     gargs = torch.zeros(256, dtype=torch.uint8, device=dev)
-    for t in (x0, mask, act, ov, olp, ga, tg):
-        t.zero_()
     _capi.check(L.brl_mb_gather_bind(0, C.byref(tp), adv.data_ptr(), tgt.data_ptr(), perm.data_ptr(), mbi.data_ptr(), B, x0.data_ptr(),
                                      mask.data_ptr(), act.data_ptr(), ov.data_ptr(), olp.data_ptr(), ga.data_ptr(), tg.data_ptr(),
                                      256 // B, gargs.data_ptr(), s))
@@ -2088,16 +2174,28 @@ def test_fused_update_helpers_match_torch():
     _capi.check(L.brl_mb_gather_dev(0, gargs.data_ptr(), B, s))
     rows = perm[B:2 * B]
     assert torch.equal(x0, flat.obs[rows].float()) and torch.equal(mask.bool(), flat.legal_action_mask[rows])
-    assert torch.equal(act, flat.action[rows]) and torch.equal(ga, adv[rows]) and torch.equal(tg, tgt[rows])
-    # ... and as extra workgroups of the Adam launch: the first launch advances the counter, the second gathers THAT minibatch
-    # beside the parameter update; a minibatch past the bound permutation (4 here) is skipped
+    assert torch.equal(act, flat.action[rows]) and torch.equal(ov, flat.value[rows]) and torch.equal(olp, flat.log_prob[rows])
+    assert torch.equal(ga, adv[rows]) and torch.equal(tg, tgt[rows])
+    # ... and as extra workgroups of the Adam launches (both the single-rank and the shard form): the norm launch advances the
+    # counter, the sweep gathers THAT minibatch beside the parameter update; a minibatch past the bound permutation (4 here) is skipped
+    geom = _capi.ShardGeom()
+    geom.nbuckets, geom.world, geom.nsub = 1, 2, 4
+    geom.off[0], geom.len[0] = 0, n // 2
+    part = torch.empty(8, device=dev)
     p2, m2, v2 = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
     step2 = torch.zeros((), device=dev)
     for want_idx in (2, 3, 4):
         grad = torch.randn(n, device=dev, generator=g)
-        _capi.check(L.brl_adam_clip_gather(0, p2.data_ptr(), grad.data_ptr(), m2.data_ptr(), v2.data_ptr(), n, step2.data_ptr(), 1e-3, None,
-                                           0.9, 0.999, 1e-5, 0.5, 1.0, scratch.data_ptr(), mbi.data_ptr(), norm.data_ptr(),
-                                           gargs.data_ptr(), B, s))
+        if want_idx == 3:
+            _capi.check(L.brl_adam_shard_norm(0, grad.data_ptr(), C.byref(geom), 0, 2, 1.0, part.data_ptr(), step2.data_ptr(), mbi.data_ptr(), s))
+            _capi.check(L.brl_adam_shard_apply(0, p2.data_ptr(), grad.data_ptr(), m2.data_ptr(), v2.data_ptr(), C.byref(geom), 0, 2, part.data_ptr(),
+                                               step2.data_ptr(), 1e-3, None, 0.9, 0.999, 1e-5, 0.5, 1.0, norm.data_ptr(), gargs.data_ptr(), B, s))
+        else:
+            parts = torch.zeros(1, tail, device=dev)
+            _capi.check(L.brl_adam_clip_fin_gather(0, p2.data_ptr(), grad.data_ptr(), m2.data_ptr(), v2.data_ptr(), n, step2.data_ptr(), 1e-3, None,
+                                                   0.9, 0.999, 1e-5, 0.5, scratch.data_ptr(), scratch.numel(), mbi.data_ptr(), norm.data_ptr(),
+                                                   gargs.data_ptr(), B, 1, (C.c_void_p * 1)(parts.data_ptr()), (C.c_int64 * 1)(tail),
+                                                   (C.c_int64 * 1)(1), (C.c_void_p * 1)(grad[n - tail:].data_ptr()), s))
         assert int(mbi.item()) == want_idx
         rows = perm[min(want_idx, 3) * B:(min(want_idx, 3) + 1) * B]     # (index 4: nothing gathered, minibatch 3 stays)
         assert torch.equal(x0, flat.obs[rows].float()) and torch.equal(act, flat.action[rows]) and torch.equal(tg, tgt[rows])
@@ -2106,10 +2204,10 @@ def test_fused_update_helpers_match_torch():
 
 @pytest.mark.parametrize("B,H,act", [(1024, 1024, 0), (1000, 1024, 1), (48, 256, 0), (17, 512, 1)])
 def test_head_kernels_match_torch_and_the_separate_launches(B, H, act):
-    """brl_ppo_heads_loss / brl_ppo_heads_bwd / brl_ppo_stats_gram / brl_bias_finalize_ex (the 39-column head of one PPO
-    minibatch step as three launches) against float64 torch and against the launches they replace: heads = h W^T + b;
-    d(heads), statistics partials and the illegal-action Gram matrix equal to brl_ppo_loss_heads / brl_ppo_stats on the SAME
-    heads (bit-identical d(heads)); dW_h, db_h, dh * act'(h) and its column sums vs torch; the illegal-action norm vs an SVD."""
+    """brl_ppo_heads_loss_split / brl_ppo_heads_bwd / brl_ppo_stats_gram / brl_bias_finalize_ex (the 39-column head of one PPO
+    minibatch step) against float64 torch and against the launches they replace: heads = h W^T + b; d(heads), statistics partials
+    and the illegal-action Gram matrix equal to brl_ppo_loss / brl_ppo_stats on the SAME heads (bit-identical d(heads)); dW_h, db_h,
+    dh * act'(h) and its column sums vs torch; the illegal-action norm vs an SVD."""
     from brl_amd import _capi
     L, dev = _capi.lib(), torch.device("cuda", 0)
     s = torch.cuda.current_stream().cuda_stream
@@ -2124,24 +2222,22 @@ def test_head_kernels_match_torch_and_the_separate_launches(B, H, act):
     groups, lgroups = (B + 15) // 16, (B + 3) // 4     # 16-row tiles of the column sums; 4-sample groups of the loss launch
     heads, dheads = torch.empty(B, 39, device=dev), torch.empty(B, 39, device=dev)
     partials, gram_p = torch.empty(lgroups, 8, device=dev), torch.empty(lgroups, 1444, device=dev)
+    def loss_of(hd, adv_):
+        """brl_ppo_loss on a given [B,39] heads matrix (logits = columns 0..37, row stride 39; value = column 38) -> d(heads) [B,39]"""
+        dl, dv = torch.empty(B, 38, device=dev), torch.empty(B, device=dev)
+        p2_, illp_ = torch.empty((B + 3) // 4, 8, device=dev), torch.empty(B, 38, device=dev)
+        val = hd[:, 38].contiguous()
+        _capi.check(L.brl_ppo_loss(0, hd.data_ptr(), 39, val.data_ptr(), mask.data_ptr(), action.data_ptr(), old_v.data_ptr(), old_lp.data_ptr(),
+                                   adv_.contiguous().data_ptr(), tgt.data_ptr(), B, 0.2, 0.5, 0.001, 1, 1, dl.data_ptr(), dv.data_ptr(),
+                                   p2_.data_ptr(), illp_.data_ptr(), s))
+        return torch.cat([dl, dv[:, None]], 1), p2_, illp_
+
     for rscale in (0, 1):
-        _capi.check(L.brl_ppo_heads_loss(0, h.data_ptr(), H, Wh.data_ptr(), bh.data_ptr(), H, mask.data_ptr(), action.data_ptr(),
-                                         old_v.data_ptr(), old_lp.data_ptr(), gae.data_ptr(), tgt.data_ptr(), B, 0.2, 0.5, 0.001, 1, 1,
-                                         rscale, heads.data_ptr(), dheads.data_ptr(), partials.data_ptr(), gram_p.data_ptr(), s))
         want = (h.double() @ Wh.double().t() + bh.double())
-        assert float((heads.double() - want).abs().max()) < 2e-5          # fp32 sum of 1024 products
-        # the loss of those heads by the separate launch (same device function: bit-identical gradients)
         adv = (gae - gae.mean()) / (gae.std(unbiased=False) + 1e-8) if rscale else gae
-        dh2, p2, illp = torch.empty(B, 39, device=dev), torch.empty((B + 3) // 4, 8, device=dev), torch.empty(B, 38, device=dev)
-        _capi.check(L.brl_ppo_loss_heads(0, heads.data_ptr(), mask.data_ptr(), action.data_ptr(), old_v.data_ptr(), old_lp.data_ptr(),
-                                         adv.contiguous().data_ptr(), tgt.data_ptr(), B, 0.2, 0.5, 0.001, 1, 1, dh2.data_ptr(),
-                                         p2.data_ptr(), illp.data_ptr(), s))
-        if rscale == 0:
-            assert torch.equal(dheads, dh2)
-        else:   # the in-kernel mean / std differ from torch's in the last bits
-            assert torch.allclose(dheads, dh2, rtol=1e-4, atol=1e-9)
-        # the two-launch form (heads product split over K across workgroups, then the loss on bias + parts): the same heads up
-        # to the order of the fp32 sums, and d(heads) / partials / Gram partials equal to the separate loss launch on ITS heads
+        # the heads product split over K across workgroups, then the loss on bias + parts: the same heads up to the order of the
+        # fp32 sums, and d(heads) / partials / Gram partials equal to the separate loss launch on ITS heads
+        first = None
         for ksplit in (1, 4) if H % 64 == 0 else (1, 2):
             heads3, dheads3 = torch.empty(B, 39, device=dev), torch.empty(B, 39, device=dev)
             partials3, gram_p3 = torch.empty(lgroups, 8, device=dev), torch.empty(lgroups, 1444, device=dev)
@@ -2151,18 +2247,19 @@ def test_head_kernels_match_torch_and_the_separate_launches(B, H, act):
                                                    1, 1, rscale, heads3.data_ptr(), dheads3.data_ptr(), partials3.data_ptr(),
                                                    gram_p3.data_ptr(), hparts.data_ptr(), ksplit, s))
             assert not torch.isnan(hparts).any()
-            assert float((heads3.double() - want).abs().max()) < 2e-5
-            dh3 = torch.empty(B, 39, device=dev)
-            _capi.check(L.brl_ppo_loss_heads(0, heads3.data_ptr(), mask.data_ptr(), action.data_ptr(), old_v.data_ptr(), old_lp.data_ptr(),
-                                             adv.contiguous().data_ptr(), tgt.data_ptr(), B, 0.2, 0.5, 0.001, 1, 1, dh3.data_ptr(),
-                                             p2.data_ptr(), illp.data_ptr(), s))
+            assert float((heads3.double() - want).abs().max()) < 2e-5          # fp32 sum of 1024 products
+            dh3, p2, illp = loss_of(heads3, adv)
             if rscale == 0:
                 assert torch.equal(dheads3, dh3)
-            else:
+            else:   # the in-kernel mean / std differ from torch's in the last bits
                 assert torch.allclose(dheads3, dh3, rtol=1e-4, atol=1e-9)
-            assert torch.allclose(dheads3, dheads, rtol=1e-3, atol=1e-6)
-            assert torch.allclose(partials3.sum(0), partials.sum(0), rtol=1e-4, atol=1e-5)
-            assert torch.allclose(gram_p3.sum(0), gram_p.sum(0), rtol=1e-4, atol=1e-7)
+            if first is None:
+                first = (dheads3, partials3, gram_p3)
+                heads.copy_(heads3); dheads.copy_(dheads3); partials.copy_(partials3); gram_p.copy_(gram_p3)
+            assert torch.allclose(dheads3, first[0], rtol=1e-3, atol=1e-6)
+            assert torch.allclose(partials3.sum(0), first[1].sum(0), rtol=1e-4, atol=1e-5)
+            assert torch.allclose(gram_p3.sum(0), first[2].sum(0), rtol=1e-4, atol=1e-7)
+        _, p2, illp = loss_of(heads, adv)
         assert torch.allclose(partials.sum(0), p2.sum(0), rtol=1e-4, atol=1e-5)
         gram = illp.double().t() @ illp.double()
         assert torch.allclose(gram_p.sum(0).double().reshape(38, 38), gram, rtol=1e-4, atol=1e-7)
@@ -2266,73 +2363,6 @@ def test_mlp_gemm_matches_float64(layout, epi, M, N, K, act):
     _capi.check(L.brl_mlp_gemm(0, layout, epi, A.data_ptr(), A.stride(0), Bm.data_ptr(), Bm.stride(0), C2.data_ptr(), N, M, N, K, act,
                                bias.data_ptr(), gate.data_ptr(), N, colsum.data_ptr(), sqsum.data_ptr(), s))
     assert torch.equal(C, C2)
-
-
-@pytest.mark.parametrize("B,Ho,Hi,act", [(1024, 1024, 1024, 0), (1000, 256, 512, 1), (64, 128, 64, 0)])
-def test_mlp_gemm_backward_pair_matches_float64(B, Ho, Hi, act):
-    """brl_mlp_gemm_bwd_pair: dz_{l-1} = (dz_l W_l) * act'(h_{l-1}) with the bias gradient's 64-row tile sums AND dW_l = dz_l^T h_{l-1}
-    with its tile square sums from ONE launch (src/update.py:86-178 under jax.grad), against float64 products of the same operands."""
-    from brl_amd import _capi
-    L = _capi.lib()
-    g = torch.Generator(device="cuda").manual_seed(B + Ho + Hi)
-    r = lambda *sh: (torch.rand(sh, device="cuda", generator=g) * 2 - 1)  # noqa: E731
-    dz, W, hp = r(B, Ho), r(Ho, Hi), r(B, Hi)
-    dz_out, dW = torch.full((B, Hi), float("nan"), device="cuda"), torch.full((Ho, Hi), float("nan"), device="cuda")
-    tb = (B + 63) // 64
-    colsum = torch.zeros((tb, Hi), device="cuda")
-    sqsum = torch.zeros((((Ho + 63) // 64) * ((Hi + 31) // 32),), device="cuda")
-    s = torch.cuda.current_stream().cuda_stream
-    _capi.check(L.brl_mlp_gemm_bwd_pair(0, dz.data_ptr(), Ho, W.data_ptr(), Hi, hp.data_ptr(), Hi, dz_out.data_ptr(), Hi, dW.data_ptr(), Hi,
-                                        B, Ho, Hi, act, colsum.data_ptr(), sqsum.data_ptr(), None, None, 0, 0, 0, None, None, None, None,
-                                        0, None, None, None, s))
-    torch.cuda.synchronize()
-    gate = (hp > 0).double() if act == 0 else (1 - hp.double() ** 2)
-    ref_dz = (dz.double() @ W.double()) * gate
-    ref_dW = dz.double().t() @ hp.double()
-    assert float((dz_out.double() - ref_dz).abs().max()) < 2e-4 * max(1.0, float(ref_dz.abs().max())) * (Ho / 1024 + 1) ** 0.5
-    assert float((dW.double() - ref_dW).abs().max()) < 2e-4 * max(1.0, float(ref_dW.abs().max())) * (B / 1024 + 1) ** 0.5
-    want = torch.stack([dz_out[64 * t:64 * t + 64].double().sum(0) for t in range(tb)])
-    assert float((colsum.double() - want).abs().max()) < 1e-3
-    assert abs(float(sqsum.double().sum()) - float((dW.double() ** 2).sum())) <= 1e-5 * max(1.0, float((dW.double() ** 2).sum()))
-
-
-@pytest.mark.parametrize("B,H,K,act,tw", [(1024, 1024, 1024, 0, 32), (1024, 1024, 1024, 0, 64), (1000, 256, 512, 1, 32), (48, 512, 480, 0, 64)])
-def test_mlp_gemm_forward_with_heads_matches_float64(B, H, K, act, tw):
-    """brl_mlp_gemm_fwd_heads: the last hidden layer (bias + activation) AND, per 64-column tile, its share of the 39-column head
-    product (src/models.py:30-33) from one launch; the sum of the parts against a float64 product of the STORED layer output, and
-    brl_ppo_heads_loss_parts' heads (bias + parts in order) against the same."""
-    from brl_amd import _capi
-    L = _capi.lib()
-    g = torch.Generator(device="cuda").manual_seed(B + H + K)
-    r = lambda *sh: (torch.rand(sh, device="cuda", generator=g) * 2 - 1)  # noqa: E731
-    x, W, b, Wh, bh = r(B, K), r(H, K) * 0.1, r(H), r(39, H) * 0.1, r(39)
-    y = torch.full((B, H), float("nan"), device="cuda")
-    nparts = (H + tw - 1) // tw     # (the number of parts selects the tile width)
-    parts = torch.full((nparts, B, 39), float("nan"), device="cuda")
-    s = torch.cuda.current_stream().cuda_stream
-    _capi.check(L.brl_mlp_gemm_fwd_heads(0, x.data_ptr(), K, W.data_ptr(), K, y.data_ptr(), H, B, H, K, act, b.data_ptr(), Wh.data_ptr(), H,
-                                         parts.data_ptr(), nparts, s))
-    torch.cuda.synchronize()
-    ref = x.double() @ W.double().t() + b.double()
-    ref = ref.clamp_min(0) if act == 0 else ref.tanh()
-    assert float((y.double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
-    want = y.double() @ Wh.double().t()                         # on what was STORED
-    assert not torch.isnan(parts).any()
-    assert float((parts.double().sum(0) - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
-    for t in range(nparts):                                     # every part is its own tile's share
-        wt = y[:, tw * t:tw * t + tw].double() @ Wh[:, tw * t:tw * t + tw].double().t()
-        assert float((parts[t].double() - wt).abs().max()) < 1e-4 * max(1.0, float(wt.abs().max()))
-    # the loss launch on those parts forms heads = bias + parts in order
-    mask = torch.ones((B, 38), dtype=torch.uint8, device="cuda")
-    z = lambda *sh: torch.zeros(sh, device="cuda")  # noqa: E731
-    action = torch.zeros(B, dtype=torch.int32, device="cuda")
-    heads, dheads, partials, gram = z(B, 39), z(B, 39), z((B + 3) // 4, 8), z((B + 3) // 4, 1444)
-    lp = torch.full((B,), -3.6, device="cuda")
-    _capi.check(L.brl_ppo_heads_loss_parts(0, bh.data_ptr(), parts.data_ptr(), nparts, mask.data_ptr(), action.data_ptr(), z(B).data_ptr(),
-                                           lp.data_ptr(), z(B).data_ptr(), z(B).data_ptr(), B, 0.2, 0.5, 0.001, 1, 1, 0, heads.data_ptr(),
-                                           dheads.data_ptr(), partials.data_ptr(), gram.data_ptr(), s))
-    torch.cuda.synchronize()
-    assert float((heads.double() - (want + bh.double())).abs().max()) < 2e-4 * max(1.0, float(want.abs().max()))
 
 
 def test_mlp_gemm_rejects_what_it_cannot_do():

@@ -1,8 +1,8 @@
 """-m gpu: the RCCL path on real links — `bench.py --gpus 2` end to end over "nccl", one GPU per rank (BASELINE.json
 configs[4] is the same launch at N = 8).  SKIPPED with a reason on a box with fewer than 2 GPUs; the N-rank control flow
 is covered there by the gloo rehearsal below and by tests/test_bench_launcher.py on CPU.  (The two-rank ppo.py loop and
-the bucketed gradient all-reduce over RCCL: tests/test_gpu_parity.py::test_ppo_loop_two_ranks_rccl,
-::test_fused_update_with_gradient_allreduce_two_ranks_rccl.)"""
+the gradient collectives over RCCL: tests/test_gpu_parity.py::test_ppo_loop_two_ranks_rccl,
+::test_fused_update_with_gradient_collectives_two_ranks_rccl.)"""
 import json
 import os
 import subprocess
