@@ -783,19 +783,23 @@ def bench_ppo(args, torch, dev, rank, world, barrier, max_over_ranks):
         torch.cuda.tunable.set_max_tuning_duration(30)
         if os.environ.get("BRL_TUNABLEOP_FILE"):
             torch.cuda.tunable.set_filename(os.environ["BRL_TUNABLEOP_FILE"])
-    cfg = dict(DEFAULTS, num_envs=NUM_ENVS, num_steps=NUM_STEPS, minibatch_size=1024, update_epochs=10,
+    # BRL_BENCH_PPO_ENVS / _EPOCHS: a REDUCED size for rehearsals of the N-rank path on a box with fewer GPUs than ranks (gloo
+    # ranks sharing a device: tests/test_multi_gpu_rccl.py); the record then says so and is not a measurement of configs[3] / [4]
+    n_envs = int(os.environ.get("BRL_BENCH_PPO_ENVS", NUM_ENVS))
+    epochs = int(os.environ.get("BRL_BENCH_PPO_EPOCHS", 10))
+    cfg = dict(DEFAULTS, num_envs=n_envs, num_steps=NUM_STEPS, minibatch_size=1024, update_epochs=epochs,
                inference_dtype=(os.environ.get("BRL_INFER_DTYPE", "fp32").replace("fp32", "") or None), graph_rollout=True)
     # (default = the reference's fp32 forwards; BRL_INFER_DTYPE=bf16 / fp16 = the opt-in, narrower inference path)
     cfg["num_minibatches"] = cfg["num_envs"] * cfg["num_steps"] // cfg["minibatch_size"]
     keys, values = synthetic_lut(LUT_LEN, 0)
-    env = brl_amd.BridgeBidding(lut=(keys, values), device=dev, env_offset=rank * NUM_ENVS)
+    env = brl_amd.BridgeBidding(lut=(keys, values), device=dev, env_offset=rank * n_envs)
     fp = make_forward_pass("relu", "DeepMind")
     params = fp.init(0, device=dev)
     opt_state = make_optimizer(cfg, params)
     roll_out = brl_amd.make_roll_out(cfg, env, fp, fp)
     calc_gae = brl_amd.make_calc_gae(cfg, fp)
     update_step = make_update_step(cfg, fp)
-    st = env.init(0, num_envs=NUM_ENVS)
+    st = env.init(0, num_envs=n_envs)
     rs = (params, opt_state, st, st.observation, 0, 0)
     iters = max(1, min(args.steps, 5))
     phases = {"rollout": [], "gae": [], "update": []}
@@ -820,9 +824,9 @@ def bench_ppo(args, torch, dev, rank, world, barrier, max_over_ranks):
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     med = {k: float(np.median(v)) for k, v in phases.items()}
-    rows = NUM_ENVS * NUM_STEPS
+    rows = n_envs * NUM_STEPS
     fwd_flop = 2 * 3_677_184                      # 7.354 MFLOP per forward per sample
-    roll_flop = 4 * rows * fwd_flop + NUM_ENVS * fwd_flop
+    roll_flop = 4 * rows * fwd_flop + n_envs * fwd_flop
     upd_flop = UPDATE_FLOP_PER_SAMPLE * rows * cfg["update_epochs"]   # executed: no input gradient for layer 0 (see bench_secondary)
     return {
         "metric": "ppo.py iteration macro-steps/sec at num_envs=8192, num_steps=32, minibatch 1024, 10 epochs (secondary, configs[3])",
@@ -830,16 +834,18 @@ def bench_ppo(args, torch, dev, rank, world, barrier, max_over_ranks):
         "ms_per_step": elapsed / iters * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": f"rollout inference {cfg['inference_dtype'] or 'fp32'}, update fp32", "data": "synthetic",
         "config": {"workload": "configs[3]: roll_out (policy in the loop, competitive) + calc_gae + update_step",
-                   "num_envs_per_gpu": NUM_ENVS, "num_steps": NUM_STEPS, "minibatch_size": 1024, "update_epochs": 10,
-                   "graph_rollout": True},
+                   "num_envs_per_gpu": n_envs, "num_steps": NUM_STEPS, "minibatch_size": 1024, "update_epochs": epochs,
+                   "graph_rollout": True, "grad_allreduce": getattr(rs[1].get("graphed"), "allreduce_mode", None),
+                   "collectives_inside_the_graph": getattr(rs[1].get("graphed"), "in_graph", None),
+                   "rehearsal_size": (n_envs, epochs) != (NUM_ENVS, 10)},
         "phases_ms": {k: v * 1e3 for k, v in med.items()},
         "rollout": {"macro_steps_per_s": rows / med["rollout"], "raw_env_steps_per_s": 4 * rows / med["rollout"],
                     "gemm_tflops": roll_flop / med["rollout"] / 1e12,
                     "mfma_peak_tflops": 2500.0 if cfg["inference_dtype"] in ("bf16", "fp16") else 157.3},
         "update": {"gemm_tflops": upd_flop / med["update"] / 1e12, "mfma_peak_tflops": 157.3,
                    "gemm_flop_per_step": UPDATE_FLOP_PER_SAMPLE * 1024,
-                   "note": "fp32 GEMMs as executed (forward, dW for every layer, dX for every layer but the first), 2560 minibatch "
-                           "steps of 1024 samples, hipGraph-replayed"},
+                   "note": "fp32 GEMMs as executed (forward, dW for every layer, dX for every layer but the first), "
+                           f"{epochs * rows // 1024} minibatch steps of 1024 samples, hipGraph-replayed"},
     }
 
 

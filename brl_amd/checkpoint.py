@@ -82,8 +82,18 @@ class _FlatMapping(dict):
             self.update(state.get("_mapping", state))
 
 
+def _encode_latin1(text, encoding="latin1"):
+    """stand-in for ``_codecs.encode`` in a protocol <= 2 numpy reduce (`_codecs.encode(<array bytes as str>, 'latin1')`): that one
+    form only — the real function would import whatever codec module an untrusted file names (bz2, zlib, ...)"""
+    if encoding not in ("latin1", "latin-1") or not isinstance(text, str):
+        raise pickle.UnpicklingError(f"refusing _codecs.encode(..., {encoding!r}): only numpy's latin1 byte strings belong in a parameter tree")
+    return text.encode("latin1")
+
+
 class _HaikuUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
+        if (module, name) == ("_codecs", "encode"):
+            return _encode_latin1
         if module.startswith("jax") and name == "_reconstruct_array":
             return _reconstruct_array
         if module.startswith("haiku") and name in ("FlatMapping", "FlatMap"):
@@ -99,8 +109,8 @@ class _HaikuUnpickler(pickle.Unpickler):
 
 _SAFE_GLOBALS = frozenset(
     [(m, n) for m in ("numpy.core.multiarray", "numpy._core.multiarray") for n in ("_reconstruct", "scalar")]
-    + [("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),   # ndarray.__reduce_ex__ under protocol 5
-       ("_codecs", "encode")]                                                           # array bytes under protocol <= 2
+    + [("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer")]   # ndarray.__reduce_ex__ under protocol 5
+    # (array bytes under protocol <= 2 come through `_codecs.encode`: resolved to `_encode_latin1` above, never the real function)
     + [("numpy", "ndarray"), ("numpy", "dtype"), ("collections", "OrderedDict"), ("builtins", "dict"), ("builtins", "list"),
        ("builtins", "tuple"), ("builtins", "set"), ("builtins", "frozenset")])
 

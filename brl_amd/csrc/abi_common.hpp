@@ -1,5 +1,5 @@
 // abi_common.hpp — what every translation unit of libbrl_hip.so shares on the host side: the thread-local error message behind
-// brl_last_error() (owned by brl_kernels.hip) and the argument / HIP-call checks of the C-ABI entry points (include/brl_hip.h).
+// brl_last_error() (owned by brl_env.hip) and the argument / HIP-call checks of the C-ABI entry points (include/brl_hip.h).
 #pragma once
 #include <hip/hip_runtime.h>
 

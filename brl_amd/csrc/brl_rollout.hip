@@ -1,7 +1,6 @@
-// brl_kernels.hip — translation unit of libbrl_hip.so: the environment (init / step / observe), the fused rollouts, the evaluators' step
-// and the 16-bit inference layer, with their C-ABI entry points (include/brl_hip.h) and the handle.  The PPO update lives in
-// brl_ppo.hip, the step's own fp32 GEMM in brl_mlp_gemm.hip.
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see brl_amd/build.py)
+// brl_rollout.hip — translation unit of libbrl_hip.so: the fused random-policy rollouts (k_rollout_fs — the BASELINE step —,
+// k_rollout_ws, k_rollout_random<K>: src/roll_out.py:49-108 with the uniform-random masked policy) and the policy sub-step of the
+// MLP-in-the-loop rollout (k_policy_step: sample / arg-max + auto_reset(step) + macro-step bookkeeping, src/utils.py:69-128).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -9,270 +8,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "../../include/brl_hip.h"
-#include "bridge_device.hpp"
-
-using namespace brl;
-
-// =====================================================================================
-// wave-level helpers (K tables per 64-lane wave, 4 waves per 256-thread workgroup)
-// =====================================================================================
-constexpr int WAVES_PER_BLOCK = 4;
-constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
-
-// Consecutive table groups go to the same XCD (blocks b and b+8 share one): neighbouring
-// rows of the [n,480] / [n,38] outputs share 128-B lines, keep those in ONE L2.  Speed only.
-__device__ __forceinline__ int64_t xcd_block(int64_t b, int64_t nb) {
-  return (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
-}
-
-template <int K>
-struct Wave {
-  LaneConst c;
-  uint8_t *wimg;   // this wave's K x 128 B LDS images
-  int tl;          // local table of this lane's logic (lane % K)
-  int64_t table0;  // first table of the wave
-  int64_t table;   // table of this lane's logic
-  bool valid;      // table < n
-};
-
-template <int K>
-__device__ __forceinline__ Wave<K> wave_begin(uint8_t *lds, const uint64_t *state_in, int64_t n, Tbl &t) {
-  Wave<K> w;
-  w.c = make_lane_const();
-  int wave = (int)(threadIdx.x >> 6);
-  int64_t blk = xcd_block((int64_t)blockIdx.x, (int64_t)gridDim.x);
-  w.table0 = (blk * WAVES_PER_BLOCK + wave) * K;
-  w.wimg = lds + wave * K * TABLE_BYTES;
-  uint64_t *wimg64 = reinterpret_cast<uint64_t *>(w.wimg);
-#pragma unroll
-  for (int i = w.c.lane; i < K * 16; i += 64) {
-    int64_t tb = w.table0 + i / 16;
-    wimg64[i] = (state_in != nullptr && tb < n) ? state_in[w.table0 * 16 + i] : 0ull;
-  }
-  wave_lds_fence();
-  w.tl = w.c.lane % K;
-  w.table = w.table0 + w.tl;
-  w.valid = w.table < n;
-  load_scalars(t, w.wimg + w.tl * TABLE_BYTES);
-  return w;
-}
-
-template <int K>
-__device__ __forceinline__ void wave_end(const Wave<K> &w, const Tbl &t, uint64_t *state_out, int64_t n) {
-  if (w.c.lane < K) store_scalars(t, w.wimg + w.tl * TABLE_BYTES);
-  wave_lds_fence();
-  const uint64_t *wimg64 = reinterpret_cast<const uint64_t *>(w.wimg);
-#pragma unroll
-  for (int i = w.c.lane; i < K * 16; i += 64) {
-    int64_t tb = w.table0 + i / 16;
-    if (tb < n) state_out[w.table0 * 16 + i] = wimg64[i];
-  }
-}
-
-template <int K>
-__device__ __forceinline__ void wave_or_hist(const Wave<K> &w, int hist_bit) {
-  if (w.c.lane < K && hist_bit >= 0) {
-    uint32_t *p = reinterpret_cast<uint32_t *>(w.wimg + w.tl * TABLE_BYTES) + (hist_bit >> 5);
-    atomicOr(p, 1u << (hist_bit & 31));  // ds_or_b32
-  }
-}
-
-typedef uint32_t brl_u32x4 __attribute__((ext_vector_type(4)));
-
-// Write-through 16-byte store (sc0 sc1: the bytes go to memory now and the line is not kept in L2).  For everything a
-// fused rollout launch writes besides the observations: a plain store leaves a dirty line in the XCD's L2 and all of them — 15 MB of
-// mask rows and scalar columns — are written back when the kernel ENDS, after the last wave: 2.6 us of 27.4.
-__device__ __forceinline__ void store_wt16(void *p, brl_u32x4 v) {
-  // (s_nop: the compiler does not know that the instruction still reads its data registers for two more cycles)
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-
-struct LutRef {
-  const int4 *keys;
-  const int4 *values;
-  uint32_t len;
-  const uint4 *hands;  // per row: the four packed hand words (hand_obs[seat] << 4, image words 7..10), derived from keys
-};
-
-// the packed hand words of every LUT row, once per upload: what a re-deal copies into a table image
-// (same card -> observation-bit mapping as deal_image: obs bit i = rank * 4 + suit, wb5/vis_pgx.py:13-24)
-__global__ void k_lut_hands(const int4 *keys, uint4 *hands, int64_t len) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= len) return;
-  const int4 k = keys[r];
-  uint64_t h[4] = {0ull, 0ull, 0ull, 0ull};
-  for (int i = 0; i < 52; i++) {
-    const int os_rank = i >> 2, os_suit = i & 3, dsuit = 3 - os_suit, rank = (os_rank + 1) % 13;
-    const uint32_t w = (uint32_t)((dsuit == 0) ? k.x : ((dsuit == 1) ? k.y : ((dsuit == 2) ? k.z : k.w)));
-    const uint32_t owner = (w >> (2 * (12 - rank))) & 3u;
-#pragma unroll
-    for (int s = 0; s < 4; s++) h[s] |= (owner == (uint32_t)s) ? (1ull << (4 + i)) : 0ull;
-  }
-  hands[2 * r] = make_uint4((uint32_t)h[0], (uint32_t)(h[0] >> 32), (uint32_t)h[1], (uint32_t)(h[1] >> 32));
-  hands[2 * r + 1] = make_uint4((uint32_t)h[2], (uint32_t)(h[2] >> 32), (uint32_t)h[3], (uint32_t)(h[3] >> 32));
-}
-
-// A5 post-step half of auto_reset (src/utils.py:45-55) for every table of the wave that
-// just terminated: deal board bctr+1 of that slot, keep (terminated, rewards).
-template <int K>
-__device__ __forceinline__ void wave_reset(const Wave<K> &w, Tbl &t, bool need, const Rng &g, uint64_t env_offset,
-                                           const LutRef &lut, uint32_t next_ctr) {
-  uint64_t needm = __ballot(need) & ((1ull << K) - 1ull);
-  if (needm == 0ull) return;
-  uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-  if (need) {
-    uint32_t keep = t.sc & ((1u << SC_TERM) | (1u << SC_ILLEGAL));
-    fresh_scalars(t, g, env_offset + (uint64_t)w.table, next_ctr, lut.len, keep);
-    int4 kv = lut.keys[t.lut];
-    int4 vv = lut.values[t.lut];
-    q0 = (uint32_t)kv.x; q1 = (uint32_t)kv.y; q2 = (uint32_t)kv.z; q3 = (uint32_t)kv.w;
-    pack_tricks(t, (uint32_t)vv.x, (uint32_t)vv.y, (uint32_t)vv.z, (uint32_t)vv.w);
-  }
-  while (needm) {
-    int j = __ffsll((unsigned long long)needm) - 1;
-    needm &= needm - 1ull;
-    deal_image(w.wimg + j * TABLE_BYTES, __builtin_amdgcn_readlane(q0, j), __builtin_amdgcn_readlane(q1, j),
-               __builtin_amdgcn_readlane(q2, j), __builtin_amdgcn_readlane(q3, j), w.c);
-  }
-  wave_lds_fence();
-}
-
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, int j) {
-  uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, j);
-  uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), j);
-  return ((uint64_t)hi << 32) | lo;
-}
-
-// emit obs/mask rows of the wave's K tables; row of table0 is row0 (rows are consecutive)
-template <int K>
-__device__ __forceinline__ void wave_emit(const Wave<K> &w, int64_t n, int oseat, uint32_t vulnib, uint64_t legal,
-                                          uint8_t *obs, uint8_t *mask, int64_t row0) {
-  uint32_t pack = (uint32_t)oseat | (vulnib << 2);
-#pragma unroll
-  for (int j = 0; j < K; j++) {
-    if (w.table0 + j < n) {
-      if (obs) {
-        uint32_t p = __builtin_amdgcn_readlane(pack, j);
-        emit_obs_row(w.wimg + j * TABLE_BYTES, (int)(p & 3u), p >> 2, obs + (row0 + j) * BRL_OBS_SIZE, w.c);
-      }
-      if (mask) emit_mask_row(readlane64(legal, j), mask + (row0 + j) * BRL_NUM_ACTIONS, w.c);
-    }
-  }
-}
-
-__device__ __forceinline__ float4 rewards_f32(const Tbl &t) {
-  return make_float4((float)reward_of(t, 0), (float)reward_of(t, 1), (float)reward_of(t, 2), (float)reward_of(t, 3));
-}
-
-__device__ __forceinline__ int sanitize_action(int a, uint32_t &bad) {
-  bad = ((uint32_t)a >= (uint32_t)BRL_NUM_ACTIONS) ? 1u : 0u;
-  return bad ? 0 : a;
-}
-
-// =====================================================================================
-// kernels
-// =====================================================================================
-struct StepOut {
-  uint8_t *obs;
-  uint8_t *mask;
-  float *rewards;
-  uint8_t *terminated;
-  int32_t *current_player;
-};
-
-template <int K>
-__device__ __forceinline__ void wave_step_outputs(const Wave<K> &w, const Tbl &t, int64_t n, const StepOut &o) {
-  int oseat = cur_seat(t);
-  wave_emit<K>(w, n, oseat, vul_nibble(t, oseat), legal_mask(t), o.obs, o.mask, w.table0);
-  if (w.c.lane < K && w.valid) {
-    if (o.rewards) reinterpret_cast<float4 *>(o.rewards)[w.table] = rewards_f32(t);
-    if (o.terminated) o.terminated[w.table] = (uint8_t)bits(t.sc, SC_TERM, 1);
-    if (o.current_player) o.current_player[w.table] = cur_player(t);
-  }
-}
-
-// ---- A1 init(random) ----------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(BLOCK_THREADS) void k_init_random(uint64_t *state, int64_t n, Rng g, uint64_t env_offset,
-                                                               LutRef lut, uint32_t board_ctr0) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES_PER_BLOCK * K * TABLE_BYTES];
-  Tbl t;
-  Wave<K> w = wave_begin<K>(lds, nullptr, n, t);
-  t.sc = 0;
-  wave_reset<K>(w, t, w.valid, g, env_offset, lut, board_ctr0);
-  wave_end<K>(w, t, state, n);
-}
-
-// ---- A1 init(explicit deals) — one thread per table (not a hot path) ------------------
-__global__ void k_init_explicit(uint64_t *state, int64_t n, const int32_t *hand, const int32_t *dealer,
-                                const uint8_t *vul_ns, const uint8_t *vul_ew, const int32_t *shuffled,
-                                const uint8_t *tricks) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  uint64_t *s = state + e * BRL_STATE_WORDS;
-  for (int i = 0; i < 7; i++) s[i] = 0;
-  for (int seat = 0; seat < 4; seat++) {
-    uint64_t m = 0;
-    for (int i = 0; i < 13; i++) {
-      int card = hand[e * 52 + seat * 13 + i];
-      int suit = card / 13, rank = card % 13;
-      int idx = ((rank + 12) % 13) * 4 + (3 - suit);  // wb5/utils.py:18-19 via pgx card order
-      m |= 1ull << idx;
-    }
-    s[W_HAND + seat] = m << 4;
-  }
-  uint32_t shuf = 0;
-  for (int seat = 0; seat < 4; seat++) shuf |= ((uint32_t)shuffled[e * 4 + seat] & 3u) << (2 * seat);
-  uint32_t sc = ((uint32_t)dealer[e] & 3u) | ((uint32_t)(vul_ns[e] != 0) << SC_VULNS) |
-                ((uint32_t)(vul_ew[e] != 0) << SC_VULEW) | (shuf << SC_SHUF);
-  uint32_t v[4];
-  for (int seat = 0; seat < 4; seat++) {
-    uint32_t x = 0;
-    for (int d = 0; d < 5; d++) x = x * 16u + (tricks[e * 20 + seat * 5 + d] & 15u);
-    v[seat] = x;
-  }
-  Tbl t;
-  pack_tricks(t, v[0], v[1], v[2], v[3]);
-  s[W_SC] = (uint64_t)sc;
-  s[W_FD] = (uint64_t)t.t2 << 32;
-  s[W_TR] = (uint64_t)t.t0 | ((uint64_t)t.t1 << 32);
-  s[W_CTR] = 0xFFFFFFFFull;
-  s[W_REW] = 0;
-}
-
-// ---- A2/A5 step ------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(BLOCK_THREADS) void k_step(const uint64_t *state_in, uint64_t *state_out, int64_t n,
-                                                        const int32_t *action, int autoreset, Rng g,
-                                                        uint64_t env_offset, LutRef lut, StepOut o) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES_PER_BLOCK * K * TABLE_BYTES];
-  Tbl t;
-  Wave<K> w = wave_begin<K>(lds, state_in, n, t);
-  uint32_t bad;
-  int a = sanitize_action(w.valid ? action[w.table] : 0, bad);
-  if (autoreset) auto_reset_clear(t);
-  bool live = !bits(t.sc, SC_TERM, 1);
-  int hb = table_step(t, a);
-  if (bad && live) t.sc |= (1u << SC_TERM) | (1u << SC_ILLEGAL) | (1u << SC_MASKALL);
-  wave_or_hist<K>(w, hb);
-  wave_lds_fence();
-  if (autoreset) wave_reset<K>(w, t, w.valid && bits(t.sc, SC_TERM, 1), g, env_offset, lut, t.bctr + 1u);
-  wave_step_outputs<K>(w, t, n, o);
-  wave_end<K>(w, t, state_out, n);
-}
-
-// ---- A3 observe --------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(BLOCK_THREADS) void k_observe(const uint64_t *state, int64_t n, const int32_t *player_id,
-                                                           uint8_t *obs, uint8_t *mask) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES_PER_BLOCK * K * TABLE_BYTES];
-  Tbl t;
-  Wave<K> w = wave_begin<K>(lds, state, n, t);
-  int oseat = cur_seat(t);
-  if (player_id != nullptr && w.valid) oseat = seat_of_player(t, player_id[w.table] & 3);
-  wave_emit<K>(w, n, oseat, vul_nibble(t, oseat), legal_mask(t), obs, mask, w.table0);
-}
+#include "handle.hpp"
+#include "policy_common.hpp"
 
 // ---- A7 fused random-policy rollout ------------------------------------------------------
 struct RolloutArgs {
@@ -1045,17 +782,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_ws(RolloutArgs A) {
 }
 
 #include "rollout_fs.hpp"  // k_rollout_fs: the flag-synchronised form of the same launch (default for the BASELINE shape)
-
 // ---- policy sub-step: masked categorical over logits + auto_reset(step) -------------------
-// What brl_set_rng / brl_set_lut change, mirrored in device memory: the policy sub-step reads it from there instead
-// of taking it by value, so that a hipGraph replay of a captured launch follows a later re-seed or LUT rotation
-// (ppo.py:525-549) instead of reading freed tables / a stale key.
-struct DevCtx {
-  LutRef lut;
-  Rng g;
-  uint64_t env_offset;
-};
-
 struct PolicyArgs {
   const uint64_t *state_in;
   uint64_t *state_out;
@@ -1072,118 +799,6 @@ struct PolicyArgs {
   StepOut o;  // o.rewards / o.terminated are ACCUMULATED
   brl_macro_ext x;  // optional per-macro-step bookkeeping (brl_policy_step_ex); all-zero otherwise
 };
-
-// Masked categorical of one table on the 64 / K lanes that share it (lane l: table l % K, slot l / K): slot s holds the
-// NI consecutive actions [s * NI, s * NI + NI).  Returns the chosen action and its log-probability on every lane of the
-// table.  `cand`: the actions the distribution ranges over — the legal ones (masked policy, src/roll_out.py:27-29) or
-// all 38 (unmasked / illegal-action-penalty policy, src/roll_out.py:33-39).
-//   mode bit 0: 0 = pi.sample (inverse CDF in action order with the 24-bit uniform of `u32`), 1 = pi.mode (first max)
-// network outputs as the GEMM wrote them: float (fmt 0), bf16 (1) or fp16 (2) -> float (exact conversions)
-__device__ __forceinline__ float net_out(const void *base, int64_t idx, int fmt) {
-  if (fmt == 0) return reinterpret_cast<const float *>(base)[idx];
-  const uint16_t h = reinterpret_cast<const uint16_t *>(base)[idx];
-  if (fmt == 1) return __uint_as_float((uint32_t)h << 16);
-  _Float16 f16;
-  __builtin_memcpy(&f16, &h, 2);
-  return (float)f16;
-}
-
-__device__ __forceinline__ float net_cvt(uint32_t raw, int fmt) {  // what net_out makes of the bits it loaded
-  if (fmt == 0) return __uint_as_float(raw);
-  if (fmt == 1) return __uint_as_float(raw << 16);
-  const uint16_t h = (uint16_t)raw;
-  _Float16 f16;
-  __builtin_memcpy(&f16, &h, 2);
-  return (float)f16;
-}
-
-template <int K>
-__device__ __forceinline__ int categorical(const void *logits, int64_t row_off, int fmt, bool valid, uint64_t cand, int mode,
-                                           uint32_t u32, int lane, float &log_prob) {
-  constexpr int LPT = 64 / K;
-  constexpr int NI = (BRL_NUM_ACTIONS + LPT - 1) / LPT;
-  const int tl = lane % K, slot = lane / K;
-  float lg[NI], e[NI];
-  bool ok[NI];
-  float mx = -INFINITY;
-  int amax = 64;
-  // the lane's NI logits: unconditional loads (clamped index), the format decided ONCE around all of them — a select or a
-  // format branch per element makes hipcc branch around every load and wait for each one (NI memory round trips)
-  uint32_t raw[NI];
-  const int64_t ro = valid ? row_off : 0;
-  if (fmt == 0) {
-#pragma unroll
-    for (int i = 0; i < NI; i++) raw[i] = reinterpret_cast<const uint32_t *>(logits)[ro + min(slot * NI + i, BRL_NUM_ACTIONS - 1)];
-  } else {
-#pragma unroll
-    for (int i = 0; i < NI; i++) raw[i] = reinterpret_cast<const uint16_t *>(logits)[ro + min(slot * NI + i, BRL_NUM_ACTIONS - 1)];
-  }
-#pragma unroll
-  for (int i = 0; i < NI; i++) {
-    const int a = slot * NI + i;
-    const bool in = a < BRL_NUM_ACTIONS;
-    lg[i] = (in && valid) ? net_cvt(raw[i], fmt) : 0.0f;
-    ok[i] = in && ((cand >> (a & 63)) & 1ull);
-    if (ok[i] && lg[i] > mx) {  // first maximum wins, like argmax
-      mx = lg[i];
-      amax = a;
-    }
-  }
-#pragma unroll
-  for (int off = K; off < 64; off <<= 1) {
-    const float omx = __shfl_xor(mx, off, 64);
-    const int oam = __shfl_xor(amax, off, 64);
-    const bool take = (omx > mx) || (omx == mx && oam < amax);
-    mx = take ? omx : mx;
-    amax = take ? oam : amax;
-  }
-  amax = (amax >= BRL_NUM_ACTIONS) ? 0 : amax;  // (no finite candidate logit: NaN / -inf everywhere)
-  float own = 0.0f;
-#pragma unroll
-  for (int i = 0; i < NI; i++) {
-    e[i] = ok[i] ? expf(lg[i] - mx) : 0.0f;
-    own += e[i];
-  }
-  // inclusive scan of the slots' sums in action order
-  float incl = own;
-#pragma unroll
-  for (int off = 1; off < LPT; off <<= 1) {
-    const float v = __shfl_up(incl, off * K, 64);
-    incl += (slot >= off) ? v : 0.0f;
-  }
-  const float total = __shfl(incl, (LPT - 1) * K + tl, 64);
-  float excl = __shfl_up(incl, K, 64);
-  excl = (slot == 0) ? 0.0f : excl;
-  int act = amax;
-  if (!(mode & 1)) {
-    const float target = (float)(u32 >> 8) * (1.0f / 16777216.0f) * total;  // inverse CDF, u in [0,1)
-    float cum = excl;
-    int first = 64, last = -1;
-#pragma unroll
-    for (int i = 0; i < NI; i++) {
-      cum += e[i];
-      if (ok[i]) {
-        last = slot * NI + i;
-        first = (first == 64 && cum > target) ? slot * NI + i : first;
-      }
-    }
-#pragma unroll
-    for (int off = K; off < 64; off <<= 1) {
-      first = min(first, __shfl_xor(first, off, 64));
-      last = max(last, __shfl_xor(last, off, 64));
-    }
-    act = (first < 64) ? first : max(last, 0);
-  }
-  // the chosen action's logit lives on slot act / NI
-  const int ai = act % NI;
-  float sel = lg[0];
-#pragma unroll
-  for (int i = 1; i < NI; i++) sel = (ai == i) ? lg[i] : sel;
-  const float la = __shfl(sel, (act / NI) * K + tl, 64);
-  log_prob = (la - mx) - logf(total);
-  return act;
-}
-
 // HEADS: the 39 head outputs (38 logits + value) of the workgroup's 16 tables are formed HERE from the last hidden layer's
 // activations (A.x.head_h, bf16 / fp16) and the head weights: one 16-row MFMA tile, the K = hidden sum split over the four waves
 // (v_mfma_f32_16x16x32_bf16 / _f16, fp32 accumulation), partial sums through LDS.  Replaces the N = 39 library GEMM in front of
@@ -1405,542 +1020,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_policy_step(PolicyArgs A) {
   wave_end<K>(w, t, A.state_out, A.n);
 }
 
-// ---- A12 duplicate_step ---------------------------------------------------------------------
-__device__ __forceinline__ float4 imp_vector(float a0, float b0) {
-  const float th[24] = {20, 50, 90, 130, 170, 220, 270, 320, 370, 430, 500, 600,
-                        750, 900, 1100, 1300, 1500, 1750, 2000, 2250, 2500, 3000, 3500, 4000};
-  float d = a0 + b0;
-  float win = (d >= 0.0f) ? 1.0f : -1.0f;  // src/duplicate.py:52-54
-  float ad = fabsf(d);
-  int imp = 0;
-#pragma unroll
-  for (int i = 0; i < 24; i++) imp += (ad >= th[i]) ? 1 : 0;  // src/duplicate.py:46-69
-  float v = (float)imp * win;
-  return make_float4(v, v, -v, -v);
-}
-
-// Probability mass the UNMASKED softmax of a table's logits puts on illegal actions — `jnp.dot(pi.probs, ~mask)` of the
-// evaluators' step log (src/evaluation.py:664-665).  Same lane layout as categorical<K>.
-template <int K>
-__device__ __forceinline__ float illegal_mass(const float *logits_row, bool valid, uint64_t legal, int lane) {
-  constexpr int LPT = 64 / K;
-  constexpr int NI = (BRL_NUM_ACTIONS + LPT - 1) / LPT;
-  const int slot = lane / K;
-  float lg[NI];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int i = 0; i < NI; i++) {
-    const int a = slot * NI + i;
-    lg[i] = (a < BRL_NUM_ACTIONS && valid) ? logits_row[a] : -INFINITY;
-    mx = fmaxf(mx, lg[i]);
-  }
-#pragma unroll
-  for (int off = K; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-  float all = 0.0f, ill = 0.0f;
-#pragma unroll
-  for (int i = 0; i < NI; i++) {
-    const int a = slot * NI + i;
-    const float e = (a < BRL_NUM_ACTIONS && valid) ? expf(lg[i] - mx) : 0.0f;
-    all += e;
-    ill += ((legal >> (a & 63)) & 1ull) ? 0.0f : e;
-  }
-#pragma unroll
-  for (int off = K; off < 64; off <<= 1) {
-    all += __shfl_xor(all, off, 64);
-    ill += __shfl_xor(ill, off, 64);
-  }
-  return ill / all;
-}
-
-// One iteration of the evaluators' loops (src/evaluation.py:87-204 simple duplicate, :583-1032 duplicate with bidding
-// statistics, :229-582 single table): the action — given, or the greedy call of the network whose team is to act
-// (players {0,1} = team 1, src/evaluation.py:146-151) —, the step log, duplicate_step (src/duplicate.py:147-192) or a
-// plain env.step, and the return accumulators.
-struct EvalArgs {
-  const uint64_t *state_in;
-  uint64_t *state_out;
-  int64_t n;
-  const int32_t *action;  // the calls to make, or NULL: arg-max of logits1 / logits2 by team
-  const float *logits1, *logits2;
-  int64_t stride1, stride2;
-  int duplicate;          // 1: duplicate_step with TA / TB; 0: env.step
-  brl_table_info TA, TB;
-  brl_eval_stats S;       // any member may be NULL
-  int bid_set;            // the single-table evaluator marks a bid made (.set(1)), the duplicate one counts it
-  float *cum_return;      // [n] += rewards[0] of the step (src/evaluation.py:167-169)
-  float *rewards_sum;     // [n,4] += rewards (src/evaluation.py:400; single-table evaluator)
-  int32_t *action_out;    // [n] the call made
-  StepOut o;
-  int acting_team;        // -1: every board acts (the reference's loop); 0 / 1: only the boards whose turn it is for THAT team
-                          // act, the others wait (finished boards always take their no-op step) — brl_eval_step_team
-  float *obs_f32;         // optional [n,480]: the new observation as the next forward's input (`.astype(jnp.float32)`) too
-};
-
-template <int K>
-__global__ __launch_bounds__(BLOCK_THREADS) void k_eval_step(EvalArgs A) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES_PER_BLOCK * K * TABLE_BYTES];
-  Tbl t;
-  Wave<K> w = wave_begin<K>(lds, A.state_in, A.n, t);
-  const bool was_term = bits(t.sc, SC_TERM, 1);
-  const int team = cur_player(t) >> 1;  // 0: players {0,1}
-  const bool idle = (A.acting_team >= 0) && !was_term && (team != A.acting_team);  // waits for its team's iteration
-  const uint64_t legal = legal_mask(t);
-  uint32_t bad = 0;
-  int a;
-  float mass = 0.0f;
-  if (A.action != nullptr) {
-    a = sanitize_action(w.valid ? A.action[w.table] : 0, bad);
-  } else {
-    const int64_t tb = w.valid ? w.table : 0;
-    const float *row = team ? A.logits2 + tb * A.stride2 : A.logits1 + tb * A.stride1;
-    float lp;
-    a = categorical<K>(row, 0, 0, w.valid, legal, 1, 0u, w.c.lane, lp);  // masked_pi.mode()
-    if (A.S.illegal_prob_sum) mass = illegal_mass<K>(row, w.valid, legal, w.c.lane);
-  }
-  if (w.c.lane < K && w.valid && !was_term && !idle) {  // make_step_log: finished boards log nothing (src/evaluation.py:736-748)
-    const int64_t st = w.table * 2 + team;
-    if (A.S.illegal_prob_sum) A.S.illegal_prob_sum[st] += mass;
-    if (A.S.step_count) A.S.step_count[st] += 1;
-    if (A.S.pass_count && a == 0) A.S.pass_count[st] += 1;
-    if (A.S.bid_count && a >= 3) {
-      int32_t *bc = A.S.bid_count + st * 35 + (a - 3);
-      *bc = A.bid_set ? 1 : *bc + 1;
-    }
-  }
-  int hb = idle ? -1 : table_step(t, a);  // src/duplicate.py:149
-  if (bad && !was_term && !idle) t.sc |= (1u << SC_TERM) | (1u << SC_ILLEGAL) | (1u << SC_MASKALL);
-  wave_or_hist<K>(w, hb);
-  wave_lds_fence();
-  if (A.duplicate) {
-    bool term = !idle && bits(t.sc, SC_TERM, 1);
-    bool a_done = w.valid ? (A.TA.terminated[w.table] != 0) : true;
-    bool b_done = w.valid ? (A.TB.terminated[w.table] != 0) : true;
-    bool to_b = w.valid && !a_done && term;                // table A just ended -> replay the board seat-swapped
-    bool emit_imp = w.valid && a_done && term && !b_done;  // table B just ended -> IMP once (G8)
-    float4 rw = rewards_f32(t);
-    // snapshots (src/duplicate.py:165-188) of the state as stepped
-    if (w.c.lane < K && (to_b || emit_imp)) {
-      const brl_table_info &T = to_b ? A.TA : A.TB;
-      T.terminated[w.table] = 1;
-      reinterpret_cast<float4 *>(T.rewards)[w.table] = rw;
-      T.last_bid[w.table] = (int)bits(t.sc, SC_LB1, 6) - 1;
-      T.last_bidder[w.table] = bits(t.sc, SC_LB1, 6) ? player_at(t, (int)bits(t.sc, SC_LBSEAT, 2)) : -1;
-      T.call_x[w.table] = (uint8_t)bits(t.sc, SC_X, 1);
-      T.call_xx[w.table] = (uint8_t)bits(t.sc, SC_XX, 1);
-    }
-    if (emit_imp) {
-      float4 ar = reinterpret_cast<const float4 *>(A.TA.rewards)[w.table];
-      float4 v = imp_vector(ar.x, rw.x);  // src/duplicate.py:157-160
-      set_rewards(t, (int)v.x, (int)v.y, (int)v.z, (int)v.w);
-    } else if (!idle) {
-      t.r01 = 0;  // src/duplicate.py:162
-      t.r23 = 0;
-    }
-    // _duplicate_init (src/duplicate.py:113-128): same hands / dealer / vulnerabilities,
-    // seats [1,0,3,2], everything else back to defaults
-    uint64_t tobm = __ballot(to_b) & ((1ull << K) - 1ull);
-    if (to_b) {
-      uint32_t sh = bits(t.sc, SC_SHUF, 8);
-      uint32_t sw = ((sh >> 2) & 0x03u) | ((sh & 0x03u) << 2) | ((sh >> 2) & 0x30u) | ((sh & 0x30u) << 2);
-      t.sc = (t.sc & 0xFu) | (sw << SC_SHUF);
-      t.sch = 0;
-      t.fd = 0;
-    }
-    if (tobm) {
-      uint64_t *wimg64 = reinterpret_cast<uint64_t *>(w.wimg);
-      for (int j = 0; j < K; j++)
-        if (((tobm >> j) & 1ull) && w.c.lane < 7) wimg64[j * 16 + w.c.lane] = 0ull;
-      wave_lds_fence();
-    }
-  }
-  if (w.c.lane < K && w.valid) {
-    if (A.action_out) A.action_out[w.table] = idle ? -1 : a;
-    if (A.cum_return && !idle) A.cum_return[w.table] += (float)reward_of(t, 0);
-    if (A.rewards_sum && !idle) {
-      float4 *p = reinterpret_cast<float4 *>(A.rewards_sum) + w.table;
-      const float4 old = *p, rw = rewards_f32(t);
-      *p = make_float4(old.x + rw.x, old.y + rw.y, old.z + rw.z, old.w + rw.w);
-    }
-  }
-  wave_step_outputs<K>(w, t, A.n, A.o);
-  if (A.obs_f32 != nullptr) {  // (as k_policy_step's obs_cast: the cast launch in front of a full-batch forward disappears)
-    const int oseat = cur_seat(t);
-    const uint32_t pack = (uint32_t)oseat | (vul_nibble(t, oseat) << 2);
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-      if (w.table0 + j < A.n) {
-        const uint32_t p = __builtin_amdgcn_readlane(pack, j);
-        emit_obs_row_cast(w.wimg + j * TABLE_BYTES, (int)(p & 3u), p >> 2,
-                          reinterpret_cast<uint8_t *>(A.obs_f32) + (w.table0 + j) * BRL_OBS_SIZE * 4, 0, w.c);
-      }
-    }
-  }
-  wave_end<K>(w, t, A.state_out, A.n);
-}
-
-// The evaluators' end-of-run statistics (src/evaluation.py:841-1031 make_terminated_log / make_contract_log and the
-// sums behind log_info): one thread per board, integer histograms in LDS, one atomic per bin and block.
-//   out[tb * EV_TABLE + ...], tb = 0 (table A) / 1 (table B):
-//     +0 pass-outs  +1/+2 doubled / redoubled contracts of team 1  +3/+4 of team 2  +5 team-1 "make"  +6 team-2 "make"
-//     +7 team-1 "down"  +8 team-2 "down" (the reference's labels: rewards[0] >= 0 x declaring team, :951-984)
-//     +9 sum of rewards[0] (table score of player 0)  +10..+44 team-1 contracts by bid  +45..+79 team-2 contracts
-//   out[2 * EV_TABLE + 35 * team + bid] = how often the team made the bid (sum of bid_count over boards)
-//   out[2 * EV_TABLE + 70] = sum of the final states' _step_count
-constexpr int EV_TABLE = 80, EV_TOTAL = 2 * EV_TABLE + 71;
-__global__ __launch_bounds__(256) void k_eval_reduce(int64_t n, brl_table_info TA, brl_table_info TB, int two_tables,
-                                                     const int32_t *bid_count, const uint64_t *state,
-                                                     long long *out) {
-  __shared__ long long h[EV_TOTAL];
-  for (int i = threadIdx.x; i < EV_TOTAL; i += blockDim.x) h[i] = 0;
-  __syncthreads();
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  auto add = [&](int i, long long v) { atomicAdd(reinterpret_cast<unsigned long long *>(&h[i]), (unsigned long long)v); };
-  if (e < n) {
-    for (int tb = 0; tb < (two_tables ? 2 : 1); tb++) {
-      const brl_table_info &T = tb ? TB : TA;
-      const int base = tb * EV_TABLE;
-      const int lb = T.last_bid[e], who = T.last_bidder[e];
-      const float r0 = T.rewards[e * 4];
-      add(base + 9, (long long)r0);
-      if (who == -1 && lb == -1) {  // passed out (G13, src/evaluation.py:841-842)
-        add(base + 0, 1);
-      } else {
-        const int team = (who < 2) ? 0 : 1;
-        add(base + 10 + 35 * team + lb, 1);
-        if (T.call_x[e]) add(base + 1 + 2 * team, 1);
-        if (T.call_xx[e]) add(base + 2 + 2 * team, 1);
-        add(base + ((r0 >= 0.0f) ? 5 : 7) + team, 1);
-      }
-    }
-    if (bid_count) {
-      // 70 counters per board = 35 aligned 8-byte pairs, fetched 7 pairs at a time and only then added (a load + a
-      // conditional add per element compiles to 70 dependent memory round trips)
-      const int2 *bc = reinterpret_cast<const int2 *>(bid_count + e * 70);
-      for (int i0 = 0; i0 < 35; i0 += 7) {
-        int2 c[7];
-#pragma unroll
-        for (int k = 0; k < 7; k++) c[k] = bc[i0 + k];
-#pragma unroll
-        for (int k = 0; k < 7; k++) {
-          if (c[k].x) add(2 * EV_TABLE + 2 * (i0 + k), c[k].x);
-          if (c[k].y) add(2 * EV_TABLE + 2 * (i0 + k) + 1, c[k].y);
-        }
-      }
-    }
-    if (state) add(2 * EV_TABLE + 70, (long long)bits((uint32_t)(state[e * BRL_STATE_WORDS + W_SC] >> 32), SCH_STEP, 10));
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < EV_TOTAL; i += blockDim.x)
-    if (h[i]) atomicAdd(reinterpret_cast<unsigned long long *>(&out[i]), (unsigned long long)h[i]);
-}
-
-// ---- A9 GAE reverse scan (src/gae.py:20-39): one lane per env, coalesced over envs --------
-// The recurrence is serial in t but its INPUTS are not: chunks of GAE_CHUNK steps are loaded up
-// front (3 x GAE_CHUNK independent loads in flight per lane) and then scanned from registers.
-constexpr int GAE_CHUNK = 32;  // all of a typical rollout's steps (ppo.py:36 num_steps=32) in flight at once
-__global__ __launch_bounds__(64) void k_gae(const uint8_t *done, const float *value, const float *reward,
-                                            const float *last_val, float gamma, float gamma_lambda, int T, int64_t n,
-                                            float *adv, float *tgt) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  float gae = 0.0f, next_value = last_val[e];
-  for (int t1 = T; t1 > 0; t1 -= GAE_CHUNK) {
-    float dn[GAE_CHUNK], vl[GAE_CHUNK], rw[GAE_CHUNK];
-#pragma unroll
-    for (int k = 0; k < GAE_CHUNK; k++) {
-      int t = t1 - 1 - k;
-      int64_t i = (int64_t)(t >= 0 ? t : 0) * n + e;
-      dn[k] = (float)done[i];
-      vl[k] = value[i];
-      rw[k] = reward[i];
-    }
-#pragma unroll
-    for (int k = 0; k < GAE_CHUNK; k++) {
-      int t = t1 - 1 - k;
-      if (t >= 0) {
-        int64_t i = (int64_t)t * n + e;
-        float nd = 1.0f - dn[k];
-        float delta = rw[k] + gamma * next_value * nd - vl[k];  // src/gae.py:28
-        gae = delta + gamma_lambda * nd * gae;                   // src/gae.py:29
-        adv[i] = gae;
-        tgt[i] = gae + vl[k];  // src/gae.py:39
-        next_value = vl[k];
-      }
-    }
-  }
-}
-
-// ---- A10 _imp_reward -----------------------------------------------------------------------
-__global__ void k_imp_reward(const float *a, const float *b, float *out, int64_t n) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  reinterpret_cast<float4 *>(out)[e] = imp_vector(a[e * 4], b[e * 4]);
-}
-
-// ---- State attribute access (one thread per table; test / host-mirror path) ------------------
-__global__ void k_get_fields(const uint64_t *state, int64_t n, brl_fields F) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  const uint64_t *s = state + e * BRL_STATE_WORDS;
-  Tbl t;
-  t.sc = (uint32_t)s[W_SC]; t.sch = (uint32_t)(s[W_SC] >> 32);
-  t.fd = (uint32_t)s[W_FD]; t.t2 = (uint32_t)(s[W_FD] >> 32);
-  t.t0 = (uint32_t)s[W_TR]; t.t1 = (uint32_t)(s[W_TR] >> 32);
-  t.lut = (uint32_t)s[W_CTR]; t.bctr = (uint32_t)(s[W_CTR] >> 32);
-  t.r01 = (uint32_t)s[W_REW]; t.r23 = (uint32_t)(s[W_REW] >> 32);
-  uint32_t lb1 = bits(t.sc, SC_LB1, 6);
-  if (F.current_player) F.current_player[e] = cur_player(t);
-  if (F.terminated) F.terminated[e] = (uint8_t)bits(t.sc, SC_TERM, 1);
-  if (F.rewards) reinterpret_cast<float4 *>(F.rewards)[e] = rewards_f32(t);
-  if (F.step_count) F.step_count[e] = (int)bits(t.sch, SCH_STEP, 10);
-  if (F.turn) F.turn[e] = (int)bits(t.sch, SCH_TURN, 9);
-  if (F.dealer) F.dealer[e] = (int)bits(t.sc, SC_DEALER, 2);
-  if (F.vul_ns) F.vul_ns[e] = (uint8_t)bits(t.sc, SC_VULNS, 1);
-  if (F.vul_ew) F.vul_ew[e] = (uint8_t)bits(t.sc, SC_VULEW, 1);
-  if (F.shuffled_players)
-    for (int k = 0; k < 4; k++) F.shuffled_players[e * 4 + k] = player_at(t, k);
-  if (F.last_bid) F.last_bid[e] = (int)lb1 - 1;
-  if (F.last_bidder) F.last_bidder[e] = lb1 ? player_at(t, (int)bits(t.sc, SC_LBSEAT, 2)) : -1;
-  if (F.call_x) F.call_x[e] = (uint8_t)bits(t.sc, SC_X, 1);
-  if (F.call_xx) F.call_xx[e] = (uint8_t)bits(t.sc, SC_XX, 1);
-  if (F.pass_num) F.pass_num[e] = (int)bits(t.sc, SC_PASS, 3);
-  for (int d = 0; d < 5; d++) {
-    if (F.first_denomination_ns) F.first_denomination_ns[e * 5 + d] = (int)bits(t.fd, 3 * d, 3) - 1;
-    if (F.first_denomination_ew) F.first_denomination_ew[e * 5 + d] = (int)bits(t.fd, 15 + 3 * d, 3) - 1;
-  }
-  if (F.hand) {
-    // invert obs index rank*4+suit back to the pgx card id; ascending ids per seat
-    for (int seat = 0; seat < 4; seat++) {
-      uint64_t m = s[W_HAND + seat] >> 4;
-      int k = 0;
-      for (int card = 0; card < 52; card++) {
-        int suit = card / 13, rank = card % 13;
-        int idx = ((rank + 12) % 13) * 4 + (3 - suit);
-        if ((m >> idx) & 1ull) F.hand[e * 52 + seat * 13 + (k++)] = card;
-      }
-    }
-  }
-  if (F.tricks)
-    for (int seat = 0; seat < 4; seat++)
-      for (int d = 0; d < 5; d++) F.tricks[e * 20 + seat * 5 + d] = (uint8_t)trick_nibble(t, seat, d);
-  if (F.lut_idx) F.lut_idx[e] = (int32_t)t.lut;
-  if (F.board_ctr) F.board_ctr[e] = t.bctr;
-  if (F.illegal) F.illegal[e] = (uint8_t)bits(t.sc, SC_ILLEGAL, 1);
-}
-
-#include "mlp_infer.hpp"   // k_linear16: one bf16 / fp16 layer of the policy MLP (inference)
-
 // =====================================================================================
 // C-ABI
 // =====================================================================================
-struct brl_handle {
-  int device;
-  int4 *lut_keys;
-  int4 *lut_values;
-  uint4 *lut_hands;
-  int64_t lut_len;
-  float *neg_log_n;
-  uint64_t seed;
-  uint64_t env_offset;
-  DevCtx *ctx_dev;  // device mirror of (LUT, seed, env_offset), read by the policy sub-step
-  int tables_per_wave;
-  int ws;  // 1: wave-specialised fused rollout k_rollout_ws<32,12,1> (default); 0: k_rollout_random<K> (BRL_ROLLOUT_WS=0)
-  int fs;  // 1: flag-synchronised k_rollout_fs where it applies (default); 0: always k_rollout_ws (BRL_ROLLOUT_FS=0)
-};
-
-static thread_local char g_err[512] = "";
-
-// (shared by every translation unit of the library through abi_common.hpp)
-int brl_fail(int code, const char *fmt, const char *detail) {
-  snprintf(g_err, sizeof(g_err), fmt, detail ? detail : "");
-  return code;
-}
-static int fail(int code, const char *fmt, const char *detail) { return brl_fail(code, fmt, detail); }
-
-#include "abi_common.hpp"   // HIP_TRY, NEED
-
-extern "C" const char *brl_last_error(void) { return g_err; }
-extern "C" int brl_version(void) { return 5; }   // include/brl_hip.h: the round the exported set last changed in
-
-static inline Rng rng_of(const brl_handle *h) { return Rng{(uint32_t)h->seed, (uint32_t)(h->seed >> 32)}; }
-static inline LutRef lut_of(const brl_handle *h) { return LutRef{h->lut_keys, h->lut_values, (uint32_t)h->lut_len, h->lut_hands}; }
-
-// Refresh the device mirror.  Callers have synchronised the device: nothing in flight reads the old contents.
-static int sync_ctx(brl_handle *h) {
-  DevCtx c{lut_of(h), rng_of(h), h->env_offset};
-  HIP_TRY(hipMemcpy(h->ctx_dev, &c, sizeof(c), hipMemcpyHostToDevice));
-  return BRL_OK;
-}
-
-static int upload_lut(brl_handle *h, const int32_t *keys, const int32_t *values, int64_t len) {
-  if (len != h->lut_len) {  // same-size rotation (ppo.py:128: every file holds hash_size rows) reuses the allocations
-    if (h->lut_keys) HIP_TRY(hipFree(h->lut_keys));
-    if (h->lut_values) HIP_TRY(hipFree(h->lut_values));
-    if (h->lut_hands) HIP_TRY(hipFree(h->lut_hands));
-    h->lut_keys = nullptr;
-    h->lut_values = nullptr;
-    h->lut_hands = nullptr;
-    h->lut_len = 0;
-  }
-  if (len > 0) {
-    NEED(keys && values, "lut_keys / lut_values are NULL with lut_len > 0");
-    NEED(len < (1ll << 32), "lut_len must be < 2^32");
-    if (!h->lut_keys) {
-      HIP_TRY(hipMalloc(&h->lut_keys, (size_t)len * 16));
-      HIP_TRY(hipMalloc(&h->lut_values, (size_t)len * 16));
-      HIP_TRY(hipMalloc(&h->lut_hands, (size_t)len * 32));
-    }
-    HIP_TRY(hipMemcpy(h->lut_keys, keys, (size_t)len * 16, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->lut_values, values, (size_t)len * 16, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_lut_hands, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, 0, h->lut_keys, h->lut_hands, len);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    h->lut_len = len;
-  }
-  return sync_ctx(h);
-}
-
-extern "C" int brl_create(int device, const int32_t *lut_keys, const int32_t *lut_values, int64_t lut_len,
-                          brl_handle **out) {
-  NEED(out != nullptr, "out");
-  NEED(lut_len >= 0, "lut_len");
-  HIP_TRY(hipSetDevice(device));
-  brl_handle *h = (brl_handle *)calloc(1, sizeof(brl_handle));
-  NEED(h != nullptr, "out of host memory");
-  h->device = device;
-  h->tables_per_wave = 4;
-  const char *env = getenv("BRL_TABLES_PER_WAVE");
-  if (env) {
-    int k = atoi(env);
-    if (k == 1 || k == 2 || k == 4 || k == 8) h->tables_per_wave = k;
-  }
-  h->ws = 1;
-  const char *ws = getenv("BRL_ROLLOUT_WS");  // "0": the K-tables-per-wave fused rollout (A/B baseline)
-  if (ws && ws[0] == '0' && ws[1] == 0) h->ws = 0;
-  h->fs = 1;
-  const char *fs = getenv("BRL_ROLLOUT_FS");  // "0": the barrier-synchronised k_rollout_ws for every shape (A/B, tests)
-  if (fs && fs[0] == '0' && fs[1] == 0) h->fs = 0;
-  float tab[BRL_NUM_ACTIONS + 1];
-  tab[0] = 0.0f;
-  for (int i = 1; i <= BRL_NUM_ACTIONS; i++) tab[i] = (float)(-log((double)i));
-  hipError_t e = hipMalloc(&h->neg_log_n, sizeof(tab));
-  if (e == hipSuccess) e = hipMemcpy(h->neg_log_n, tab, sizeof(tab), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMalloc(&h->ctx_dev, sizeof(DevCtx));
-  if (e != hipSuccess) {
-    free(h);
-    return fail(BRL_E_HIP, "brl_create: %s", hipGetErrorString(e));
-  }
-  int rc = upload_lut(h, lut_keys, lut_values, lut_len);
-  if (rc != BRL_OK) {
-    (void)hipFree(h->neg_log_n);
-    (void)hipFree(h->ctx_dev);
-    free(h);
-    return rc;
-  }
-  *out = h;
-  return BRL_OK;
-}
-
-extern "C" int brl_set_lut(brl_handle *h, const int32_t *lut_keys, const int32_t *lut_values, int64_t lut_len) {
-  NEED(h != nullptr, "handle");
-  NEED(lut_len >= 0, "lut_len");
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipDeviceSynchronize());  // in-flight kernels may still read the old table
-  return upload_lut(h, lut_keys, lut_values, lut_len);
-}
-
-extern "C" int brl_destroy(brl_handle *h) {
-  if (!h) return BRL_OK;
-  (void)hipSetDevice(h->device);
-  if (h->lut_keys) (void)hipFree(h->lut_keys);
-  if (h->lut_values) (void)hipFree(h->lut_values);
-  if (h->lut_hands) (void)hipFree(h->lut_hands);
-  if (h->neg_log_n) (void)hipFree(h->neg_log_n);
-  if (h->ctx_dev) (void)hipFree(h->ctx_dev);
-  free(h);
-  return BRL_OK;
-}
-
-extern "C" int brl_set_rng(brl_handle *h, uint64_t seed, uint64_t env_offset) {
-  NEED(h != nullptr, "handle");
-  if (seed == h->seed && env_offset == h->env_offset) return BRL_OK;
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipDeviceSynchronize());  // launches in flight (and captured graphs being replayed) may still read the old key
-  h->seed = seed;
-  h->env_offset = env_offset;
-  return sync_ctx(h);
-}
-
-static inline unsigned wave_grid(int64_t n, int K) {
-  int64_t per_block = (int64_t)WAVES_PER_BLOCK * K;
-  return (unsigned)((n + per_block - 1) / per_block);
-}
-static inline unsigned thread_grid(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
-
-#define LAUNCH_K(h, kernel, n, stream, ...)                                                                  \
-  do {                                                                                                       \
-    hipStream_t _s = (hipStream_t)(stream);                                                                  \
-    switch ((h)->tables_per_wave) {                                                                          \
-      case 1: hipLaunchKernelGGL(kernel<1>, dim3(wave_grid(n, 1)), dim3(BLOCK_THREADS), 0, _s, __VA_ARGS__); break; \
-      case 2: hipLaunchKernelGGL(kernel<2>, dim3(wave_grid(n, 2)), dim3(BLOCK_THREADS), 0, _s, __VA_ARGS__); break; \
-      case 8: hipLaunchKernelGGL(kernel<8>, dim3(wave_grid(n, 8)), dim3(BLOCK_THREADS), 0, _s, __VA_ARGS__); break; \
-      default: hipLaunchKernelGGL(kernel<4>, dim3(wave_grid(n, 4)), dim3(BLOCK_THREADS), 0, _s, __VA_ARGS__); break; \
-    }                                                                                                        \
-    HIP_TRY(hipGetLastError());                                                                              \
-  } while (0)
-
-#define COMMON(h, n)                 \
-  NEED((h) != nullptr, "handle");    \
-  NEED((n) >= 0, "n");               \
-  if ((n) == 0) return BRL_OK;       \
-  HIP_TRY(hipSetDevice((h)->device))
-
-extern "C" int brl_init_random(brl_handle *h, uint64_t *state, int64_t n, uint32_t board_ctr0, void *stream) {
-  COMMON(h, n);
-  NEED(state != nullptr, "state");
-  if (h->lut_len == 0) return fail(BRL_E_NOLUT, "brl_init_random needs a LUT%s", "");
-  LAUNCH_K(h, k_init_random, n, stream, state, n, rng_of(h), h->env_offset, lut_of(h), board_ctr0);
-  return BRL_OK;
-}
-
-extern "C" int brl_init_from_deals(brl_handle *h, uint64_t *state, int64_t n, const int32_t *hand,
-                                   const int32_t *dealer, const uint8_t *vul_ns, const uint8_t *vul_ew,
-                                   const int32_t *shuffled_players, const uint8_t *tricks, void *stream) {
-  COMMON(h, n);
-  NEED(state && hand && dealer && vul_ns && vul_ew && shuffled_players && tricks, "NULL input array");
-  hipLaunchKernelGGL(k_init_explicit, dim3(thread_grid(n, 128)), dim3(128), 0, (hipStream_t)stream, state, n, hand,
-                     dealer, vul_ns, vul_ew, shuffled_players, tricks);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
-}
-
-extern "C" int brl_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
-                        const int32_t *action, int autoreset, uint8_t *obs, uint8_t *mask, float *rewards,
-                        uint8_t *terminated, int32_t *current_player, void *stream) {
-  COMMON(h, n);
-  NEED(state_in && state_out && action, "NULL state / action");
-  if (autoreset && h->lut_len == 0) return fail(BRL_E_NOLUT, "auto-reset needs a LUT%s", "");
-  StepOut o{obs, mask, rewards, terminated, current_player};
-  LAUNCH_K(h, k_step, n, stream, state_in, state_out, n, action, autoreset, rng_of(h), h->env_offset, lut_of(h), o);
-  return BRL_OK;
-}
-
-extern "C" int brl_observe(brl_handle *h, const uint64_t *state, int64_t n, const int32_t *player_id, uint8_t *obs,
-                           uint8_t *mask, void *stream) {
-  COMMON(h, n);
-  NEED(state != nullptr, "state");
-  LAUNCH_K(h, k_observe, n, stream, state, n, player_id, obs, mask);
-  return BRL_OK;
-}
-
-extern "C" int brl_get_fields(brl_handle *h, const uint64_t *state, int64_t n, const brl_fields *out, void *stream) {
-  COMMON(h, n);
-  NEED(state && out, "state / out");
-  hipLaunchKernelGGL(k_get_fields, dim3(thread_grid(n, 128)), dim3(128), 0, (hipStream_t)stream, state, n, *out);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
-}
-
 // The fused rollout kernels store 16 bytes per lane (observation pieces, mask chunks, four tables of a scalar column) and
 // 4 bytes of `done` at a time: every output array must start on such a boundary (any hipMalloc / torch allocation does;
 // an odd view into one does not).
@@ -2113,322 +1195,4 @@ extern "C" int brl_policy_step_ex(brl_handle *h, const uint64_t *state_in, uint6
                                   const brl_macro_ext *ext, void *stream) {
   return policy_step_impl(h, state_in, state_out, n, logits, logits_stride, mode, draw_base, draw_offset, autoreset,
                           action, log_prob, obs, mask, rewards_acc, terminated_acc, current_player, stream, ext);
-}
-
-// observation bytes (0/1) -> the network's input dtype: 16 bytes in, 16 elements out per thread
-// (src/roll_out.py:75 `last_obs.astype(jnp.float32)`; torch's generic bool->bf16 copy takes 15 us for 3.9 MB)
-template <int FMT>  // 0: f32, 1: bf16 (0x3F80), 2: f16 (0x3C00)
-__device__ __forceinline__ void obs_cast16(const uint4 v, void *out, int64_t i) {
-  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-  if (FMT == 0) {
-    float4 *o = reinterpret_cast<float4 *>(out) + 4 * i;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      o[k] = make_float4((w[k] & 1u) ? 1.0f : 0.0f, (w[k] & 0x100u) ? 1.0f : 0.0f, (w[k] & 0x10000u) ? 1.0f : 0.0f,
-                         (w[k] & 0x1000000u) ? 1.0f : 0.0f);
-  } else {
-    const uint32_t one = (FMT == 1) ? 0x3F80u : 0x3C00u;
-    uint4 *o = reinterpret_cast<uint4 *>(out) + 2 * i;
-    uint32_t h[8];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {  // bytes (b0,b1,b2,b3) of a dword -> halves (b0,b1) and (b2,b3)
-      h[2 * k] = ((w[k] & 1u) ? one : 0u) | ((w[k] & 0x100u) ? (one << 16) : 0u);
-      h[2 * k + 1] = ((w[k] & 0x10000u) ? one : 0u) | ((w[k] & 0x1000000u) ? (one << 16) : 0u);
-    }
-    o[0] = make_uint4(h[0], h[1], h[2], h[3]);
-    o[1] = make_uint4(h[4], h[5], h[6], h[7]);
-  }
-}
-
-template <int FMT>
-__global__ __launch_bounds__(256) void k_obs_cast(const uint4 *in, void *out, int64_t n16) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n16) return;
-  obs_cast16<FMT>(in[i], out, i);
-}
-
-// the same for the rows rows[0..m) of `in` only (out row r = in row rows[r]): the forwards of an evaluator run on the boards
-// that are still playing
-template <int FMT>
-__global__ __launch_bounds__(256) void k_obs_cast_rows(const uint4 *in, const int64_t *rows, void *out, int64_t m16) {
-  constexpr int PER_ROW = BRL_OBS_SIZE / 16;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m16) return;
-  const int64_t r = i / PER_ROW;
-  obs_cast16<FMT>(in[rows[r] * PER_ROW + (i - r * PER_ROW)], out, i);
-}
-
-extern "C" int brl_obs_cast(brl_handle *h, const uint8_t *obs, int64_t n, void *out, int fmt, void *stream) {
-  COMMON(h, n);
-  NEED(obs && out, "NULL obs / out");
-  NEED(fmt >= 0 && fmt <= 2, "fmt");
-  const int64_t n16 = n * (BRL_OBS_SIZE / 16);
-  const dim3 grid((unsigned)((n16 + 255) / 256)), block(256);
-  if (fmt == 0) hipLaunchKernelGGL(k_obs_cast<0>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, out, n16);
-  else if (fmt == 1) hipLaunchKernelGGL(k_obs_cast<1>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, out, n16);
-  else hipLaunchKernelGGL(k_obs_cast<2>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, out, n16);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
-}
-
-extern "C" int brl_obs_cast_rows(brl_handle *h, const uint8_t *obs, const int64_t *rows, int64_t m, void *out, int fmt,
-                                 void *stream) {
-  COMMON(h, m);
-  NEED(obs && rows && out, "NULL obs / rows / out");
-  NEED(fmt >= 0 && fmt <= 2, "fmt");
-  const int64_t m16 = m * (BRL_OBS_SIZE / 16);
-  const dim3 grid((unsigned)((m16 + 255) / 256)), block(256);
-  if (fmt == 0) hipLaunchKernelGGL(k_obs_cast_rows<0>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, rows, out, m16);
-  else if (fmt == 1) hipLaunchKernelGGL(k_obs_cast_rows<1>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, rows, out, m16);
-  else hipLaunchKernelGGL(k_obs_cast_rows<2>, grid, block, 0, (hipStream_t)stream, (const uint4 *)obs, rows, out, m16);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
-}
-
-// The loop condition of the evaluators, `~state.terminated.all()` (src/evaluation.py:120-122), as data: how many boards are
-// finished, and the indices of the others in ascending order at the front of `live` (the entries behind them are left as they
-// are: the caller initialises the list with 0..n-1 once, so they stay valid board indices).  One workgroup: a thread counts
-// its run of boards, the runs' offsets come from a scan in LDS — deterministic order, no atomics.
-__global__ __launch_bounds__(1024) void k_live_index(const uint8_t *terminated, int64_t n, int64_t *live, int64_t *finished, int64_t tag) {
-  __shared__ int64_t part[1024];
-  const int tid = (int)threadIdx.x;
-  // (a thread's run of boards, rounded up to 8 so that the flags can be read 8 at a time: one load instead of a chain of byte loads)
-  const int64_t per = ((n + 1023) / 1024 + 7) / 8 * 8, a0 = (int64_t)tid * per, a = (a0 < n) ? a0 : n, b = (a + per < n) ? a + per : n;
-  const bool wide = (reinterpret_cast<uintptr_t>(terminated) & 7u) == 0;
-  int64_t c = 0;
-  for (int64_t i = a; i < b; i += 8) {
-    if (wide && i + 8 <= b) {
-      const uint64_t f = *reinterpret_cast<const uint64_t *>(terminated + i);
-      // bytes are 0 / 1 (bool) or any non-zero: count the zero bytes
-      uint64_t nz = f | (f >> 4); nz |= nz >> 2; nz |= nz >> 1; nz &= 0x0101010101010101ull;
-      c += 8 - __popcll(nz);
-    } else {
-      for (int64_t k = i; k < b && k < i + 8; k++) c += terminated[k] ? 0 : 1;
-    }
-  }
-  part[tid] = c;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan
-    const int64_t v = (tid >= off) ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  int64_t pos = part[tid] - c;
-  if (live != nullptr)
-    for (int64_t i = a; i < b; i++)
-      if (!terminated[i]) live[pos++] = i;
-  if (tid == 1023 && finished != nullptr) {
-    const int64_t count = n - part[1023];
-    // tag >= 0: the word is read by the HOST while the stream runs on (pinned memory, no event): tag and count arrive as one
-    // 64-bit store, released at system scope
-    if (tag >= 0) __hip_atomic_store(finished, (tag << 32) | count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    else *finished = count;
-  }
-}
-
-extern "C" int brl_live_index(brl_handle *h, const uint8_t *terminated, int64_t n, int64_t *live, int64_t *finished, int64_t tag,
-                              void *stream) {
-  COMMON(h, n);
-  NEED(terminated && (live || finished), "NULL terminated / outputs");
-  NEED(tag < ((int64_t)1 << 31) && n < ((int64_t)1 << 32), "tag below 2^31, n below 2^32");
-  if (finished != nullptr) {
-    // `finished` may be PINNED HOST memory: the launch then stores the count where the host reads it (behind an event) — no copy
-    // launch, no copy engine between two iterations of an evaluator.  Translated to the address the device uses.
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, finished) == hipSuccess && at.type == hipMemoryTypeHost) {
-      void *dp = nullptr;
-      HIP_TRY(hipHostGetDevicePointer(&dp, finished, 0));
-      finished = (int64_t *)dp;
-    } else {
-      (void)hipGetLastError();   // (an address the runtime does not know: left as it is)
-    }
-  }
-  hipLaunchKernelGGL(k_live_index, dim3(1), dim3(1024), 0, (hipStream_t)stream, terminated, n, live, finished, tag);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
-}
-
-static int lin16_attr(int fmt) {
-  static bool done[3] = {false, false, false};
-  if (!done[fmt]) {   // 144 KB of dynamic LDS: above the default 64 KB limit
-    if (fmt == 1) HIP_TRY(hipFuncSetAttribute((const void *)lin16::k_linear16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lin16::LDS_BYTES));
-    else HIP_TRY(hipFuncSetAttribute((const void *)lin16::k_linear16<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lin16::LDS_BYTES));
-    done[fmt] = true;
-  }
-  return BRL_OK;
-}
-
-static int lin16_store_mode() {
-  static int store_mode = -1;
-  if (store_mode < 0) {
-    // y leaves write-through by default: measured in the bf16 graph rollout, 8192 tables: 12.47 ms against 13.30 (plain
-    // stores: the dirty lines are written back when the kernel ends) and 13.01 (non-temporal); BRL_LIN16_STORE=0/1/2 for A/B
-    const char *e = getenv("BRL_LIN16_STORE");
-    store_mode = (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : 2;
-  }
-  return store_mode;
-}
-
-#ifdef LIN16_TIMING   // scripts/time_linear16.py --stamps: 4 shader-clock stamps per workgroup
-static unsigned long long *g_lin16_dbg = nullptr;
-extern "C" void brl_lin16_set_dbg(void *p) { g_lin16_dbg = (unsigned long long *)p; }
-#endif
-static int linear_act_impl(brl_handle *h, const void *x, int64_t ldx, const void *w, int64_t ldw, const float *bias, void *y,
-                           int64_t ldy, int64_t m, int n_out, int k, int relu, int fmt, const void *head_w, int64_t ld_head_w,
-                           int n_heads, float *head_part, int64_t head_part_ld, int64_t head_part_stride, void *stream) {
-  COMMON(h, m);
-  NEED(x && w && (y || head_part), "NULL x / w / y");
-  if (head_part) {
-    NEED(head_w && n_heads >= 1 && n_heads <= 48 && ld_head_w >= n_out && ld_head_w % 8 == 0 && (((uintptr_t)head_w) & 15) == 0,
-         "head_w / n_heads (<= 48) / ld_head_w");
-    NEED(head_part_ld >= ((n_heads + 3) & ~3) && head_part_ld % 4 == 0 && head_part_stride >= m * head_part_ld && head_part_stride % 4 == 0
-         && (((uintptr_t)head_part) & 15) == 0, "head_part (16-byte aligned) / head_part_ld (% 4, >= n_heads rounded up to 4) / head_part_stride");
-  }
-  if (!y) ldy = n_out;
-  NEED(fmt == 1 || fmt == 2, "fmt (1 = bf16, 2 = fp16)");
-  NEED(n_out > 0 && n_out % lin16::BN == 0, "n_out % 128");
-  NEED(k >= 8 && k % 8 == 0, "k % 8");
-  NEED(ldx >= k && ldw >= k && ldy >= n_out && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0, "ldx / ldw / ldy");
-  NEED((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0, "x / w / y not 16-byte aligned");
-  NEED(m * ldx * 2 < ((int64_t)1 << 32) && (int64_t)n_out * ldw * 2 < ((int64_t)1 << 32), "operand larger than 4 GB");
-  NEED(m <= (int64_t)1 << 30, "m");
-  if (int rc = lin16_attr(fmt)) return rc;
-  lin16::Args A;
-  memset(&A, 0, sizeof(A));
-  A.x = (const uint16_t *)x; A.ldx = ldx;
-  A.w = (const uint16_t *)w; A.ldw = ldw;
-  A.bias = bias;
-  A.y = (uint16_t *)y; A.ldy = ldy;
-  A.M = (int)m; A.N = n_out; A.K = k;
-  A.relu = relu;
-  A.head_w = (const uint16_t *)head_w; A.ld_head_w = ld_head_w; A.n_heads = n_heads;
-  A.head_part = head_part; A.head_part_ld = head_part_ld; A.head_part_stride = head_part_stride;
-  A.store_mode = lin16_store_mode();
-#ifdef LIN16_TIMING
-  A.dbg = g_lin16_dbg;
-#endif
-  const int tiles = (int)((m + lin16::BM - 1) / lin16::BM) * (n_out / lin16::BN);
-  if (fmt == 1) hipLaunchKernelGGL(lin16::k_linear16<1>, dim3(tiles), dim3(lin16::THREADS), lin16::LDS_BYTES, (hipStream_t)stream, A);
-  else hipLaunchKernelGGL(lin16::k_linear16<2>, dim3(tiles), dim3(lin16::THREADS), lin16::LDS_BYTES, (hipStream_t)stream, A);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
-}
-
-extern "C" int brl_linear_act(brl_handle *h, const void *x, int64_t ldx, const void *w, int64_t ldw, const float *bias, void *y,
-                            int64_t ldy, int64_t m, int n_out, int k, int relu, int fmt, void *stream) {
-  NEED(y != nullptr, "NULL y");
-  return linear_act_impl(h, x, ldx, w, ldw, bias, y, ldy, m, n_out, k, relu, fmt, nullptr, 0, 0, nullptr, 0, 0, stream);
-}
-
-extern "C" int brl_linear_act_heads(brl_handle *h, const void *x, int64_t ldx, const void *w, int64_t ldw, const float *bias,
-                                  void *y, int64_t ldy, int64_t m, int n_out, int k, int relu, int fmt, const void *head_w,
-                                  int64_t ld_head_w, int n_heads, float *head_part, int64_t head_part_ld,
-                                  int64_t head_part_stride, void *stream) {
-  NEED(head_part != nullptr, "NULL head_part");
-  return linear_act_impl(h, x, ldx, w, ldw, bias, y, ldy, m, n_out, k, relu, fmt, head_w, ld_head_w, n_heads, head_part,
-                         head_part_ld, head_part_stride, stream);
-}
-
-extern "C" int brl_gae(brl_handle *h, const uint8_t *done, const float *value, const float *reward,
-                       const float *last_val, float gamma, float gamma_lambda, int T, int64_t n, float *advantages,
-                       float *targets, void *stream) {
-  COMMON(h, n);
-  NEED(done && value && reward && last_val && advantages && targets, "NULL array");
-  NEED(T >= 0, "T");
-  hipLaunchKernelGGL(k_gae, dim3(thread_grid(n, 64)), dim3(64), 0, (hipStream_t)stream, done, value, reward, last_val,
-                     gamma, gamma_lambda, T, n, advantages, targets);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
-}
-
-extern "C" int brl_imp_reward(brl_handle *h, const float *a, const float *b, float *out, int64_t n, void *stream) {
-  COMMON(h, n);
-  NEED(a && b && out, "NULL array");
-  hipLaunchKernelGGL(k_imp_reward, dim3(thread_grid(n, 128)), dim3(128), 0, (hipStream_t)stream, a, b, out, n);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
-}
-
-static bool table_info_ok(const brl_table_info *t) {
-  return t && t->terminated && t->rewards && t->last_bid && t->last_bidder && t->call_x && t->call_xx;
-}
-
-static int eval_step_impl(brl_handle *h, EvalArgs &A, void *stream) {
-  LAUNCH_K(h, k_eval_step, A.n, stream, A);
-  return BRL_OK;
-}
-
-extern "C" int brl_duplicate_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
-                                  const int32_t *action, const brl_table_info *table_a,
-                                  const brl_table_info *table_b, uint8_t *obs, uint8_t *mask, float *rewards,
-                                  uint8_t *terminated, int32_t *current_player, void *stream) {
-  COMMON(h, n);
-  NEED(state_in && state_out && action, "NULL state / action");
-  NEED(table_info_ok(table_a) && table_info_ok(table_b), "table_a / table_b has NULL members");
-  EvalArgs A{};
-  A.state_in = state_in; A.state_out = state_out; A.n = n; A.action = action; A.duplicate = 1;
-  A.TA = *table_a; A.TB = *table_b;
-  A.o = StepOut{obs, mask, rewards, terminated, current_player};
-  A.acting_team = -1;
-  return eval_step_impl(h, A, stream);
-}
-
-extern "C" int brl_eval_step(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n,
-                             const float *logits_team1, int64_t stride1, const float *logits_team2, int64_t stride2,
-                             const brl_table_info *table_a, const brl_table_info *table_b, const brl_eval_stats *stats,
-                             int bid_set, float *cum_return, float *rewards_sum, int32_t *action_out, uint8_t *obs,
-                             uint8_t *mask, float *rewards, uint8_t *terminated, int32_t *current_player, void *stream) {
-  COMMON(h, n);
-  NEED(state_in && state_out && logits_team1 && logits_team2, "NULL state / logits");
-  NEED(stride1 >= BRL_NUM_ACTIONS && stride2 >= BRL_NUM_ACTIONS, "logits stride");
-  NEED((table_a == nullptr) == (table_b == nullptr), "table_a and table_b go together");
-  if (table_a) NEED(table_info_ok(table_a) && table_info_ok(table_b), "table_a / table_b has NULL members");
-  EvalArgs A{};
-  A.state_in = state_in; A.state_out = state_out; A.n = n;
-  A.logits1 = logits_team1; A.logits2 = logits_team2; A.stride1 = stride1; A.stride2 = stride2;
-  A.duplicate = table_a != nullptr;
-  if (table_a) { A.TA = *table_a; A.TB = *table_b; }
-  if (stats) A.S = *stats;
-  A.bid_set = bid_set; A.cum_return = cum_return; A.rewards_sum = rewards_sum; A.action_out = action_out;
-  A.o = StepOut{obs, mask, rewards, terminated, current_player};
-  A.acting_team = -1;
-  return eval_step_impl(h, A, stream);
-}
-
-extern "C" int brl_eval_step_team(brl_handle *h, const uint64_t *state_in, uint64_t *state_out, int64_t n, const float *logits,
-                                  int64_t stride, int acting_team, const brl_table_info *table_a,
-                                  const brl_table_info *table_b, const brl_eval_stats *stats, int bid_set, float *cum_return,
-                                  float *rewards_sum, int32_t *action_out, uint8_t *obs, uint8_t *mask, float *rewards,
-                                  uint8_t *terminated, int32_t *current_player, float *obs_f32, void *stream) {
-  COMMON(h, n);
-  NEED(state_in && state_out && logits, "NULL state / logits");
-  NEED(stride >= BRL_NUM_ACTIONS, "logits stride");
-  NEED(acting_team == 0 || acting_team == 1, "acting_team");
-  NEED((((uintptr_t)obs_f32) & 15) == 0, "obs_f32 not 16-byte aligned");
-  NEED((table_a == nullptr) == (table_b == nullptr), "table_a and table_b go together");
-  if (table_a) NEED(table_info_ok(table_a) && table_info_ok(table_b), "table_a / table_b has NULL members");
-  EvalArgs A{};
-  A.state_in = state_in; A.state_out = state_out; A.n = n;
-  A.logits1 = logits; A.logits2 = logits; A.stride1 = stride; A.stride2 = stride;
-  A.duplicate = table_a != nullptr;
-  if (table_a) { A.TA = *table_a; A.TB = *table_b; }
-  if (stats) A.S = *stats;
-  A.bid_set = bid_set; A.cum_return = cum_return; A.rewards_sum = rewards_sum; A.action_out = action_out;
-  A.o = StepOut{obs, mask, rewards, terminated, current_player};
-  A.acting_team = acting_team;
-  A.obs_f32 = obs_f32;
-  return eval_step_impl(h, A, stream);
-}
-
-extern "C" int brl_eval_reduce(brl_handle *h, int64_t n, const brl_table_info *table_a, const brl_table_info *table_b,
-                               const int32_t *bid_count, const uint64_t *state, int64_t *out, void *stream) {
-  COMMON(h, n);
-  NEED(table_info_ok(table_a) && out, "table_a / out");
-  if (table_b) NEED(table_info_ok(table_b), "table_b has NULL members");
-  HIP_TRY(hipMemsetAsync(out, 0, sizeof(int64_t) * EV_TOTAL, (hipStream_t)stream));
-  hipLaunchKernelGGL(k_eval_reduce, dim3(thread_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, *table_a,
-                     table_b ? *table_b : *table_a, table_b ? 1 : 0, bid_count, state, (long long *)out);
-  HIP_TRY(hipGetLastError());
-  return BRL_OK;
 }

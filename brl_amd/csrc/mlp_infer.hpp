@@ -21,7 +21,7 @@
 //     heads' weights: partial products per column tile, summed by brl_policy_step_ex — and y itself need not be stored;
 //   * K need not be a multiple of 64 (the observation is 480 wide): the pieces of the last chunk that lie beyond K are
 //     fetched from a 16-byte block of zeros instead.
-// Included by brl_kernels.hip.
+// Included by brl_infer16.hip.
 #pragma once
 
 namespace lin16 {

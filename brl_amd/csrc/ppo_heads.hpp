@@ -12,7 +12,7 @@
 //                 that layer's bias-gradient column sums per 16-row tile;
 //   k_ppo_stats2  the logged statistics + the illegal-action spectral norm from the Gram partials (4 squarings by the whole block
 //                 + 16 power-iteration steps by one wave = G^256 v, like k_ppo_stats' 8 squarings, in ~3 us instead of 62).
-// Included by brl_kernels.hip after ppo_update.hpp.
+// Included by brl_ppo.hip after ppo_update.hpp.
 #pragma once
 
 constexpr int HD_ROWS = 4;     // samples per workgroup of k_heads_loss (of the 16 rows of an MFMA tile; see the kernel)
@@ -38,16 +38,7 @@ struct HeadsLossArgs {
   int64_t part_stride;
 };
 
-#ifdef HD_TIMING   // scripts/time_heads.py --stamps (a -DHD_TIMING build): shader cycles at 6 points of workgroup 0..63, wave 0, into heads_out
-#define HD_STAMP(k) do { if (tid == 0) hd_st[k] = (float)(__builtin_amdgcn_s_memtime() - hd_t0); } while (0)
-#else
-#define HD_STAMP(k) do { } while (0)
-#endif
 __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
-#ifdef HD_TIMING
-  const unsigned long long hd_t0 = __builtin_amdgcn_s_memtime();
-  float hd_st[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#endif
   __shared__ float illp_s[HD_ROWS][BRL_NUM_ACTIONS + 2];
   __shared__ float part_s[HD_ROWS][8];
   __shared__ float rs_red[HD_WAVES], rs_stat[2];
@@ -120,9 +111,7 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
       for (int k = 0; k < 8; k++) part_s[sl][k] = (k < 5) ? st[k] : 0.0f;
     }
   }
-  HD_STAMP(2);   // this wave's loss done
   __syncthreads();
-  HD_STAMP(3);   // everybody's loss done
   if (tid < 8) {   // per-workgroup partial sums over its 16 samples, in order (deterministic statistics)
     float s = 0.0f;
     for (int k = 0; k < HD_ROWS; k++) s += part_s[k][tid];
@@ -137,13 +126,6 @@ __global__ __launch_bounds__(HD_WAVES * 64) void k_heads_loss(HeadsLossArgs A) {
       A.gram_partials[(int64_t)blockIdx.x * HD_GRAM + e] = s;
     }
   }
-#ifdef HD_TIMING
-  __syncthreads();
-  HD_STAMP(4);
-  if (tid == 0 && A.heads_out) {   // (row 1023's columns 0..4 of workgroup-indexed scratch: heads_out must be [B + 64, 39] in the timing script)
-    for (int k = 0; k < 5; k++) A.heads_out[(A.P.B + blockIdx.x) * HD_NOUT + k] = hd_st[k];
-  }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------

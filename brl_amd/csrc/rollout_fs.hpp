@@ -1,5 +1,5 @@
 // rollout_fs.hpp — k_rollout_fs: the fused random-policy rollout (A7, src/roll_out.py:63-107 with a uniform random legal policy),
-// flag-synchronised.  Included by brl_kernels.hip after k_rollout_ws (shares RolloutArgs, the command format and LutRef).
+// flag-synchronised.  Included by brl_rollout.hip after k_rollout_ws (shares RolloutArgs, the command format and LutRef).
 //
 // Same roles as k_rollout_ws — one workgroup owns 32 consecutive tables; a LOGIC wave runs the per-table dependency chain,
 // a LOADER fetches boards, a SCORER writes the scalar Transition columns, EMIT waves write observations — but NO workgroup
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(FS_NW * 64) void k_rollout_fs(RolloutArgs A) {
     }
   } else if (wave == 12) {
     // ------------------------------------------------------------------ prep wave: raw -> command, two slots per pass
-    // (lanes 0..31: slot s, lanes 32..63: slot s + 1 when it is already there).  Command format: brl_kernels.hip (k_rollout_ws).
+    // (lanes 0..31: slot s, lanes 32..63: slot s + 1 when it is already there).  Command format: brl_rollout.hip (k_rollout_ws).
     int avail = 0;
     int s = 0;
     while (s <= total) {

@@ -72,6 +72,7 @@ _OWN_FORWARD_ROWS = int(os.environ.get("BRL_EVAL_OWN_ROWS", "1024"))
 
 _STEP_CASTS = os.environ.get("BRL_EVAL_STEP_CASTS", "1") != "0"   # (0: a cast launch in front of every full-batch forward: A/B)
 _HOST_COUNT = os.environ.get("BRL_EVAL_HOST_COUNT", "1") != "0"   # (0: count to device memory + a copy launch, the earlier form: A/B)
+_WORD_VISIBLE = [True]   # cleared for the process when a launch's store into pinned memory was never seen by the host (_DoneWatch.poll)
 
 
 def masked_mode(logits: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
@@ -170,6 +171,8 @@ class _DoneWatch:
         self.idx = None
         self.busy = False
         self.epoch = 0
+        self.by_word = [False] * self.RING   # how slot k's count travels: the launch's own store into pinned memory, or copy + event
+        self.last = None                     # event behind the last launch that writes this watch's memory (see release)
         if compact:   # (entries behind the live boards stay valid board indices: initialised with 0..n-1)
             self.idx = [torch.arange(n, dtype=torch.int64, device=env.device) for _ in range(self.RING)]
 
@@ -189,7 +192,18 @@ class _DoneWatch:
         return w
 
     def release(self):
+        """hands the watch back; the launches of the loop's last iterations may still be in flight and WRITE this watch's pinned
+        word: an event behind them is what `__del__` waits for before the memory goes away"""
         self.busy = False
+        self.last = torch.cuda.Event()
+        self.last.record()
+
+    def __del__(self):
+        try:
+            if self.last is not None and not self.last.query():
+                self.last.synchronize()
+        except Exception:   # (interpreter shutdown, a capturing stream: never raise from a destructor)
+            pass
 
     def _tag(self, i: int) -> int:
         return (self.epoch << 16) | ((i + 1) & 0xFFFF)
@@ -198,7 +212,8 @@ class _DoneWatch:
         """after iteration i's launches: publish how many boards are finished (and which are not) — ONE launch"""
         k = i % self.RING
         live = ptr(self.idx[k]) if self.idx is not None else None
-        if _HOST_COUNT:   # the launch stores tag | count in the pinned word itself (include/brl_hip.h: brl_live_index)
+        self.by_word[k] = _HOST_COUNT and _WORD_VISIBLE[0]
+        if self.by_word[k]:   # the launch stores tag | count in the pinned word itself (include/brl_hip.h: brl_live_index)
             check(_capi.lib().brl_live_index(self._h, ptr(terminated), self.n, live, self.host.data_ptr() + 8 * k, self._tag(i), _stream()))
             return
         check(_capi.lib().brl_live_index(self._h, ptr(terminated), self.n, live, ptr(self.dev[k:k + 1]), -1, _stream()))
@@ -211,7 +226,7 @@ class _DoneWatch:
         if j < 0:
             return None
         k = j % self.RING
-        if _HOST_COUNT:
+        if self.by_word[k]:
             import time
             want, words, t0, spins = self._tag(j), self.words, None, 0
             while True:
@@ -219,9 +234,23 @@ class _DoneWatch:
                 if (v >> 32) == want:
                     return v & 0xFFFFFFFF, (self.idx[k] if self.idx is not None else None)
                 spins += 1
-                if spins & 0x3FFF == 0:   # (a launch that never completes must not hang the host for ever)
+                if spins & 0xFF == 0:
+                    time.sleep(0)             # (yield the GIL: other Python threads of the host process run while this one waits)
+                if spins & 0x3FFF == 0:
                     t0 = t0 or time.perf_counter()
-                    if time.perf_counter() - t0 > 60.0:
+                    waited = time.perf_counter() - t0
+                    # The launch has completed (the stream is idle) and its system-scope store is still not visible to the host:
+                    # this host allocation is not coherent (HIP_HOST_COHERENT=0, coarse-grained pinned memory).  From here on the
+                    # count travels by copy + event for the whole process; this iteration's count is simply unknown (the loop
+                    # runs one more iteration: finished boards take no-op calls).
+                    if waited > 2.0 and torch.cuda.current_stream().query() and (int(words[k]) >> 32) != want:
+                        _WORD_VISIBLE[0] = False
+                        import warnings
+                        warnings.warn("brl_amd.evaluation: a count stored by a launch into pinned host memory never became "
+                                      "visible (non-coherent host allocation?): falling back to copy + event per iteration.",
+                                      RuntimeWarning)
+                        return None
+                    if waited > 60.0:         # (a launch that never completes must not hang the host for ever)
                         raise RuntimeError("brl_amd.evaluation: the finished-board count of an iteration never arrived (GPU fault?)")
         self.events[k].synchronize()
         return int(self.host[k]), (self.idx[k] if self.idx is not None else None)

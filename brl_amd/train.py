@@ -43,6 +43,8 @@ DEFAULTS = dict(  # ppo.py:122-180 (PPOConfig), same names and defaults
     # build-side knobs (not in the reference)
     lut_len=100_000, synthetic_lut_files=3, inference_dtype=None, graph_rollout=False, evaluate=True,
     tunable_gemm=False,  # torch TunableOp: time every rocBLAS / hipBLASLt solution once per GEMM shape (update: -5 %)
+    memoize_eval=True, memoize_eval_check_every=0,   # the per-iteration duplicate evaluations: play each distinct pair once (train())
+    grad_allreduce="sharded",   # the gradient step under a process group: "sharded" | "flat" (brl_amd/fused_update.py)
 )
 
 
@@ -276,9 +278,22 @@ def train(config, log=print, on_rollout=None):
     memo = {"key": None, "imp": None}
     opp_version = 0
 
+    # config["memoize_eval"] (default on): off = the reference's three evaluations per iteration, played each time;
+    # config["memoize_eval_check_every"] = N > 0: every N-th memo hit is re-played and must give the remembered IMP (a guard
+    # against a future in-place change of `params` / `opp_params` outside the counted sites: the key is bookkeeping, not a checksum)
+    memoize = bool(config.get("memoize_eval", True))
+    check_every = int(config.get("memoize_eval_check_every", 0) or 0)
+    hits = [0]
+
     def duplicate_imp(params, opp, version):
         key = (version, opp_version)
-        if memo["key"] == key:
+        if memoize and memo["key"] == key:
+            hits[0] += 1
+            if check_every and hits[0] % check_every == 0:
+                again = float(simple_duplicate_evaluate(params, opp, eval_rng)[0][0])
+                if again != memo["imp"]:
+                    raise RuntimeError(f"brl_amd.train: a memoised evaluation is stale (key {key}: {memo['imp']} remembered, {again} "
+                                       f"re-played): parameters changed outside the loop's counted sites — set memoize_eval=False")
             return memo["imp"]
         imp = float(simple_duplicate_evaluate(params, opp, eval_rng)[0][0])
         memo.update(key=key, imp=imp)

@@ -1,12 +1,12 @@
 """Same-box A/B of k_rollout_ws builds.  usage: python scripts/ab2.py name[=flags] ...
-Each variant is brl_kernels.hip compiled with its -D flags (e.g. `base exp1=-DBRL_EXP=1`) into brl_amd/lib/variants/<name>.so
+Each variant is the library (every csrc/*.hip) compiled with its -D flags (e.g. `base exp1=-DBRL_EXP=1`) into brl_amd/lib/variants/<name>.so
 when built here (CPU container, `--build`), and timed on the GPU box in alternating subprocesses (`--run`): median of 5
 repeats of 128 back-to-back launches between one event pair, 3 rotating output buffers.  `--check` also compares
 every variant's Transition against the first variant's (bit-exact)."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VDIR = os.path.join(ROOT, "brl_amd", "lib", "variants")
-SRC = os.path.join(ROOT, "brl_amd", "csrc", "brl_kernels.hip")
+SRC = sorted(__import__("glob").glob(os.path.join(ROOT, "brl_amd", "csrc", "*.hip")))
 
 BODY = r'''
 import os, sys, json, hashlib
@@ -90,7 +90,7 @@ def main():
         for name, flags in variants:
             out = os.path.join(VDIR, name + ".so")
             subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
-                                  + [f for f in flags if not f.startswith("env:")] + ["-o", out, SRC], stderr=subprocess.DEVNULL)
+                                  + [f for f in flags if not f.startswith("env:")] + ["-o", out] + SRC, stderr=subprocess.DEVNULL)
             print("built", out)
     if "--run" in sys.argv:
         res = {n: [] for n, _ in variants}

@@ -1,4 +1,4 @@
-"""Times the head kernels of the fused PPO minibatch step (brl_ppo_heads_loss / _bwd / brl_ppo_stats_gram / brl_bias_finalize_ex)
+"""Times the head kernels of the fused PPO minibatch step (brl_ppo_heads_loss_split / _bwd / brl_ppo_stats_gram / brl_bias_finalize_ex)
 at minibatch 1024, hidden 1024: 200 launches between one HIP-event pair each."""
 import ctypes as C
 import os
@@ -28,6 +28,7 @@ dh, ts = torch.empty(B, H, device=dev), torch.empty(groups, H, device=dev)
 out = torch.zeros(8, device=dev)
 row = torch.zeros(1, dtype=torch.int32, device=dev)
 ssum, gsum, rows_out = torch.zeros(2560, 8, device=dev), torch.zeros(2560, 1444, device=dev), torch.zeros(2560, 8, device=dev)
+hparts = torch.empty(4, B, 39, device=dev)
 gW, gb, gbias = torch.empty(39, H, device=dev), torch.empty(39, device=dev), torch.empty(H, device=dev)
 parts = (C.c_void_p * 3)(dwp.data_ptr(), dbp.data_ptr(), ts.data_ptr())
 cols, tiles = (C.c_int64 * 3)(39 * H, 39, H), (C.c_int64 * 3)(nsplit, nsplit, groups)
@@ -35,9 +36,9 @@ outs = (C.c_void_p * 3)(gW.data_ptr(), gb.data_ptr(), gbias.data_ptr())
 
 
 def loss():
-    _capi.check(L.brl_ppo_heads_loss(0, h.data_ptr(), H, Wh.data_ptr(), bh.data_ptr(), H, mask.data_ptr(), action.data_ptr(),
-                                     old_v.data_ptr(), old_lp.data_ptr(), gae.data_ptr(), tgt.data_ptr(), B, 0.2, 0.5, 0.001, 1, 1, 0,
-                                     None, dheads.data_ptr(), partials.data_ptr(), gram_p.data_ptr(), s))
+    _capi.check(L.brl_ppo_heads_loss_split(0, h.data_ptr(), H, Wh.data_ptr(), bh.data_ptr(), H, mask.data_ptr(), action.data_ptr(),
+                                           old_v.data_ptr(), old_lp.data_ptr(), gae.data_ptr(), tgt.data_ptr(), B, 0.2, 0.5, 0.001, 1, 1, 0,
+                                           None, dheads.data_ptr(), partials.data_ptr(), gram_p.data_ptr(), hparts.data_ptr(), 4, s))
 
 
 def bwd():
@@ -62,7 +63,7 @@ def act_bwd():
     _capi.check(L.brl_act_bwd_colsum(0, dh.data_ptr(), h.data_ptr(), B, H, H, 0, ts.data_ptr(), s))
 
 
-for name, fn in (("brl_ppo_heads_loss", loss), ("brl_ppo_heads_bwd", bwd), ("brl_ppo_stats_gram", stats), ("brl_ppo_stats_rows (2560 rows)", stats_rows), ("brl_bias_finalize_ex (3 segments)", fin),
+for name, fn in (("brl_ppo_heads_loss_split (ksplit 4)", loss), ("brl_ppo_heads_bwd", bwd), ("brl_ppo_stats_gram", stats), ("brl_ppo_stats_rows (2560 rows)", stats_rows), ("brl_bias_finalize_ex (3 segments)", fin),
                  ("brl_act_bwd_colsum", act_bwd)):
     for _ in range(20):
         fn()

@@ -3,9 +3,9 @@ import os, sys, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = "/tmp/libbrl_timing.so"
-SRC = os.environ.get("SRC", os.path.join(ROOT, "brl_amd/csrc/brl_kernels.hip"))
+SRC = sorted(__import__("glob").glob(os.path.join(ROOT, "brl_amd/csrc/*.hip")))   # (every unit of the library)
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-                       "-DBRL_TIMING"] + os.environ.get("FLAGS", "").split() + ["-o", so, SRC], stderr=subprocess.DEVNULL)
+                       "-DBRL_TIMING"] + os.environ.get("FLAGS", "").split() + ["-o", so] + SRC, stderr=subprocess.DEVNULL)
 from brl_amd import _capi
 _capi.LIB_PATH = so
 import numpy as np, torch, ctypes as C

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = "/tmp/libbrl_timing_fs.so"
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-DBRL_TIMING"]
-                      + os.environ.get("FLAGS", "").split() + ["-o", so, os.path.join(ROOT, "brl_amd/csrc/brl_kernels.hip")], stderr=subprocess.DEVNULL)
+                      + os.environ.get("FLAGS", "").split() + ["-o", so] + sorted(__import__("glob").glob(os.path.join(ROOT, "brl_amd/csrc/*.hip"))), stderr=subprocess.DEVNULL)   # (every unit of the library)
 from brl_amd import _capi
 _capi.LIB_PATH = so
 import numpy as np, torch, ctypes as C

@@ -1551,6 +1551,22 @@ def test_ppo_loop_two_ranks(tmp_path):
     assert not np.array_equal(obs0, obs1)
 
 
+def test_ppo_loop_four_ranks(tmp_path):
+    """The same loop on FOUR gloo ranks sharing the GPU (a box of this pool allows at most 6 processes on its card: the pytest
+    process + 4): the sharded gradient step at world 4 (4 buckets x 4 slices), the pool's opponent index broadcast to three
+    followers, four env shards — identical parameters on every rank, and rank 3's first rollout replayed through the oracle at
+    env_offset = 3 * 256."""
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mp.start_processes(_train_rank, args=(4, port, str(tmp_path)), nprocs=4, join=True, start_method="spawn")
+    rs = [torch.load(tmp_path / f"rank{r}.pt") for r in range(4)]
+    assert all(r[2] == "FusedMinibatch" and r[3] == 4 for r in rs)
+    for r in rs[1:]:
+        assert torch.equal(rs[0][0], r[0]) and r[1] != rs[0][1]
+    _replay_rank_rollout(tmp_path, 3)
+
+
 def test_ppo_loop_two_ranks_rccl(tmp_path):
     """The same loop over RCCL ("nccl"), one GPU per rank — BASELINE configs[4]'s collective path (the flat gradient's
     all-reduce between FusedMinibatch's graphs, opponent-index broadcast, summed counters) on real xGMI links.

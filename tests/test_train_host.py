@@ -141,6 +141,14 @@ def test_haiku_pickle_reader_refuses_foreign_globals(tmp_path):
     for payload in (_Evil(), {"actor_critic/linear": {"w": _Evil()}}):
         with pytest.raises(pickle.UnpicklingError, match="refusing"):
             ckpt.load_haiku_pickle(pickle.dumps(payload))
+    # `_codecs.encode` (numpy's protocol <= 2 byte strings) resolves to a latin1-only stand-in: a file cannot name another codec
+    # (the real function would import encodings.<name>: bz2, zlib, ...)
+    class _Codec:
+        def __reduce__(self):
+            import _codecs
+            return (_codecs.encode, ("abc", "bz2"))
+    with pytest.raises(pickle.UnpicklingError, match="latin1"):
+        ckpt.load_haiku_pickle(pickle.dumps({"actor_critic/linear": {"w": _Codec()}}, protocol=2))
     # a plain numpy tree (what a jax-free writer would dump) still loads
     tree = {"actor_critic/linear": {"w": np.ones((480, 4), np.float32), "b": np.zeros(4, np.float32)}}
     back = ckpt.load_haiku_pickle(pickle.dumps(tree))
