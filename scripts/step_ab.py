@@ -2,7 +2,8 @@
     python scripts/step_ab.py own_gemm=0 own_gemm=1 [rounds=5] [steps=256]
 Each variant is `key=value[,key=value...]` over the configs[3] settings (8192 x 32 synthetic trajectory, minibatch 1024, DeepMind
 MLP, fp32); prints ms per minibatch step (median / min over the rounds) and, with `check=1`, the max parameter difference between
-the variants after the same steps from the same start (should be rounding-level)."""
+the variants after the same steps from the same start (should be rounding-level).  `rccl=1`: under a world-1 RCCL process group
+(variants with `force_collectives=1,grad_allreduce=sharded|flat` then carry real collective nodes in their graphs)."""
 import os
 import sys
 import time
@@ -35,7 +36,7 @@ def parse(v):
 
 def main():
     args = [a for a in sys.argv[1:]]
-    opts = {"rounds": 5, "steps": 256, "check": 0}
+    opts = {"rounds": 5, "steps": 256, "check": 0, "rccl": 0}
     variants = []
     for a in args:
         k = a.split("=")[0]
@@ -44,6 +45,10 @@ def main():
         else:
             variants.append(a)
     dev = torch.device("cuda", 0)
+    if opts["rccl"]:   # a world-1 RCCL process group: `force_collectives=1,grad_allreduce=sharded` then runs the multi-rank program with
+        import torch.distributed as dist   # real (single-peer) reduce-scatter / all-gather nodes inside the step's hipGraph
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     N, T, mbs = 8192, 32, 1024
     rows = N * T
     g = torch.Generator(device=dev).manual_seed(0)
