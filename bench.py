@@ -760,7 +760,7 @@ def rehearse_multirank(torch, dev, cfg, fp, traj, adv, tgt, single_ms):
             ts.append(time.perf_counter() - t0)
             fm.end_update()
         t = float(np.median(ts[1:]))
-        res[mode] = {"ms_per_minibatch": t / (rows // 1024) * 1e3, "graph_replays_per_step": 1.0 / fm.multi if fm.in_graph else None,
+        res[mode] = {"ms_per_minibatch": t / (rows // 1024) * 1e3, "graph_replays_per_step": 1.0 / fm.graph_steps if fm.in_graph else None,
                      "collectives_per_step": per_step, "collectives_inside_the_graph": bool(fm.in_graph),
                      "adam_sweep_fraction": 1.0 / world if mode == "sharded" else 1.0,
                      "overhead_vs_single_rank_ms": t / (rows // 1024) * 1e3 - single_ms}

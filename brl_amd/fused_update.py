@@ -30,51 +30,23 @@ class _DistCollectives:
         return dist.all_gather_into_tensor(out, inp, async_op=async_op)
 
 
-class FusedMinibatch:
-    """One PPO minibatch step of a "DeepMind" MLP (src/update.py:74-242) with the forward layers and the batched weight gradient
-    left to the library and everything else hand-written HIP (DESIGN.md §4.3): the minibatch gather (``brl_mb_gather_dev``:
-    device-resident arguments), the 39-column head + ``_loss_fn`` + its gradients (``brl_ppo_heads_loss_split``), the head's
-    backward (``brl_ppo_heads_bwd``), dz_{l-1} = (dz_l W_l) act'(h_{l-1}) with the bias gradient's tile sums in the epilogue
-    (``brl_mlp_gemm``), global-norm clipping + Adam on flat parameter / gradient / moment buffers; the backward pass is written
-    out (no autograd); EIGHT steps are one hipGraph; the logged statistics are formed once per update from per-step sums
-    (``brl_ppo_stats_rows``).
+class FusedStep:
+    """What every fused PPO minibatch step shares: the FLAT parameter / gradient / moment buffers the module's parameters and the
+    optimizer's state become views of, the device-resident minibatch gather, the step as a PROGRAM — a list of kernel groups
+    ("k"), collectives ("c") and waits ("w") built once by the subclass — and its two execution strategies: captured whole,
+    collectives included, ``update_graph_steps`` times per hipGraph (single rank, and RCCL, whose collectives record into a graph);
+    or, for a backend that cannot be captured (gloo), one graph per kernel group with the collectives issued eagerly between the
+    replays.  Subclasses: ``FusedMinibatch`` (the DeepMind MLPs), ``FusedFair`` (the FAIR residual net)."""
 
-    The step is a PROGRAM — a list of kernel groups ("k"), collectives ("c") and waits ("w") — built once and executed by one of
-    two strategies: captured whole, collectives included, ``update_graph_steps`` times per hipGraph (single rank, and RCCL, whose
-    collectives record into a graph); or, for a backend that cannot be captured (gloo), one graph per kernel group with the
-    collectives issued eagerly between the replays.  Under a process group (``world > 1``, ``config["grad_allreduce"]``):
-
-      "sharded" (default)  reduce-scatter of the gradient bucket by bucket (one bucket per hidden layer, issued as soon as its
-          weight gradient exists, overlapping the rest of the backward pass; the last bucket = layer 0 + head + biases), the
-          norm's partial sums of the rank's own slices + a 4 KB all-gather, clip + Adam on the rank's 1/world slices only, then
-          the all-gather of the updated parameters bucket by bucket in forward order — the next step's layer l waits for ITS
-          bucket only.  Same ring bytes as an all-reduce; the Adam sweep shrinks by 1/world; the moments are valid on the rank's
-          slices only (``gather_optimizer_state`` completes them for a checkpoint).
-      "flat"  the same launches, ONE all-reduce of the flat gradient behind them, clip + Adam replicated on every rank.  Nothing
-          overlaps the collective: the simple form, kept as the fallback and as the check of the sharded one.
-
-    Both forms give bit-identical parameters (the norm's partials have one layout: csrc/ppo_update.hpp ShardGeom).
-
-    The module's parameters and the optimizer's moments become VIEWS of the flat buffers, so ``params``, ``state_dict``
-    checkpoints and the eager path keep working on the same memory.  Mirrors torch.optim.Adam's arithmetic and
-    ``clip_grad_norm_``; checked against the float64 numpy restatement and the eager path (tests/test_gpu_parity.py)."""
-
-    @staticmethod
-    def supports(config, params) -> bool:
-        # the DeepMind MLPs (4 / 6 / 8 x 1024) with either activation (src/models.py:16), reward_scaling and a non-zero
-        # illegal_action_l2norm_coef included; the FAIR net takes the autograd path
-        return (bool(config.get("fused_update", True)) and str(getattr(params, "model", "")).startswith("DeepMind")
-                and getattr(params, "act", None) in (torch.relu, torch.tanh)
-                and params.body[0].weight.shape[0] % 256 == 0
-                and next(params.parameters()).is_cuda and next(params.parameters()).dtype == torch.float32)
+    rows_at_end = True      # the log rows are formed from per-step sums by ONE launch at the end of the update (brl_ppo_stats_rows)
 
     def __init__(self, config, params, opt, mbs: int, device, world: int = 1, log_capacity: int = 0, collective=None):
         from . import _capi
-        import ctypes as C
         self.cfg, self.params, self.opt, self.mbs, self.dev = config, params, opt, int(mbs), device
         self.lib, self.capi = _capi.lib(), _capi
         self.world = int(world)
         multi = self.world > 1 or bool(config.get("force_collectives", False))   # (force_collectives: the multi-rank program at world 1 — tests / bench)
+        self.multi = multi
         self.allreduce_mode = str(config.get("grad_allreduce", "sharded")) if multi else "none"
         if self.allreduce_mode not in ("none", "flat", "sharded"):
             raise ValueError("config['grad_allreduce'] must be 'sharded' or 'flat'")
@@ -83,37 +55,15 @@ class FusedMinibatch:
         if config.get("tuned_gemm", True):   # committed TunableOp solutions for the step's GEMM shapes (brl_amd/tuned): lookups only
             from . import tuned
             tuned.enable()
-        f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)  # noqa: E731
-        body = list(params.body)
-        nl = len(body)
-        H = body[0].weight.shape[0]
-        K = params.actor.weight.shape[0] + 1
+        f = self._f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)  # noqa: E731
         B = self.mbs
-        self.H, self.K, self.nl = H, K, nl
-        # ---- flat layout: W_1 .. W_{nl-1} (consecutive [H, H] blocks: one batched weight-gradient product, one collective bucket
-        # each), then the TAIL = W_0 | actor.weight | critic.weight (one [39, H] matrix) | the biases (hidden layers, actor |
-        # critic): the tail is what the backward pass finishes last — one bucket —, and its last part (head + biases) is what the
-        # sums of partials produce (brl_adam_clip_fin_gather wants those at the END of the buffer)
-        plist = [lin.weight for lin in body[1:]] + [body[0].weight, params.actor.weight, params.critic.weight] \
-            + [lin.bias for lin in body] + [params.actor.bias, params.critic.bias]
+        self.act = 0 if params.act is torch.relu else 1
+        self.ill_coef = float(config.get("illegal_action_l2norm_coef", 0.0) or 0.0)
+        # ---- the subclass orders the parameters in the flat buffers and (multi-rank) cuts them into collective buckets
+        plist, sizes, offs, lens, n = self._layout()
         assert len(plist) == len(list(params.parameters()))
-        sizes = [q.numel() for q in plist]
-        hid = (nl - 1) * H * H
-        tail = sum(sizes) - hid
-        # buckets of the multi-rank step: every hidden layer + the tail, each cut into `world` slices of whole float4s
-        self.sharded_geom = multi and (H * H) % (4 * self.world) == 0
-        if self.allreduce_mode == "sharded" and not self.sharded_geom:
-            raise ValueError(f"grad_allreduce='sharded' needs hidden^2 divisible by 4 * world (hidden {H}, world {self.world}): use 'flat'")
-        quantum = 4 * self.world if multi else 4
-        tail_pad = (tail + quantum - 1) // quantum * quantum
-        self.n = n = hid + tail_pad             # zero padding at the end
+        self.n = n
         if multi:
-            if self.sharded_geom:
-                offs = [l * H * H for l in range(nl - 1)] + [hid]
-                lens = [H * H // self.world] * (nl - 1) + [tail_pad // self.world]
-            else:                                # one bucket: the whole buffer
-                self.n = n = (sum(sizes) + quantum - 1) // quantum * quantum
-                offs, lens = [0], [n // self.world]
             g = _capi.ShardGeom()
             g.nbuckets, g.world = len(offs), self.world
             g.nsub = max(1, 1024 // (self.world * len(offs)))
@@ -143,64 +93,15 @@ class FusedMinibatch:
                 views[q] = sl
                 off += k
         self.views = views
-        self.W = [lin.weight for lin in body]                      # [out, in] views of P
-        self.b = [lin.bias for lin in body]
-        self.GW = [self.G[views[lin.weight]].view(lin.weight.shape) for lin in body]
-        self.Gb = [self.G[views[lin.bias]] for lin in body]
-        wa = views[params.actor.weight]
-        self.Wh = self.P[wa.start:wa.start + K * H].view(K, H)     # actor rows, then the critic row
-        self.GWh = self.G[wa.start:wa.start + K * H].view(K, H)
-        ba = views[params.actor.bias]
-        self.bh = self.P[ba.start:ba.start + K]
-        self.Gbh = self.G[ba.start:ba.start + K]
-        # Activations and the gradients w.r.t. the pre-activations live in STACKED static buffers (out= costs the fused bias +
-        # ReLU GEMM nothing: scripts/fwd_probe.py): the hidden layers' weight gradients are ONE batched product
-        self.hs = f(nl, B, H)                       # h_l = act(h_{l-1} W_l^T + b_l)
-        self.dzs = f(nl, B, H)                      # d(loss) / d(pre-activation of layer l)
-        self.h = [self.hs[l] for l in range(nl)]
-        self.GW_hidden = self.G[:hid].view(nl - 1, H, H) if nl > 1 else None   # the gradients of W_1 .. W_{nl-1} as one tensor
         self.x0 = f(B, 480)
         self.mask = torch.zeros((B, 38), dtype=torch.uint8, device=device)
         self.mask[:, 0] = 1  # a valid dummy batch for the warm-up iterations
         self.action = torch.zeros(B, dtype=torch.int32, device=device)
         self.old_v, self.old_lp, self.adv, self.tgt = f(B), f(B), f(B), f(B)
-        self.dheads = f(B, K)
-        self.ill_coef = float(config.get("illegal_action_l2norm_coef", 0.0) or 0.0)
-        self.heads = f(B, K) if self.ill_coef else None      # the gradient of the illegal-action norm re-reads the logits
-        self.head_ksplit = max(1, min(4, H // 256))          # K ranges of the heads product (brl_ppo_heads_loss_split)
-        self.head_parts = f(self.head_ksplit, B, K)
-        self.vec = f(40) if self.ill_coef else None          # v1 [38], sigma_1 of the step's illegal-action matrix
-        self.act = 0 if params.act is torch.relu else 1
-        groups = (B + 15) // 16                        # 16-row tiles of the bias-gradient column sums
         self.lgroups = (B + 3) // 4                    # 4-sample groups of the loss launch (statistics / Gram partials)
         self.partials = f(self.lgroups, 8)
-        self.gram_partials = f(self.lgroups, 38 * 38)
         self.out = f(8)
-        self.scratch = f(8192)   # single rank: norm partials (1024 blocks + the finalize blocks that ride in the norm launch)
-        self.nsplit = (B + 63) // 64                   # batch splits of the head's weight / bias gradient (brl_ppo_heads_bwd)
-        self.dwh_partials = f(self.nsplit, K * H)
-        self.dbh_partials = f(self.nsplit, K)
-        # the step's 1024^3-class products on this library's own fp32 MFMA kernel (brl_mlp_gemm, csrc/mlp_gemm.hpp) where its
-        # fused epilogue removes a launch: dh = dz W with the activation derivative and the bias-gradient tile sums inside
-        # (replaces torch.mm + brl_act_bwd_colsum), and — sharded form — each layer's own weight gradient.  The forward layers
-        # (config["own_gemm_fwd"]: opt-in, 19.8-20.1 us per layer in the step against the tuned library kernel's 19.0-19.6) and
-        # the single-rank batched weight gradient stay with the library.
-        self.own_gemm = bool(config.get("own_gemm", True)) and B % 4 == 0 and H % 4 == 0 and nl > 1
-        self.own_fwd = self.own_gemm and bool(config.get("own_gemm_fwd", False))
-        # the head's weight-gradient role (not on the backward chain) rides with the first launch of the dz chain below the top
-        self.dw_deferred = nl > 1
-        groups64 = (B + 63) // 64                      # 64-row tiles of brl_mlp_gemm's column sums
-        self.tile_rows = [64 if (self.own_gemm and l < nl - 1) else 16 for l in range(nl)]
-        self.tile_sums = [f(groups * H) for _ in body]   # per-layer partial column sums (bias gradients)
-        # one launch finishes every sum of partials: the head's weight gradient, the hidden layers' bias gradients, the head's
-        # bias gradient — in the order they sit at the end of the flat buffer
-        nseg = nl + 2
-        self._seg_scratch = (C.c_void_p * nseg)(*([self.dwh_partials.data_ptr()] + [t.data_ptr() for t in self.tile_sums]
-                                                  + [self.dbh_partials.data_ptr()]))
-        self._seg_cols = (C.c_int64 * nseg)(*([K * H] + [H] * nl + [K]))
-        self._seg_tiles = (C.c_int64 * nseg)(*([self.nsplit] + [groups64 if r == 64 else groups for r in self.tile_rows] + [self.nsplit]))
-        self._seg_db = (C.c_void_p * nseg)(*([self.GWh.data_ptr()] + [g.data_ptr() for g in self.Gb] + [self.Gbh.data_ptr()]))
-        self._nseg = nseg
+        self._alloc()                                  # the subclass's activations, scratch and segment tables
         # The logged statistics (src/update.py:136-167) are NOT formed step by step: every step leaves its sums — 8 floats and
         # the 38 x 38 Gram matrix of the illegal-action probabilities, reduced by spare workgroups of the head-backward
         # launch — in row mb_index of these buffers, and ONE launch at the end of the update turns all rows into log rows
@@ -249,9 +150,9 @@ class FusedMinibatch:
                     self.graph = self._capture_steps(1, gkw)
                     # ... and the same step K times in ONE graph: a replay boundary costs ~5 us (graph launch behind the last
                     # kernel), the step ~0.23 ms; mb_index lives in device memory, so the K copies walk K minibatches
-                    self.multi = int(config.get("update_graph_steps", 8))
-                    if self.multi > 1:
-                        self.graph_multi = self._capture_steps(self.multi, gkw)
+                    self.graph_steps = int(config.get("update_graph_steps", 8))
+                    if self.graph_steps > 1:
+                        self.graph_multi = self._capture_steps(self.graph_steps, gkw)
                 else:
                     pool = torch.cuda.graph_pool_handle()
                     self.segs = []          # the program with every run of kernel groups replaced by its graph
@@ -278,41 +179,6 @@ class FusedMinibatch:
                 for t, q in zip((self.P, self.M, self.V, self.step, self.mb_index), saved):
                     t.copy_(q)
 
-    # ---- the step as a program ---------------------------------------------------------------------------------------
-    def _build_program(self):
-        """-> [("k", fn) | ("c", key, fn(async_op) -> work) | ("w", key)]: one minibatch step on the current stream"""
-        nl = self.nl
-        if self.allreduce_mode == "none":
-            return [("k", self._step_single)]
-        co, G, P = self.coll, self.G, self.P
-        if self.allreduce_mode == "flat":
-            return [("k", self._grads_chain),
-                    ("c", "ar", lambda a: co.all_reduce(G, a)), ("w", "ar"),          # SUM: the sweep scales by 1 / world
-                    ("k", lambda: (self._shard_norm(0, self.world), self._shard_apply(0, self.world)))]
-        # "sharded"
-        r = self.rank
-        bucket = lambda t, b: t[self.bucket_off[b]:self.bucket_off[b] + self.world * self.bucket_len[b]]   # noqa: E731
-        mine = lambda t, b: t[self.bucket_off[b] + r * self.bucket_len[b]:self.bucket_off[b] + (r + 1) * self.bucket_len[b]]  # noqa: E731
-        tail = nl - 1                                  # bucket index of W_0 | head | biases; bucket l - 1 = W_l
-        np_ = self.norm_partials
-        per = np_.numel() // self.world
-        prog = [("w", "ag%d" % tail), ("k", lambda: self._forward(0))]
-        for l in range(1, nl):                         # layer l multiplies with W_l: its all-gather (of the step before) must be in
-            prog += [("w", "ag%d" % (l - 1)), ("k", lambda l=l: self._forward(l))]
-        prog += [("k", self._heads)]
-        for l in range(nl - 1, 0, -1):                 # dW_l as soon as dz_l exists -> its bucket leaves; then dz_{l-1}
-            prog += [("k", lambda l=l: self._dw(l)),
-                     ("c", "rs%d" % (l - 1), lambda a, l=l: co.reduce_scatter(mine(G, l - 1), bucket(G, l - 1), a)),
-                     ("k", lambda l=l: self._dz(l))]
-        prog += [("k", lambda: (self._dw(0), self._seg_fin())),
-                 ("c", "rs%d" % tail, lambda a: co.reduce_scatter(mine(G, tail), bucket(G, tail), a))]
-        prog += [("w", "rs%d" % b) for b in range(nl)]
-        prog += [("k", lambda: self._shard_norm(r, r + 1)),
-                 ("c", "agn", lambda a: co.all_gather(np_, np_[r * per:(r + 1) * per], a)), ("w", "agn"),
-                 ("k", lambda: self._shard_apply(r, r + 1))]
-        for b in [tail] + list(range(nl - 1)):         # parameters back, in the order the next forward pass needs them
-            prog += [("c", "ag%d" % b, lambda a, b=b: co.all_gather(bucket(P, b), mine(P, b), a))]
-        return prog
 
     def _capture_steps(self, k, gkw):
         g = torch.cuda.CUDAGraph()
@@ -357,6 +223,270 @@ class FusedMinibatch:
 
     def _di(self):
         return self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+
+    # ---- clip + Adam on rank slices (multi-rank forms) -----------------------------------------------------------------
+    def _shard_norm(self, lo, hi):
+        import ctypes as C
+        self.capi.check(self.lib.brl_adam_shard_norm(self._di(), self.G.data_ptr(), C.byref(self.geom), lo, hi, 1.0 / self.world,
+                                                     self.norm_partials.data_ptr(), self.step.data_ptr(), self.mb_index.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream))
+
+    def _shard_apply(self, lo, hi):
+        import ctypes as C
+        self.capi.check(self.lib.brl_adam_shard_apply(
+            self._di(), self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), C.byref(self.geom), lo, hi,
+            self.norm_partials.data_ptr(), self.step.data_ptr(), self.lr, self.lr_dev.data_ptr(), float(self.b1), float(self.b2),
+            self.eps, self.max_norm, 1.0 / self.world, self.norm.data_ptr(), self.gargs.data_ptr(), self.mbs,
+            torch.cuda.current_stream().cuda_stream))
+
+    # ---- one update_step call -----------------------------------------------------------------------------------
+    def begin_update(self, flat: Transition, adv_f, tgt_f, perms):
+        """flat: the [T*N, ...] views of the trajectory; adv_f / tgt_f: [T*N]; perms: one permutation of T*N per epoch.
+        Binds the step's gather to them (device-resident arguments) and resets the minibatch counter."""
+        steps = sum(p.numel() for p in perms) // self.mbs
+        if steps > self._log_cap:   # (checked before anything is touched; update_step never gets here: it rebuilds first)
+            raise RuntimeError("FusedMinibatch: more minibatch steps per update than its log holds (log_capacity)")
+        self._keep = (Transition(*[x.contiguous() for x in flat]), adv_f.contiguous(), tgt_f.contiguous())
+        fl, adv_c, tgt_c = self._keep
+        self._steps = steps
+        with torch.no_grad():
+            self._readopt()
+            allp = torch.cat(perms)
+            if self.perm is None or self.perm.numel() != allp.numel():
+                self.perm = torch.empty_like(allp)
+            self.perm.copy_(allp)
+            self.mb_index.zero_()
+            self.step.copy_(self.opt.state[self.plist[0]]["step"])  # the optimizer may have been stepped eagerly / loaded
+            self.lr_dev.fill_(float(self.opt.param_groups[0]["lr"]))  # constant within an update (ppo.py:186-192)
+            self._bind_gather(fl, adv_c, tgt_c, self.perm)
+
+    def _readopt(self):
+        """`opt.load_state_dict` (resume) or a foreign `p.data = ...` replaces tensors that were views of the flat buffers:
+        copy their contents in and point them back at the buffers (addresses are baked into the graph)."""
+        for q in self.plist:
+            sl = self.views[q]
+            if q.data.data_ptr() != self.P[sl].data_ptr():
+                self.P[sl].copy_(q.data.reshape(-1))
+                q.data = self.P[sl].view(q.shape)
+            st = self.opt.state.get(q)
+            if st is None or "exp_avg" not in st:
+                self.M[sl].zero_(); self.V[sl].zero_()
+                self.opt.state[q] = {"step": torch.zeros((), dtype=torch.float32, device=self.dev),
+                                     "exp_avg": self.M[sl].view(q.shape), "exp_avg_sq": self.V[sl].view(q.shape)}
+                continue
+            if st["exp_avg"].data_ptr() != self.M[sl].data_ptr():
+                self.M[sl].copy_(st["exp_avg"].reshape(-1))
+                self.V[sl].copy_(st["exp_avg_sq"].reshape(-1))
+                st["exp_avg"], st["exp_avg_sq"] = self.M[sl].view(q.shape), self.V[sl].view(q.shape)
+            if not torch.is_tensor(st["step"]) or st["step"].device != self.P.device:
+                st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=self.dev).reshape(())
+
+    def run_steps(self, n: int):
+        """the next n minibatch steps of the bound update"""
+        if self.in_graph:
+            k = self.graph_steps if self.graph_multi is not None else 0
+            while k and n >= k:
+                self.graph_multi.replay()
+                n -= k
+            for _ in range(n):
+                self.graph.replay()
+            return
+        for _ in range(n):          # a backend that cannot be captured: graphs of kernel groups, eager blocking collectives between
+            for item in self.segs:
+                if item[0] == "g":
+                    item[1].replay()
+                else:
+                    w = item[2](False)
+                    if w is not None:
+                        w.wait()
+
+    def gather_optimizer_state(self):
+        """"sharded": Adam's moments are current on this rank's slices only — before the optimizer state is SAVED, every rank
+        calls this (a collective: two all-gathers per bucket) and ends with the complete moments, as in the replicated forms."""
+        if self.allreduce_mode != "sharded":
+            return
+        r = self.rank
+        for t in (self.M, self.V):
+            for o, ln in zip(self.bucket_off, self.bucket_len):
+                w = self.coll.all_gather(t[o:o + self.world * ln], t[o + r * ln:o + (r + 1) * ln], False)
+                if w is not None:
+                    w.wait()
+
+    def end_update(self):
+        """-> the [steps, 8] log of the update (total, value_loss, loss_actor, entropy, approx_kl, clipfrac, illegal-action
+        norm / 2, 0): ONE launch over the sums the steps left behind"""
+        with torch.no_grad():  # every parameter's step counter (torch keeps one per parameter)
+            for q in self.plist:
+                self.opt.state[q]["step"].copy_(self.step)
+            if self.rows_at_end:
+                self.capi.check(self.lib.brl_ppo_stats_rows(self._di(), self.stat_sums.data_ptr(), self.gram_sums.data_ptr(), self._steps,
+                                                            self.mbs, float(self.cfg["vf_coef"]), float(self.cfg["ent_coef"]),
+                                                            self.ill_coef, self.log.data_ptr(),
+                                                            torch.cuda.current_stream().cuda_stream))
+            self._bind_gather(*self._dummy, first=False)   # (the trajectory may be freed by the caller now)
+        self._keep = None
+        return self.log[:self._steps]
+
+
+class FusedMinibatch(FusedStep):
+    """One PPO minibatch step of a "DeepMind" MLP (src/update.py:74-242) with the forward layers and the batched weight gradient
+    left to the library and everything else hand-written HIP (DESIGN.md §4.3): the minibatch gather (``brl_mb_gather_dev``:
+    device-resident arguments), the 39-column head + ``_loss_fn`` + its gradients (``brl_ppo_heads_loss_split``), the head's
+    backward (``brl_ppo_heads_bwd``), dz_{l-1} = (dz_l W_l) act'(h_{l-1}) with the bias gradient's tile sums in the epilogue
+    (``brl_mlp_gemm``), global-norm clipping + Adam on flat parameter / gradient / moment buffers; the backward pass is written
+    out (no autograd); EIGHT steps are one hipGraph; the logged statistics are formed once per update from per-step sums
+    (``brl_ppo_stats_rows``).
+
+    Under a process group (``world > 1``, ``config["grad_allreduce"]``) the program (see ``FusedStep``) carries collectives:
+
+      "sharded" (default)  reduce-scatter of the gradient bucket by bucket (one bucket per hidden layer, issued as soon as its
+          weight gradient exists, overlapping the rest of the backward pass; the last bucket = layer 0 + head + biases), the
+          norm's partial sums of the rank's own slices + a 4 KB all-gather, clip + Adam on the rank's 1/world slices only, then
+          the all-gather of the updated parameters bucket by bucket in forward order — the next step's layer l waits for ITS
+          bucket only.  Same ring bytes as an all-reduce; the Adam sweep shrinks by 1/world; the moments are valid on the rank's
+          slices only (``gather_optimizer_state`` completes them for a checkpoint).
+      "flat"  the same launches, ONE all-reduce of the flat gradient behind them, clip + Adam replicated on every rank.  Nothing
+          overlaps the collective: the simple form, kept as the fallback and as the check of the sharded one.
+
+    Both forms give bit-identical parameters (the norm's partials have one layout: csrc/ppo_update.hpp ShardGeom).
+
+    The module's parameters and the optimizer's moments become VIEWS of the flat buffers, so ``params``, ``state_dict``
+    checkpoints and the eager path keep working on the same memory.  Mirrors torch.optim.Adam's arithmetic and
+    ``clip_grad_norm_``; checked against the float64 numpy restatement and the eager path (tests/test_gpu_parity.py)."""
+
+    @staticmethod
+    def supports(config, params) -> bool:
+        # the DeepMind MLPs (4 / 6 / 8 x 1024) with either activation (src/models.py:16), reward_scaling and a non-zero
+        # illegal_action_l2norm_coef included; the FAIR net takes the autograd path
+        return (bool(config.get("fused_update", True)) and str(getattr(params, "model", "")).startswith("DeepMind")
+                and getattr(params, "act", None) in (torch.relu, torch.tanh)
+                and params.body[0].weight.shape[0] % 256 == 0
+                and next(params.parameters()).is_cuda and next(params.parameters()).dtype == torch.float32)
+
+    def _layout(self):
+        """-> (parameters in flat order, their sizes, bucket offsets, slice lengths, n)"""
+        params, multi = self.params, self.multi
+        body = list(params.body)
+        nl = len(body)
+        H = body[0].weight.shape[0]
+        K = params.actor.weight.shape[0] + 1
+        self.H, self.K, self.nl = H, K, nl
+        # ---- flat layout: W_1 .. W_{nl-1} (consecutive [H, H] blocks: one batched weight-gradient product, one collective bucket
+        # each), then the TAIL = W_0 | actor.weight | critic.weight (one [39, H] matrix) | the biases (hidden layers, actor |
+        # critic): the tail is what the backward pass finishes last — one bucket —, and its last part (head + biases) is what the
+        # sums of partials produce (brl_adam_clip_fin_gather wants those at the END of the buffer)
+        plist = [lin.weight for lin in body[1:]] + [body[0].weight, params.actor.weight, params.critic.weight] \
+            + [lin.bias for lin in body] + [params.actor.bias, params.critic.bias]
+        sizes = [q.numel() for q in plist]
+        hid = (nl - 1) * H * H
+        tail = sum(sizes) - hid
+        # buckets of the multi-rank step: every hidden layer + the tail, each cut into `world` slices of whole float4s
+        self.sharded_geom = multi and (H * H) % (4 * self.world) == 0
+        if self.allreduce_mode == "sharded" and not self.sharded_geom:
+            raise ValueError(f"grad_allreduce='sharded' needs hidden^2 divisible by 4 * world (hidden {H}, world {self.world}): use 'flat'")
+        quantum = 4 * self.world if multi else 4
+        tail_pad = (tail + quantum - 1) // quantum * quantum
+        n = hid + tail_pad                      # zero padding at the end
+        offs = lens = None
+        if multi:
+            if self.sharded_geom:
+                offs = [l * H * H for l in range(nl - 1)] + [hid]
+                lens = [H * H // self.world] * (nl - 1) + [tail_pad // self.world]
+            else:                                # one bucket: the whole buffer
+                n = (sum(sizes) + quantum - 1) // quantum * quantum
+                offs, lens = [0], [n // self.world]
+        self._hid = hid
+        return plist, sizes, offs, lens, n
+
+    def _alloc(self):
+        import ctypes as C
+        params, views, f, B, config = self.params, self.views, self._f, self.mbs, self.cfg
+        body = list(params.body)
+        nl, H, K, hid = self.nl, self.H, self.K, self._hid
+        self.W = [lin.weight for lin in body]                      # [out, in] views of P
+        self.b = [lin.bias for lin in body]
+        self.GW = [self.G[views[lin.weight]].view(lin.weight.shape) for lin in body]
+        self.Gb = [self.G[views[lin.bias]] for lin in body]
+        wa = views[params.actor.weight]
+        self.Wh = self.P[wa.start:wa.start + K * H].view(K, H)     # actor rows, then the critic row
+        self.GWh = self.G[wa.start:wa.start + K * H].view(K, H)
+        ba = views[params.actor.bias]
+        self.bh = self.P[ba.start:ba.start + K]
+        self.Gbh = self.G[ba.start:ba.start + K]
+        # Activations and the gradients w.r.t. the pre-activations live in STACKED static buffers (out= costs the fused bias +
+        # ReLU GEMM nothing: scripts/fwd_probe.py): the hidden layers' weight gradients are ONE batched product
+        self.hs = f(nl, B, H)                       # h_l = act(h_{l-1} W_l^T + b_l)
+        self.dzs = f(nl, B, H)                      # d(loss) / d(pre-activation of layer l)
+        self.h = [self.hs[l] for l in range(nl)]
+        self.GW_hidden = self.G[:hid].view(nl - 1, H, H) if nl > 1 else None   # the gradients of W_1 .. W_{nl-1} as one tensor
+        self.dheads = f(B, K)
+        self.heads = f(B, K) if self.ill_coef else None      # the gradient of the illegal-action norm re-reads the logits
+        self.head_ksplit = max(1, min(4, H // 256))          # K ranges of the heads product (brl_ppo_heads_loss_split)
+        self.head_parts = f(self.head_ksplit, B, K)
+        self.vec = f(40) if self.ill_coef else None          # v1 [38], sigma_1 of the step's illegal-action matrix
+        groups = (B + 15) // 16                        # 16-row tiles of the bias-gradient column sums
+        self.gram_partials = f(self.lgroups, 38 * 38)
+        self.scratch = f(8192)   # single rank: norm partials (1024 blocks + the finalize blocks that ride in the norm launch)
+        self.nsplit = (B + 63) // 64                   # batch splits of the head's weight / bias gradient (brl_ppo_heads_bwd)
+        self.dwh_partials = f(self.nsplit, K * H)
+        self.dbh_partials = f(self.nsplit, K)
+        # the step's 1024^3-class products on this library's own fp32 MFMA kernel (brl_mlp_gemm, csrc/mlp_gemm.hpp) where its
+        # fused epilogue removes a launch: dh = dz W with the activation derivative and the bias-gradient tile sums inside
+        # (replaces torch.mm + brl_act_bwd_colsum), and — sharded form — each layer's own weight gradient.  The forward layers
+        # (config["own_gemm_fwd"]: opt-in, 19.8-20.1 us per layer in the step against the tuned library kernel's 19.0-19.6) and
+        # the single-rank batched weight gradient stay with the library.
+        self.own_gemm = bool(config.get("own_gemm", True)) and B % 4 == 0 and H % 4 == 0 and nl > 1
+        self.own_fwd = self.own_gemm and bool(config.get("own_gemm_fwd", False))
+        # the head's weight-gradient role (not on the backward chain) rides with the first launch of the dz chain below the top
+        self.dw_deferred = nl > 1
+        groups64 = (B + 63) // 64                      # 64-row tiles of brl_mlp_gemm's column sums
+        self.tile_rows = [64 if (self.own_gemm and l < nl - 1) else 16 for l in range(nl)]
+        self.tile_sums = [f(groups * H) for _ in body]   # per-layer partial column sums (bias gradients)
+        # one launch finishes every sum of partials: the head's weight gradient, the hidden layers' bias gradients, the head's
+        # bias gradient — in the order they sit at the end of the flat buffer
+        nseg = nl + 2
+        self._seg_scratch = (C.c_void_p * nseg)(*([self.dwh_partials.data_ptr()] + [t.data_ptr() for t in self.tile_sums]
+                                                  + [self.dbh_partials.data_ptr()]))
+        self._seg_cols = (C.c_int64 * nseg)(*([K * H] + [H] * nl + [K]))
+        self._seg_tiles = (C.c_int64 * nseg)(*([self.nsplit] + [groups64 if r == 64 else groups for r in self.tile_rows] + [self.nsplit]))
+        self._seg_db = (C.c_void_p * nseg)(*([self.GWh.data_ptr()] + [g.data_ptr() for g in self.Gb] + [self.Gbh.data_ptr()]))
+        self._nseg = nseg
+
+    # ---- the step as a program ---------------------------------------------------------------------------------------
+    def _build_program(self):
+        """-> [("k", fn) | ("c", key, fn(async_op) -> work) | ("w", key)]: one minibatch step on the current stream"""
+        nl = self.nl
+        if self.allreduce_mode == "none":
+            return [("k", self._step_single)]
+        co, G, P = self.coll, self.G, self.P
+        if self.allreduce_mode == "flat":
+            return [("k", self._grads_chain),
+                    ("c", "ar", lambda a: co.all_reduce(G, a)), ("w", "ar"),          # SUM: the sweep scales by 1 / world
+                    ("k", lambda: (self._shard_norm(0, self.world), self._shard_apply(0, self.world)))]
+        # "sharded"
+        r = self.rank
+        bucket = lambda t, b: t[self.bucket_off[b]:self.bucket_off[b] + self.world * self.bucket_len[b]]   # noqa: E731
+        mine = lambda t, b: t[self.bucket_off[b] + r * self.bucket_len[b]:self.bucket_off[b] + (r + 1) * self.bucket_len[b]]  # noqa: E731
+        tail = nl - 1                                  # bucket index of W_0 | head | biases; bucket l - 1 = W_l
+        np_ = self.norm_partials
+        per = np_.numel() // self.world
+        prog = [("w", "ag%d" % tail), ("k", lambda: self._forward(0))]
+        for l in range(1, nl):                         # layer l multiplies with W_l: its all-gather (of the step before) must be in
+            prog += [("w", "ag%d" % (l - 1)), ("k", lambda l=l: self._forward(l))]
+        prog += [("k", self._heads)]
+        for l in range(nl - 1, 0, -1):                 # dW_l as soon as dz_l exists -> its bucket leaves; then dz_{l-1}
+            prog += [("k", lambda l=l: self._dw(l)),
+                     ("c", "rs%d" % (l - 1), lambda a, l=l: co.reduce_scatter(mine(G, l - 1), bucket(G, l - 1), a)),
+                     ("k", lambda l=l: self._dz(l))]
+        prog += [("k", lambda: (self._dw(0), self._seg_fin())),
+                 ("c", "rs%d" % tail, lambda a: co.reduce_scatter(mine(G, tail), bucket(G, tail), a))]
+        prog += [("w", "rs%d" % b) for b in range(nl)]
+        prog += [("k", lambda: self._shard_norm(r, r + 1)),
+                 ("c", "agn", lambda a: co.all_gather(np_, np_[r * per:(r + 1) * per], a)), ("w", "agn"),
+                 ("k", lambda: self._shard_apply(r, r + 1))]
+        for b in [tail] + list(range(nl - 1)):         # parameters back, in the order the next forward pass needs them
+            prog += [("c", "ag%d" % b, lambda a, b=b: co.all_gather(bucket(P, b), mine(P, b), a))]
+        return prog
 
     # ---- kernel groups (each on the current stream) --------------------------------------------------------------------
     def _step_single(self):
@@ -486,103 +616,217 @@ class FusedMinibatch:
             self.scratch.numel(), self.mb_index.data_ptr(), self.norm.data_ptr(), self.gargs.data_ptr(), self.mbs, self._nseg,
             self._seg_scratch, self._seg_cols, self._seg_tiles, self._seg_db, torch.cuda.current_stream().cuda_stream))
 
-    def _shard_norm(self, lo, hi):
+
+
+class FusedFair(FusedStep):
+    """The same for the "FAIR" network (src/models.py:34-69: eleven 200-wide ``hk.Linear``s in four residual blocks, the observation
+    concatenated back in front of the seventh, the two heads on the last block's output): forward and backward written out (no
+    autograd) on the flat buffers.  Its 35 products are 80 MFLOP each — launch-bound —, so the step is shaped by launch count:
+    the nine 200 x 200 layers' weight gradients are ONE batched product (their inputs and pre-activation gradients live in stacked
+    buffers, their weights are consecutive in the flat buffer), the backward chain's dz = (dz' W) act'(h) comes from ``brl_mlp_gemm``
+    with the bias gradient's tile sums in its epilogue, the other bias gradients from ``brl_act_bwd_colsum``, ALL eleven finished by
+    one ``brl_bias_finalize_ex``; ``_loss_fn`` + its gradients are one launch (``brl_ppo_loss``), the log rows are formed once per
+    update from per-step sums (``brl_ppo_stats_rows``), clip + Adam run through the shard launches (one bucket = the whole buffer).
+    ~70 launches per step, eight steps per hipGraph: 0.35 ms per step at configs[3]'s sizes (launch-count-bound: ~4.7 us per small
+    launch inside the graph); the autograd step it replaces (GraphedMinibatch), which re-gathers the whole trajectory per epoch and
+    copies every minibatch in: 0.70 ms.
+    Multi-rank: one bucket — "flat" = all-reduce + replicated sweep, "sharded" = reduce-scatter, sweep of the rank's slice,
+    all-gather of the parameters; bit-identical.  Not covered (-> the autograd path): a non-zero illegal_action_l2norm_coef."""
+
+    SQUARE = (1, 2, 3, 4, 5, 7, 8, 9, 10)      # the 200 x 200 layers, in the order of their stacked buffers
+    # input of layer l (name in self.t) — the stacked input buffer holds them in SQUARE's order
+    INPUT = {1: "h0", 2: "h1", 3: "g1", 4: "h3", 5: "x2", 7: "h6", 8: "h7", 9: "g3", 10: "h9"}
+
+    @staticmethod
+    def supports(config, params) -> bool:
+        return (bool(config.get("fused_update", True)) and getattr(params, "model", "") == "FAIR"
+                and getattr(params, "act", None) in (torch.relu, torch.tanh)
+                and not (config.get("illegal_action_l2norm_coef", 0.0) or 0.0)
+                and next(params.parameters()).is_cuda and next(params.parameters()).dtype == torch.float32)
+
+    def _layout(self):
+        p = self.params
+        L = list(p.l)
+        # the square layers first and consecutive (one batched weight-gradient product), then W_0, W_6, the heads, the biases
+        plist = [L[l].weight for l in self.SQUARE] + [L[0].weight, L[6].weight, p.actor.weight, p.critic.weight] \
+            + [lin.bias for lin in L] + [p.actor.bias, p.critic.bias]
+        sizes = [q.numel() for q in plist]
+        quantum = 4 * self.world if self.multi else 4
+        n = (sum(sizes) + quantum - 1) // quantum * quantum
+        return plist, sizes, ([0] if self.multi else None), ([n // self.world] if self.multi else None), n
+
+    def _alloc(self):
         import ctypes as C
-        self.capi.check(self.lib.brl_adam_shard_norm(self._di(), self.G.data_ptr(), C.byref(self.geom), lo, hi, 1.0 / self.world,
-                                                     self.norm_partials.data_ptr(), self.step.data_ptr(), self.mb_index.data_ptr(),
-                                                     torch.cuda.current_stream().cuda_stream))
+        p, f, B, views = self.params, self._f, self.mbs, self.views
+        L = list(p.l)
+        H = self.H = L[0].weight.shape[0]
+        nsq = len(self.SQUARE)
+        self.W, self.b = [lin.weight for lin in L], [lin.bias for lin in L]
+        self.GW = [self.G[views[lin.weight]].view(lin.weight.shape) for lin in L]
+        self.Gb = [self.G[views[lin.bias]] for lin in L]
+        gv = lambda q: self.G[views[q]].view(q.shape)   # noqa: E731
+        self.Wa, self.wc, self.ba, self.bc = p.actor.weight, p.critic.weight, p.actor.bias, p.critic.bias
+        self.GWa, self.Gwc, self.Gba, self.Gbc = gv(p.actor.weight), gv(p.critic.weight), gv(p.actor.bias), gv(p.critic.bias)
+        self.GW_square = self.G[:nsq * H * H].view(nsq, H, H)          # the square layers' weight gradients as one tensor
+        # L[6] multiplies cat([z5, obs]): its two column blocks as (strided) views — no concatenation is ever formed
+        self.W6a, self.W6b = L[6].weight[:, :H], L[6].weight[:, H:]
+        self.GW6 = self.GW[6]
+        self.cat6 = f(B, H + 480)                                      # [z5 | obs]: only dW_6 = dz_6^T cat6 reads it whole
+        self.inp = f(nsq, B, H)                                        # the square layers' inputs, stacked
+        self.dzs = f(nsq, B, H)                                        # ... and their pre-activation gradients
+        self.t = {name: self.inp[i] for i, name in enumerate(self.INPUT[l] for l in self.SQUARE)}
+        for name in "z0 h2 x1 h4 z6 h8 x3 h10 x4 dc dx dz0 dz6".split():
+            self.t[name] = f(B, H)
+        self.t["z5"] = self.cat6[:, :H]
+        self.dz = {l: self.dzs[i] for i, l in enumerate(self.SQUARE)}
+        self.dz[0], self.dz[6] = self.t["dz0"], self.t["dz6"]
+        self.logits, self.value = f(B, 38), f(B)
+        self.dlogits, self.dvalue, self.illp, self.gram = f(B, 38), f(B), f(B, 38), f(1, 38 * 38)
+        self.ones_row = torch.ones((1, B), dtype=torch.float32, device=self.dev)
+        # a gate under which act' == 1 (column sums of a gradient that has no activation in front of it)
+        self.unit_gate = torch.ones((B, H), dtype=torch.float32, device=self.dev) if self.act == 0 else f(B, H)
+        self.own_gemm = bool(self.cfg.get("own_gemm", True)) and B % 4 == 0 and H % 4 == 0
+        # bias gradients: every layer's dz leaves column sums per row tile (16 rows: brl_act_bwd_colsum; 64 rows: brl_mlp_gemm's
+        # epilogue), ONE launch finishes all eleven
+        self.from_gemm = (1, 3, 7, 9) if self.own_gemm else ()
+        t16, t64 = (B + 15) // 16, (B + 63) // 64
+        self.tiles = [f((t64 if l in self.from_gemm else t16), H) for l in range(11)]
+        self._seg_scratch = (C.c_void_p * 11)(*[t.data_ptr() for t in self.tiles])
+        self._seg_cols = (C.c_int64 * 11)(*([H] * 11))
+        self._seg_tiles = (C.c_int64 * 11)(*[t.shape[0] for t in self.tiles])
+        self._seg_db = (C.c_void_p * 11)(*[g.data_ptr() for g in self.Gb])
+        if not self.multi:      # single rank: the sweep through the shard launches with a one-bucket, world-1 geometry
+            g = self.capi.ShardGeom()
+            g.nbuckets, g.world, g.nsub = 1, 1, 1024
+            g.off[0], g.len[0] = 0, self.n
+            self.geom, self.norm_partials = g, f(1024)
 
-    def _shard_apply(self, lo, hi):
-        import ctypes as C
-        self.capi.check(self.lib.brl_adam_shard_apply(
-            self._di(), self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), C.byref(self.geom), lo, hi,
-            self.norm_partials.data_ptr(), self.step.data_ptr(), self.lr, self.lr_dev.data_ptr(), float(self.b1), float(self.b2),
-            self.eps, self.max_norm, 1.0 / self.world, self.norm.data_ptr(), self.gargs.data_ptr(), self.mbs,
-            torch.cuda.current_stream().cuda_stream))
+    # ---- the step ------------------------------------------------------------------------------------------------------
+    def _build_program(self):
+        if self.allreduce_mode == "none":
+            return [("k", lambda: (self._grads(), self._shard_norm(0, 1), self._shard_apply(0, 1)))]
+        co, G, P, r, W = self.coll, self.G, self.P, self.rank, self.world
+        if self.allreduce_mode == "flat":
+            return [("k", self._grads), ("c", "ar", lambda a: co.all_reduce(G, a)), ("w", "ar"),
+                    ("k", lambda: (self._shard_norm(0, W), self._shard_apply(0, W)))]
+        ln = self.bucket_len[0]
+        np_ = self.norm_partials
+        per = np_.numel() // W
+        return [("w", "ag"), ("k", self._grads),
+                ("c", "rs", lambda a: co.reduce_scatter(G[r * ln:(r + 1) * ln], G, a)), ("w", "rs"),
+                ("k", lambda: self._shard_norm(r, r + 1)),
+                ("c", "agn", lambda a: co.all_gather(np_, np_[r * per:(r + 1) * per], a)), ("w", "agn"),
+                ("k", lambda: self._shard_apply(r, r + 1)),
+                ("c", "ag", lambda a: co.all_gather(P, P[r * ln:(r + 1) * ln], a))]
 
-    # ---- one update_step call -----------------------------------------------------------------------------------
-    def begin_update(self, flat: Transition, adv_f, tgt_f, perms):
-        """flat: the [T*N, ...] views of the trajectory; adv_f / tgt_f: [T*N]; perms: one permutation of T*N per epoch.
-        Binds the step's gather to them (device-resident arguments) and resets the minibatch counter."""
-        steps = sum(p.numel() for p in perms) // self.mbs
-        if steps > self._log_cap:   # (checked before anything is touched; update_step never gets here: it rebuilds first)
-            raise RuntimeError("FusedMinibatch: more minibatch steps per update than its log holds (log_capacity)")
-        self._keep = (Transition(*[x.contiguous() for x in flat]), adv_f.contiguous(), tgt_f.contiguous())
-        fl, adv_c, tgt_c = self._keep
-        self._steps = steps
-        with torch.no_grad():
-            self._readopt()
-            allp = torch.cat(perms)
-            if self.perm is None or self.perm.numel() != allp.numel():
-                self.perm = torch.empty_like(allp)
-            self.perm.copy_(allp)
-            self.mb_index.zero_()
-            self.step.copy_(self.opt.state[self.plist[0]]["step"])  # the optimizer may have been stepped eagerly / loaded
-            self.lr_dev.fill_(float(self.opt.param_groups[0]["lr"]))  # constant within an update (ppo.py:186-192)
-            self._bind_gather(fl, adv_c, tgt_c, self.perm)
+    def _a(self, x, out):
+        return torch.clamp_min(x, 0.0, out=out) if self.act == 0 else torch.tanh(x, out=out)
 
-    def _readopt(self):
-        """`opt.load_state_dict` (resume) or a foreign `p.data = ...` replaces tensors that were views of the flat buffers:
-        copy their contents in and point them back at the buffers (addresses are baked into the graph)."""
-        for q in self.plist:
-            sl = self.views[q]
-            if q.data.data_ptr() != self.P[sl].data_ptr():
-                self.P[sl].copy_(q.data.reshape(-1))
-                q.data = self.P[sl].view(q.shape)
-            st = self.opt.state.get(q)
-            if st is None or "exp_avg" not in st:
-                self.M[sl].zero_(); self.V[sl].zero_()
-                self.opt.state[q] = {"step": torch.zeros((), dtype=torch.float32, device=self.dev),
-                                     "exp_avg": self.M[sl].view(q.shape), "exp_avg_sq": self.V[sl].view(q.shape)}
-                continue
-            if st["exp_avg"].data_ptr() != self.M[sl].data_ptr():
-                self.M[sl].copy_(st["exp_avg"].reshape(-1))
-                self.V[sl].copy_(st["exp_avg_sq"].reshape(-1))
-                st["exp_avg"], st["exp_avg_sq"] = self.M[sl].view(q.shape), self.V[sl].view(q.shape)
-            if not torch.is_tensor(st["step"]) or st["step"].device != self.P.device:
-                st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=self.dev).reshape(())
+    def _lin(self, x, l, out, act):
+        """out = [act](x W_l^T + b_l)"""
+        if act and self.act == 0:
+            return torch._addmm_activation(self.b[l], x, self.W[l].t(), use_gelu=False, out=out)
+        torch.addmm(self.b[l], x, self.W[l].t(), out=out)
+        return out.tanh_() if act else out
 
-    def run_steps(self, n: int):
-        """the next n minibatch steps of the bound update"""
-        if self.in_graph:
-            k = self.multi if self.graph_multi is not None else 0
-            while k and n >= k:
-                self.graph_multi.replay()
-                n -= k
-            for _ in range(n):
-                self.graph.replay()
+    def _colsum(self, l, gate):
+        """dz_l *= act'(gate) in place (gate = the activation's OUTPUT; self.unit_gate: no activation) + its column sums per
+        16-row tile = the partials of db_l"""
+        dz = self.dz[l]
+        self.capi.check(self.lib.brl_act_bwd_colsum(self._di(), dz.data_ptr(), gate.data_ptr(), self.mbs, self.H, dz.stride(0), self.act,
+                                                    self.tiles[l].data_ptr(), torch.cuda.current_stream().cuda_stream))
+
+    def _dx(self, l, gate, out, bias_of=None):
+        """out = (dz_l W_l) * act'(gate); bias_of = k: `out` IS dz_k and the launch leaves db_k's partials (brl_mlp_gemm, GATE_COLSUM)"""
+        dz, W = self.dz[l], self.W[l]
+        if self.own_gemm:
+            cs = self.tiles[bias_of] if bias_of is not None else None
+            self.capi.check(self.lib.brl_mlp_gemm(self._di(), 1, 2, dz.data_ptr(), dz.stride(0), W.data_ptr(), W.stride(0), out.data_ptr(),
+                                                  out.stride(0), self.mbs, W.shape[1], W.shape[0], self.act, None, gate.data_ptr(),
+                                                  gate.stride(0), cs.data_ptr() if cs is not None else None, None,
+                                                  torch.cuda.current_stream().cuda_stream))
             return
-        for _ in range(n):          # a backend that cannot be captured: graphs of kernel groups, eager blocking collectives between
-            for item in self.segs:
-                if item[0] == "g":
-                    item[1].replay()
-                else:
-                    w = item[2](False)
-                    if w is not None:
-                        w.wait()
+        torch.mm(dz, W, out=out)
+        if bias_of is not None:
+            self._colsum(bias_of, gate)        # (out is self.dz[bias_of])
+        elif self.act == 0:
+            torch.mul(out, (gate > 0), out=out)
+        else:
+            torch.addcmul(out, out * gate, gate, value=-1.0, out=out)
 
-    def gather_optimizer_state(self):
-        """"sharded": Adam's moments are current on this rank's slices only — before the optimizer state is SAVED, every rank
-        calls this (a collective: two all-gathers per bucket) and ends with the complete moments, as in the replicated forms."""
-        if self.allreduce_mode != "sharded":
-            return
-        r = self.rank
-        for t in (self.M, self.V):
-            for o, ln in zip(self.bucket_off, self.bucket_len):
-                w = self.coll.all_gather(t[o:o + self.world * ln], t[o + r * ln:o + (r + 1) * ln], False)
-                if w is not None:
-                    w.wait()
+    def _grads(self):
+        """forward, `_loss_fn`, the step's statistics sums, backward: every gradient into the flat buffer"""
+        t, cfg, B, dz = self.t, self.cfg, self.mbs, self.dz
+        a = self._a
+        x0 = self.x0
+        # ---- forward (src/models.py:34-69)
+        self._lin(x0, 0, t["z0"], False)                       # shortcut_1 = the PRE-activation
+        a(t["z0"], t["h0"])
+        self._lin(t["h0"], 1, t["h1"], True)
+        self._lin(t["h1"], 2, t["h2"], True)
+        torch.add(t["h2"], t["z0"], out=t["x1"])               # shortcut_2
+        a(t["x1"], t["g1"])
+        self._lin(t["g1"], 3, t["h3"], True)
+        self._lin(t["h3"], 4, t["h4"], True)
+        torch.add(t["h4"], t["x1"], out=t["x2"])
+        self._lin(t["x2"], 5, t["z5"], False)                  # (into the left block of cat6)
+        self.cat6[:, self.H:].copy_(x0)                        # jnp.concatenate([x, input])
+        self._lin(self.cat6, 6, t["z6"], False)                # shortcut_3
+        a(t["z6"], t["h6"])
+        self._lin(t["h6"], 7, t["h7"], True)
+        self._lin(t["h7"], 8, t["h8"], True)
+        torch.add(t["h8"], t["z6"], out=t["x3"])               # shortcut_4
+        a(t["x3"], t["g3"])
+        self._lin(t["g3"], 9, t["h9"], True)
+        self._lin(t["h9"], 10, t["h10"], True)
+        torch.add(t["h10"], t["x3"], out=t["x4"])
+        torch.addmm(self.ba, t["x4"], self.Wa.t(), out=self.logits)
+        torch.addmv(self.bc, t["x4"], self.wc[0], out=self.value)
+        # ---- `_loss_fn` and its gradient w.r.t. (logits, value): one launch; this step's sums for the log (row *mb_index)
+        adv = self.adv
+        if cfg.get("reward_scaling", False):                   # src/update.py:31-44 (jnp std: ddof = 0)
+            adv = (adv - adv.mean()) / (adv.std(unbiased=False) + 1e-8)
+        s = torch.cuda.current_stream().cuda_stream
+        chk, L, di = self.capi.check, self.lib, self._di()
+        chk(L.brl_ppo_loss(di, self.logits.data_ptr(), 38, self.value.data_ptr(), self.mask.data_ptr(), self.action.data_ptr(),
+                           self.old_v.data_ptr(), self.old_lp.data_ptr(), adv.data_ptr(), self.tgt.data_ptr(), B, float(cfg["clip_eps"]),
+                           float(cfg["vf_coef"]), float(cfg["ent_coef"]), int(bool(cfg.get("actor_illegal_action_mask", True))),
+                           int(bool(cfg.get("value_clipping", True))), self.dlogits.data_ptr(), self.dvalue.data_ptr(),
+                           self.partials.data_ptr(), self.illp.data_ptr(), s))
+        row = self.mb_index.to(torch.int64)
+        self.stat_sums.index_copy_(0, row, torch.mm(self.ones_row[:, :self.lgroups], self.partials))
+        self.gram_sums.index_copy_(0, row, torch.mm(self.illp.t(), self.illp).view(1, -1))
+        # ---- backward of the heads
+        dx = t["dx"]
+        torch.mm(self.dlogits, self.Wa, out=dx)
+        dx.addr_(self.dvalue, self.wc[0])
+        torch.mm(self.dlogits.t(), t["x4"], out=self.GWa)
+        torch.mm(self.dvalue[None, :], t["x4"], out=self.Gwc)
+        torch.mm(self.ones_row, self.dlogits, out=self.Gba.view(1, -1))
+        torch.sum(self.dvalue, 0, keepdim=True, out=self.Gbc)
+        # ---- a residual block  x_out = act(L_b(act(L_a(g)))) + x_in  with g = act(x_in) (or act of a pre-activation):
+        # dx (the gradient w.r.t. x_out) -> dz_b, dz_a (kept: the batched weight-gradient product reads them) and dx += (dz_a W_a) act'(g)
 
-    def end_update(self):
-        """-> the [steps, 8] log of the update (total, value_loss, loss_actor, entropy, approx_kl, clipfrac, illegal-action
-        norm / 2, 0): ONE launch over the sums the steps left behind"""
-        with torch.no_grad():  # every parameter's step counter (torch keeps one per parameter)
-            for q in self.plist:
-                self.opt.state[q]["step"].copy_(self.step)
-            self.capi.check(self.lib.brl_ppo_stats_rows(self._di(), self.stat_sums.data_ptr(), self.gram_sums.data_ptr(), self._steps,
-                                                        self.mbs, float(self.cfg["vf_coef"]), float(self.cfg["ent_coef"]),
-                                                        self.ill_coef, self.log.data_ptr(),
-                                                        torch.cuda.current_stream().cuda_stream))
-            self._bind_gather(*self._dummy, first=False)   # (the trajectory may be freed by the caller now)
-        self._keep = None
-        return self.log[:self._steps]
+        def block(lb, la, hb, ha, g):
+            dz[lb].copy_(dx)
+            self._colsum(lb, hb)                                    # dz_b = dx * act'(h_b), db_b partials
+            self._dx(lb, ha, dz[la], bias_of=la)                    # dz_a = (dz_b W_b) act'(h_a), db_a partials
+            self._dx(la, g, t["dc"])
+            dx.add_(t["dc"])
+
+        block(10, 9, t["h10"], t["h9"], t["g3"])                    # x4 = h10 + x3, g3 = act(x3): dx is now d/dx3
+        block(8, 7, t["h8"], t["h7"], t["h6"])                      # x3 = h8 + z6, h6 = act(z6): dx is now d/dz6
+        dz[6].copy_(dx)
+        self._colsum(6, self.unit_gate)                             # db_6 partials
+        torch.mm(dz[6], self.W6a, out=dz[5])                        # d/dz5 (L5 has no activation; the obs block needs no gradient)
+        self._colsum(5, self.unit_gate)
+        torch.mm(dz[5], self.W[5], out=dx)                          # d/dx2
+        block(4, 3, t["h4"], t["h3"], t["g1"])                      # x2 = h4 + x1, g1 = act(x1): d/dx1
+        block(2, 1, t["h2"], t["h1"], t["h0"])                      # x1 = h2 + z0, h0 = act(z0): d/dz0
+        dz[0].copy_(dx)
+        self._colsum(0, self.unit_gate)
+        # ---- weight gradients: the nine square layers as ONE batched product, W_6 on [z5 | obs], W_0 on obs; every bias gradient
+        torch.bmm(self.dzs.transpose(1, 2), self.inp, out=self.GW_square)
+        torch.mm(dz[6].t(), self.cat6, out=self.GW6)
+        torch.mm(dz[0].t(), x0, out=self.GW[0])
+        chk(L.brl_bias_finalize_ex(di, 11, self._seg_scratch, self._seg_cols, self._seg_tiles, self._seg_db, s))

@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 from ._capture import quiet_gc
-from .fused_update import FusedMinibatch   # noqa: F401  (the default path of update_step; re-exported)
+from .fused_update import FusedFair, FusedMinibatch, FusedStep   # noqa: F401  (the default paths of update_step; re-exported)
 from .roll_out import Transition
 
 _NEG = torch.finfo(torch.float32).min
@@ -255,26 +255,19 @@ def make_update_step(config, actor_forward_pass, optimizer=None):
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         graphed = None
         fused = None
-        want_fused = adv_f.is_cuda and FusedMinibatch.supports(config, params)
+        fused_cls = next((c for c in (FusedMinibatch, FusedFair) if adv_f.is_cuda and c.supports(config, params)), None)
+        want_fused = fused_cls is not None
         need_log = int(config["update_epochs"]) * num_mb
-        if (adv_f.is_cuda and not want_fused and config.get("fused_update", True) and not opt_state.get("warned_unfused")
-                and not str(getattr(params, "model", "")).startswith("DeepMind")):
-            # a supported configuration on the slower path because of the network type: say so once (src/models.py:34-69)
-            import warnings
-            opt_state["warned_unfused"] = True
-            warnings.warn(f"brl_amd.update: FusedMinibatch covers the DeepMind MLPs only; model_type "
-                          f"{getattr(params, 'model', type(params).__name__)!r} takes the hipGraph-captured autograd step "
-                          f"(GraphedMinibatch: ~1.6x slower per minibatch at minibatch 1024).", RuntimeWarning)
         if config.get("graph_update", True) and adv_f.is_cuda and (want_fused or (sched is None and not multi)):
             graphed = opt_state.get("graphed")
             world = dist.get_world_size() if multi else 1
             # (False = an earlier capture failed, on this or — under a process group — any rank: stay eager, do not retry)
             if graphed is None or (graphed is not False and (
-                    graphed.params is not params or graphed.mbs != mbs or isinstance(graphed, FusedMinibatch) != want_fused
+                    graphed.params is not params or graphed.mbs != mbs or isinstance(graphed, FusedStep) != want_fused
                     or getattr(graphed, "world", 1) != world
-                    or (isinstance(graphed, FusedMinibatch) and graphed._log_cap < need_log))):   # e.g. minibatch 512: 5120 steps
+                    or (isinstance(graphed, FusedStep) and graphed._log_cap < need_log))):   # e.g. minibatch 512: 5120 steps
                 try:
-                    graphed = FusedMinibatch(config, params, opt, mbs, adv_f.device, world, log_capacity=need_log) if want_fused \
+                    graphed = fused_cls(config, params, opt, mbs, adv_f.device, world, log_capacity=need_log) if want_fused \
                         else GraphedMinibatch(config, actor_forward_pass, params, opt, mbs, adv_f.device)
                 except Exception as e:  # capture is an optimisation, never a requirement — but never a SILENT ~1.7x cliff
                     graphed = False
@@ -286,15 +279,15 @@ def make_update_step(config, actor_forward_pass, optimizer=None):
                     # every rank must issue the SAME collective sequence: a rank whose capture failed would run the eager path's
                     # one all-reduce per minibatch while the others run FusedMinibatch's collectives, and RCCL would hang
                     # until its timeout.  Agree (MIN over ranks): all fused, or all eager.
-                    ok = torch.tensor([1 if isinstance(graphed, FusedMinibatch) else 0], dtype=torch.int32, device=adv_f.device)
+                    ok = torch.tensor([1 if isinstance(graphed, FusedStep) else 0], dtype=torch.int32, device=adv_f.device)
                     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                    if int(ok.item()) == 0 and isinstance(graphed, FusedMinibatch):
+                    if int(ok.item()) == 0 and isinstance(graphed, FusedStep):
                         opt_state["graph_error"] = "another rank failed to capture the minibatch step: all ranks run eager"
                         import warnings
                         warnings.warn("brl_amd.update: " + opt_state["graph_error"], RuntimeWarning)
                         graphed = False
                 opt_state["graphed"] = graphed
-            if isinstance(graphed, FusedMinibatch):
+            if isinstance(graphed, FusedStep):
                 fused = graphed
         if fused is not None:
             # minibatches are gathered straight from the un-shuffled buffer by index: no per-epoch take(), no copies

@@ -1,5 +1,5 @@
 """One PPO minibatch step as the GPU ran it: kernel start / duration / gap after the previous kernel, from a rocprofv3 kernel trace.
-usage: python scripts/update_timeline.py <kernel_trace.csv> [step index]"""
+usage: python scripts/update_timeline.py <kernel_trace.csv> [step index] [name of the step's last kernel: k_adam_apply | k_shard_apply]"""
 import csv
 import re
 import sys
@@ -7,8 +7,9 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a step ends with k_adam_apply (whose extra workgroups gather the next minibatch): from the kernel behind one to the kernel behind the next
-idx = [i for i, r in enumerate(rows) if "k_adam_apply" in r["Kernel_Name"]]
-k = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
+last = sys.argv[3] if len(sys.argv) > 3 else "k_adam_apply"
+idx = [i for i, r in enumerate(rows) if last in r["Kernel_Name"]]
+k = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) >= 0 else len(idx) // 2
 a, b = idx[k] + 1, idx[k + 1] + 1
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = None

@@ -1,6 +1,7 @@
 """float64 numpy restatement of ONE PPO minibatch step of the reference (src/update.py:86-178 + the optax chain of
-ppo.py:195-211) for the "DeepMind" ReLU MLP (src/models.py:23-33): forward, `_loss_fn`, hand-derived backward,
-clip_by_global_norm, Adam(eps=1e-5).  TEST INFRASTRUCTURE — the checker for brl_amd/update.py on CPU and GPU."""
+ppo.py:195-211) for the "DeepMind" ReLU MLP (src/models.py:23-33) and the "FAIR" residual net (src/models.py:34-69): forward,
+`_loss_fn`, hand-derived backward, clip_by_global_norm, Adam(eps=1e-5).  TEST INFRASTRUCTURE — the checker for brl_amd/update.py
+and brl_amd/fused_update.py on CPU and GPU."""
 import numpy as np
 
 
@@ -134,3 +135,76 @@ def adam_first_step(cfg, params, grads):
             new.append(x - cfg["lr"] * m_hat / (np.sqrt(v_hat) + 1e-5))
         out.append(tuple(new))
     return out, gn
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the FAIR network (src/models.py:34-69), written as the reference writes it: x = L(x); shortcut = x; x = act(x); ...
+# ---------------------------------------------------------------------------------------------------------------
+def fair_params_of(net):
+    lins = list(net.l) + [net.actor, net.critic]
+    return [(l.weight.detach().cpu().double().numpy().copy(), l.bias.detach().cpu().double().numpy().copy()) for l in lins]
+
+
+def fair_loss_and_grads(cfg, params, obs, mask, action, old_value, old_log_prob, gae, tgt, activation="relu"):
+    """-> (total, aux, grads like params): the loss of `head_loss` on the FAIR forward pass and its gradient by reverse-mode
+    differentiation of the reference's own statement order (a tape of (kind, ...) entries; no shared code with the build)."""
+    act = (lambda z: np.maximum(z, 0.0)) if activation == "relu" else np.tanh
+    dact = (lambda out: (out > 0).astype(np.float64)) if activation == "relu" else (lambda out: 1.0 - out * out)
+    x = obs.astype(np.float64)
+    inp = x
+    tape = []
+
+    def lin(k, v):
+        tape.append(("lin", k, v))
+        return v @ params[k][0].T + params[k][1]
+
+    def activate(v):
+        out = act(v)
+        tape.append(("act", out))
+        return out
+
+    x = lin(0, x); s1 = x
+    x = activate(x); x = lin(1, x); x = activate(x); x = lin(2, x); x = activate(x)
+    x = x + s1; tape.append(("add", "s1")); s2 = x
+    x = activate(x); x = lin(3, x); x = activate(x); x = lin(4, x); x = activate(x)
+    x = x + s2; tape.append(("add", "s2"))
+    x = lin(5, x)
+    x = np.concatenate([x, inp], axis=-1); tape.append(("cat", 200))
+    x = lin(6, x); s3 = x
+    x = activate(x); x = lin(7, x); x = activate(x); x = lin(8, x); x = activate(x)
+    x = x + s3; tape.append(("add", "s3")); s4 = x
+    x = activate(x); x = lin(9, x); x = activate(x); x = lin(10, x); x = activate(x)
+    x = x + s4; tape.append(("add", "s4"))
+    logits = x @ params[11][0].T + params[11][1]
+    value = (x @ params[12][0].T + params[12][1])[:, 0]
+    total, aux, dlogits, dv = head_loss(cfg, logits, value, mask, action, old_value, old_log_prob, gae, tgt)
+    grads = [None] * len(params)
+    grads[11] = (dlogits.T @ x, dlogits.sum(0))
+    grads[12] = (dv[None, :] @ x, np.array([dv.sum()]))
+    d = dlogits @ params[11][0] + dv[:, None] * params[12][0]
+    # the shortcuts were taken right AFTER the linear layers 0 and 6 (s1, s3) and after the first / third block's sum (s2, s4):
+    # a pending shortcut gradient is added where its value was defined
+    pending = {}
+    defined_after = {"s4": ("add", "s3"), "s2": ("add", "s1")}     # s4 = the value after `add s3`, s2 = the value after `add s1`
+    for entry in reversed(tape):
+        if entry[0] == "add":
+            name = entry[1]
+            pending[name] = d.copy()                                 # x = x + s: the gradient flows to both
+            for later, where in defined_after.items():
+                if where == entry and later in pending:              # this sum's OUTPUT was also taken as shortcut `later`
+                    d = d + pending.pop(later)
+                    pending[name] = d.copy()
+        elif entry[0] == "act":
+            d = d * dact(entry[1])
+        elif entry[0] == "cat":
+            d = d[:, :entry[1]]
+        else:
+            _, k, v = entry
+            if k == 6 and "s3" in pending:
+                d = d + pending.pop("s3")
+            if k == 0 and "s1" in pending:
+                d = d + pending.pop("s1")
+            grads[k] = (d.T @ v, d.sum(0))
+            d = d @ params[k][0]
+    assert not pending
+    return total, aux, grads

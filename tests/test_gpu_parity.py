@@ -1602,7 +1602,7 @@ def test_ppo_iteration_at_config3_size(tmp_path, infer):
     assert 0.0 < h["train/policy_entropy"] < np.log(38) and 0.0 <= h["train/clipflacs"] <= 1.0
     assert "hash_table_next" in h                                                      # ~96 k boards > hash_size: table rotated (G14)
     fresh = __import__("brl_amd.models", fromlist=["make_forward_pass"]).make_forward_pass("relu", "DeepMind").init(0, device="cuda")
-    moved = max(float((a - b).abs().max()) for a, b in zip(rs[0].parameters(), fresh.parameters()))
+    moved = max(float((a.detach() - b.detach()).abs().max()) for a, b in zip(rs[0].parameters(), fresh.parameters()))
     assert 0.0 < moved <= 2560 * 1e-5 * 1.01                                            # 2560 Adam steps of at most lr = 1e-5 each
     assert ckpt.list_checkpoints(os.path.join(str(tmp_path), "c3", "rl_params")) == ["params-00000001.pt"]
 
@@ -1903,12 +1903,12 @@ def test_graphed_update_built_after_eager_steps_keeps_adam_state(fused):
         assert torch.allclose(outs[0], outs[1], atol=1e-5, rtol=1e-4)
 
 
-def _fused_rank(rank, world, port, out_dir, backend="gloo", mode="sharded", in_graph=None):
+def _fused_rank(rank, world, port, out_dir, backend="gloo", mode="sharded", in_graph=None, model="DeepMind"):
     import sys
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from brl_amd.models import make_forward_pass
-    from brl_amd.update import FusedMinibatch, make_update_step
+    from brl_amd.update import FusedStep, make_update_step
     from tests.test_update_cpu import CFG, fake_batch
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -1917,17 +1917,18 @@ def _fused_rank(rank, world, port, out_dir, backend="gloo", mode="sharded", in_g
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU of the box
-    fp = make_forward_pass("relu", "DeepMind")
+    fp = make_forward_pass("relu", model)
     net = fp.init(11, device="cuda")
     tb, adv, tgt = fake_batch(4, 256, seed=3)                       # the SAME shard on both ranks: mean gradient == own gradient
     tb = type(tb)(*[x.cuda() for x in tb])
     cfg = dict(CFG, minibatch_size=256, update_epochs=2, grad_allreduce=mode, force_collectives=True, collective_in_graph=in_graph)
     rs, (total, _) = make_update_step(cfg, fp)((net, None, None, None, 0, 5), tb, adv.cuda(), tgt.cuda())
     fm = rs[1].get("graphed")
-    assert isinstance(fm, FusedMinibatch) and fm.world == world, rs[1].get("graph_error")
+    assert isinstance(fm, FusedStep) and fm.world == world, rs[1].get("graph_error")
     assert fm.allreduce_mode == mode and fm.in_graph == (backend == "nccl" if in_graph is None else in_graph)
-    if not fm.in_graph:   # graphs of kernel groups between eager collectives: flat 1, sharded (hidden layers + 1) + 1 + (hidden layers + 1)
-        assert len([x for x in fm.segs if x[0] == "c"]) == (1 if mode == "flat" else 2 * len(net.body) + 1)
+    if not fm.in_graph:   # graphs of kernel groups between eager collectives: flat 1, sharded (buckets) + 1 + (buckets)
+        nb = len(net.body) if model == "DeepMind" else 1
+        assert len([x for x in fm.segs if x[0] == "c"]) == (1 if mode == "flat" else 2 * nb + 1)
     fm.gather_optimizer_state()     # (sharded: the moments of the other ranks' slices)
     flat = lambda ts: torch.cat([t.detach().reshape(-1) for t in ts]).cpu()   # noqa: E731
     st = rs[1]["opt"].state
@@ -1937,11 +1938,11 @@ def _fused_rank(rank, world, port, out_dir, backend="gloo", mode="sharded", in_g
     dist.destroy_process_group()
 
 
-def _single_process_reference():
+def _single_process_reference(model="DeepMind"):
     from brl_amd.models import make_forward_pass
     from brl_amd.update import make_update_step
     from tests.test_update_cpu import CFG, fake_batch
-    fp = make_forward_pass("relu", "DeepMind")
+    fp = make_forward_pass("relu", model)
     net = fp.init(11, device="cuda")
     tb, adv, tgt = fake_batch(4, 256, seed=3)
     tb = type(tb)(*[x.cuda() for x in tb])
@@ -1951,7 +1952,7 @@ def _single_process_reference():
     return flat(net.parameters()), total.cpu(), flat([st[q]["exp_avg"] for q in net.parameters()])
 
 
-def _check_two_rank_step(tmp_path, backend, world=2, in_graph=None):
+def _check_two_rank_step(tmp_path, backend, world=2, in_graph=None, model="DeepMind"):
     """both forms of the multi-rank step: every rank ends with the same parameters, "sharded" == "flat" BIT FOR BIT (parameters
     and — after gather_optimizer_state — both Adam moments), and both equal the single-process step up to the fp32 order of the
     norm's partial sums"""
@@ -1960,7 +1961,7 @@ def _check_two_rank_step(tmp_path, backend, world=2, in_graph=None):
     res = {}
     for mode in ("flat", "sharded"):
         sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-        mp.start_processes(_fused_rank, args=(world, port, str(tmp_path), backend, mode, in_graph), nprocs=world, join=True,
+        mp.start_processes(_fused_rank, args=(world, port, str(tmp_path), backend, mode, in_graph, model), nprocs=world, join=True,
                            start_method="spawn")
         res[mode] = [torch.load(tmp_path / f"{mode}{r}.pt") for r in range(world)]
         for r in range(1, world):
@@ -1968,7 +1969,7 @@ def _check_two_rank_step(tmp_path, backend, world=2, in_graph=None):
                 assert torch.equal(a, b), f"{mode}: rank {r} differs from rank 0"
     for a, b in zip(res["flat"][0], res["sharded"][0]):
         assert torch.equal(a, b)                       # parameters, losses, exp_avg, exp_avg_sq
-    single, total, m1 = _single_process_reference()
+    single, total, m1 = _single_process_reference(model)
     got = res["sharded"][0]
     assert torch.allclose(total, got[1], atol=1e-6) and torch.allclose(single, got[0], atol=1e-6, rtol=1e-5)
     assert torch.allclose(m1, got[2], atol=1e-6, rtol=1e-4)
@@ -1979,6 +1980,14 @@ def test_fused_update_with_gradient_collectives_two_ranks(tmp_path):
     clip + Adam on the rank's slices, all-gather of the parameters) and "flat" (ONE all-reduce, replicated clip + Adam): two gloo
     ranks on this box's GPU (graphs of kernel groups between eager collectives; RCCL captures them into the step's graph)."""
     _check_two_rank_step(tmp_path, "gloo")
+
+
+def test_fused_fair_update_with_gradient_collectives_two_ranks(tmp_path):
+    """FusedFair under a process group (one bucket: all-reduce + replicated sweep, or reduce-scatter + the rank's slice + all-gather):
+    two gloo ranks, both forms bit-identical and equal to the single-process step; then the same with REAL RCCL nodes inside the
+    graph at world 1."""
+    _check_two_rank_step(tmp_path, "gloo", model="FAIR")
+    _check_two_rank_step(tmp_path, "nccl", world=1, model="FAIR")
 
 
 def test_fused_update_with_gradient_collectives_two_ranks_rccl(tmp_path):
@@ -2062,6 +2071,80 @@ def test_fused_update_sharded_geometry_of_eight_ranks_on_one_gpu(tmp_path):
         opt.step()
         assert abs(a[3][it] - want_norm) < 1e-5 * want_norm
     assert torch.allclose(a[0], ref.detach(), atol=2e-6), float((a[0] - ref.detach()).abs().max())
+
+
+@pytest.mark.parametrize("activation,rscale,masked", [("relu", False, True), ("tanh", False, True), ("relu", True, True), ("relu", False, False)])
+def test_fused_fair_step_matches_numpy_restatement(activation, rscale, masked):
+    """FusedFair (src/models.py:34-69 written out: forward, `_loss_fn`, backward on flat buffers, clip + Adam) — ONE minibatch step
+    at minibatch 1024 vs the float64 numpy restatement (tests/ppo_numpy.py::fair_loss_and_grads, itself checked against autograd in
+    float64 on the CPU): every gradient before the sweep, the losses, the pre-clip norm, every parameter after the first Adam step."""
+    from brl_amd.models import make_forward_pass
+    from brl_amd.roll_out import Transition
+    from brl_amd.update import FusedFair, make_update_step
+    from tests.ppo_numpy import adam_first_step, fair_loss_and_grads, fair_params_of
+    from tests.test_update_cpu import CFG, fake_batch
+    tb, adv, tgt = fake_batch(4, 256, seed=2)
+    B = 1024
+    cfg = dict(CFG, minibatch_size=B, update_epochs=1, lr=1e-3, reward_scaling=rscale, actor_illegal_action_mask=masked)
+    fp = make_forward_pass(activation, "FAIR")
+    net = fp.init(4, device="cuda")
+    P0 = fair_params_of(net)
+    flat = Transition(*[x.reshape((B,) + x.shape[2:]) for x in tb])
+    gae64 = adv.reshape(-1).double().numpy()
+    if rscale:                                                  # src/update.py:31-44 (jnp std: ddof = 0)
+        gae64 = (gae64 - gae64.mean()) / (gae64.std() + 1e-8)
+    want_total, want_aux, G = fair_loss_and_grads(cfg, P0, flat.obs.numpy(), flat.legal_action_mask.numpy(), flat.action.numpy().astype(np.int64),
+                                                  flat.value.double().numpy(), flat.log_prob.double().numpy(), gae64,
+                                                  tgt.reshape(-1).double().numpy(), activation=activation)
+    P1, gn = adam_first_step(cfg, P0, G)
+    rs, (total, aux) = make_update_step(cfg, fp)((net, None, None, None, 0, 9), Transition(*[x.cuda() for x in tb]), adv.cuda(), tgt.cuda())
+    fm = rs[1].get("graphed")
+    assert isinstance(fm, FusedFair), rs[1].get("graph_error")
+    assert abs(float(total[0, 0]) - want_total) < 2e-5
+    for k in range(5):
+        assert abs(float(aux[k][0, 0]) - want_aux[k]) < 2e-5, k
+    assert abs(float(fm.norm[0]) - gn) < 1e-4 * gn
+    lins = list(net.l) + [net.actor, net.critic]
+    scale = max(np.abs(gw).max() for gw, _ in G)
+    for lin, (gw, gb) in zip(lins, G):     # the gradients the step left in the flat buffer (the sweep does not change them)
+        assert np.abs(lin.weight.grad.cpu().double().numpy() - gw).max() < 2e-5 * scale + 1e-9
+        assert np.abs(lin.bias.grad.cpu().double().numpy() - gb).max() < 2e-5 * scale + 1e-9
+    got = fair_params_of(net)
+    worst = max(max(np.abs(a - c).max(), np.abs(b - d).max()) for (a, b), (c, d) in zip(got, P1))
+    moved = max(np.abs(a - c).max() for (a, _), (c, _) in zip(P0, P1))
+    assert worst < 0.02 * cfg["lr"] and moved > 0.5 * cfg["lr"], (worst, moved, gn)
+
+
+@pytest.mark.parametrize("variant", ["relu", "tanh", "reward_scaling", "unmasked"])
+def test_fused_fair_update_matches_eager(variant):
+    """FusedFair vs the eager autograd path from the same start: ONE update of one epoch x 4 minibatches (the single step is checked
+    against float64 above; over more steps Adam turns the rounding differences of near-zero gradients into +- lr moves) — parameters
+    (mean 1e-5, max 2 lr: the bound of test_fused_update_variants_match_eager), the logged rows of every step, the step counters;
+    then a second update on the fused path alone: finite, counters at 8."""
+    from brl_amd.models import make_forward_pass
+    from brl_amd.update import FusedFair, make_optimizer, make_update_step
+    from tests.test_update_cpu import CFG, fake_batch
+    fp = make_forward_pass("tanh" if variant == "tanh" else "relu", "FAIR")
+    cfg0 = dict(CFG, minibatch_size=256, update_epochs=1, reward_scaling=variant == "reward_scaling",
+                actor_illegal_action_mask=variant != "unmasked")
+    tb, adv, tgt = fake_batch(4, 256, seed=40)
+    tb = type(tb)(*[x.cuda() for x in tb])
+    outs = []
+    for fused in (False, True):
+        net = fp.init(7, device="cuda")
+        cfg = dict(cfg0, graph_update=fused, fused_update=fused)
+        rs = (net, make_optimizer(cfg, net), None, None, 0, 5)
+        rs, (total, aux) = make_update_step(cfg, fp)(rs, tb, adv.cuda(), tgt.cuda())
+        if fused:
+            assert isinstance(rs[1].get("graphed"), FusedFair), rs[1].get("graph_error")
+        assert {int(st["step"]) for st in rs[1]["opt"].state.values()} == {4}
+        outs.append((torch.cat([p.detach().reshape(-1) for p in net.parameters()]), total.clone(), torch.stack(list(aux)).clone()))
+    d = (outs[0][0] - outs[1][0]).abs()
+    assert float(d.mean()) < 1e-5 and float(d.max()) < 2 * CFG["lr"], (float(d.mean()), float(d.max()))
+    assert torch.allclose(outs[0][1], outs[1][1], atol=2e-4) and torch.allclose(outs[0][2][:5], outs[1][2][:5], atol=2e-4)
+    assert torch.allclose(outs[0][2][5], outs[1][2][5], rtol=2e-3, atol=1e-6)     # the illegal-action norm (no SVD on the fused path)
+    rs, (total, _) = make_update_step(cfg, fp)(rs, tb, adv.cuda(), tgt.cuda())
+    assert bool(torch.isfinite(total).all()) and {int(st["step"]) for st in rs[1]["opt"].state.values()} == {8}
 
 
 @pytest.mark.parametrize("variant", ["DeepMind_6", "anneal_lr", "tanh", "reward_scaling", "illegal_coef"])

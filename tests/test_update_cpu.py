@@ -5,6 +5,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -201,3 +202,25 @@ def test_inference_snapshot_matches_module_cpu():
     assert torch.allclose(lg3, lg4, atol=1e-5) and torch.allclose(v3, v4, atol=1e-5)
     assert ptrs == [w.data_ptr() for w, _ in snap.body] + [snap.head_w.data_ptr()]
     assert InferenceSnapshot.make(make_forward_pass("relu", "FAIR").init(0)) is None  # not covered: callers fall back
+
+
+@pytest.mark.parametrize("activation", ["relu", "tanh"])
+def test_fair_numpy_restatement_matches_autograd_in_float64(activation):
+    """tests/ppo_numpy.py's FAIR forward / backward (the checker of brl_amd.fused_update.FusedFair) against torch autograd through
+    the module itself, both in float64: every gradient to 1e-12."""
+    from brl_amd.update import ppo_loss
+    from tests.ppo_numpy import fair_loss_and_grads, fair_params_of
+    net = make_forward_pass(activation, "FAIR").init(3).double()
+    tb, adv, tgt = fake_batch(2, 64, seed=1)
+    B = 128
+    flat = Transition(*[x.reshape((B,) + x.shape[2:]) for x in tb])
+    logits, value = net(flat.obs.double())
+    b64 = Transition(flat.done, flat.action, flat.value.double(), flat.reward, flat.log_prob.double(), flat.obs, flat.legal_action_mask)
+    total, _ = ppo_loss(dict(CFG), logits, value, b64, adv.reshape(-1).double(), tgt.reshape(-1).double())
+    total.backward()
+    wt, _, G = fair_loss_and_grads(dict(CFG), fair_params_of(net), flat.obs.numpy(), flat.legal_action_mask.numpy(),
+                                   flat.action.numpy().astype(np.int64), flat.value.double().numpy(), flat.log_prob.double().numpy(),
+                                   adv.reshape(-1).double().numpy(), tgt.reshape(-1).double().numpy(), activation=activation)
+    assert abs(float(total.detach()) - wt) < 1e-12
+    for lin, (gw, gb) in zip(list(net.l) + [net.actor, net.critic], G):
+        assert np.abs(lin.weight.grad.numpy() - gw).max() < 1e-12 and np.abs(lin.bias.grad.numpy() - gb).max() < 1e-12
