@@ -138,10 +138,14 @@ class FusedStep:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side), torch.no_grad():
-                for _ in range(3):      # (kernel groups only: the collectives of a warm-up would have to pair up across ranks)
+                for _ in range(2):      # kernel groups only (allocator, library heuristics)
                     for item in self.program:
                         if item[0] == "k":
                             item[1]()
+                # ... then the whole program once, collectives included (every rank builds its step at the same point of
+                # update_step, so they pair up): the communicator and RCCL's per-size set-up exist BEFORE a stream captures
+                self._run_program(True)
+                self._drain()
             torch.cuda.current_stream().wait_stream(side)
             from ._capture import graph_kwargs
             gkw = graph_kwargs()

@@ -45,6 +45,7 @@ DEFAULTS = dict(  # ppo.py:122-180 (PPOConfig), same names and defaults
     tunable_gemm=False,  # torch TunableOp: time every rocBLAS / hipBLASLt solution once per GEMM shape (update: -5 %)
     memoize_eval=True, memoize_eval_check_every=0,   # the per-iteration duplicate evaluations: play each distinct pair once (train())
     grad_allreduce="sharded",   # the gradient step under a process group: "sharded" | "flat" (brl_amd/fused_update.py)
+    check_rank_sync=True,       # under a process group: a parameter checksum compared across the ranks after every update
 )
 
 
@@ -351,6 +352,16 @@ def train(config, log=print, on_rollout=None):
         torch.cuda.synchronize(); t2 = time.perf_counter()
         runner_state, loss_info = update_step(runner_state, traj, adv, tgt)                           # ppo.py:473
         torch.cuda.synchronize(); t3 = time.perf_counter()
+        if world > 1 and config.get("check_rank_sync", True):
+            # every rank must hold the SAME parameters after an update (all-reduced / reduce-scattered gradients, all-gathered
+            # slices): one scalar per rank, MIN and MAX over the ranks — a desynchronised run fails here, not silently later
+            with torch.no_grad():
+                ck = torch.stack([q.detach().double().sum() for q in runner_state[0].parameters()]).sum().reshape(1)
+                lo, hi = ck.clone(), ck.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if float(lo) != float(hi):
+                raise RuntimeError(f"brl_amd.train: the ranks' parameters differ after update {i} (checksum {float(lo)!r} .. {float(hi)!r})")
         imp_after = duplicate_imp(runner_state[0], opp_params, i + 1) if do_eval else float("nan")    # ppo.py:480
         steps += config["num_envs"] * config["num_steps"] * world                                     # ppo.py:489
         total_loss, (value_loss, loss_actor, entropy, approx_kl, clipfracs, illegal_action_loss) = loss_info
