@@ -47,7 +47,7 @@ class FusedStep:
         self.world = int(world)
         multi = self.world > 1 or bool(config.get("force_collectives", False))   # (force_collectives: the multi-rank program at world 1 — tests / bench)
         self.multi = multi
-        self.allreduce_mode = str(config.get("grad_allreduce", "sharded")) if multi else "none"
+        self.allreduce_mode = str(config.get("grad_allreduce", "flat")) if multi else "none"
         if self.allreduce_mode not in ("none", "flat", "sharded"):
             raise ValueError("config['grad_allreduce'] must be 'sharded' or 'flat'")
         self.coll = collective if collective is not None else (_DistCollectives() if multi else None)
@@ -343,16 +343,18 @@ class FusedMinibatch(FusedStep):
 
     Under a process group (``world > 1``, ``config["grad_allreduce"]``) the program (see ``FusedStep``) carries collectives:
 
-      "sharded" (default)  reduce-scatter of the gradient bucket by bucket (one bucket per hidden layer, issued as soon as its
-          weight gradient exists, overlapping the rest of the backward pass; the last bucket = layer 0 + head + biases), the
-          norm's partial sums of the rank's own slices + a 4 KB all-gather, clip + Adam on the rank's 1/world slices only, then
-          the all-gather of the updated parameters bucket by bucket in forward order — the next step's layer l waits for ITS
-          bucket only.  Same ring bytes as an all-reduce; the Adam sweep shrinks by 1/world; the moments are valid on the rank's
-          slices only (``gather_optimizer_state`` completes them for a checkpoint).
-      "flat"  the same launches, ONE all-reduce of the flat gradient behind them, clip + Adam replicated on every rank.  Nothing
-          overlaps the collective: the simple form, kept as the fallback and as the check of the sharded one.
+      "flat" (default)  the single-rank launches, ONE all-reduce of the flat gradient behind them, clip + Adam replicated on every
+          rank.  Nothing overlaps the collective.
+      "sharded"  reduce-scatter of the gradient bucket by bucket (one bucket per hidden layer, issued as soon as its weight
+          gradient exists, beside the rest of the backward pass; the last bucket = layer 0 + head + biases), the norm's partial
+          sums of the rank's own slices + a 4 KB all-gather, clip + Adam on the rank's 1/world slices only, then the all-gather
+          of the updated parameters bucket by bucket in forward order — the next step's layer l waits for ITS bucket only.  Same
+          ring bytes as an all-reduce; the Adam sweep shrinks by 1/world; the moments are valid on the rank's slices only
+          (``gather_optimizer_state`` completes them for a checkpoint).  Opt-in: with collectives that hold CUs the GEMMs beside
+          them pay a second wave of workgroups, and the emulation (scripts/overlap_probe.py) puts the two forms level.
 
-    Both forms give bit-identical parameters (the norm's partials have one layout: csrc/ppo_update.hpp ShardGeom).
+    Given the same launches (config["per_layer_dw"]) both forms give bit-identical parameters (the norm's partials have one
+    layout: csrc/ppo_update.hpp ShardGeom).
 
     The module's parameters and the optimizer's moments become VIEWS of the flat buffers, so ``params``, ``state_dict``
     checkpoints and the eager path keep working on the same memory.  Mirrors torch.optim.Adam's arithmetic and
@@ -503,16 +505,20 @@ class FusedMinibatch(FusedStep):
         self._fin_opt()
 
     def _grads_chain(self):
-        """multi-rank "flat" form: everything that produces this rank's gradient, by the SAME launches as the sharded form (a weight
-        gradient per layer, not the single-rank batched product: the two forms then reduce bit-identical gradients), the sums of
-        partials as a launch of their own (they must exist before the all-reduce)"""
+        """multi-rank "flat" form: everything that produces this rank's gradient — the single-rank chain (batched weight gradients),
+        the sums of partials as a launch of their own (they must exist before the all-reduce).  config["per_layer_dw"]: the SAME
+        launches as the sharded form instead (a weight gradient per layer): the two forms then reduce bit-identical gradients —
+        what the tests compare."""
         for l in range(self.nl):
             self._forward(l)
         self._heads()
-        for l in range(self.nl - 1, 0, -1):
-            self._dw(l)
-            self._dz(l)
-        self._dw(0)
+        if self.cfg.get("per_layer_dw", False):
+            for l in range(self.nl - 1, 0, -1):
+                self._dw(l)
+                self._dz(l)
+            self._dw(0)
+        else:
+            self._backward_chain()
         self._seg_fin()
 
     def _forward(self, l):

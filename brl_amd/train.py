@@ -44,7 +44,7 @@ DEFAULTS = dict(  # ppo.py:122-180 (PPOConfig), same names and defaults
     lut_len=100_000, synthetic_lut_files=3, inference_dtype=None, graph_rollout=False, evaluate=True,
     tunable_gemm=False,  # torch TunableOp: time every rocBLAS / hipBLASLt solution once per GEMM shape (update: -5 %)
     memoize_eval=True, memoize_eval_check_every=0,   # the per-iteration duplicate evaluations: play each distinct pair once (train())
-    grad_allreduce="sharded",   # the gradient step under a process group: "sharded" | "flat" (brl_amd/fused_update.py)
+    grad_allreduce="flat",      # the gradient step under a process group: "flat" | "sharded" (brl_amd/fused_update.py)
     check_rank_sync=True,       # under a process group: a parameter checksum compared across the ranks after every update
 )
 

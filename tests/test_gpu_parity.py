@@ -1491,7 +1491,7 @@ def _train_rank(rank, world, port, out_dir, backend="gloo"):
     cfg = dict(DEFAULTS, num_envs=256, num_steps=8, total_timesteps=world * 256 * 8 * 3, minibatch_size=512, update_epochs=2,
                lut_len=2000, synthetic_lut_files=2, hash_size=100_000, num_eval_envs=128, num_prioritized_envs=64,
                num_eval_step=2, lr=1e-4, ratio_model_zoo=1.0, log_path=out_dir, exp_name="t",   # ONE pool directory: rank 0 saves
-               graph_rollout=True)
+               graph_rollout=True, grad_allreduce="sharded" if world == 4 else "flat")   # (both forms run the loop)
     def keep_first_rollout(i, runner_state, traj, roll_out):
         """iteration 0's Transition + sub-step actions + final packed state of THIS rank's shard, for the parent's oracle replay"""
         if i == 0:
@@ -1535,7 +1535,7 @@ def _replay_rank_rollout(tmp_path, rank, num_envs=256):
 
 def test_ppo_loop_two_ranks(tmp_path):
     """BASELINE config 5 at toy size: the ppo.py loop on two ranks (own env shard each via env_offset, ONE all-reduce of the flat
-    gradient between FusedMinibatch's graphs — the default "flat" form —, the pool's opponent index broadcast from rank 0; gloo on
+    gradient — the default "flat" form —, the pool's opponent index broadcast from rank 0; gloo on
     this one-GPU box, RCCL on a node): both ranks end with IDENTICAL parameters although their shards differ — and each rank's
     first rollout IS its shard: replayed through the oracle at env_offset = rank * num_envs."""
     import socket
@@ -1903,7 +1903,7 @@ def test_graphed_update_built_after_eager_steps_keeps_adam_state(fused):
         assert torch.allclose(outs[0], outs[1], atol=1e-5, rtol=1e-4)
 
 
-def _fused_rank(rank, world, port, out_dir, backend="gloo", mode="sharded", in_graph=None, model="DeepMind"):
+def _fused_rank(rank, world, port, out_dir, backend="gloo", mode="sharded", in_graph=None, model="DeepMind", per_layer=True):
     import sys
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -1921,7 +1921,8 @@ def _fused_rank(rank, world, port, out_dir, backend="gloo", mode="sharded", in_g
     net = fp.init(11, device="cuda")
     tb, adv, tgt = fake_batch(4, 256, seed=3)                       # the SAME shard on both ranks: mean gradient == own gradient
     tb = type(tb)(*[x.cuda() for x in tb])
-    cfg = dict(CFG, minibatch_size=256, update_epochs=2, grad_allreduce=mode, force_collectives=True, collective_in_graph=in_graph)
+    cfg = dict(CFG, minibatch_size=256, update_epochs=2, grad_allreduce=mode, force_collectives=True, collective_in_graph=in_graph,
+               per_layer_dw=per_layer)   # (True: flat by the sharded form's launches — the two forms must then agree bit for bit)
     rs, (total, _) = make_update_step(cfg, fp)((net, None, None, None, 0, 5), tb, adv.cuda(), tgt.cuda())
     fm = rs[1].get("graphed")
     assert isinstance(fm, FusedStep) and fm.world == world, rs[1].get("graph_error")
@@ -1933,7 +1934,7 @@ def _fused_rank(rank, world, port, out_dir, backend="gloo", mode="sharded", in_g
     flat = lambda ts: torch.cat([t.detach().reshape(-1) for t in ts]).cpu()   # noqa: E731
     st = rs[1]["opt"].state
     torch.save((flat(net.parameters()), total.cpu(), flat([st[q]["exp_avg"] for q in net.parameters()]),
-                flat([st[q]["exp_avg_sq"] for q in net.parameters()])), os.path.join(out_dir, f"{mode}{rank}.pt"))
+                flat([st[q]["exp_avg_sq"] for q in net.parameters()])), os.path.join(out_dir, f"{mode}{'' if per_layer else '_default'}{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -1973,12 +1974,20 @@ def _check_two_rank_step(tmp_path, backend, world=2, in_graph=None, model="DeepM
     got = res["sharded"][0]
     assert torch.allclose(total, got[1], atol=1e-6) and torch.allclose(single, got[0], atol=1e-6, rtol=1e-5)
     assert torch.allclose(m1, got[2], atol=1e-6, rtol=1e-4)
+    # ... and the DEFAULT flat form (the single-rank launches: batched weight gradients): the same up to fp32 summation order
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mp.start_processes(_fused_rank, args=(world, port, str(tmp_path), backend, "flat", in_graph, model, False), nprocs=world, join=True,
+                       start_method="spawn")
+    dflt = [torch.load(tmp_path / f"flat_default{r}.pt") for r in range(world)]
+    for r in range(1, world):
+        assert torch.equal(dflt[0][0], dflt[r][0])
+    assert torch.allclose(single, dflt[0][0], atol=1e-6, rtol=1e-5) and torch.allclose(total, dflt[0][1], atol=1e-6)
 
 
 def test_fused_update_with_gradient_collectives_two_ranks(tmp_path):
-    """FusedMinibatch under a process group — "sharded" (the default: reduce-scatter per layer bucket behind the backward pass,
-    clip + Adam on the rank's slices, all-gather of the parameters) and "flat" (ONE all-reduce, replicated clip + Adam): two gloo
-    ranks on this box's GPU (graphs of kernel groups between eager collectives; RCCL captures them into the step's graph)."""
+    """FusedMinibatch under a process group — "flat" (the default: ONE all-reduce, replicated clip + Adam) and "sharded"
+    (reduce-scatter per layer bucket behind the backward pass, clip + Adam on the rank's slices, all-gather of the parameters): two
+    gloo ranks on this box's GPU (graphs of kernel groups between eager collectives; RCCL captures them into the step's graph)."""
     _check_two_rank_step(tmp_path, "gloo")
 
 
