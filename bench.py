@@ -792,6 +792,9 @@ def bench_ppo(args, torch, dev, rank, world, barrier, max_over_ranks):
     # ranks sharing a device: tests/test_multi_gpu_rccl.py); the record then says so and is not a measurement of configs[3] / [4]
     n_envs = int(os.environ.get("BRL_BENCH_PPO_ENVS", NUM_ENVS))
     epochs = int(os.environ.get("BRL_BENCH_PPO_EPOCHS", 10))
+    # BRL_GRAD_ALLREDUCE=flat|sharded: the form of the multi-rank gradient step (default: brl_amd's, "flat")
+    if os.environ.get("BRL_GRAD_ALLREDUCE"):
+        DEFAULTS = dict(DEFAULTS, grad_allreduce=os.environ["BRL_GRAD_ALLREDUCE"])
     cfg = dict(DEFAULTS, num_envs=n_envs, num_steps=NUM_STEPS, minibatch_size=1024, update_epochs=epochs,
                inference_dtype=(os.environ.get("BRL_INFER_DTYPE", "fp32").replace("fp32", "") or None), graph_rollout=True)
     # (default = the reference's fp32 forwards; BRL_INFER_DTYPE=bf16 / fp16 = the opt-in, narrower inference path)

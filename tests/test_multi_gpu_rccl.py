@@ -71,14 +71,14 @@ def test_rccl_run_with_one_device_for_two_ranks_is_refused(monkeypatch):
 
 def test_bench_ppo_four_gloo_ranks_on_one_gpu():
     """configs[4]'s measurement path — `bench.py --gpus N --config ppo`: per-rank env shards (env_offset = rank * num_envs), the
-    policy rollout, calc_gae, the fused update with its gradient collective (FusedMinibatch(world = N), the default "flat" form; the
-    sharded form runs in test_ppo_loop_four_ranks), barrier + max-over-ranks, ONE JSON line — rehearsed with FOUR gloo ranks sharing this box's GPU at a
+    policy rollout, calc_gae, the fused update with its gradient collectives (FusedMinibatch(world = N), here the sharded form:
+    BRL_GRAD_ALLREDUCE; the default "flat" form runs in the two-rank loop), barrier + max-over-ranks, ONE JSON line — rehearsed with FOUR gloo ranks sharing this box's GPU at a
     reduced size (1024 tables, 2 epochs).  Four, not eight: a GPU box of this pool allows at most 6 processes on its card; the
     world = 8 geometry itself runs in one process (test_fused_update_sharded_geometry_of_eight_ranks_on_one_gpu,
     bench.py's config4_rehearsal).  Not a measurement: the record says so (`rehearsal_size`)."""
     r, out = _bench(["--gpus", "4", "--config", "ppo", "--steps", "1"], BRL_BENCH_BACKEND="gloo", BRL_BENCH_PPO_ENVS="1024",
-                    BRL_BENCH_PPO_EPOCHS="2")
+                    BRL_BENCH_PPO_EPOCHS="2", BRL_GRAD_ALLREDUCE="sharded")
     assert r.returncode == 0 and out is not None, r.stderr[-3000:]
     assert out["n_gpus"] == 4 and out["config"]["rehearsal_size"] is True and out["config"]["num_envs_per_gpu"] == 1024
-    assert out["config"]["grad_allreduce"] == "flat" and out["config"]["collectives_inside_the_graph"] is False   # gloo: eager
+    assert out["config"]["grad_allreduce"] == "sharded" and out["config"]["collectives_inside_the_graph"] is False   # gloo: eager
     assert out["value"] > 0 and all(v > 0 for v in out["phases_ms"].values())
