@@ -224,3 +224,28 @@ def test_sharded_evaluator_plays_its_global_boards(dds, oracle):
     for T_, oT in ((A, oA), (B, oB)):
         for f in ("terminated", "rewards", "last_bid", "last_bidder", "call_x", "call_xx"):
             assert np.array_equal(to_np(getattr(T_, f)).astype(np.float64), oT[f].astype(np.float64)), f
+
+
+def test_empty_batches_are_no_ops(dds, oracle):
+    """n = 0 (an evaluator shard of a rank that got no board, a filtered batch): every handle-taking entry point returns OK without
+    a launch — through the host mirror and through the raw C-ABI with NULL arrays — and leaves the handle usable."""
+    import brl_amd
+    from brl_amd import _capi
+    env = brl_amd.BridgeBidding(lut=(dds["keys"], dds["values"]))
+    st = env.init(5, num_envs=0)
+    assert st.packed.shape == (0, 16) and st.observation.shape == (0, 480) and st.legal_action_mask.shape == (0, 38)
+    st2 = env.step(st, torch.zeros(0, dtype=torch.int32), autoreset=True)
+    assert st2.packed.shape == (0, 16) and st2.rewards.shape == (0, 4)
+    L, h, s = _capi.lib(), env._h, torch.cuda.current_stream().cuda_stream
+    p = _capi.TransitionPtrs()
+    assert L.brl_init_random(h, None, 0, 0, s) == 0
+    assert L.brl_step(h, None, None, 0, None, 1, None, None, None, None, None, s) == 0
+    assert L.brl_observe(h, None, 0, None, None, None, s) == 0
+    assert L.brl_rollout_random(h, None, 0, 32, 1, 0, 7600.0, C.byref(p), None, None, None, s) == 0
+    assert L.brl_rollout_random_gae(h, None, 0, 32, 0, 7600.0, C.byref(p), None, None, None, None, 1.0, 0.95, None, None, s) == 0
+    assert L.brl_gae(h, None, None, None, None, 1.0, 0.95, 32, 0, None, None, s) == 0
+    assert L.brl_imp_reward(h, None, None, None, 0, s) == 0
+    # ... and a negative n is an argument error with a message, not a launch
+    assert L.brl_init_random(h, None, -1, 0, s) == -1 and b"n" in L.brl_last_error()
+    ref = oracle.init_random(7, seed=5)
+    assert_state_equal(env.init(5, num_envs=7), ref, where="after the empty calls")
