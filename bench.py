@@ -746,7 +746,7 @@ def rehearse_multirank(torch, dev, cfg, fp, traj, adv, tgt, single_ms):
     res = {"what": "one rank's minibatch step with world = 8 geometry on one GPU, collectives = no-ops with an asynchronous "
                    "collective's stream edges, captured inside the eight-step hipGraph; 256 steps, median of 3; ring traffic per "
                    "step and rank at world 8: 2 * 7/8 * 14.7 MB = 25.8 MB in both forms ('flat' is the default; what a collective's "
-                   "kernel costs the GEMMs beside it is measured by scripts/overlap_probe.py: profiles/r05/r05h_overlap_probe.txt)",
+                   "kernel costs the GEMMs beside it is measured by scripts/overlap_probe.py: profiles/r05/r05i_overlap_probe.txt)",
            "single_rank_ms_per_minibatch": single_ms}
     for mode in ("flat", "sharded"):
         net = fp.init(0, device=dev)
