@@ -36,7 +36,10 @@
 constexpr int FS_TPB = 32;
 constexpr int FS_NW = 13;          // logic, loader/mask, scorer A, 8 emit, scorer B, prep
 constexpr int FS_MAX_TOTAL = 40;   // sub-steps per launch
-constexpr int FS_RING = 12;
+#ifndef FS_RING_N        // (timing experiments only: fewer prefetched boards give WRONG results for tables that deal more)
+#define FS_RING_N 12
+#endif
+constexpr int FS_RING = FS_RING_N;
 constexpr int FS_CHUNK = 8;        // scorer: slots per pass
 #ifndef FS_EXP
 #define FS_EXP 0                   // timing experiments (scripts/timing_fs.py, FLAGS=-DFS_EXP=8): 8 = no observation stores
