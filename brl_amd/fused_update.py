@@ -38,8 +38,6 @@ class FusedStep:
     or, for a backend that cannot be captured (gloo), one graph per kernel group with the collectives issued eagerly between the
     replays.  Subclasses: ``FusedMinibatch`` (the DeepMind MLPs), ``FusedFair`` (the FAIR residual net)."""
 
-    rows_at_end = True      # the log rows are formed from per-step sums by ONE launch at the end of the update (brl_ppo_stats_rows)
-
     def __init__(self, config, params, opt, mbs: int, device, world: int = 1, log_capacity: int = 0, collective=None):
         from . import _capi
         self.cfg, self.params, self.opt, self.mbs, self.dev = config, params, opt, int(mbs), device
@@ -183,7 +181,6 @@ class FusedStep:
                 for t, q in zip((self.P, self.M, self.V, self.step, self.mb_index), saved):
                     t.copy_(q)
 
-
     def _capture_steps(self, k, gkw):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, **gkw), torch.no_grad():
@@ -249,7 +246,7 @@ class FusedStep:
         Binds the step's gather to them (device-resident arguments) and resets the minibatch counter."""
         steps = sum(p.numel() for p in perms) // self.mbs
         if steps > self._log_cap:   # (checked before anything is touched; update_step never gets here: it rebuilds first)
-            raise RuntimeError("FusedMinibatch: more minibatch steps per update than its log holds (log_capacity)")
+            raise RuntimeError("FusedStep: more minibatch steps per update than its log holds (log_capacity)")
         self._keep = (Transition(*[x.contiguous() for x in flat]), adv_f.contiguous(), tgt_f.contiguous())
         fl, adv_c, tgt_c = self._keep
         self._steps = steps
@@ -322,11 +319,10 @@ class FusedStep:
         with torch.no_grad():  # every parameter's step counter (torch keeps one per parameter)
             for q in self.plist:
                 self.opt.state[q]["step"].copy_(self.step)
-            if self.rows_at_end:
-                self.capi.check(self.lib.brl_ppo_stats_rows(self._di(), self.stat_sums.data_ptr(), self.gram_sums.data_ptr(), self._steps,
-                                                            self.mbs, float(self.cfg["vf_coef"]), float(self.cfg["ent_coef"]),
-                                                            self.ill_coef, self.log.data_ptr(),
-                                                            torch.cuda.current_stream().cuda_stream))
+            self.capi.check(self.lib.brl_ppo_stats_rows(self._di(), self.stat_sums.data_ptr(), self.gram_sums.data_ptr(), self._steps,
+                                                        self.mbs, float(self.cfg["vf_coef"]), float(self.cfg["ent_coef"]),
+                                                        self.ill_coef, self.log.data_ptr(),
+                                                        torch.cuda.current_stream().cuda_stream))
             self._bind_gather(*self._dummy, first=False)   # (the trajectory may be freed by the caller now)
         self._keep = None
         return self.log[:self._steps]
