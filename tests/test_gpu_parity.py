@@ -2124,7 +2124,7 @@ def test_fused_fair_step_matches_numpy_restatement(activation, rscale, masked):
     assert worst < 0.02 * cfg["lr"] and moved > 0.5 * cfg["lr"], (worst, moved, gn)
 
 
-@pytest.mark.parametrize("variant", ["relu", "tanh", "reward_scaling", "unmasked"])
+@pytest.mark.parametrize("variant", ["relu", "tanh", "reward_scaling", "unmasked", "library_gemms"])
 def test_fused_fair_update_matches_eager(variant):
     """FusedFair vs the eager autograd path from the same start: ONE update of one epoch x 4 minibatches (the single step is checked
     against float64 above; over more steps Adam turns the rounding differences of near-zero gradients into +- lr moves) — parameters
@@ -2135,7 +2135,7 @@ def test_fused_fair_update_matches_eager(variant):
     from tests.test_update_cpu import CFG, fake_batch
     fp = make_forward_pass("tanh" if variant == "tanh" else "relu", "FAIR")
     cfg0 = dict(CFG, minibatch_size=256, update_epochs=1, reward_scaling=variant == "reward_scaling",
-                actor_illegal_action_mask=variant != "unmasked")
+                actor_illegal_action_mask=variant != "unmasked", own_gemm=variant != "library_gemms")
     tb, adv, tgt = fake_batch(4, 256, seed=40)
     tb = type(tb)(*[x.cuda() for x in tb])
     outs = []
@@ -2156,7 +2156,7 @@ def test_fused_fair_update_matches_eager(variant):
     assert bool(torch.isfinite(total).all()) and {int(st["step"]) for st in rs[1]["opt"].state.values()} == {8}
 
 
-@pytest.mark.parametrize("variant", ["DeepMind_6", "anneal_lr", "tanh", "reward_scaling", "illegal_coef"])
+@pytest.mark.parametrize("variant", ["DeepMind_6", "anneal_lr", "tanh", "reward_scaling", "illegal_coef", "library_gemms", "own_gemm_fwd"])
 def test_fused_update_variants_match_eager(variant):
     """FusedMinibatch on the 6-layer MLP of wb5/models.py, under ppo.py:186-192's linear learning-rate schedule (the
     rate lives in device memory, so the captured Adam launch follows it), with the tanh activation (src/models.py:16) and
@@ -2167,7 +2167,9 @@ def test_fused_update_variants_match_eager(variant):
     fp = make_forward_pass("tanh" if variant == "tanh" else "relu", "DeepMind_6" if variant == "DeepMind_6" else "DeepMind")
     cfg0 = dict(CFG, minibatch_size=256, update_epochs=1, num_minibatches=4, num_updates=4, anneal_lr=variant == "anneal_lr",
                 reward_scaling=variant == "reward_scaling",
-                illegal_action_l2norm_coef=0.5 if variant == "illegal_coef" else 0.0)   # src/update.py:146-152
+                illegal_action_l2norm_coef=0.5 if variant == "illegal_coef" else 0.0,   # src/update.py:146-152
+                # the step's switches: every product with the library + brl_act_bwd_colsum[_heads_dw] / the forward layers on brl_mlp_gemm too
+                own_gemm=variant != "library_gemms", own_gemm_fwd=variant == "own_gemm_fwd")
     outs = []
     for fused in (False, True):
         net = fp.init(7, device="cuda")
