@@ -145,6 +145,15 @@ class FusedStep:
                 self._run_program(True)
                 self._drain()
             torch.cuda.current_stream().wait_stream(side)
+            if multi and self.in_graph and isinstance(self.coll, _DistCollectives):
+                # RCCL's stream becomes part of the capture.  ProcessGroupNCCL's watchdog thread polls the end events of EAGER
+                # collectives it has not yet seen complete (every 100 ms), and HIP refuses a query of an event whose stream is
+                # capturing ("operation not permitted on an event last recorded in a capturing stream": the watchdog throws, the
+                # process aborts — scripts/rccl_eager_then_capture_probe.py, profiles/r05/).  So: everything issued so far has
+                # finished, and the watchdog has had three periods to retire it, before a stream captures.
+                import time
+                torch.cuda.synchronize()
+                time.sleep(0.3)
             from ._capture import graph_kwargs
             gkw = graph_kwargs()
             with quiet_gc():   # (_capture.py: no collector run while a stream captures)
