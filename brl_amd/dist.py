@@ -7,6 +7,14 @@ from __future__ import annotations
 import os
 
 
+def distributed() -> bool:
+    """A process group exists AND its collectives are to be issued: world_size > 1 — or BRL_FORCE_DIST=1, the world-1 REHEARSAL of
+    the multi-rank control flow (every collective of the loop really goes through RCCL with one peer: scripts/soak_train_rccl_world1.py;
+    how the eager-collective-before-capture abort was found, profiles/r05/r05_experiments.txt section 10)."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("BRL_FORCE_DIST") == "1")
+
+
 def rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
@@ -43,7 +51,7 @@ def broadcast_int(value: int, device=None, src: int = 0) -> int:
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not distributed():
         return int(value)
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)
     dist.broadcast(t, src=src)
@@ -56,7 +64,7 @@ def broadcast_parameters(module, src: int = 0) -> None:
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not distributed():
         return
     with torch.no_grad():
         for p in module.parameters():

@@ -40,6 +40,7 @@ class _Shard:
 
     def __init__(self, n_global: int, shard):
         import torch.distributed as dist
+        self.forced = shard is True    # (shard=True at world 1 under BRL_FORCE_DIST=1: one shard, the sums still all-reduced)
         if shard is True:
             shard = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else None
         self.rank, self.world = (0, 1) if not shard else (int(shard[0]), int(shard[1]))
@@ -50,7 +51,8 @@ class _Shard:
 
     @property
     def active(self) -> bool:
-        return self.world > 1
+        from .dist import distributed
+        return self.world > 1 or (self.forced and distributed())
 
     def init(self, env: BridgeBidding, rng_key) -> State:
         if self.active:

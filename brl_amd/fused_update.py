@@ -43,7 +43,9 @@ class FusedStep:
         self.cfg, self.params, self.opt, self.mbs, self.dev = config, params, opt, int(mbs), device
         self.lib, self.capi = _capi.lib(), _capi
         self.world = int(world)
-        multi = self.world > 1 or bool(config.get("force_collectives", False))   # (force_collectives: the multi-rank program at world 1 — tests / bench)
+        # force_collectives / BRL_FORCE_DIST=1 under a process group: the multi-rank program at world 1 (tests, bench, rehearsals)
+        from .dist import distributed
+        multi = self.world > 1 or bool(config.get("force_collectives", False)) or (collective is None and distributed())
         self.multi = multi
         self.allreduce_mode = str(config.get("grad_allreduce", "flat")) if multi else "none"
         if self.allreduce_mode not in ("none", "flat", "sharded"):

@@ -159,7 +159,7 @@ def train(config, log=print, on_rollout=None):
     import brl_amd
     from brl_amd import checkpoint as ckpt
     from brl_amd.bridge_bidding import load_dds_table
-    from brl_amd.dist import broadcast_int, broadcast_parameters, rank_world, shard_offset, sum_over_ranks
+    from brl_amd.dist import broadcast_int, broadcast_parameters, distributed, rank_world, shard_offset, sum_over_ranks
     from brl_amd.evaluation import (make_evaluate, make_evaluate_log, make_simple_duplicate_evaluate,
                                     make_simple_evaluate)
     from brl_amd.models import make_forward_pass
@@ -170,7 +170,7 @@ def train(config, log=print, on_rollout=None):
         torch.cuda.tunable.set_max_tuning_duration(30)
 
     rank, world = rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("BRL_FORCE_DIST") == "1") and not dist.is_initialized():
         # BRL_DIST_BACKEND=gloo: rehearsal on a box with fewer GPUs than ranks (ranks share the devices round-robin)
         backend = os.environ.get("BRL_DIST_BACKEND", "nccl")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
@@ -206,7 +206,7 @@ def train(config, log=print, on_rollout=None):
     # boards a single process would deal) and the sums are all-reduced, so every rank holds the same statistics and the pool
     # decisions agree (ppo.py:366-381,461-484 runs 3-4 evaluations of 10 000 boards per iteration)
     eval_env = brl_amd.BridgeBidding(lut=eval_lut, device=dev)
-    sharded = world > 1
+    sharded = distributed()
 
     actor_fp = make_forward_pass(config["actor_activation"], config["actor_model_type"])
     opp_fp = make_forward_pass(config["opp_activation"], config["opp_model_type"])
@@ -304,7 +304,7 @@ def train(config, log=print, on_rollout=None):
         params = runner_state[0]
         if i != 0 and i % config["save_model_interval"] == 0 and config["save_model"] and rank == 0:  # ppo.py:351-362
             ckpt.save_params(params, os.path.join(pool_dir, f"params-{i:08}.pt"))
-        if world > 1:
+        if sharded:
             dist.barrier()  # the pool listing below must see rank 0's file
         rec = {}
         t_eval = time.perf_counter()
@@ -352,7 +352,7 @@ def train(config, log=print, on_rollout=None):
         torch.cuda.synchronize(); t2 = time.perf_counter()
         runner_state, loss_info = update_step(runner_state, traj, adv, tgt)                           # ppo.py:473
         torch.cuda.synchronize(); t3 = time.perf_counter()
-        if world > 1 and config.get("check_rank_sync", True):
+        if sharded and config.get("check_rank_sync", True):
             # every rank must hold the SAME parameters after an update (all-reduced / reduce-scattered gradients, all-gathered
             # slices): one scalar per rank, MIN and MAX over the ranks — a desynchronised run fails here, not silently later
             with torch.no_grad():

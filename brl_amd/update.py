@@ -154,7 +154,8 @@ def loss_and_backward(config, logits, value, batch, gae, targets):
 
 def allreduce_gradients(params: torch.nn.Module):
     """One flat all-reduce (mean) of every gradient — 14.7 MB for the DeepMind MLP."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    from .dist import distributed
+    if not distributed():
         return
     grads = [p.grad for p in params.parameters() if p.grad is not None]
     flat = torch._utils._flatten_dense_tensors(grads)
@@ -252,7 +253,8 @@ def make_update_step(config, actor_forward_pass, optimizer=None):
         gen = torch.Generator(device=adv_f.device)
         gen.manual_seed(int(rng) & 0xFFFFFFFF)   # (the same mod-2^32 convention as the action-draw counter)
         totals, auxes = [], []
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        from .dist import distributed
+        multi = distributed()      # (under BRL_FORCE_DIST=1 also at world 1: FusedStep then runs the multi-rank program with one peer)
         graphed = None
         fused = None
         fused_cls = next((c for c in (FusedMinibatch, FusedFair) if adv_f.is_cuda and c.supports(config, params)), None)

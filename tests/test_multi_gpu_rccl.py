@@ -82,3 +82,19 @@ def test_bench_ppo_four_gloo_ranks_on_one_gpu():
     assert out["n_gpus"] == 4 and out["config"]["rehearsal_size"] is True and out["config"]["num_envs_per_gpu"] == 1024
     assert out["config"]["grad_allreduce"] == "sharded" and out["config"]["collectives_inside_the_graph"] is False   # gloo: eager
     assert out["value"] > 0 and all(v > 0 for v in out["phases_ms"].values())
+
+
+def test_ppo_loop_with_every_collective_over_rccl_at_world_1():
+    """brl_amd.train with BRL_FORCE_DIST=1 under a world-1 RCCL process group (scripts/soak_train_rccl_world1.py, 4 iterations x 1024
+    tables, both forms of the gradient step): parameter broadcast, barriers, the sharded evaluators' all-reduces, the opponent-index
+    broadcast, rollout captures, the update's graph with RCCL nodes inside, rank-sync checksums, the optimizer-state gather — the
+    ORDER of eager collectives, captures and replays under ProcessGroupNCCL's watchdog thread, which is what a node run shares with
+    this box (an eager collective polled by the watchdog during a capture that contains collectives aborts the process: the guard in
+    FusedStep, profiles/r05/r05n_rccl_eager_then_capture_probe.txt)."""
+    env = {k: v for k, v in os.environ.items() if k not in DROP}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "soak_train_rccl_world1.py"), "4", "1024"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if "iterations under a world-1 RCCL process group" in l]
+    assert len(lines) == 2 and all("collectives inside the graph: True" in l and "backend nccl" in l for l in lines), r.stdout[-2000:]
+    assert "mode flat" in lines[0] and "mode sharded" in lines[1]
