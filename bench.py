@@ -273,7 +273,15 @@ def main():
     # BRL_BENCH_BACKEND=gloo: rehearsal of the N-rank path on a box with fewer GPUs than ranks (ranks share the devices
     # round-robin, the control plane runs over gloo); the driver's runs use RCCL, one GPU per rank
     backend = os.environ.get("BRL_BENCH_BACKEND", "nccl")
-    if world > 1:
+    # BRL_FORCE_DIST=1 at N = 1: the N-rank control flow (barrier, MAX over ranks, the per-rank records gathered) really over RCCL
+    # with one peer — a rehearsal of what the driver's N > 1 runs execute, on a one-GPU box (tests/test_multi_gpu_rccl.py)
+    forced = world == 1 and os.environ.get("BRL_FORCE_DIST") == "1" and not FAKE
+    if forced:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or forced:
         import torch.distributed as dist
         if FAKE:
             dist.init_process_group("gloo")
@@ -306,7 +314,7 @@ def main():
         out = bench_ppo(args, torch, dev, rank, world, barrier, max_over_ranks)
     else:
         out = bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks,
-                            dist=dist, backend="fake" if FAKE else (backend if world > 1 else "none"))
+                            dist=dist, backend="fake" if FAKE else (backend if (world > 1 or forced) else "none"))
         if out.get("ranks_error"):
             print("bench.py: " + out["ranks_error"], file=sys.stderr)
             rc = 3

@@ -98,3 +98,13 @@ def test_ppo_loop_with_every_collective_over_rccl_at_world_1():
     lines = [l for l in r.stdout.splitlines() if "iterations under a world-1 RCCL process group" in l]
     assert len(lines) == 2 and all("collectives inside the graph: True" in l and "backend nccl" in l for l in lines), r.stdout[-2000:]
     assert "mode flat" in lines[0] and "mode sharded" in lines[1]
+
+
+def test_bench_control_flow_over_rccl_at_world_1():
+    """The N-rank control flow of `bench.py` (process-group set-up with the device bound, barriers, MAX over ranks of the step time,
+    the per-rank records gathered with all_gather_object) really over RCCL with one peer (BRL_FORCE_DIST=1): what the driver's N > 1
+    runs execute besides the step itself."""
+    r, out = _bench(["--gpus", "1", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-secondary"], BRL_FORCE_DIST="1")
+    assert r.returncode == 0 and out is not None, r.stderr[-3000:]
+    assert out["n_gpus"] == 1 and out["ranks_backend"].startswith("RCCL") and len(out["ranks"]) == 1 and "ranks_error" not in out
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0.05
