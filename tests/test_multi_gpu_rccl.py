@@ -108,3 +108,12 @@ def test_bench_control_flow_over_rccl_at_world_1():
     assert r.returncode == 0 and out is not None, r.stderr[-3000:]
     assert out["n_gpus"] == 1 and out["ranks_backend"].startswith("RCCL") and len(out["ranks"]) == 1 and "ranks_error" not in out
     assert out["value"] > 0 and out["roofline"]["frac"] > 0.05
+
+
+def test_bench_ppo_over_rccl_at_world_1():
+    """`bench.py --config ppo` (configs[4]'s measurement path) with its gradient all-reduce a REAL RCCL node of the update's hipGraph
+    (world 1, BRL_FORCE_DIST=1), at a reduced size: the record names the form and says the collectives are inside the graph."""
+    r, out = _bench(["--gpus", "1", "--config", "ppo", "--steps", "1"], BRL_FORCE_DIST="1", BRL_BENCH_PPO_ENVS="1024", BRL_BENCH_PPO_EPOCHS="2")
+    assert r.returncode == 0 and out is not None, r.stderr[-3000:]
+    assert out["config"]["grad_allreduce"] == "flat" and out["config"]["collectives_inside_the_graph"] is True
+    assert out["value"] > 0 and out["config"]["rehearsal_size"] is True
