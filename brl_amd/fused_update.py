@@ -357,8 +357,9 @@ class FusedMinibatch(FusedStep):
           sums of the rank's own slices + a 4 KB all-gather, clip + Adam on the rank's 1/world slices only, then the all-gather
           of the updated parameters bucket by bucket in forward order — the next step's layer l waits for ITS bucket only.  Same
           ring bytes as an all-reduce; the Adam sweep shrinks by 1/world; the moments are valid on the rank's slices only
-          (``gather_optimizer_state`` completes them for a checkpoint).  Opt-in: with collectives that hold CUs the GEMMs beside
-          them pay a second wave of workgroups, and the emulation (scripts/overlap_probe.py) puts the two forms level.
+          (``gather_optimizer_state`` completes them for a checkpoint).  Opt-in: every kernel on a second branch of the graph
+          costs ~10 us per cross-stream edge (scripts/graph_overlap_micro2.py), nine collectives per step pay back what they
+          hide, and the emulation (scripts/overlap_probe.py) puts the two forms level.
 
     Given the same launches (config["per_layer_dw"]) both forms give bit-identical parameters (the norm's partials have one
     layout: csrc/ppo_update.hpp ShardGeom).
