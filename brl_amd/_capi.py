@@ -58,6 +58,17 @@ class ShardGeom(C.Structure):
                 ("off", C.c_int64 * 12), ("len", C.c_int64 * 12)]
 
 
+class FairNet(C.Structure):
+    """brl_fair_net: the FAIR network's parameters (nn.Linear layout), device pointers"""
+    _fields_ = [("w", _vp * 11), ("b", _vp * 11), ("head_w", _vp), ("head_b", _vp)]
+
+
+class FairWork(C.Structure):
+    """brl_fair_work: what brl_fair_chain leaves for the weight-gradient products and brl_bias_finalize_rows"""
+    _names = ("inp", "dzs", "gates", "cat6", "x4", "dz0", "dz6", "dheads", "tiles", "partials", "gram_partials")
+    _fields_ = [(n, _vp) for n in _names]
+
+
 EVAL_COUNTS = 231  # BRL_EVAL_COUNTS
 
 
@@ -128,6 +139,9 @@ def lib() -> C.CDLL:
         "brl_act_bwd_colsum_heads_dw": [i32, _vp, _vp, i64, i64, i64, i32, _vp, _vp, _vp, i64, i64, i64, i32, _vp, _vp, _vp, _vp, i64,
                                         _vp, _vp, _vp, _vp],
         "brl_bias_finalize_ex": [i32, i32, _vp, _vp, _vp, _vp, _vp],
+        "brl_bias_finalize_rows": [i32, i32, _vp, _vp, _vp, _vp, i32, _vp, _vp],
+        "brl_fair_chain": [i32, C.POINTER(FairNet), _vp, _vp, _vp, _vp, _vp, _vp, _vp, i64, f32, f32, f32, i32, i32, i32, i32,
+                           C.POINTER(FairWork), _vp],
         "brl_mlp_gemm": [i32, i32, i32, _vp, i64, _vp, i64, _vp, i64, i64, i64, i64, i32, _vp, _vp, i64, _vp, _vp, _vp],
         "brl_mlp_forward_rows": [i32, C.POINTER(MlpRef), _vp, _vp, i64, _vp, i64, _vp, i64, _vp],
         "brl_adam_shard_norm": [i32, _vp, C.POINTER(ShardGeom), i32, i32, f32, _vp, _vp, _vp, _vp],
@@ -149,7 +163,8 @@ EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_de
            "brl_rollout_random", "brl_policy_step", "brl_policy_step_at", "brl_obs_cast", "brl_obs_cast_rows", "brl_live_index", "brl_linear_act", "brl_linear_act_heads", "brl_gae", "brl_imp_reward", "brl_duplicate_step",
            "brl_eval_step", "brl_eval_reduce", "brl_ppo_loss", "brl_ppo_stats", "brl_policy_step_ex",
            "brl_eval_step_team", "brl_rollout_random_gae", "brl_ppo_heads_loss_split", "brl_adam_shard_norm", "brl_adam_shard_apply", "brl_ppo_heads_bwd", "brl_ppo_stats_gram",
-           "brl_act_bwd_colsum", "brl_act_bwd_colsum_heads_dw", "brl_bias_finalize_ex", "brl_ppo_stats_rows", "brl_mb_gather_bind", "brl_mb_gather_dev", "brl_ppo_illegal_grad", "brl_adam_clip_fin_gather", "brl_mlp_gemm", "brl_mlp_gemm_dh_heads_dw", "brl_mlp_forward_rows"]
+           "brl_act_bwd_colsum", "brl_act_bwd_colsum_heads_dw", "brl_bias_finalize_ex", "brl_ppo_stats_rows", "brl_mb_gather_bind", "brl_mb_gather_dev", "brl_ppo_illegal_grad", "brl_adam_clip_fin_gather", "brl_mlp_gemm", "brl_mlp_gemm_dh_heads_dw", "brl_mlp_forward_rows",
+           "brl_bias_finalize_rows", "brl_fair_chain"]
 
 
 def check(rc: int) -> None:

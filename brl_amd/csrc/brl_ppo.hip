@@ -230,6 +230,7 @@ __global__ __launch_bounds__(512) void k_ppo_stats(const float *partials, int64_
 
 #include "ppo_update.hpp"  // k_mb_gather_dev, k_relu_bwd_tiles4, k_bias_finalize, k_adam_norm_fin / k_adam_apply, k_shard_norm / k_shard_apply
 #include "ppo_heads.hpp"   // k_heads_loss, k_heads_bwd, k_ppo_stats2: the 39-column head products and what hangs on them
+#include "fair_chain.hpp"  // k_fair_chain: the FAIR network's forward + loss + backward chain, 16 samples per workgroup
 
 // =====================================================================================
 // C-ABI
@@ -330,6 +331,58 @@ extern "C" int brl_bias_finalize_ex(int device, int nseg, const float *const *pa
     maxc = cols[i] > maxc ? cols[i] : maxc;
   }
   hipLaunchKernelGGL(k_bias_finalize, dim3((unsigned)((maxc + 63) / 64), (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, S);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_bias_finalize_rows(int device, int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles,
+                                      float *const *out, int first_row_seg, const int32_t *row_index, void *stream) {
+  NEED(nseg >= 1 && nseg <= BIAS_MAX_SEGS && partials && cols && tiles && out, "nseg / partials / cols / tiles / out");
+  NEED(first_row_seg >= 0 && first_row_seg <= nseg && (row_index || first_row_seg == nseg), "first_row_seg / row_index");
+  HIP_TRY(hipSetDevice(device));
+  BiasSegs S{};
+  S.n = nseg;
+  int64_t maxc = 0;
+  for (int i = 0; i < nseg; i++) {
+    NEED(partials[i] && out[i] && cols[i] > 0 && tiles[i] > 0, "segment");
+    S.tiles[i] = tiles[i]; S.partials[i] = partials[i]; S.cols[i] = cols[i]; S.db[i] = out[i];
+    maxc = cols[i] > maxc ? cols[i] : maxc;
+  }
+  S.row_index = (first_row_seg < nseg) ? row_index : nullptr;
+  S.first_row_seg = first_row_seg;
+  hipLaunchKernelGGL(k_bias_finalize, dim3((unsigned)((maxc + 63) / 64), (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, S);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_fair_chain(int device, const brl_fair_net *net, const float *x0, const uint8_t *mask, const int32_t *action,
+                              const float *old_value, const float *old_log_prob, const float *gae, const float *targets,
+                              int64_t batch, float clip_eps, float vf_coef, float ent_coef, int masked, int value_clipping,
+                              int reward_scaling, int act, const brl_fair_work *work, void *stream) {
+  NEED(net && work && x0 && mask && action && old_value && old_log_prob && gae && targets, "NULL input");
+  NEED(batch > 0 && batch % fair::R == 0, "batch (a multiple of 16)");
+  NEED(act == 0 || act == 1, "act");
+  fair::Args A{};
+  for (int l = 0; l < 11; l++) {
+    NEED(net->w[l] && net->b[l], "net: NULL layer");
+    NEED((((uintptr_t)net->w[l]) & 15) == 0 && (((uintptr_t)net->b[l]) & 15) == 0, "net: 16-byte alignment");
+    A.net.w[l] = net->w[l]; A.net.b[l] = net->b[l];
+  }
+  NEED(net->head_w && net->head_b && (((uintptr_t)net->head_w) & 15) == 0, "net: heads");
+  A.net.wh = net->head_w; A.net.bh = net->head_b;
+  NEED(work->inp && work->dzs && work->gates && work->cat6 && work->x4 && work->dz0 && work->dz6 && work->dheads && work->tiles &&
+       work->partials, "work: NULL array");
+  const void *al[] = {x0, work->inp, work->dzs, work->gates, work->cat6, work->x4, work->dz0, work->dz6, work->tiles};
+  for (const void *q : al) NEED((((uintptr_t)q) & 15) == 0, "16-byte alignment");
+  A.o = fair::Bufs{work->inp, work->dzs, work->gates, work->cat6, work->x4, work->dz0, work->dz6, work->dheads, work->tiles,
+                   work->partials, work->gram_partials};
+  A.x0 = x0;
+  A.P = PpoArgs{nullptr, 0, nullptr, mask, action, old_value, old_log_prob, gae, targets, batch, clip_eps, vf_coef,
+                ent_coef, masked, value_clipping, nullptr, nullptr, nullptr, nullptr, 1, BRL_NUM_ACTIONS, 1};
+  A.act = act;
+  A.reward_scaling = reward_scaling;
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(fair::k_fair_chain, dim3((unsigned)(batch / fair::R)), dim3(fair::NW * 64), 0, (hipStream_t)stream, A);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

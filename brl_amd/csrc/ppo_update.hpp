@@ -112,13 +112,16 @@ __global__ __launch_bounds__(256) void k_relu_bwd_tiles4(float *dh, const float 
   relu_bwd_tiles4_block(dh, h, rows, cols, ld, partials, act, (int)blockIdx.x, (int)blockIdx.y);
 }
 
-constexpr int BIAS_MAX_SEGS = 12;  // DeepMind_8: 8 hidden layers + the head
-struct BiasSegs {  // up to 12 layers finalised by one launch (blockIdx.y = layer)
+constexpr int BIAS_MAX_SEGS = 16;  // DeepMind_8: 8 hidden layers + the head; FAIR: 11 layers + the head + 2 statistics rows
+struct BiasSegs {  // up to 16 sums finalised by one launch (blockIdx.y = segment)
   int n;
   int64_t tiles[BIAS_MAX_SEGS];
   const float *partials[BIAS_MAX_SEGS];
   int64_t cols[BIAS_MAX_SEGS];
   float *db[BIAS_MAX_SEGS];
+  // segments >= first_row_seg are rows of a log: written at db[seg] + *row_index * cols[seg] (row_index: device memory; NULL: none)
+  const int32_t *row_index;
+  int first_row_seg;
 };
 
 // (64 columns per block, 4 threads per column: thread group g adds tiles g, g + 4, ... in order, then (g0 + g1) + (g2 + g3):
@@ -144,7 +147,9 @@ __device__ __forceinline__ float bias_finalize_block(const BiasSegs &S, const in
   float v = 0.0f;
   if (g == 0 && col < cols) {
     v = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
-    S.db[seg][col] = v;
+    float *db = S.db[seg];
+    if (S.row_index != nullptr && seg >= S.first_row_seg) db += (int64_t)(*S.row_index) * cols;
+    db[col] = v;
   }
   return v;
 }

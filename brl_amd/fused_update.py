@@ -101,7 +101,6 @@ class FusedStep:
         self.lgroups = (B + 3) // 4                    # 4-sample groups of the loss launch (statistics / Gram partials)
         self.partials = f(self.lgroups, 8)
         self.out = f(8)
-        self._alloc()                                  # the subclass's activations, scratch and segment tables
         # The logged statistics (src/update.py:136-167) are NOT formed step by step: every step leaves its sums — 8 floats and
         # the 38 x 38 Gram matrix of the illegal-action probabilities, reduced by spare workgroups of the head-backward
         # launch — in row mb_index of these buffers, and ONE launch at the end of the update turns all rows into log rows
@@ -112,6 +111,7 @@ class FusedStep:
         self.gram_sums = f(self._log_cap, 38 * 38)
         self.norm = f(1)
         self.mb_index = torch.zeros(1, dtype=torch.int32, device=device)  # minibatch step within the current update
+        self._alloc()                                  # the subclass's activations, scratch and segment tables
         self.perm = None  # static int64 [epochs * T*N]: every epoch's permutation, filled by begin_update
         # the step's own gather reads ITS arguments from device memory (brl_mb_gather_bind, once per update): the captured
         # step needs no eager launch in front of it.  Until the first update: a dummy trajectory of mbs valid rows.
@@ -718,6 +718,32 @@ class FusedFair(FusedStep):
             g.nbuckets, g.world, g.nsub = 1, 1, 1024
             g.off[0], g.len[0] = 0, self.n
             self.geom, self.norm_partials = g, f(1024)
+        # forward + loss + backward chain as ONE launch (brl_fair_chain: 16 samples per workgroup, activations in LDS)
+        self.chain = bool(self.cfg.get("fair_chain", True)) and B % 16 == 0 and H == 200 and self.x0.shape[1] == 480
+        if self.chain:
+            nwg = B // 16
+            assert p.critic.weight.data_ptr() == p.actor.weight.data_ptr() + 38 * H * 4 \
+                and p.critic.bias.data_ptr() == p.actor.bias.data_ptr() + 38 * 4      # the heads as one [39, H] / [39] in the flat buffer
+            sw, sb = views[p.actor.weight], views[p.critic.bias]
+            self.GWh = self.G[sw.start:sw.start + 39 * H].view(39, H)
+            self.gates, self.dheads = f(4, B, H), f(B, 39)
+            self.ctiles = f(11 * nwg * H + nwg * 39)
+            self.cpartials, self.cgram = f(nwg, 8), f(nwg, 38 * 38)
+            net, wk = self.capi.FairNet(), self.capi.FairWork()
+            for l, lin in enumerate(L):
+                net.w[l], net.b[l] = lin.weight.data_ptr(), lin.bias.data_ptr()
+            net.head_w, net.head_b = p.actor.weight.data_ptr(), p.actor.bias.data_ptr()
+            for name, t_ in (("inp", self.inp), ("dzs", self.dzs), ("gates", self.gates), ("cat6", self.cat6), ("x4", self.t["x4"]),
+                             ("dz0", self.dz[0]), ("dz6", self.dz[6]), ("dheads", self.dheads), ("tiles", self.ctiles),
+                             ("partials", self.cpartials), ("gram_partials", self.cgram)):
+                setattr(wk, name, t_.data_ptr())
+            self._net, self._work = net, wk
+            # one launch finishes the eleven bias gradients, the heads' and this step's row of the statistics / Gram sums
+            parts = [self.ctiles.data_ptr() + 4 * l * nwg * H for l in range(12)] + [self.cpartials.data_ptr(), self.cgram.data_ptr()]
+            outs = [g_.data_ptr() for g_ in self.Gb] + [self.G[views[p.actor.bias].start:].data_ptr(), self.stat_sums.data_ptr(),
+                                                         self.gram_sums.data_ptr()]
+            cols = [H] * 11 + [39, 8, 38 * 38]
+            self._cseg = ((C.c_void_p * 14)(*parts), (C.c_int64 * 14)(*cols), (C.c_int64 * 14)(*([nwg] * 14)), (C.c_void_p * 14)(*outs))
 
     # ---- the step ------------------------------------------------------------------------------------------------------
     def _build_program(self):
@@ -772,8 +798,27 @@ class FusedFair(FusedStep):
         else:
             torch.addcmul(out, out * gate, gate, value=-1.0, out=out)
 
+    def _grads_chain(self):
+        """the same through brl_fair_chain: one launch for forward, loss and the backward chain, the weight gradients as four
+        products, one launch for every bias gradient and the step's statistics row"""
+        cfg, B = self.cfg, self.mbs
+        s = torch.cuda.current_stream().cuda_stream
+        chk, L, di = self.capi.check, self.lib, self._di()
+        chk(L.brl_fair_chain(di, self._net, self.x0.data_ptr(), self.mask.data_ptr(), self.action.data_ptr(), self.old_v.data_ptr(),
+                             self.old_lp.data_ptr(), self.adv.data_ptr(), self.tgt.data_ptr(), B, float(cfg["clip_eps"]),
+                             float(cfg["vf_coef"]), float(cfg["ent_coef"]), int(bool(cfg.get("actor_illegal_action_mask", True))),
+                             int(bool(cfg.get("value_clipping", True))), int(bool(cfg.get("reward_scaling", False))), self.act,
+                             self._work, s))
+        torch.bmm(self.dzs.transpose(1, 2), self.inp, out=self.GW_square)
+        torch.mm(self.dz[6].t(), self.cat6, out=self.GW6)
+        torch.mm(self.dz[0].t(), self.x0, out=self.GW[0])
+        torch.mm(self.dheads.t(), self.t["x4"], out=self.GWh)
+        chk(L.brl_bias_finalize_rows(di, 14, *self._cseg, 12, self.mb_index.data_ptr(), s))
+
     def _grads(self):
         """forward, `_loss_fn`, the step's statistics sums, backward: every gradient into the flat buffer"""
+        if self.chain:
+            return self._grads_chain()
         t, cfg, B, dz = self.t, self.cfg, self.mbs, self.dz
         a = self._a
         x0 = self.x0

@@ -1,14 +1,17 @@
 """``src/update.py`` — the PPO-clip update.
 
 The data it consumes is the time-major ``Transition`` buffer the HIP rollout kernels wrote; flattening is ``reshape(T*N, ...)`` ->
-row ``t*N+n`` (G7, src/update.py:193-206).  Default path for the DeepMind MLPs: ``FusedMinibatch`` — the step's big GEMMs stay
-with the library (hipBLASLt / rocBLAS through torch, committed tuned solutions), everything else is hand-written HIP
-(``csrc/ppo_heads.hpp``, ``csrc/ppo_update.hpp``), eight steps per hipGraph.  Other architectures (FAIR) and CPU tensors take the
-torch autograd path (``ppo_loss``).  Under ``torch.distributed`` the fp32 gradient (3 681 319 elements = 14.7 MB for the DeepMind
-MLP) crosses the ranks once per minibatch — RCCL over xGMI on MI355X (backend "nccl"), gloo in the CPU tests: in the fused path
-reduce-scattered per layer behind the backward pass, Adam on the rank's slices, parameters all-gathered under the next forward
-pass (or one flat all-reduce: ``config["grad_allreduce"]``); one flat all-reduce on the autograd path.  Each rank permutes its own
-shard (statistically equivalent to the reference's global permutation, not bit-equal — SURVEY §8e caveat) and uses
+row ``t*N+n`` (G7, src/update.py:193-206).  Default paths (``brl_amd/fused_update.py``): ``FusedMinibatch`` for the DeepMind MLPs — the
+step's big GEMMs stay with the library (hipBLASLt / rocBLAS through torch, committed tuned solutions) or ``brl_mlp_gemm``, everything
+else is hand-written HIP (``csrc/ppo_heads.hpp``, ``csrc/ppo_update.hpp``) — and ``FusedFair`` for the FAIR network, eight steps per
+hipGraph.  CPU tensors, a non-fp32 network and FAIR with an illegal-action norm term take the torch autograd path (``ppo_loss``).
+Under ``torch.distributed`` the fp32 gradient (3 681 319 elements = 14.7 MB for the DeepMind MLP) crosses the ranks once per
+minibatch — RCCL over xGMI on MI355X (backend "nccl", the collective a node of the step's hipGraph), gloo in the CPU tests: ONE flat
+all-reduce and the replicated clip + Adam sweep by default; ``config["grad_allreduce"] = "sharded"``: reduce-scattered per layer
+behind the backward pass, Adam on the rank's slices, parameters all-gathered under the next forward pass (bit-identical given
+``per_layer_dw``; DESIGN section 7 for why it is not the default).  Each rank permutes its own shard (statistically equivalent to the
+reference's global permutation, not bit-equal — SURVEY §8e caveat: set ``minibatch_size`` to 1024 / world for the reference's global
+1024) and uses
 ``minibatch_size`` PER RANK.
 """
 from __future__ import annotations

@@ -449,10 +449,48 @@ int brl_act_bwd_colsum_heads_dw(int device, float *dz, const float *hh, int64_t 
                                 float *gram_sums, void *stream);
 
 /* The sums of several layers' tile partials in one launch: out[i][c] = sum_{t < tiles[i]} partials[i][t * cols[i] + c],
- * in order, for nseg <= 12 segments (bias gradients of the layers, and the head's weight / bias gradients from
+ * in order, for nseg <= 16 segments (bias gradients of the layers, and the head's weight / bias gradients from
  * brl_ppo_heads_bwd's batch splits). */
 int brl_bias_finalize_ex(int device, int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles,
                          float *const *out, void *stream);
+/* The same, with the segments i >= first_row_seg written as rows of a log: out[i] + *row_index * cols[i] (row_index: device
+ * memory, e.g. the minibatch counter the Adam launches advance) — the step's statistics / Gram partials summed into row
+ * *row_index of stat_sums [rows,8] / gram_sums [rows,1444] (what brl_ppo_stats_rows reads) by the launch that finishes the bias
+ * gradients. */
+int brl_bias_finalize_rows(int device, int nseg, const float *const *partials, const int64_t *cols, const int64_t *tiles,
+                           float *const *out, int first_row_seg, const int32_t *row_index, void *stream);
+
+/* ---- the "FAIR" network's minibatch step without its small launches (src/models.py:34-69 `actor_model_type == "FAIR"`: eleven
+ * 200-wide hk.Linear's in four residual blocks, the observation concatenated back in front of the seventh, the two heads on the
+ * last block's output; src/update.py:74-167 for the loss) — brl_amd/csrc/fair_chain.hpp, brl_amd/fused_update.py::FusedFair.
+ * ONE launch: forward, `_loss_fn` and the whole backward chain of 16 samples per workgroup (rows are independent up to the weight
+ * gradients; the activations stay in LDS, the weights stream from L2, products are fp32 MFMA tiles).  It leaves what the
+ * weight-gradient products (library GEMMs) and brl_bias_finalize_rows need:
+ *   inp   float [9][batch][200]  the inputs of the square layers 1,2,3,4,5,7,8,9,10 (in that order)
+ *   dzs   float [9][batch][200]  d(loss)/d(their pre-activations)          -> dW_l = dzs[i]^T inp[i] (one batched product)
+ *   cat6  float [batch][680] = [z5 | x0], dz6 float [batch][200]           -> dW_6 = dz6^T cat6
+ *   dz0   float [batch][200]                                               -> dW_0 = dz0^T x0
+ *   x4    float [batch][200], dheads float [batch][39]                     -> d(head_w) = dheads^T x4
+ *   gates float [4][batch][200]  scratch (h2, h4, h8, h10: activation outputs the backward re-reads)
+ *   tiles float [11][batch/16][200] + [batch/16][39]  per workgroup: column sums of dz_l (segments l = 0..10) and, behind them,
+ *         of dheads = the bias gradients' partials (brl_bias_finalize_rows: tiles = batch / 16)
+ *   partials float [batch/16][8], gram_partials float [batch/16][1444] (may be NULL): the statistics as brl_ppo_heads_loss_split's.
+ * net: weights in nn.Linear's [out,in] layout (w[0] [200,480], w[6] [200,680], the others [200,200]); head_w [39,200] = actor rows,
+ * then the critic row; head_b [39].  act: 0 ReLU, 1 tanh.  Loss arguments as brl_ppo_heads_loss_split.  batch % 16 == 0; every
+ * array 16-byte aligned. */
+typedef struct brl_fair_net {
+  const float *w[11];
+  const float *b[11];
+  const float *head_w;
+  const float *head_b;
+} brl_fair_net;
+typedef struct brl_fair_work {
+  float *inp, *dzs, *gates, *cat6, *x4, *dz0, *dz6, *dheads, *tiles, *partials, *gram_partials;
+} brl_fair_work;
+int brl_fair_chain(int device, const brl_fair_net *net, const float *x0, const uint8_t *mask, const int32_t *action,
+                   const float *old_value, const float *old_log_prob, const float *gae, const float *targets, int64_t batch,
+                   float clip_eps, float vf_coef, float ent_coef, int masked, int value_clipping, int reward_scaling, int act,
+                   const brl_fair_work *work, void *stream);
 
 /* optax.chain(clip_by_global_norm(max_norm), adam(lr, eps)) (ppo.py:195-211) on FLAT fp32 buffers of n elements (n a multiple of
  * 4: pad with zeros), single rank, two launches.  Launch 1: *step (device float) += 1, *mb_index += 1 (may be NULL), the `nseg`

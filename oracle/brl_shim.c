@@ -537,6 +537,20 @@ int brl_bias_finalize_ex(int device, int nseg, const float *const *parts, const 
   (void)device; (void)nseg; (void)parts; (void)cols; (void)tiles; (void)out; (void)s;
   NOT_HERE("brl_bias_finalize_ex");
 }
+int brl_bias_finalize_rows(int device, int nseg, const float *const *parts, const int64_t *cols, const int64_t *tiles,
+                           float *const *out, int first_row_seg, const int32_t *row_index, void *s) {
+  (void)device; (void)nseg; (void)parts; (void)cols; (void)tiles; (void)out; (void)first_row_seg; (void)row_index; (void)s;
+  NOT_HERE("brl_bias_finalize_rows");
+}
+int brl_fair_chain(int device, const brl_fair_net *net, const float *x0, const uint8_t *mask, const int32_t *action,
+                   const float *old_value, const float *old_log_prob, const float *gae, const float *targets, int64_t batch,
+                   float clip_eps, float vf_coef, float ent_coef, int masked, int value_clipping, int reward_scaling, int act,
+                   const brl_fair_work *work, void *s) {
+  (void)device; (void)net; (void)x0; (void)mask; (void)action; (void)old_value; (void)old_log_prob; (void)gae; (void)targets;
+  (void)batch; (void)clip_eps; (void)vf_coef; (void)ent_coef; (void)masked; (void)value_clipping; (void)reward_scaling; (void)act;
+  (void)work; (void)s;
+  NOT_HERE("brl_fair_chain");
+}
 int brl_ppo_stats_rows(int device, const float *ss, const float *gs, int64_t rows, int64_t b, float vc, float ec, float ic, float *out,
                        void *s) {
   (void)ic; (void)device; (void)ss; (void)gs; (void)rows; (void)b; (void)vc; (void)ec; (void)out; (void)s;

@@ -2097,11 +2097,14 @@ def test_fused_update_sharded_geometry_of_eight_ranks_on_one_gpu(tmp_path):
     assert torch.allclose(a[0], ref.detach(), atol=2e-6), float((a[0] - ref.detach()).abs().max())
 
 
+@pytest.mark.parametrize("chain", [True, False])
 @pytest.mark.parametrize("activation,rscale,masked", [("relu", False, True), ("tanh", False, True), ("relu", True, True), ("relu", False, False)])
-def test_fused_fair_step_matches_numpy_restatement(activation, rscale, masked):
+def test_fused_fair_step_matches_numpy_restatement(activation, rscale, masked, chain):
     """FusedFair (src/models.py:34-69 written out: forward, `_loss_fn`, backward on flat buffers, clip + Adam) — ONE minibatch step
     at minibatch 1024 vs the float64 numpy restatement (tests/ppo_numpy.py::fair_loss_and_grads, itself checked against autograd in
-    float64 on the CPU): every gradient before the sweep, the losses, the pre-clip norm, every parameter after the first Adam step."""
+    float64 on the CPU): every gradient before the sweep, the losses, the pre-clip norm, every parameter after the first Adam step.
+    chain: forward + loss + backward chain as ONE launch (brl_fair_chain, the default) / as ~55 launches (library products +
+    brl_mlp_gemm + elementwise kernels)."""
     from brl_amd.models import make_forward_pass
     from brl_amd.roll_out import Transition
     from brl_amd.update import FusedFair, make_update_step
@@ -2109,7 +2112,7 @@ def test_fused_fair_step_matches_numpy_restatement(activation, rscale, masked):
     from tests.test_update_cpu import CFG, fake_batch
     tb, adv, tgt = fake_batch(4, 256, seed=2)
     B = 1024
-    cfg = dict(CFG, minibatch_size=B, update_epochs=1, lr=1e-3, reward_scaling=rscale, actor_illegal_action_mask=masked)
+    cfg = dict(CFG, minibatch_size=B, update_epochs=1, lr=1e-3, reward_scaling=rscale, actor_illegal_action_mask=masked, fair_chain=chain)
     fp = make_forward_pass(activation, "FAIR")
     net = fp.init(4, device="cuda")
     P0 = fair_params_of(net)
@@ -2123,7 +2126,7 @@ def test_fused_fair_step_matches_numpy_restatement(activation, rscale, masked):
     P1, gn = adam_first_step(cfg, P0, G)
     rs, (total, aux) = make_update_step(cfg, fp)((net, None, None, None, 0, 9), Transition(*[x.cuda() for x in tb]), adv.cuda(), tgt.cuda())
     fm = rs[1].get("graphed")
-    assert isinstance(fm, FusedFair), rs[1].get("graph_error")
+    assert isinstance(fm, FusedFair) and fm.chain == chain, rs[1].get("graph_error")
     assert abs(float(total[0, 0]) - want_total) < 2e-5
     for k in range(5):
         assert abs(float(aux[k][0, 0]) - want_aux[k]) < 2e-5, k
@@ -2139,7 +2142,7 @@ def test_fused_fair_step_matches_numpy_restatement(activation, rscale, masked):
     assert worst < 0.02 * cfg["lr"] and moved > 0.5 * cfg["lr"], (worst, moved, gn)
 
 
-@pytest.mark.parametrize("variant", ["relu", "tanh", "reward_scaling", "unmasked", "library_gemms"])
+@pytest.mark.parametrize("variant", ["relu", "tanh", "reward_scaling", "unmasked", "launches", "library_gemms"])
 def test_fused_fair_update_matches_eager(variant):
     """FusedFair vs the eager autograd path from the same start: ONE update of one epoch x 4 minibatches (the single step is checked
     against float64 above; over more steps Adam turns the rounding differences of near-zero gradients into +- lr moves) — parameters
@@ -2150,7 +2153,8 @@ def test_fused_fair_update_matches_eager(variant):
     from tests.test_update_cpu import CFG, fake_batch
     fp = make_forward_pass("tanh" if variant == "tanh" else "relu", "FAIR")
     cfg0 = dict(CFG, minibatch_size=256, update_epochs=1, reward_scaling=variant == "reward_scaling",
-                actor_illegal_action_mask=variant != "unmasked", own_gemm=variant != "library_gemms")
+                actor_illegal_action_mask=variant != "unmasked", own_gemm=variant != "library_gemms",
+                fair_chain=variant not in ("launches", "library_gemms"))    # (the default: brl_fair_chain; else launch by launch)
     tb, adv, tgt = fake_batch(4, 256, seed=40)
     tb = type(tb)(*[x.cuda() for x in tb])
     outs = []
