@@ -43,7 +43,7 @@ extern "C" int brl_mlp_gemm(int device, int layout, int epilogue, const float *a
   NEED(n % 4 == 0 && ldc % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc >= n, "n and the leading dimensions multiples of 4 (16-byte pieces)");
   const bool akc = layout != BRL_GEMM_TN, bkc = layout == BRL_GEMM_NT;
   NEED(!akc || k % 4 == 0, "k a multiple of 4 where it is the contiguous index of an operand");
-  NEED(akc ? lda >= k : (lda >= m && m % 4 == 0), "lda (and m a multiple of 4 where it is contiguous in a)");
+  NEED(akc ? lda >= k : lda >= ((m + 3) & ~(int64_t)3), "lda (where m is contiguous in a: at least m rounded up to 4 — whole 16-byte pieces are read)");
   NEED(bkc ? ldb >= k : ldb >= n, "ldb");
   // every byte offset inside an operand is a 32-bit buffer offset
   NEED((akc ? m * lda : k * lda) < (1ll << 29) && (bkc ? n * ldb : k * ldb) < (1ll << 29), "operands below 2 GB");
@@ -76,6 +76,46 @@ extern "C" int brl_mlp_gemm(int device, int layout, int epilogue, const float *a
     else MG_LAUNCH(false, false, mg::EPI_NONE);
   }
 #undef MG_LAUNCH
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_mlp_gemm_group(int device, int layout, int count, const float *const *a, const int64_t *lda, const float *const *b,
+                                  const int64_t *ldb, float *const *c, const int64_t *ldc, const int64_t *m, const int64_t *n,
+                                  const int64_t *k, void *stream) {
+  NEED(count >= 1 && count <= mg::GROUP_MAX && a && lda && b && ldb && c && ldc && m && n && k, "count (1..16) / NULL array");
+  NEED(layout >= BRL_GEMM_NT && layout <= BRL_GEMM_TN, "layout (BRL_GEMM_NT / _NN / _TN)");
+  const bool akc = layout != BRL_GEMM_TN, bkc = layout == BRL_GEMM_NT;
+  mg::GroupArgs GA{};
+  GA.n = count;
+  int64_t tiles64 = 0;
+  for (int i = 0; i < count; i++) tiles64 += ((m[i] + 63) / 64) * ((n[i] + 63) / 64);
+  const int nb = (tiles64 <= 256) ? 1 : 2;     // (brl_mlp_gemm's rule: 64 x 32 tiles up to one 64 x 64 tile per CU)
+  for (int i = 0; i < count; i++) {
+    NEED(a[i] && b[i] && c[i] && m[i] > 0 && n[i] > 0 && k[i] > 0, "a / b / c / m / n / k");
+    NEED(m[i] < (1 << 24) && n[i] < (1 << 24) && k[i] < (1 << 24), "m / n / k below 2^24");
+    NEED(n[i] % 4 == 0 && ldc[i] % 4 == 0 && lda[i] % 4 == 0 && ldb[i] % 4 == 0 && ldc[i] >= n[i], "n and the leading dimensions multiples of 4");
+    NEED(!akc || k[i] % 4 == 0, "k a multiple of 4 where it is the contiguous index of an operand");
+    NEED(akc ? lda[i] >= k[i] : lda[i] >= ((m[i] + 3) & ~(int64_t)3), "lda (where m is contiguous in a: at least m rounded up to 4)");
+    NEED(bkc ? ldb[i] >= k[i] : ldb[i] >= n[i], "ldb");
+    NEED((akc ? m[i] * lda[i] : k[i] * lda[i]) < (1ll << 29) && (bkc ? n[i] * ldb[i] : k[i] * ldb[i]) < (1ll << 29), "operands below 2 GB");
+    mg::Args &G = GA.g[i];
+    G.A = a[i]; G.lda = lda[i]; G.B = b[i]; G.ldb = ldb[i]; G.C = c[i]; G.ldc = ldc[i];
+    G.M = (int)m[i]; G.N = (int)n[i]; G.K = (int)k[i];
+    GA.first[i + 1] = GA.first[i] + (int)(((m[i] + 63) / 64) * ((n[i] + 32 * nb - 1) / (32 * nb)));
+  }
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned tiles = (unsigned)GA.first[count];
+#define MG_GROUP(AK, BK_)                                                                                         \
+  do {                                                                                                            \
+    if (nb == 2) hipLaunchKernelGGL((mg::k_gemm_group<AK, BK_, 2>), dim3(tiles), dim3(mg::THREADS), 0, s, GA);     \
+    else hipLaunchKernelGGL((mg::k_gemm_group<AK, BK_, 1>), dim3(tiles), dim3(mg::THREADS), 0, s, GA);             \
+  } while (0)
+  if (layout == BRL_GEMM_NT) MG_GROUP(true, true);
+  else if (layout == BRL_GEMM_NN) MG_GROUP(true, false);
+  else MG_GROUP(false, false);
+#undef MG_GROUP
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

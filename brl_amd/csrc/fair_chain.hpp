@@ -9,7 +9,7 @@
 // them: 64 x 24 x 160 KB per step, L2-resident), products are v_mfma_f32_16x16x4_f32 tiles (13 column tiles of 16 over 8 waves), and
 // what the weight-gradient products need afterwards — every layer's input and pre-activation gradient — is written out once:
 //   inp [9][B][200]  inputs of the square layers 1,2,3,4,5,7,8,9,10      dzs [9][B][200]  their pre-activation gradients
-//   cat6 [B][680] = [z5 | x0]   dz6, dz0, x4 [B][200]   dheads [B][39]   gates [4][B][200] = h2, h4, h8, h10 (activation outputs
+//   cat6 [B][680] = [z5 | x0]   dz6, dz0, x4 [B][200]   dheads [B][40]   gates [4][B][200] = h2, h4, h8, h10 (activation outputs
 //   the backward re-reads)   tiles [11][B/16][200] + [B/16][39]: column sums of dz_l (l = 0..10) and of dheads per workgroup = the
 //   bias gradients' partials (finished by k_bias_finalize), partials [B/16][8] + gram_partials [B/16][1444]: the statistics.
 // MFMA operand order: the weight fragment is the instruction's A operand, the sample fragment its B operand, so that lane
@@ -466,9 +466,9 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
       O.gram_partials[(int64_t)blockIdx.x * HD_GRAM + e] = s;
     }
   }
-  for (int e = tid; e < R * HD_NOUT; e += NW * 64) {
-    const int r = e / HD_NOUT, n = e - r * HD_NOUT;
-    O.dheads[(row0 + r) * HD_NOUT + n] = DH[r * LDH + n];
+  for (int e = tid; e < R * 40; e += NW * 64) {      // [B][40]: column 39 = 0 (a 16-byte-piece row for the weight-gradient product)
+    const int r = e / 40, n = e - r * 40;
+    O.dheads[(row0 + r) * 40 + n] = DH[r * LDH + n];
   }
   float *const tiles_wg = O.tiles + (int64_t)blockIdx.x * H;   // + l * nwg * H: this workgroup's row of layer l's partials
   const int64_t tstride = nwg * H;

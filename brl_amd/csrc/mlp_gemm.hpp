@@ -440,5 +440,22 @@ __global__ __launch_bounds__(THREADS) void k_gemm64(Args G) {
   gemm_tile<A_KC, B_KC, EPI, 2>(G, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// Several products of one layout as ONE launch (the FAIR step's eleven weight gradients: as launches of their own they are
+// 0.08-0.5 GFLOP each and cost a launch's latency apiece): workgroup b works on tile b - first[p] of problem p.
+constexpr int GROUP_MAX = 16;
+struct GroupArgs {
+  int n;
+  int first[GROUP_MAX + 1];   // prefix sums of the problems' tile counts
+  Args g[GROUP_MAX];
+};
+template <bool A_KC, bool B_KC, int NB>
+__global__ __launch_bounds__(THREADS) void k_gemm_group(GroupArgs GA) {
+  __shared__ __attribute__((aligned(16))) float lds[lds_floats<NB>()];
+  const int b = (int)blockIdx.x;
+  int p = 0;
+  while (p + 1 < GA.n && b >= GA.first[p + 1]) p++;
+  gemm_tile<A_KC, B_KC, EPI_NONE, NB>(GA.g[p], lds, b - GA.first[p], GA.first[p + 1] - GA.first[p]);
+}
+
 #undef MG_SB
 }  // namespace mg

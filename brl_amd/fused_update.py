@@ -726,7 +726,7 @@ class FusedFair(FusedStep):
                 and p.critic.bias.data_ptr() == p.actor.bias.data_ptr() + 38 * 4      # the heads as one [39, H] / [39] in the flat buffer
             sw, sb = views[p.actor.weight], views[p.critic.bias]
             self.GWh = self.G[sw.start:sw.start + 39 * H].view(39, H)
-            self.gates, self.dheads = f(4, B, H), f(B, 39)
+            self.gates, self.dheads = f(4, B, H), f(B, 40)
             self.ctiles = f(11 * nwg * H + nwg * 39)
             self.cpartials, self.cgram = f(nwg, 8), f(nwg, 38 * 38)
             net, wk = self.capi.FairNet(), self.capi.FairWork()
@@ -744,6 +744,15 @@ class FusedFair(FusedStep):
                                                          self.gram_sums.data_ptr()]
             cols = [H] * 11 + [39, 8, 38 * 38]
             self._cseg = ((C.c_void_p * 14)(*parts), (C.c_int64 * 14)(*cols), (C.c_int64 * 14)(*([nwg] * 14)), (C.c_void_p * 14)(*outs))
+            # the twelve weight gradients (eleven layers + the heads) dW = dz^T x as ONE launch (brl_mlp_gemm_group; else: library products)
+            self.group_dw = self.own_gemm and bool(self.cfg.get("fair_group_dw", True))
+            a_ = [self.dzs[i] for i in range(nsq)] + [self.dz[6], self.dz[0], self.dheads]
+            b_ = [self.inp[i] for i in range(nsq)] + [self.cat6, self.x0, self.t["x4"]]
+            c_ = [self.GW_square[i] for i in range(nsq)] + [self.GW6, self.GW[0], self.GWh]
+            i64, vp = C.c_int64 * 12, C.c_void_p * 12
+            self._gdw = (vp(*[t_.data_ptr() for t_ in a_]), i64(*[t_.stride(0) for t_ in a_]), vp(*[t_.data_ptr() for t_ in b_]),
+                         i64(*[t_.stride(0) for t_ in b_]), vp(*[t_.data_ptr() for t_ in c_]), i64(*[t_.stride(0) for t_ in c_]),
+                         i64(*[t_.shape[0] for t_ in c_]), i64(*[t_.shape[1] for t_ in c_]), i64(*([B] * 12)))
 
     # ---- the step ------------------------------------------------------------------------------------------------------
     def _build_program(self):
@@ -809,10 +818,13 @@ class FusedFair(FusedStep):
                              float(cfg["vf_coef"]), float(cfg["ent_coef"]), int(bool(cfg.get("actor_illegal_action_mask", True))),
                              int(bool(cfg.get("value_clipping", True))), int(bool(cfg.get("reward_scaling", False))), self.act,
                              self._work, s))
-        torch.bmm(self.dzs.transpose(1, 2), self.inp, out=self.GW_square)
-        torch.mm(self.dz[6].t(), self.cat6, out=self.GW6)
-        torch.mm(self.dz[0].t(), self.x0, out=self.GW[0])
-        torch.mm(self.dheads.t(), self.t["x4"], out=self.GWh)
+        if self.group_dw:
+            chk(L.brl_mlp_gemm_group(di, 2, 12, *self._gdw, s))
+        else:
+            torch.bmm(self.dzs.transpose(1, 2), self.inp, out=self.GW_square)
+            torch.mm(self.dz[6].t(), self.cat6, out=self.GW6)
+            torch.mm(self.dz[0].t(), self.x0, out=self.GW[0])
+            torch.mm(self.dheads[:, :39].t(), self.t["x4"], out=self.GWh)
         chk(L.brl_bias_finalize_rows(di, 14, *self._cseg, 12, self.mb_index.data_ptr(), s))
 
     def _grads(self):

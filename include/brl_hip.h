@@ -470,7 +470,7 @@ int brl_bias_finalize_rows(int device, int nseg, const float *const *partials, c
  *   dzs   float [9][batch][200]  d(loss)/d(their pre-activations)          -> dW_l = dzs[i]^T inp[i] (one batched product)
  *   cat6  float [batch][680] = [z5 | x0], dz6 float [batch][200]           -> dW_6 = dz6^T cat6
  *   dz0   float [batch][200]                                               -> dW_0 = dz0^T x0
- *   x4    float [batch][200], dheads float [batch][39]                     -> d(head_w) = dheads^T x4
+ *   x4    float [batch][200], dheads float [batch][40] (column 39 = 0)     -> d(head_w) = dheads[:, :39]^T x4
  *   gates float [4][batch][200]  scratch (h2, h4, h8, h10: activation outputs the backward re-reads)
  *   tiles float [11][batch/16][200] + [batch/16][39]  per workgroup: column sums of dz_l (segments l = 0..10) and, behind them,
  *         of dheads = the bias gradients' partials (brl_bias_finalize_rows: tiles = batch / 16)
@@ -552,7 +552,8 @@ int brl_adam_shard_apply(int device, float *p, const float *g, float *m, float *
  *                                   colsum may be NULL
  *   BRL_GEMM_EPI_SQSUM        (TN)  sqsum [ceil(m / 64) * ceil(n / 64)] = the sum of squares of every output tile
  *                                   (clip_by_global_norm's partial sums, ppo.py:195-211)
- * n, lda, ldb, ldc (ldg) multiples of 4; k a multiple of 4 where it is an operand's contiguous index, m where it is; operands
+ * n, lda, ldb, ldc (ldg) multiples of 4; k a multiple of 4 where it is an operand's contiguous index; where m is (TN), lda >= m
+ * rounded up to 4 (whole 16-byte pieces are read; rows of c beyond m are not written); operands
  * below 2 GB.  Deterministic (no atomics).  Replaces torch.mm / torch.addmm + brl_act_bwd_colsum in FusedMinibatch. */
 #define BRL_GEMM_NT 0
 #define BRL_GEMM_NN 1
@@ -564,6 +565,13 @@ int brl_adam_shard_apply(int device, float *p, const float *g, float *m, float *
 int brl_mlp_gemm(int device, int layout, int epilogue, const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
                  int64_t ldc, int64_t m, int64_t n, int64_t k, int act, const float *bias, const float *gate, int64_t ldg,
                  float *colsum, float *sqsum, void *stream);
+
+/* `count` <= 16 plain products of one layout as ONE launch (arguments as brl_mlp_gemm's, one array element per product): the FAIR
+ * network's eleven weight gradients dW_l = dz_l^T x_l (BRL_GEMM_TN; src/models.py:34-69's 200-wide layers are 0.08-0.5 GFLOP
+ * each — a launch apiece costs more than the arithmetic). */
+int brl_mlp_gemm_group(int device, int layout, int count, const float *const *a, const int64_t *lda, const float *const *b,
+                       const int64_t *ldb, float *const *c, const int64_t *ldc, const int64_t *m, const int64_t *n,
+                       const int64_t *k, void *stream);
 
 /* brl_mlp_gemm(BRL_GEMM_NN, BRL_GEMM_EPI_GATE_COLSUM, dz, w, ...) of the hidden layer below the top with the weight-gradient
  * role of brl_ppo_heads_bwd (arguments as brl_act_bwd_colsum_heads_dw) as extra workgroups of the same launch: call

