@@ -355,6 +355,13 @@ extern "C" int brl_bias_finalize_rows(int device, int nseg, const float *const *
   return BRL_OK;
 }
 
+#ifdef FAIR_TIMING
+extern "C" int brl_fair_set_dbg(void *p) {
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_fair_dbg), &p, sizeof(p)));
+  return BRL_OK;
+}
+#endif
+
 extern "C" int brl_fair_chain(int device, const brl_fair_net *net, const float *x0, const uint8_t *mask, const int32_t *action,
                               const float *old_value, const float *old_log_prob, const float *gae, const float *targets,
                               int64_t batch, float clip_eps, float vf_coef, float ent_coef, int masked, int value_clipping,

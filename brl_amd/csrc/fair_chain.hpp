@@ -20,7 +20,14 @@
 
 #ifndef FAIR_EXP
 #define FAIR_EXP 0   // experiment builds (scripts/fair_chain_probe.py): 1 no MFMAs, 2 no weight loads, 4 no LDS fragment reads,
-                     // 8 no global stores of activations / gradients, 16 filler jobs load real weights
+                     // 8 no global stores of activations / gradients, 16 filler jobs load real weights, 32 / 64 no backward / forward
+                     // weight loads, 256 every weight load out of range (issued, answered with 0 without a memory access)
+#endif
+#ifdef FAIR_TIMING   // scripts/fair_chain_probe.py --stamps: shader-clock stamps of wave 0 / lane 0 behind every phase
+__device__ unsigned long long *g_fair_dbg = nullptr;
+#define FAIR_STAMP(k) do { if (threadIdx.x == 0 && g_fair_dbg) g_fair_dbg[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FAIR_STAMP(k) do { } while (0)
 #endif
 namespace fair {
 constexpr int H = 200, OBS = 480, CAT = 680;
@@ -123,61 +130,99 @@ struct Job {                            // wave-uniform
 
 // (buffer loads: descriptor + 32-bit lane offset + scalar / immediate offset — no VALU instruction per load and a quarter of the
 //  issue cost of a 64-bit VGPR address; profiles/r04: every VALU instruction between f32 MFMAs costs ~14 cycles of issue)
-template <int LDW>
-__device__ __forceinline__ void load_bwd(Frag &F, const __amdgpu_buffer_rsrc_t rs, const int voff, const int vtail) {
-#pragma unroll
-  for (int j = 0; j < 12; j++) {
-#pragma unroll
-    for (int s = 0; s < 4; s++)
-      F.w[j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (16 * j + s) * LDW * 4, 0));
-  }
-#pragma unroll
-  for (int s = 0; s < 4; s++) F.w[12][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vtail, (192 + s) * LDW * 4, 0));
-}
-__device__ __forceinline__ void load_job(Frag &F, const Job &J, const int c, const int g) {
-  if (FAIR_EXP & 2) return;
-  if ((FAIR_EXP & 32) && J.nn) return;      // (32: no backward weight loads, 64: no forward weight loads)
-  if ((FAIR_EXP & 64) && !J.nn) return;
+// a job's addressing, formed once: descriptor + this lane's byte offsets
+struct JobAddr {
+  __amdgpu_buffer_rsrc_t rs;
+  int voff, vtail;          // byte offset of the lane's piece from the job's base; the same for chunk 12 (the K tail: clamped lanes)
+  int nn, wide, nch;        // backward (column access: four dwords per chunk); ldw == 680; chunks
+};
+__device__ __forceinline__ JobAddr job_addr(const Job &J, const int c, const int g) {
+  JobAddr a;
   const int n = (J.n0 + c < J.nmax) ? J.n0 + c : J.nmax - 1;
   const bool tail = J.nch == 13 && g >= 2;     // this lane's K indices of chunk 12 do not exist: any valid address (X is zero there)
   // (a filler job's descriptor holds no records: every load is out of range = 0, without a memory access)
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(J.W), (short)0, (J.real != 0 || (FAIR_EXP & 16) != 0) ? 0x7FFFFFFF : 0,
-                                                                      0x00020000);
+  a.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(J.W), (short)0,
+                                           (FAIR_EXP & 256) ? 0 : (J.real != 0 || (FAIR_EXP & 16) != 0) ? 0x7FFFFFFF : 0, 0x00020000);
+  a.nn = J.nn; a.wide = J.ldw != H; a.nch = J.nch;
   if (!J.nn) {
-    const int voff = (n * J.ldw + 4 * g) * 4, vt = tail ? voff : voff + 192 * 4;
-#pragma unroll
-    for (int j = 0; j < 12; j++) F.w[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 64 * j, 0));
-    F.w[12] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vt, 0, 0));
-    if (J.nch > 13) {
-      F.w[13] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 64 * 13, 0));
-      F.w[14] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 64 * 14, 0));
-    }
+    a.voff = (n * J.ldw + 4 * g) * 4;
+    a.vtail = tail ? a.voff : a.voff + 192 * 4;
   } else {
-    const int voff = (4 * g * J.ldw + n) * 4, vtail = tail ? n * 4 : voff;
-    if (J.ldw == H) load_bwd<H>(F, rs, voff, vtail);
-    else load_bwd<CAT>(F, rs, voff, vtail);
+    a.voff = (4 * g * J.ldw + n) * 4;
+    a.vtail = tail ? n * 4 : a.voff;      // (row offsets are scalar: the clamped lane drops its own 4 g rows -> rows 192 + s)
+  }
+  return a;
+}
+// chunk j (compile-time) of a job's weight fragments.  Buffer loads: descriptor + 32-bit lane offset + scalar / immediate offset —
+// no VALU instruction per load (profiles/r04: every VALU instruction between f32 MFMAs costs ~14 cycles of issue).
+template <int j>
+__device__ __forceinline__ void load_chunk(Frag &F, const JobAddr &a) {
+  if (FAIR_EXP & 2) return;
+  if ((FAIR_EXP & 32) && a.nn) return;      // (32: no backward weight loads, 64: no forward weight loads)
+  if ((FAIR_EXP & 64) && !a.nn) return;
+  if (!a.nn) {
+    if (j == 12) F.w[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a.rs, a.vtail, 0, 0));
+    else F.w[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a.rs, a.voff, 64 * j, 0));
+  } else {
+    const int v = (j == 12) ? a.vtail : a.voff;
+    if (!a.wide) {
+#pragma unroll
+      for (int s = 0; s < 4; s++) F.w[j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a.rs, v, (16 * j + s) * H * 4, 0));
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; s++) F.w[j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a.rs, v, (16 * j + s) * CAT * 4, 0));
+    }
   }
 }
-// acc += X (LDS rows, zero beyond K) times the job's fragments
-__device__ __forceinline__ void mac_job(f32x4 &acc, const Frag &F, const int nch, const float *X, const int ldx, const int c, const int g) {
+template <int j>
+__device__ __forceinline__ void mac_chunk(f32x4 &acc, const Frag &F, const float *xrow) {
+  const f32x4 xv = (FAIR_EXP & 4) ? f32x4{1.f, 1.f, 1.f, 1.f} : ld4(xrow + 16 * j);
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    if (FAIR_EXP & 1) acc[s] += F.w[j][s] * xv[s];
+    else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(F.w[j][s], xv[s], acc, 0, 0, 0);
+  }
+}
+// One slot of the pipeline: the NEXT job's weight fragments are requested chunk by chunk BETWEEN the products of the current job
+// (fragments in `use`, loaded a slot ago).  All at once in front of the products, the eight waves of the workgroup — in step behind
+// every barrier — queued 104 KB at the CU's one vector-memory pipe (64 B per clock) and waited for it, then all multiplied while it
+// sat idle: 12-14 k cycles per 200 x 200 layer against 6.7 k of MFMA issue (in-kernel stamps, profiles/r05).
+template <int j>
+__device__ __forceinline__ void slot_step(f32x4 &acc, const Frag &use, Frag &pre, const JobAddr &na, const int nch, const float *xrow) {
+  if (j < 13 || na.nch > 13) load_chunk<j>(pre, na);
+  if (j < 13 || nch > 13) mac_chunk<j>(acc, use, xrow);
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void slot_run(f32x4 &acc, const Frag &use, Frag &pre, const Job &cur, const Job &nxt, const float *X,
+                                         const int ldx, const int c, const int g) {
+  const JobAddr na = job_addr(nxt, c, g);
   const float *xrow = X + c * ldx + 4 * g;
-#pragma unroll
-  for (int j = 0; j < 13; j++) {
-    const f32x4 xv = (FAIR_EXP & 4) ? f32x4{1.f, 1.f, 1.f, 1.f} : ld4(xrow + 16 * j);
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-      if (FAIR_EXP & 1) acc[s] += F.w[j][s] * xv[s];
-      else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(F.w[j][s], xv[s], acc, 0, 0, 0);
-    }
+  const int nch = cur.nch;
+  __builtin_amdgcn_sched_barrier(0);
+  slot_step<0>(acc, use, pre, na, nch, xrow);
+  slot_step<1>(acc, use, pre, na, nch, xrow);
+  slot_step<2>(acc, use, pre, na, nch, xrow);
+  slot_step<3>(acc, use, pre, na, nch, xrow);
+  slot_step<4>(acc, use, pre, na, nch, xrow);
+  slot_step<5>(acc, use, pre, na, nch, xrow);
+  slot_step<6>(acc, use, pre, na, nch, xrow);
+  slot_step<7>(acc, use, pre, na, nch, xrow);
+  slot_step<8>(acc, use, pre, na, nch, xrow);
+  slot_step<9>(acc, use, pre, na, nch, xrow);
+  slot_step<10>(acc, use, pre, na, nch, xrow);
+  slot_step<11>(acc, use, pre, na, nch, xrow);
+  slot_step<12>(acc, use, pre, na, nch, xrow);
+  if (nch > 13 || na.nch > 13) {
+    slot_step<13>(acc, use, pre, na, nch, xrow);
+    slot_step<14>(acc, use, pre, na, nch, xrow);
   }
-  if (nch > 13) {
-#pragma unroll
-    for (int j = 13; j < 15; j++) {
-      const f32x4 xv = ld4(xrow + 16 * j);
-#pragma unroll
-      for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(F.w[j][s], xv[s], acc, 0, 0, 0);
-    }
-  }
+}
+__device__ __forceinline__ void load_job(Frag &F, const Job &J, const int c, const int g) {     // (the very first job only)
+  const JobAddr a = job_addr(J, c, g);
+  load_chunk<0>(F, a); load_chunk<1>(F, a); load_chunk<2>(F, a); load_chunk<3>(F, a); load_chunk<4>(F, a); load_chunk<5>(F, a);
+  load_chunk<6>(F, a); load_chunk<7>(F, a); load_chunk<8>(F, a); load_chunk<9>(F, a); load_chunk<10>(F, a); load_chunk<11>(F, a);
+  load_chunk<12>(F, a);
+  if (a.nch > 13) { load_chunk<13>(F, a); load_chunk<14>(F, a); }
 }
 
 __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
@@ -204,6 +249,9 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
   auto job_fwd = [&](const float *W, int ldw, int nch, bool B) { return Job{W, ldw, nch, 0, B ? tB : tA, H, (B ? hasB : hasA) ? 1 : 0}; };
   auto job_bwd = [&](const float *W, int ldw, bool B) { return Job{W, ldw, 13, 1, B ? tB : tA, H, (B ? hasB : hasA) ? 1 : 0}; };
   Frag FP, FQ;
+  int stamp_i = 0;
+  (void)stamp_i;
+  FAIR_STAMP(stamp_i++);
   load_job(FP, job_fwd(N.w[0], OBS, 15, false), c, g);        // the first job's weights: requested before anything else
 
   // ---- the observation rows -> LDS (and into the right block of cat6 = jnp.concatenate([x, input]), src/models.py:51)
@@ -249,6 +297,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
     adv_inv = rs_stat[1];
   }
   __syncthreads();
+  FAIR_STAMP(stamp_i++);
 
   // position of this lane's four outputs in the tile at column n0: row c, columns n0 + 4 g .. + 3 (all four exist or none)
   const int64_t grow = (row0 + c) * H;          // offset of row c in a [B,200] array
@@ -262,10 +311,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
   // all of it.
   auto slot = [&](Frag &use, Frag &pre, const Job &cur, const Job &nxt, const float *X, int ldx, f32x4 &acc, const float *e4) {
     const f32x4 e = ld4(e4);
-    load_job(pre, nxt, c, g);
-    __builtin_amdgcn_sched_barrier(0);
-    mac_job(acc, use, cur.nch, X, ldx, c, g);
-    __builtin_amdgcn_sched_barrier(0);
+    slot_run(acc, use, pre, cur, nxt, X, ldx, c, g);
     return e;
   };
   struct E2 { f32x4 a, b; };
@@ -274,10 +320,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
     E2 e;
     e.a = ld4(e4a);
     e.b = ld4(e4b);
-    load_job(pre, nxt, c, g);
-    __builtin_amdgcn_sched_barrier(0);
-    mac_job(acc, use, cur.nch, X, ldx, c, g);
-    __builtin_amdgcn_sched_barrier(0);
+    slot_run(acc, use, pre, cur, nxt, X, ldx, c, g);
     return e;
   };
   // this lane's columns in the tile at n0, clamped to existing ones (the clamped lanes' results are dropped)
@@ -294,6 +337,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
     e = slot(F2, F1, jB, next, X, LDA, acc, eptr(jB.n0));
     ep(acc, e, jB.n0, hasB);
     __syncthreads();
+    FAIR_STAMP(stamp_i++);
   };
   auto fwd_jobs = [&](int l, Job &jA, Job &jB) {
     jA = job_fwd(N.w[l], H, 13, false);
@@ -327,6 +371,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
     (void)slot(FQ, FP, jB1, job_fwd(N.w[1], H, 13, false), X0 + 240, LDX, acc, N.b[0]);
     ep(acc, e, tB, hasB);
     __syncthreads();
+    FAIR_STAMP(stamp_i++);
   }
   // a plain layer: out = act(in W^T + b) -> LDS `out` and the global array `gout`
   auto layer = [&](const float *in, float *out, int l, float *gout, const Job &next) {
@@ -409,6 +454,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
     (void)slot(FQ, FP, jB2, first_fwd(7), X0 + 240, LDX, acc, N.b[6]);
     ep(acc, e, tB, hasB);
     __syncthreads();
+    FAIR_STAMP(stamp_i++);
   }
   layer(a2, a1, 7, O.inp + 6 * BH, first_fwd(8));                                              // h7
   layer_res(a1, a0, 8, O.gates + 2 * BH, a2, O.inp + 7 * BH, true, first_fwd(9));              // h8; x3 = h8 + z6 (a0); g3 (a2)
@@ -430,6 +476,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
         if (col + i < HD_NOUT) HD[c * LDH + col + i] = acc[i] + N.bh[col + i];
     }
     __syncthreads();
+    FAIR_STAMP(stamp_i++);
   }
 
   // ================================================= `_loss_fn` (src/update.py:90-167): wave w takes rows 2 w, 2 w + 1
@@ -452,6 +499,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
     }
   }
   __syncthreads();
+  FAIR_STAMP(stamp_i++);
   if (tid < 8) {   // the workgroup's statistics partials, rows in order (deterministic)
     float s = 0.0f;
     for (int r = 0; r < R; r++) s += part_s[r][tid];
@@ -510,6 +558,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
       then_step(acc, g2, col, true, T);
     }
     __syncthreads();
+    FAIR_STAMP(stamp_i++);
   }
   // dst = (src W_l) * act'(gate) [+ the old dst when `accumulate`]; gout / lsum: global copy + column sums (dz of layer lsum) or none;
   // T (dst is a finished dx): the step above
@@ -539,6 +588,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
     e = slot2(FP, FQ, jB, next, src, LDA, acc, gbase + grow + colc(jB.n0), g2base + grow + colc(jB.n0));
     ep(acc, e, jB.n0, hasB);
     __syncthreads();
+    FAIR_STAMP(stamp_i++);
   };
   auto first_bwd = [&](int l, int ldw) { return job_bwd(N.w[l], ldw, false); };
   // a residual block  x_out = act(L_b(act(L_a(g)))) + x_in, g = act(x_in or a pre-activation), its dz_b already formed (a1):

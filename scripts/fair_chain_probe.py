@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VDIR = os.path.join(ROOT, "brl_amd", "lib", "variants")
 
 BODY = r'''
-import sys, ctypes as C
+import os, sys, ctypes as C
 sys.path.insert(0, ROOT)
 from brl_amd import _capi
 _capi.LIB_PATH = LIB
@@ -35,12 +35,20 @@ for k, shp in bufs.items():
 x0 = (torch.rand((B, 480), device=dev, generator=g) < 0.1).float()
 mask = (torch.rand((B, 38), device=dev, generator=g) < 0.5).to(torch.uint8); mask[:, 0] = 1
 action = torch.zeros(B, dtype=torch.int32, device=dev)
-ov, olp, adv, tgt = f(B), -torch.rand(B, device=dev) - 0.5, f(B), f(B)
+ov, olp, adv, tgt = f(B), -torch.rand(B, device=dev, generator=g) - 0.5, f(B), f(B)
 s = torch.cuda.current_stream()
 L = _capi.lib()
 def launch():
     _capi.check(L.brl_fair_chain(0, net, x0.data_ptr(), mask.data_ptr(), action.data_ptr(), ov.data_ptr(), olp.data_ptr(), adv.data_ptr(),
                                  tgt.data_ptr(), B, 0.2, 0.5, 0.01, 1, 1, 0, 0, wk, s.cuda_stream))
+launch(); torch.cuda.synchronize()
+# forward check against torch in float64: h0 = relu(x0 W0^T + b0) (inp[0]) and h1 (inp[1])
+W0, b0, W1, b1 = keep[0].double(), keep[1].double(), keep[2].double(), keep[3].double()
+h0 = torch.relu(x0.double() @ W0.t() + b0); h1 = torch.relu(h0 @ W1.t() + b1)
+inp_t = keep[24]
+print(f"{NAME}: |inp[0] - h0| = {float((inp_t[0].double() - h0).abs().max()):.2e}, |inp[1] - h1| = {float((inp_t[1].double() - h1).abs().max()):.2e}")
+if os.environ.get("FAIR_DUMP"):     # every output of one launch -> <dir>/<name>.npz (compare two builds on the same inputs)
+    np.savez(os.path.join(os.environ["FAIR_DUMP"], NAME + ".npz"), **{k: t.cpu().numpy() for k, t in zip(bufs, keep[24:])})
 for _ in range(20): launch()
 ts = []
 for rep in range(5):
@@ -50,6 +58,19 @@ for rep in range(5):
     e1.record(s); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1) / 200 * 1e3)
 print(f"{NAME:16s} {np.median(ts):8.2f} us per launch (min {min(ts):.2f})")
+if hasattr(L, "brl_fair_set_dbg"):     # a -DFAIR_TIMING build: shader-clock stamps of thread 0 behind every phase, per workgroup
+    dbg = torch.zeros((nwg, 64), dtype=torch.int64, device=dev)
+    L.brl_fair_set_dbg.argtypes = [C.c_void_p]
+    _capi.check(L.brl_fair_set_dbg(dbg.data_ptr()))
+    launch(); torch.cuda.synchronize()
+    d = dbg.cpu().numpy()
+    n = int((d[0] != 0).sum())
+    names = ["start", "prologue", "L0"] + [f"L{l}" for l in (1, 2, 3, 4, 5)] + ["L6", "L7", "L8", "L9", "L10", "heads", "loss", "dx heads"] \
+        + ["b10", "b9", "b8", "b7", "b6", "b5", "b4", "b3", "b2", "b1"]
+    for wg in (0, 1, nwg // 2, nwg - 1):
+        seg = np.diff(d[wg, :n])
+        print(f"  workgroup {wg:3d}: total {int(d[wg, n - 1] - d[wg, 0])} ticks; " + "  ".join(f"{names[i + 1] if i + 1 < len(names) else i}:{int(v)}" for i, v in enumerate(seg)))
+    print("  (s_memtime ticks: 100 MHz on gfx950 -> 10 ns each)")
 '''
 
 
@@ -70,7 +91,7 @@ def main():
         lib = os.path.join(VDIR, name + ".so") if name != "product" else os.path.join(ROOT, "brl_amd", "lib", "libbrl_hip.so")
         code = f"ROOT={ROOT!r}\nLIB={lib!r}\nNAME={name!r}\n" + BODY
         r = subprocess.run(["timeout", "-k", "5", "120", sys.executable, "-c", code], capture_output=True, text=True)
-        print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else (name + " FAILED " + r.stderr[-600:]))
+        print(r.stdout.strip() if r.stdout.strip() else (name + " FAILED " + r.stderr[-600:]))
 
 
 main()
