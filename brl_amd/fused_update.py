@@ -639,15 +639,16 @@ class FusedMinibatch(FusedStep):
 class FusedFair(FusedStep):
     """The same for the "FAIR" network (src/models.py:34-69: eleven 200-wide ``hk.Linear``s in four residual blocks, the observation
     concatenated back in front of the seventh, the two heads on the last block's output): forward and backward written out (no
-    autograd) on the flat buffers.  Its 35 products are 80 MFLOP each — launch-bound —, so the step is shaped by launch count:
-    the nine 200 x 200 layers' weight gradients are ONE batched product (their inputs and pre-activation gradients live in stacked
-    buffers, their weights are consecutive in the flat buffer), the backward chain's dz = (dz' W) act'(h) comes from ``brl_mlp_gemm``
-    with the bias gradient's tile sums in its epilogue, the other bias gradients from ``brl_act_bwd_colsum``, ALL eleven finished by
-    one ``brl_bias_finalize_ex``; ``_loss_fn`` + its gradients are one launch (``brl_ppo_loss``), the log rows are formed once per
-    update from per-step sums (``brl_ppo_stats_rows``), clip + Adam run through the shard launches (one bucket = the whole buffer).
-    ~70 launches per step, eight steps per hipGraph: 0.35 ms per step at configs[3]'s sizes (launch-count-bound: ~4.7 us per small
-    launch inside the graph); the autograd step it replaces (GraphedMinibatch), which re-gathers the whole trajectory per epoch and
-    copies every minibatch in: 0.70 ms.
+    autograd) on the flat buffers.  Its 35 products are 80 MFLOP each, so the step is shaped by launch count.  FIVE launches:
+    ``brl_fair_chain`` (csrc/fair_chain.hpp: forward, ``_loss_fn`` and the whole backward chain of 16 samples per workgroup — rows
+    are independent up to the weight gradients; activations in LDS, weights streamed from L2 a job ahead of the fp32 MFMA tiles that
+    use them; 114 us), ``brl_mlp_gemm_group`` (the twelve weight gradients dz^T x as one launch, 21 us), ``brl_bias_finalize_rows``
+    (every bias gradient + this step's row of the statistics / Gram sums), clip + Adam through the two shard launches (one bucket =
+    the whole buffer); the log rows are formed once per update (``brl_ppo_stats_rows``).  Eight steps per hipGraph: 0.150 ms per
+    step at configs[3]'s sizes.  ``fair_chain=False`` (or a minibatch that is not a multiple of 16): the same step launch by launch
+    (library products, ``brl_mlp_gemm`` GATE_COLSUM for the chain, ``brl_act_bwd_colsum``; ~70 launches x ~4.7 us = 0.35 ms); the
+    autograd step both replace (GraphedMinibatch), which re-gathers the whole trajectory per epoch and copies every minibatch in:
+    0.70 ms (profiles/r05/r05t_fair_step_probe.txt).
     Multi-rank: one bucket — "flat" = all-reduce + replicated sweep, "sharded" = reduce-scatter, sweep of the rank's slice,
     all-gather of the parameters; bit-identical.  Not covered (-> the autograd path): a non-zero illegal_action_l2norm_coef."""
 
