@@ -54,7 +54,8 @@ const char *brl_last_error(void);
  *     brl_ppo_heads_loss_parts, brl_adam_clip_fin_gather_defer, brl_mlp_gemm_adam, brl_adam_apply_range;
  *   removed (superseded forms): brl_ppo_loss_heads, brl_mb_gather, brl_relu_bwd_colsum, brl_adam_clip, brl_ppo_heads_loss,
  *     brl_adam_clip_gather (the multi-rank Adam: replaced by the two below);
- *   added: brl_adam_shard_norm, brl_adam_shard_apply (clip + Adam on a rank's slices of the bucketed flat buffers). */
+ *   added: brl_adam_shard_norm, brl_adam_shard_apply (clip + Adam on a rank's slices of the bucketed flat buffers);
+ *     brl_fair_chain, brl_mlp_gemm_group, brl_bias_finalize_rows (the FAIR network's step as five launches).  48 symbols. */
 int brl_version(void);
 
 /* BridgeBidding(dds_results_table_path)  — ppo.py:303, pgx.bridge_bidding.BridgeBidding.
