@@ -120,3 +120,23 @@ def test_shard_adam_on_the_shim_sharded_equals_replicated_equals_torch(shim):
     assert abs(a[3] - want_norm) < 1e-5 * want_norm
     assert np.allclose(a[0], ref.detach().numpy(), atol=2e-6)
     assert shim.brl_adam_shard_norm(0, ptr(p0), ctypes.byref(geom), 2, 2, f32(1.0), ptr(p0), ptr(p0), None, None) == -1   # empty rank range
+
+
+def test_mlp_gemm_group_on_the_shim(shim):
+    """brl_mlp_gemm_group through the shim (the plain definition, product by product) against numpy in float64: the FAIR step's
+    TN products, including the heads' 39 rows out of a [K, 40] array (lda = m rounded up to 4)."""
+    rng = np.random.default_rng(5)
+    shapes = [(8, 12, 20, 8), (39, 16, 24, 40)]        # (m, n, k, lda)
+    As = [np.ascontiguousarray(rng.standard_normal((k, lda)).astype(np.float32)) for m, n, k, lda in shapes]
+    Bs = [np.ascontiguousarray(rng.standard_normal((k, n)).astype(np.float32)) for m, n, k, lda in shapes]
+    Cs = [np.full((m, n), np.nan, np.float32) for m, n, k, lda in shapes]
+    cnt = len(shapes)
+    vp, i64 = ctypes.c_void_p * cnt, ctypes.c_int64 * cnt
+    shim.brl_mlp_gemm_group.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 10
+    rc = shim.brl_mlp_gemm_group(0, 2, cnt, vp(*[a.ctypes.data for a in As]), i64(*[s[3] for s in shapes]),
+                                 vp(*[b.ctypes.data for b in Bs]), i64(*[s[1] for s in shapes]), vp(*[c.ctypes.data for c in Cs]),
+                                 i64(*[s[1] for s in shapes]), i64(*[s[0] for s in shapes]), i64(*[s[1] for s in shapes]),
+                                 i64(*[s[2] for s in shapes]), None)
+    assert rc == 0
+    for (m, n, k, lda), a, b, c in zip(shapes, As, Bs, Cs):
+        assert np.allclose(c, a[:, :m].astype(np.float64).T @ b.astype(np.float64), atol=1e-5)
