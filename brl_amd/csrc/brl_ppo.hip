@@ -389,7 +389,34 @@ extern "C" int brl_fair_chain(int device, const brl_fair_net *net, const float *
   A.act = act;
   A.reward_scaling = reward_scaling;
   HIP_TRY(hipSetDevice(device));
-  hipLaunchKernelGGL(fair::k_fair_chain, dim3((unsigned)(batch / fair::R)), dim3(fair::NW * 64), 0, (hipStream_t)stream, A);
+  A.nrows = batch;
+  hipLaunchKernelGGL(fair::k_fair_chain<true>, dim3((unsigned)(batch / fair::R)), dim3(fair::NW * 64), 0, (hipStream_t)stream, A);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_fair_forward(int device, const brl_fair_net *net, const float *x, int64_t rows, int act, float *logits, float *value,
+                                void *stream) {
+  NEED(net && x && logits && value, "NULL array");
+  NEED(rows >= 0 && rows < (1ll << 31), "rows");
+  NEED(act == 0 || act == 1, "act");
+  if (rows == 0) return BRL_OK;
+  fair::Args A{};
+  for (int l = 0; l < 11; l++) {
+    NEED(net->w[l] && net->b[l], "net: NULL layer");
+    NEED((((uintptr_t)net->w[l]) & 15) == 0 && (((uintptr_t)net->b[l]) & 15) == 0, "net: 16-byte alignment");
+    A.net.w[l] = net->w[l]; A.net.b[l] = net->b[l];
+  }
+  NEED(net->head_w && net->head_b && (((uintptr_t)net->head_w) & 15) == 0 && (((uintptr_t)x) & 15) == 0, "net: heads / x: 16-byte alignment");
+  A.net.wh = net->head_w; A.net.bh = net->head_b;
+  A.x0 = x;
+  A.act = act;
+  A.nrows = rows;
+  A.logits_out = logits;
+  A.value_out = value;
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(fair::k_fair_chain<false>, dim3((unsigned)((rows + fair::R - 1) / fair::R)), dim3(fair::NW * 64), 0,
+                     (hipStream_t)stream, A);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

@@ -54,6 +54,9 @@ struct Args {
   PpoArgs P;                        // the loss inputs (logits / value / outputs unused: they live in LDS here)
   int act;                          // 0 ReLU, 1 tanh
   int reward_scaling;
+  // inference (k_fair_chain<false>): rows of x0, where the heads go; Bufs / P unused
+  int64_t nrows;
+  float *logits_out, *value_out;    // [nrows,38], [nrows]
 };
 
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
@@ -225,15 +228,18 @@ __device__ __forceinline__ void load_job(Frag &F, const Job &J, const int c, con
   if (a.nch > 13) { load_chunk<13>(F, a); load_chunk<14>(F, a); }
 }
 
+// TRAIN == false: the forward pass alone (`actor(x), critic(x)` for rollouts / evaluators: brl_fair_forward) — nothing but the heads
+// is written, any number of rows (a partial last block reads clamped rows), 75 KB of LDS = two workgroups per CU.
+template <bool TRAIN>
 __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
   __shared__ __attribute__((aligned(16))) float X0[R * LDX];
   __shared__ __attribute__((aligned(16))) float AB[3][R * LDA];
-  __shared__ __attribute__((aligned(16))) float HD[R * LDH], DH[R * LDH];
-  __shared__ float illp_s[R][BRL_NUM_ACTIONS], part_s[R][8];
+  __shared__ __attribute__((aligned(16))) float HD[R * LDH], DH[TRAIN ? R * LDH : 4];
+  __shared__ float illp_s[TRAIN ? R : 1][BRL_NUM_ACTIONS], part_s[TRAIN ? R : 1][8];
   __shared__ float rs_red[NW], rs_stat[2];
   const int tid = (int)threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // (the compiler must know the wave index is uniform: jobs live in SGPRs)
-  const int64_t B = A.P.B, row0 = (int64_t)blockIdx.x * R, nwg = gridDim.x;
+  const int64_t B = TRAIN ? A.P.B : A.nrows, row0 = (int64_t)blockIdx.x * R, nwg = gridDim.x;
   const int act = A.act;
   const Net &N = A.net;
   const Bufs &O = A.o;
@@ -257,16 +263,20 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
   // ---- the observation rows -> LDS (and into the right block of cat6 = jnp.concatenate([x, input]), src/models.py:51)
   for (int e = tid; e < R * (OBS / 4); e += NW * 64) {
     const int r = e / (OBS / 4), q = e - r * (OBS / 4);
-    const f32x4 v = ld4(A.x0 + (row0 + r) * OBS + 4 * q);
+    const int64_t row = (TRAIN || row0 + r < B) ? row0 + r : B - 1;
+    const f32x4 v = ld4(A.x0 + row * OBS + 4 * q);
     st4(X0 + r * LDX + 4 * q, v);
-    st4(O.cat6 + (row0 + r) * CAT + H + 4 * q, v);
+    if (TRAIN) st4(O.cat6 + (row0 + r) * CAT + H + 4 * q, v);
   }
-  for (int e = tid; e < R * LDH; e += NW * 64) { HD[e] = 0.f; DH[e] = 0.f; }
+  for (int e = tid; e < R * LDH; e += NW * 64) {
+    HD[e] = 0.f;
+    if (TRAIN) DH[e] = 0.f;
+  }
   for (int e = tid; e < 3 * R * LDA; e += NW * 64) AB[0][e] = 0.f;     // (the pad columns 200..211 are never written again)
   // the minibatch's advantage statistics (reward_scaling: src/update.py:31-44, jnp std = ddof 0) — every workgroup forms them
   // itself in the same fixed order: identical everywhere, no hand-off
   float adv_mean = 0.0f, adv_inv = 1.0f;
-  if (A.reward_scaling) {
+  if (TRAIN && A.reward_scaling) {
     float s = 0.0f;
     for (int64_t i = tid; i < B; i += NW * 64) s += A.P.gae[i];
     s = wave_sum_f(s);
@@ -304,6 +314,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
   float *const sink = AB[0];   // (FAIR_EXP & 8: global stores land in LDS instead)
   auto gptr = [&](float *base, int col) { return (FAIR_EXP & 8) ? sink + c * LDA + (col % 200) : base + grow + col; };
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto gst = [&](float *p, const f32x4 &v) { if (TRAIN) st4(p, v); };   // (the forward pass alone keeps nothing but the heads)
 
   // one slot of the pipeline: request the NEXT job's weights into `pre`, then multiply the current job (fragments in `use`) into acc.
   // `e4` (may be nullptr-free: always a valid address): the epilogue's global operand (bias / gate values) of THIS tile, requested
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
         const f32x4 z = acc + bias, h = act4(z, act);
         st4(a0 + c * LDA + col, z);
         st4(a1 + c * LDA + col, h);
-        st4(gptr(O.inp + 0 * BH, col), h);
+        gst(gptr(O.inp + 0 * BH, col), h);
       }
     };
     const Job jA0 = job_fwd(N.w[0], OBS, 15, false), jA1 = job_fwd(N.w[0] + 240, OBS, 15, false);
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
       if (col < H && valid) {
         const f32x4 h = act4(acc + bias, act);
         st4(out + c * LDA + col, h);
-        st4(gptr(gout, col), h);
+        gst(gptr(gout, col), h);
       }
     });
   };
@@ -397,15 +408,15 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
       const int col = n0 + 4 * g;
       if (col < H && valid) {
         const f32x4 h = act4(acc + bias, act);
-        st4(gptr(ggate, col), h);
+        gst(gptr(ggate, col), h);
         const f32x4 x = h + ld4(res + c * LDA + col);
         st4(res + c * LDA + col, x);
         if (act_out) {
           const f32x4 gg = act4(x, act);
           st4(out + c * LDA + col, gg);
-          st4(gptr(gout, col), gg);
+          gst(gptr(gout, col), gg);
         } else {
-          st4(gptr(gout, col), x);
+          gst(gptr(gout, col), x);
         }
       }
     });
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
       if (col < H && valid) {
         const f32x4 z = acc + bias;
         st4(a1 + c * LDA + col, z);
-        st4(O.cat6 + (row0 + c) * CAT + col, z);
+        gst(O.cat6 + (row0 + c) * CAT + col, z);
       }
     });
   }
@@ -437,7 +448,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
         const f32x4 z = acc + bias, h = act4(z, act);
         st4(a0 + c * LDA + col, z);
         st4(a2 + c * LDA + col, h);
-        st4(gptr(O.inp + 5 * BH, col), h);
+        gst(gptr(O.inp + 5 * BH, col), h);
       }
     };
     const float *W6 = N.w[6];
@@ -467,6 +478,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
     Job bA, bB;
     bwd_jobs(10, H, bA, bB);
     (void)bB;
+    if (!TRAIN) bA.real = 0;
     f32x4 acc = zero4;
     (void)slot(FP, FQ, jheads, bA, a0, LDA, acc, N.b[0]);     // dz9 = (dz10 W10) ...: its tile-A weights (FQ) travel while the loss is computed
     if (w < 3) {
@@ -477,6 +489,17 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
     }
     __syncthreads();
     FAIR_STAMP(stamp_i++);
+  }
+
+  if (!TRAIN) {   // the forward pass alone: logits [nrows,38], value [nrows]
+    for (int e = tid; e < R * HD_NOUT; e += NW * 64) {
+      const int r = e / HD_NOUT, n = e - r * HD_NOUT;
+      if (row0 + r < B) {
+        if (n < BRL_NUM_ACTIONS) A.logits_out[(row0 + r) * BRL_NUM_ACTIONS + n] = HD[r * LDH + n];
+        else A.value_out[row0 + r] = HD[r * LDH + n];
+      }
+    }
+    return;
   }
 
   // ================================================= `_loss_fn` (src/update.py:90-167): wave w takes rows 2 w, 2 w + 1

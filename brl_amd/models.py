@@ -45,12 +45,48 @@ class ActorCritic(nn.Module):
         else:
             raise ValueError(model)
 
+    def _fair_forward(self, x):
+        """``actor(x), critic(x)`` of the FAIR network as ONE launch (brl_fair_forward: csrc/fair_chain.hpp's forward half, 16 rows per
+        workgroup) instead of ~25 — inference only (rollouts, evaluators: no autograd), fp32 on the GPU.  None: not applicable."""
+        if torch.is_grad_enabled() or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 480) \
+                or self.l[0].weight.dtype != torch.float32 or self.act not in (torch.relu, torch.tanh) \
+                or os.environ.get("BRL_FAIR_FORWARD", "1") == "0":
+            return None
+        from . import _capi
+        x = x.contiguous()
+        n = x.shape[0]
+        net = _capi.FairNet()
+        for l, lin in enumerate(self.l):
+            if not (lin.weight.is_contiguous() and lin.bias.is_contiguous()):
+                return None
+            net.w[l], net.b[l] = lin.weight.data_ptr(), lin.bias.data_ptr()
+        aw, cw, ab, cb = self.actor.weight, self.critic.weight, self.actor.bias, self.critic.bias
+        if cw.data_ptr() == aw.data_ptr() + 38 * 200 * 4 and cb.data_ptr() == ab.data_ptr() + 38 * 4 and aw.is_contiguous():
+            net.head_w, net.head_b = aw.data_ptr(), ab.data_ptr()       # (FusedFair's flat buffer: the heads are one [39, 200] already)
+        else:   # the two heads as one matrix: a buffer of this module, re-read per call (inside a captured graph: per replay)
+            hw = getattr(self, "_fair_head_w", None)
+            if hw is None or hw.device != x.device:
+                hw = self._fair_head_w = torch.empty((39, 200), dtype=torch.float32, device=x.device)
+                self._fair_head_b = torch.empty(39, dtype=torch.float32, device=x.device)
+            hb = self._fair_head_b
+            hw[:38].copy_(aw.detach()); hw[38:].copy_(cw.detach()); hb[:38].copy_(ab.detach()); hb[38:].copy_(cb.detach())
+            net.head_w, net.head_b = hw.data_ptr(), hb.data_ptr()
+        logits = torch.empty((n, 38), dtype=torch.float32, device=x.device)
+        value = torch.empty(n, dtype=torch.float32, device=x.device)
+        di = x.device.index if x.device.index is not None else torch.cuda.current_device()
+        _capi.check(_capi.lib().brl_fair_forward(di, net, x.data_ptr(), n, 0 if self.act is torch.relu else 1, logits.data_ptr(),
+                                                 value.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        return logits, value
+
     def forward(self, x):
         a = self.act
         if self.model.startswith("DeepMind"):
             for lin in self.body:
                 x = a(lin(x))
         else:
+            fast = self._fair_forward(x)
+            if fast is not None:
+                return fast
             inp = x
             L = self.l
             x = L[0](x); s1 = x

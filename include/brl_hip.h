@@ -55,7 +55,8 @@ const char *brl_last_error(void);
  *   removed (superseded forms): brl_ppo_loss_heads, brl_mb_gather, brl_relu_bwd_colsum, brl_adam_clip, brl_ppo_heads_loss,
  *     brl_adam_clip_gather (the multi-rank Adam: replaced by the two below);
  *   added: brl_adam_shard_norm, brl_adam_shard_apply (clip + Adam on a rank's slices of the bucketed flat buffers);
- *     brl_fair_chain, brl_mlp_gemm_group, brl_bias_finalize_rows (the FAIR network's step as five launches).  48 symbols. */
+ *     brl_fair_chain, brl_mlp_gemm_group, brl_bias_finalize_rows (the FAIR network's step as five launches), brl_fair_forward.
+ *     49 symbols. */
 int brl_version(void);
 
 /* BridgeBidding(dds_results_table_path)  — ppo.py:303, pgx.bridge_bidding.BridgeBidding.
@@ -488,6 +489,11 @@ typedef struct brl_fair_net {
 typedef struct brl_fair_work {
   float *inp, *dzs, *gates, *cat6, *x4, *dz0, *dz6, *dheads, *tiles, *partials, *gram_partials;
 } brl_fair_work;
+/* `actor(x), critic(x)` of the FAIR network alone (src/models.py:34-69 as called per env.step by src/roll_out.py:73-76 and the
+ * evaluators, src/evaluation.py:52-60): x float [rows,480] -> logits float [rows,38], value float [rows], ONE launch of the same
+ * kernel's forward half (16 rows per workgroup; any number of rows).  head_w = actor rows then the critic row, contiguous. */
+int brl_fair_forward(int device, const brl_fair_net *net, const float *x, int64_t rows, int act, float *logits, float *value,
+                     void *stream);
 int brl_fair_chain(int device, const brl_fair_net *net, const float *x0, const uint8_t *mask, const int32_t *action,
                    const float *old_value, const float *old_log_prob, const float *gae, const float *targets, int64_t batch,
                    float clip_eps, float vf_coef, float ent_coef, int masked, int value_clipping, int reward_scaling, int act,

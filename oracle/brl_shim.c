@@ -547,6 +547,49 @@ int brl_mlp_gemm_group(int device, int layout, int count, const float *const *a,
   }
   return BRL_OK;
 }
+/* brl_fair_forward on the host: src/models.py:34-69 written out, float64 accumulation (act: 0 ReLU, 1 tanh) */
+static void fair_lin(const float *w, const float *b, const double *x, int in, int out, double *y) {
+  for (int o = 0; o < out; o++) {
+    double a = b[o];
+    for (int i = 0; i < in; i++) a += (double)w[(int64_t)o * in + i] * x[i];
+    y[o] = a;
+  }
+}
+int brl_fair_forward(int device, const brl_fair_net *net, const float *x, int64_t rows, int act, float *logits, float *value, void *s) {
+  (void)device; (void)s;
+  if (!net || !x || !logits || !value || rows < 0 || (act != 0 && act != 1)) {
+    snprintf(g_err, sizeof(g_err), "bad argument: brl_fair_forward (oracle shim)");
+    return BRL_E_ARG;
+  }
+#define FAIR_ACT(v) (act == 0 ? ((v) > 0.0 ? (v) : 0.0) : tanh(v))
+  for (int64_t r = 0; r < rows; r++) {
+    double in0[480], cat[680], a[200], bb[200], sc[200], h[39];
+    for (int i = 0; i < 480; i++) in0[i] = x[r * 480 + i];
+    fair_lin(net->w[0], net->b[0], in0, 480, 200, sc);                      /* shortcut_1 = the pre-activation */
+    for (int i = 0; i < 200; i++) a[i] = FAIR_ACT(sc[i]);
+    for (int blk = 0; blk < 2; blk++) {                                     /* two residual blocks: layers 1-2, 3-4 */
+      fair_lin(net->w[1 + 2 * blk], net->b[1 + 2 * blk], a, 200, 200, bb);
+      for (int i = 0; i < 200; i++) bb[i] = FAIR_ACT(bb[i]);
+      fair_lin(net->w[2 + 2 * blk], net->b[2 + 2 * blk], bb, 200, 200, a);
+      for (int i = 0; i < 200; i++) { sc[i] = FAIR_ACT(a[i]) + sc[i]; a[i] = FAIR_ACT(sc[i]); }
+    }
+    fair_lin(net->w[5], net->b[5], sc, 200, 200, cat);                      /* (no activation) */
+    for (int i = 0; i < 480; i++) cat[200 + i] = in0[i];
+    fair_lin(net->w[6], net->b[6], cat, 680, 200, sc);
+    for (int i = 0; i < 200; i++) a[i] = FAIR_ACT(sc[i]);
+    for (int blk = 0; blk < 2; blk++) {                                     /* layers 7-8, 9-10 */
+      fair_lin(net->w[7 + 2 * blk], net->b[7 + 2 * blk], a, 200, 200, bb);
+      for (int i = 0; i < 200; i++) bb[i] = FAIR_ACT(bb[i]);
+      fair_lin(net->w[8 + 2 * blk], net->b[8 + 2 * blk], bb, 200, 200, a);
+      for (int i = 0; i < 200; i++) { sc[i] = FAIR_ACT(a[i]) + sc[i]; a[i] = FAIR_ACT(sc[i]); }
+    }
+    fair_lin(net->head_w, net->head_b, sc, 200, 39, h);
+    for (int i = 0; i < 38; i++) logits[r * 38 + i] = (float)h[i];
+    value[r] = (float)h[38];
+  }
+#undef FAIR_ACT
+  return BRL_OK;
+}
 int brl_bias_finalize_rows(int device, int nseg, const float *const *parts, const int64_t *cols, const int64_t *tiles,
                            float *const *out, int first_row_seg, const int32_t *row_index, void *s) {
   (void)device; (void)nseg; (void)parts; (void)cols; (void)tiles; (void)out; (void)first_row_seg; (void)row_index; (void)s;

@@ -2142,6 +2142,84 @@ def test_fused_fair_step_matches_numpy_restatement(activation, rscale, masked, c
     assert worst < 0.02 * cfg["lr"] and moved > 0.5 * cfg["lr"], (worst, moved, gn)
 
 
+@pytest.mark.parametrize("activation,n", [("relu", 16), ("relu", 1000), ("tanh", 333), ("relu", 8192)])
+def test_fair_forward_matches_float64(activation, n):
+    """brl_fair_forward (`actor(x), critic(x)` of the FAIR network, src/models.py:34-69, as one launch) — through the module's own
+    inference path (no autograd: ActorCritic._fair_forward) against the same module in float64 on the host, against the launch-by-launch
+    torch forward on the GPU, and against the oracle shim's float64 restatement of the entry point; with the heads as two separate
+    parameters (a fresh module) and as one [39, 200] block (what FusedFair's flat buffer makes of them)."""
+    import ctypes as C
+    import oracle
+    from brl_amd import _capi
+    from brl_amd.models import make_forward_pass
+    from oracle.binding import shim_path
+    fp = make_forward_pass(activation, "FAIR")
+    net = fp.init(3, device="cuda")
+    with torch.no_grad():
+        for q in net.parameters():
+            q.add_(torch.randn_like(q) * 0.05)          # (hk.Linear's zero biases would hide a bias mix-up)
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = (torch.rand((n, 480), device="cuda", generator=g) < 0.12).float()
+    with torch.no_grad():
+        lg, v = net(x)
+        os.environ["BRL_FAIR_FORWARD"] = "0"
+        try:
+            lg_t, v_t = net(x)
+        finally:
+            del os.environ["BRL_FAIR_FORWARD"]
+        ref = fp.init(3, device="cpu").double()
+        ref.load_state_dict({k: t.double().cpu() for k, t in net.state_dict().items()})
+        lg64, v64 = ref(x.double().cpu())
+    assert lg.shape == (n, 38) and v.shape == (n,)
+    scale = max(1.0, float(lg64.abs().max()))
+    assert float((lg.double().cpu() - lg64).abs().max()) < 2e-5 * scale and float((v.double().cpu() - v64).abs().max()) < 2e-5 * scale
+    assert float((lg - lg_t).abs().max()) < 2e-5 * scale and float((v - v_t).abs().max()) < 2e-5 * scale
+    # the heads as ONE block behind each other (FusedFair's flat layout): the zero-copy branch gives the same bits
+    hw = torch.cat([net.actor.weight.detach(), net.critic.weight.detach()], 0).contiguous()
+    hb = torch.cat([net.actor.bias.detach(), net.critic.bias.detach()], 0).contiguous()
+    net.actor.weight.data, net.critic.weight.data, net.actor.bias.data, net.critic.bias.data = hw[:38], hw[38:], hb[:38], hb[38:]
+    with torch.no_grad():
+        lg2, v2 = net(x)
+    assert torch.equal(lg, lg2) and torch.equal(v, v2)
+    # the oracle shim's restatement of the same entry point (float64 accumulation), a few rows
+    oracle.build()
+    shim = C.CDLL(shim_path())
+    m = min(n, 24)
+    fnet = _capi.FairNet()
+    keep = []
+    for l, lin in enumerate(net.l):
+        w, b = lin.weight.detach().cpu().contiguous().numpy(), lin.bias.detach().cpu().contiguous().numpy()
+        keep += [w, b]
+        fnet.w[l], fnet.b[l] = w.ctypes.data, b.ctypes.data
+    hwn, hbn, xn = hw.cpu().numpy(), hb.cpu().numpy(), x[:m].cpu().contiguous().numpy()
+    fnet.head_w, fnet.head_b = hwn.ctypes.data, hbn.ctypes.data
+    lo, vo = np.zeros((m, 38), np.float32), np.zeros(m, np.float32)
+    shim.brl_fair_forward.argtypes = [C.c_int, C.POINTER(_capi.FairNet), C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert shim.brl_fair_forward(0, fnet, xn.ctypes.data, m, 0 if activation == "relu" else 1, lo.ctypes.data, vo.ctypes.data, None) == 0
+    assert np.abs(lo - lg[:m].cpu().numpy()).max() < 2e-5 * scale and np.abs(vo - v[:m].cpu().numpy()).max() < 2e-5 * scale
+
+
+@pytest.mark.parametrize("model,activation", [("FAIR", "relu"), ("DeepMind", "tanh")])
+def test_graphed_rollout_follows_the_parameters_after_updates(model, activation, tmp_path):
+    """The architectures without an inference snapshot (FAIR; tanh) run `module(x)` inside the captured rollout, and the fused
+    update re-points the module's parameters into its flat buffers: after every update the replayed rollout must read the LIVE
+    parameters — scan step 0's values recomputed eagerly from traj.obs[0] with the loop's current parameters, four iterations."""
+    from brl_amd.train import train
+    cfg = dict(num_envs=1024, num_steps=8, minibatch_size=1024, update_epochs=2, total_timesteps=1024 * 8 * 4, graph_rollout=True,
+               evaluate=False, save_model=False, log_path=str(tmp_path), exp_name="stale", actor_model_type=model,
+               actor_activation=activation, lr=1e-2)
+    seen = []
+
+    def on_rollout(i, rs, traj, roll_out):
+        with torch.no_grad():
+            _, v = rs[0](traj.obs[0].float())
+        seen.append((float((v - traj.value[0]).abs().max()), float(v.abs().max())))
+
+    train(cfg, log=lambda s: None, on_rollout=on_rollout)
+    assert len(seen) == 4 and all(d <= 1e-6 * max(1.0, m) for d, m in seen), seen
+    assert abs(seen[0][1] - seen[-1][1]) > 1e-4      # (the parameters did move)
+
+
 @pytest.mark.parametrize("variant", ["relu", "tanh", "reward_scaling", "unmasked", "launches", "library_gemms"])
 def test_fused_fair_update_matches_eager(variant):
     """FusedFair vs the eager autograd path from the same start: ONE update of one epoch x 4 minibatches (the single step is checked
