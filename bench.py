@@ -693,6 +693,38 @@ def bench_secondary(torch, dev):
                             "what": "per iteration (ppo.py:366-381,461-484, self_play): jit_simple_evaluate + 3 x "
                                     "jit_simple_duplicate_evaluate; the full duplicate evaluation with statistics runs every "
                                     "num_eval_step iterations only and is not included"}
+    # ---- the same iteration with ppo.py's other architecture, actor_model_type = "FAIR" (src/models.py:34-69): rollout through
+    # brl_fair_forward (one launch per forward), update through FusedFair (brl_fair_chain + brl_mlp_gemm_group: five launches per step)
+    try:
+        fpf = make_forward_pass("relu", "FAIR")
+        netf = fpf.init(0, device=dev)
+        roll_f = brl_amd.make_roll_out(cfg32, env, fpf, fpf)
+        stf = env.init(0, num_envs=NUM_ENVS)
+        fbox = {"rs": (netf, None, stf, stf.observation, 0, 0)}
+
+        def do_roll_f():
+            fbox["rs"], fbox["traj"] = roll_f(fbox["rs"], netf)
+            return None
+        t_roll_f, _ = timed(do_roll_f, 3)
+        advf, tgtf = brl_amd.make_calc_gae(cfg32, fpf)(fbox["rs"], fbox["traj"])
+        upd_f = make_update_step(cfg32, fpf)
+        fu = {"rs": (netf, make_optimizer(cfg32, netf)) + tuple(fbox["rs"][2:])}
+
+        def do_update_f():
+            fu["rs"], info = upd_f(fu["rs"], fbox["traj"], advf, tgtf)
+            return info
+        t_upd_f, _ = timed(do_update_f, 3)
+        gf = fu["rs"][1].get("graphed")
+        out["config3_fair"] = {"workload": "configs[3]'s iteration with actor_model_type = FAIR (eleven 200-wide layers, residual; "
+                                           "0.60 M parameters), fp32",
+                               "rollout_ms": t_roll_f * 1e3, "update_ms": t_upd_f * 1e3, "ms_per_minibatch": t_upd_f / nmb * 1e3,
+                               "iteration_ms": (t_roll_f + t_upd_f) * 1e3 + phases["calc_gae"]["ms"],
+                               "path": type(gf).__name__ if gf else "eager: " + str(fu["rs"][1].get("graph_error")),
+                               "what": "rollout: brl_fair_forward per forward; update: brl_fair_chain (forward + loss + backward chain, "
+                                       "16 rows per workgroup) + brl_mlp_gemm_group (12 weight gradients) + finalize + clip / Adam"}
+        del roll_f, upd_f, fu, fbox
+    except Exception as e:   # (secondary: never in the way of the line)
+        out["config3_fair"] = {"error": repr(e)}
     it32 = phases["rollout_fp32"]["ms"] + phases["calc_gae"]["ms"] + phases["update"]["ms"]
     it16 = phases["rollout_bf16"]["ms"] + phases["calc_gae"]["ms"] + phases["update"]["ms"]
     full32 = it32 + phases["evaluators"]["ms"]
