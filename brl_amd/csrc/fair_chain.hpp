@@ -80,45 +80,6 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 __device__ __forceinline__ f32x4 row16_sum4(f32x4 v) { return f32x4{row16_sum(v.x), row16_sum(v.y), row16_sum(v.z), row16_sum(v.w)}; }
 
-// acc += X (LDS, 16 rows, row stride ldx, K columns) times the weights of output columns n0 .. n0 + 15:
-//   NN == false:  out[r][n] = sum_k X[r][k] W[n][k]   (forward: W row n, contiguous in k — one float4 per chunk)
-//   NN == true:   out[r][n] = sum_k X[r][k] W[k][n]   (backward: W column n — four dwords per chunk, 64 B per row and K group)
-// nmax: output columns that exist (indices are clamped; the caller drops the extra columns); X must be zero (or finite and
-// multiplied by a clamped weight that is dropped) beyond K up to the next multiple of 16.  K % 4 == 0 unless NN (rows clamped).
-template <bool NN, int K, int CH>
-__device__ __forceinline__ void tile_mac(f32x4 &acc, const float *X, const int ldx, const float *__restrict__ W, const int ldw,
-                                         const int n0, const int nmax, const int c, const int g) {
-  constexpr int NCH = (K + 15) / 16;
-  const int n = (n0 + c < nmax) ? n0 + c : nmax - 1;
-  const float *xrow = X + c * ldx + 4 * g;
-#pragma unroll 1
-  for (int j0 = 0; j0 < NCH; j0 += CH) {
-    f32x4 wv[CH];
-    // every weight fragment of the batch is requested before the first product waits for one (the scheduler would otherwise
-    // keep two loads in flight and pay an L2 round trip per 16 K: 163 us for the launch instead of ~90)
-#pragma unroll
-    for (int jj = 0; jj < CH; jj++) {
-      const int k0 = 16 * (j0 + jj) + 4 * g;
-      if (!NN) {
-        wv[jj] = ld4(W + (int64_t)n * ldw + ((k0 < K) ? k0 : 0));
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; s++) wv[jj][s] = W[(int64_t)((k0 + s < K) ? k0 + s : K - 1) * ldw + n];
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int jj = 0; jj < CH; jj++) {
-      const int k0 = 16 * (j0 + jj) + 4 * g;
-      f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (k0 < K) xv = ld4(xrow + 16 * (j0 + jj));
-#pragma unroll
-      for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[jj][s], xv[s], acc, 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
 // ---- products: a "job" = one 16-column output tile times <= 240 K indices, its weight fragments held in registers ---------------
 // Weight fragments are requested one job AHEAD of the MFMAs that use them (two register sets in alternation, also across the
 // workgroup barriers between layers: weights do not depend on activations) — issued together with the MFMAs of a tile they
@@ -258,21 +219,32 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
   int stamp_i = 0;
   (void)stamp_i;
   FAIR_STAMP(stamp_i++);
-  load_job(FP, job_fwd(N.w[0], OBS, 15, false), c, g);        // the first job's weights: requested before anything else
-
-  // ---- the observation rows -> LDS (and into the right block of cat6 = jnp.concatenate([x, input]), src/models.py:51)
-  for (int e = tid; e < R * (OBS / 4); e += NW * 64) {
-    const int r = e / (OBS / 4), q = e - r * (OBS / 4);
+  // ---- the observation rows -> LDS (and into the right block of cat6 = jnp.concatenate([x, input]), src/models.py:51): requested
+  // first (memory operations retire in order), then the first job's weights; the LDS images are cleared while both travel
+  constexpr int XP = (R * (OBS / 4) + NW * 64 - 1) / (NW * 64);      // 16-byte pieces per thread: 4 (the last one partly)
+  f32x4 xv[XP];
+#pragma unroll
+  for (int i = 0; i < XP; i++) {
+    const int e = tid + i * NW * 64, ec = (e < R * (OBS / 4)) ? e : 0;
+    const int r = ec / (OBS / 4), q = ec - r * (OBS / 4);
     const int64_t row = (TRAIN || row0 + r < B) ? row0 + r : B - 1;
-    const f32x4 v = ld4(A.x0 + row * OBS + 4 * q);
-    st4(X0 + r * LDX + 4 * q, v);
-    if (TRAIN) st4(O.cat6 + (row0 + r) * CAT + H + 4 * q, v);
+    xv[i] = ld4(A.x0 + row * OBS + 4 * q);
   }
+  load_job(FP, job_fwd(N.w[0], OBS, 15, false), c, g);
   for (int e = tid; e < R * LDH; e += NW * 64) {
     HD[e] = 0.f;
     if (TRAIN) DH[e] = 0.f;
   }
-  for (int e = tid; e < 3 * R * LDA; e += NW * 64) AB[0][e] = 0.f;     // (the pad columns 200..211 are never written again)
+  for (int e = tid; e < 3 * R * LDA / 4; e += NW * 64) st4(AB[0] + 4 * e, f32x4{0.f, 0.f, 0.f, 0.f});   // (pad columns 200..211: never written again)
+#pragma unroll
+  for (int i = 0; i < XP; i++) {
+    const int e = tid + i * NW * 64;
+    if (e < R * (OBS / 4)) {
+      const int r = e / (OBS / 4), q = e - r * (OBS / 4);
+      st4(X0 + r * LDX + 4 * q, xv[i]);
+      if (TRAIN) st4(O.cat6 + (row0 + r) * CAT + H + 4 * q, xv[i]);
+    }
+  }
   // the minibatch's advantage statistics (reward_scaling: src/update.py:31-44, jnp std = ddof 0) — every workgroup forms them
   // itself in the same fixed order: identical everywhere, no hand-off
   float adv_mean = 0.0f, adv_inv = 1.0f;
@@ -472,6 +444,12 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
   layer(a2, a1, 9, O.inp + 8 * BH, first_fwd(10));                                             // h9
   // (behind L10: the heads' product, then — across the loss — the first backward product's weights)
   const Job jheads = Job{N.wh, H, 13, 0, 16 * ((w < 3) ? w : 2), HD_NOUT, (w < 3) ? 1 : 0};      // (waves 3..7: a filler job)
+  // what the loss of this wave's two samples reads from global memory: requested two layers ahead of its use
+  PpoSampleIn smp[2];
+  if (TRAIN) {
+    smp[0] = ppo_sample_load(A.P, row0 + 2 * w, true, lane);
+    smp[1] = ppo_sample_load(A.P, row0 + 2 * w + 1, true, lane);
+  }
   layer_res(a1, a0, 10, O.gates + 3 * BH, nullptr, O.x4, false, jheads);                       // h10; x4 = h10 + x3 (a0)
   // heads = x4 Wh^T + bh: 39 columns = 3 tiles
   {
@@ -502,14 +480,34 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
     return;
   }
 
+  // (what the first backward product, dx = d(heads) Wh, reads from global memory — its K = 39 is three chunks, not worth a place in
+  //  the pipeline — travels while the loss is computed: the weight fragments of this wave's tiles w, w + 8 and their gate values)
+  f32x4 hw_[2][3], hg_[2];
+  {
+    const float *g3 = O.gates + 3 * BH;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int t = (w + 8 * i < NT) ? w + 8 * i : w, n = (16 * t + c < H) ? 16 * t + c : H - 1;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int k = 16 * j + 4 * g + q;
+          hw_[i][j][q] = N.wh[(int64_t)((k < HD_NOUT) ? k : HD_NOUT - 1) * H + n];
+        }
+      }
+      hg_[i] = ld4(g3 + grow + colc(16 * t));
+    }
+  }
+
   // ================================================= `_loss_fn` (src/update.py:90-167): wave w takes rows 2 w, 2 w + 1
   {
     PpoArgs P = A.P;
     P.dlogits = DH; P.dls = LDH; P.dvalue = DH + BRL_NUM_ACTIONS; P.dvs = LDH; P.illp = &illp_s[0][0];
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < 2; i++) {
       const int r = 2 * w + i;
-      const PpoSampleIn S = ppo_sample_load(A.P, row0 + r, true, lane);
+      const PpoSampleIn S = smp[i];
       const float lg = (lane < HD_NOUT) ? HD[r * LDH + lane] : 0.0f;
       const float v = HD[r * LDH + BRL_NUM_ACTIONS];
       const float adv = A.reward_scaling ? (S.gae - adv_mean) * adv_inv : S.gae;
@@ -569,16 +567,22 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
     }
     if (valid) colsum(v, col, T.lsum2);
   };
-  // dx = d(heads) Wh (K = 39: three chunks, not worth a place in the pipeline) -> a0; then dz10 = dx * act'(h10)
+  // dx = d(heads) Wh -> a0; then dz10 = dx * act'(h10)
   {
     const Then T{O.gates + 3 * BH, a1, O.dzs + 8 * BH, 10};
-    for (int t = w; t < NT; t += NW) {
-      const int col = 16 * t + 4 * g;
-      const f32x4 g2 = ld4(T.gate2 + grow + colc(16 * t));
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const bool valid = w + 8 * i < NT;
+      const int t = valid ? w + 8 * i : w, col = 16 * t + 4 * g;
       f32x4 acc = zero4;
-      tile_mac<true, HD_NOUT, 3>(acc, DH, LDH, N.wh, H, 16 * t, H, c, g);
-      if (col < H) st4(a0 + c * LDA + col, acc);
-      then_step(acc, g2, col, true, T);
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const f32x4 xv = ld4(DH + c * LDH + 16 * j + 4 * g);       // (columns 39..47 of DH are zero)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hw_[i][j][q], xv[q], acc, 0, 0, 0);
+      }
+      if (col < H && valid) st4(a0 + c * LDA + col, acc);
+      then_step(acc, hg_[i], col, valid, T);
     }
     __syncthreads();
     FAIR_STAMP(stamp_i++);
