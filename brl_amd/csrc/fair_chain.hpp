@@ -7,7 +7,8 @@
 // GEMMs + elementwise kernels) the step was bound by launch count (~70 x 4.7 us, profiles/r05/r05f_fair_step_timeline.txt).  Here
 // the activations of a row block never leave the CU (LDS), the 1.8 MB of weights stream from L2 (every workgroup reads all of
 // them: 64 x 24 x 160 KB per step, L2-resident), products are v_mfma_f32_16x16x4_f32 tiles (13 column tiles of 16 over 8 waves), and
-// what the weight-gradient products need afterwards — every layer's input and pre-activation gradient — is written out once:
+// what the weight-gradient products need afterwards — every layer's input and pre-activation gradient — is written out once
+// (k_fair_chain<true>; <false> = the forward half alone for rollouts / evaluators: brl_fair_forward):
 //   inp [9][B][200]  inputs of the square layers 1,2,3,4,5,7,8,9,10      dzs [9][B][200]  their pre-activation gradients
 //   cat6 [B][680] = [z5 | x0]   dz6, dz0, x4 [B][200]   dheads [B][40]   gates [4][B][200] = h2, h4, h8, h10 (activation outputs
 //   the backward re-reads)   tiles [11][B/16][200] + [B/16][39]: column sums of dz_l (l = 0..10) and of dheads per workgroup = the
@@ -82,8 +83,9 @@ __device__ __forceinline__ f32x4 row16_sum4(f32x4 v) { return f32x4{row16_sum(v.
 
 // ---- products: a "job" = one 16-column output tile times <= 240 K indices, its weight fragments held in registers ---------------
 // Weight fragments are requested one job AHEAD of the MFMAs that use them (two register sets in alternation, also across the
-// workgroup barriers between layers: weights do not depend on activations) — issued together with the MFMAs of a tile they
-// waited for an L2 round trip plus the CU's share of L2 bandwidth per tile: 141 us for the launch.
+// workgroup barriers between layers: weights do not depend on activations), one chunk between every four MFMAs of the current
+// job (slot_run below).  History of the launch at minibatch 1024 (profiles/r05/r05_experiments.txt section 15): loads and MFMAs
+// of a tile issued together 163 us, all loads of a tile first 141, a job ahead but in one burst 140, interleaved 114.
 constexpr int FCH = 15;                 // fragments per job: 15 x 16 K (13 for the 200-wide products: the last one half empty)
 struct Frag { f32x4 w[FCH]; };
 struct Job {                            // wave-uniform
