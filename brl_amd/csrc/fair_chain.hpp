@@ -141,8 +141,7 @@ __device__ __forceinline__ void load_chunk(Frag &F, const JobAddr &a) {
   }
 }
 template <int j>
-__device__ __forceinline__ void mac_chunk(f32x4 &acc, const Frag &F, const float *xrow) {
-  const f32x4 xv = (FAIR_EXP & 4) ? f32x4{1.f, 1.f, 1.f, 1.f} : ld4(xrow + 16 * j);
+__device__ __forceinline__ void mac_chunk(f32x4 &acc, const Frag &F, const f32x4 &xv) {
 #pragma unroll
   for (int s = 0; s < 4; s++) {
     if (FAIR_EXP & 1) acc[s] += F.w[j][s] * xv[s];
@@ -153,34 +152,40 @@ __device__ __forceinline__ void mac_chunk(f32x4 &acc, const Frag &F, const float
 // (fragments in `use`, loaded a slot ago).  All at once in front of the products, the eight waves of the workgroup — in step behind
 // every barrier — queued 104 KB at the CU's one vector-memory pipe (64 B per clock) and waited for it, then all multiplied while it
 // sat idle: 12-14 k cycles per 200 x 200 layer against 6.7 k of MFMA issue (in-kernel stamps, profiles/r05).
+// (the sample fragment of chunk j + 1 is read from LDS in front of chunk j's MFMAs: its latency sits under them)
 template <int j>
-__device__ __forceinline__ void slot_step(f32x4 &acc, const Frag &use, Frag &pre, const JobAddr &na, const int nch, const float *xrow) {
+__device__ __forceinline__ void slot_step(f32x4 &acc, const Frag &use, Frag &pre, const JobAddr &na, const int nch, const float *xrow,
+                                          f32x4 &xv) {
+  f32x4 xn = xv;
+  if (!(FAIR_EXP & 4) && (j + 1 < 13 || (j + 1 < FCH && nch > 13))) xn = ld4(xrow + 16 * (j + 1));
   if (j < 13 || na.nch > 13) load_chunk<j>(pre, na);
-  if (j < 13 || nch > 13) mac_chunk<j>(acc, use, xrow);
+  if (j < 13 || nch > 13) mac_chunk<j>(acc, use, xv);
   __builtin_amdgcn_sched_barrier(0);
+  xv = xn;
 }
 __device__ __forceinline__ void slot_run(f32x4 &acc, const Frag &use, Frag &pre, const Job &cur, const Job &nxt, const float *X,
                                          const int ldx, const int c, const int g) {
   const JobAddr na = job_addr(nxt, c, g);
   const float *xrow = X + c * ldx + 4 * g;
   const int nch = cur.nch;
+  f32x4 xv = (FAIR_EXP & 4) ? f32x4{1.f, 1.f, 1.f, 1.f} : ld4(xrow);
   __builtin_amdgcn_sched_barrier(0);
-  slot_step<0>(acc, use, pre, na, nch, xrow);
-  slot_step<1>(acc, use, pre, na, nch, xrow);
-  slot_step<2>(acc, use, pre, na, nch, xrow);
-  slot_step<3>(acc, use, pre, na, nch, xrow);
-  slot_step<4>(acc, use, pre, na, nch, xrow);
-  slot_step<5>(acc, use, pre, na, nch, xrow);
-  slot_step<6>(acc, use, pre, na, nch, xrow);
-  slot_step<7>(acc, use, pre, na, nch, xrow);
-  slot_step<8>(acc, use, pre, na, nch, xrow);
-  slot_step<9>(acc, use, pre, na, nch, xrow);
-  slot_step<10>(acc, use, pre, na, nch, xrow);
-  slot_step<11>(acc, use, pre, na, nch, xrow);
-  slot_step<12>(acc, use, pre, na, nch, xrow);
+  slot_step<0>(acc, use, pre, na, nch, xrow, xv);
+  slot_step<1>(acc, use, pre, na, nch, xrow, xv);
+  slot_step<2>(acc, use, pre, na, nch, xrow, xv);
+  slot_step<3>(acc, use, pre, na, nch, xrow, xv);
+  slot_step<4>(acc, use, pre, na, nch, xrow, xv);
+  slot_step<5>(acc, use, pre, na, nch, xrow, xv);
+  slot_step<6>(acc, use, pre, na, nch, xrow, xv);
+  slot_step<7>(acc, use, pre, na, nch, xrow, xv);
+  slot_step<8>(acc, use, pre, na, nch, xrow, xv);
+  slot_step<9>(acc, use, pre, na, nch, xrow, xv);
+  slot_step<10>(acc, use, pre, na, nch, xrow, xv);
+  slot_step<11>(acc, use, pre, na, nch, xrow, xv);
+  slot_step<12>(acc, use, pre, na, nch, xrow, xv);
   if (nch > 13 || na.nch > 13) {
-    slot_step<13>(acc, use, pre, na, nch, xrow);
-    slot_step<14>(acc, use, pre, na, nch, xrow);
+    slot_step<13>(acc, use, pre, na, nch, xrow, xv);
+    slot_step<14>(acc, use, pre, na, nch, xrow, xv);
   }
 }
 __device__ __forceinline__ void load_job(Frag &F, const Job &J, const int c, const int g) {     // (the very first job only)
