@@ -85,7 +85,7 @@ __device__ __forceinline__ f32x4 row16_sum4(f32x4 v) { return f32x4{row16_sum(v.
 // Weight fragments are requested one job AHEAD of the MFMAs that use them (two register sets in alternation, also across the
 // workgroup barriers between layers: weights do not depend on activations), one chunk between every four MFMAs of the current
 // job (slot_run below).  History of the launch at minibatch 1024 (profiles/r05/r05_experiments.txt section 15): loads and MFMAs
-// of a tile issued together 163 us, all loads of a tile first 141, a job ahead but in one burst 140, interleaved 114.
+// of a tile issued together 163 us, all loads of a tile first 141, a job ahead but in one burst 140, interleaved 114, the LDS reads a chunk ahead 108.
 constexpr int FCH = 15;                 // fragments per job: 15 x 16 K (13 for the 200-wide products: the last one half empty)
 struct Frag { f32x4 w[FCH]; };
 struct Job {                            // wave-uniform

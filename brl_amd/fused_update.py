@@ -642,9 +642,9 @@ class FusedFair(FusedStep):
     autograd) on the flat buffers.  Its 35 products are 80 MFLOP each, so the step is shaped by launch count.  FIVE launches:
     ``brl_fair_chain`` (csrc/fair_chain.hpp: forward, ``_loss_fn`` and the whole backward chain of 16 samples per workgroup — rows
     are independent up to the weight gradients; activations in LDS, weights streamed from L2 a job ahead of the fp32 MFMA tiles that
-    use them; 114 us), ``brl_mlp_gemm_group`` (the twelve weight gradients dz^T x as one launch, 21 us), ``brl_bias_finalize_rows``
+    use them; 108 us), ``brl_mlp_gemm_group`` (the twelve weight gradients dz^T x as one launch, 21 us), ``brl_bias_finalize_rows``
     (every bias gradient + this step's row of the statistics / Gram sums), clip + Adam through the two shard launches (one bucket =
-    the whole buffer); the log rows are formed once per update (``brl_ppo_stats_rows``).  Eight steps per hipGraph: 0.150 ms per
+    the whole buffer); the log rows are formed once per update (``brl_ppo_stats_rows``).  Eight steps per hipGraph: 0.147 ms per
     step at configs[3]'s sizes.  ``fair_chain=False`` (or a minibatch that is not a multiple of 16): the same step launch by launch
     (library products, ``brl_mlp_gemm`` GATE_COLSUM for the chain, ``brl_act_bwd_colsum``; ~70 launches x ~4.7 us = 0.35 ms); the
     autograd step both replace (GraphedMinibatch), which re-gathers the whole trajectory per epoch and copies every minibatch in:
