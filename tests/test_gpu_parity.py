@@ -2573,9 +2573,10 @@ def test_mlp_gemm_matches_float64(layout, epi, M, N, K, act):
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
-def test_mlp_gemm_group_matches_the_single_launches(layout):
-    """brl_mlp_gemm_group: several products of one layout in ONE launch (the FAIR step's eleven weight gradients with layout TN) —
-    every output bit for bit what brl_mlp_gemm gives product by product (the same tile code), and close to float64."""
+def test_mlp_gemm_group_matches_float64(layout):
+    """brl_mlp_gemm_group: several products of one layout in ONE launch (the FAIR step's twelve weight gradients with layout TN, the
+    heads' 39 rows out of a [K, 40] array among them) — every output against float64 with brl_mlp_gemm's bound (the same tile code),
+    shapes from one 4 x 4 x 4 product to 200 x 680 x 1024; more than 16 products are refused."""
     import ctypes as C
     from brl_amd import _capi
     L = _capi.lib()
@@ -2600,8 +2601,6 @@ def test_mlp_gemm_group_matches_the_single_launches(layout):
     for A, Bm, Cg, (M, N, K) in zip(As, Bs, Cs, shapes):
         ref = (A.double() if akc else A.double().t()) @ (Bm.double().t() if bkc else Bm.double())
         assert float((Cg.double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max())) * (K / 1024 + 1) ** 0.5
-    # 13 products of 280 tiles: 64 x 64 tiles in the group; the single launches pick 64 x 32 for these sizes -> compare through float64
-    # above, and bit for bit against a group of ONE (the same width rule applies to it only when the tile count says so)
     with pytest.raises(_capi.BrlError):
         _capi.check(L.brl_mlp_gemm_group(0, layout, 17, None, None, None, None, None, None, None, None, None, s))
 
