@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../brl_amd/csrc/mlp_gemm_x3.hpp"
+#include "../../brl_amd/csrc/mlp_gemm_x3w.hpp"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -36,6 +37,13 @@ static void launch_x3(const Case &c, const mg::Args &G, hipStream_t s) {
   else { printf("layout not instantiated\n"); exit(1); }
 #undef L
 }
+static bool launch_x3w(const Case &c, const mg::Args &G, hipStream_t s) {
+  const int tiles = ((G.M + 63) / 64) * ((G.N + 63) / 64);
+  if (!(c.akc && c.bkc)) return false;
+  if (c.epi == mg::EPI_BIAS_ACT) hipLaunchKernelGGL((mgw::k_gemm_x3w_nt<mg::EPI_BIAS_ACT>), dim3(tiles), dim3(mgw::THREADS), 0, s, G);
+  else hipLaunchKernelGGL((mgw::k_gemm_x3w_nt<mg::EPI_NONE>), dim3(tiles), dim3(mgw::THREADS), 0, s, G);
+  return true;
+}
 static void launch_f32(const Case &c, const mg::Args &G, hipStream_t s, int nb) {
   const int tiles = ((G.M + 63) / 64) * ((G.N + 32 * nb - 1) / (32 * nb));
 #define L(a, b, e) do { if (nb == 2) hipLaunchKernelGGL((mg::k_gemm64n<a, b, e, 2>), dim3(tiles), dim3(mg::THREADS), 0, s, G); \
@@ -50,7 +58,7 @@ static void launch_f32(const Case &c, const mg::Args &G, hipStream_t s, int nb) 
 int main(int argc, char **argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 5;
   const int pad = argc > 2 ? atoi(argv[2]) : 0;     // floats added to the operands' leading dimensions (L2 channel experiment)
-  printf("bf16x3: NPROD %d (3 accumulators)  EXP %d  ld pad %d\n", MGX_NPROD, MGX_EXP, pad);
+  printf("bf16x3: NPROD %d  EXP %d / x3w EXP %d NACC %d  ld pad %d\n", MGX_NPROD, MGX_EXP, MGW_EXP, MGW_NACC, pad);
   const Case cases[] = {
       {"NT 1024^3 uniform", true, true, 1024, 1024, 1024, mg::EPI_NONE, 0, 0},
       {"NT 1024^3 relu(N) x N/sqrt(K) +bias relu", true, true, 1024, 1024, 1024, mg::EPI_BIAS_ACT, 0, 1},
@@ -103,7 +111,8 @@ int main(int argc, char **argv) {
     G.dbg = ddbg;
     G2.dbg = nullptr;
 #endif
-    launch_x3(c, G, s);
+    const bool usew = getenv("X3W") && c.akc && c.bkc;
+    if (usew) launch_x3w(c, G, s); else launch_x3(c, G, s);
     launch_f32(c, G2, s, 2);
     CK(hipStreamSynchronize(s));
     std::vector<float> C((size_t)M * N), C2((size_t)M * N);
@@ -155,12 +164,12 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<double> t3, t32, t32n;
-    for (int i = 0; i < 20; i++) { launch_x3(c, G, s); launch_f32(c, G2, s, 2); launch_f32(c, G2, s, 1); }
+    for (int i = 0; i < 20; i++) { if (usew) launch_x3w(c, G, s); else launch_x3(c, G, s); launch_f32(c, G2, s, 2); launch_f32(c, G2, s, 1); }
     for (int r = 0; r < rounds; r++) {
       float ms;
       for (int which = 0; which < 3; which++) {
         CK(hipEventRecord(e0, s));
-        for (int i = 0; i < 200; i++) { if (which == 0) launch_x3(c, G, s); else launch_f32(c, G2, s, which == 1 ? 2 : 1); }
+        for (int i = 0; i < 200; i++) { if (which == 0) { if (usew) launch_x3w(c, G, s); else launch_x3(c, G, s); } else launch_f32(c, G2, s, which == 1 ? 2 : 1); }
         CK(hipEventRecord(e1, s));
         CK(hipStreamSynchronize(s));
         CK(hipEventElapsedTime(&ms, e0, e1));
@@ -171,7 +180,7 @@ int main(int argc, char **argv) {
     const double u3 = t3[t3.size() / 2], u32 = t32[t32.size() / 2], u32n = t32n[t32n.size() / 2];
     printf("%-42s %s  max|err| x3 %.3e f32 %.3e (ratio %.2f)  rms x3 %.3e f32 %.3e  max|ref| %.2f max sum|ab| %.1f%s\n"
            "    %-38s x3 %6.2f us (%6.1f TF fp32-equivalent)  |  exact fp32 64x64 %6.2f us  64x32 %6.2f us (%6.1f TF)\n",
-           c.name, ok ? "ok  " : "FAIL", e3, e32, e3 / fmax(e32, 1e-300), sqrt(q3 / cnt), sqrt(q32 / cnt), maxref, absdot,
+           usew ? "[x3w]" : c.name, ok ? "ok  " : "FAIL", e3, e32, e3 / fmax(e32, 1e-300), sqrt(q3 / cnt), sqrt(q32 / cnt), maxref, absdot,
            unstored ? "  NaN / unstored outputs / epilogue sums wrong!" : "", "", u3, 2.0 * M * N * K / (u3 * 1e-6) / 1e12, u32, u32n,
            2.0 * M * N * K / (fmin(u32, u32n) * 1e-6) / 1e12);
 #ifdef MG_TIMING
