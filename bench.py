@@ -136,7 +136,7 @@ def cpu_baseline(keys, values, budget_s: float = 12.0):
     `-O3 -march=native -fopenmp` for this leg (the parity tests keep their own -O2 -ffp-contract=off build), timed on
     this box's host cores: >= 3 warm-up calls, median of >= 10 timed calls, wall clock around a synchronous call.
     A restatement ("port"), NOT the JAX reference — see BASELINE.md §2.
-    Team size: every candidate (bounded by the box's CPU quota where one is set, else by the affinity mask) is judged on a
+    Team size: every candidate (bounded by 4 x the box's CPU quota where one is set, else by the affinity mask) is judged on a
     SUSTAINED run (>= 0.5 s and >= 10 rollouts, median); the full protocol then runs on the best two and the better one is
     reported; `sweep` carries the whole table, `suspect` is set when configs[1] runs below half of configs[0]'s rate."""
     try:
@@ -150,7 +150,10 @@ def cpu_baseline(keys, values, budget_s: float = 12.0):
         affinity = len(os.sched_getaffinity(0))
         quota, quota_src = cpu_quota()
         # BRL_CPU_TEAM_LIMIT: an explicit bound for experiments (the whole sweep is reported either way)
-        limit = int(os.environ.get("BRL_CPU_TEAM_LIMIT", 0)) or (min(affinity, max(1, math.ceil(quota))) if quota else affinity)
+        # (a team up to 4 x the quota still gains — the waits of one thread are another's turn: 64 threads on a 16-CPU quota ran
+        #  10.9 ms against 14.6 with 16 — beyond it the cgroup throttles the whole team: 87 ms with 128, 189 with 256;
+        #  profiles/r06/r06a_cgroup_and_cpu_sweep.txt)
+        limit = int(os.environ.get("BRL_CPU_TEAM_LIMIT", 0)) or (min(affinity, max(1, 4 * math.ceil(quota))) if quota else affinity)
         st = orc.init_random(NUM_ENVS, seed=0)
         box = {"draw": 0}
 
@@ -198,7 +201,7 @@ def cpu_baseline(keys, values, budget_s: float = 12.0):
         # a 64-fold larger batch on a larger team must not run BELOW half the rate of 128 tables on a handful of threads: if it
         # does, the team was throttled / over-subscribed on this box and the number is not a baseline
         suspect = bool(config0.get("value")) and value < 0.5 * config0["value"]
-        return {"value": value, "unit": "macro-steps/s", "cores": threads, "kind": "port", "config0": config0,
+        return {"value": value, "unit": "macro-steps/s", "cores": threads, "cpus_obtained": best["cpus_obtained"], "kind": "port", "config0": config0,
                 "cpu_model": cpu_model(), "flags": flags, "cpus_in_affinity_mask": affinity,
                 "cpu_quota": quota, "cpu_quota_source": quota_src, "team_limit": limit,
                 "sweep": sweep, "finals": finals, "suspect": suspect, "ms_per_rollout": med * 1e3,
@@ -623,7 +626,7 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks, dist=N
 # estimated cost (s) of each secondary leg on an MI355X box, first call included (graph capture, library heuristics): what
 # the budget check uses BEFORE a leg starts; measured values are reported beside them (secondary.legs_s)
 LEG_ESTIMATE_S = {"config2": 4.0, "config3_rollout_fp32": 4.0, "config3_calc_gae": 1.0, "config3_update": 8.0,
-                  "config3_update_bf16x3": 8.0, "config4_rehearsal": 8.0, "config3_evaluators": 8.0, "config3_fair": 12.0,
+                  "config4_rehearsal": 8.0, "config3_evaluators": 8.0, "config3_fair": 12.0,
                   "config3_rollout_bf16": 5.0}
 
 
@@ -802,19 +805,6 @@ def bench_secondary(torch, dev, budget_s: float = 60.0):
 
     leg("config3_evaluators", evaluators_leg)
 
-    # ---- the opt-in fp32-equivalent products on the bf16 matrix pipe (config key gemm_precision = "bf16x3": every fp32 operand
-    # as three bf16 planes, six products per K chunk, fp32 accumulators): its own line, never the headline update number
-    def bf16x3_leg():
-        from brl_amd.fused_update import gemm_precision_supported
-        if not gemm_precision_supported("bf16x3"):
-            raise RuntimeError("this library has no bf16x3 product")
-        update_leg("update_bf16x3", {"gemm_precision": "bf16x3"})
-        phases["update_bf16x3"]["dtype"] = "fp32 operands as 3 bf16 planes, 6 bf16 MFMA products, fp32 accumulation (opt-in)"
-        phases["update_bf16x3"]["roofline"]["what"] += "; the products run on the bf16 pipe: the fp32 peak is a yardstick here"
-
-    if os.environ.get("BRL_BENCH_BF16X3", "1") != "0":
-        leg("config3_update_bf16x3", bf16x3_leg, needs=("config3_calc_gae",))
-
     # ---- configs[4] rehearsal on ONE GPU: the compute side of a rank's minibatch step under a process group (world = 8
     # geometry: buckets, slices, the norm's partials, grad_scale), every collective replaced by a no-op with the same stream
     # ordering inside the step's graph
@@ -869,9 +859,6 @@ def bench_secondary(torch, dev, budget_s: float = 60.0):
         if "rollout_bf16" in phases:
             it16 = phases["rollout_bf16"]["ms"] + phases["calc_gae"]["ms"] + phases["update"]["ms"]
             c3.update(iteration_ms_bf16_rollout=it16, iteration_macro_steps_per_s_bf16_rollout=rows / (it16 * 1e-3))
-        if "update_bf16x3" in phases:
-            itx = phases["rollout_fp32"]["ms"] + phases["calc_gae"]["ms"] + phases["update_bf16x3"]["ms"]
-            c3.update(iteration_ms_bf16x3_update=itx)
     out["config3"] = c3
     out["legs_s"] = legs_s
     out["dropped"] = dropped

@@ -11,8 +11,8 @@
 #include <algorithm>
 #include <vector>
 
-#include "../../brl_amd/csrc/mlp_gemm_x3.hpp"
-#include "../../brl_amd/csrc/mlp_gemm_x3w.hpp"
+#include "mlp_gemm_x3.hpp"
+#include "mlp_gemm_x3w.hpp"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 

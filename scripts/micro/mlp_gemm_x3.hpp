@@ -27,7 +27,7 @@
 //     output columns of one row — 16-byte stores and gate loads; epilogues as in mlp_gemm.hpp.
 #pragma once
 
-#include "mlp_gemm.hpp"
+#include "../../brl_amd/csrc/mlp_gemm.hpp"
 
 namespace mgx {
 

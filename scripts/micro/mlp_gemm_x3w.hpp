@@ -17,7 +17,7 @@
 // Layouts: "KC" operands only in this file (the summation index contiguous: the forward pass, dz as dh's A operand).
 #pragma once
 
-#include "mlp_gemm.hpp"
+#include "../../brl_amd/csrc/mlp_gemm.hpp"
 #include "mlp_gemm_x3.hpp"
 
 namespace mgw {
