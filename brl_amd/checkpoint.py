@@ -37,6 +37,13 @@ def save_params(params: torch.nn.Module, path: str) -> None:
 
 
 def save_opt_state(opt_state: dict, path: str) -> None:
+    """Under ``grad_allreduce="sharded"`` Adam's moments are current on each rank's own slices only: every rank calls
+    ``opt_state["graphed"].gather_optimizer_state()`` first (a collective — this function, usually called by rank 0 alone, cannot);
+    a state with partial moments is refused rather than written."""
+    fused = opt_state.get("graphed")
+    if getattr(fused, "moments_partial", False):
+        raise RuntimeError("save_opt_state: Adam's moments are partial (grad_allreduce='sharded'): call "
+                           "opt_state['graphed'].gather_optimizer_state() on every rank first")
     tmp = path + ".tmp"
     torch.save(opt_state["opt"].state_dict(), tmp)
     os.replace(tmp, path)

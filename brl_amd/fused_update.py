@@ -10,24 +10,60 @@ from ._capture import quiet_gc
 from .roll_out import Transition
 
 
+_CAPTURE_GROUP = {}
+
+
+def _capture_group():
+    """The process group whose collectives are issued ONLY while a stream captures (one per process, created on first use — a
+    collective call: every rank builds its first fused step at the same point of update_step).  Why a group of its own:
+    ProcessGroupNCCL's watchdog thread polls the end events of EAGER collectives it has not yet seen complete (every 100 ms), and HIP
+    refuses the query of an event whose stream is capturing ("operation not permitted on an event last recorded in a capturing
+    stream": the watchdog throws, the process aborts — scripts/rccl_eager_then_capture_probe.py case F, profiles/r05/).  Round 5
+    fenced that with synchronize + 0.3 s of sleep: a probability.  A communicator that never carries an eager collective has
+    nothing in its watchdog's list, and the default group's stream — barriers, broadcasts, the evaluators' sums, the optimizer-state
+    gather — never captures.  The communicator is connected eagerly (no collective, no work item); RCCL's per-size set-up happens
+    inside a throw-away capture (FusedStep.__init__)."""
+    key = dist.get_world_size(), dist.get_rank()
+    if key not in _CAPTURE_GROUP:
+        g = dist.new_group(backend="nccl")
+        try:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            g._get_backend(dev).eager_connect_single_device(dev)
+        except Exception:   # (an older torch: the communicator is then created by the first captured collective)
+            pass
+        _CAPTURE_GROUP[key] = g
+    return _CAPTURE_GROUP[key]
+
+
 class _DistCollectives:
     """The three collectives of the multi-rank step on torch.distributed (backend "nccl" = RCCL over xGMI on MI355X; gloo in the
     CPU / one-GPU rehearsals).  ``capturable``: RCCL's collectives record into a hipGraph (probed: scripts/rccl_capture_probe.py),
-    gloo's copy through the host and cannot.  ``bench.py`` passes an object of the same shape whose collectives are no-ops with a
-    collective's stream edges (its one-GPU rehearsal of the step)."""
+    gloo's copy through the host and cannot.  While a stream captures the collectives go through ``_capture_group()``; issued
+    eagerly (``gather_optimizer_state``, the per-kernel-group strategy) through the default group.  ``bench.py`` passes an object of
+    the same shape whose collectives are no-ops with a collective's stream edges (its one-GPU rehearsal of the step)."""
 
     def __init__(self):
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.capturable = dist.get_backend() == "nccl"
+        self.capture_group = _capture_group() if self.capturable else None
+
+    def _group(self):
+        return self.capture_group if (self.capturable and torch.cuda.is_current_stream_capturing()) else None
 
     def all_reduce(self, t, async_op):
-        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._group(), async_op=async_op)
 
     def reduce_scatter(self, out, inp, async_op):      # out = this rank's slice OF inp (in place)
-        return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, async_op=async_op)
+        return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self._group(), async_op=async_op)
 
     def all_gather(self, out, inp, async_op):          # inp = this rank's slice OF out (in place)
-        return dist.all_gather_into_tensor(out, inp, async_op=async_op)
+        return dist.all_gather_into_tensor(out, inp, group=self._group(), async_op=async_op)
+
+    def agree(self, ok: bool, device) -> bool:
+        """True iff ``ok`` on EVERY rank (one eager 4-byte MIN all-reduce on the default group)"""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if self.capturable else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
 
 
 class FusedStep:
@@ -52,6 +88,37 @@ class FusedStep:
             raise ValueError("config['grad_allreduce'] must be 'sharded' or 'flat'")
         self.coll = collective if collective is not None else (_DistCollectives() if multi else None)
         self.rank = int(getattr(self.coll, "rank", 0)) if multi else 0
+        # Under a process group the construction is PHASED, with an agreement (MIN over ranks: _agree) after every phase that can
+        # fail on one rank alone — a rank that raised would otherwise leave for update_step's own 4-byte agreement while its peers
+        # sit in this constructor's 14.7 MB collectives: mismatched collectives, a hang until the RCCL timeout.  Every rank runs
+        # the same three agreements or raises at the same one.
+        #   phase 1   allocations, the flat buffers, the program, first launches of every kernel group — no collective   -> agree
+        #   phase 2   RCCL in the graph: a THROW-AWAY capture of the whole program (RCCL's lazy set-up happens while it records; no
+        #             eager collective ever touches the capture group)                                                  -> agree
+        #             then its one replay (every rank holds a valid graph: the collectives pair up);
+        #             other backends: the program once, eagerly
+        #   phase 3   the step's graphs                                                                                 -> agree
+        err = None
+        self._saved = None
+        try:
+            self._setup(log_capacity)
+        except Exception as e:
+            err = e
+            self._restore()
+        self._agree(err, "allocation / first launches")
+        self._capture_all()
+
+    def _restore(self):
+        """the warm-up and the captures run real steps on the dummy batch: parameters, moments and counters as they were"""
+        if self._saved is not None:
+            with torch.no_grad():
+                for t, q in zip((self.P, self.M, self.V, self.step, self.mb_index), self._saved):
+                    t.copy_(q)
+            self._saved = None
+
+    def _setup(self, log_capacity):
+        config, params, opt, device, multi = self.cfg, self.params, self.opt, self.dev, self.multi
+        _capi = self.capi
         if config.get("tuned_gemm", True):   # committed TunableOp solutions for the step's GEMM shapes (brl_amd/tuned): lookups only
             from . import tuned
             tuned.enable()
@@ -131,66 +198,89 @@ class FusedStep:
         want = config.get("collective_in_graph")
         self.in_graph = (not multi) or (bool(getattr(self.coll, "capturable", False)) if want is None else bool(want))
         self._works = {}
-        # warm-up and capture run real steps on the dummy batch: put parameters, moments and counters back afterwards
-        saved = [t.clone() for t in (self.P, self.M, self.V, self.step, self.mb_index)]
+        self.moments_partial = False    # "sharded": True once a step has run and gather_optimizer_state has not
         self.graph = self.graph_multi = self.segs = None
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side), torch.no_grad():
-                for _ in range(2):      # kernel groups only (allocator, library heuristics)
-                    for item in self.program:
-                        if item[0] == "k":
-                            item[1]()
-                # ... then the whole program once, collectives included (every rank builds its step at the same point of
-                # update_step, so they pair up): the communicator and RCCL's per-size set-up exist BEFORE a stream captures
-                self._run_program(True)
-                self._drain()
-            torch.cuda.current_stream().wait_stream(side)
-            if multi and self.in_graph and isinstance(self.coll, _DistCollectives):
-                # RCCL's stream becomes part of the capture.  ProcessGroupNCCL's watchdog thread polls the end events of EAGER
-                # collectives it has not yet seen complete (every 100 ms), and HIP refuses a query of an event whose stream is
-                # capturing ("operation not permitted on an event last recorded in a capturing stream": the watchdog throws, the
-                # process aborts — scripts/rccl_eager_then_capture_probe.py, profiles/r05/).  So: everything issued so far has
-                # finished, and the watchdog has had three periods to retire it, before a stream captures.
-                import time
-                torch.cuda.synchronize()
-                time.sleep(0.3)
-            from ._capture import graph_kwargs
-            gkw = graph_kwargs()
-            with quiet_gc():   # (_capture.py: no collector run while a stream captures)
-                if self.in_graph:
-                    self.graph = self._capture_steps(1, gkw)
-                    # ... and the same step K times in ONE graph: a replay boundary costs ~5 us (graph launch behind the last
-                    # kernel), the step ~0.23 ms; mb_index lives in device memory, so the K copies walk K minibatches
-                    self.graph_steps = int(config.get("update_graph_steps", 8))
-                    if self.graph_steps > 1:
-                        self.graph_multi = self._capture_steps(self.graph_steps, gkw)
-                else:
-                    pool = torch.cuda.graph_pool_handle()
-                    self.segs = []          # the program with every run of kernel groups replaced by its graph
-                    run = []
+        # warm-up and capture run real steps on the dummy batch: parameters, moments and counters are put back afterwards
+        self._saved = [t.clone() for t in (self.P, self.M, self.V, self.step, self.mb_index)]
+        self._side = torch.cuda.Stream()
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side), torch.no_grad():
+            for _ in range(2):      # kernel groups only (allocator, library heuristics)
+                for item in self.program:
+                    if item[0] == "k":
+                        item[1]()
+        torch.cuda.current_stream().wait_stream(self._side)
+        torch.cuda.synchronize()
 
-                    def close():
-                        if run:
-                            fns = list(run)
-                            g = torch.cuda.CUDAGraph()
-                            with torch.cuda.graph(g, pool=pool, **gkw), torch.no_grad():
-                                for fn in fns:
-                                    fn()
-                            self.segs.append(("g", g))
-                            run.clear()
-                    for item in self.program:
-                        if item[0] == "k":
-                            run.append(item[1])
-                        elif item[0] == "c":
-                            close()
-                            self.segs.append(item)
-                    close()
+    def _capture_all(self):
+        from ._capture import graph_kwargs
+        config, multi, side = self.cfg, self.multi, self._side
+        gkw = graph_kwargs()
+        try:
+            err = None
+            scratch = None
+            try:
+                if multi and self.in_graph:
+                    with quiet_gc():
+                        scratch = self._capture_steps(1, gkw)
+                else:
+                    with torch.cuda.stream(side), torch.no_grad():
+                        self._run_program(True)     # (single rank: a third warm-up; gloo: the collectives pair up eagerly)
+                        self._drain()
+                    torch.cuda.current_stream().wait_stream(side)
+            except Exception as e:
+                err = e
+            self._agree(err, "first pass of the program's collectives")
+            if scratch is not None:
+                scratch.replay()
+                torch.cuda.synchronize()
+                del scratch
+            try:
+                with quiet_gc():   # (_capture.py: no collector run while a stream captures)
+                    if self.in_graph:
+                        self.graph = self._capture_steps(1, gkw)
+                        # ... and the same step K times in ONE graph: a replay boundary costs ~5 us (graph launch behind the last
+                        # kernel), the step ~0.23 ms; mb_index lives in device memory, so the K copies walk K minibatches
+                        self.graph_steps = int(config.get("update_graph_steps", 8))
+                        if self.graph_steps > 1:
+                            self.graph_multi = self._capture_steps(self.graph_steps, gkw)
+                    else:
+                        pool = torch.cuda.graph_pool_handle()
+                        self.segs = []          # the program with every run of kernel groups replaced by its graph
+                        run = []
+
+                        def close():
+                            if run:
+                                fns = list(run)
+                                g = torch.cuda.CUDAGraph()
+                                with torch.cuda.graph(g, pool=pool, **gkw), torch.no_grad():
+                                    for fn in fns:
+                                        fn()
+                                self.segs.append(("g", g))
+                                run.clear()
+                        for item in self.program:
+                            if item[0] == "k":
+                                run.append(item[1])
+                            elif item[0] == "c":
+                                close()
+                                self.segs.append(item)
+                        close()
+            except Exception as e:
+                err = e
+            self._agree(err, "capture of the step")
         finally:
-            with torch.no_grad():
-                for t, q in zip((self.P, self.M, self.V, self.step, self.mb_index), saved):
-                    t.copy_(q)
+            self._restore()
+
+    def _agree(self, err, what):
+        """raises on EVERY rank if the phase failed on any (single rank: re-raises its own error)"""
+        agree = getattr(self.coll, "agree", None) if self.multi else None
+        ok = err is None
+        if agree is not None:
+            ok = agree(ok, self.dev)
+        if err is not None:
+            raise err
+        if not ok:
+            raise RuntimeError(f"FusedStep: {what} failed on another rank: no rank builds the fused step")
 
     def _capture_steps(self, k, gkw):
         g = torch.cuda.CUDAGraph()
@@ -295,6 +385,8 @@ class FusedStep:
 
     def run_steps(self, n: int):
         """the next n minibatch steps of the bound update"""
+        if self.allreduce_mode == "sharded" and n > 0:
+            self.moments_partial = True
         if self.in_graph:
             k = self.graph_steps if self.graph_multi is not None else 0
             while k and n >= k:
@@ -317,6 +409,7 @@ class FusedStep:
         calls this (a collective: two all-gathers per bucket) and ends with the complete moments, as in the replicated forms."""
         if self.allreduce_mode != "sharded":
             return
+        self.moments_partial = False
         r = self.rank
         for t in (self.M, self.V):
             for o, ln in zip(self.bucket_off, self.bucket_len):

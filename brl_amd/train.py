@@ -388,8 +388,10 @@ def train(config, log=print, on_rollout=None):
         if rank == 0:
             log(json.dumps(rec))
     fused = runner_state[1].get("graphed") if isinstance(runner_state[1], dict) else None
-    if config["save_model"] and hasattr(fused, "gather_optimizer_state"):
-        fused.gather_optimizer_state()   # (sharded Adam: every rank holds the moments of its own slices only — a collective)
+    if hasattr(fused, "gather_optimizer_state"):
+        # sharded Adam: every rank holds the moments of its own slices only — the runner_state this returns (and any checkpoint of
+        # it) carries complete moments; a collective, so unconditional: every rank is here
+        fused.gather_optimizer_state()
     if config["save_model"] and rank == 0:                                                            # ppo.py:550-570
         ckpt.save_params(runner_state[0], os.path.join(pool_dir, f"params-{i + 1:08}.pt"))
         ckpt.save_opt_state(runner_state[1], os.path.join(pool_dir, f"opt_state-{i + 1:08}.pt"))

@@ -271,6 +271,7 @@ def make_update_step(config, actor_forward_pass, optimizer=None):
                     graphed.params is not params or graphed.mbs != mbs or isinstance(graphed, FusedStep) != want_fused
                     or getattr(graphed, "world", 1) != world
                     or (isinstance(graphed, FusedStep) and graphed._log_cap < need_log))):   # e.g. minibatch 512: 5120 steps
+                prev = graphed
                 try:
                     graphed = fused_cls(config, params, opt, mbs, adv_f.device, world, log_capacity=need_log) if want_fused \
                         else GraphedMinibatch(config, actor_forward_pass, params, opt, mbs, adv_f.device)
@@ -283,7 +284,8 @@ def make_update_step(config, actor_forward_pass, optimizer=None):
                 if multi:
                     # every rank must issue the SAME collective sequence: a rank whose capture failed would run the eager path's
                     # one all-reduce per minibatch while the others run FusedMinibatch's collectives, and RCCL would hang
-                    # until its timeout.  Agree (MIN over ranks): all fused, or all eager.
+                    # until its timeout.  FusedStep's constructor already ends the same way on every rank (its phases agree,
+                    # fused_update.py); this MIN over ranks covers what can differ before it is entered.  All fused, or all eager.
                     ok = torch.tensor([1 if isinstance(graphed, FusedStep) else 0], dtype=torch.int32, device=adv_f.device)
                     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                     if int(ok.item()) == 0 and isinstance(graphed, FusedStep):
@@ -291,6 +293,10 @@ def make_update_step(config, actor_forward_pass, optimizer=None):
                         import warnings
                         warnings.warn("brl_amd.update: " + opt_state["graph_error"], RuntimeWarning)
                         graphed = False
+                    if graphed is False and isinstance(prev, FusedStep) and prev.moments_partial:
+                        # the step being replaced ran "sharded": Adam's moments are current on each rank's own slices only, and the
+                        # eager path's replicated Adam would diverge across ranks.  Every rank is here (the agreement above):
+                        prev.gather_optimizer_state()
                 opt_state["graphed"] = graphed
             if isinstance(graphed, FusedStep):
                 fused = graphed

@@ -100,6 +100,23 @@ def test_ppo_loop_with_every_collective_over_rccl_at_world_1():
     assert "mode flat" in lines[0] and "mode sharded" in lines[1]
 
 
+def test_capture_group_needs_no_sleep_between_an_eager_collective_and_a_capture(tmp_path):
+    """Round 5 fenced FusedStep's captures with synchronize + 0.3 s of sleep (an eager collective still in ProcessGroupNCCL's watchdog
+    list when RCCL's stream starts to capture aborts the process).  Round 6: the captured collectives have a process group of their
+    own (fused_update._capture_group) that never carries an eager one.  scripts/rccl_eager_then_capture_probe.py case I: twenty times
+    in one process an eager all-reduce on the default group, AT ONCE a 0.6 s capture with a collective inside — no synchronize, no
+    sleep; case J the same behind a throw-away capture (FusedStep's phase 2); case F (one group, no fence) is the control that
+    aborts where the runtime still behaves as in round 5."""
+    env = {k: v for k, v in os.environ.items() if k not in DROP}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", CASES="IJ", REPEAT="20")
+    out = tmp_path / "probe.txt"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "rccl_eager_then_capture_probe.py"), str(out)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    text = out.read_text()
+    assert "case I: survived" in text and "case J: survived" in text, text
+
+
 def test_bench_control_flow_over_rccl_at_world_1():
     """The N-rank control flow of `bench.py` (process-group set-up with the device bound, barriers, MAX over ranks of the step time,
     the per-rank records gathered with all_gather_object) really over RCCL with one peer (BRL_FORCE_DIST=1): what the driver's N > 1
