@@ -47,35 +47,58 @@ class ActorCritic(nn.Module):
 
     def _fair_forward(self, x):
         """``actor(x), critic(x)`` of the FAIR network as ONE launch (brl_fair_forward: csrc/fair_chain.hpp's forward half, 16 rows per
-        workgroup) instead of ~25 — inference only (rollouts, evaluators: no autograd), fp32 on the GPU.  None: not applicable."""
-        if torch.is_grad_enabled() or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 480) \
-                or self.l[0].weight.dtype != torch.float32 or self.act not in (torch.relu, torch.tanh) \
-                or os.environ.get("BRL_FAIR_FORWARD", "1") == "0":
+        workgroup) instead of ~25 — inference only (rollouts, evaluators: no autograd), fp32 on the GPU.  None = not applicable
+        (any shape, layout, device or alignment the entry point would refuse — the caller then runs the layers one by one)."""
+        if torch.is_grad_enabled() or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2) \
+                or self.act not in (torch.relu, torch.tanh) or os.environ.get("BRL_FAIR_FORWARD", "1") == "0":
+            return None
+        # the kernel's fixed geometry (src/models.py:34-69): 480 observation bits, eleven 200-wide layers (the seventh reads 200 + 480
+        # inputs), 38 + 1 head rows — all parameters fp32, contiguous, 16-byte aligned, on x's device
+        dev = x.device
+        ins = [480] + [200] * 5 + [680] + [200] * 4
+        if x.shape[1] != 480 or len(self.l) != 11 or self.actor.weight.shape != (38, 200) or self.critic.weight.shape != (1, 200):
+            return None
+        tensors = [self.actor.weight, self.actor.bias, self.critic.weight, self.critic.bias]
+        for lin, k in zip(self.l, ins):
+            if lin.weight.shape != (200, k) or lin.bias.shape != (200,):
+                return None
+            tensors += [lin.weight, lin.bias]
+        if any(t.device != dev or t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16 for t in tensors
+               if t is not self.critic.bias and t is not self.critic.weight):
             return None
         from . import _capi
         x = x.contiguous()
+        if x.data_ptr() % 16:
+            return None
         n = x.shape[0]
         net = _capi.FairNet()
         for l, lin in enumerate(self.l):
-            if not (lin.weight.is_contiguous() and lin.bias.is_contiguous()):
-                return None
             net.w[l], net.b[l] = lin.weight.data_ptr(), lin.bias.data_ptr()
         aw, cw, ab, cb = self.actor.weight, self.critic.weight, self.actor.bias, self.critic.bias
-        if cw.data_ptr() == aw.data_ptr() + 38 * 200 * 4 and cb.data_ptr() == ab.data_ptr() + 38 * 4 and aw.is_contiguous():
+        if cw.device == dev and cb.device == dev and cw.data_ptr() == aw.data_ptr() + 38 * 200 * 4 and cb.data_ptr() == ab.data_ptr() + 38 * 4:
             net.head_w, net.head_b = aw.data_ptr(), ab.data_ptr()       # (FusedFair's flat buffer: the heads are one [39, 200] already)
-        else:   # the two heads as one matrix: a buffer of this module, re-read per call (inside a captured graph: per replay)
+        else:   # the two heads as one matrix: a buffer of this module, rewritten when a head parameter has changed (its _version)
+            if cw.device != dev or cb.device != dev or cw.dtype != torch.float32 or cb.dtype != torch.float32:
+                return None
+            key = (dev, aw._version, cw._version, ab._version, cb._version, aw.data_ptr(), cw.data_ptr(), ab.data_ptr(), cb.data_ptr())
             hw = getattr(self, "_fair_head_w", None)
-            if hw is None or hw.device != x.device:
-                hw = self._fair_head_w = torch.empty((39, 200), dtype=torch.float32, device=x.device)
-                self._fair_head_b = torch.empty(39, dtype=torch.float32, device=x.device)
+            capturing = torch.cuda.is_current_stream_capturing()
+            if hw is None or hw.device != dev:
+                hw = self._fair_head_w = torch.empty((39, 200), dtype=torch.float32, device=dev)
+                self._fair_head_b = torch.empty(39, dtype=torch.float32, device=dev)
+                self._fair_head_key = None
             hb = self._fair_head_b
-            hw[:38].copy_(aw.detach()); hw[38:].copy_(cw.detach()); hb[:38].copy_(ab.detach()); hb[38:].copy_(cb.detach())
+            if capturing or getattr(self, "_fair_head_key", None) != key:   # (inside a captured graph: re-read per replay)
+                hw[:38].copy_(aw.detach()); hw[38:].copy_(cw.detach()); hb[:38].copy_(ab.detach()); hb[38:].copy_(cb.detach())
+                self._fair_head_key = None if capturing else key
             net.head_w, net.head_b = hw.data_ptr(), hb.data_ptr()
-        logits = torch.empty((n, 38), dtype=torch.float32, device=x.device)
-        value = torch.empty(n, dtype=torch.float32, device=x.device)
-        di = x.device.index if x.device.index is not None else torch.cuda.current_device()
-        _capi.check(_capi.lib().brl_fair_forward(di, net, x.data_ptr(), n, 0 if self.act is torch.relu else 1, logits.data_ptr(),
-                                                 value.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        logits = torch.empty((n, 38), dtype=torch.float32, device=dev)
+        value = torch.empty(n, dtype=torch.float32, device=dev)
+        di = dev.index if dev.index is not None else torch.cuda.current_device()
+        rc = _capi.lib().brl_fair_forward(di, net, x.data_ptr(), n, 0 if self.act is torch.relu else 1, logits.data_ptr(),
+                                          value.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        if rc != 0:       # refused (the documented fallback: the layers one by one), never an exception from an optimisation
+            return None
         return logits, value
 
     def forward(self, x):

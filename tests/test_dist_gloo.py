@@ -111,7 +111,7 @@ def _grad_step_worker(rank, world, port, out_dir):
                     dist.reduce_scatter_tensor(bucket[rank * ln:(rank + 1) * ln], bucket)
                 assert shim.brl_adam_shard_norm(0, ptr(g), ctypes.byref(geom), rank, rank + 1, f32(1.0 / world), ptr(part), ptr(step), None, None) == 0
                 per = npart // world
-                dist.all_gather_into_tensor(part, part[rank * per:(rank + 1) * per].clone())    # the partials of the other ranks' slices
+                dist.all_gather_into_tensor(part, part[rank * per:(rank + 1) * per])    # the partials of the other ranks' slices
                 lo, hi = rank, rank + 1
             assert not torch.isnan(part).any()
             assert shim.brl_adam_shard_apply(0, ptr(p), ptr(g), ptr(m), ptr(v), ctypes.byref(geom), lo, hi, ptr(part), ptr(step), f32(1e-3), None,
@@ -119,12 +119,12 @@ def _grad_step_worker(rank, world, port, out_dir):
             if mode == "sharded":
                 for b, ln in enumerate(lens):                                                   # parameters back, bucket by bucket, in place
                     bucket = p[offs[b]:offs[b] + world * ln]
-                    dist.all_gather_into_tensor(bucket, bucket[rank * ln:(rank + 1) * ln].clone())
+                    dist.all_gather_into_tensor(bucket, bucket[rank * ln:(rank + 1) * ln])
         if mode == "sharded":                                                                   # gather_optimizer_state
             for t_ in (m, v):
                 for b, ln in enumerate(lens):
                     bucket = t_[offs[b]:offs[b] + world * ln]
-                    dist.all_gather_into_tensor(bucket, bucket[rank * ln:(rank + 1) * ln].clone())
+                    dist.all_gather_into_tensor(bucket, bucket[rank * ln:(rank + 1) * ln])
         res[mode] = (p.clone(), m.clone(), v.clone(), float(norm))
     torch.save(res, os.path.join(out_dir, f"step{rank}.pt"))
     dist.barrier()

@@ -2115,6 +2115,10 @@ def test_fused_fair_step_matches_numpy_restatement(activation, rscale, masked, c
     cfg = dict(CFG, minibatch_size=B, update_epochs=1, lr=1e-3, reward_scaling=rscale, actor_illegal_action_mask=masked, fair_chain=chain)
     fp = make_forward_pass(activation, "FAIR")
     net = fp.init(4, device="cuda")
+    with torch.no_grad():   # hk.Linear's biases start at zero: a wrong bias index in the chain's forward would change nothing — perturb
+        gen = torch.Generator(device="cuda").manual_seed(11)   # EVERY parameter, the biases by ~0.1 (test_fair_forward does the same)
+        for q in net.parameters():
+            q.add_(torch.randn(q.shape, device="cuda", generator=gen) * (0.1 if q.dim() == 1 else 0.01))
     P0 = fair_params_of(net)
     flat = Transition(*[x.reshape((B,) + x.shape[2:]) for x in tb])
     gae64 = adv.reshape(-1).double().numpy()
