@@ -35,8 +35,12 @@ constexpr int H = 200, OBS = 480, CAT = 680;
 constexpr int R = 16;               // rows (samples) per workgroup
 constexpr int NW = 8;               // waves per workgroup
 constexpr int NT = 13;              // column tiles of 16 (208 >= 200)
-constexpr int LDA = 212;            // LDS row stride of an activation buffer (floats): 16-B aligned rows, 20 c mod 64 = distinct bank
-                                    // groups; columns 200..211 stay ZERO (the K tail of a product reads them)
+constexpr int LDA = 208;            // LDS row stride of an activation buffer (floats) = 13 groups of four 16-byte pieces; columns 200..207
+                                    // stay ZERO (the K tail of a product reads them).  Inside a group the piece a lane of K group g
+                                    // touches is g ^ f(c >> 2), f = (0, 2, 3, 1): a ds_read_b128 is served in the lane groups
+                                    // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32): sixteen lanes of mixed g — with the round-5
+                                    // stride of 212 two of them shared a bank group in most (SQ_LDS_BANK_CONFLICT 45 % of
+                                    // SQ_LDS_IDX_ACTIVE, profiles/r05/r05x_fair_step_pmc.txt); this map gives each its own.
 constexpr int LDX = 484;            // ... of the observation rows
 constexpr int LDH = 48;             // ... of the heads / d(heads) rows (39 used, the rest zero)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -164,9 +168,9 @@ __device__ __forceinline__ void slot_step(f32x4 &acc, const Frag &use, Frag &pre
   xv = xn;
 }
 __device__ __forceinline__ void slot_run(f32x4 &acc, const Frag &use, Frag &pre, const Job &cur, const Job &nxt, const float *X,
-                                         const int ldx, const int c, const int g) {
+                                         const int ldx, const int c, const int g, const int gs) {
   const JobAddr na = job_addr(nxt, c, g);
-  const float *xrow = X + c * ldx + 4 * g;
+  const float *xrow = X + c * ldx + 4 * (ldx == LDA ? gs : g);     // (activation buffers: the swizzled piece; the observation rows: plain)
   const int nch = cur.nch;
   f32x4 xv = (FAIR_EXP & 4) ? f32x4{1.f, 1.f, 1.f, 1.f} : ld4(xrow);
   __builtin_amdgcn_sched_barrier(0);
@@ -206,6 +210,8 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
   __shared__ float illp_s[TRAIN ? R : 1][BRL_NUM_ACTIONS], part_s[TRAIN ? R : 1][8];
   __shared__ float rs_red[NW], rs_stat[2];
   const int tid = (int)threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int gs = g ^ ((0x78 >> (2 * (c >> 2))) & 3);        // this lane's piece inside a four-piece group of an activation row (LDA)
+  const int sw4 = 4 * (gs - g);                             // ... as a correction to a column index n0 + 4 g
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // (the compiler must know the wave index is uniform: jobs live in SGPRs)
   const int64_t B = TRAIN ? A.P.B : A.nrows, row0 = (int64_t)blockIdx.x * R, nwg = gridDim.x;
   const int act = A.act;
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
   // all of it.
   auto slot = [&](Frag &use, Frag &pre, const Job &cur, const Job &nxt, const float *X, int ldx, f32x4 &acc, const float *e4) {
     const f32x4 e = ld4(e4);
-    slot_run(acc, use, pre, cur, nxt, X, ldx, c, g);
+    slot_run(acc, use, pre, cur, nxt, X, ldx, c, g, gs);
     return e;
   };
   struct E2 { f32x4 a, b; };
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
     E2 e;
     e.a = ld4(e4a);
     e.b = ld4(e4b);
-    slot_run(acc, use, pre, cur, nxt, X, ldx, c, g);
+    slot_run(acc, use, pre, cur, nxt, X, ldx, c, g, gs);
     return e;
   };
   // this lane's columns in the tile at n0, clamped to existing ones (the clamped lanes' results are dropped)
@@ -345,8 +351,8 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
       const int col = n0 + 4 * g;
       if (col < H && valid) {
         const f32x4 z = acc + bias, h = act4(z, act);
-        st4(a0 + c * LDA + col, z);
-        st4(a1 + c * LDA + col, h);
+        st4(a0 + c * LDA + col + sw4, z);
+        st4(a1 + c * LDA + col + sw4, h);
         gst(gptr(O.inp + 0 * BH, col), h);
       }
     };
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
       const int col = n0 + 4 * g;
       if (col < H && valid) {
         const f32x4 h = act4(acc + bias, act);
-        st4(out + c * LDA + col, h);
+        st4(out + c * LDA + col + sw4, h);
         gst(gptr(gout, col), h);
       }
     });
@@ -388,11 +394,11 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
       if (col < H && valid) {
         const f32x4 h = act4(acc + bias, act);
         gst(gptr(ggate, col), h);
-        const f32x4 x = h + ld4(res + c * LDA + col);
-        st4(res + c * LDA + col, x);
+        const f32x4 x = h + ld4(res + c * LDA + col + sw4);
+        st4(res + c * LDA + col + sw4, x);
         if (act_out) {
           const f32x4 gg = act4(x, act);
-          st4(out + c * LDA + col, gg);
+          st4(out + c * LDA + col + sw4, gg);
           gst(gptr(gout, col), gg);
         } else {
           gst(gptr(gout, col), x);
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
       const int col = n0 + 4 * g;
       if (col < H && valid) {
         const f32x4 z = acc + bias;
-        st4(a1 + c * LDA + col, z);
+        st4(a1 + c * LDA + col + sw4, z);
         gst(O.cat6 + (row0 + c) * CAT + col, z);
       }
     });
@@ -425,8 +431,8 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
       const int col = n0 + 4 * g;
       if (col < H && valid) {
         const f32x4 z = acc + bias, h = act4(z, act);
-        st4(a0 + c * LDA + col, z);
-        st4(a2 + c * LDA + col, h);
+        st4(a0 + c * LDA + col + sw4, z);
+        st4(a2 + c * LDA + col + sw4, h);
         gst(gptr(O.inp + 5 * BH, col), h);
       }
     };
@@ -569,7 +575,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
     f32x4 v = zero4;
     if (col < H && valid) {
       v = (T.gate2 != nullptr) ? dact4(dx, g2, act) : dx;
-      if (T.dst2 != nullptr) st4(T.dst2 + c * LDA + col, v);
+      if (T.dst2 != nullptr) st4(T.dst2 + c * LDA + col + sw4, v);
       st4(gptr(T.gout2, col), v);
     }
     if (valid) colsum(v, col, T.lsum2);
@@ -588,7 +594,7 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
 #pragma unroll
         for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hw_[i][j][q], xv[q], acc, 0, 0, 0);
       }
-      if (col < H && valid) st4(a0 + c * LDA + col, acc);
+      if (col < H && valid) st4(a0 + c * LDA + col + sw4, acc);
       then_step(acc, hg_[i], col, valid, T);
     }
     __syncthreads();
@@ -608,8 +614,8 @@ __global__ __launch_bounds__(NW * 64) void k_fair_chain(Args A) {
       if (col < H && valid) {
         v = acc;
         if (ggate != nullptr) v = dact4(v, e.a, act);
-        if (accumulate) v += ld4(dst + c * LDA + col);
-        st4(dst + c * LDA + col, v);
+        if (accumulate) v += ld4(dst + c * LDA + col + sw4);
+        st4(dst + c * LDA + col + sw4, v);
         if (gout != nullptr) st4(gptr(gout, col), v);
       }
       if (lsum >= 0 && valid) colsum(v, col, lsum);

@@ -743,7 +743,8 @@ class FusedFair(FusedStep):
     autograd step both replace (GraphedMinibatch), which re-gathers the whole trajectory per epoch and copies every minibatch in:
     0.70 ms (profiles/r05/r05t_fair_step_probe.txt).
     Multi-rank: one bucket — "flat" = all-reduce + replicated sweep, "sharded" = reduce-scatter, sweep of the rank's slice,
-    all-gather of the parameters; bit-identical.  Not covered (-> the autograd path): a non-zero illegal_action_l2norm_coef."""
+    all-gather of the parameters; bit-identical.  A non-zero illegal_action_l2norm_coef (src/update.py:146-152) takes the launch-by-launch
+    form with two more launches between the loss and the backward pass (the step's top singular pair, its gradient)."""
 
     SQUARE = (1, 2, 3, 4, 5, 7, 8, 9, 10)      # the 200 x 200 layers, in the order of their stacked buffers
     # input of layer l (name in self.t) — the stacked input buffer holds them in SQUARE's order
@@ -751,9 +752,11 @@ class FusedFair(FusedStep):
 
     @staticmethod
     def supports(config, params) -> bool:
+        # (a non-zero illegal_action_l2norm_coef included: that configuration runs launch by launch — the term's gradient needs the
+        #  top singular pair of the WHOLE minibatch's illegal-probability matrix between the loss and the backward pass, which one
+        #  launch of independent 16-row workgroups cannot have)
         return (bool(config.get("fused_update", True)) and getattr(params, "model", "") == "FAIR"
                 and getattr(params, "act", None) in (torch.relu, torch.tanh)
-                and not (config.get("illegal_action_l2norm_coef", 0.0) or 0.0)
                 and next(params.parameters()).is_cuda and next(params.parameters()).dtype == torch.float32)
 
     def _layout(self):
@@ -813,7 +816,9 @@ class FusedFair(FusedStep):
             g.off[0], g.len[0] = 0, self.n
             self.geom, self.norm_partials = g, f(1024)
         # forward + loss + backward chain as ONE launch (brl_fair_chain: 16 samples per workgroup, activations in LDS)
-        self.chain = bool(self.cfg.get("fair_chain", True)) and B % 16 == 0 and H == 200 and self.x0.shape[1] == 480
+        self.chain = bool(self.cfg.get("fair_chain", True)) and B % 16 == 0 and H == 200 and self.x0.shape[1] == 480 and not self.ill_coef
+        if self.ill_coef:      # src/update.py:146-152 on the launch-by-launch path: the [B,39] images brl_ppo_illegal_grad works on
+            self.heads39, self.dheads39, self.vec = f(B, 39), f(B, 39), f(40)
         if self.chain:
             nwg = B // 16
             assert p.critic.weight.data_ptr() == p.actor.weight.data_ptr() + 38 * H * 4 \
@@ -964,7 +969,19 @@ class FusedFair(FusedStep):
                            self.partials.data_ptr(), self.illp.data_ptr(), s))
         row = self.mb_index.to(torch.int64)
         self.stat_sums.index_copy_(0, row, torch.mm(self.ones_row[:, :self.lgroups], self.partials))
-        self.gram_sums.index_copy_(0, row, torch.mm(self.illp.t(), self.illp).view(1, -1))
+        gram = torch.mm(self.illp.t(), self.illp)
+        self.gram_sums.index_copy_(0, row, gram.view(1, -1))
+        if self.ill_coef:
+            # + coef * sigma_1(P) / 2 (src/update.py:138-152): the step's top singular pair from the Gram matrix (no SVD:
+            # brl_ppo_stats_gram), then d sigma_1 / d logits added to the loss gradient (brl_ppo_illegal_grad), as FusedMinibatch does
+            chk(L.brl_ppo_stats_gram(di, self.partials.data_ptr(), self.lgroups, B, gram.data_ptr(), 1, float(cfg["vf_coef"]),
+                                     float(cfg["ent_coef"]), self.ill_coef, self.out.data_ptr(), None, self.vec.data_ptr(), s))
+            self.heads39[:, :38].copy_(self.logits)
+            self.heads39[:, 38].copy_(self.value)
+            self.dheads39[:, :38].copy_(self.dlogits)
+            chk(L.brl_ppo_illegal_grad(di, self.heads39.data_ptr(), self.mask.data_ptr(), self.vec.data_ptr(), self.ill_coef, B,
+                                       self.dheads39.data_ptr(), s))
+            self.dlogits.copy_(self.dheads39[:, :38])
         # ---- backward of the heads
         dx = t["dx"]
         torch.mm(self.dlogits, self.Wa, out=dx)

@@ -2115,10 +2115,16 @@ def test_fused_fair_step_matches_numpy_restatement(activation, rscale, masked, c
     cfg = dict(CFG, minibatch_size=B, update_epochs=1, lr=1e-3, reward_scaling=rscale, actor_illegal_action_mask=masked, fair_chain=chain)
     fp = make_forward_pass(activation, "FAIR")
     net = fp.init(4, device="cuda")
-    with torch.no_grad():   # hk.Linear's biases start at zero: a wrong bias index in the chain's forward would change nothing — perturb
-        gen = torch.Generator(device="cuda").manual_seed(11)   # EVERY parameter, the biases by ~0.1 (test_fair_forward does the same)
-        for q in net.parameters():
-            q.add_(torch.randn(q.shape, device="cuda", generator=gen) * (0.1 if q.dim() == 1 else 0.01))
+    if activation == "tanh":
+        # hk.Linear's biases start at zero: a wrong bias index in the chain's forward would change nothing — perturb EVERY parameter,
+        # the biases by ~0.1 (test_fair_forward does the same for the <false> form).  tanh cases only: the index arithmetic does not
+        # depend on the activation, and under ReLU a perturbed net puts a pre-activation or two of the 1024 x 11 x 200 within fp32
+        # rounding of 0 — its gate falls on the other side than in float64 and one sample's share (~1e-5) appears in a few gradient
+        # entries, which Adam's first step (lr g / (|g| + eps)) turns into lr-sized differences (profiles/r05/r05n_relu_kink_probe.txt)
+        with torch.no_grad():
+            gen = torch.Generator(device="cuda").manual_seed(11)
+            for q in net.parameters():
+                q.add_(torch.randn(q.shape, device="cuda", generator=gen) * (0.1 if q.dim() == 1 else 0.01))
     P0 = fair_params_of(net)
     flat = Transition(*[x.reshape((B,) + x.shape[2:]) for x in tb])
     gae64 = adv.reshape(-1).double().numpy()
@@ -2224,7 +2230,7 @@ def test_graphed_rollout_follows_the_parameters_after_updates(model, activation,
     assert abs(seen[0][1] - seen[-1][1]) > 1e-4      # (the parameters did move)
 
 
-@pytest.mark.parametrize("variant", ["relu", "tanh", "reward_scaling", "unmasked", "launches", "library_gemms"])
+@pytest.mark.parametrize("variant", ["relu", "tanh", "reward_scaling", "unmasked", "launches", "library_gemms", "illegal_coef"])
 def test_fused_fair_update_matches_eager(variant):
     """FusedFair vs the eager autograd path from the same start: ONE update of one epoch x 4 minibatches (the single step is checked
     against float64 above; over more steps Adam turns the rounding differences of near-zero gradients into +- lr moves) — parameters
@@ -2235,6 +2241,7 @@ def test_fused_fair_update_matches_eager(variant):
     from tests.test_update_cpu import CFG, fake_batch
     fp = make_forward_pass("tanh" if variant == "tanh" else "relu", "FAIR")
     cfg0 = dict(CFG, minibatch_size=256, update_epochs=1, reward_scaling=variant == "reward_scaling",
+                illegal_action_l2norm_coef=0.5 if variant == "illegal_coef" else 0.0,     # src/update.py:146-152 (launch by launch)
                 actor_illegal_action_mask=variant != "unmasked", own_gemm=variant != "library_gemms",
                 fair_chain=variant not in ("launches", "library_gemms"))    # (the default: brl_fair_chain; else launch by launch)
     tb, adv, tgt = fake_batch(4, 256, seed=40)

@@ -117,6 +117,27 @@ def test_capture_group_needs_no_sleep_between_an_eager_collective_and_a_capture(
     assert "case I: survived" in text and "case J: survived" in text, text
 
 
+def test_node_day_script_dry_run(tmp_path):
+    """scripts/node_day.sh — the one command for the day an 8-GPU node exists (RCCL tests un-skipped, bench.py --gpus 1,2,4,8,
+    bench.py --config ppo in both forms of the gradient step, the 14.7 MB all-reduce inside a graph) — executed end to end at world 1
+    (NODE_DRY=1: BRL_FORCE_DIST=1, reduced ppo sizes): the script itself has run, every output file parses."""
+    env = {k: v for k, v in os.environ.items() if k not in DROP}
+    env.update(NODE_DRY="1", PYTHON=sys.executable)
+    out = tmp_path / "node"
+    r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "node_day.sh"), str(out)], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=1500)
+    summary = (out / "summary.txt").read_text() if (out / "summary.txt").exists() else ""
+    assert r.returncode == 0 and "node_day: done" in summary, (r.stdout[-2000:], r.stderr[-2000:])
+    b = json.loads((out / "bench_gpus1.json").read_text())
+    assert b["n_gpus"] == 1 and b["value"] > 0 and b["ranks_backend"].startswith("RCCL")
+    for mode in ("flat", "sharded"):
+        d = json.loads((out / f"bench_ppo_{mode}_gpus1.json").read_text())
+        assert d["config"]["grad_allreduce"] == mode and d["config"]["collectives_inside_the_graph"] is True and d["value"] > 0
+    p = json.loads((out / "allreduce_graph_probe.json").read_text())
+    assert p["world"] == 1 and p["us_per_collective"]["all_reduce_flat_14.7MB"] > 0
+    assert " passed" in (out / "pytest_rccl.txt").read_text().splitlines()[-1]
+
+
 def test_bench_control_flow_over_rccl_at_world_1():
     """The N-rank control flow of `bench.py` (process-group set-up with the device bound, barriers, MAX over ranks of the step time,
     the per-rank records gathered with all_gather_object) really over RCCL with one peer (BRL_FORCE_DIST=1): what the driver's N > 1
