@@ -138,6 +138,21 @@ def test_node_day_script_dry_run(tmp_path):
     assert " passed" in (out / "pytest_rccl.txt").read_text().splitlines()[-1]
 
 
+def test_peer_pointer_optimizer_prototype_two_processes_one_gpu(tmp_path):
+    """scripts/micro/peer_adam.hip ("what comes next": the gradient collective fused into the optimizer launches — every
+    rank maps its peers' gradient / parameter buffers with hipIpcOpenMemHandle, reduces ITS slice straight from them, runs clip + Adam on
+    it and stores the new parameters into every peer; three monotone flag words per peer instead of collective kernels and
+    cross-stream edges).  A prototype outside the library, never a default: this is its functional proof — two processes on the one
+    GPU, three steps: no wait times out, both ranks end with bit-identical parameters equal to a float64 restatement, the moments
+    live on the owner's slice only."""
+    env = {k: v for k, v in os.environ.items() if k not in DROP}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = tmp_path / "peer.txt"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "peer_adam_probe.py"), "2", str(1 << 20), str(out)], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and out.read_text().strip().endswith("PASS"), (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_bench_control_flow_over_rccl_at_world_1():
     """The N-rank control flow of `bench.py` (process-group set-up with the device bound, barriers, MAX over ranks of the step time,
     the per-rank records gathered with all_gather_object) really over RCCL with one peer (BRL_FORCE_DIST=1): what the driver's N > 1
