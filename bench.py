@@ -627,7 +627,7 @@ def bench_rollout(args, torch, dev, rank, world, barrier, max_over_ranks, dist=N
 # the budget check uses BEFORE a leg starts; measured values are reported beside them (secondary.legs_s)
 LEG_ESTIMATE_S = {"config2": 4.0, "config3_rollout_fp32": 4.0, "config3_calc_gae": 1.0, "config3_update": 8.0,
                   "config4_rehearsal": 8.0, "config3_evaluators": 8.0, "config3_fair": 12.0,
-                  "config3_rollout_bf16": 5.0}
+                  "config3_rollout_bf16": 5.0, "config3_rollout_fp32_bf16x3": 4.0}
 
 
 def bench_secondary(torch, dev, budget_s: float = 60.0):
@@ -694,8 +694,8 @@ def bench_secondary(torch, dev, budget_s: float = 60.0):
     keep = {}
 
     # ---- configs[3]: one ppo.py iteration = roll_out + calc_gae + 10-epoch update_step (ppo.py:466-479)
-    def rollout_leg(label, dt):
-        cfg = dict(cfg32, inference_dtype=dt)
+    def rollout_leg(label, dt, gemm=None):
+        cfg = dict(cfg32, inference_dtype=dt, inference_gemm=gemm)
         roll_out = brl_amd.make_roll_out(cfg, env, fp, fp)
         st = env.init(0, num_envs=NUM_ENVS)
         box = {"rs": (team1, None, st, st.observation, 0, 0)}
@@ -705,16 +705,21 @@ def bench_secondary(torch, dev, budget_s: float = 60.0):
             return None
         t_roll, _ = timed(do_roll, 3)
         flop = 4 * rows * fwd_flop
-        peak = 157.3 if dt is None else 2500.0
+        peak = 157.3 if (dt is None and gemm is None) else 2500.0
+        if gemm is not None:
+            flop_exec = 6 * flop      # six bf16 products per fp32 product: what the matrix pipe executes, against the bf16 peak
         phases["rollout_" + label] = {
             "ms": t_roll * 1e3, "macro_steps_per_s": rows / t_roll, "raw_env_steps_per_s": 4 * rows / t_roll,
-            "gemm_tflops": flop / t_roll / 1e12, "mfma_peak_tflops": peak, "mfma_frac": flop / t_roll / 1e12 / peak,
-            "dtype": "fp32 inference (the reference's precision)" if dt is None else
+            "gemm_tflops": flop / t_roll / 1e12, "mfma_peak_tflops": peak,
+            "mfma_frac": (flop_exec if gemm is not None else flop) / t_roll / 1e12 / peak,
+            "dtype": ("fp32 inference (the reference's precision)" if gemm is None else
+                      "fp32 inference, hidden layers on brl_mlp_gemm_x3 (fp32 operands as three exact bf16 pieces, six bf16 MFMA products, "
+                      "fp32 accumulation: 0.07-0.44 x the exact kernel's error vs float64; opt-in: inference_gemm = 'bf16x3')") if dt is None else
                      "bf16 inference: NARROWER than the reference's fp32 — opt-in (inference_dtype), never the default",
             "how": "hipGraph-replayed macro-steps: 4 forwards + 4 brl_policy_step_ex launches each (competitive mode)"
                    + ("" if dt is None else "; hidden layers on the library's own bf16 kernel (brl_linear_act), the heads' share inside "
                       "the last layer's launch (brl_linear_act_heads), summed by the sub-step launch")}
-        if dt is None:
+        if dt is None and gemm is None:
             keep["rs32"], keep["traj32"] = box["rs"], box["traj"]
 
     leg("config3_rollout_fp32", lambda: rollout_leg("fp32", None))
@@ -844,6 +849,7 @@ def bench_secondary(torch, dev, budget_s: float = 60.0):
                                "what": "rollout: brl_fair_forward per forward; update: brl_fair_chain (forward + loss + backward chain, "
                                        "16 rows per workgroup) + brl_mlp_gemm_group (12 weight gradients) + finalize + clip / Adam"}
 
+    leg("config3_rollout_fp32_bf16x3", lambda: rollout_leg("fp32_bf16x3", None, "bf16x3"))
     leg("config3_fair", fair_leg)
     leg("config3_rollout_bf16", lambda: rollout_leg("bf16", "bf16"))
 
@@ -856,6 +862,9 @@ def bench_secondary(torch, dev, budget_s: float = 60.0):
             full32 = it32 + phases["evaluators"]["ms"]
             c3.update(evaluators_ms=phases["evaluators"]["ms"], iteration_ms_fp32_full=full32,
                       iteration_macro_steps_per_s_fp32_full=rows / (full32 * 1e-3))
+        if "rollout_fp32_bf16x3" in phases:
+            itx = phases["rollout_fp32_bf16x3"]["ms"] + phases["calc_gae"]["ms"] + phases["update"]["ms"]
+            c3.update(iteration_ms_fp32_bf16x3_rollout=itx, iteration_macro_steps_per_s_fp32_bf16x3_rollout=rows / (itx * 1e-3))
         if "rollout_bf16" in phases:
             it16 = phases["rollout_bf16"]["ms"] + phases["calc_gae"]["ms"] + phases["update"]["ms"]
             c3.update(iteration_ms_bf16_rollout=it16, iteration_macro_steps_per_s_bf16_rollout=rows / (it16 * 1e-3))

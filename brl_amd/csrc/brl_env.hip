@@ -220,7 +220,7 @@ int brl_fail(int code, const char *fmt, const char *detail) {
 
 
 extern "C" const char *brl_last_error(void) { return g_err; }
-extern "C" int brl_version(void) { return 5; }   // include/brl_hip.h: the round the exported set last changed in
+extern "C" int brl_version(void) { return 6; }   // include/brl_hip.h: the round the exported set last changed in
 // Refresh the device mirror.  Callers have synchronised the device: nothing in flight reads the old contents.
 static int sync_ctx(brl_handle *h) {
   DevCtx c{lut_of(h), rng_of(h), h->env_offset};

@@ -1,0 +1,72 @@
+// brl_mlp_gemm_x3.hip — translation unit of libbrl_hip.so: fp32 products as six bf16 MFMA products of three-piece operands
+// (csrc/mlp_gemm_x3.hpp: 128 x 128 tiles, optional split K) behind brl_mlp_gemm_x3 (include/brl_hip.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "abi_common.hpp"
+#include "mlp_gemm_x3.hpp"
+
+static int64_t x3_tiles(int64_t m, int64_t n) { return ((m + 127) / 128) * ((n + 127) / 128); }
+
+static int64_t x3_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+  const int sk = mgs::pick_splitk(m, n, k);
+  if (sk == 1) return 0;
+  const int64_t tiles = x3_tiles(m, n);
+  return ((tiles * 4 + 255) / 256) * 256 + tiles * sk * (int64_t)mgs::SLAB_FLOATS * 4;
+}
+
+extern "C" int brl_mlp_gemm_x3_workspace(int64_t m, int64_t n, int64_t k, int64_t *bytes) {
+  NEED(bytes && m > 0 && n > 0 && k > 0, "bytes / m / n / k");
+  *bytes = x3_workspace_bytes(m, n, k);
+  return BRL_OK;
+}
+
+extern "C" int brl_mlp_gemm_x3(int device, int layout, int epilogue, const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
+                               int64_t ldc, int64_t m, int64_t n, int64_t k, int act, const float *bias, const float *gate, int64_t ldg,
+                               float *colsum, void *workspace, int64_t workspace_bytes, void *stream) {
+  NEED(a && b && c && m > 0 && n > 0 && k > 0, "a / b / c / m / n / k");
+  NEED(layout >= BRL_GEMM_NT && layout <= BRL_GEMM_TN, "layout (BRL_GEMM_NT / _NN / _TN)");
+  NEED(m < (1 << 24) && n < (1 << 24) && k < (1 << 24), "m / n / k below 2^24");
+  NEED(n % 4 == 0 && ldc % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc >= n, "n and the leading dimensions multiples of 4 (16-byte pieces)");
+  const bool akc = layout != BRL_GEMM_TN, bkc = layout == BRL_GEMM_NT;
+  NEED(!akc || k % 4 == 0, "k a multiple of 4 where it is the contiguous index of an operand");
+  NEED(akc ? lda >= k : lda >= ((m + 3) & ~(int64_t)3), "lda (where m is contiguous in a: at least m rounded up to 4 — whole 16-byte pieces are read)");
+  NEED(bkc ? ldb >= k : ldb >= n, "ldb");
+  NEED((akc ? m * lda : k * lda) < (1ll << 29) && (bkc ? n * ldb : k * ldb) < (1ll << 29), "operands below 2 GB");
+  NEED(act == 0 || act == 1, "act (0 ReLU, 1 tanh)");
+  NEED((epilogue == BRL_GEMM_EPI_NONE) || (epilogue == BRL_GEMM_EPI_BIAS_ACT && layout == BRL_GEMM_NT && bias) ||
+           (epilogue == BRL_GEMM_EPI_GATE_COLSUM && layout == BRL_GEMM_NN && gate && ldg >= n && ldg % 4 == 0),
+       "epilogue (NONE; BIAS_ACT with NT + bias; GATE_COLSUM with NN + gate)");
+  NEED((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)bias | (uintptr_t)gate | (uintptr_t)colsum) & 15) == 0, "16-byte alignment");
+  HIP_TRY(hipSetDevice(device));
+  mgs::Args X{};
+  mg::Args &G = X.g;
+  G.A = a; G.lda = lda; G.B = b; G.ldb = ldb; G.C = c; G.ldc = ldc;
+  G.M = (int)m; G.N = (int)n; G.K = (int)k; G.act = act;
+  G.bias = bias; G.gate = gate; G.ldg = ldg; G.colsum = colsum;
+  // K slices: as many as fill the chip — if the caller brought the memory the partial tiles need (else one slice per tile)
+  const int64_t tiles = x3_tiles(m, n);
+  int sk = mgs::pick_splitk(m, n, k);
+  const int64_t tick = ((tiles * 4 + 255) / 256) * 256;
+  if (sk > 1 && (workspace == nullptr || workspace_bytes < tick + tiles * sk * (int64_t)mgs::SLAB_FLOATS * 4)) sk = 1;
+  NEED(sk == 1 || (((uintptr_t)workspace) & 255) == 0, "workspace: 256-byte alignment");
+  NEED(sk == 1 || tiles * sk * (int64_t)mgs::SLAB_FLOATS * 4 < (1ll << 31), "partial tiles below 2 GB");
+  X.splitk = sk;
+  X.tickets = (unsigned *)workspace;                                   // zero before the first launch (the caller's memset): put back by the last arriver
+  X.slabs = sk > 1 ? (float *)((char *)workspace + tick) : nullptr;
+  const unsigned blocks = (unsigned)(tiles * sk);
+  hipStream_t s = (hipStream_t)stream;
+#define X3_LAUNCH(AK, BK_, E) hipLaunchKernelGGL((mgs::k_gemm_x3s<AK, BK_, E>), dim3(blocks), dim3(mgs::THREADS), 0, s, X)
+  if (layout == BRL_GEMM_NT) {
+    if (epilogue == BRL_GEMM_EPI_BIAS_ACT) X3_LAUNCH(true, true, mg::EPI_BIAS_ACT);
+    else X3_LAUNCH(true, true, mg::EPI_NONE);
+  } else if (layout == BRL_GEMM_NN) {
+    if (epilogue == BRL_GEMM_EPI_GATE_COLSUM) X3_LAUNCH(true, false, mg::EPI_GATE_COLSUM);
+    else X3_LAUNCH(true, false, mg::EPI_NONE);
+  } else {
+    X3_LAUNCH(false, false, mg::EPI_NONE);
+  }
+#undef X3_LAUNCH
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}

@@ -132,7 +132,7 @@ class InferenceSnapshot:
     updates (``refresh`` re-reads them in place).  ``make`` returns None for architectures it does not cover (callers fall
     back to ``module(x)``)."""
 
-    def __init__(self, module: "ActorCritic", dtype=None, env=None, own_cast=True, views=False):
+    def __init__(self, module: "ActorCritic", dtype=None, env=None, own_cast=True, views=False, gemm=None):
         # env: a BridgeBidding whose library runs the 16-bit hidden layers (brl_linear_act) and — own_cast — converts the 0/1
         # observation bytes to `dtype` (brl_obs_cast: 3 us instead of 15 us of GPU time per forward, but a slower launch than
         # torch's .to(): only worth it in hipGraph replays)
@@ -140,6 +140,17 @@ class InferenceSnapshot:
         self.own_cast = bool(own_cast)
         self.dtype = dtype or torch.float32
         dt = self.dtype
+        # gemm = "bf16x3" (config["inference_gemm"] / BRL_INFERENCE_GEMM; opt-in, fp32 only): batches of >= 4096 rows run their hidden layers
+        # on brl_mlp_gemm_x3 — the fp32 product as six bf16 MFMA products of three exact bf16 pieces per operand, 0.07-0.44 x the
+        # exact kernel's error and 1.4 x its rate on such batches (csrc/mlp_gemm_x3.hpp) — straight on the module's own [out, in]
+        # weights (nothing to copy or refresh); NOT bit-identical to the library product
+        self.gemm_x3 = (gemm or os.environ.get("BRL_INFERENCE_GEMM", "")) == "bf16x3" and dt == torch.float32
+        # nn.Linear's own [out, in] layout: the module's parameters themselves under `views`, else copies `refresh` re-reads (their
+        # addresses are baked into captured graphs; the update re-points the module's parameters at its flat buffers)
+        self.lin = None
+        if self.gemm_x3:
+            self.lin = [(lin.weight.detach(), lin.bias.detach()) if views else (lin.weight.detach().clone(), lin.bias.detach().clone())
+                        for lin in module.body]
         # views (fp32 only): the hidden layers multiply with the module's own weights through transposed VIEWS — nothing is
         # copied (an evaluator builds its snapshots per call: nine launches per network otherwise) and nothing needs a refresh
         self.views = bool(views) and dt == torch.float32 and all(lin.weight.dtype == torch.float32 for lin in module.body)
@@ -170,6 +181,13 @@ class InferenceSnapshot:
         """Re-read the weights of `module` INTO the existing tensors (their addresses are baked into captured graphs)."""
         if self.body_nk is not None:
             return self._refresh16(module)
+        if self.lin is not None:
+            if self.views:
+                self.lin = [(lin.weight.detach(), lin.bias.detach()) for lin in module.body]
+            else:
+                for (w, b), lin in zip(self.lin, module.body):
+                    w.copy_(lin.weight.detach())
+                    b.copy_(lin.bias.detach())
         if self.views:   # (the hidden layers alias the module's parameters: only the merged heads are copies)
             self.body = [(lin.weight.detach().t(), lin.bias.detach()) for lin in module.body]
         else:
@@ -210,10 +228,10 @@ class InferenceSnapshot:
         self._body_stale = True   # self.body's weights ([in, out]) no longer match: rebuilt on demand (_body)
 
     @staticmethod
-    def make(module, dtype=None, env=None, own_cast=True, views=False):
+    def make(module, dtype=None, env=None, own_cast=True, views=False, gemm=None):
         if not str(getattr(module, "model", "")).startswith("DeepMind") or module.act is not torch.relu:
             return None
-        return InferenceSnapshot(module, dtype, env, own_cast, views)
+        return InferenceSnapshot(module, dtype, env, own_cast, views, gemm)
 
     _FMT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
@@ -238,6 +256,16 @@ class InferenceSnapshot:
                 y = torch.empty((x.shape[0], w.shape[0]), dtype=self.dtype, device=x.device)
                 _capi.check(L.brl_linear_act(self.env._h, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), b.data_ptr(),
                                            y.data_ptr(), y.stride(0), x.shape[0], w.shape[0], w.shape[1], 1, fmt, st))
+                x = y
+            return x
+        if self.gemm_x3 and x.is_cuda and x.dim() == 2 and x.shape[0] >= 4096 and x.is_contiguous() and x.data_ptr() % 16 == 0:
+            from . import _capi
+            L, st = _capi.lib(), torch.cuda.current_stream(x.device).cuda_stream
+            di = x.device.index if x.device.index is not None else torch.cuda.current_device()
+            for w, b in self.lin:      # nn.Linear's own layout: y = relu(x W^T + b), W [out, in]
+                y = torch.empty((x.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
+                _capi.check(L.brl_mlp_gemm_x3(di, 0, 1, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), y.data_ptr(), y.stride(0),
+                                              x.shape[0], w.shape[0], w.shape[1], 0, b.data_ptr(), None, 0, None, None, 0, st))
                 x = y
             return x
         if getattr(self, "_body_stale", False):   # (only after a 16-bit refresh, and only if this path is taken at all)

@@ -128,11 +128,12 @@ class _PolicyRollout:
     calls are followed by the replays.  ``sub_actions`` [T,3,n] keeps the actions of sub-steps 2-4 (tests replay the
     whole rollout through the oracle)."""
 
-    def __init__(self, env, n, T, reward_scale, game_mode, masked, infer_dtype, actor_fp, opp_fp, static, fuse_heads=True,
+    def __init__(self, env, n, T, reward_scale, game_mode, masked, infer_dtype, actor_fp, opp_fp, static, fuse_heads=True, gemm=None,
                  graph_steps=4):
         self.graph_steps = max(1, int(graph_steps))
         self.env, self.n, self.T, self.reward_scale = env, n, T, reward_scale
         self.fuse_heads = bool(fuse_heads)
+        self.gemm = gemm      # config["inference_gemm"]: "bf16x3" = the hidden layers of the fp32 forwards on brl_mlp_gemm_x3 (models.InferenceSnapshot)
         self.game_mode, self.masked, self.infer_dtype, self.static = game_mode, masked, infer_dtype, static
         self.actor_fp, self.opp_fp = actor_fp, opp_fp
         self.graphs = None
@@ -165,15 +166,15 @@ class _PolicyRollout:
         """(Re)build the inference views of the two networks for this call."""
         if self.static:
             if self.snap_actor is None:
-                self.snap_actor = InferenceSnapshot.make(params, self.infer_dtype, self.env)
-                self.snap_opp = InferenceSnapshot.make(opp_params, self.infer_dtype, self.env)
+                self.snap_actor = InferenceSnapshot.make(params, self.infer_dtype, self.env, gemm=self.gemm)
+                self.snap_opp = InferenceSnapshot.make(opp_params, self.infer_dtype, self.env, gemm=self.gemm)
             else:  # weights are re-read INTO the tensors whose addresses the graphs hold
                 self.snap_actor.refresh(params)
                 self.snap_opp.refresh(opp_params)
         else:  # eager: host-bound, torch's own cast launches faster than brl_obs_cast (same layer kernels as the replayed form)
-            self.snap_actor = InferenceSnapshot.make(params, self.infer_dtype, self.env, own_cast=False)
+            self.snap_actor = InferenceSnapshot.make(params, self.infer_dtype, self.env, own_cast=False, gemm=self.gemm)
             self.snap_opp = self.snap_actor if opp_params is params \
-                else InferenceSnapshot.make(opp_params, self.infer_dtype, self.env, own_cast=False)
+                else InferenceSnapshot.make(opp_params, self.infer_dtype, self.env, own_cast=False, gemm=self.gemm)
         self.params, self.opp_params = params, opp_params
 
     _FMT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
@@ -369,7 +370,7 @@ def make_roll_out(config, env: BridgeBidding, actor_forward_pass, opp_forward_pa
         if eng is None:
             eng = engines[(n, static)] = _PolicyRollout(env, n, T, reward_scale, mode, masked, infer_dtype,
                                                         actor_forward_pass, opp_forward_pass, static,
-                                                        fuse_heads=config.get("fuse_heads", True),
+                                                        fuse_heads=config.get("fuse_heads", True), gemm=config.get("inference_gemm"),
                                                         graph_steps=config.get("rollout_graph_steps", 4))
         out = eng.run(runner_state, opp_params)
         roll_out.sub_actions = eng.sub_actions

@@ -47,8 +47,10 @@ extern "C" {
 typedef struct brl_handle brl_handle;
 
 const char *brl_last_error(void);
-/* The version of the EXPORTED SET: the number of the build round in which a symbol was last added, removed or changed (5 now).
- * Under ONE version a symbol's signature and meaning never change.  Version 5 against version 4 — the boundary is the path, the
+/* The version of the EXPORTED SET: the number of the build round in which a symbol was last added, removed or changed (6 now).
+ * Under ONE version a symbol's signature and meaning never change.  Version 6 against version 5: added brl_mlp_gemm_x3 and
+ * brl_mlp_gemm_x3_workspace (fp32 products on the bf16 matrix pipe at fp32-grade error: the large-batch forward layers); 51 symbols.
+ * Version 5 against version 4 — the boundary is the path, the
  * experiment log (profiles/r04/r04_experiments.txt) keeps what was measured and dropped:
  *   removed (fusions of the PPO step that measured no faster): brl_mlp_gemm_bwd_pair, brl_mlp_gemm_fwd_heads,
  *     brl_ppo_heads_loss_parts, brl_adam_clip_fin_gather_defer, brl_mlp_gemm_adam, brl_adam_apply_range;
@@ -572,6 +574,19 @@ int brl_adam_shard_apply(int device, float *p, const float *g, float *m, float *
 int brl_mlp_gemm(int device, int layout, int epilogue, const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
                  int64_t ldc, int64_t m, int64_t n, int64_t k, int act, const float *bias, const float *gate, int64_t ldg,
                  float *colsum, float *sqsum, void *stream);
+
+/* The same product "bf16x3" (csrc/mlp_gemm_x3.hpp; config["inference_gemm"], opt-in): every fp32 operand as three exact bf16
+ * pieces, six bf16 MFMA products per K step, fp32 accumulators by magnitude class — max |err| against float64 0.07-0.44 x
+ * brl_mlp_gemm's on the same inputs, and NOT bit-identical to it; 128 x 128 tiles: for outputs of >= 256 of them (the policy
+ * rollout's and the evaluators' forward layers, src/roll_out.py:49-108, src/models.py:23-33) 1.4 x brl_mlp_gemm's rate.  Arguments as
+ * brl_mlp_gemm's; epilogues NONE, BIAS_ACT (NT), GATE_COLSUM (NN); every pointer 16-byte aligned.  Outputs of fewer tiles may
+ * divide K among several workgroups per tile: `workspace` (may be NULL: then never) = *bytes of brl_mlp_gemm_x3_workspace (0: none) of
+ * device memory, 256-byte aligned, ZERO before the first call and owned by one stream at a time (partial tiles + a ticket per tile;
+ * the last workgroup of a tile adds the partial tiles in K order: deterministic). */
+int brl_mlp_gemm_x3_workspace(int64_t m, int64_t n, int64_t k, int64_t *bytes);
+int brl_mlp_gemm_x3(int device, int layout, int epilogue, const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
+                    int64_t ldc, int64_t m, int64_t n, int64_t k, int act, const float *bias, const float *gate, int64_t ldg,
+                    float *colsum, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* `count` <= 16 plain products of one layout as ONE launch (arguments as brl_mlp_gemm's, one array element per product): the FAIR
  * network's eleven weight gradients dW_l = dz_l^T x_l (BRL_GEMM_TN; src/models.py:34-69's 200-wide layers are 0.08-0.5 GFLOP

@@ -31,7 +31,7 @@ static int fail(const char *msg) {
   return BRL_E_ARG;
 }
 const char *brl_last_error(void) { return g_err; }
-int brl_version(void) { return 5; }   /* the exported set of include/brl_hip.h, version 5 */
+int brl_version(void) { return 6; }   /* the exported set of include/brl_hip.h, version 6 */
 
 static int set_lut(brl_handle *h, const int32_t *keys, const int32_t *values, int64_t len) {
   free(h->keys);
@@ -345,6 +345,19 @@ int brl_mlp_gemm(int device, int layout, int epilogue, const float *a, int64_t l
       if (epilogue == 3) sqsum[(i / 64) * tn + j / 64] += v * v;
     }
   return BRL_OK;
+}
+/* brl_mlp_gemm_x3 on the host: the SAME plain definition in float64 (the device kernel's three-piece operands and six products are an
+ * implementation of the fp32 product, not a different function); no partial tiles here: the workspace is not touched */
+int brl_mlp_gemm_x3_workspace(int64_t m, int64_t n, int64_t k, int64_t *bytes) { (void)m; (void)n; (void)k; if (bytes) *bytes = 0; return BRL_OK; }
+int brl_mlp_gemm_x3(int device, int layout, int epilogue, const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
+                    int64_t ldc, int64_t m, int64_t n, int64_t k, int act, const float *bias, const float *gate, int64_t ldg,
+                    float *colsum, void *workspace, int64_t workspace_bytes, void *s) {
+  (void)workspace; (void)workspace_bytes;
+  if (epilogue == BRL_GEMM_EPI_SQSUM) {
+    snprintf(g_err, sizeof(g_err), "bad argument: brl_mlp_gemm_x3: epilogue (oracle shim)");
+    return BRL_E_ARG;
+  }
+  return brl_mlp_gemm(device, layout, epilogue, a, lda, b, ldb, c, ldc, m, n, k, act, bias, gate, ldg, colsum, NULL, s);
 }
 /* the policy network's forward for selected rows, float64 accumulation (the checker of brl_mlp_forward_rows: src/models.py:23-33) */
 int brl_mlp_forward_rows(int device, const brl_mlp_ref *net, const uint8_t *obs, const int64_t *rows, int64_t m, float *scratch,

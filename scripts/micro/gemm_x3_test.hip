@@ -13,6 +13,7 @@
 
 #include "mlp_gemm_x3.hpp"
 #include "mlp_gemm_x3w.hpp"
+#include "mlp_gemm_x3s.hpp"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -37,6 +38,20 @@ static void launch_x3(const Case &c, const mg::Args &G, hipStream_t s) {
   else { printf("layout not instantiated\n"); exit(1); }
 #undef L
 }
+static float *g_slabs = nullptr;
+static unsigned *g_tickets = nullptr;
+static void launch_x3s(const Case &c, const mg::Args &G, hipStream_t s) {
+  mgs::Args X{};
+  X.g = G; X.slabs = g_slabs; X.tickets = g_tickets;
+  X.splitk = getenv("X3S_SK") ? atoi(getenv("X3S_SK")) : mgs::pick_splitk(G.M, G.N, G.K);
+  const int tiles = ((G.M + 127) / 128) * ((G.N + 127) / 128) * X.splitk;
+#define L(a, b, e) hipLaunchKernelGGL((mgs::k_gemm_x3s<a, b, e>), dim3(tiles), dim3(mgs::THREADS), 0, s, X)
+  if (c.akc && c.bkc) { if (c.epi == mg::EPI_BIAS_ACT) L(true, true, mg::EPI_BIAS_ACT); else L(true, true, mg::EPI_NONE); }
+  else if (c.akc && !c.bkc) { if (c.epi == mg::EPI_GATE_COLSUM) L(true, false, mg::EPI_GATE_COLSUM); else L(true, false, mg::EPI_NONE); }
+  else if (!c.akc && !c.bkc) L(false, false, mg::EPI_NONE);
+  else { printf("layout not instantiated\n"); exit(1); }
+#undef L
+}
 static bool launch_x3w(const Case &c, const mg::Args &G, hipStream_t s) {
   const int tiles = ((G.M + 63) / 64) * ((G.N + 63) / 64);
   if (!(c.akc && c.bkc)) return false;
@@ -58,7 +73,7 @@ static void launch_f32(const Case &c, const mg::Args &G, hipStream_t s, int nb) 
 int main(int argc, char **argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 5;
   const int pad = argc > 2 ? atoi(argv[2]) : 0;     // floats added to the operands' leading dimensions (L2 channel experiment)
-  printf("bf16x3: NPROD %d  EXP %d / x3w EXP %d NACC %d  ld pad %d\n", MGX_NPROD, MGX_EXP, MGW_EXP, MGW_NACC, pad);
+  printf("bf16x3: NPROD %d  EXP %d / x3w EXP %d NACC %d / x3s EXP %d (%s)  ld pad %d\n", MGX_NPROD, MGX_EXP, MGW_EXP, MGW_NACC, MGS_EXP, getenv("X3S") ? "x3s: 128 x 128 tiles + split K" : getenv("X3W") ? "x3w" : "x3", pad);
   const Case cases[] = {
       {"NT 1024^3 uniform", true, true, 1024, 1024, 1024, mg::EPI_NONE, 0, 0},
       {"NT 1024^3 relu(N) x N/sqrt(K) +bias relu", true, true, 1024, 1024, 1024, mg::EPI_BIAS_ACT, 0, 1},
@@ -77,6 +92,7 @@ int main(int argc, char **argv) {
   };
   hipStream_t s;
   CK(hipStreamCreate(&s));
+  CK(hipMalloc(&g_slabs, (size_t)4096 * 128 * 128 * 4)); CK(hipMalloc(&g_tickets, 4096 * 4)); CK(hipMemset(g_tickets, 0, 4096 * 4));   // (x3s: up to 4096 slabs)
   int bad = 0;
   for (const Case &c : cases) {
     const int M = c.M, N = c.N, K = c.K;
@@ -112,7 +128,8 @@ int main(int argc, char **argv) {
     G2.dbg = nullptr;
 #endif
     const bool usew = getenv("X3W") && c.akc && c.bkc;
-    if (usew) launch_x3w(c, G, s); else launch_x3(c, G, s);
+    const bool uses = getenv("X3S") != nullptr;
+    if (uses) launch_x3s(c, G, s); else if (usew) launch_x3w(c, G, s); else launch_x3(c, G, s);
     launch_f32(c, G2, s, 2);
     CK(hipStreamSynchronize(s));
     std::vector<float> C((size_t)M * N), C2((size_t)M * N);
@@ -151,7 +168,7 @@ int main(int argc, char **argv) {
           for (int m = 64 * b; m < 64 * b + 64 && m < M; m++) { tt += C[(size_t)m * N + n]; ta += fabs(C[(size_t)m * N + n]); }
           cserr = fmax(cserr, fabs(tt - cs[(size_t)b * N + n]) / fmax(ta, 1e-30));
         }
-    if (c.epi == mg::EPI_SQSUM) {
+    if (c.epi == mg::EPI_SQSUM && !uses) {
       double tt = 0, u = 0;
       for (size_t i = 0; i < C.size(); i++) tt += (double)C[i] * C[i];
       for (int i = 0; i < ntile; i++) u += sqv[i];
@@ -164,12 +181,12 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<double> t3, t32, t32n;
-    for (int i = 0; i < 20; i++) { if (usew) launch_x3w(c, G, s); else launch_x3(c, G, s); launch_f32(c, G2, s, 2); launch_f32(c, G2, s, 1); }
+    for (int i = 0; i < 20; i++) { if (uses) launch_x3s(c, G, s); else if (usew) launch_x3w(c, G, s); else launch_x3(c, G, s); launch_f32(c, G2, s, 2); launch_f32(c, G2, s, 1); }
     for (int r = 0; r < rounds; r++) {
       float ms;
       for (int which = 0; which < 3; which++) {
         CK(hipEventRecord(e0, s));
-        for (int i = 0; i < 200; i++) { if (which == 0) { if (usew) launch_x3w(c, G, s); else launch_x3(c, G, s); } else launch_f32(c, G2, s, which == 1 ? 2 : 1); }
+        for (int i = 0; i < 200; i++) { if (which == 0) { if (uses) launch_x3s(c, G, s); else if (usew) launch_x3w(c, G, s); else launch_x3(c, G, s); } else launch_f32(c, G2, s, which == 1 ? 2 : 1); }
         CK(hipEventRecord(e1, s));
         CK(hipStreamSynchronize(s));
         CK(hipEventElapsedTime(&ms, e0, e1));
@@ -180,7 +197,7 @@ int main(int argc, char **argv) {
     const double u3 = t3[t3.size() / 2], u32 = t32[t32.size() / 2], u32n = t32n[t32n.size() / 2];
     printf("%-42s %s  max|err| x3 %.3e f32 %.3e (ratio %.2f)  rms x3 %.3e f32 %.3e  max|ref| %.2f max sum|ab| %.1f%s\n"
            "    %-38s x3 %6.2f us (%6.1f TF fp32-equivalent)  |  exact fp32 64x64 %6.2f us  64x32 %6.2f us (%6.1f TF)\n",
-           usew ? "[x3w]" : c.name, ok ? "ok  " : "FAIL", e3, e32, e3 / fmax(e32, 1e-300), sqrt(q3 / cnt), sqrt(q32 / cnt), maxref, absdot,
+           uses ? c.name : usew ? "[x3w]" : c.name, ok ? "ok  " : "FAIL", e3, e32, e3 / fmax(e32, 1e-300), sqrt(q3 / cnt), sqrt(q32 / cnt), maxref, absdot,
            unstored ? "  NaN / unstored outputs / epilogue sums wrong!" : "", "", u3, 2.0 * M * N * K / (u3 * 1e-6) / 1e12, u32, u32n,
            2.0 * M * N * K / (fmin(u32, u32n) * 1e-6) / 1e12);
 #ifdef MG_TIMING

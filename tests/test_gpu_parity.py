@@ -417,6 +417,8 @@ POLICY_CFG = {"reward_scale": 7600, "game_mode": "competitive", "actor_illegal_a
 
 @pytest.mark.parametrize("n,T,graph,dt,calls", [(2048, 32, False, None, 2), (2048, 32, True, None, 2),
                                                 (8192, 32, True, None, 1),     # configs[3]'s rollout at the reference's fp32
+                                                (8192, 32, True, "x3", 2),     # ... its hidden layers on brl_mlp_gemm_x3 (inference_gemm = "bf16x3")
+                                                (8192, 8, False, "x3", 1),
                                                 (8192, 32, True, "bf16", 1), (1000, 9, False, "bf16", 2),
                                                 (1000, 9, True, "fp16", 2)])
 def test_policy_rollout_replays_through_oracle(env, oracle, n, T, graph, dt, calls):
@@ -425,7 +427,9 @@ def test_policy_rollout_replays_through_oracle(env, oracle, n, T, graph, dt, cal
     fp32); value / log_prob vs an fp32 torch recomputation on the stored obs (tolerances stated below)."""
     import brl_amd
     from brl_amd.models import make_forward_pass
-    cfg = dict(POLICY_CFG, num_steps=T, graph_rollout=graph, inference_dtype=dt)
+    gemm = "bf16x3" if dt == "x3" else None
+    dt = None if dt == "x3" else dt
+    cfg = dict(POLICY_CFG, num_steps=T, graph_rollout=graph, inference_dtype=dt, inference_gemm=gemm)
     fp = make_forward_pass("relu", "DeepMind")
     actor, opp = fp.init(0, device="cuda"), fp.init(1, device="cuda")
     roll = brl_amd.make_roll_out(cfg, env, fp, fp)
@@ -438,7 +442,7 @@ def test_policy_rollout_replays_through_oracle(env, oracle, n, T, graph, dt, cal
         rs, traj = roll(rs, opp)
         torch.cuda.synchronize()
         want = replay_policy_rollout(oracle, ref, traj, roll.sub_actions, seed)
-        where = f"n={n} T={T} graph={graph} dt={dt} call {call}"
+        where = f"n={n} T={T} graph={graph} dt={dt} gemm={gemm} call {call}"
         for name in ("obs", "legal_action_mask", "done", "reward"):
             assert np.array_equal(to_np(getattr(traj, name)), want[name]), f"{where}: {name}"
         mask, act = want["legal_action_mask"], to_np(traj.action)
@@ -451,6 +455,7 @@ def test_policy_rollout_replays_through_oracle(env, oracle, n, T, graph, dt, cal
             logits, value = actor(traj.obs.reshape(T * n, 480).float())
         lsm = _masked_log_softmax(to_np(logits), mask.reshape(T * n, 38))
         # fp32 inference: accumulation order of the GEMMs differs (fused epilogue / merged heads): 2e-4; bf16: 8 mantissa bits
+        # (bf16x3: fp32 operands as three exact bf16 pieces — fp32-grade: the same 2e-4)
         tol = 2e-4 if dt is None else (0.08 if dt == "bf16" else 0.01)   # (fp16: 11 mantissa bits)
         assert np.abs(to_np(traj.log_prob).reshape(-1) - lsm[np.arange(T * n), act.reshape(-1)]).max() < tol
         assert np.abs(to_np(traj.value).reshape(-1) - to_np(value)).max() < tol
@@ -2581,6 +2586,71 @@ def test_mlp_gemm_matches_float64(layout, epi, M, N, K, act):
     _capi.check(L.brl_mlp_gemm(0, layout, epi, A.data_ptr(), A.stride(0), Bm.data_ptr(), Bm.stride(0), C2.data_ptr(), N, M, N, K, act,
                                bias.data_ptr(), gate.data_ptr(), N, colsum.data_ptr(), sqsum.data_ptr(), s))
     assert torch.equal(C, C2)
+
+
+@pytest.mark.parametrize("layout,epi,M,N,K,act,ws", [
+    (0, 1, 8192, 1024, 1024, 0, False), (0, 1, 4096, 1024, 480, 0, False), (0, 1, 1024, 1024, 1024, 0, True), (0, 1, 1024, 1024, 1024, 0, False),
+    (0, 1, 200, 72, 64, 1, True), (0, 0, 48, 256, 1000, 0, True), (0, 0, 64, 64, 36, 0, False),
+    (1, 2, 1024, 1024, 1024, 0, True), (1, 2, 100, 36, 96, 1, True), (1, 2, 1000, 256, 252, 0, False),
+    (2, 0, 1024, 1024, 1024, 0, True), (2, 0, 68, 132, 1000, 0, True), (2, 0, 1024, 480, 1024, 0, False)])
+def test_mlp_gemm_x3_beats_the_exact_kernels_error(layout, epi, M, N, K, act, ws):
+    """brl_mlp_gemm_x3 (csrc/mlp_gemm_x3.hpp: the fp32 product as six bf16 MFMA products of three exact bf16 pieces per operand,
+    128 x 128 tiles, optionally K divided among workgroups) on the SAME operands as brl_mlp_gemm, both against a float64 product: every
+    layout and epilogue it offers, the rollout's and the step's shapes, edge tiles, K tails, with and without the split-K workspace.
+    The bound is the exact kernel's own (2e-4 * max|ref| at K = 1024) AND its error on these very inputs: max |err| of bf16x3 <= the exact
+    kernel's (measured 0.07 - 0.64 x: scripts/micro/gemm_x3_test.hip) + one ulp of slack for the tiny shapes.  Deterministic: the same bits twice."""
+    import ctypes as C
+    from brl_amd import _capi
+    L = _capi.lib()
+    g = torch.Generator(device="cuda").manual_seed(layout * 1000 + M + N + K)
+    r = lambda *sh: (torch.rand(sh, device="cuda", generator=g) * 2 - 1)  # noqa: E731
+    akc, bkc = layout != 2, layout == 0
+    A = r(M, K) if akc else r(K, M)
+    Bm = r(N, K) if bkc else r(K, N)
+    bias, gate = r(N), r(M, N)
+    tm = (M + 63) // 64
+    s = torch.cuda.current_stream().cuda_stream
+    need = C.c_int64(0)
+    _capi.check(L.brl_mlp_gemm_x3_workspace(M, N, K, C.byref(need)))
+    assert need.value >= 0 and (need.value > 0) == (((M + 127) // 128) * ((N + 127) // 128) < 256 and K >= 128)
+    work = torch.zeros(max(need.value, 256) // 4, dtype=torch.int32, device="cuda") if ws else None
+
+    def run(fn_x3):
+        Cm = torch.full((M, N), float("nan"), device="cuda")
+        colsum = torch.full((tm, N), float("nan"), device="cuda")
+        if fn_x3:
+            _capi.check(L.brl_mlp_gemm_x3(0, layout, epi, A.data_ptr(), A.stride(0), Bm.data_ptr(), Bm.stride(0), Cm.data_ptr(), N, M, N, K, act,
+                                          bias.data_ptr(), gate.data_ptr(), N, colsum.data_ptr(), work.data_ptr() if ws else None,
+                                          need.value if ws else 0, s))
+        else:
+            _capi.check(L.brl_mlp_gemm(0, layout, epi, A.data_ptr(), A.stride(0), Bm.data_ptr(), Bm.stride(0), Cm.data_ptr(), N, M, N, K, act,
+                                       bias.data_ptr(), gate.data_ptr(), N, colsum.data_ptr(), None, s))
+        torch.cuda.synchronize()
+        return Cm, colsum
+    C3, cs3 = run(True)
+    C1, _ = run(False)
+    a64 = A.double() if akc else A.double().t()
+    b64 = Bm.double().t() if bkc else Bm.double()
+    ref = a64 @ b64
+    if epi == 1:
+        ref = ref + bias.double()
+        ref = ref.clamp_min(0) if act == 0 else ref.tanh()
+    if epi == 2:
+        ref = ref * ((gate > 0).double() if act == 0 else (1 - gate.double() ** 2))
+    e3, e1 = float((C3.double() - ref).abs().max()), float((C1.double() - ref).abs().max())
+    assert e3 < 2e-4 * max(1.0, float(ref.abs().max())) * (K / 1024 + 1) ** 0.5
+    assert e3 <= e1 + 2.0 ** -22 * max(1.0, float(ref.abs().max())), (e3, e1)
+    if epi == 2:   # column sums of what was STORED, per 64-row tile
+        want = torch.stack([C3[64 * t:64 * t + 64].double().sum(0) for t in range(tm)])
+        assert float((cs3.double() - want).abs().max()) < 1e-3
+    C3b, _ = run(True)
+    assert torch.equal(C3, C3b)
+    if ws:   # every ticket is back at zero: the workspace is ready for the next product
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        assert int(work[:tiles].abs().sum()) == 0
+    # refusals: an epilogue it does not offer, a misaligned operand
+    assert L.brl_mlp_gemm_x3(0, 2, 3, A.data_ptr(), A.stride(0), Bm.data_ptr(), Bm.stride(0), C3.data_ptr(), N, M, N, K, act, None, None, 0,
+                             None, None, 0, s) == _capi.BRL_E_ARG if hasattr(_capi, "BRL_E_ARG") else True
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
