@@ -234,7 +234,8 @@ __device__ __forceinline__ void gemm_tile(const Args &X, unsigned char *lds, int
   //                     vector instructions; the plane stores behind a piece's second half): <= 6 vector instructions per MFMA gap
   //   slots 4 9 14 19   the request of piece j of chunk i + 2 into the registers just split
   //   slot 20           every LDS operation of the wave done, barrier
-  //   slots 21 .. 23    the step-0 fragments of chunk i + 1 (three reads each)
+  //   slots 21 .. 23    the step-0 fragments of chunk i + 1 (three reads each: B, A block 0, A block 1)
+  // (tried: THREE stages, the barrier at slot 0 waiting for stores a phase old — 98.7 us against 88.4 for 8192 x 1024 x 1024, dropped)
   auto phase = [&](auto full_tag, auto par_tag, int i) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_tag)::value;
     constexpr int PAR = decltype(par_tag)::value, NS = PAR ^ 1;
@@ -266,9 +267,12 @@ __device__ __forceinline__ void gemm_tile(const Args &X, unsigned char *lds, int
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
-      if (s > 20 && nxt) {
+      if (s > 20 && nxt) {      // B first, then A block 0 — what the next phase's first MFMAs multiply —, A block 1 last
 #pragma unroll
-        for (int u = 3 * (s - 21); u < 3 * (s - 21) + 3; u++) f0[u] = read_frag(sn, 0, u);
+        for (int q = 0; q < 3; q++) {
+          const int u = (s == 21) ? 6 + q : (s == 22) ? q : 3 + q;
+          f0[u] = read_frag(sn, 0, u);
+        }
       }
     };
 #define MGS_STEP(s)                                                                 \

@@ -13,7 +13,7 @@
 
 #include "mlp_gemm_x3.hpp"
 #include "mlp_gemm_x3w.hpp"
-#include "mlp_gemm_x3s.hpp"
+#include "../../brl_amd/csrc/mlp_gemm_x3.hpp"   // (namespace mgs: the library's kernel; scripts/micro/mlp_gemm_x3s.hpp is its first form)
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
