@@ -705,24 +705,24 @@ def bench_secondary(torch, dev, budget_s: float = 60.0):
             return None
         t_roll, _ = timed(do_roll, 3)
         flop = 4 * rows * fwd_flop
-        peak = 157.3 if (dt is None and gemm is None) else 2500.0
-        if gemm is not None:
-            flop_exec = 6 * flop      # six bf16 products per fp32 product: what the matrix pipe executes, against the bf16 peak
+        x3 = gemm == "bf16x3"
+        peak = 157.3 if (dt is None and not x3) else 2500.0
+        flop_exec = 6 * flop if x3 else flop     # (bf16x3: six bf16 products per fp32 product: what the matrix pipe executes, against the bf16 peak)
         phases["rollout_" + label] = {
             "ms": t_roll * 1e3, "macro_steps_per_s": rows / t_roll, "raw_env_steps_per_s": 4 * rows / t_roll,
             "gemm_tflops": flop / t_roll / 1e12, "mfma_peak_tflops": peak,
-            "mfma_frac": (flop_exec if gemm is not None else flop) / t_roll / 1e12 / peak,
-            "dtype": ("fp32 inference (the reference's precision)" if gemm is None else
+            "mfma_frac": flop_exec / t_roll / 1e12 / peak,
+            "dtype": ("fp32 inference (the reference's precision), every layer on the library's exact-fp32 GEMM (inference_gemm = 'library')" if not x3 else
                       "fp32 inference, hidden layers on brl_mlp_gemm_x3 (fp32 operands as three exact bf16 pieces, six bf16 MFMA products, "
-                      "fp32 accumulation: 0.07-0.44 x the exact kernel's error vs float64; opt-in: inference_gemm = 'bf16x3')") if dt is None else
+                      "fp32 accumulation: 0.07-0.44 x the exact kernel's error vs float64; inference_gemm = 'bf16x3', brl_amd's default)") if dt is None else
                      "bf16 inference: NARROWER than the reference's fp32 — opt-in (inference_dtype), never the default",
             "how": "hipGraph-replayed macro-steps: 4 forwards + 4 brl_policy_step_ex launches each (competitive mode)"
                    + ("" if dt is None else "; hidden layers on the library's own bf16 kernel (brl_linear_act), the heads' share inside "
                       "the last layer's launch (brl_linear_act_heads), summed by the sub-step launch")}
-        if dt is None and gemm is None:
+        if dt is None and gemm == "library":
             keep["rs32"], keep["traj32"] = box["rs"], box["traj"]
 
-    leg("config3_rollout_fp32", lambda: rollout_leg("fp32", None))
+    leg("config3_rollout_fp32", lambda: rollout_leg("fp32", None, "library"))
 
     def gae_leg():
         calc_gae = brl_amd.make_calc_gae(cfg32, fp)
@@ -768,6 +768,7 @@ def bench_secondary(torch, dev, budget_s: float = 60.0):
         return info
 
     leg("config3_update", lambda: update_leg("update", {}), needs=("config3_calc_gae",))
+    leg("config3_rollout_fp32_bf16x3", lambda: rollout_leg("fp32_bf16x3", None, "bf16x3"))     # (brl_amd's default fp32 rollout)
 
     # ---- configs[2]: 8192-board duplicate evaluation, two different networks, fp32 (src/evaluation.py:69-204)
     def config2_leg():
@@ -849,7 +850,6 @@ def bench_secondary(torch, dev, budget_s: float = 60.0):
                                "what": "rollout: brl_fair_forward per forward; update: brl_fair_chain (forward + loss + backward chain, "
                                        "16 rows per workgroup) + brl_mlp_gemm_group (12 weight gradients) + finalize + clip / Adam"}
 
-    leg("config3_rollout_fp32_bf16x3", lambda: rollout_leg("fp32_bf16x3", None, "bf16x3"))
     leg("config3_fair", fair_leg)
     leg("config3_rollout_bf16", lambda: rollout_leg("bf16", "bf16"))
 
@@ -1020,7 +1020,7 @@ def bench_ppo(args, torch, dev, rank, world, barrier, max_over_ranks):
         "metric": "ppo.py iteration macro-steps/sec at num_envs=8192, num_steps=32, minibatch 1024, 10 epochs (secondary, configs[3])",
         "value": world * rows * iters / elapsed, "unit": "macro-steps/s", "n_gpus": world, "steps": iters, "warmup": 1,
         "ms_per_step": elapsed / iters * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": f"rollout inference {cfg['inference_dtype'] or 'fp32'}, update fp32", "data": "synthetic",
+        "dtype": f"rollout inference {cfg['inference_dtype'] or 'fp32 (hidden layers: ' + str(cfg.get('inference_gemm') or 'bf16x3') + ')'}, update fp32", "data": "synthetic",
         "config": {"workload": "configs[3]: roll_out (policy in the loop, competitive) + calc_gae + update_step",
                    "num_envs_per_gpu": n_envs, "num_steps": NUM_STEPS, "minibatch_size": 1024, "update_epochs": epochs,
                    "graph_rollout": True, "grad_allreduce": getattr(rs[1].get("graphed"), "allreduce_mode", None),

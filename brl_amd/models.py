@@ -140,11 +140,12 @@ class InferenceSnapshot:
         self.own_cast = bool(own_cast)
         self.dtype = dtype or torch.float32
         dt = self.dtype
-        # gemm = "bf16x3" (config["inference_gemm"] / BRL_INFERENCE_GEMM; opt-in, fp32 only): batches of >= 4096 rows run their hidden layers
-        # on brl_mlp_gemm_x3 — the fp32 product as six bf16 MFMA products of three exact bf16 pieces per operand, 0.07-0.44 x the
-        # exact kernel's error and 1.4 x its rate on such batches (csrc/mlp_gemm_x3.hpp) — straight on the module's own [out, in]
-        # weights (nothing to copy or refresh); NOT bit-identical to the library product
-        self.gemm_x3 = (gemm or os.environ.get("BRL_INFERENCE_GEMM", "")) == "bf16x3" and dt == torch.float32
+        # gemm (config["inference_gemm"], else BRL_INFERENCE_GEMM, else "bf16x3"): "bf16x3" = fp32 forwards of >= 4096 rows run their hidden
+        # layers on brl_mlp_gemm_x3 — the fp32 product as six bf16 MFMA products of three EXACT bf16 pieces per operand, fp32 accumulators
+        # by magnitude class: 0.07-0.44 x the exact fp32 kernel's error against float64 and 1.4 x its rate on such batches
+        # (csrc/mlp_gemm_x3.hpp) — on nn.Linear's own [out, in] weights; "library" = torch's fp32 GEMM for every batch.
+        # Either way an fp32 forward (src/models.py:23-33); the two are not bit-identical to each other.
+        self.gemm_x3 = (gemm or os.environ.get("BRL_INFERENCE_GEMM", "") or "bf16x3") == "bf16x3" and dt == torch.float32
         # nn.Linear's own [out, in] layout: the module's parameters themselves under `views`, else copies `refresh` re-reads (their
         # addresses are baked into captured graphs; the update re-points the module's parameters at its flat buffers)
         self.lin = None
