@@ -39,6 +39,12 @@ constexpr int OFF_B = 3 * PLANE, STAGE = 6 * PLANE;
 constexpr int LDS_BYTES = 2 * STAGE;          // 96 KB
 constexpr int SLAB_FLOATS = 128 * 128;
 
+#ifndef MGS_R1
+#define MGS_R1 6      // first slot of the step-1 fragment reads (B, then A block 0: three slots each)
+#endif
+#ifndef MGS_BAR
+#define MGS_BAR 20    // the barrier's slot in a phase of 24 (the staging ends before it, the next chunk's first fragments are read behind it)
+#endif
 #ifndef MGS_EXP
 #define MGS_EXP 0      // timing experiments (wrong results): 1 = no split arithmetic, 2 = no MFMA
 #endif
@@ -242,37 +248,40 @@ __device__ __forceinline__ void gemm_tile(const Args &X, unsigned char *lds, int
     unsigned char *st = lds + PAR * STAGE, *sn = lds + NS * STAGE;
     const bool real = FULL || i < ni, nxt = FULL || i + 1 < ni, nxt2 = FULL || i + 2 < ni;
     const int cn = c0 + i + 1, c3 = c0 + i + 2;
+    // staging schedule: half piece h (0..7) starts at slot HB(h) = floor(h (BAR - 2) / 8) and takes three slots; BAR = the barrier's slot
+    constexpr int BAR = MGS_BAR;
     auto slot = [&](int s) __attribute__((always_inline)) {
       // (reads placed late: step 0's A-block-0 fragments are dead after slot 5, its other fragments after slot 11 — the two sets never
       //  live whole side by side: 256 registers per wave at two waves per SIMD)
-      if (s >= 6 && s < 9 && real) f1[6 + (s - 6)] = read_frag(st, 1, 6 + (s - 6));      // B hi / mid / lo
-      if (s >= 9 && s < 12 && real) f1[s - 9] = read_frag(st, 1, s - 9);                 // A block 0
+      if (s >= MGS_R1 && s < MGS_R1 + 3 && real) f1[6 + (s - MGS_R1)] = read_frag(st, 1, 6 + (s - MGS_R1));           // B hi / mid / lo
+      if (s >= MGS_R1 + 3 && s < MGS_R1 + 6 && real) f1[s - MGS_R1 - 3] = read_frag(st, 1, s - MGS_R1 - 3);         // A block 0
       if (s >= 12 && s < 15 && real) f1[3 + (s - 12)] = read_frag(st, 1, 3 + (s - 12));   // A block 1
-      if (s < 20 && nxt) {
+      if (s < BAR && nxt) {
 #pragma unroll
         for (int h = 0; h < 8; h++) {
-          const int b = (5 * h) / 2;
+          const int b = (h * (BAR - 2)) / 8;
 #pragma unroll
           for (int part = 0; part < 3; part++)
             if (s == b + part) stage_part(IntTag<0>{}, full_tag, h >> 1, h & 1, part, cn, sn);
         }
       }
-      if ((s == 4 || s == 9 || s == 14 || s == 19) && nxt2) {
-        const int j = s / 5;
-        if (FULL) gload_full(IntTag<0>{}, j); else gload(IntTag<0>{}, j, c3);
-        if (s == 19) gadvance();
+#pragma unroll
+      for (int j = 0; j < NP; j++) {
+        if (s == ((2 * j + 1) * (BAR - 2)) / 8 + 2 && nxt2) {      // behind the last part that reads piece j's registers
+          if (FULL) gload_full(IntTag<0>{}, j); else gload(IntTag<0>{}, j, c3);
+          if (j == NP - 1) gadvance();
+        }
       }
-      if (s == 20) {
+      if (s == BAR) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
-      if (s > 20 && nxt) {      // B first, then A block 0 — what the next phase's first MFMAs multiply —, A block 1 last
+      if (s > BAR && nxt) {      // B first, then A block 0 — what the next phase's first MFMAs multiply —, A block 1 last
+        constexpr int order[9] = {6, 7, 8, 0, 1, 2, 3, 4, 5};
+        const int n = 23 - BAR, k = s - BAR - 1;
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-          const int u = (s == 21) ? 6 + q : (s == 22) ? q : 3 + q;
-          f0[u] = read_frag(sn, 0, u);
-        }
+        for (int q = (9 * k) / n; q < (9 * (k + 1)) / n; q++) f0[order[q]] = read_frag(sn, 0, order[q]);
       }
     };
 #define MGS_STEP(s)                                                                 \
