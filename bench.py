@@ -749,15 +749,28 @@ def bench_secondary(torch, dev, budget_s: float = 60.0):
         uflop = UPDATE_FLOP_PER_SAMPLE * rows * cfg["update_epochs"]
         nominal = 3 * rows * fwd_flop * cfg["update_epochs"]
         graphed = ubox["rs"][1].get("graphed")
+        graphed = ubox["rs"][1].get("graphed")
+        # config["dw_gemm"] = "bf16x3" (the default): the weight gradients of the four body layers run as SIX bf16 products each on the bf16
+        # matrix pipe (brl_mlp_gemm_x3_group); the step's speed of light is then the time of the remaining fp32 products at the
+        # v_mfma_f32 peak + six times the weight gradients' FLOPs at the dense bf16 peak
+        dw_x3 = bool(getattr(graphed, "dw_x3", False))
+        x3_per_sample = 2 * (480 * 1024 + 3 * 1024 * 1024) if dw_x3 else 0
+        samples = rows * cfg["update_epochs"]
+        t_min = samples * ((UPDATE_FLOP_PER_SAMPLE - x3_per_sample) / 157.3e12 + 6 * x3_per_sample / 2500e12)
+        blended = uflop / t_min / 1e12
         phases[name] = {"ms": t_upd * 1e3, "minibatch_steps": nmb, "ms_per_minibatch": t_upd / nmb * 1e3,
-                        "gemm_flop_per_step": step_flop, "gemm_tflops": uflop / t_upd / 1e12, "mfma_peak_tflops": 157.3,
-                        "mfma_frac": uflop / t_upd / 1e12 / 157.3,
-                        "roofline": {"bound": "mfma_f32", "achieved": uflop / t_upd / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                                     "frac": uflop / t_upd / 1e12 / 157.3, "flop_per_step": step_flop,
+                        "gemm_flop_per_step": step_flop, "gemm_tflops": uflop / t_upd / 1e12, "mfma_peak_tflops": blended,
+                        "mfma_frac": t_min / t_upd,
+                        "fp32_equivalent_vs_f32_peak": uflop / t_upd / 1e12 / 157.3,
+                        "roofline": {"bound": "mfma_f32+bf16x3" if dw_x3 else "mfma_f32", "achieved": uflop / t_upd / 1e12, "peak": blended,
+                                     "unit": "TFLOP/s", "frac": t_min / t_upd, "flop_per_step": step_flop,
+                                     "bf16x3_flop_per_step": x3_per_sample * cfg["minibatch_size"],
                                      "ms_per_step": t_upd / nmb * 1e3,
-                                     "what": "fp32 FLOPs the step's launches execute / the step's time, against the dense "
-                                             "v_mfma_f32 peak (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz); kernel-by-kernel "
-                                             "timeline of the same step: profiles/r06/*_update_timeline.txt"},
+                                     "what": "fp32-equivalent FLOPs the step's launches form / the step's time; the peak is the one of "
+                                             "this mix: the exact-fp32 products at the dense v_mfma_f32 peak (157.3 = 256 CUs x 4 SIMDs "
+                                             "x 64 FLOP/clk x 2.4 GHz), the bf16x3 weight gradients as 6 bf16 products at the dense bf16 "
+                                             "peak (2500); kernel-by-kernel timeline of the same step: "
+                                             "profiles/r06/*_update_timeline.txt"},
                         "nominal_3x_forward": {"gemm_flop_per_step": 3 * fwd_flop * cfg["minibatch_size"],
                                                "gemm_tflops": nominal / t_upd / 1e12, "mfma_frac": nominal / t_upd / 1e12 / 157.3,
                                                "note": "counts layer 0's input gradient, which no launch forms: not a rate the "

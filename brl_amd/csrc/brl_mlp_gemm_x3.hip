@@ -70,3 +70,37 @@ extern "C" int brl_mlp_gemm_x3(int device, int layout, int epilogue, const float
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }
+
+extern "C" int brl_mlp_gemm_x3_group(int device, int layout, int count, const float *const *a, const int64_t *lda, const float *const *b,
+                                     const int64_t *ldb, float *const *c, const int64_t *ldc, const int64_t *m, const int64_t *n,
+                                     const int64_t *k, void *stream) {
+  NEED(count >= 1 && count <= mgs::GROUP_MAX && a && lda && b && ldb && c && ldc && m && n && k, "count (1..8) / NULL array");
+  NEED(layout >= BRL_GEMM_NT && layout <= BRL_GEMM_TN, "layout (BRL_GEMM_NT / _NN / _TN)");
+  const bool akc = layout != BRL_GEMM_TN, bkc = layout == BRL_GEMM_NT;
+  mgs::GroupArgs GA{};
+  GA.n = count;
+  for (int i = 0; i < count; i++) {
+    NEED(a[i] && b[i] && c[i] && m[i] > 0 && n[i] > 0 && k[i] > 0, "a / b / c / m / n / k");
+    NEED(m[i] < (1 << 24) && n[i] < (1 << 24) && k[i] < (1 << 24), "m / n / k below 2^24");
+    NEED(n[i] % 4 == 0 && ldc[i] % 4 == 0 && lda[i] % 4 == 0 && ldb[i] % 4 == 0 && ldc[i] >= n[i], "n and the leading dimensions multiples of 4");
+    NEED(!akc || k[i] % 4 == 0, "k a multiple of 4 where it is the contiguous index of an operand");
+    NEED(akc ? lda[i] >= k[i] : lda[i] >= ((m[i] + 3) & ~(int64_t)3), "lda (where m is contiguous in a: at least m rounded up to 4)");
+    NEED(bkc ? ldb[i] >= k[i] : ldb[i] >= n[i], "ldb");
+    NEED((akc ? m[i] * lda[i] : k[i] * lda[i]) < (1ll << 29) && (bkc ? n[i] * ldb[i] : k[i] * ldb[i]) < (1ll << 29), "operands below 2 GB");
+    NEED((((uintptr_t)a[i] | (uintptr_t)b[i] | (uintptr_t)c[i]) & 15) == 0, "16-byte alignment");
+    mgs::Args &X = GA.x[i];
+    mg::Args &G = X.g;
+    G.A = a[i]; G.lda = lda[i]; G.B = b[i]; G.ldb = ldb[i]; G.C = c[i]; G.ldc = ldc[i];
+    G.M = (int)m[i]; G.N = (int)n[i]; G.K = (int)k[i];
+    X.splitk = 1;
+    GA.first[i + 1] = GA.first[i] + (int)x3_tiles(m[i], n[i]);
+  }
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)GA.first[count];
+  if (layout == BRL_GEMM_NT) hipLaunchKernelGGL((mgs::k_gemm_x3s_group<true, true>), dim3(blocks), dim3(mgs::THREADS), 0, s, GA);
+  else if (layout == BRL_GEMM_NN) hipLaunchKernelGGL((mgs::k_gemm_x3s_group<true, false>), dim3(blocks), dim3(mgs::THREADS), 0, s, GA);
+  else hipLaunchKernelGGL((mgs::k_gemm_x3s_group<false, false>), dim3(blocks), dim3(mgs::THREADS), 0, s, GA);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}

@@ -410,6 +410,24 @@ __global__ __launch_bounds__(THREADS) void k_gemm_x3s(Args X) {
   gemm_tile<A_KC, B_KC, EPI>(X, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// Several products of one layout as ONE launch, one K slice each (the DeepMind step's four weight gradients dz_l^T h_{l-1}: three
+// 1024 x 1024 outputs + one 1024 x 480 = 224 tiles of 128 x 128 — one per CU and no partial tiles to add): workgroup b works on tile
+// b - first[p] of problem p.
+constexpr int GROUP_MAX = 8;
+struct GroupArgs {
+  int n;
+  int first[GROUP_MAX + 1];   // prefix sums of the problems' tile counts
+  Args x[GROUP_MAX];
+};
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(THREADS) void k_gemm_x3s_group(GroupArgs GA) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  const int b = (int)blockIdx.x;
+  int p = 0;
+  while (p + 1 < GA.n && b >= GA.first[p + 1]) p++;
+  gemm_tile<A_KC, B_KC, mg::EPI_NONE>(GA.x[p], lds, b - GA.first[p], GA.first[p + 1] - GA.first[p]);
+}
+
 // slices per tile: enough workgroups for the chip (256 CUs), at least two chunks per slice
 static inline int pick_splitk(int64_t m, int64_t n, int64_t k) {
   const int64_t tiles = ((m + 127) / 128) * ((n + 127) / 128);

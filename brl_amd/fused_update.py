@@ -544,6 +544,20 @@ class FusedMinibatch(FusedStep):
         # the single-rank batched weight gradient stay with the library.
         self.own_gemm = bool(config.get("own_gemm", True)) and B % 4 == 0 and H % 4 == 0 and nl > 1
         self.own_fwd = self.own_gemm and bool(config.get("own_gemm_fwd", False))
+        # config["dw_gemm"] = "bf16x3" (the default; "library": torch.bmm + torch.mm): the single-rank / flat step's weight gradients
+        # dz_l^T h_{l-1} (every layer, layer 0 included) as ONE launch of brl_mlp_gemm_x3_group (224 tiles of 128 x 128 at the default
+        # shape: one per CU) instead of the library's batched product + a launch for layer 0: 41 us instead of 47 + 11
+        # (profiles/r06/r06aa_step_ab.txt: the step 0.229 -> 0.211 ms); the products carry the bf16x3 error (below the exact fp32
+        # kernel's rounding: tests/test_gpu_parity.py::test_mlp_gemm_x3_beats_the_exact_kernels_error)
+        self.dw_x3 = (config.get("dw_gemm") or "bf16x3") == "bf16x3" and B % 4 == 0 and H % 4 == 0 and self.x0.shape[1] % 4 == 0 and nl <= 8
+        if self.dw_x3:
+            a_ = [self.dzs[l] for l in range(nl)]
+            b_ = [self.x0] + [self.hs[l] for l in range(nl - 1)]
+            c_ = [self.GW[l] for l in range(nl)]
+            i64, vp = C.c_int64 * nl, C.c_void_p * nl
+            self._gdw = (vp(*[t_.data_ptr() for t_ in a_]), i64(*[t_.stride(0) for t_ in a_]), vp(*[t_.data_ptr() for t_ in b_]),
+                         i64(*[t_.stride(0) for t_ in b_]), vp(*[t_.data_ptr() for t_ in c_]), i64(*[t_.stride(0) for t_ in c_]),
+                         i64(*[t_.shape[0] for t_ in c_]), i64(*[t_.shape[1] for t_ in c_]), i64(*([B] * nl)))
         # the head's weight-gradient role (not on the backward chain) rides with the first launch of the dz chain below the top
         self.dw_deferred = nl > 1
         groups64 = (B + 63) // 64                      # 64-row tiles of brl_mlp_gemm's column sums
@@ -711,6 +725,9 @@ class FusedMinibatch(FusedStep):
         nl = self.nl
         for l in range(nl - 1, 0, -1):
             self._dz(l)
+        if self.dw_x3:
+            self.capi.check(self.lib.brl_mlp_gemm_x3_group(self._di(), 2, nl, *self._gdw, torch.cuda.current_stream().cuda_stream))
+            return
         if nl > 1:
             torch.bmm(self.dzs[1:].transpose(1, 2), self.hs[:nl - 1], out=self.GW_hidden)
         torch.mm(self.dzs[0].t(), self.x0, out=self.GW[0])

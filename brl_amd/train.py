@@ -41,7 +41,7 @@ DEFAULTS = dict(  # ppo.py:122-180 (PPOConfig), same names and defaults
     actor_illegal_action_mask=True, actor_illegal_action_penalty=False, illegal_action_penalty=-1.0,
     illegal_action_l2norm_coef=0.0,
     # build-side knobs (not in the reference)
-    lut_len=100_000, synthetic_lut_files=3, inference_dtype=None, inference_gemm=None, graph_rollout=False, evaluate=True,
+    lut_len=100_000, synthetic_lut_files=3, inference_dtype=None, inference_gemm=None, dw_gemm=None, graph_rollout=False, evaluate=True,
     tunable_gemm=False,  # torch TunableOp: time every rocBLAS / hipBLASLt solution once per GEMM shape (update: -5 %)
     memoize_eval=True, memoize_eval_check_every=0,   # the per-iteration duplicate evaluations: play each distinct pair once (train())
     grad_allreduce="flat",      # the gradient step under a process group: "flat" | "sharded" (brl_amd/fused_update.py)

@@ -49,7 +49,8 @@ typedef struct brl_handle brl_handle;
 const char *brl_last_error(void);
 /* The version of the EXPORTED SET: the number of the build round in which a symbol was last added, removed or changed (6 now).
  * Under ONE version a symbol's signature and meaning never change.  Version 6 against version 5: added brl_mlp_gemm_x3 and
- * brl_mlp_gemm_x3_workspace (fp32 products on the bf16 matrix pipe at fp32-grade error: the large-batch forward layers); 51 symbols.
+ * brl_mlp_gemm_x3_workspace, brl_mlp_gemm_x3_group (fp32 products on the bf16 matrix pipe at fp32-grade error: the large-batch forward
+ * layers, the step's weight gradients as one launch); 52 symbols.
  * Version 5 against version 4 — the boundary is the path, the
  * experiment log (profiles/r04/r04_experiments.txt) keeps what was measured and dropped:
  *   removed (fusions of the PPO step that measured no faster): brl_mlp_gemm_bwd_pair, brl_mlp_gemm_fwd_heads,
@@ -587,6 +588,14 @@ int brl_mlp_gemm_x3_workspace(int64_t m, int64_t n, int64_t k, int64_t *bytes);
 int brl_mlp_gemm_x3(int device, int layout, int epilogue, const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
                     int64_t ldc, int64_t m, int64_t n, int64_t k, int act, const float *bias, const float *gate, int64_t ldg,
                     float *colsum, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* `count` <= 8 plain bf16x3 products of one layout as ONE launch, one K slice each (arguments as brl_mlp_gemm_group's; every pointer
+ * 16-byte aligned): the DeepMind MLP's weight gradients dW_l = dz_l^T h_{l-1} of one minibatch step (src/update.py:74-242) — three
+ * 1024 x 1024 outputs + one 1024 x 480 = 224 tiles, one per CU, instead of a batched library product + one more launch
+ * (config["dw_gemm"] = "bf16x3"). */
+int brl_mlp_gemm_x3_group(int device, int layout, int count, const float *const *a, const int64_t *lda, const float *const *b,
+                          const int64_t *ldb, float *const *c, const int64_t *ldc, const int64_t *m, const int64_t *n,
+                          const int64_t *k, void *stream);
 
 /* `count` <= 16 plain products of one layout as ONE launch (arguments as brl_mlp_gemm's, one array element per product): the FAIR
  * network's eleven weight gradients dW_l = dz_l^T x_l (BRL_GEMM_TN; src/models.py:34-69's 200-wide layers are 0.08-0.5 GFLOP

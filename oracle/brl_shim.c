@@ -359,6 +359,15 @@ int brl_mlp_gemm_x3(int device, int layout, int epilogue, const float *a, int64_
   }
   return brl_mlp_gemm(device, layout, epilogue, a, lda, b, ldb, c, ldc, m, n, k, act, bias, gate, ldg, colsum, NULL, s);
 }
+int brl_mlp_gemm_x3_group(int device, int layout, int count, const float *const *a, const int64_t *lda, const float *const *b,
+                          const int64_t *ldb, float *const *c, const int64_t *ldc, const int64_t *m, const int64_t *n,
+                          const int64_t *k, void *s) {   /* the plain definition, product by product */
+  if (count < 1 || count > 8) {
+    snprintf(g_err, sizeof(g_err), "bad argument: brl_mlp_gemm_x3_group: count (oracle shim)");
+    return BRL_E_ARG;
+  }
+  return brl_mlp_gemm_group(device, layout, count, a, lda, b, ldb, c, ldc, m, n, k, s);
+}
 /* the policy network's forward for selected rows, float64 accumulation (the checker of brl_mlp_forward_rows: src/models.py:23-33) */
 int brl_mlp_forward_rows(int device, const brl_mlp_ref *net, const uint8_t *obs, const int64_t *rows, int64_t m, float *scratch,
                          int64_t scratch_len, float *out, int64_t ldo, void *s) {

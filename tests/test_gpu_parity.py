@@ -2269,7 +2269,8 @@ def test_fused_fair_update_matches_eager(variant):
     assert bool(torch.isfinite(total).all()) and {int(st["step"]) for st in rs[1]["opt"].state.values()} == {8}
 
 
-@pytest.mark.parametrize("variant", ["DeepMind_6", "anneal_lr", "tanh", "reward_scaling", "illegal_coef", "library_gemms", "own_gemm_fwd"])
+@pytest.mark.parametrize("variant", ["DeepMind_6", "anneal_lr", "tanh", "reward_scaling", "illegal_coef", "library_gemms", "own_gemm_fwd", "dw_bf16x3",
+                                     "dw_bf16x3_6"])
 def test_fused_update_variants_match_eager(variant):
     """FusedMinibatch on the 6-layer MLP of wb5/models.py, under ppo.py:186-192's linear learning-rate schedule (the
     rate lives in device memory, so the captured Adam launch follows it), with the tanh activation (src/models.py:16) and
@@ -2277,8 +2278,10 @@ def test_fused_update_variants_match_eager(variant):
     from brl_amd.models import make_forward_pass
     from brl_amd.update import FusedMinibatch, make_optimizer, make_update_step
     from tests.test_update_cpu import CFG, fake_batch
-    fp = make_forward_pass("tanh" if variant == "tanh" else "relu", "DeepMind_6" if variant == "DeepMind_6" else "DeepMind")
+    fp = make_forward_pass("tanh" if variant == "tanh" else "relu", "DeepMind_6" if variant in ("DeepMind_6", "dw_bf16x3_6") else "DeepMind")
     cfg0 = dict(CFG, minibatch_size=256, update_epochs=1, num_minibatches=4, num_updates=4, anneal_lr=variant == "anneal_lr",
+                # the default: every weight gradient as ONE brl_mlp_gemm_x3_group launch; "library": torch.bmm + torch.mm
+                dw_gemm="library" if variant in ("library_gemms", "DeepMind_6", "tanh") else None,
                 reward_scaling=variant == "reward_scaling",
                 illegal_action_l2norm_coef=0.5 if variant == "illegal_coef" else 0.0,   # src/update.py:146-152
                 # the step's switches: every product with the library + brl_act_bwd_colsum[_heads_dw] / the forward layers on brl_mlp_gemm too
@@ -2293,6 +2296,7 @@ def test_fused_update_variants_match_eager(variant):
             rs, _ = make_update_step(cfg, fp)(rs, type(tb)(*[x.cuda() for x in tb]), adv.cuda(), tgt.cuda())
         if fused:
             assert isinstance(rs[1].get("graphed"), FusedMinibatch), rs[1].get("graph_error")
+            assert rs[1]["graphed"].dw_x3 == (variant not in ("library_gemms", "DeepMind_6", "tanh"))
         outs.append((torch.cat([p.detach().reshape(-1) for p in net.parameters()]), rs[1]["opt"].param_groups[0]["lr"]))
     assert abs(outs[0][1] - outs[1][1]) < 1e-12 and (variant != "anneal_lr" or abs(outs[0][1] - 0.5 * CFG["lr"]) < 1e-12)
     d = (outs[0][0] - outs[1][0]).abs()
@@ -2684,6 +2688,43 @@ def test_mlp_gemm_group_matches_float64(layout):
         assert float((Cg.double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max())) * (K / 1024 + 1) ** 0.5
     with pytest.raises(_capi.BrlError):
         _capi.check(L.brl_mlp_gemm_group(0, layout, 17, None, None, None, None, None, None, None, None, None, s))
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_mlp_gemm_x3_group_matches_its_single_launches(layout):
+    """brl_mlp_gemm_x3_group: up to 8 bf16x3 products in ONE launch (the DeepMind step's weight gradients, layout TN: three 1024 x 1024 +
+    one 1024 x 480 at K = 1024, here with an edge-tile shape and a K tail beside them): the SAME bits as brl_mlp_gemm_x3 without a
+    workspace product by product (the same tile code, one K slice), each within the exact kernel's bound of float64; 9 products, a
+    misaligned operand are refused."""
+    import ctypes as C
+    from brl_amd import _capi
+    L = _capi.lib()
+    g = torch.Generator(device="cuda").manual_seed(177 + layout)
+    r = lambda *sh: (torch.rand(sh, device="cuda", generator=g) * 2 - 1)  # noqa: E731
+    akc, bkc = layout != 2, layout == 0
+    shapes = [(1024, 1024, 1024)] * 3 + [(1024, 480, 1024), (200, 680, 1000), (64, 36, 52), (4, 4, 4)]
+    As = [r(M, K) if akc else r(K, M) for M, N, K in shapes]
+    Bs = [r(N, K) if bkc else r(K, N) for M, N, K in shapes]
+    Cs = [torch.full((M, N), float("nan"), device="cuda") for M, N, K in shapes]
+    n = len(shapes)
+    vp, i64 = C.c_void_p * n, C.c_int64 * n
+    s = torch.cuda.current_stream().cuda_stream
+    args = (vp(*[t.data_ptr() for t in As]), i64(*[t.stride(0) for t in As]), vp(*[t.data_ptr() for t in Bs]), i64(*[t.stride(0) for t in Bs]),
+            vp(*[t.data_ptr() for t in Cs]), i64(*[sh[1] for sh in shapes]), i64(*[sh[0] for sh in shapes]), i64(*[sh[1] for sh in shapes]),
+            i64(*[sh[2] for sh in shapes]))
+    _capi.check(L.brl_mlp_gemm_x3_group(0, layout, n, *args, s))
+    for A, Bm, Cg, (M, N, K) in zip(As, Bs, Cs, shapes):
+        ref = (A.double() if akc else A.double().t()) @ (Bm.double().t() if bkc else Bm.double())
+        assert float((Cg.double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max())) * (K / 1024 + 1) ** 0.5
+        one = torch.full((M, N), float("nan"), device="cuda")
+        _capi.check(L.brl_mlp_gemm_x3(0, layout, 0, A.data_ptr(), A.stride(0), Bm.data_ptr(), Bm.stride(0), one.data_ptr(), N, M, N, K, 0,
+                                      None, None, 0, None, None, 0, s))
+        assert torch.equal(one, Cg)
+    with pytest.raises(_capi.BrlError):
+        _capi.check(L.brl_mlp_gemm_x3_group(0, layout, 9, *args, s))
+    off = vp(*([As[0].data_ptr() + 4] + [t.data_ptr() for t in As[1:]]))
+    with pytest.raises(_capi.BrlError):
+        _capi.check(L.brl_mlp_gemm_x3_group(0, layout, n, off, *args[1:], s))
 
 
 def test_mlp_gemm_rejects_what_it_cannot_do():
