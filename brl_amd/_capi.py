@@ -147,6 +147,8 @@ def lib() -> C.CDLL:
         "brl_mlp_gemm": [i32, i32, i32, _vp, i64, _vp, i64, _vp, i64, i64, i64, i64, i32, _vp, _vp, i64, _vp, _vp, _vp],
         "brl_mlp_gemm_x3_workspace": [i64, i64, i64, _vp],
         "brl_mlp_gemm_x3_group": [i32, i32, i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+        "brl_split_planes": [i32, _vp, i64, _vp, i64, _vp],
+        "brl_linear_x3p": [i32, _vp, i32, i64, i64, _vp, i64, i64, _vp, i32, _vp, i64, _vp, i64, i64, i64, i64, i64, _vp],
         "brl_mlp_gemm_x3": [i32, i32, i32, _vp, i64, _vp, i64, _vp, i64, i64, i64, i64, i32, _vp, _vp, i64, _vp, _vp, i64, _vp],
         "brl_mlp_forward_rows": [i32, C.POINTER(MlpRef), _vp, _vp, i64, _vp, i64, _vp, i64, _vp],
         "brl_adam_shard_norm": [i32, _vp, C.POINTER(ShardGeom), i32, i32, f32, _vp, _vp, _vp, _vp],
@@ -169,7 +171,7 @@ EXPORTS = ["brl_last_error", "brl_version", "brl_create", "brl_set_lut", "brl_de
            "brl_eval_step", "brl_eval_reduce", "brl_ppo_loss", "brl_ppo_stats", "brl_policy_step_ex",
            "brl_eval_step_team", "brl_rollout_random_gae", "brl_ppo_heads_loss_split", "brl_adam_shard_norm", "brl_adam_shard_apply", "brl_ppo_heads_bwd", "brl_ppo_stats_gram",
            "brl_act_bwd_colsum", "brl_act_bwd_colsum_heads_dw", "brl_bias_finalize_ex", "brl_ppo_stats_rows", "brl_mb_gather_bind", "brl_mb_gather_dev", "brl_ppo_illegal_grad", "brl_adam_clip_fin_gather", "brl_mlp_gemm", "brl_mlp_gemm_dh_heads_dw", "brl_mlp_forward_rows",
-           "brl_bias_finalize_rows", "brl_fair_chain", "brl_mlp_gemm_group", "brl_fair_forward", "brl_mlp_gemm_x3", "brl_mlp_gemm_x3_workspace", "brl_mlp_gemm_x3_group"]
+           "brl_bias_finalize_rows", "brl_fair_chain", "brl_mlp_gemm_group", "brl_fair_forward", "brl_mlp_gemm_x3", "brl_mlp_gemm_x3_workspace", "brl_mlp_gemm_x3_group", "brl_split_planes", "brl_linear_x3p"]
 
 
 def check(rc: int) -> None:

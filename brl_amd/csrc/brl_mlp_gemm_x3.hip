@@ -1,10 +1,13 @@
 // brl_mlp_gemm_x3.hip — translation unit of libbrl_hip.so: fp32 products as six bf16 MFMA products of three-piece operands
-// (csrc/mlp_gemm_x3.hpp: 128 x 128 tiles, optional split K) behind brl_mlp_gemm_x3 (include/brl_hip.h).
+// (csrc/mlp_gemm_x3.hpp: 128 x 128 tiles, the split in registers, optional split K: brl_mlp_gemm_x3 / _group; csrc/mlp_linear_x3p.hpp: the
+// inference layer on operands already split into planes: brl_split_planes, brl_linear_x3p) — include/brl_hip.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "abi_common.hpp"
 #include "mlp_gemm_x3.hpp"
+#include "mlp_linear_x3p.hpp"
 
 static int64_t x3_tiles(int64_t m, int64_t n) { return ((m + 127) / 128) * ((n + 127) / 128); }
 
@@ -101,6 +104,41 @@ extern "C" int brl_mlp_gemm_x3_group(int device, int layout, int count, const fl
   if (layout == BRL_GEMM_NT) hipLaunchKernelGGL((mgs::k_gemm_x3s_group<true, true>), dim3(blocks), dim3(mgs::THREADS), 0, s, GA);
   else if (layout == BRL_GEMM_NN) hipLaunchKernelGGL((mgs::k_gemm_x3s_group<true, false>), dim3(blocks), dim3(mgs::THREADS), 0, s, GA);
   else hipLaunchKernelGGL((mgs::k_gemm_x3s_group<false, false>), dim3(blocks), dim3(mgs::THREADS), 0, s, GA);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_split_planes(int device, const float *x, int64_t n, uint16_t *planes, int64_t plane_stride, void *stream) {
+  NEED(x && planes && n > 0 && n % 4 == 0 && plane_stride >= n && plane_stride % 4 == 0, "x / planes / n (a multiple of 4) / plane_stride");
+  NEED((((uintptr_t)x) & 15) == 0 && (((uintptr_t)planes) & 7) == 0, "alignment (x 16 bytes, planes 8)");
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(lx3::k_split_planes, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, planes, plane_stride, n / 4);
+  HIP_TRY(hipGetLastError());
+  return BRL_OK;
+}
+
+extern "C" int brl_linear_x3p(int device, const uint16_t *x_planes, int npx, int64_t ldx, int64_t sx, const uint16_t *w_planes, int64_t ldw,
+                              int64_t sw, const float *bias, int relu, float *y, int64_t ldy, uint16_t *y_planes, int64_t ldyp, int64_t syp,
+                              int64_t m, int64_t n, int64_t k, void *stream) {
+  NEED(x_planes && w_planes && bias && (y || y_planes) && m > 0 && n > 0 && k > 0, "x_planes / w_planes / bias / an output / m / n / k");
+  NEED(npx == 1 || npx == 3, "npx (3 planes, or 1: x exact in bf16)");
+  NEED(n % 128 == 0 && k % 32 == 0, "n a multiple of 128, k a multiple of 32");
+  NEED(m < (1 << 24) && n < (1 << 24) && k < (1 << 24), "m / n / k below 2^24");
+  NEED(ldx >= k && ldx % 8 == 0 && ldw >= k && ldw % 8 == 0, "ldx / ldw (at least k, multiples of 8: 16-byte pieces)");
+  NEED(m * ldx < (1ll << 31) && n * ldw < (1ll << 31), "planes below 4 GB each");
+  NEED(!y || (ldy >= n && ldy % 4 == 0), "ldy");
+  NEED(!y_planes || (ldyp >= n && ldyp % 8 == 0 && syp % 8 == 0), "ldyp / syp (multiples of 8)");
+  NEED(sx % 8 == 0 && sw % 8 == 0, "plane strides multiples of 8");
+  NEED((((uintptr_t)x_planes | (uintptr_t)w_planes | (uintptr_t)bias | (uintptr_t)y | (uintptr_t)y_planes) & 15) == 0, "16-byte alignment");
+  HIP_TRY(hipSetDevice(device));
+  lx3::Args G{};
+  G.x = x_planes; G.ldx = ldx; G.sx = sx; G.w = w_planes; G.ldw = ldw; G.sw = sw; G.bias = bias;
+  G.y = y; G.ldy = ldy; G.yp = y_planes; G.ldyp = ldyp; G.syp = syp;
+  G.M = (int)m; G.N = (int)n; G.K = (int)k; G.relu = relu ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)(((m + 127) / 128) * (n / 128));
+  if (npx == 3) hipLaunchKernelGGL(lx3::k_linear_x3p<3>, dim3(blocks), dim3(lx3::THREADS), 0, s, G);
+  else hipLaunchKernelGGL(lx3::k_linear_x3p<1>, dim3(blocks), dim3(lx3::THREADS), 0, s, G);
   HIP_TRY(hipGetLastError());
   return BRL_OK;
 }

@@ -128,6 +128,10 @@ class _Forward:
 
     def __call__(self, obs_bool, obs_f32):
         if self.snap is not None:
+            # forwards of >= 4096 rows run on brl_linear_x3p (models.InferenceSnapshot.planes_for): it takes the 0/1 observation as bf16
+            # (one plane) — from the bool rows, or already gathered + cast by the caller
+            if obs_bool is not None and self.snap.planes_for(obs_bool.shape[0]):
+                return self.snap.heads(obs_bool)
             return self.snap.heads(obs_f32)
         logits, _ = self.fp.apply(self.params, obs_f32)
         return logits.contiguous()
@@ -293,7 +297,11 @@ class _ActiveRows:
         if getattr(fwd, "constant", False):   # (the same logits whatever the observation: nothing to compute)
             return fwd(obs, None)
         if self.idx is None or self.full is None:
-            self.full = fwd(obs, x if x is not None else obs.to(torch.float32))
+            snap = getattr(fwd, "snap", None)
+            if snap is not None and snap.planes_for(obs.shape[0]):      # (takes the bool rows themselves: _Forward.__call__)
+                self.full = fwd(obs, None)
+            else:
+                self.full = fwd(obs, x if x is not None else obs.to(torch.float32))
             if getattr(fwd, "ref", None) is not None and self.full.stride(0) <= NUM_ACTIONS:
                 # (the module's own [n, 38] logits: brl_mlp_forward_rows writes 38 + 1 numbers per row later on)
                 wide = torch.empty((self.full.shape[0], NUM_ACTIONS + 2), dtype=torch.float32, device=self.full.device)
@@ -305,8 +313,10 @@ class _ActiveRows:
             # back in one call (brl_mlp_forward_rows; rows of finished boards keep their last logits: never used)
             fwd.rows(obs, self.idx, self.m, self.full, env)
             return self.full
-        x = torch.empty((self.m, OBS_SIZE), dtype=torch.float32, device=obs.device)
-        check(_capi.lib().brl_obs_cast_rows(env._h, ptr(obs), ptr(self.idx), self.m, ptr(x), 0, _stream()))   # gather + astype
+        snap = getattr(fwd, "snap", None)
+        as_bf16 = snap is not None and snap.planes_for(self.m)      # (brl_linear_x3p: the observation as one bf16 plane)
+        x = torch.empty((self.m, OBS_SIZE), dtype=torch.bfloat16 if as_bf16 else torch.float32, device=obs.device)
+        check(_capi.lib().brl_obs_cast_rows(env._h, ptr(obs), ptr(self.idx), self.m, ptr(x), 1 if as_bf16 else 0, _stream()))   # gather + astype
         out = fwd(None, x)
         self.full[:, :out.shape[1]].index_copy_(0, self.idx, out)   # (rows of finished boards keep their last logits: never used)
         return self.full
@@ -365,9 +375,11 @@ def _eval_loop(env: BridgeBidding, state: State, fwd1: _Forward, fwd2: _Forward,
             rows[team].update(polled)
             lg = rows[team].forward(fwd2 if team else fwd1, obs, env, obs_f32)
             # the next iteration's forward still takes every board: this launch writes its float32 input as well
-            nxt = rows[team ^ 1]
+            nxt, nfwd = rows[team ^ 1], (fwd1 if team else fwd2)
+            nsnap = getattr(nfwd, "snap", None)
             obs_f32 = torch.empty((n, OBS_SIZE), dtype=torch.float32, device=dev) \
-                if (_STEP_CASTS and nxt.idx is None and not getattr(fwd1 if team else fwd2, "constant", False)) else None
+                if (_STEP_CASTS and nxt.idx is None and not getattr(nfwd, "constant", False)
+                    and not (nsnap is not None and nsnap.planes_for(n))) else None
             check(_capi.lib().brl_eval_step_team(
                 env._h, ptr(packed), ptr(packed), n, lg.data_ptr(), lg.stride(0), team,
                 C.byref(pa) if pa is not None else None, C.byref(pb) if pb is not None else None,

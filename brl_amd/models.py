@@ -149,9 +149,19 @@ class InferenceSnapshot:
         # nn.Linear's own [out, in] layout: the module's parameters themselves under `views`, else copies `refresh` re-reads (their
         # addresses are baked into captured graphs; the update re-points the module's parameters at its flat buffers)
         self.lin = None
+        self.wp = None
         if self.gemm_x3:
             self.lin = [(lin.weight.detach(), lin.bias.detach()) if views else (lin.weight.detach().clone(), lin.bias.detach().clone())
                         for lin in module.body]
+            # ... and, where the shapes allow (out % 128, in % 32), on brl_linear_x3p (csrc/mlp_linear_x3p.hpp): the SAME products on
+            # operands already split into bf16 planes — the weights here, once per refresh (they are constant over a rollout's 128
+            # forwards), an activation by the launch that produces it — so that the K loop has no vector work.
+            # BRL_INFERENCE_PLANES=0: brl_mlp_gemm_x3 (the split in registers) for every layer.
+            if os.environ.get("BRL_INFERENCE_PLANES", "1") != "0" and all(
+                    w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.shape[0] % 128 == 0 and w.shape[1] % 32 == 0
+                    and w.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 for w, b in self.lin):
+                self.wp = [torch.empty((3,) + tuple(w.shape), dtype=torch.bfloat16, device=w.device) for w, _ in self.lin]
+                self._split_weights()
         # views (fp32 only): the hidden layers multiply with the module's own weights through transposed VIEWS — nothing is
         # copied (an evaluator builds its snapshots per call: nine launches per network otherwise) and nothing needs a refresh
         self.views = bool(views) and dt == torch.float32 and all(lin.weight.dtype == torch.float32 for lin in module.body)
@@ -189,6 +199,8 @@ class InferenceSnapshot:
                 for (w, b), lin in zip(self.lin, module.body):
                     w.copy_(lin.weight.detach())
                     b.copy_(lin.bias.detach())
+            if self.wp is not None:
+                self._split_weights()
         if self.views:   # (the hidden layers alias the module's parameters: only the merged heads are copies)
             self.body = [(lin.weight.detach().t(), lin.bias.detach()) for lin in module.body]
         else:
@@ -203,6 +215,38 @@ class InferenceSnapshot:
         if not self.views:
             self.head_wt.copy_(self.head_w.t())
         self.head_bf.copy_(self.head_b)
+
+    def _split_weights(self):
+        """the hidden layers' weights -> their three bf16 planes (brl_split_planes: w == hi + mid + lo exactly)"""
+        from . import _capi
+        L = _capi.lib()
+        for (w, _), wp in zip(self.lin, self.wp):
+            di = w.device.index if w.device.index is not None else torch.cuda.current_device()
+            _capi.check(L.brl_split_planes(di, w.data_ptr(), w.numel(), wp.data_ptr(), w.numel(),
+                                           torch.cuda.current_stream(w.device).cuda_stream))
+
+    def planes_for(self, n):
+        """True where a forward of `n` rows runs on brl_linear_x3p: its input may then come as bf16 (the 0/1 observation is exact in it)"""
+        return self.wp is not None and n >= 4096
+
+    def _body_planes(self, x):
+        """the hidden layers on brl_linear_x3p: x bf16 [n, in] — the 0/1 observation, exact as given: ONE plane (an fp32 input stays on
+        brl_mlp_gemm_x3: splitting it first costs what the first layer then saves); every layer writes the planes of its output, the last
+        one fp32 (what the heads' product reads)"""
+        from . import _capi
+        L, st = _capi.lib(), torch.cuda.current_stream(x.device).cuda_stream
+        di = x.device.index if x.device.index is not None else torch.cuda.current_device()
+        n, k = x.shape
+        xp, npx, sx = x, 1, 0
+        y = None
+        for li, ((w, b), wp) in enumerate(zip(self.lin, self.wp)):
+            out, last = w.shape[0], li + 1 == len(self.lin)
+            y = torch.empty((n, out), dtype=torch.float32, device=x.device) if last else None
+            yp = None if last else torch.empty((3, n, out), dtype=torch.bfloat16, device=x.device)
+            _capi.check(L.brl_linear_x3p(di, xp.data_ptr(), npx, k, sx, wp.data_ptr(), k, out * k, b.data_ptr(), 1,
+                                         y.data_ptr() if last else None, out, None if last else yp.data_ptr(), out, n * out, n, out, k, st))
+            xp, npx, sx, k = yp, 3, n * out, out
+        return y
 
     def _refresh16(self, module):
         """`refresh` of the 16-bit layout: a handful of multi-tensor copies instead of ~30 cast launches per network and
@@ -229,8 +273,13 @@ class InferenceSnapshot:
         self._body_stale = True   # self.body's weights ([in, out]) no longer match: rebuilt on demand (_body)
 
     @staticmethod
+    def covers(module):
+        """the architectures a snapshot exists for ("DeepMind" bodies with ReLU)"""
+        return str(getattr(module, "model", "")).startswith("DeepMind") and getattr(module, "act", None) is torch.relu
+
+    @staticmethod
     def make(module, dtype=None, env=None, own_cast=True, views=False, gemm=None):
-        if not str(getattr(module, "model", "")).startswith("DeepMind") or module.act is not torch.relu:
+        if not InferenceSnapshot.covers(module):
             return None
         return InferenceSnapshot(module, dtype, env, own_cast, views, gemm)
 
@@ -241,10 +290,15 @@ class InferenceSnapshot:
                 and self.dtype in self._FMT:
             from . import _capi
             from .bridge_bidding import _stream
-            x = torch.empty(obs.shape, dtype=self.dtype, device=obs.device)
-            _capi.check(_capi.lib().brl_obs_cast(self.env._h, obs.data_ptr(), obs.numel() // 480, x.data_ptr(),
-                                                 self._FMT[self.dtype], _stream()))
+            dt = torch.bfloat16 if (self.dtype == torch.float32 and obs.dim() == 2 and self.planes_for(obs.shape[0])) else self.dtype
+            x = torch.empty(obs.shape, dtype=dt, device=obs.device)
+            _capi.check(_capi.lib().brl_obs_cast(self.env._h, obs.data_ptr(), obs.numel() // 480, x.data_ptr(), self._FMT[dt], _stream()))
             return x
+        if self.dtype == torch.float32 and obs.dim() == 2 and self.planes_for(obs.shape[0]):
+            if obs.dtype in (torch.bool, torch.uint8):
+                return obs.to(torch.bfloat16)      # 0 / 1: exact — one plane for brl_linear_x3p
+            if obs.dtype == torch.bfloat16:
+                return obs                         # (already cast by the caller: brl_obs_cast_rows with format 1)
         return obs.to(self.dtype)
 
     def _body(self, x):
@@ -259,6 +313,12 @@ class InferenceSnapshot:
                                            y.data_ptr(), y.stride(0), x.shape[0], w.shape[0], w.shape[1], 1, fmt, st))
                 x = y
             return x
+        if x.dim() == 2 and self.planes_for(x.shape[0]) and x.is_cuda and x.is_contiguous() and x.data_ptr() % 16 == 0 \
+                and x.dtype == torch.bfloat16 and self.dtype == torch.float32:
+            return self._body_planes(x)
+        if x.dtype != self.dtype:
+            raise RuntimeError(f"InferenceSnapshot: input in {x.dtype} where the layers run in {self.dtype} (bf16 input is taken by the "
+                               "planes path only: >= 4096 contiguous rows)")
         if self.gemm_x3 and x.is_cuda and x.dim() == 2 and x.shape[0] >= 4096 and x.is_contiguous() and x.data_ptr() % 16 == 0:
             from . import _capi
             L, st = _capi.lib(), torch.cuda.current_stream(x.device).cuda_stream

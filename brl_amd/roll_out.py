@@ -176,6 +176,16 @@ class _PolicyRollout:
             self.snap_opp = self.snap_actor if opp_params is params \
                 else InferenceSnapshot.make(opp_params, self.infer_dtype, self.env, own_cast=False, gemm=self.gemm)
         self.params, self.opp_params = params, opp_params
+        # fp32 inference whose every forward runs on brl_linear_x3p (models.InferenceSnapshot.planes_for): the step kernels write each new
+        # observation as bf16 instead of fp32 (0 / 1: exact) — the first layer then reads ONE plane and multiplies three products
+        consumers = [self.snap_actor] + ([self.snap_opp] if self.game_mode == "competitive" else [])
+        want = self.infer_dtype or torch.float32
+        if self.infer_dtype is None and all(sn is not None and sn.planes_for(self.n) for sn in consumers):
+            want = torch.bfloat16
+        if getattr(self, "xin", None) is not None and self.xin.dtype != want:
+            if self.graphs is not None:
+                raise RuntimeError("the captured rollout holds the observation buffer in " + str(self.xin.dtype))
+            self.xin = torch.empty((self.n, OBS_SIZE), dtype=want, device=self.env.device)
 
     _FMT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
@@ -364,8 +374,7 @@ def make_roll_out(config, env: BridgeBidding, actor_forward_pass, opp_forward_pa
         params, env_state = runner_state[0], runner_state[2]
         n = env_state.num_envs
         static = bool(config.get("graph_rollout")) and mode == "competitive" \
-            and InferenceSnapshot.make(params, infer_dtype) is not None \
-            and InferenceSnapshot.make(opp_params, infer_dtype) is not None
+            and InferenceSnapshot.covers(params) and InferenceSnapshot.covers(opp_params)
         eng = engines.get((n, static))
         if eng is None:
             eng = engines[(n, static)] = _PolicyRollout(env, n, T, reward_scale, mode, masked, infer_dtype,
@@ -374,6 +383,7 @@ def make_roll_out(config, env: BridgeBidding, actor_forward_pass, opp_forward_pa
                                                         graph_steps=config.get("rollout_graph_steps", 4))
         out = eng.run(runner_state, opp_params)
         roll_out.sub_actions = eng.sub_actions
+        roll_out.engine = eng
         return out
 
     roll_out.sub_actions = None

@@ -50,7 +50,8 @@ const char *brl_last_error(void);
 /* The version of the EXPORTED SET: the number of the build round in which a symbol was last added, removed or changed (6 now).
  * Under ONE version a symbol's signature and meaning never change.  Version 6 against version 5: added brl_mlp_gemm_x3 and
  * brl_mlp_gemm_x3_workspace, brl_mlp_gemm_x3_group (fp32 products on the bf16 matrix pipe at fp32-grade error: the large-batch forward
- * layers, the step's weight gradients as one launch); 52 symbols.
+ * layers, the step's weight gradients as one launch), brl_split_planes, brl_linear_x3p (the large-batch inference layer on pre-split
+ * operands); 54 symbols.
  * Version 5 against version 4 — the boundary is the path, the
  * experiment log (profiles/r04/r04_experiments.txt) keeps what was measured and dropped:
  *   removed (fusions of the PPO step that measured no faster): brl_mlp_gemm_bwd_pair, brl_mlp_gemm_fwd_heads,
@@ -596,6 +597,21 @@ int brl_mlp_gemm_x3(int device, int layout, int epilogue, const float *a, int64_
 int brl_mlp_gemm_x3_group(int device, int layout, int count, const float *const *a, const int64_t *lda, const float *const *b,
                           const int64_t *ldb, float *const *c, const int64_t *ldc, const int64_t *m, const int64_t *n,
                           const int64_t *k, void *stream);
+
+/* The inference layer of LARGE batches on operands ALREADY split into bf16 planes (csrc/mlp_linear_x3p.hpp): in a rollout the weights
+ * are constant over 128 forwards and an activation is split once by the launch that produces it, so the product itself is DMA -> LDS ->
+ * MFMA with no vector work (brl_mlp_gemm_x3 splits every operand element once per tile that reads it).
+ * brl_split_planes: x[n] (fp32, n a multiple of 4) -> planes[3][..]: plane p (0 hi, 1 mid, 2 lo; x == hi + mid + lo exactly) at
+ * planes + p * plane_stride (uint16 elements). */
+int brl_split_planes(int device, const float *x, int64_t n, uint16_t *planes, int64_t plane_stride, void *stream);
+/* y[m, n] = (relu ? max(., 0) : .)(x[m, k] w[n, k]^T + bias[n]) — one `hk.Linear` (+ `jax.nn.relu`) of `forward_fn` (src/models.py:23-33) in
+ * fp32-grade arithmetic: x as npx planes [npx][m][ldx] (plane stride sx; npx = 3, or 1 where x is exact in bf16: the 0/1 observation as the
+ * step kernel writes it, brl_macro_ext.obs_cast with obs_fmt 1), w as three planes [3][n][ldw] (nn.Linear's layout; stride sw); outputs:
+ * y fp32 [m][ldy] and / or y_planes [3][m][ldyp] (stride syp) — either may be NULL, not both.  n % 128 == 0, k % 32 == 0, leading
+ * dimensions and strides of planes multiples of 8, every pointer 16-byte aligned. */
+int brl_linear_x3p(int device, const uint16_t *x_planes, int npx, int64_t ldx, int64_t sx, const uint16_t *w_planes, int64_t ldw, int64_t sw,
+                   const float *bias, int relu, float *y, int64_t ldy, uint16_t *y_planes, int64_t ldyp, int64_t syp, int64_t m, int64_t n,
+                   int64_t k, void *stream);
 
 /* `count` <= 16 plain products of one layout as ONE launch (arguments as brl_mlp_gemm's, one array element per product): the FAIR
  * network's eleven weight gradients dW_l = dz_l^T x_l (BRL_GEMM_TN; src/models.py:34-69's 200-wide layers are 0.08-0.5 GFLOP

@@ -359,6 +359,57 @@ int brl_mlp_gemm_x3(int device, int layout, int epilogue, const float *a, int64_
   }
   return brl_mlp_gemm(device, layout, epilogue, a, lda, b, ldb, c, ldc, m, n, k, act, bias, gate, ldg, colsum, NULL, s);
 }
+/* the plane split and the layer on planes, restated plainly: hi / mid / lo by truncation; the product from the planes' SUMS in float64 */
+static float shim_bf(uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; }
+static void shim_split1(float x, uint16_t out[3]) {
+  uint32_t u; memcpy(&u, &x, 4);
+  uint32_t uh = u & 0xffff0000u; float h; memcpy(&h, &uh, 4);
+  float r = x - h; uint32_t ur; memcpy(&ur, &r, 4);
+  uint32_t um = ur & 0xffff0000u; float md; memcpy(&md, &um, 4);
+  float l = r - md; uint32_t ul; memcpy(&ul, &l, 4);
+  out[0] = (uint16_t)(u >> 16); out[1] = (uint16_t)(ur >> 16); out[2] = (uint16_t)(ul >> 16);
+}
+int brl_split_planes(int device, const float *x, int64_t n, uint16_t *planes, int64_t plane_stride, void *s) {
+  (void)device; (void)s;
+  if (!x || !planes || n <= 0 || n % 4 || plane_stride < n) {
+    snprintf(g_err, sizeof(g_err), "bad argument: brl_split_planes (oracle shim)");
+    return BRL_E_ARG;
+  }
+  for (int64_t i = 0; i < n; i++) {
+    uint16_t pl[3];
+    shim_split1(x[i], pl);
+    planes[i] = pl[0]; planes[plane_stride + i] = pl[1]; planes[2 * plane_stride + i] = pl[2];
+  }
+  return BRL_OK;
+}
+int brl_linear_x3p(int device, const uint16_t *xp, int npx, int64_t ldx, int64_t sx, const uint16_t *wp, int64_t ldw, int64_t sw,
+                   const float *bias, int relu, float *y, int64_t ldy, uint16_t *yp, int64_t ldyp, int64_t syp, int64_t m, int64_t n,
+                   int64_t k, void *s) {
+  (void)device; (void)s;
+  if (!xp || !wp || !bias || (!y && !yp) || (npx != 1 && npx != 3) || n % 128 || k % 32) {
+    snprintf(g_err, sizeof(g_err), "bad argument: brl_linear_x3p (oracle shim)");
+    return BRL_E_ARG;
+  }
+  for (int64_t i = 0; i < m; i++)
+    for (int64_t j = 0; j < n; j++) {
+      double acc = 0.0;
+      for (int64_t q = 0; q < k; q++) {
+        double xv = 0.0, wv = 0.0;
+        for (int p = 0; p < npx; p++) xv += (double)shim_bf(xp[p * sx + i * ldx + q]);
+        for (int p = 0; p < 3; p++) wv += (double)shim_bf(wp[p * sw + j * ldw + q]);
+        acc += xv * wv;
+      }
+      float o = (float)(acc + (double)bias[j]);
+      if (relu && o < 0.0f) o = 0.0f;
+      if (y) y[i * ldy + j] = o;
+      if (yp) {
+        uint16_t pl[3];
+        shim_split1(o, pl);
+        for (int p = 0; p < 3; p++) yp[p * syp + i * ldyp + j] = pl[p];
+      }
+    }
+  return BRL_OK;
+}
 int brl_mlp_gemm_x3_group(int device, int layout, int count, const float *const *a, const int64_t *lda, const float *const *b,
                           const int64_t *ldb, float *const *c, const int64_t *ldc, const int64_t *m, const int64_t *n,
                           const int64_t *k, void *s) {   /* the plain definition, product by product */

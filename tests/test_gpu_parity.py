@@ -418,17 +418,22 @@ POLICY_CFG = {"reward_scale": 7600, "game_mode": "competitive", "actor_illegal_a
 @pytest.mark.parametrize("n,T,graph,dt,calls", [(2048, 32, False, None, 2), (2048, 32, True, None, 2),
                                                 (8192, 32, True, None, 1),     # configs[3]'s rollout at the reference's fp32
                                                 (8192, 32, True, "x3", 2),     # ... its hidden layers on brl_mlp_gemm_x3 (inference_gemm = "bf16x3")
-                                                (8192, 8, False, "x3", 1),
+                                                (8192, 8, False, "x3", 1),     # (both: brl_linear_x3p — operands pre-split into planes, bf16 observations)
+                                                (8192, 8, True, "x3s", 1),     # BRL_INFERENCE_PLANES=0: brl_mlp_gemm_x3, the split in registers
                                                 (8192, 32, True, "bf16", 1), (1000, 9, False, "bf16", 2),
                                                 (1000, 9, True, "fp16", 2)])
-def test_policy_rollout_replays_through_oracle(env, oracle, n, T, graph, dt, calls):
+def test_policy_rollout_replays_through_oracle(env, oracle, n, T, graph, dt, calls, monkeypatch):
     """A7 with MLPs in the loop (BASELINE configs[2]/[3] rollout): every integer / byte column of the Transition and the
     final packed state bit-exact vs the oracle replay of the recorded actions; reward exact (integer scores / 7600 in
     fp32); value / log_prob vs an fp32 torch recomputation on the stored obs (tolerances stated below)."""
     import brl_amd
     from brl_amd.models import make_forward_pass
-    gemm = "bf16x3" if dt == "x3" else None
-    dt = None if dt == "x3" else dt
+    gemm = "bf16x3" if dt in ("x3", "x3s") else None
+    no_planes = dt == "x3s"
+    if no_planes:
+        monkeypatch.setenv("BRL_INFERENCE_PLANES", "0")
+    planes = dt == "x3" or (dt is None and n >= 4096)      # (the default for fp32 forwards of >= 4096 rows)
+    dt = None if dt in ("x3", "x3s") else dt
     cfg = dict(POLICY_CFG, num_steps=T, graph_rollout=graph, inference_dtype=dt, inference_gemm=gemm)
     fp = make_forward_pass("relu", "DeepMind")
     actor, opp = fp.init(0, device="cuda"), fp.init(1, device="cuda")
@@ -451,6 +456,8 @@ def test_policy_rollout_replays_through_oracle(env, oracle, n, T, graph, dt, cal
         assert np.array_equal(to_np(rs[3]), ref["observation"])
         total += want["terminated_count"]
         assert int(rs[4].item()) == total and rs[5] == 4 * T * (call + 1)
+        if dt is None:      # which layer kernel ran: the planes path takes its observations as bf16
+            assert (roll.engine.xin.dtype == torch.bfloat16) == planes and (roll.engine.snap_actor.wp is not None) == (not no_planes)
         with torch.no_grad():
             logits, value = actor(traj.obs.reshape(T * n, 480).float())
         lsm = _masked_log_softmax(to_np(logits), mask.reshape(T * n, 38))
@@ -2688,6 +2695,69 @@ def test_mlp_gemm_group_matches_float64(layout):
         assert float((Cg.double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max())) * (K / 1024 + 1) ** 0.5
     with pytest.raises(_capi.BrlError):
         _capi.check(L.brl_mlp_gemm_group(0, layout, 17, None, None, None, None, None, None, None, None, None, s))
+
+
+@pytest.mark.parametrize("M,N,K,npx", [(8192, 1024, 1024, 3), (8192, 1024, 480, 1), (5000, 256, 480, 1), (4097, 128, 32, 3), (300, 384, 96, 3)])
+def test_linear_x3p_matches_float64_and_beats_the_exact_kernel(M, N, K, npx):
+    """brl_split_planes + brl_linear_x3p (csrc/mlp_linear_x3p.hpp: the large-batch inference layer on operands pre-split into bf16 planes;
+    npx = 1: a 0/1 input as ONE bf16 plane, the observation): the planes reproduce their fp32 source exactly (hi + mid + lo == x); the
+    layer's fp32 output against float64 within the exact kernel's bound AND no worse than brl_mlp_gemm (exact fp32 MFMA chain) on the same
+    operands; the output planes == the fp32 output, bit for bit; edge row tiles; the same bits twice; the oracle shim's restatement
+    on a few rows; refusals."""
+    import ctypes as C
+    from brl_amd import _capi
+    from oracle.binding import shim_path
+    import oracle
+    L = _capi.lib()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    s = torch.cuda.current_stream().cuda_stream
+    x = (torch.rand((M, K), device="cuda", generator=g) < 0.1).float() if npx == 1 else torch.rand((M, K), device="cuda", generator=g) * 2 - 1
+    w = (torch.rand((N, K), device="cuda", generator=g) * 2 - 1) * 0.05
+    b = torch.rand(N, device="cuda", generator=g) - 0.5
+    wp = torch.empty((3, N, K), dtype=torch.bfloat16, device="cuda")
+    _capi.check(L.brl_split_planes(0, w.data_ptr(), N * K, wp.data_ptr(), N * K, s))
+    assert torch.equal((wp[0].float() + wp[1].float()) + wp[2].float(), w)
+    if npx == 3:
+        xp = torch.empty((3, M, K), dtype=torch.bfloat16, device="cuda")
+        _capi.check(L.brl_split_planes(0, x.data_ptr(), M * K, xp.data_ptr(), M * K, s))
+        assert torch.equal((xp[0].float() + xp[1].float()) + xp[2].float(), x)
+    else:
+        xp = x.to(torch.bfloat16)
+
+    def run(with_y, with_planes):
+        y = torch.full((M, N), float("nan"), device="cuda") if with_y else None
+        yp = torch.zeros((3, M, N), dtype=torch.bfloat16, device="cuda") if with_planes else None
+        _capi.check(L.brl_linear_x3p(0, xp.data_ptr(), npx, K, M * K if npx == 3 else 0, wp.data_ptr(), K, N * K, b.data_ptr(), 1,
+                                     y.data_ptr() if with_y else None, N, yp.data_ptr() if with_planes else None, N, M * N, M, N, K, s))
+        torch.cuda.synchronize()
+        return y, yp
+    y, yp = run(True, True)
+    ref = (x.double() @ w.double().t() + b.double()).clamp_min(0)
+    e3 = float((y.double() - ref).abs().max())
+    y1 = torch.empty((M, N), device="cuda")
+    _capi.check(L.brl_mlp_gemm(0, 0, 1, x.data_ptr(), K, w.data_ptr(), K, y1.data_ptr(), N, M, N, K, 0, b.data_ptr(), None, 0, None, None, s))
+    e1 = float((y1.double() - ref).abs().max())
+    scale = max(1.0, float(ref.abs().max()))
+    assert e3 < 2e-4 * scale * (K / 1024 + 1) ** 0.5 and e3 <= e1 + 2.0 ** -22 * scale, (e3, e1)
+    assert torch.equal((yp[0].float() + yp[1].float()) + yp[2].float(), y)
+    y_only, _ = run(True, False)
+    _, p_only = run(False, True)
+    assert torch.equal(y_only, y) and torch.equal(p_only, yp)
+    # the oracle shim's restatement (float64 over the planes' sums) on the first rows
+    oracle.build()
+    shim = C.CDLL(shim_path())
+    m = 3
+    xs, ws, bs = xp.cpu().contiguous().view(torch.int16).numpy(), wp.cpu().contiguous().view(torch.int16).numpy(), b.cpu().numpy()
+    ys = np.zeros((m, N), np.float32)
+    shim.brl_linear_x3p.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
+    assert shim.brl_linear_x3p(0, xs.ctypes.data, npx, K, M * K if npx == 3 else 0, ws.ctypes.data, K, N * K, bs.ctypes.data, 1, ys.ctypes.data, N,
+                               None, 0, 0, m, N, K, None) == 0
+    assert np.abs(ys - y[:m].cpu().numpy()).max() < 2e-4 * scale
+    # refusals: n not a multiple of 128, k not of 32, no output at all
+    for bad in ((M, N - 64, K), (M, N, K - 8)):
+        assert L.brl_linear_x3p(0, xp.data_ptr(), npx, K, M * K, wp.data_ptr(), K, N * K, b.data_ptr(), 1, y.data_ptr(), N, None, 0, 0, *bad, s) == -1
+    assert L.brl_linear_x3p(0, xp.data_ptr(), npx, K, M * K, wp.data_ptr(), K, N * K, b.data_ptr(), 1, None, 0, None, 0, 0, M, N, K, s) == -1
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
