@@ -707,14 +707,20 @@ def bench_secondary(torch, dev, budget_s: float = 60.0):
         flop = 4 * rows * fwd_flop
         x3 = gemm == "bf16x3"
         peak = 157.3 if (dt is None and not x3) else 2500.0
-        flop_exec = 6 * flop if x3 else flop     # (bf16x3: six bf16 products per fp32 product: what the matrix pipe executes, against the bf16 peak)
+        # (bf16x3: six bf16 products per fp32 product — three in the first layer, whose 0/1 input is one plane: what the matrix pipe
+        #  executes, against the bf16 peak)
+        l0 = 2 * 480 * 1024 / fwd_flop
+        flop_exec = (6 * (1 - l0) + 3 * l0) * flop if x3 else flop
         phases["rollout_" + label] = {
             "ms": t_roll * 1e3, "macro_steps_per_s": rows / t_roll, "raw_env_steps_per_s": 4 * rows / t_roll,
             "gemm_tflops": flop / t_roll / 1e12, "mfma_peak_tflops": peak,
             "mfma_frac": flop_exec / t_roll / 1e12 / peak,
             "dtype": ("fp32 inference (the reference's precision), every layer on the library's exact-fp32 GEMM (inference_gemm = 'library')" if not x3 else
-                      "fp32 inference, hidden layers on brl_mlp_gemm_x3 (fp32 operands as three exact bf16 pieces, six bf16 MFMA products, "
-                      "fp32 accumulation: 0.07-0.44 x the exact kernel's error vs float64; inference_gemm = 'bf16x3', brl_amd's default)") if dt is None else
+                      "fp32 inference, hidden layers as bf16x3 products (fp32 operands as three exact bf16 pieces, six bf16 MFMA products, "
+                      "fp32 accumulation: 0.07-0.44 x the exact kernel's error vs float64) on brl_linear_x3p — operands pre-split into "
+                      "planes: the weights once per parameter version, an activation by the layer that produces it, the 0/1 "
+                      "observation as one bf16 plane (BRL_INFERENCE_PLANES=0: brl_mlp_gemm_x3, the split in registers); "
+                      "inference_gemm = 'bf16x3', brl_amd's default") if dt is None else
                      "bf16 inference: NARROWER than the reference's fp32 — opt-in (inference_dtype), never the default",
             "how": "hipGraph-replayed macro-steps: 4 forwards + 4 brl_policy_step_ex launches each (competitive mode)"
                    + ("" if dt is None else "; hidden layers on the library's own bf16 kernel (brl_linear_act), the heads' share inside "
