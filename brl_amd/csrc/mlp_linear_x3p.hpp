@@ -55,6 +55,9 @@ struct Args {
 template <bool V>
 struct BoolTag { static constexpr bool value = V; };
 
+#ifndef LX3_STORE
+#define LX3_STORE 0   // the planes' stores: 0 plain, 1 non-temporal, 2 write-through (sc0 sc1)
+#endif
 #ifndef LX3_EXP
 #define LX3_EXP 0   // timing experiments (wrong results; scripts/micro/lx3_exp.hip): 1 = no DMA in the loop, 2 = no MFMA, 4 = no fragment reads in the loop, 8 = no barrier
 #endif
@@ -276,7 +279,16 @@ __global__ __launch_bounds__(THREADS) void k_linear_x3p(Args G) {
     for (int it = 0; it < (3 * 128 * 16) / THREADS; it++) {
       const int idx = it * THREADS + tid, pl = idx >> 11, row = (idx >> 4) & 127, ch = idx & 15;
       const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + (pl * 128 + row) * C_ROW_BYTES + ch * 16);
-      if (m0 + row < G.M) *reinterpret_cast<u32x4 *>(G.yp + (int64_t)pl * G.syp + (int64_t)(m0 + row) * G.ldyp + n0 + ch * 8) = v;
+      if (m0 + row < G.M) {
+        u32x4 *dst = reinterpret_cast<u32x4 *>(G.yp + (int64_t)pl * G.syp + (int64_t)(m0 + row) * G.ldyp + n0 + ch * 8);
+#if LX3_STORE == 1
+        __builtin_nontemporal_store(v, dst);
+#elif LX3_STORE == 2
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+#else
+        *dst = v;
+#endif
+      }
     }
   }
 }
