@@ -2754,6 +2754,20 @@ def test_linear_x3p_matches_float64_and_beats_the_exact_kernel(M, N, K, npx):
     assert shim.brl_linear_x3p(0, xs.ctypes.data, npx, K, M * K if npx == 3 else 0, ws.ctypes.data, K, N * K, bs.ctypes.data, 1, ys.ctypes.data, N,
                                None, 0, 0, m, N, K, None) == 0
     assert np.abs(ys - y[:m].cpu().numpy()).max() < 2e-4 * scale
+    # strided operands and outputs: rows of x / W / y inside wider arrays, planes further apart than they are long
+    if M <= 5000:
+        ldx, ldw, ldy = K + 8, K + 16, N + 4
+        xs2 = torch.zeros((npx, M, ldx), dtype=torch.bfloat16, device="cuda")
+        xs2[:, :, :K] = xp if npx == 3 else xp[None]
+        ws2 = torch.zeros((3, N + 5, ldw), dtype=torch.bfloat16, device="cuda")
+        ws2[:, :N, :K] = wp
+        y2 = torch.full((M, ldy), 7.0, device="cuda")
+        yp2 = torch.zeros((3, M + 1, N + 8), dtype=torch.bfloat16, device="cuda")
+        _capi.check(L.brl_linear_x3p(0, xs2.data_ptr(), npx, ldx, M * ldx, ws2.data_ptr(), ldw, (N + 5) * ldw, b.data_ptr(), 1, y2.data_ptr(), ldy,
+                                     yp2.data_ptr(), N + 8, (M + 1) * (N + 8), M, N, K, s))
+        torch.cuda.synchronize()
+        assert torch.equal(y2[:, :N], y) and bool((y2[:, N:] == 7.0).all()) and torch.equal(yp2[:, :M, :N], yp)
+        assert not bool(yp2[:, M:].any()) and not bool(yp2[:, :, N:].any())
     # refusals: n not a multiple of 128, k not of 32, no output at all
     for bad in ((M, N - 64, K), (M, N, K - 8)):
         assert L.brl_linear_x3p(0, xp.data_ptr(), npx, K, M * K, wp.data_ptr(), K, N * K, b.data_ptr(), 1, y.data_ptr(), N, None, 0, 0, *bad, s) == -1
