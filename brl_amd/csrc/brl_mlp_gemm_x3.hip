@@ -3,7 +3,6 @@
 // inference layer on operands already split into planes: brl_split_planes, brl_linear_x3p) — include/brl_hip.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "abi_common.hpp"
 #include "mlp_gemm_x3.hpp"
