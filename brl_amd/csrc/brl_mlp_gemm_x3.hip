@@ -31,7 +31,7 @@ extern "C" int brl_mlp_gemm_x3(int device, int layout, int epilogue, const float
   NEED(m < (1 << 24) && n < (1 << 24) && k < (1 << 24), "m / n / k below 2^24");
   NEED(n % 4 == 0 && ldc % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc >= n, "n and the leading dimensions multiples of 4 (16-byte pieces)");
   const bool akc = layout != BRL_GEMM_TN, bkc = layout == BRL_GEMM_NT;
-  NEED(!akc || k % 4 == 0, "k a multiple of 4 where it is the contiguous index of an operand");
+  NEED(k % 32 == 0, "k a multiple of 32 (whole 32-deep chunks; other k: brl_mlp_gemm)");
   NEED(akc ? lda >= k : lda >= ((m + 3) & ~(int64_t)3), "lda (where m is contiguous in a: at least m rounded up to 4 — whole 16-byte pieces are read)");
   NEED(bkc ? ldb >= k : ldb >= n, "ldb");
   NEED((akc ? m * lda : k * lda) < (1ll << 29) && (bkc ? n * ldb : k * ldb) < (1ll << 29), "operands below 2 GB");
@@ -85,7 +85,7 @@ extern "C" int brl_mlp_gemm_x3_group(int device, int layout, int count, const fl
     NEED(a[i] && b[i] && c[i] && m[i] > 0 && n[i] > 0 && k[i] > 0, "a / b / c / m / n / k");
     NEED(m[i] < (1 << 24) && n[i] < (1 << 24) && k[i] < (1 << 24), "m / n / k below 2^24");
     NEED(n[i] % 4 == 0 && ldc[i] % 4 == 0 && lda[i] % 4 == 0 && ldb[i] % 4 == 0 && ldc[i] >= n[i], "n and the leading dimensions multiples of 4");
-    NEED(!akc || k[i] % 4 == 0, "k a multiple of 4 where it is the contiguous index of an operand");
+    NEED(k[i] % 32 == 0, "k a multiple of 32 (whole 32-deep chunks; other k: brl_mlp_gemm_group)");
     NEED(akc ? lda[i] >= k[i] : lda[i] >= ((m[i] + 3) & ~(int64_t)3), "lda (where m is contiguous in a: at least m rounded up to 4)");
     NEED(bkc ? ldb[i] >= k[i] : ldb[i] >= n[i], "ldb");
     NEED((akc ? m[i] * lda[i] : k[i] * lda[i]) < (1ll << 29) && (bkc ? n[i] * ldb[i] : k[i] * ldb[i]) < (1ll << 29), "operands below 2 GB");

@@ -77,34 +77,23 @@ __device__ __forceinline__ void gemm_tile(const Args &X, unsigned char *lds, int
     tn = tile - tm * tiles_n;
   }
   const int m0 = tm * 128, n0 = tn * 128;
-  const int nchunks = (G.K + BK - 1) / BK, kfull = G.K / BK;
+  const int nchunks = G.K / BK;                                 // (K % 32 == 0: the host checks)
   const int cps = (nchunks + SK - 1) / SK;                      // chunks per slice
   const int c0 = ks * cps, c1 = (c0 + cps < nchunks) ? c0 + cps : nchunks;
   const int ni = c1 > c0 ? c1 - c0 : 0;                         // this workgroup's chunks: c0 + i
 
   // ---- staging.  KC operand, 128 rows x 32 k = 1024 loads of 4 k: item q = tid + 512 jj -> row = q >> 3, P = (q >> 1) & 3,
   //   half = q & 1: k = 16 half + 4 P.   MC operand, 32 k rows x 128 columns: item q -> k row q >> 5, columns 4 (q & 31) ..
-  // (kk / gs — the piece's k index inside a chunk and the part of its offset that selects k — are needed by a partial last chunk
-  //  only: recomputed there, not held in registers across the loop)
   uint32_t go[NP];
   int lw[NP];
-  auto kk_of = [&](int j) __attribute__((always_inline)) -> int {
-    const int q = tid + 512 * (j & 1);
-    return ((j >= 2) ? B_KC : A_KC) ? 16 * (q & 1) + 4 * ((q >> 1) & 3) : (q >> 5);
-  };
-  auto gs_of = [&](int j) __attribute__((always_inline)) -> uint32_t {
-    const bool isB = j >= 2;
-    return (isB ? B_KC : A_KC) ? (uint32_t)(kk_of(j) * 4) : (uint32_t)(((int64_t)kk_of(j) * (isB ? G.ldb : G.lda)) * 4);
-  };
 #pragma unroll
   for (int j = 0; j < NP; j++) {
     const bool isB = j >= 2;
     const int q = tid + 512 * (j & 1);
-    const bool kc = isB ? B_KC : A_KC;
     const int x0 = isB ? n0 : m0, Xn = isB ? G.N : G.M;
     const int64_t ld = isB ? G.ldb : G.lda;
     const int base = isB ? OFF_B : 0;
-    if (kc) {
+    if (isB ? B_KC : A_KC) {
       const int row = q >> 3, P = (q >> 1) & 3, half = q & 1;
       const int x = (x0 + row < Xn) ? x0 + row : Xn - 1;
       go[j] = (uint32_t)(((int64_t)x * ld + 16 * half + 4 * P) * 4);
@@ -124,28 +113,26 @@ __device__ __forceinline__ void gemm_tile(const Args &X, unsigned char *lds, int
   asm volatile("s_mov_b32 %0, 0xffff0000" : "=s"(msk));
   f32x4 rg[1][NP];      // ONE chunk in flight: a phase is ~1600 cycles, a request made in phase i lands before phase i + 1 splits it
                         // (a second register set — two phases of slack — costs 16 registers the 256-register budget does not have)
-  auto gload = [&](auto set_tag, int j, int c) __attribute__((always_inline)) {
-    constexpr int S = decltype(set_tag)::value;
-    const bool isB = j >= 2;
-    const uint32_t off = go[j] - ((c < kfull || kk_of(j) < G.K - c * BK) ? 0u : gs_of(j));
-    rg[S][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(isB ? srdb : srda, (int)off, (int)(isB ? sob : soa), 0));
-  };
-  auto gload_full = [&](auto set_tag, int j) __attribute__((always_inline)) {
+  // Every phase is branch-free: the requests of the chunks BEHIND the slice's last one (two per slice) read that last chunk again — the
+  // scalar offset stops advancing —, are split and stored like any other and never multiplied.
+  int nreq = 0;         // chunks requested so far
+  auto gload = [&](auto set_tag, int j) __attribute__((always_inline)) {
     constexpr int S = decltype(set_tag)::value;
     const bool isB = j >= 2;
     rg[S][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(isB ? srdb : srda, (int)go[j], (int)(isB ? sob : soa), 0));
   };
-  auto gadvance = [&]() __attribute__((always_inline)) { soa += stepa; sob += stepb; };
+  auto gadvance = [&]() __attribute__((always_inline)) {
+    nreq++;
+    if (nreq < ni) { soa += stepa; sob += stepb; }
+  };
   // the split of one half piece in three parts, so that no MFMA gap carries more than ~5 vector instructions:
   //   part 0: hi pair, r = x - hi        part 1: mid pair, l = r - mid        part 2: lo pair; behind the second half the plane stores
   unsigned sh[3][2];   // [plane][half]
   float sr0, sr1;      // the residuals between the parts
-  auto stage_part = [&](auto set_tag, auto full_tag, int j, int half, int part, int c, unsigned char *st) __attribute__((always_inline)) {
+  auto stage_part = [&](auto set_tag, int j, int half, int part, unsigned char *st) __attribute__((always_inline)) {
     constexpr int S = decltype(set_tag)::value;
-    constexpr bool FULL = decltype(full_tag)::value;
     if (part == 0) {
-      f32x4 v = rg[S][j];
-      if (!FULL && c >= kfull && kk_of(j) >= G.K - c * BK) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      const f32x4 v = rg[S][j];
       const float x0 = half ? v.z : v.x, x1 = half ? v.w : v.y;
       const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
       sh[0][half] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
@@ -213,18 +200,16 @@ __device__ __forceinline__ void gemm_tile(const Args &X, unsigned char *lds, int
   // ---- prologue: chunk 0 -> stage 0, chunk 1 in flight
   if (ni > 0) {
 #pragma unroll
-    for (int j = 0; j < NP; j++) gload(IntTag<0>{}, j, c0);
+    for (int j = 0; j < NP; j++) gload(IntTag<0>{}, j);
     gadvance();
 #pragma unroll
     for (int j = 0; j < NP; j++)
 #pragma unroll
       for (int h = 0; h < 2; h++)
 #pragma unroll
-        for (int part = 0; part < 3; part++) stage_part(IntTag<0>{}, BoolTag<false>{}, j, h, part, c0, lds);
-  }
-  if (ni > 1) {
+        for (int part = 0; part < 3; part++) stage_part(IntTag<0>{}, j, h, part, lds);
 #pragma unroll
-    for (int j = 0; j < NP; j++) gload(IntTag<0>{}, j, c0 + 1);
+    for (int j = 0; j < NP; j++) gload(IntTag<0>{}, j);
     gadvance();
   }
   __syncthreads();
@@ -242,12 +227,10 @@ __device__ __forceinline__ void gemm_tile(const Args &X, unsigned char *lds, int
   //   slot 20           every LDS operation of the wave done, barrier
   //   slots 21 .. 23    the step-0 fragments of chunk i + 1 (three reads each: B, A block 0, A block 1)
   // (tried: THREE stages, the barrier at slot 0 waiting for stores a phase old — 98.7 us against 88.4 for 8192 x 1024 x 1024, dropped)
-  auto phase = [&](auto full_tag, auto par_tag, int i) __attribute__((always_inline)) {
-    constexpr bool FULL = decltype(full_tag)::value;
+  auto phase = [&](auto par_tag) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_tag)::value, NS = PAR ^ 1;
     unsigned char *st = lds + PAR * STAGE, *sn = lds + NS * STAGE;
-    const bool real = FULL || i < ni, nxt = FULL || i + 1 < ni, nxt2 = FULL || i + 2 < ni;
-    const int cn = c0 + i + 1, c3 = c0 + i + 2;
+    constexpr bool real = true, nxt = true, nxt2 = true;
     // staging schedule: half piece h (0..7) starts at slot HB(h) = floor(h (BAR - 2) / 8) and takes three slots; BAR = the barrier's slot
     constexpr int BAR = MGS_BAR;
     auto slot = [&](int s) __attribute__((always_inline)) {
@@ -262,13 +245,13 @@ __device__ __forceinline__ void gemm_tile(const Args &X, unsigned char *lds, int
           const int b = (h * (BAR - 2)) / 8;
 #pragma unroll
           for (int part = 0; part < 3; part++)
-            if (s == b + part) stage_part(IntTag<0>{}, full_tag, h >> 1, h & 1, part, cn, sn);
+            if (s == b + part) stage_part(IntTag<0>{}, h >> 1, h & 1, part, sn);
         }
       }
 #pragma unroll
       for (int j = 0; j < NP; j++) {
         if (s == ((2 * j + 1) * (BAR - 2)) / 8 + 2 && nxt2) {      // behind the last part that reads piece j's registers
-          if (FULL) gload_full(IntTag<0>{}, j); else gload(IntTag<0>{}, j, c3);
+          gload(IntTag<0>{}, j);
           if (j == NP - 1) gadvance();
         }
       }
@@ -299,14 +282,11 @@ __device__ __forceinline__ void gemm_tile(const Args &X, unsigned char *lds, int
   };
   {
     int i = 0;
-    for (; i + 3 < ni && c0 + i + 3 < kfull; i += 2) {     // both phases FULL: chunks i + 1 .. i + 3 exist and are whole
-      phase(BoolTag<true>{}, IntTag<0>{}, i);
-      phase(BoolTag<true>{}, IntTag<1>{}, i + 1);
+    for (; i + 1 < ni; i += 2) {
+      phase(IntTag<0>{});
+      phase(IntTag<1>{});
     }
-    for (; i < ni; i++) {
-      if (i & 1) phase(BoolTag<false>{}, IntTag<1>{}, i);
-      else phase(BoolTag<false>{}, IntTag<0>{}, i);
-    }
+    if (i < ni) phase(IntTag<0>{});
   }
   MG_STAMP(2);
 
@@ -432,7 +412,7 @@ __global__ __launch_bounds__(THREADS) void k_gemm_x3s_group(GroupArgs GA) {
 static inline int pick_splitk(int64_t m, int64_t n, int64_t k) {
   const int64_t tiles = ((m + 127) / 128) * ((n + 127) / 128);
   int sk = 1;
-  while (sk < 8 && tiles * sk < 256 && (k + 31) / 32 / (2 * sk) >= 2) sk *= 2;
+  while (sk < 8 && tiles * sk < 256 && k / 32 / (2 * sk) >= 2) sk *= 2;
   return sk;
 }
 

@@ -549,7 +549,7 @@ class FusedMinibatch(FusedStep):
         # shape: one per CU) instead of the library's batched product + a launch for layer 0: 41 us instead of 47 + 11
         # (profiles/r06/r06aa_step_ab.txt: the step 0.229 -> 0.211 ms); the products carry the bf16x3 error (below the exact fp32
         # kernel's rounding: tests/test_gpu_parity.py::test_mlp_gemm_x3_beats_the_exact_kernels_error)
-        self.dw_x3 = (config.get("dw_gemm") or "bf16x3") == "bf16x3" and B % 4 == 0 and H % 4 == 0 and self.x0.shape[1] % 4 == 0 and nl <= 8
+        self.dw_x3 = (config.get("dw_gemm") or "bf16x3") == "bf16x3" and B % 32 == 0 and H % 4 == 0 and self.x0.shape[1] % 4 == 0 and nl <= 8
         if self.dw_x3:
             a_ = [self.dzs[l] for l in range(nl)]
             b_ = [self.x0] + [self.hs[l] for l in range(nl - 1)]

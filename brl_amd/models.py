@@ -145,7 +145,8 @@ class InferenceSnapshot:
         # by magnitude class: 0.07-0.44 x the exact fp32 kernel's error against float64 and 1.4 x its rate on such batches
         # (csrc/mlp_gemm_x3.hpp) — on nn.Linear's own [out, in] weights; "library" = torch's fp32 GEMM for every batch.
         # Either way an fp32 forward (src/models.py:23-33); the two are not bit-identical to each other.
-        self.gemm_x3 = (gemm or os.environ.get("BRL_INFERENCE_GEMM", "") or "bf16x3") == "bf16x3" and dt == torch.float32
+        self.gemm_x3 = (gemm or os.environ.get("BRL_INFERENCE_GEMM", "") or "bf16x3") == "bf16x3" and dt == torch.float32 \
+            and all(lin.weight.shape[1] % 32 == 0 and lin.weight.shape[0] % 4 == 0 for lin in module.body)   # (whole 32-deep K chunks)
         # nn.Linear's own [out, in] layout: the module's parameters themselves under `views`, else copies `refresh` re-reads (their
         # addresses are baked into captured graphs; the update re-points the module's parameters at its flat buffers)
         self.lin = None

@@ -581,7 +581,8 @@ int brl_mlp_gemm(int device, int layout, int epilogue, const float *a, int64_t l
  * pieces, six bf16 MFMA products per K step, fp32 accumulators by magnitude class — max |err| against float64 0.07-0.44 x
  * brl_mlp_gemm's on the same inputs, and NOT bit-identical to it; 128 x 128 tiles: for outputs of >= 256 of them (the policy
  * rollout's and the evaluators' forward layers, src/roll_out.py:49-108, src/models.py:23-33) 1.4 x brl_mlp_gemm's rate.  Arguments as
- * brl_mlp_gemm's; epilogues NONE, BIAS_ACT (NT), GATE_COLSUM (NN); every pointer 16-byte aligned.  Outputs of fewer tiles may
+ * brl_mlp_gemm's; epilogues NONE, BIAS_ACT (NT), GATE_COLSUM (NN); k a multiple of 32 (whole chunks: every phase of the K loop is
+ * branch-free; other k: brl_mlp_gemm); every pointer 16-byte aligned.  Outputs of fewer tiles may
  * divide K among several workgroups per tile: `workspace` (may be NULL: then never) = *bytes of brl_mlp_gemm_x3_workspace (0: none) of
  * device memory, 256-byte aligned, ZERO before the first call and owned by one stream at a time (partial tiles + a ticket per tile;
  * the last workgroup of a tile adds the partial tiles in K order: deterministic). */
@@ -591,7 +592,7 @@ int brl_mlp_gemm_x3(int device, int layout, int epilogue, const float *a, int64_
                     float *colsum, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* `count` <= 8 plain bf16x3 products of one layout as ONE launch, one K slice each (arguments as brl_mlp_gemm_group's; every pointer
- * 16-byte aligned): the DeepMind MLP's weight gradients dW_l = dz_l^T h_{l-1} of one minibatch step (src/update.py:74-242) — three
+ * 16-byte aligned, every k a multiple of 32): the DeepMind MLP's weight gradients dW_l = dz_l^T h_{l-1} of one minibatch step (src/update.py:74-242) — three
  * 1024 x 1024 outputs + one 1024 x 480 = 224 tiles, one per CU, instead of a batched library product + one more launch
  * (config["dw_gemm"] = "bf16x3"). */
 int brl_mlp_gemm_x3_group(int device, int layout, int count, const float *const *a, const int64_t *lda, const float *const *b,

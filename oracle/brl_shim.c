@@ -353,8 +353,8 @@ int brl_mlp_gemm_x3(int device, int layout, int epilogue, const float *a, int64_
                     int64_t ldc, int64_t m, int64_t n, int64_t k, int act, const float *bias, const float *gate, int64_t ldg,
                     float *colsum, void *workspace, int64_t workspace_bytes, void *s) {
   (void)workspace; (void)workspace_bytes;
-  if (epilogue == BRL_GEMM_EPI_SQSUM) {
-    snprintf(g_err, sizeof(g_err), "bad argument: brl_mlp_gemm_x3: epilogue (oracle shim)");
+  if (epilogue == BRL_GEMM_EPI_SQSUM || k % 32) {
+    snprintf(g_err, sizeof(g_err), "bad argument: brl_mlp_gemm_x3: epilogue / k a multiple of 32 (oracle shim)");
     return BRL_E_ARG;
   }
   return brl_mlp_gemm(device, layout, epilogue, a, lda, b, ldb, c, ldc, m, n, k, act, bias, gate, ldg, colsum, NULL, s);
@@ -417,6 +417,11 @@ int brl_mlp_gemm_x3_group(int device, int layout, int count, const float *const 
     snprintf(g_err, sizeof(g_err), "bad argument: brl_mlp_gemm_x3_group: count (oracle shim)");
     return BRL_E_ARG;
   }
+  for (int i = 0; i < count; i++)
+    if (!k || k[i] % 32) {
+      snprintf(g_err, sizeof(g_err), "bad argument: brl_mlp_gemm_x3_group: k a multiple of 32 (oracle shim)");
+      return BRL_E_ARG;
+    }
   return brl_mlp_gemm_group(device, layout, count, a, lda, b, ldb, c, ldc, m, n, k, s);
 }
 /* the policy network's forward for selected rows, float64 accumulation (the checker of brl_mlp_forward_rows: src/models.py:23-33) */

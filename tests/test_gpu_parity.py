@@ -2601,13 +2601,14 @@ def test_mlp_gemm_matches_float64(layout, epi, M, N, K, act):
 
 @pytest.mark.parametrize("layout,epi,M,N,K,act,ws", [
     (0, 1, 8192, 1024, 1024, 0, False), (0, 1, 4096, 1024, 480, 0, False), (0, 1, 1024, 1024, 1024, 0, True), (0, 1, 1024, 1024, 1024, 0, False),
-    (0, 1, 200, 72, 64, 1, True), (0, 0, 48, 256, 1000, 0, True), (0, 0, 64, 64, 36, 0, False),
-    (1, 2, 1024, 1024, 1024, 0, True), (1, 2, 100, 36, 96, 1, True), (1, 2, 1000, 256, 252, 0, False),
-    (2, 0, 1024, 1024, 1024, 0, True), (2, 0, 68, 132, 1000, 0, True), (2, 0, 1024, 480, 1024, 0, False)])
+    (0, 1, 200, 72, 64, 1, True), (0, 0, 48, 256, 992, 0, True), (0, 0, 64, 64, 32, 0, False),
+    (1, 2, 1024, 1024, 1024, 0, True), (1, 2, 100, 36, 96, 1, True), (1, 2, 1000, 256, 256, 0, False),
+    (2, 0, 1024, 1024, 1024, 0, True), (2, 0, 68, 132, 992, 0, True), (2, 0, 1024, 480, 1024, 0, False)])
 def test_mlp_gemm_x3_beats_the_exact_kernels_error(layout, epi, M, N, K, act, ws):
     """brl_mlp_gemm_x3 (csrc/mlp_gemm_x3.hpp: the fp32 product as six bf16 MFMA products of three exact bf16 pieces per operand,
     128 x 128 tiles, optionally K divided among workgroups) on the SAME operands as brl_mlp_gemm, both against a float64 product: every
-    layout and epilogue it offers, the rollout's and the step's shapes, edge tiles, K tails, with and without the split-K workspace.
+    layout and epilogue it offers, the rollout's and the step's shapes, edge tiles, one chunk and odd chunk counts (k is a multiple of 32:
+    other k are refused — brl_mlp_gemm takes them), with and without the split-K workspace.
     The bound is the exact kernel's own (2e-4 * max|ref| at K = 1024) AND its error on these very inputs: max |err| of bf16x3 <= the exact
     kernel's (measured 0.07 - 0.64 x: scripts/micro/gemm_x3_test.hip) + one ulp of slack for the tiny shapes.  Deterministic: the same bits twice."""
     import ctypes as C
@@ -2659,7 +2660,9 @@ def test_mlp_gemm_x3_beats_the_exact_kernels_error(layout, epi, M, N, K, act, ws
     if ws:   # every ticket is back at zero: the workspace is ready for the next product
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
         assert int(work[:tiles].abs().sum()) == 0
-    # refusals: an epilogue it does not offer, a misaligned operand
+    # refusals: k not a multiple of 32, an epilogue it does not offer
+    assert L.brl_mlp_gemm_x3(0, layout, 0, A.data_ptr(), A.stride(0), Bm.data_ptr(), Bm.stride(0), C3.data_ptr(), N, M, N, K - 4, act, None, None, 0,
+                             None, None, 0, s) == -1
     assert L.brl_mlp_gemm_x3(0, 2, 3, A.data_ptr(), A.stride(0), Bm.data_ptr(), Bm.stride(0), C3.data_ptr(), N, M, N, K, act, None, None, 0,
                              None, None, 0, s) == _capi.BRL_E_ARG if hasattr(_capi, "BRL_E_ARG") else True
 
@@ -2777,7 +2780,7 @@ def test_linear_x3p_matches_float64_and_beats_the_exact_kernel(M, N, K, npx):
 @pytest.mark.parametrize("layout", [0, 1, 2])
 def test_mlp_gemm_x3_group_matches_its_single_launches(layout):
     """brl_mlp_gemm_x3_group: up to 8 bf16x3 products in ONE launch (the DeepMind step's weight gradients, layout TN: three 1024 x 1024 +
-    one 1024 x 480 at K = 1024, here with an edge-tile shape and a K tail beside them): the SAME bits as brl_mlp_gemm_x3 without a
+    one 1024 x 480 at K = 1024, here with edge-tile shapes and other chunk counts beside them): the SAME bits as brl_mlp_gemm_x3 without a
     workspace product by product (the same tile code, one K slice), each within the exact kernel's bound of float64; 9 products, a
     misaligned operand are refused."""
     import ctypes as C
@@ -2786,7 +2789,7 @@ def test_mlp_gemm_x3_group_matches_its_single_launches(layout):
     g = torch.Generator(device="cuda").manual_seed(177 + layout)
     r = lambda *sh: (torch.rand(sh, device="cuda", generator=g) * 2 - 1)  # noqa: E731
     akc, bkc = layout != 2, layout == 0
-    shapes = [(1024, 1024, 1024)] * 3 + [(1024, 480, 1024), (200, 680, 1000), (64, 36, 52), (4, 4, 4)]
+    shapes = [(1024, 1024, 1024)] * 3 + [(1024, 480, 1024), (200, 680, 992), (64, 36, 64), (4, 4, 32)]
     As = [r(M, K) if akc else r(K, M) for M, N, K in shapes]
     Bs = [r(N, K) if bkc else r(K, N) for M, N, K in shapes]
     Cs = [torch.full((M, N), float("nan"), device="cuda") for M, N, K in shapes]
