@@ -111,9 +111,11 @@ __device__ __forceinline__ void gemm_tile(const Args &X, unsigned char *lds, int
   uint32_t soa = (uint32_t)c0 * stepa, sob = (uint32_t)c0 * stepb;
   unsigned msk;
   asm volatile("s_mov_b32 %0, 0xffff0000" : "=s"(msk));
-  f32x4 rg[1][NP];      // ONE chunk in flight: a phase is ~1600 cycles, a request made in phase i lands before phase i + 1 splits it
-                        // (a second register set — two phases of slack — costs 16 registers the 256-register budget does not have)
-  // Every phase is branch-free: the requests of the chunks BEHIND the slice's last one (two per slice) read that last chunk again — the
+#ifndef MGS_SETS
+#define MGS_SETS 1     // register sets of the operand stream: 1 = one chunk in flight (a request made in phase i lands before phase i + 1 splits
+#endif                 // it), 2 = two (chunk c lives in set c & 1: requested two phases before it is split) — measured equal (r06ap_sets.txt)
+  f32x4 rg[MGS_SETS][NP];
+  // Every phase is branch-free: the requests of the chunks BEHIND the slice's last one (two or three per slice) read that last chunk again — the
   // scalar offset stops advancing —, are split and stored like any other and never multiplied.
   int nreq = 0;         // chunks requested so far
   auto gload = [&](auto set_tag, int j) __attribute__((always_inline)) {
@@ -209,8 +211,13 @@ __device__ __forceinline__ void gemm_tile(const Args &X, unsigned char *lds, int
 #pragma unroll
         for (int part = 0; part < 3; part++) stage_part(IntTag<0>{}, j, h, part, lds);
 #pragma unroll
-    for (int j = 0; j < NP; j++) gload(IntTag<0>{}, j);
+    for (int j = 0; j < NP; j++) gload(IntTag<(MGS_SETS == 2 ? 1 : 0)>{}, j);      // chunk 1
     gadvance();
+    if (MGS_SETS == 2) {
+#pragma unroll
+      for (int j = 0; j < NP; j++) gload(IntTag<0>{}, j);                          // chunk 2
+      gadvance();
+    }
   }
   __syncthreads();
   bf16x8 f0[9], f1[9];
@@ -245,13 +252,13 @@ __device__ __forceinline__ void gemm_tile(const Args &X, unsigned char *lds, int
           const int b = (h * (BAR - 2)) / 8;
 #pragma unroll
           for (int part = 0; part < 3; part++)
-            if (s == b + part) stage_part(IntTag<0>{}, h >> 1, h & 1, part, sn);
+            if (s == b + part) stage_part(IntTag<(MGS_SETS == 2 ? NS : 0)>{}, h >> 1, h & 1, part, sn);
         }
       }
 #pragma unroll
       for (int j = 0; j < NP; j++) {
         if (s == ((2 * j + 1) * (BAR - 2)) / 8 + 2 && nxt2) {      // behind the last part that reads piece j's registers
-          gload(IntTag<0>{}, j);
+          gload(IntTag<(MGS_SETS == 2 ? NS : 0)>{}, j);
           if (j == NP - 1) gadvance();
         }
       }

@@ -83,12 +83,12 @@ int main(int argc, char **argv) {
       {"NT 1024x1024x480 uniform +bias relu", true, true, 1024, 1024, 480, mg::EPI_BIAS_ACT, 0, 0},
       {"NT 8192x1024x1024 relu(N) +bias relu", true, true, 8192, 1024, 1024, mg::EPI_BIAS_ACT, 0, 1},
       {"NT 200x72x64 uniform +bias tanh (edges)", true, true, 200, 72, 64, mg::EPI_BIAS_ACT, 1, 0},
-      {"NT 48x256x1000 uniform (K tail)", true, true, 48, 256, 1000, mg::EPI_NONE, 0, 0},
+      {"NT 48x256x992 uniform (31 chunks)", true, true, 48, 256, 992, mg::EPI_NONE, 0, 0},
       {"NN 100x36x96 uniform gate tanh colsum", true, false, 100, 36, 96, mg::EPI_GATE_COLSUM, 1, 0},
-      {"NN 1000x256x250.. K=252 gate colsum", true, false, 1000, 256, 252, mg::EPI_GATE_COLSUM, 0, 0},
-      {"TN 68x132x1000 uniform K tail sqsum", false, false, 68, 132, 1000, mg::EPI_SQSUM, 0, 0},
+      {"NN 1000x256x256 gate colsum", true, false, 1000, 256, 256, mg::EPI_GATE_COLSUM, 0, 0},
+      {"TN 68x132x992 uniform sqsum", false, false, 68, 132, 992, mg::EPI_SQSUM, 0, 0},
       {"TN 64x64x32 uniform one chunk", false, false, 64, 64, 32, mg::EPI_NONE, 0, 0},
-      {"NT 64x64x33.. K=36 two chunks", true, true, 64, 64, 36, mg::EPI_NONE, 0, 0},
+      {"NT 64x64x64 two chunks", true, true, 64, 64, 64, mg::EPI_NONE, 0, 0},
   };
   hipStream_t s;
   CK(hipStreamCreate(&s));
