@@ -2777,6 +2777,48 @@ def test_linear_x3p_matches_float64_and_beats_the_exact_kernel(M, N, K, npx):
     assert L.brl_linear_x3p(0, xp.data_ptr(), npx, K, M * K, wp.data_ptr(), K, N * K, b.data_ptr(), 1, None, 0, None, 0, 0, M, N, K, s) == -1
 
 
+@pytest.mark.parametrize("model", ["DeepMind", "DeepMind_6"])
+def test_inference_snapshot_large_batch_paths_against_float64(model, monkeypatch):
+    """The three ways an fp32 forward of 8192 observations runs its hidden layers — brl_linear_x3p (the default: bf16x3 products on operands
+    pre-split into planes, the 0/1 observation as one bf16 plane), brl_mlp_gemm_x3 (BRL_INFERENCE_PLANES=0: the split in registers) and the
+    library's exact fp32 GEMM (inference_gemm = "library") — through the WHOLE network (src/models.py:23-33) against the module in float64:
+    the two bf16x3 paths are no further from float64 than the library path (fp32-grade end to end), and follow refreshed weights."""
+    from brl_amd.models import InferenceSnapshot, make_forward_pass
+    fp = make_forward_pass("relu", model)
+    net = fp.init(11, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    obs = torch.rand((8192, 480), device="cuda", generator=g) < 0.12
+    with torch.no_grad():
+        ref = fp.init(11, device="cpu").double()
+        ref.load_state_dict({k: t.double().cpu() for k, t in net.state_dict().items()})
+        lg64, v64 = ref(obs.double().cpu())
+    want = torch.cat([lg64, v64[:, None]], 1)
+
+    def run(gemm, planes):
+        monkeypatch.setenv("BRL_INFERENCE_PLANES", "1" if planes else "0")
+        snap = InferenceSnapshot.make(net, gemm=gemm)
+        assert (snap.wp is not None) == (planes and gemm != "library")
+        with torch.no_grad():
+            out = snap.heads(obs)
+        return snap, float((out.double().cpu() - want).abs().max())
+    snap_p, e_planes = run("bf16x3", True)
+    _, e_x3 = run("bf16x3", False)
+    _, e_lib = run("library", False)
+    scale = max(1.0, float(want.abs().max()))
+    assert e_lib < 2e-4 * scale and e_planes <= e_lib * 1.05 + 1e-7 * scale and e_x3 <= e_lib * 1.05 + 1e-7 * scale, (e_planes, e_x3, e_lib)
+    # new weights: refresh re-splits the planes INTO the same tensors (their addresses sit in captured graphs)
+    ptrs = [w.data_ptr() for w in snap_p.wp]
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.mul_(1.01)
+        snap_p.refresh(net)
+        ref.load_state_dict({k: t.double().cpu() for k, t in net.state_dict().items()})
+        lg64, v64 = ref(obs.double().cpu())
+        out = snap_p.heads(obs)
+    assert [w.data_ptr() for w in snap_p.wp] == ptrs
+    assert float((out.double().cpu() - torch.cat([lg64, v64[:, None]], 1)).abs().max()) < 2e-4 * scale
+
+
 @pytest.mark.parametrize("layout", [0, 1, 2])
 def test_mlp_gemm_x3_group_matches_its_single_launches(layout):
     """brl_mlp_gemm_x3_group: up to 8 bf16x3 products in ONE launch (the DeepMind step's weight gradients, layout TN: three 1024 x 1024 +
