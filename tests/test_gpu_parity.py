@@ -2242,6 +2242,29 @@ def test_graphed_rollout_follows_the_parameters_after_updates(model, activation,
     assert abs(seen[0][1] - seen[-1][1]) > 1e-4      # (the parameters did move)
 
 
+def test_graphed_rollout_on_planes_follows_the_parameters_after_updates(tmp_path):
+    """The DeepMind / ReLU policy at 4096 tables: the captured rollout's forwards run on brl_linear_x3p with the weights' bf16 planes held by
+    the inference snapshot; every iteration's `refresh` re-splits the UPDATED weights into the same plane tensors (their addresses sit in
+    the graphs).  Scan step 0's values recomputed eagerly from traj.obs[0] with the loop's current parameters, three iterations, lr large
+    enough that stale planes would show."""
+    from brl_amd.train import train
+    cfg = dict(num_envs=4096, num_steps=4, minibatch_size=1024, update_epochs=2, total_timesteps=4096 * 4 * 3, graph_rollout=True,
+               evaluate=False, save_model=False, log_path=str(tmp_path), exp_name="planes", actor_model_type="DeepMind",
+               actor_activation="relu", lr=1e-2)
+    seen = []
+
+    def on_rollout(i, rs, traj, roll_out):
+        eng = roll_out.engine
+        assert eng.xin.dtype == torch.bfloat16 and eng.snap_actor.wp is not None
+        with torch.no_grad():
+            _, v = rs[0](traj.obs[0].float())
+        seen.append((float((v - traj.value[0]).abs().max()), float(v.abs().max())))
+
+    train(cfg, log=lambda s: None, on_rollout=on_rollout)
+    assert len(seen) == 3 and all(d <= 2e-4 * max(1.0, m) for d, m in seen), seen
+    assert abs(seen[0][1] - seen[-1][1]) > 1e-4      # (the parameters did move)
+
+
 @pytest.mark.parametrize("variant", ["relu", "tanh", "reward_scaling", "unmasked", "launches", "library_gemms", "illegal_coef"])
 def test_fused_fair_update_matches_eager(variant):
     """FusedFair vs the eager autograd path from the same start: ONE update of one epoch x 4 minibatches (the single step is checked
