@@ -50,7 +50,16 @@ struct Args {
   int64_t ldyp, syp;
   int M, N, K;
   int relu;
+#ifdef LX3_TIMING
+  unsigned long long *dbg;   // [workgroups][4]: s_memtime (shader clock) and s_memrealtime (100 MHz) at the start and the end of the K loop
+#endif
 };
+#ifdef LX3_TIMING
+#define LX3_STAMP(k) do { if (threadIdx.x == 0 && G.dbg) { G.dbg[(size_t)blockIdx.x * 4 + 2 * (k)] = __builtin_amdgcn_s_memtime(); \
+                                                          G.dbg[(size_t)blockIdx.x * 4 + 2 * (k) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define LX3_STAMP(k) do { } while (0)
+#endif
 
 template <bool V>
 struct BoolTag { static constexpr bool value = V; };
@@ -184,6 +193,7 @@ __global__ __launch_bounds__(THREADS) void k_linear_x3p(Args G) {
     for (int j = 0; j < NI; j++) stage_one(lds + 2 * STAGE_BYTES, j);
     kc++;
   }
+  LX3_STAMP(0);
   bf16x8 f0[2][NFR], f1[2][NFR];
 #pragma unroll
   for (int q = 0; q < 2 * NFR; q++) {
@@ -247,6 +257,7 @@ __global__ __launch_bounds__(THREADS) void k_linear_x3p(Args G) {
     if (c < nchunks) phase(F{}, f0, f1, c, stage);
   }
 
+  LX3_STAMP(1);
   // ---- epilogue: lane holds, per block b, row m0 + 64 wm + 32 b + r32, columns n0 + 32 wn + 8 g + 4 hh + (0..3)
   __syncthreads();      // every wave is done with the stages (its last fragments are in registers; no DMA is in flight)
   const float floor_v = G.relu ? 0.0f : -__builtin_inff();
